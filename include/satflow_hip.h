@@ -1,0 +1,142 @@
+/*
+ * satflow_hip.h -- C ABI of libsatflow_hip.so (gfx950 / MI355X).
+ *
+ * Drop-in boundary for the spatiotemporal hot path of openclimatefix/satflow
+ * (SURVEY.md section 8).  The reference has no FFI: its boundary is a Python
+ * nn.Module surface, every "kernel" being a chain of ATen ops.  Each entry
+ * point below names the reference code (file:line under /root/reference) whose
+ * arithmetic it replaces; the Python host in satflow_amd/ mirrors the module
+ * surface and calls these through ctypes.
+ *
+ * Conventions
+ *  - Plain C symbols, no global state except a thread-local error string.
+ *  - Every call takes a hipStream_t (as void*) and only enqueues work on it;
+ *    no allocation, no synchronisation, safe under hipGraph capture.
+ *  - All pointers are DEVICE pointers owned by the caller.
+ *  - Activations are NHWC ("pixel-major"): element (n, y, x, c) of a tensor
+ *    lives at base[((n*H + y)*W + x)*stride + c].  `stride` (elements per
+ *    pixel) may exceed the channel count, so a channel slice of a wider
+ *    tensor is a valid tensor.  Channel counts seen by the convolution
+ *    kernels are padded to a multiple of SF_CPAD with zero-filled pad lanes.
+ *  - Return value: 0 = ok, nonzero = error (see sf_last_error_string()).
+ */
+#ifndef SATFLOW_HIP_H
+#define SATFLOW_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SF_ABI_VERSION 1
+#define SF_CPAD 16 /* channel padding granule of NHWC activations */
+
+typedef void* sfStream; /* hipStream_t */
+
+/* Arithmetic/storage type of a kernel family. */
+enum { SF_F32 = 0, SF_BF16 = 1 };
+
+/* Epilogues of sf_conv3x3_fwd. */
+enum {
+  SF_EPI_LINEAR = 0,  /* out = conv + bias                                  */
+  SF_EPI_SIGMOID = 1, /* out = sigmoid(conv + bias)                         */
+};
+
+int sf_abi_version(void);
+const char* sf_last_error_string(void);
+
+/* A strided NHWC channel slice. */
+typedef struct {
+  void* ptr;      /* first channel of pixel (0,0,0)            */
+  int32_t c;      /* channels (padded; multiple of SF_CPAD for conv inputs) */
+  int32_t stride; /* elements per pixel                        */
+} sfTensor;
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight repack (derived cache; the saved form stays the reference's OIHW fp32 state_dict).
+ *
+ * w: [O][I][3][3] fp32 (reference nn.Conv2d layout, e.g. ConvLSTMCell.conv.weight,
+ *    satflow/models/layers/ConvLSTM.py:34-40).
+ * Packed GEMM-B image: [Np/nb][Kp/16][9 taps][nb][16] with
+ *    transpose == 0:  B(n, k, tap) = w[nmap[n]][kmap[k]][tap]          (forward)
+ *    transpose == 1:  B(n, k, tap) = w[kmap[k]][nmap[n]][8 - tap]      (backward-data: W^T, flipped)
+ * nmap[Np], kmap[Kp]: device int32 tables, -1 marks a zero pad lane; nb = 32*nf.
+ * bias (nullable) [O] -> bias_packed[Np] gathered through nmap (transpose == 0 only).
+ * ------------------------------------------------------------------------------------------- */
+size_t sf_conv3x3_packed_elems(int32_t Np, int32_t Kp);
+int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t* nmap, int32_t Np,
+                            const int32_t* kmap, int32_t Kp, int32_t nf, int32_t transpose,
+                            void* packed, const float* bias, float* bias_packed, int32_t dtype,
+                            sfStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3x3 "same" convolution, implicit GEMM on MFMA, K = 9*(src0.c + src1.c) over [src0 ; src1].
+ * Replaces nn.Conv2d(k=3, padding=1) call sites on the path: the Conv3d(1,3,3)+Sigmoid head
+ * (satflow/models/conv_lstm.py:164-169,200-201), the DownSampler convolutions of metnet.MetNet
+ * (call site satflow/models/pl_metnet.py:46-59) and, with a transpose==1 weight image, the
+ * input-gradient of every convolution on the path.
+ * out.c output channels are written (pad lanes included); Np >= out.c.
+ * ------------------------------------------------------------------------------------------- */
+int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w,
+                   const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
+                   int32_t epilogue, sfTensor out, int32_t dtype, sfStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Fused ConvLSTM cell step.  Replaces ConvLSTMCell.forward,
+ * satflow/models/layers/ConvLSTM.py:42-57 (cat -> conv -> split i,f,o,g -> sigmoid x3, tanh ->
+ * c' = f*c + i*g -> h' = o*tanh(c')), one launch instead of ~11 ATen kernels.
+ *   x       : layer input (src0), h_prev : previous hidden state (src1; ptr NULL == zeros,
+ *             i.e. init_hidden, layers/ConvLSTM.py:59-64, without materialising them)
+ *   c_prev  : previous cell state (ptr NULL == zeros);  h_out, c_out : new states
+ *   gates   : nullable; receives post-activation i,f,o,g as [.., 4*hidp] (gate-major) for backward
+ *   wpacked : image from sf_conv3x3_pack_weights with the LSTM nmap (32 hidden channels x 4 gates
+ *             per N-block, nf == 4), bias_packed likewise.  hidp = padded hidden channels.
+ * ------------------------------------------------------------------------------------------- */
+int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n, int32_t h,
+                         int32_t w, const void* wpacked, const float* bias_packed, int32_t hidp,
+                         sfTensor h_out, sfTensor c_out, sfTensor gates, int32_t dtype,
+                         sfStream stream);
+
+/* Pointwise part of the cell's backward (autograd of layers/ConvLSTM.py:48-55):
+ *   dh = sum of up to three incoming hidden-state gradients (NULL ptr = absent)
+ *   dc_next (nullable) gradient flowing into c'; gates = saved i,f,o,g; c_prev nullable (zeros)
+ *   -> dz [.., 4*hidp] gradient wrt the pre-activation conv output, dc_prev (nullable out). */
+int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor dc_next,
+                               sfTensor gates, sfTensor c_prev, sfTensor c_new, int64_t pixels,
+                               int32_t hidp, sfTensor dz, sfTensor dc_prev, int32_t dtype,
+                               sfStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Weight/bias gradient of a 3x3 same convolution (autograd of the call sites above):
+ *   dW[o][i][ky][kx] (+)= sum_{n,y,x} dout[n,y,x,o] * in[n,y+ky-1,x+kx-1,i],   db[o] (+)= sum dout
+ * in = [src0 ; src1] (padded channels), dout.c = padded output channels.  nmap/kmap translate the
+ * padded indices to rows/columns of the OIHW gradient ( -1 = skip ).  `accumulate` != 0 adds into
+ * dw/db.  workspace: sf_conv3x3_bwd_weight_workspace_bytes() bytes of scratch.
+ * ------------------------------------------------------------------------------------------- */
+size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w);
+int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h,
+                          int32_t w, const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I,
+                          float* dw, float* db, int32_t accumulate, void* workspace,
+                          size_t workspace_bytes, int32_t dtype, sfStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Layout conversion at the module boundary (the reference keeps NCHW-style tensors throughout:
+ * x[B,T,C,H,W] in, [B,C,T,H,W] out, satflow/models/conv_lstm.py:205-228,198-201).
+ * The NCHW-side tensor is addressed as  base[b*stride_b + t*stride_t + c*stride_c + y*w + x]
+ * for b < nb, t < nt; the NHWC side holds nb*nt images, image index j = t*nb + b (time-major).
+ *   nchw_to_nhwc: gathers c real channels, zero-fills the pad lanes dst.c - c
+ *   nhwc_to_nchw: scatters the first c channels back.
+ * ------------------------------------------------------------------------------------------- */
+int sf_nchw_to_nhwc(const float* src, int64_t stride_b, int64_t stride_t, int64_t stride_c, int32_t nb,
+                    int32_t nt, int32_t c, int32_t h, int32_t w, sfTensor dst, int32_t dtype,
+                    sfStream stream);
+int sf_nhwc_to_nchw(sfTensor src, int32_t nb, int32_t nt, int32_t c, int32_t h, int32_t w, float* dst,
+                    int64_t stride_b, int64_t stride_t, int64_t stride_c, int32_t dtype,
+                    sfStream stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SATFLOW_HIP_H */

@@ -1,0 +1,103 @@
+"""ctypes binding of libsatflow_hip.so (the C ABI declared in include/satflow_hip.h).
+
+The library is the product; there is no fallback.  If it is missing, importing
+the symbols raises with the build command.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from typing import Optional
+
+import torch
+
+_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatflow_hip.so")
+
+SF_F32, SF_BF16 = 0, 1
+SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
+SF_CPAD = 16
+ABI_VERSION = 1
+
+
+class sfTensor(C.Structure):
+    _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32)]
+
+
+# name -> (restype, argtypes); mirrors include/satflow_hip.h one to one
+_i32, _i64, _vp, _sz = C.c_int32, C.c_int64, C.c_void_p, C.c_size_t
+PROTOTYPES = {
+    "sf_abi_version": (C.c_int, []),
+    "sf_last_error_string": (C.c_char_p, []),
+    "sf_conv3x3_packed_elems": (_sz, [_i32, _i32]),
+    "sf_conv3x3_pack_weights": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
+    "sf_conv3x3_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_convlstm_cell_fwd": (
+        C.c_int,
+        [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
+    ),
+    "sf_convlstm_cell_bwd_gates": (
+        C.c_int,
+        [sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, _i32, _vp],
+    ),
+    "sf_conv3x3_bwd_weight_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "sf_conv3x3_bwd_weight": (
+        C.c_int,
+        [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp],
+    ),
+    "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),
+}
+
+_lib: Optional[C.CDLL] = None
+
+
+def lib() -> C.CDLL:
+    """Load (once) and return the shared library; raise loudly if it is not built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB_PATH):
+            raise RuntimeError(
+                f"satflow_amd: {_LIB_PATH} is missing - the HIP library is the product path and has no fallback. "
+                "Build it with `python -m satflow_amd.build` (needs hipcc, cross-compiles for gfx950)."
+            )
+        L = C.CDLL(_LIB_PATH)
+        for name, (res, args) in PROTOTYPES.items():
+            fn = getattr(L, name)  # AttributeError here == header/library drift
+            fn.restype, fn.argtypes = res, args
+        if L.sf_abi_version() != ABI_VERSION:
+            raise RuntimeError(f"satflow_amd: ABI mismatch, library {L.sf_abi_version()} != binding {ABI_VERSION}")
+        _lib = L
+    return _lib
+
+
+def check(rc: int, what: str) -> None:
+    if rc != 0:
+        raise RuntimeError(f"{what} failed (rc={rc}): {lib().sf_last_error_string().decode()}")
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def require_device(t: torch.Tensor, name: str) -> None:
+    if not t.is_cuda:
+        raise RuntimeError(
+            f"satflow_amd: `{name}` lives on {t.device}; this path runs only on a HIP device (MI355X) - "
+            "there is no CPU implementation behind it (the CPU oracle is test infrastructure)."
+        )
+
+
+NULL = sfTensor(None, 0, 0)
+
+
+def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0) -> sfTensor:
+    """Describe a channels-last tensor ``[..., C]`` (or a channel slice ``offset:offset+c`` of it)."""
+    if t is None:
+        return sfTensor(None, c or 0, 0)
+    assert t.is_contiguous() and t.dtype == torch.float32, (t.shape, t.dtype, t.is_contiguous())
+    stride = t.shape[-1]
+    return sfTensor(t.data_ptr() + 4 * offset, stride - offset if c is None else c, stride)
+
+
+def cpad(c: int) -> int:
+    return (c + SF_CPAD - 1) // SF_CPAD * SF_CPAD

@@ -1,0 +1,196 @@
+// Weight / bias gradient of the 3x3 same convolution on the fp32 matrix cores.
+//
+//   dW[tap][co][ci] = sum over pixels  dout[pixel][co] * in[pixel + tap][ci]
+//
+// GEMM view: M = co, N = ci, K = pixels (one GEMM per tap, sharing the A operand).
+// A workgroup (4 waves) owns a 128(co) x 32(ci) x 9(tap) slab of dW; wave w owns co rows
+// 32w..32w+31 and keeps 9 accumulator tiles (144 VGPRs).  It walks its share of the K range in
+// 4x16-pixel tiles: the dout tile [64 px][128 co] and the input halo tile [6x18 px][32 ci] are
+// staged in LDS in their native NHWC order, which is already the layout the f32 MFMA wants
+// (operand element per lane = one float, lanes along the channel axis -> conflict-free
+// ds_read_b32); per K-step of 2 pixels: 1 A read + 9 shifted B reads feed 9 MFMAs.
+// Split-K partial slabs go to a workspace and are reduced (deterministically, no atomics) by a
+// second kernel that also scatters to the reference's OIHW gradient layout and sums the bias
+// gradient, which the main kernel gets for free from the A operand it already holds.
+#include "sf_common.h"
+
+namespace {
+
+constexpr int KT_H = 4, KT_W = 16;                 // K tile (pixels)
+constexpr int KT_PIX = KT_H * KT_W;                // 64
+constexpr int HALO_H = KT_H + 2, HALO_W = KT_W + 2;
+constexpr int CO_T = 128, CI_T = 32;
+constexpr int PA = CO_T;                           // LDS floats per dout pixel
+constexpr int PB = CI_T;                           // LDS floats per input pixel
+
+struct WgradParams {
+  const float* src0; const float* src1; int c0, c1, s0, s1;
+  const float* dout; int dc, ds;
+  int N, H, W, tiles_x, tiles_y, ntiles, KS;
+  float* partial; float* partial_db;
+  int NpT, KpT;
+};
+
+__global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) {
+  __shared__ __attribute__((aligned(16))) float lds[KT_PIX * PA + HALO_H * HALO_W * PB];
+  float* lds_a = lds;
+  float* lds_b = lds + KT_PIX * PA;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int r = lane & 31, kh = lane >> 5;
+  const int ks = blockIdx.x, cot = blockIdx.y, cit = blockIdx.z;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float asum = 0.f;
+
+  for (int tile = ks; tile < p.ntiles; tile += p.KS) {
+    int t = tile;
+    const int tx = t % p.tiles_x; t /= p.tiles_x;
+    const int ty = t % p.tiles_y;
+    const int n = t / p.tiles_y;
+    const int x0 = tx * KT_W, y0 = ty * KT_H;
+    __syncthreads();
+    // dout tile: 64 px x 32 float4
+    for (int pc = tid; pc < KT_PIX * (CO_T / 4); pc += 256) {
+      const int pix = pc / (CO_T / 4), c4 = (pc % (CO_T / 4)) * 4;
+      const int gy = y0 + (pix >> 4), gx = x0 + (pix & 15);
+      const int co = cot * CO_T + c4;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy < p.H && gx < p.W && co < p.dc)
+        v = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(n * p.H + gy) * p.W + gx) * p.ds + co);
+      *reinterpret_cast<f32x4*>(lds_a + pix * PA + c4) = v;
+    }
+    // input halo tile: 108 px x 8 float4
+    for (int pc = tid; pc < HALO_H * HALO_W * (CI_T / 4); pc += 256) {
+      const int pix = pc / (CI_T / 4), c4 = (pc % (CI_T / 4)) * 4;
+      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      const int kc = cit * CI_T + c4;  // channel in the concatenated padded K space
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        const size_t gp = (size_t)(n * p.H + gy) * p.W + gx;
+        if (kc < p.c0) v = *reinterpret_cast<const f32x4*>(p.src0 + gp * p.s0 + kc);
+        else if (kc - p.c0 < p.c1) v = *reinterpret_cast<const f32x4*>(p.src1 + gp * p.s1 + (kc - p.c0));
+      }
+      *reinterpret_cast<f32x4*>(lds_b + pix * PB + c4) = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int kstep = 0; kstep < KT_PIX / 2; ++kstep) {
+      const int px = 2 * kstep + kh;  // pixel of this lane's k index
+      const float a = lds_a[px * PA + 32 * wave + r];
+      asum += a;
+      const float* bb = lds_b + ((px >> 4) * HALO_W + (px & 15)) * PB + r;
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        const float b = bb[((tap / 3) * HALO_W + (tap % 3)) * PB];
+        acc[tap] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[tap], 0, 0, 0);
+      }
+    }
+  }
+
+  // partial[ks][tap][co][ci]
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = cot * CO_T + 32 * wave + frag_row(reg, kh);
+      const int ci = cit * CI_T + r;
+      p.partial[(((size_t)ks * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
+    }
+  if (cit == 0) {
+    const float tot = asum + __shfl_xor(asum, 32);
+    if (kh == 0) p.partial_db[(size_t)ks * p.NpT + cot * CO_T + 32 * wave + r] = tot;
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db, int KS, int NpT,
+                                    int KpT, int Np, int Kp, const int* __restrict__ nmap, const int* __restrict__ kmap, int I,
+                                    float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const size_t slab = (size_t)9 * NpT * KpT;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < slab) {
+    const int ci = gid % KpT;
+    const int co = (gid / KpT) % NpT;
+    const int tap = gid / ((size_t)KpT * NpT);
+    if (co < Np && ci < Kp) {
+      const int o = nmap[co], i = kmap[ci];
+      if (o >= 0 && i >= 0) {
+        float s = 0.f;
+        for (int k = 0; k < KS; ++k) s += partial[k * slab + gid];
+        float* d = dw + ((size_t)o * I + i) * 9 + tap;
+        *d = accumulate ? *d + s : s;
+      }
+    }
+  }
+  if (db && gid < (size_t)NpT) {
+    const int co = (int)gid;
+    if (co < Np && nmap[co] >= 0) {
+      float s = 0.f;
+      for (int k = 0; k < KS; ++k) s += partial_db[(size_t)k * NpT + co];
+      float* d = db + nmap[co];
+      *d = accumulate ? *d + s : s;
+    }
+  }
+}
+
+struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; };
+
+Plan make_plan(int Np, int Kp, int n, int h, int w) {
+  Plan pl;
+  pl.tiles_x = (w + KT_W - 1) / KT_W;
+  pl.tiles_y = (h + KT_H - 1) / KT_H;
+  pl.ntiles = pl.tiles_x * pl.tiles_y * n;
+  pl.cot = (Np + CO_T - 1) / CO_T;
+  pl.cit = (Kp + CI_T - 1) / CI_T;
+  int want = 1024 / (pl.cot * pl.cit);
+  if (want < 8) want = 8;
+  if (want > 256) want = 256;
+  pl.KS = pl.ntiles < want ? pl.ntiles : want;
+  if (pl.KS < 1) pl.KS = 1;
+  pl.ws_floats = (size_t)pl.KS * ((size_t)9 * pl.cot * CO_T * pl.cit * CI_T + (size_t)pl.cot * CO_T);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w) {
+  return make_plan(Np, Kp, n, h, w).ws_floats * sizeof(float);
+}
+
+int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h, int32_t w,
+                          const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I, float* dw, float* db,
+                          int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_conv3x3_bwd_weight: dtype %d not built", dtype);
+  SF_REQUIRE(src0.c % SF_CPAD == 0 && src1.c % SF_CPAD == 0 && dout.c % 4 == 0, "bwd_weight: channel padding");
+  SF_REQUIRE(src0.ptr || src0.c == 0, "bwd_weight: src0 null");
+  SF_REQUIRE(src1.ptr || src1.c == 0, "bwd_weight: src1 null with c=%d (pass c=0)", src1.c);
+  const int Np = dout.c, Kp = src0.c + src1.c;
+  const Plan pl = make_plan(Np, Kp, n, h, w);
+  SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
+             workspace_bytes, pl.ws_floats * sizeof(float));
+  WgradParams p{};
+  p.src0 = (const float*)src0.ptr; p.src1 = (const float*)src1.ptr;
+  p.c0 = src0.c; p.c1 = src1.c; p.s0 = src0.stride; p.s1 = src1.stride;
+  p.dout = (const float*)dout.ptr; p.dc = dout.c; p.ds = dout.stride;
+  p.N = n; p.H = h; p.W = w; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.KS = pl.KS;
+  p.NpT = pl.cot * CO_T; p.KpT = pl.cit * CI_T;
+  p.partial = (float*)workspace;
+  p.partial_db = p.partial + (size_t)pl.KS * 9 * p.NpT * p.KpT;
+  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(pl.KS, pl.cot, pl.cit), dim3(256), 0, (hipStream_t)stream, p);
+  SF_CHECK_LAUNCH("wgrad_f32");
+  const size_t slab = (size_t)9 * p.NpT * p.KpT;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     p.partial, p.partial_db, pl.KS, p.NpT, p.KpT, Np, Kp, nmap, kmap, I, dw, db, accumulate);
+  SF_CHECK_LAUNCH("wgrad_reduce");
+  (void)O;
+  return 0;
+}
+
+}  // extern "C"

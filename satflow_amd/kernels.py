@@ -1,0 +1,202 @@
+"""Typed Python entry points over the C ABI (one function per symbol of include/satflow_hip.h).
+
+Everything here takes/returns torch CUDA tensors in the kernels' layout: NHWC, fp32, channel
+count padded to ``SF_CPAD``.  PyTorch only owns the memory and the stream; all arithmetic is in
+libsatflow_hip.so.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import torch
+
+from . import _hip
+from ._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, SF_F32, T, check, cpad, lib, stream_ptr, sfTensor
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# GEMM index maps: how padded N / K lanes of a kernel map onto rows / columns of the reference's
+# OIHW weight.  Built on the host once per module, kept as tiny device tables.
+# ----------------------------------------------------------------------------------------------
+def choose_nf(lanes: int) -> int:
+    """N fragments (32 lanes each) per workgroup: fewest total fragments, then fewest blocks."""
+    best = None
+    for nf in range(1, 6):
+        nblk = -(-lanes // (32 * nf))
+        key = (nblk * nf, nblk)
+        if best is None or key < best[0]:
+            best = (key, nf)
+    return best[1]
+
+
+@dataclass
+class GemmMap:
+    nmap: List[int]  # len Np (multiple of 32*nf)
+    kmap: List[int]  # len Kp (multiple of 16)
+    nf: int
+    n_lanes: int  # lanes actually written by the kernel (out.c)
+    _dev: Dict[torch.device, Tuple[Tensor, Tensor]] = field(default_factory=dict, repr=False)
+
+    @property
+    def Np(self) -> int:
+        return len(self.nmap)
+
+    @property
+    def Kp(self) -> int:
+        return len(self.kmap)
+
+    def tables(self, device) -> Tuple[Tensor, Tensor]:
+        device = torch.device(device)
+        if device not in self._dev:
+            self._dev[device] = (
+                torch.tensor(self.nmap, dtype=torch.int32, device=device),
+                torch.tensor(self.kmap, dtype=torch.int32, device=device),
+            )
+        return self._dev[device]
+
+
+def _padded(real: int, base: int = 0) -> List[int]:
+    return [base + i if i < real else -1 for i in range(cpad(real))]
+
+
+def _finish(nlanes_map: List[int], kmap: List[int], nf: Optional[int] = None) -> GemmMap:
+    lanes = len(nlanes_map)
+    nf = nf or choose_nf(lanes)
+    Np = -(-lanes // (32 * nf)) * 32 * nf
+    return GemmMap(nlanes_map + [-1] * (Np - lanes), kmap, nf, lanes)
+
+
+def linear_map(cins: Sequence[int], cout: int) -> GemmMap:
+    """Plain conv over the channel concatenation of ``cins`` sources."""
+    kmap, base = [], 0
+    for c in cins:
+        kmap += _padded(c, base)
+        base += c
+    return _finish(_padded(cout), kmap)
+
+
+def linear_bwd_map(cins: Sequence[int], cout: int, need: Sequence[bool]) -> GemmMap:
+    """Input-gradient conv: K = padded out channels, N = padded input lanes of the needed sources."""
+    nm, base = [], 0
+    for c, nd in zip(cins, need):
+        if nd:
+            nm += _padded(c, base)
+        base += c
+    return _finish(nm, _padded(cout))
+
+
+def lstm_fwd_map(cin: int, hid: int) -> GemmMap:
+    """ConvLSTM gate conv: each N block = 4 gates x 32 hidden channels (gate order i,f,o,g,
+    reference layers/ConvLSTM.py:48), so one wave holds all four gates of a hidden channel."""
+    hidp = cpad(hid)
+    nblk = -(-hidp // 32)
+    nmap = []
+    for nb in range(nblk):
+        for g in range(4):
+            for j in range(32):
+                hc = nb * 32 + j
+                nmap.append(g * hid + hc if hc < hid else -1)
+    return GemmMap(nmap, _padded(cin) + _padded(hid, cin), 4, nblk * 128)
+
+
+def lstm_dz_kmap(hid: int) -> List[int]:
+    hidp = cpad(hid)
+    return [g * hid + j if j < hid else -1 for g in range(4) for j in range(hidp)]
+
+
+def lstm_bwd_map(cin: int, hid: int, need_dx: bool) -> GemmMap:
+    """dz [4*hidp gate-major] -> [dx (if needed) ; dh_prev]."""
+    nm = (_padded(cin) if need_dx else []) + _padded(hid, cin)
+    return _finish(nm, lstm_dz_kmap(hid))
+
+
+def lstm_wgrad_map(cin: int, hid: int) -> GemmMap:
+    """Weight-gradient index maps: dout lanes = dz (gate-major), K lanes = [x ; h]."""
+    return GemmMap(lstm_dz_kmap(hid), _padded(cin) + _padded(hid, cin), 0, 4 * cpad(hid))
+
+
+# ----------------------------------------------------------------------------------------------
+# thin wrappers
+# ----------------------------------------------------------------------------------------------
+def pack_weights(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, transpose: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """OIHW fp32 -> packed MFMA B image (+ packed bias).  sf_conv3x3_pack_weights."""
+    _hip.require_device(weight, "weight")
+    w = weight.detach().contiguous()
+    O, I = w.shape[0], w.shape[1]
+    assert w.shape[2:] == (3, 3), "only 3x3 kernels are on the path"
+    nmap, kmap = gm.tables(w.device)
+    packed = torch.empty(gm.Np * gm.Kp * 9, dtype=torch.float32, device=w.device)
+    bp = torch.empty(gm.Np, dtype=torch.float32, device=w.device) if (bias is not None and not transpose) else None
+    check(
+        lib().sf_conv3x3_pack_weights(
+            w.data_ptr(), O, I, nmap.data_ptr(), gm.Np, kmap.data_ptr(), gm.Kp, gm.nf, int(transpose), packed.data_ptr(),
+            bias.detach().contiguous().data_ptr() if bp is not None else None, bp.data_ptr() if bp is not None else None,
+            SF_F32, stream_ptr(),
+        ),
+        "sf_conv3x3_pack_weights",
+    )
+    return packed, bp
+
+
+def conv3x3(src0: sfTensor, src1: sfTensor, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor],
+            gm: GemmMap, out: sfTensor, epilogue: int = SF_EPI_LINEAR) -> None:
+    check(
+        lib().sf_conv3x3_fwd(src0, src1, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
+                             gm.Np, gm.nf, epilogue, out, SF_F32, stream_ptr()),
+        "sf_conv3x3_fwd",
+    )
+
+
+def convlstm_cell_fwd(x: sfTensor, h_prev: sfTensor, c_prev: sfTensor, n: int, h: int, w: int, packed: Tensor,
+                      bias_packed: Optional[Tensor], hidp: int, h_out: sfTensor, c_out: sfTensor, gates: sfTensor) -> None:
+    check(
+        lib().sf_convlstm_cell_fwd(x, h_prev, c_prev, n, h, w, packed.data_ptr(),
+                                   bias_packed.data_ptr() if bias_packed is not None else None, hidp, h_out, c_out, gates,
+                                   SF_F32, stream_ptr()),
+        "sf_convlstm_cell_fwd",
+    )
+
+
+def convlstm_cell_bwd_gates(dh: Sequence[sfTensor], dc_next: sfTensor, gates: sfTensor, c_prev: sfTensor, c_new: sfTensor,
+                            pixels: int, hidp: int, dz: sfTensor, dc_prev: sfTensor) -> None:
+    dh = list(dh) + [NULL] * (3 - len(dh))
+    check(
+        lib().sf_convlstm_cell_bwd_gates(dh[0], dh[1], dh[2], dc_next, gates, c_prev, c_new, pixels, hidp, dz, dc_prev, SF_F32,
+                                         stream_ptr()),
+        "sf_convlstm_cell_bwd_gates",
+    )
+
+
+def conv3x3_bwd_weight(src0: sfTensor, src1: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, dw: Tensor,
+                       db: Optional[Tensor], accumulate: bool) -> None:
+    """dW/db of a 3x3 conv into the reference's OIHW gradient tensors.  sf_conv3x3_bwd_weight."""
+    dev = dw.device
+    nmap, kmap = gm.tables(dev)
+    nbytes = lib().sf_conv3x3_bwd_weight_workspace_bytes(dout.c, src0.c + src1.c, n, h, w)
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+    O, I = dw.shape[0], dw.shape[1]
+    assert dw.is_contiguous() and (db is None or db.is_contiguous())
+    check(
+        lib().sf_conv3x3_bwd_weight(src0, src1, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), O, I, dw.data_ptr(),
+                                    db.data_ptr() if db is not None else None, int(accumulate), ws.data_ptr(), nbytes, SF_F32,
+                                    stream_ptr()),
+        "sf_conv3x3_bwd_weight",
+    )
+
+
+def to_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int], cp: Optional[int] = None) -> Tensor:
+    """NCHW-side tensor -> time-major NHWC ``[nt*nb, h, w, cp]`` (pad lanes zero).  sf_nchw_to_nhwc."""
+    _hip.require_device(src, "input")
+    cp = cp or cpad(c)
+    dst = torch.empty(nt * nb, h, w, cp, dtype=torch.float32, device=src.device)
+    check(lib().sf_nchw_to_nhwc(src.data_ptr(), *strides, nb, nt, c, h, w, T(dst), SF_F32, stream_ptr()), "sf_nchw_to_nhwc")
+    return dst
+
+
+def from_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, dst: Tensor, strides: Tuple[int, int, int]) -> Tensor:
+    """Time-major NHWC -> NCHW-side tensor ``dst`` addressed with ``strides=(b,t,c)``.  sf_nhwc_to_nchw."""
+    check(lib().sf_nhwc_to_nchw(T(src), nb, nt, c, h, w, dst.data_ptr(), *strides, SF_F32, stream_ptr()), "sf_nhwc_to_nchw")
+    return dst

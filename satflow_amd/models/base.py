@@ -1,0 +1,87 @@
+"""Model registry, LightningModule surface and loss factory for the hot-path models.
+
+The reference gets these from un-vendored packages: ``register_model / create_model /
+get_model / list_models / BaseModel`` and ``get_loss`` from ``nowcasting_utils``
+(reference ``satflow/models/__init__.py:1``, ``conv_lstm.py:7-8``, ``pl_metnet.py:8-9``) and
+``LightningModule`` from ``pytorch_lightning``.  This file supplies the same call surface
+(SURVEY.md 8b): names are the class ``__name__``; ``create_model`` forwards ``pretrained``.
+If ``pytorch_lightning`` is importable its ``LightningModule`` is used, otherwise a shim
+with the method names the models and a Trainer-like loop rely on.
+"""
+from __future__ import annotations
+
+import inspect
+from typing import Any, Callable, Dict, List, Type, Union
+
+import torch
+from torch import nn
+
+try:  # pragma: no cover - not installed in the build image
+    from pytorch_lightning import LightningModule as _LightningModule
+except Exception:  # noqa: BLE001
+
+    class _LightningModule(nn.Module):
+        """Minimal stand-in: hyper-parameter capture + metric log sink."""
+
+        def __init__(self) -> None:
+            super().__init__()
+            self.hparams: Dict[str, Any] = {}
+            self.logged: Dict[str, Any] = {}
+
+        def save_hyperparameters(self, *args: Any, **kwargs: Any) -> None:
+            frame = inspect.currentframe().f_back
+            init = getattr(type(self), "__init__")
+            names = [n for n in inspect.signature(init).parameters if n != "self"]
+            self.hparams = {n: frame.f_locals[n] for n in names if n in frame.f_locals}
+
+        def log(self, name: str, value: Any, **kwargs: Any) -> None:
+            self.logged[name] = value
+
+        def log_dict(self, values: Dict[str, Any], **kwargs: Any) -> None:
+            self.logged.update(values)
+
+
+LightningModule = _LightningModule
+
+_REGISTRY: Dict[str, Type[nn.Module]] = {}
+
+
+def register_model(cls: Type[nn.Module]) -> Type[nn.Module]:
+    """Class decorator: register under ``cls.__name__`` (reference ``conv_lstm.py:13``, ``pl_metnet.py:15``)."""
+    _REGISTRY[cls.__name__] = cls
+    return cls
+
+
+def list_models() -> List[str]:
+    return sorted(_REGISTRY)
+
+
+def get_model(name: str) -> Type[nn.Module]:
+    if name not in _REGISTRY:
+        raise KeyError(f"unknown model {name!r}; registered: {list_models()}")
+    return _REGISTRY[name]
+
+
+def create_model(name: str, pretrained: bool = False, **kwargs: Any) -> nn.Module:
+    """``create_model(name, pretrained=False, **kw)`` (reference ``tests/test_models.py:64-76``).
+
+    ``hf_hub:`` names need network access (skipped in the reference's own tests, ``:79-102``).
+    """
+    if name.startswith("hf_hub:"):
+        raise RuntimeError("hf_hub checkpoints need network access, which this build does not have")
+    return get_model(name)(pretrained=pretrained, **kwargs)
+
+
+class BaseModel(LightningModule):
+    """Placeholder for ``nowcasting_utils.models.base.BaseModel`` (``pl_metnet.py:16``)."""
+
+
+def get_loss(loss: Union[str, nn.Module, Callable] = "mse", **kwargs: Any) -> nn.Module:
+    """``nowcasting_utils.models.loss.get_loss``: only ``"mse"`` is on the hot path."""
+    if isinstance(loss, nn.Module):
+        return loss
+    if callable(loss) and not isinstance(loss, str):
+        return loss
+    if loss in ("mse", "MSE"):
+        return nn.MSELoss()
+    raise ValueError(f"loss {loss!r} is outside the hot-path scope (only 'mse'; see DESIGN.md)")

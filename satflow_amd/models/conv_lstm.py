@@ -1,0 +1,360 @@
+"""ConvLSTM encoder-decoder on the HIP kernels.
+
+Module surface of reference ``satflow/models/conv_lstm.py``: ``ConvLSTM(input_channels,
+hidden_dim, out_channels, conv_type)`` with sub-modules ``encoder_1_convlstm,
+encoder_2_convlstm, decoder_1_convlstm, decoder_2_convlstm, decoder_CNN`` (``:132-169``; the
+``state_dict`` keys are pinned in ``tests/golden/convlstm_state_dict_keys.txt``) and the
+registered Lightning wrapper ``EncoderDecoderConvLSTM`` (``:13-91``).
+
+Execution differs from the reference by design.  ``ConvLSTM.forward`` (reference ``:171-228``)
+is ONE autograd node, ``_StackFn``: the whole 2x(T_in+T_out) unroll runs as a sequence of fused
+cell launches on time-major NHWC sequence buffers (hidden/cell/gate tensors of every step stay
+resident in HBM - there is room for all of them in 288 GB - so nothing is re-materialised, no
+``cat``/``stack``/``permute`` copies exist, and t=0 reads no state at all instead of
+allocating zeros, ``:218-221``).  Its backward walks the unroll in reverse with one pointwise
+launch + one input-gradient convolution per cell step, and defers every weight gradient to a
+single split-K GEMM per cell over all timesteps at the end.
+"""
+from __future__ import annotations
+
+from typing import Any, Dict, List, Optional, Tuple, Union
+
+import torch
+from torch import nn
+
+from .. import kernels as K
+from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, require_device, sfTensor
+from .base import LightningModule, get_loss, register_model
+from .layers.ConvLSTM import CellEngine, ConvLSTMCell
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# layout ops (autograd-aware): NCHW-side tensors <-> time-major NHWC
+# ----------------------------------------------------------------------------------------------
+class _ToNHWC(torch.autograd.Function):
+    """``src`` addressed as [nb][nt] images with element strides ``(sb, st, sc)`` -> ``[nt*nb,H,W,Cp]``."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
+        src = src.contiguous()
+        ctx.meta = (src.shape, nb, nt, c, h, w, strides)
+        return K.to_nhwc(src, nb, nt, c, h, w, strides)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        shape, nb, nt, c, h, w, strides = ctx.meta
+        out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        K.from_nhwc(g.contiguous(), nb, nt, c, h, w, out, strides)
+        return out, None, None, None, None, None, None
+
+
+class _FromNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, shape: Tuple[int, ...], nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
+        ctx.meta = (nb, nt, c, h, w, strides, src.shape[-1])
+        out = torch.empty(shape, dtype=torch.float32, device=src.device)
+        return K.from_nhwc(src.contiguous(), nb, nt, c, h, w, out, strides)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        nb, nt, c, h, w, strides, cp = ctx.meta
+        return K.to_nhwc(g.contiguous(), nb, nt, c, h, w, strides, cp), None, None, None, None, None, None, None
+
+
+def nchw_to_nhwc(x: Tensor) -> Tensor:
+    """``[N,C,H,W] -> [N,H,W,Cp]``."""
+    n, c, h, w = x.shape
+    return _ToNHWC.apply(x, n, 1, c, h, w, (c * h * w, 0, h * w))
+
+
+def nhwc_to_nchw(x: Tensor, c: int) -> Tensor:
+    """``[N,H,W,Cp] -> [N,c,H,W]``."""
+    n, h, w, _ = x.shape
+    return _FromNHWC.apply(x, (n, c, h, w), n, 1, c, h, w, (c * h * w, 0, h * w))
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 convolution on NHWC with fused epilogue (the Conv3d(1,3,3)+Sigmoid head, conv_lstm.py:164-169,200-201)
+# ----------------------------------------------------------------------------------------------
+class Conv3x3Engine:
+    def __init__(self, cin: int, cout: int) -> None:
+        self.cin, self.cout = cin, cout
+        self.fwd_map = K.linear_map([cin], cout)
+        self.bwd_map = K.linear_bwd_map([cin], cout, [True])
+        self.wgrad_map = K.GemmMap(K._padded(cout), K._padded(cin), 0, cpad(cout))
+        self._key, self._packed = None, {}
+
+    def packed(self, weight: Tensor, bias: Optional[Tensor], kind: str):
+        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version))
+        if key != self._key:
+            self._key, self._packed = key, {}
+        if kind not in self._packed:
+            w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
+            if kind == "fwd":
+                self._packed[kind] = K.pack_weights(w4, bias, self.fwd_map, transpose=False)
+            else:
+                self._packed[kind] = K.pack_weights(w4, None, self.bwd_map, transpose=True)
+        return self._packed[kind]
+
+
+class _Conv3x3Fn(torch.autograd.Function):
+    """``y = act(conv3x3(x) + b)`` on ``x[N,H,W,Cinp]`` -> ``[N,H,W,Coutp]``; act in {identity, sigmoid}."""
+
+    @staticmethod
+    def forward(ctx, eng: Conv3x3Engine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool):
+        n, H, W, _ = x.shape
+        packed, bp = eng.packed(weight, bias, "fwd")
+        y = torch.empty(n, H, W, cpad(eng.cout), dtype=torch.float32, device=x.device)
+        K.conv3x3(T(x), NULL, n, H, W, packed, bp, eng.fwd_map, T(y), SF_EPI_SIGMOID if sigmoid else SF_EPI_LINEAR)
+        ctx.eng, ctx.sigmoid = eng, sigmoid
+        ctx.save_for_backward(x, y if sigmoid else x.new_empty(0), weight, bias if bias is not None else x.new_empty(0))
+        ctx.has_bias = bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        eng: Conv3x3Engine = ctx.eng
+        x, y, weight, bias = ctx.saved_tensors
+        n, H, W, _ = x.shape
+        gy = gy.contiguous()
+        if ctx.sigmoid:
+            gy = gy * y * (1.0 - y)  # pointwise; pad lanes carry gy == 0 from the layout op
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, None, "bwd")[0], None, eng.bwd_map, T(dx))
+        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=x.device)
+        db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
+        K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
+        return None, dx, dw4.reshape(weight.shape), db, None
+
+
+# ----------------------------------------------------------------------------------------------
+# the unrolled 4-cell encoder-decoder as one autograd node
+# ----------------------------------------------------------------------------------------------
+class _StackFn(torch.autograd.Function):
+    """x ``[T*B,H,W,Cp]`` time-major -> decoder-2 hidden states ``[Tout*B,H,W,hidp]`` time-major.
+
+    Dataflow of reference ``conv_lstm.py:171-196``: encoder cells 1,2 over the T input frames;
+    decoder cell 3 is fed ``h2[T-1]`` at the first forecast step and ``h4[s-1]`` afterwards
+    (``:185,195``); decoder cell 4 is fed ``h3[s]``.
+    """
+
+    @staticmethod
+    def forward(ctx, engines: List[CellEngine], B: int, T_in: int, T_out: int, x: Tensor, *params: Tensor):
+        e1, e2, d1, d2 = engines
+        H, W = x.shape[1], x.shape[2]
+        hidp = e1.hidp
+        dev = x.device
+        keep = any(ctx.needs_input_grad)  # False under no_grad / inference: no gates are written
+
+        def seq(steps: int, ch: int) -> Tensor:
+            return torch.empty(steps, B, H, W, ch, dtype=torch.float32, device=dev)
+
+        steps = (T_in, T_in, T_out, T_out)
+        Hs = [seq(s, hidp) for s in steps]
+        Cs = [seq(s, hidp) for s in steps]
+        Gs = [seq(s, 4 * hidp) if keep else None for s in steps]
+        xs = x.view(T_in, B, H, W, x.shape[-1])
+
+        def run(k: int, eng: CellEngine, inp: Tensor, t: int) -> None:
+            eng.step(T(inp), Hs[k][t - 1] if t else None, Cs[k][t - 1] if t else None, B, H, W, Hs[k][t], Cs[k][t],
+                     Gs[k][t] if keep else None)
+
+        for t in range(T_in):
+            run(0, e1, xs[t], t)
+            run(1, e2, Hs[0][t], t)
+        for s in range(T_out):
+            run(2, d1, Hs[1][T_in - 1] if s == 0 else Hs[3][s - 1], s)
+            run(3, d2, Hs[2][s], s)
+
+        ctx.engines, ctx.dims = engines, (B, T_in, T_out, H, W)
+        ctx.need_dx = x.requires_grad
+        if keep:
+            ctx.save_for_backward(x, *Hs, *Cs, *Gs)
+        return Hs[3].view(T_out * B, H, W, hidp)
+
+    @staticmethod
+    def backward(ctx, g_out: Tensor):
+        e1, e2, d1, d2 = engines = ctx.engines
+        B, T_in, T_out, H, W = ctx.dims
+        saved = ctx.saved_tensors
+        x, Hs, Cs, Gs = saved[0], saved[1:5], saved[5:9], saved[9:13]
+        hidp = e1.hidp
+        dev = x.device
+        g_out = g_out.contiguous().view(T_out, B, H, W, hidp)
+        xs = x.view(T_in, B, H, W, x.shape[-1])
+        need_dx = [ctx.need_dx, True, True, True]
+        # per cell: [dx (if needed) ; dh_prev] scratch of the input-gradient conv, and the dc carry
+        widths = [(eng.cinp if nd else 0) + hidp for eng, nd in zip(engines, need_dx)]
+        dcat = [torch.empty(B, H, W, wd, dtype=torch.float32, device=dev) for wd in widths]
+        dc = [torch.empty(B, H, W, hidp, dtype=torch.float32, device=dev) for _ in range(4)]
+        dxs = torch.empty_like(xs) if ctx.need_dx else None
+
+        def dx_of(k: int) -> sfTensor:  # gradient wrt the cell's layer input, left by its last bwd_data
+            return T(dcat[k], engines[k].cinp, 0)
+
+        def dh_of(k: int) -> sfTensor:  # gradient wrt the cell's previous hidden state
+            return T(dcat[k], hidp, widths[k] - hidp)
+
+        def back(k: int, t: int, last: bool, sources: List[sfTensor]) -> None:
+            """Backward of cell k at step t.  dz overwrites the saved gates in place."""
+            eng = engines[k]
+            if not last:
+                sources = sources + [dh_of(k)]
+            eng.bwd_gates(sources, None if last else dc[k], Gs[k][t], Cs[k][t - 1] if t else None, Cs[k][t], Gs[k][t],
+                          dc[k] if t else None)
+            if t or need_dx[k]:
+                eng.bwd_data(Gs[k][t], B, H, W, need_dx[k], dcat[k])
+
+        for s in range(T_out - 1, -1, -1):
+            last = s == T_out - 1
+            # decoder 2: head gradient + (decoder 1 consumed h4[s] as its input at step s+1)
+            back(3, s, last, [T(g_out[s])] + ([] if last else [dx_of(2)]))
+            back(2, s, last, [dx_of(3)])
+        for t in range(T_in - 1, -1, -1):
+            last = t == T_in - 1
+            # encoder 2: at the last input step its h feeds decoder 1's first step
+            back(1, t, last, [dx_of(2)] if last else [])
+            back(0, t, last, [dx_of(1)])
+            if ctx.need_dx:
+                dxs[t].copy_(dcat[0][..., : e1.cinp])
+
+        # weight gradients: one split-K GEMM per cell over all of its timesteps (Gs now hold dz)
+        grads: List[Optional[Tensor]] = []
+        zeros = torch.zeros(B, H, W, hidp, dtype=torch.float32, device=dev)
+
+        def wgrad(eng: CellEngine, inp: sfTensor, hprev: sfTensor, dz: Tensor, steps: int, dw: Tensor, db: Tensor, acc: bool):
+            eng.bwd_weight(inp, hprev, T(dz), steps * B, H, W, dw, db, acc)
+
+        for k, eng in enumerate(engines):
+            dw = torch.empty_like(eng.conv.weight)
+            db = torch.empty_like(eng.conv.bias)
+            steps = T_in if k < 2 else T_out
+            # step 0 has a zero previous state; steps 1.. read h[t-1] straight from the sequence buffer
+            if k == 0:
+                first_in, rest_in = xs[0], xs[1:]
+            elif k == 1:
+                first_in, rest_in = Hs[0][0], Hs[0][1:]
+            elif k == 2:
+                first_in, rest_in = Hs[1][T_in - 1], Hs[3][: T_out - 1]
+            else:
+                first_in, rest_in = Hs[2][0], Hs[2][1:]
+            wgrad(eng, T(first_in), T(zeros), Gs[k][0], 1, dw, db, False)
+            if steps > 1:
+                wgrad(eng, T(rest_in), T(Hs[k][: steps - 1]), Gs[k][1:], steps - 1, dw, db, True)
+            grads += [dw, db]
+        gx = dxs.view(x.shape) if ctx.need_dx else None
+        return (None, None, None, None, gx, *grads)
+
+
+class ConvLSTM(nn.Module):
+    def __init__(self, input_channels, hidden_dim, out_channels, conv_type: str = "standard"):
+        super().__init__()
+        cell = lambda cin: ConvLSTMCell(input_dim=cin, hidden_dim=hidden_dim, kernel_size=(3, 3), bias=True, conv_type=conv_type)
+        self.encoder_1_convlstm = cell(input_channels)
+        self.encoder_2_convlstm = cell(hidden_dim)
+        self.decoder_1_convlstm = cell(hidden_dim)
+        self.decoder_2_convlstm = cell(hidden_dim)
+        self.decoder_CNN = nn.Conv3d(in_channels=hidden_dim, out_channels=out_channels, kernel_size=(1, 3, 3), padding=(0, 1, 1))
+        self.hidden_dim, self.out_channels, self.input_channels = hidden_dim, out_channels, input_channels
+        self._head = Conv3x3Engine(hidden_dim, out_channels)
+
+    def cells(self) -> List[ConvLSTMCell]:
+        return [self.encoder_1_convlstm, self.encoder_2_convlstm, self.decoder_1_convlstm, self.decoder_2_convlstm]
+
+    def forward(self, x: Tensor, forecast_steps: int = 0, hidden_state=None) -> Tensor:
+        """``x[B,T,C,H,W] -> [B, out, forecast_steps, H, W]`` (reference ``conv_lstm.py:205-228``).
+
+        ``hidden_state`` is accepted and ignored, as in the reference (``:205,218-221``).
+        """
+        require_device(x, "x")
+        B, T_in, C, H, W = x.shape
+        if C != self.input_channels:
+            raise RuntimeError(f"expected {self.input_channels} input channels, got {C}")
+        if forecast_steps < 1 or T_in < 1:
+            raise RuntimeError("ConvLSTM needs at least one input frame and forecast_steps >= 1 (torch.stack of an empty list "
+                               "fails in the reference too, conv_lstm.py:198)")
+        x = x.float()
+        xs = _ToNHWC.apply(x, B, T_in, C, H, W, (T_in * C * H * W, C * H * W, H * W))  # [T*B,H,W,Cp]
+        cells = self.cells()
+        params = [p for c in cells for p in (c.conv.weight, c.conv.bias)]
+        hseq = _StackFn.apply([c.engine for c in cells], B, T_in, forecast_steps, xs, *params)
+        y = _Conv3x3Fn.apply(self._head, hseq, self.decoder_CNN.weight, self.decoder_CNN.bias, True)
+        O, To = self.out_channels, forecast_steps
+        return _FromNHWC.apply(y, (B, O, To, H, W), B, To, O, H, W, (O * To * H * W, H * W, To * H * W))
+
+
+@register_model
+class EncoderDecoderConvLSTM(LightningModule):
+    def __init__(
+        self,
+        hidden_dim: int = 64,
+        input_channels: int = 12,
+        out_channels: int = 1,
+        forecast_steps: int = 48,
+        lr: float = 0.001,
+        visualize: bool = False,
+        loss: Union[str, torch.nn.Module] = "mse",
+        pretrained: bool = False,
+        conv_type: str = "standard",
+    ):
+        """Same keyword surface as reference ``conv_lstm.py:15-33`` (so ``configs/model/convlstm.yaml`` loads)."""
+        super().__init__()
+        self.forecast_steps = forecast_steps
+        self.criterion = get_loss(loss)
+        self.lr = lr
+        self.visualize = visualize
+        self.model = ConvLSTM(input_channels, hidden_dim, out_channels, conv_type=conv_type)
+        self.save_hyperparameters()
+
+    @classmethod
+    def from_config(cls, config):
+        return EncoderDecoderConvLSTM(
+            hidden_dim=config.get("num_hidden", 64),
+            input_channels=config.get("in_channels", 12),
+            out_channels=config.get("out_channels", 1),
+            forecast_steps=config.get("forecast_steps", 1),
+            lr=config.get("lr", 0.001),
+        )
+
+    def forward(self, x, future_seq=0, hidden_state=None):
+        return self.model.forward(x, future_seq, hidden_state)
+
+    def configure_optimizers(self):
+        return torch.optim.Adam(self.parameters(), lr=self.lr)
+
+    # -- steps: same metric names as the reference (train/loss, {train,val}/frame_{f}_loss), but the
+    #    per-frame losses come from ONE reduction and ONE host sync instead of forecast_steps .item() calls
+    #    (reference conv_lstm.py:66-68,80-82).
+    def _frame_losses(self, y_hat: Tensor, y: Tensor) -> Tensor:
+        return ((y_hat.detach() - y) ** 2).mean(dim=(0, 2, 3, 4))
+
+    def _log_frames(self, prefix: str, frames: Tensor) -> None:
+        vals = frames.tolist()  # one sync
+        self.log_dict({f"{prefix}/frame_{f}_loss": v for f, v in enumerate(vals)}, on_step=False, on_epoch=True)
+
+    def training_step(self, batch, batch_idx):
+        x, y = batch
+        y_hat = self(x, self.forecast_steps)
+        y_hat = torch.permute(y_hat, dims=(0, 2, 1, 3, 4))
+        loss = self.criterion(y_hat, y)
+        self.log("train/loss", loss, on_step=True)
+        self._log_frames("train", self._frame_losses(y_hat, y))
+        return loss
+
+    def validation_step(self, batch, batch_idx):
+        x, y = batch
+        y_hat = self(x, self.forecast_steps)
+        y_hat = torch.permute(y_hat, dims=(0, 2, 1, 3, 4))
+        val_loss = self.criterion(y_hat, y)
+        self.log("val/loss", val_loss, on_step=True, on_epoch=True)
+        self._log_frames("val", self._frame_losses(y_hat, y))
+        return val_loss
+
+    def test_step(self, batch, batch_idx):
+        x, y = batch
+        y_hat = self(x, self.forecast_steps)
+        return self.criterion(y_hat, y)

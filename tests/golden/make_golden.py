@@ -1,0 +1,195 @@
+#!/usr/bin/env python3
+"""Generate the golden vectors under tests/golden/ FROM THE REFERENCE ITSELF.
+
+Runs only in the build container (needs /root/reference).  It imports the
+reference's in-tree ConvLSTM path with namespace shims for the packages that
+are not installed (pytorch_lightning, torchvision, nowcasting_utils; SURVEY.md
+8c), executes it on CPU in fp32 on seeded inputs, and writes inputs, weights,
+outputs and gradients as .npz.  It also checks, on the spot, that the CPU
+restatement in oracle/ reproduces the reference (the "pin").
+
+Only tensors are written; no reference source travels.
+
+    python tests/golden/make_golden.py            # regenerate + verify oracle
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+import numpy as np
+import torch
+
+REF = os.environ.get("SATFLOW_REFERENCE", "/root/reference")
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+
+def _shim_reference():
+    sys.path.insert(0, REF)
+
+    def mk(name, path=None):
+        m = types.ModuleType(name)
+        if path:
+            m.__path__ = [path]
+        sys.modules[name] = m
+        return m
+
+    mk("satflow", f"{REF}/satflow")
+    mk("satflow.models", f"{REF}/satflow/models")
+    pl = mk("pytorch_lightning")
+
+    class LightningModule(torch.nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+    pl.LightningModule = LightningModule
+    mk("torchvision")
+    mk("nowcasting_utils")
+    mk("nowcasting_utils.models")
+    mk("nowcasting_utils.models.base").register_model = lambda cls: cls
+    mk("nowcasting_utils.models.loss").get_loss = lambda name, **kw: torch.nn.MSELoss()
+
+
+def _np(d):
+    return {k: (v.detach().cpu().numpy() if isinstance(v, torch.Tensor) else np.asarray(v)) for k, v in d.items()}
+
+
+def _heat(module, scale, gen):
+    """'Hot' weights: scale default init so gates saturate, biases U(-1,1)."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("bias"):
+                p.copy_(torch.rand(p.shape, generator=gen) * 2 - 1)
+            else:
+                p.mul_(scale)
+
+
+def cell_cases():
+    from satflow.models.layers.ConvLSTM import ConvLSTMCell
+    from oracle import convlstm as O
+
+    specs = [  # name, Cin, hid, H, W, B, heat
+        ("a", 4, 8, 16, 16, 2, 1.0),
+        ("b", 12, 64, 16, 16, 1, 1.0),
+        ("odd", 3, 5, 7, 9, 2, 6.0),
+        ("hot", 12, 16, 20, 24, 2, 6.0),
+    ]
+    for name, cin, hid, H, W, B, heat in specs:
+        g = torch.Generator().manual_seed(1000 + len(name) + cin)
+        torch.manual_seed(7 + cin)
+        cell = ConvLSTMCell(cin, hid, (3, 3), True)
+        if heat != 1.0:
+            _heat(cell, heat, g)
+        x = torch.randn(B, cin, H, W, generator=g).requires_grad_()
+        h = (torch.randn(B, hid, H, W, generator=g) * 0.5).requires_grad_()
+        c = torch.randn(B, hid, H, W, generator=g).requires_grad_()
+        gh = torch.randn(B, hid, H, W, generator=g)
+        gc = torch.randn(B, hid, H, W, generator=g)
+        h1, c1 = cell(x, (h, c))
+        ((h1 * gh).sum() + (c1 * gc).sum()).backward()
+        out = dict(
+            x=x, h=h, c=c, weight=cell.conv.weight, bias=cell.conv.bias, h_out=h1, c_out=c1,
+            gh=gh, gc=gc, dx=x.grad, dh=h.grad, dc=c.grad, dweight=cell.conv.weight.grad, dbias=cell.conv.bias.grad,
+        )
+        # pin the oracle
+        oh, oc = O.convlstm_cell(x.detach(), h.detach(), c.detach(), cell.conv.weight.detach(), cell.conv.bias.detach())
+        assert torch.equal(oh, h1.detach()) and torch.equal(oc, c1.detach()), f"oracle cell mismatch {name}"
+        np.savez(f"{HERE}/convlstm_cell_{name}.npz", **_np(out))
+        print(f"cell {name}: ok  |h'|max={h1.abs().max():.3f} |dW|max={cell.conv.weight.grad.abs().max():.3f}")
+
+
+def model_cases():
+    from satflow.models.conv_lstm import EncoderDecoderConvLSTM
+    from oracle import convlstm as O
+
+    specs = [  # name, B, T, C, H, W, hid, out, forecast, heat, full
+        ("cfg1_h8", 2, 4, 4, 64, 64, 8, 1, 4, 1.0, True),
+        ("cfg1_h32_hot", 2, 4, 4, 64, 64, 32, 1, 4, 4.0, True),
+        ("rect_h16_o12", 1, 3, 5, 24, 40, 16, 12, 2, 5.0, True),
+        ("t1_f1", 2, 1, 4, 16, 16, 8, 3, 1, 5.0, True),
+        ("cfg1_h64_hot", 2, 4, 4, 64, 64, 64, 1, 4, 3.0, False),
+    ]
+    for name, B, T, C, H, W, hid, out_ch, fs, heat, full in specs:
+        g = torch.Generator().manual_seed(2000 + hid + fs)
+        torch.manual_seed(11 + hid)
+        m = EncoderDecoderConvLSTM(hidden_dim=hid, input_channels=C, out_channels=out_ch, forecast_steps=fs)
+        if heat != 1.0:
+            _heat(m.model, heat, g)
+        x = torch.randn(B, T, C, H, W, generator=g).requires_grad_()
+        y = torch.rand(B, fs, out_ch, H, W, generator=g)
+        cot = torch.randn(B, out_ch, fs, H, W, generator=g)
+        pred = m(x, fs)
+        assert pred.shape == (B, out_ch, fs, H, W)
+        # (1) raw forward + random-cotangent gradients
+        (pred * cot).sum().backward()
+        params = {k: v for k, v in m.model.state_dict().items()}
+        rec = dict(x=x, y=y, cot=cot, pred=pred, dx=x.grad, forecast_steps=fs)
+        for k, v in m.model.named_parameters():
+            rec[f"param.{k}"] = v
+            if full or k.endswith("bias") or k.startswith("decoder_CNN"):
+                rec[f"grad.{k}"] = v.grad
+        # (2) the Lightning training_step loss on (x, y) (conv_lstm.py:53-70)
+        loss = m.training_step((x.detach(), y), 0)
+        rec["train_loss"] = loss
+        # pin the oracle: forward and loss
+        o_pred = O.convlstm_forward(x.detach(), fs, params)
+        assert torch.equal(o_pred, pred.detach()), f"oracle model mismatch {name}"
+        o_loss, o_frames = O.training_loss(x.detach(), y, fs, params)
+        assert torch.allclose(o_loss, loss.detach(), rtol=1e-6, atol=0)
+        rec["frame_losses"] = o_frames
+        # bf16-autocast prediction for tolerance calibration
+        with torch.autocast("cpu", dtype=torch.bfloat16), torch.no_grad():
+            rec["pred_bf16_autocast"] = m(x.detach(), fs).float()
+        np.savez(f"{HERE}/convlstm_model_{name}.npz", **_np(rec))
+        err = (rec["pred_bf16_autocast"] - pred.detach()).abs().max()
+        print(f"model {name}: ok  pred in [{pred.min():.3f},{pred.max():.3f}]  |dx|max={x.grad.abs().max():.3g}  bf16 autocast max abs err={err:.2e}")
+    # registry/state_dict key pin
+    keys = list(EncoderDecoderConvLSTM(hidden_dim=8, input_channels=4).state_dict().keys())
+    with open(f"{HERE}/convlstm_state_dict_keys.txt", "w") as f:
+        f.write("\n".join(keys) + "\n")
+
+
+def layer_cases():
+    from satflow.models.layers.ConditionTime import ConditionTime
+    from satflow.models.layers.TimeDistributed import TimeDistributed
+    import importlib
+
+    utils = importlib.import_module("satflow.models.utils")
+    from oracle import metnet as M
+
+    g = torch.Generator().manual_seed(3)
+    x5 = torch.randn(2, 3, 4, 6, 5, generator=g)
+    ct5 = ConditionTime(7)(x5, 2)
+    assert torch.equal(M.condition_time(x5, 2, 7), ct5)
+    x4 = torch.randn(2, 6, 5, 4, generator=g)
+    ct4 = ConditionTime(5, ch_dim=3, num_dims=4)(x4, 4)
+    torch.manual_seed(5)
+    conv = torch.nn.Conv2d(4, 3, 3, padding=1)
+    td = TimeDistributed(conv)(x5)
+    td_low = TimeDistributed(conv, low_mem=True)(x5)
+    assert torch.equal(M.time_distributed(conv, x5), td)
+    s4 = torch.randn(2, 8, 6, 3, generator=g)
+    s2d = torch.from_numpy(utils.space_to_depth(s4.numpy(), spatial_block_size=2))
+    assert torch.equal(M.space_to_depth(s4, 2), s2d)
+    np.savez(
+        f"{HERE}/metnet_layers.npz",
+        **_np(dict(x5=x5, ct5=ct5, x4=x4, ct4=ct4, td_weight=conv.weight, td_bias=conv.bias, td=td, td_low=td_low, s4=s4, s2d=s2d)),
+    )
+    print("layers: ok (ConditionTime 5-D/4-D, TimeDistributed fast/low_mem, space_to_depth)")
+
+
+if __name__ == "__main__":
+    torch.set_num_threads(8)
+    _shim_reference()
+    cell_cases()
+    model_cases()
+    layer_cases()
