@@ -136,6 +136,16 @@ int sf_nhwc_to_nchw(sfTensor src, int32_t nb, int32_t nt, int32_t c, int32_t h, 
                     int64_t stride_b, int64_t stride_t, int64_t stride_c, int32_t dtype,
                     sfStream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Fused Adam step on flat fp32 buffers (p, g, m, v of n elements).  Arithmetic of torch.optim.Adam
+ * (no amsgrad / weight decay) as configured by the reference (satflow/models/conv_lstm.py:48-51,
+ * pl_metnet.py:70): m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+ * p -= lr/(1-b1^t) * m / (sqrt(v)/sqrt(1-b2^t) + eps).  g is multiplied by grad_scale first
+ * (1/world_size after a SUM all-reduce).  step counts from 1.
+ * ------------------------------------------------------------------------------------------- */
+int sf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
+                 float beta2, float eps, int32_t step, float grad_scale, sfStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -45,6 +45,7 @@ PROTOTYPES = {
         [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp],
     ),
     "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, C.c_float, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),
 }
 
@@ -97,6 +98,19 @@ def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0) -> sf
     assert t.is_contiguous() and t.dtype == torch.float32, (t.shape, t.dtype, t.is_contiguous())
     stride = t.shape[-1]
     return sfTensor(t.data_ptr() + 4 * offset, stride - offset if c is None else c, stride)
+
+
+# Parameter generation: bumped whenever parameters are rewritten through raw pointers (sf_adam_step),
+# which torch's per-tensor version counters cannot see.  Packed-weight caches key on it.
+_GENERATION = [0]
+
+
+def bump_generation() -> None:
+    _GENERATION[0] += 1
+
+
+def generation() -> int:
+    return _GENERATION[0]
 
 
 def cpad(c: int) -> int:

@@ -23,7 +23,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
-from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, require_device, sfTensor
+from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, generation, require_device, sfTensor
 from .base import LightningModule, get_loss, register_model
 from .layers.ConvLSTM import CellEngine, ConvLSTMCell
 
@@ -87,7 +87,7 @@ class Conv3x3Engine:
         self._key, self._packed = None, {}
 
     def packed(self, weight: Tensor, bias: Optional[Tensor], kind: str):
-        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version))
+        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), generation())
         if key != self._key:
             self._key, self._packed = key, {}
         if kind not in self._packed:

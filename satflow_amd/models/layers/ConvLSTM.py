@@ -19,7 +19,7 @@ import torch
 from torch import nn
 
 from ... import kernels as K
-from ..._hip import NULL, T, cpad, require_device, sfTensor
+from ..._hip import NULL, T, cpad, generation, require_device, sfTensor
 from ..utils import get_conv_layer
 
 Tensor = torch.Tensor
@@ -40,7 +40,7 @@ class CellEngine:
     # ---- packed weights (derived cache, refreshed when the parameters change) ----
     def _refresh(self) -> None:
         w, b = self.conv.weight, self.conv.bias
-        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), w.device)
+        key = (w.data_ptr(), w._version, None if b is None else (b.data_ptr(), b._version), w.device, generation())
         if key != self._key:
             self._packed = {}
             self._key = key

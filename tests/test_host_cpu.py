@@ -1,0 +1,98 @@
+"""CPU: host logic - C-ABI symbol table, registry/config surface, state_dict keys, GEMM index maps, loud failure."""
+import os
+import re
+
+import pytest
+import torch
+
+from conftest import GOLDEN, ROOT
+
+
+def test_abi_exports_every_declared_symbol():
+    from satflow_amd import _hip
+
+    header = open(os.path.join(ROOT, "include", "satflow_hip.h")).read()
+    declared = set(re.findall(r"\b(sf_[a-z0-9_]+)\s*\(", header))
+    assert declared, "no symbols parsed"
+    L = _hip.lib()
+    for name in declared:
+        assert hasattr(L, name), f"libsatflow_hip.so does not export {name}"
+    assert declared == set(_hip.PROTOTYPES), declared ^ set(_hip.PROTOTYPES)
+    assert L.sf_abi_version() == _hip.ABI_VERSION
+
+
+def test_registry_and_state_dict_keys():
+    from satflow_amd.models import EncoderDecoderConvLSTM, create_model, get_model, list_models
+
+    assert "EncoderDecoderConvLSTM" in list_models()
+    assert get_model("EncoderDecoderConvLSTM") is EncoderDecoderConvLSTM
+    for name in list_models():  # reference tests/test_models.py:64-76
+        create_model(name)
+    m = create_model("EncoderDecoderConvLSTM", pretrained=False, hidden_dim=8, input_channels=4)
+    want = open(os.path.join(GOLDEN, "convlstm_state_dict_keys.txt")).read().split()
+    assert list(m.state_dict().keys()) == want
+    assert m.model.encoder_1_convlstm.conv.weight.shape == (32, 12, 3, 3)
+    assert m.model.decoder_CNN.weight.shape == (1, 8, 1, 3, 3)
+    assert isinstance(m.configure_optimizers(), torch.optim.Adam)
+    with pytest.raises(KeyError):
+        get_model("nope")
+
+
+def test_configs_load_unchanged():
+    from satflow_amd.config import instantiate, load_config
+    from satflow_amd.models import EncoderDecoderConvLSTM
+
+    cfg = load_config(os.path.join(GOLDEN, "configs", "convlstm.yaml"))
+    m = instantiate(cfg)
+    assert isinstance(m, EncoderDecoderConvLSTM)
+    assert m.forecast_steps == 24 and m.lr == 1e-4 and m.model.input_channels == 17
+    cfg.pop("_target_")
+    assert EncoderDecoderConvLSTM(**cfg).hparams["hidden_dim"] == 64  # reference tests/test_models.py:43-45 pattern
+    with pytest.raises(NotImplementedError):
+        instantiate(load_config(os.path.join(GOLDEN, "configs", "convlstm_coord.yaml")))
+    with pytest.raises(ValueError):
+        EncoderDecoderConvLSTM(conv_type="bogus")
+
+
+def test_gemm_maps_cover_every_weight_once():
+    from satflow_amd import kernels as K
+
+    for cin, hid in [(4, 8), (12, 64), (3, 5), (64, 64), (17, 40)]:
+        f = K.lstm_fwd_map(cin, hid)
+        assert sorted(i for i in f.nmap if i >= 0) == list(range(4 * hid))
+        assert sorted(i for i in f.kmap if i >= 0) == list(range(cin + hid))
+        assert f.Np % 128 == 0 and f.Kp % 16 == 0
+        # all four gates of a hidden channel sit at the same column of consecutive 32-lane fragments
+        for nb in range(f.Np // 128):
+            for j in range(32):
+                col = [f.nmap[nb * 128 + g * 32 + j] for g in range(4)]
+                if col[0] >= 0:
+                    assert [c - col[0] for c in col] == [0, hid, 2 * hid, 3 * hid]
+        for need_dx in (False, True):
+            b = K.lstm_bwd_map(cin, hid, need_dx)
+            want = list(range(cin + hid)) if need_dx else list(range(cin, cin + hid))
+            assert sorted(i for i in b.nmap if i >= 0) == want
+            assert sorted(i for i in b.kmap if i >= 0) == list(range(4 * hid))
+            assert b.Np % (32 * b.nf) == 0
+    assert K.choose_nf(160) == 5 and K.choose_nf(256) == 4 and K.choose_nf(96) == 3 and K.choose_nf(16) == 1
+
+
+def test_cpu_input_fails_loudly():
+    from satflow_amd.models import ConvLSTM
+
+    net = ConvLSTM(4, 8, 1)
+    with pytest.raises(RuntimeError, match="no CPU implementation"):
+        net(torch.randn(1, 2, 4, 16, 16), 2)
+
+
+def test_product_never_imports_oracle():
+    import subprocess
+    import sys
+
+    code = "import sys; import satflow_amd.models, satflow_amd.kernels, satflow_amd.config; assert not any(m.split('.')[0]=='oracle' for m in sys.modules)"
+    subprocess.run([sys.executable, "-c", code], check=True, cwd=ROOT)
+    for dirpath, _, files in os.walk(os.path.join(ROOT, "satflow_amd")):
+        for f in files:
+            if f.endswith(".py"):
+                src = open(os.path.join(dirpath, f)).read()
+                assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
