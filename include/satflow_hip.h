@@ -47,11 +47,17 @@ enum {
 int sf_abi_version(void);
 const char* sf_last_error_string(void);
 
-/* A strided NHWC channel slice. */
+/* A strided NHWC channel slice.  Convolution INPUTS may additionally remap the image index:
+ * the kernel's image n reads image (n / idiv) % imod of this tensor (idiv <= 1: no division,
+ * imod == 0: no modulo).  That is how one tensor is broadcast over the lead-time axis of MetNet
+ * (frames shared by all lead times: imod = frames; one-hot lead-time planes: idiv = frames)
+ * without materialising the copies ConditionTime makes (satflow/models/layers/ConditionTime.py:22-33). */
 typedef struct {
   void* ptr;      /* first channel of pixel (0,0,0)            */
   int32_t c;      /* channels (padded; multiple of SF_CPAD for conv inputs) */
   int32_t stride; /* elements per pixel                        */
+  int32_t idiv;   /* image-index divisor (0/1 = none)          */
+  int32_t imod;   /* image-index modulus (0 = none)            */
 } sfTensor;
 
 /* ---------------------------------------------------------------------------------------------
@@ -145,6 +151,80 @@ int sf_nhwc_to_nchw(sfTensor src, int32_t nb, int32_t nt, int32_t c, int32_t h, 
  * ------------------------------------------------------------------------------------------- */
 int sf_adam_step(float* p, const float* g, float* m, float* v, int64_t n, float lr, float beta1,
                  float beta2, float eps, int32_t step, float grad_scale, sfStream stream);
+
+/* =============================================================================================
+ * MetNet stack.  The arithmetic lives in the un-vendored packages metnet>=0.0.3 / axial_attention
+ * (reference requirements.txt:18); the reference's call site is satflow/models/pl_metnet.py:46-59,65
+ * (LitMetNet -> metnet.MetNet).  Each entry names the upstream module it replaces.
+ * ============================================================================================= */
+
+/* MetNetPreprocessor(sat_channels, crop_size, use_space2depth=True, split_input=True):
+ * imgs[B][T][C][H][W] (H = W = 4*crop) -> frames j = t*B + b of [crop][crop][out.c]:
+ * lanes [0,4*sat) PixelUnshuffle(2) (lane c*4+dh*2+dw) centre-cropped, [4*sat,8*sat) its 2x2 mean,
+ * then the C-sat other channels (2x2 mean of the raw image, centre-cropped); pad lanes zero. */
+int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C, int32_t sat,
+                             int32_t H, int32_t W, int32_t crop, sfTensor out, int32_t dtype,
+                             sfStream stream);
+
+/* nn.MaxPool2d(2, stride 2) of the DownSampler, forward / backward (argmax recomputed from `in`).
+ * perm_l > 0: images are reordered on the pooled side, input image (l*perm_t + t)*B + b <->
+ * pooled image (t*perm_l + l)*B + b (lead-time-major encoder order -> time-major ConvGRU order). */
+int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l,
+                    int32_t perm_t, int32_t dtype, sfStream stream);
+int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din,
+                    int32_t perm_l, int32_t perm_t, int32_t dtype, sfStream stream);
+
+/* nn.BatchNorm2d of the DownSampler.  Training mode: `groups` independent batches of
+ * pix_per_group pixels each (one per lead time: the reference calls the encoder once per lead
+ * time, so statistics are per call), biased variance, running stats updated group after group with
+ * `momentum` (unbiased variance).  Scratch: sums [groups][2][C] doubles; mean/rstd/scale/shift
+ * [groups][C] floats (mean, rstd are what the backward needs).  creal = real channels of gamma/beta. */
+int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal,
+                           const float* gamma, const float* beta, float eps, float momentum,
+                           float* running_mean, float* running_var, float* mean, float* rstd,
+                           float* scale, float* shift, double* sums, sfTensor y, int32_t dtype,
+                           sfStream stream);
+int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float* gamma,
+                          const float* beta, float eps, const float* running_mean,
+                          const float* running_var, float* scale, float* shift, sfTensor y,
+                          int32_t dtype, sfStream stream);
+int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups,
+                           int32_t creal, const float* gamma, const float* mean, const float* rstd,
+                           double* sums, sfTensor dx, float* dgamma, float* dbeta, int32_t dtype,
+                           sfStream stream);
+
+/* ConvGRUCell step, recurrent half:  given gx = conv_x(x_t) = [z_x | r_x | n_x] (+ their biases; one
+ * sf_conv3x3_fwd over all timesteps at once) and h_prev (NULL ptr = zero state):
+ *   [z_h | r_h | h2] = conv3x3(h_prev) (+ bias on h2);  z = sig(z_x+z_h), r = sig(r_x+r_h),
+ *   n = tanh(n_x + r*h2),  h' = (1-z)*n + z*h_prev.   gates (nullable) <- [z | r | n | h2].
+ * wpacked: GRU nmap (32 hidden channels x 3 maps per N block, nf == 3). */
+int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int32_t w,
+                        const void* wpacked, const float* bias_packed, int32_t hidp, sfTensor h_out,
+                        sfTensor gates, int32_t dtype, sfStream stream);
+/* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
+ * dh_direct = dh*z (nullable). */
+int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor gates, sfTensor h_prev,
+                         int64_t pixels, int32_t hidp, sfTensor dgx, sfTensor dgh,
+                         sfTensor dh_direct, int32_t dtype, sfStream stream);
+
+/* Pointwise linear map over pixels (axial-attention to_q/to_kv/to_out, MetNet 1x1 head):
+ *   y[p][n] = sum_k x[p][k]*W[n][k] + bias[n],  W row-major [N][x.c];  lanes N..y.c-1 are zeroed.
+ * bwd_weight: dW[n][k] = sum_p dy[p][n]*x[p][k], db[n] = sum_p dy[p][n] (db nullable). */
+int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const float* bias, sfTensor y,
+                  int32_t dtype, sfStream stream);
+size_t sf_linear_bwd_weight_workspace_bytes(int32_t N, int32_t K, int64_t rows);
+int sf_linear_bwd_weight(sfTensor dy, int32_t N, sfTensor x, int64_t rows, float* dW, float* db,
+                         void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream);
+
+/* AxialAttention core: qkv [img][h][w][6*hidp] = [q0|k0|v0|q1|k1|v1] (axis 0 attends along h, axis 1
+ * along w; channel = head*(hid/heads)+j) -> att [..][2*hidp] = [axis0 | axis1], softmax(q k^T e^-1/2) v
+ * per head.  bwd: datt [..][2*hidp] -> dqkv [..][6*hidp]. */
+int sf_axial_attention_core_fwd(sfTensor qkv, int64_t nimg, int32_t h, int32_t w, int32_t hid,
+                                int32_t hidp, int32_t heads, sfTensor att, int32_t dtype,
+                                sfStream stream);
+int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32_t h, int32_t w,
+                                int32_t hid, int32_t hidp, int32_t heads, sfTensor dqkv,
+                                int32_t dtype, sfStream stream);
 
 #ifdef __cplusplus
 }

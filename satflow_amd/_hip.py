@@ -20,7 +20,7 @@ ABI_VERSION = 1
 
 
 class sfTensor(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32), ("idiv", C.c_int32), ("imod", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/satflow_hip.h one to one
@@ -45,6 +45,25 @@ PROTOTYPES = {
         [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp],
     ),
     "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_metnet_preprocess_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_maxpool2_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, _i32, _vp]),
+    "sf_maxpool2_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, _i32, _vp]),
+    "sf_batchnorm_train_fwd": (
+        C.c_int,
+        [sfTensor, _i64, _i32, _i32, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, sfTensor, _i32, _vp],
+    ),
+    "sf_batchnorm_eval_fwd": (C.c_int, [sfTensor, _i64, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, sfTensor, _i32, _vp]),
+    "sf_batchnorm_train_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),
+    "sf_convgru_step_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
+    "sf_convgru_bwd_gates": (
+        C.c_int,
+        [sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
+    ),
+    "sf_linear_fwd": (C.c_int, [sfTensor, _i64, _vp, _i32, _vp, sfTensor, _i32, _vp]),
+    "sf_linear_bwd_weight_workspace_bytes": (_sz, [_i32, _i32, _i64]),
+    "sf_linear_bwd_weight": (C.c_int, [sfTensor, _i32, sfTensor, _i64, _vp, _vp, _vp, _sz, _i32, _vp]),
+    "sf_axial_attention_core_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_axial_attention_core_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, C.c_float, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),
 }
@@ -88,16 +107,18 @@ def require_device(t: torch.Tensor, name: str) -> None:
         )
 
 
-NULL = sfTensor(None, 0, 0)
+NULL = sfTensor(None, 0, 0, 0, 0)
 
 
-def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0) -> sfTensor:
-    """Describe a channels-last tensor ``[..., C]`` (or a channel slice ``offset:offset+c`` of it)."""
+def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0, idiv: int = 0, imod: int = 0) -> sfTensor:
+    """Describe a channels-last tensor ``[..., C]`` (or a channel slice ``offset:offset+c`` of it).
+
+    ``idiv`` / ``imod``: image-index remap for convolution inputs (see ``sfTensor`` in the header)."""
     if t is None:
-        return sfTensor(None, c or 0, 0)
+        return sfTensor(None, c or 0, 0, 0, 0)
     assert t.is_contiguous() and t.dtype == torch.float32, (t.shape, t.dtype, t.is_contiguous())
     stride = t.shape[-1]
-    return sfTensor(t.data_ptr() + 4 * offset, stride - offset if c is None else c, stride)
+    return sfTensor(t.data_ptr() + 4 * offset, stride - offset if c is None else c, stride, idiv, imod)
 
 
 # Parameter generation: bumped whenever parameters are rewritten through raw pointers (sf_adam_step),

@@ -1,0 +1,173 @@
+// Axial attention core (lucidrains AxialAttention(dim, dim_index=1, heads=8, num_dimensions=2) as used
+// by metnet.MetNet.temporal_agg; reference call site satflow/models/pl_metnet.py:46-59).
+//
+// Input  qkv [img][H][W][6*hidp] = [q0|k0|v0|q1|k1|v1]: projections for axis 0 (attend along H, one
+//        sequence per column) and axis 1 (along W, one sequence per row); channel = head*e + j.
+// Output att [img][H][W][2*hidp] = [axis-0 result | axis-1 result] (heads merged); the caller's
+// out-projection over the concatenation IS the sum of the two axes' to_out (sum_axial_out).
+//
+// Sequences are <= 32 long and e = hid/heads is tiny, so a whole softmax row lives in one lane's
+// registers: one thread per (pixel, axis, head); no LDS, no cross-lane reduction, no atomics.  The
+// backward is gather-form as well (each thread recomputes the softmax rows of its line), so it is
+// deterministic.  Work is ~10 MFLOP per image: latency-bound by construction.
+#include "sf_common.h"
+
+namespace {
+
+constexpr int MAXL = 32;  // max sequence length along an axis
+constexpr int MAXE = 16;  // max head dim
+
+struct AttnParams {
+  const float* qkv; int qs;
+  float* att; int as;
+  const float* datt; int das;
+  float* dqkv; int dqs;
+  long long nimg; int H, W, hid, hidp, heads;
+  float scale;
+};
+
+struct Line { long long base; int len, step, pos; };  // pixel index = base + i*step, own position pos
+
+__device__ __forceinline__ Line line_of(long long img, int y, int x, int axis, int H, int W) {
+  Line l;
+  if (axis == 0) { l.base = img * H * W + x; l.len = H; l.step = W; l.pos = y; }
+  else           { l.base = (img * H + y) * (long long)W; l.len = W; l.step = 1; l.pos = x; }
+  return l;
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_kernel(const AttnParams p) {
+  const int e = p.hid / p.heads;
+  const long long total = p.nimg * p.H * p.W * 2 * p.heads;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    // head fastest, then axis, then pixel: neighbouring lanes share the line's k/v cache lines
+    const int head = idx % p.heads;
+    const int axis = (idx / p.heads) % 2;
+    const long long pix = idx / (2 * p.heads);
+    const int x = pix % p.W, y = (pix / p.W) % p.H;
+    const long long img = pix / ((long long)p.W * p.H);
+    const Line ln = line_of(img, y, x, axis, p.H, p.W);
+    const int off = axis * 3 * p.hidp + head * e;
+    float q[MAXE];
+    for (int j = 0; j < e; ++j) q[j] = p.qkv[pix * p.qs + off + j] * p.scale;
+    float s[MAXL];
+    float m = -INFINITY;
+    for (int i = 0; i < ln.len; ++i) {
+      const float* k = p.qkv + (ln.base + (long long)i * ln.step) * p.qs + off + p.hidp;
+      float d = 0.f;
+      for (int j = 0; j < e; ++j) d += q[j] * k[j];
+      s[i] = d; m = fmaxf(m, d);
+    }
+    float z = 0.f;
+    for (int i = 0; i < ln.len; ++i) { s[i] = expf(s[i] - m); z += s[i]; }
+    const float inv = 1.f / z;
+    float o[MAXE];
+    for (int j = 0; j < e; ++j) o[j] = 0.f;
+    for (int i = 0; i < ln.len; ++i) {
+      const float* v = p.qkv + (ln.base + (long long)i * ln.step) * p.qs + off + 2 * p.hidp;
+      const float w = s[i] * inv;
+      for (int j = 0; j < e; ++j) o[j] += w * v[j];
+    }
+    float* out = p.att + pix * p.as + axis * p.hidp + head * e;
+    for (int j = 0; j < e; ++j) out[j] = o[j];
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
+  const int e = p.hid / p.heads;
+  const long long total = p.nimg * p.H * p.W * 2 * p.heads;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int head = idx % p.heads;
+    const int axis = (idx / p.heads) % 2;
+    const long long pix = idx / (2 * p.heads);
+    const int x = pix % p.W, y = (pix / p.W) % p.H;
+    const long long img = pix / ((long long)p.W * p.H);
+    const Line ln = line_of(img, y, x, axis, p.H, p.W);
+    const int off = axis * 3 * p.hidp + head * e;
+    const int doff = axis * p.hidp + head * e;
+    float dq[MAXE], dk[MAXE], dv[MAXE];
+    for (int j = 0; j < e; ++j) dq[j] = dk[j] = dv[j] = 0.f;
+    // every query row r of this line: its softmax, then the pieces that land on this pixel
+    for (int rq = 0; rq < ln.len; ++rq) {
+      const long long rp = ln.base + (long long)rq * ln.step;
+      float q[MAXE], g[MAXE];
+      for (int j = 0; j < e; ++j) { q[j] = p.qkv[rp * p.qs + off + j]; g[j] = p.datt[rp * p.das + doff + j]; }
+      float s[MAXL], dP[MAXL];
+      float m = -INFINITY;
+      for (int i = 0; i < ln.len; ++i) {
+        const float* kv = p.qkv + (ln.base + (long long)i * ln.step) * p.qs + off;
+        float d = 0.f, dp = 0.f;
+        for (int j = 0; j < e; ++j) { d += q[j] * kv[p.hidp + j]; dp += g[j] * kv[2 * p.hidp + j]; }
+        s[i] = d * p.scale; dP[i] = dp; m = fmaxf(m, s[i]);
+      }
+      float z = 0.f;
+      for (int i = 0; i < ln.len; ++i) { s[i] = expf(s[i] - m); z += s[i]; }
+      const float inv = 1.f / z;
+      float spd = 0.f;
+      for (int i = 0; i < ln.len; ++i) { s[i] *= inv; spd += s[i] * dP[i]; }
+      // as key/value position `pos` of query row rq
+      const float pj = s[ln.pos];
+      const float dsj = pj * (dP[ln.pos] - spd) * p.scale;
+      for (int j = 0; j < e; ++j) { dv[j] += pj * g[j]; dk[j] += dsj * q[j]; }
+      // as the query itself
+      if (rq == ln.pos) {
+        for (int i = 0; i < ln.len; ++i) {
+          const float ds = s[i] * (dP[i] - spd) * p.scale;
+          const float* k = p.qkv + (ln.base + (long long)i * ln.step) * p.qs + off + p.hidp;
+          for (int j = 0; j < e; ++j) dq[j] += ds * k[j];
+        }
+      }
+    }
+    float* d = p.dqkv + pix * p.dqs + off;
+    for (int j = 0; j < e; ++j) { d[j] = dq[j]; d[p.hidp + j] = dk[j]; d[2 * p.hidp + j] = dv[j]; }
+  }
+}
+
+int check(const AttnParams& p, sfTensor qkv, int c_other, const char* what) {
+  if (p.hid % p.heads != 0 || p.hid / p.heads > MAXE || p.H > MAXL || p.W > MAXL || p.hid > p.hidp || qkv.c < 6 * p.hidp || c_other < 2 * p.hidp) {
+    sf_set_error("%s: unsupported shape hid=%d heads=%d H=%d W=%d (need hid%%heads==0, hid/heads<=%d, H,W<=%d)", what, p.hid, p.heads, p.H,
+                 p.W, MAXE, MAXL);
+    return 1;
+  }
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_axial_attention_core_fwd(sfTensor qkv, int64_t nimg, int32_t h, int32_t w, int32_t hid, int32_t hidp, int32_t heads, sfTensor att,
+                                int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_axial_attention_core_fwd: dtype %d not built", dtype);
+  AttnParams p{};
+  p.qkv = (const float*)qkv.ptr; p.qs = qkv.stride; p.att = (float*)att.ptr; p.as = att.stride;
+  p.nimg = nimg; p.H = h; p.W = w; p.hid = hid; p.hidp = hidp; p.heads = heads;
+  if (check(p, qkv, att.c, "axial_attention fwd")) return 1;
+  p.scale = 1.0f / sqrtf((float)(hid / heads));
+  const long long total = nimg * h * w * 2 * heads;
+  if (total == 0) return 0;
+  // pad lanes of att (hid..hidp) are never written by the kernel: zero them once
+  if (hid < hidp) SF_REQUIRE(hipMemsetAsync(att.ptr, 0, (size_t)nimg * h * w * att.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
+  hipLaunchKernelGGL(attn_fwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  SF_CHECK_LAUNCH("axial_attention_fwd");
+  return 0;
+}
+
+int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32_t h, int32_t w, int32_t hid, int32_t hidp, int32_t heads,
+                                sfTensor dqkv, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_axial_attention_core_bwd: dtype %d not built", dtype);
+  AttnParams p{};
+  p.qkv = (const float*)qkv.ptr; p.qs = qkv.stride; p.datt = (const float*)datt.ptr; p.das = datt.stride;
+  p.dqkv = (float*)dqkv.ptr; p.dqs = dqkv.stride;
+  p.nimg = nimg; p.H = h; p.W = w; p.hid = hid; p.hidp = hidp; p.heads = heads;
+  if (check(p, qkv, datt.c, "axial_attention bwd")) return 1;
+  SF_REQUIRE(dqkv.c >= 6 * hidp, "axial_attention bwd: dqkv lanes");
+  p.scale = 1.0f / sqrtf((float)(hid / heads));
+  const long long total = nimg * h * w * 2 * heads;
+  if (total == 0) return 0;
+  if (hid < hidp) SF_REQUIRE(hipMemsetAsync(dqkv.ptr, 0, (size_t)nimg * h * w * dqkv.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
+  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  SF_CHECK_LAUNCH("axial_attention_bwd");
+  return 0;
+}
+
+}  // extern "C"

@@ -23,11 +23,12 @@ constexpr int HALO = TILE + 2;    // staged tile edge
 constexpr int KC = 16;            // input channels per K chunk
 constexpr int PITCH = KC + 4;     // LDS floats per pixel / per weight row (80 B)
 
-enum { EPI_LINEAR = 0, EPI_SIGMOID = 1, EPI_LSTM = 2 };
+enum { EPI_LINEAR = 0, EPI_SIGMOID = 1, EPI_LSTM = 2, EPI_GRU = 3 };
 
 struct ConvParams {
   const float* src0; const float* src1;
   int c0, c1, s0, s1;
+  int idiv0, imod0, idiv1, imod1;  // image-index remap of the sources (see sfTensor)
   int N, H, W, tiles_x, tiles_y;
   const float* wp;     // [nblk][chunks][9][32*NF][16]
   const float* bias;   // [nblk*32*NF] or null
@@ -40,6 +41,9 @@ struct ConvParams {
   float* h_out; int hout_s;
   float* gates; int gates_s;
   int hidp;
+  // gru epilogue (h_out / gates / hidp shared with lstm): precomputed x-part [z|r|n] and previous state
+  const float* gx; int gx_s;
+  const float* h_prev; int hprev_s;
 };
 
 template <int NF, int EPI>
@@ -106,8 +110,9 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvParams p)
       // ---- stage the halo tile of this channel chunk ----
       const int ci = s / 9;
       const float* src; int cbase, stride;
-      if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; }
-      else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; }
+      int ns;
+      if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
+      else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
       __syncthreads();  // everyone is done reading the previous chunk's tile / weight buffers
       for (int pc = tid; pc < HALO * HALO * 4; pc += 256) {
         const int pix = pc >> 2, piece = pc & 3;
@@ -115,7 +120,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvParams p)
         const int gy = y0 + iy - 1, gx = x0 + ix - 1;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-          v = *reinterpret_cast<const f32x4*>(src + ((size_t)(n * p.H + gy) * p.W + gx) * stride + cbase + piece * 4);
+          v = *reinterpret_cast<const f32x4*>(src + ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + piece * 4);
         *reinterpret_cast<f32x4*>(lds_in + pix * PITCH + piece * 4) = v;
       }
     }
@@ -173,6 +178,33 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvParams p)
             if (p.gates) {
               float* gp = p.gates + pix * p.gates_s + hc;
               gp[0] = gi; gp[p.hidp] = gf; gp[2 * p.hidp] = go; gp[3 * p.hidp] = gg;
+            }
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GRU) {
+    static_assert(NF == 3, "GRU epilogue: z, r and the candidate's h-part in one wave");
+    const int hc = nb * 32 + r;
+    if (hc < p.hidp) {
+      const float b2 = p.bias ? p.bias[nb * NB + 64 + r] : 0.f;
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rr = frag_row(reg, kh);
+          const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
+          if (py < p.H && px < p.W) {
+            const size_t pix = (size_t)(n * p.H + py) * p.W + px;
+            const float* gx = p.gx + pix * p.gx_s + hc;
+            const float z = sf_sigmoid(acc[mf][0][reg] + gx[0]);
+            const float rg = sf_sigmoid(acc[mf][1][reg] + gx[p.hidp]);
+            const float h2 = acc[mf][2][reg] + b2;
+            const float cand = tanhf(gx[2 * p.hidp] + rg * h2);
+            const float hp = p.h_prev ? p.h_prev[pix * p.hprev_s + hc] : 0.f;
+            p.h_out[pix * p.hout_s + hc] = (1.f - z) * cand + z * hp;
+            if (p.gates) {
+              float* gp = p.gates + pix * p.gates_s + hc;
+              gp[0] = z; gp[p.hidp] = rg; gp[2 * p.hidp] = cand; gp[3 * p.hidp] = h2;
             }
           }
         }
@@ -243,6 +275,11 @@ int launch_conv(const ConvParams& p, int nf, int nblk, hipStream_t st) {
   return 0;
 }
 
+void set_remap(ConvParams& p, const sfTensor& a, const sfTensor& b) {
+  p.idiv0 = a.idiv > 1 ? a.idiv : 1; p.imod0 = a.imod > 0 ? a.imod : 0;
+  p.idiv1 = b.idiv > 1 ? b.idiv : 1; p.imod1 = b.imod > 0 ? b.imod : 0;
+}
+
 int check_src(const sfTensor& t, const char* name) {
   if (t.c % SF_CPAD != 0 || t.c < 0) { sf_set_error("%s: channels %d not a multiple of %d", name, t.c, SF_CPAD); return 1; }
   if (t.ptr && (t.stride % 4 != 0 || ((uintptr_t)t.ptr & 15))) { sf_set_error("%s: needs 16-byte aligned pixels (stride %d)", name, t.stride); return 1; }
@@ -278,6 +315,7 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
   ConvParams p{};
   p.src0 = (const float*)src0.ptr; p.src1 = (const float*)src1.ptr;
   p.c0 = src0.c; p.c1 = src1.c; p.s0 = src0.stride; p.s1 = src1.stride;
+  set_remap(p, src0, src1);
   p.N = n; p.H = h; p.W = w; p.tiles_x = (w + TILE - 1) / TILE; p.tiles_y = (h + TILE - 1) / TILE;
   p.wp = (const float*)wpacked; p.bias = bias_packed; p.chunks_total = (src0.c + src1.c) / KC;
   p.out = (float*)out.ptr; p.out_c = out.c; p.out_s = out.stride;
@@ -298,6 +336,7 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   ConvParams p{};
   p.src0 = (const float*)x.ptr; p.src1 = (const float*)h_prev.ptr;
   p.c0 = x.c; p.c1 = h_prev.c; p.s0 = x.stride; p.s1 = h_prev.stride;
+  set_remap(p, x, h_prev);
   p.N = n; p.H = h; p.W = w; p.tiles_x = (w + TILE - 1) / TILE; p.tiles_y = (h + TILE - 1) / TILE;
   p.wp = (const float*)wpacked; p.bias = bias_packed; p.chunks_total = (x.c + h_prev.c) / KC;
   p.c_prev = (const float*)c_prev.ptr; p.cprev_s = c_prev.stride;
@@ -309,6 +348,30 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
   hipLaunchKernelGGL((conv3x3_f32_kernel<4, EPI_LSTM>), grid, block, 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("convlstm_cell_fwd");
+  return 0;
+}
+
+int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int32_t w, const void* wpacked,
+                        const float* bias_packed, int32_t hidp, sfTensor h_out, sfTensor gates, int32_t dtype,
+                        sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_convgru_step_fwd: dtype %d not built", dtype);
+  if (check_src(h_prev, "convgru h_prev")) return 1;
+  SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp && gx.c == 3 * hidp, "convgru: hidp=%d h_prev.c=%d gx.c=%d", hidp, h_prev.c, gx.c);
+  SF_REQUIRE(gx.ptr && h_out.ptr, "convgru: gx and h_out must be non-null");
+  ConvParams p{};
+  p.src0 = (const float*)h_prev.ptr; p.c0 = h_prev.c; p.s0 = h_prev.stride;
+  p.idiv0 = p.idiv1 = 1;
+  p.N = n; p.H = h; p.W = w; p.tiles_x = (w + TILE - 1) / TILE; p.tiles_y = (h + TILE - 1) / TILE;
+  p.wp = (const float*)wpacked; p.bias = bias_packed; p.chunks_total = h_prev.c / KC;
+  p.h_out = (float*)h_out.ptr; p.hout_s = h_out.stride;
+  p.gates = (float*)gates.ptr; p.gates_s = gates.stride;
+  p.gx = (const float*)gx.ptr; p.gx_s = gx.stride;
+  p.h_prev = (const float*)h_prev.ptr; p.hprev_s = h_prev.stride;
+  p.hidp = hidp;
+  const int nblk = (hidp + 31) / 32;
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
+  hipLaunchKernelGGL((conv3x3_f32_kernel<3, EPI_GRU>), grid, block, 0, (hipStream_t)stream, p);
+  SF_CHECK_LAUNCH("convgru_step_fwd");
   return 0;
 }
 

@@ -25,6 +25,7 @@ constexpr int PB = CI_T;                           // LDS floats per input pixel
 
 struct WgradParams {
   const float* src0; const float* src1; int c0, c1, s0, s1;
+  int idiv0, imod0, idiv1, imod1;
   const float* dout; int dc, ds;
   int N, H, W, tiles_x, tiles_y, ntiles, KS;
   float* partial; float* partial_db;
@@ -72,9 +73,13 @@ __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) 
       const int kc = cit * CI_T + c4;  // channel in the concatenated padded K space
       f32x4 v = {0.f, 0.f, 0.f, 0.f};
       if (gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-        const size_t gp = (size_t)(n * p.H + gy) * p.W + gx;
-        if (kc < p.c0) v = *reinterpret_cast<const f32x4*>(p.src0 + gp * p.s0 + kc);
-        else if (kc - p.c0 < p.c1) v = *reinterpret_cast<const f32x4*>(p.src1 + gp * p.s1 + (kc - p.c0));
+        if (kc < p.c0) {
+          int ns = n / p.idiv0; if (p.imod0) ns %= p.imod0;
+          v = *reinterpret_cast<const f32x4*>(p.src0 + ((size_t)(ns * p.H + gy) * p.W + gx) * p.s0 + kc);
+        } else if (kc - p.c0 < p.c1) {
+          int ns = n / p.idiv1; if (p.imod1) ns %= p.imod1;
+          v = *reinterpret_cast<const f32x4*>(p.src1 + ((size_t)(ns * p.H + gy) * p.W + gx) * p.s1 + (kc - p.c0));
+        }
       }
       *reinterpret_cast<f32x4*>(lds_b + pix * PB + c4) = v;
     }
@@ -178,6 +183,8 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   WgradParams p{};
   p.src0 = (const float*)src0.ptr; p.src1 = (const float*)src1.ptr;
   p.c0 = src0.c; p.c1 = src1.c; p.s0 = src0.stride; p.s1 = src1.stride;
+  p.idiv0 = src0.idiv > 1 ? src0.idiv : 1; p.imod0 = src0.imod > 0 ? src0.imod : 0;
+  p.idiv1 = src1.idiv > 1 ? src1.idiv : 1; p.imod1 = src1.imod > 0 ? src1.imod : 0;
   p.dout = (const float*)dout.ptr; p.dc = dout.c; p.ds = dout.stride;
   p.N = n; p.H = h; p.W = w; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.KS = pl.KS;
   p.NpT = pl.cot * CO_T; p.KpT = pl.cit * CI_T;

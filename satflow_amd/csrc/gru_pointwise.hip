@@ -1,0 +1,84 @@
+// Pointwise half of the ConvGRU cell backward (upstream metnet ConvGRUCell):
+//   h' = (1-z)*n + z*h,  n = tanh(gx_n + r*h2),  z = sigmoid(gx_z + hz), r = sigmoid(gx_r + hr)
+// From dh' and the saved (z, r, n, h2) produce the gradient wrt the pre-activations:
+//   dgx = [da_z | da_r | da_n]   (x-part conv outputs; also the h-part's z/r pre-activations)
+//   dgh = [da_z | da_r | dh2]    (h-part conv outputs)
+//   dh_direct = dh' * z          (the blend's direct path to the previous state)
+// HBM-bound streaming kernel, 16-byte accesses.
+#include "sf_common.h"
+
+namespace {
+
+struct GruBwdParams {
+  const float* dh0; const float* dh1; const float* dh2; int s0, s1, s2;
+  const float* gates; int s_g;
+  const float* h_prev; int s_hp;
+  float* dgx; int s_dgx;
+  float* dgh; int s_dgh;
+  float* dh_direct; int s_dd;
+  long long pixels; int hidp;
+};
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+__global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p) {
+  const int q = p.hidp >> 2;
+  const long long total = p.pixels * q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long pix = idx / q;
+    const int c = (int)(idx - pix * q) * 4;
+    f32x4 dh = ld4(p.dh0 + pix * p.s0 + c);
+    if (p.dh1) dh += ld4(p.dh1 + pix * p.s1 + c);
+    if (p.dh2) dh += ld4(p.dh2 + pix * p.s2 + c);
+    const float* g = p.gates + pix * p.s_g + c;
+    const f32x4 z = ld4(g), r = ld4(g + p.hidp), n = ld4(g + 2 * p.hidp), h2 = ld4(g + 3 * p.hidp);
+    f32x4 hp = {0.f, 0.f, 0.f, 0.f};
+    if (p.h_prev) hp = ld4(p.h_prev + pix * p.s_hp + c);
+    f32x4 az, ar, an, d2, dd;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float dn = dh[j] * (1.f - z[j]);
+      const float dz = dh[j] * (hp[j] - n[j]);
+      an[j] = dn * (1.f - n[j] * n[j]);
+      ar[j] = an[j] * h2[j] * r[j] * (1.f - r[j]);
+      d2[j] = an[j] * r[j];
+      az[j] = dz * z[j] * (1.f - z[j]);
+      dd[j] = dh[j] * z[j];
+    }
+    float* a = p.dgx + pix * p.s_dgx + c;
+    st4(a, az); st4(a + p.hidp, ar); st4(a + 2 * p.hidp, an);
+    float* b = p.dgh + pix * p.s_dgh + c;
+    st4(b, az); st4(b + p.hidp, ar); st4(b + 2 * p.hidp, d2);
+    if (p.dh_direct) st4(p.dh_direct + pix * p.s_dd + c, dd);
+  }
+}
+
+bool ok4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0); }
+
+}  // namespace
+
+extern "C" int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor gates, sfTensor h_prev, int64_t pixels,
+                                    int32_t hidp, sfTensor dgx, sfTensor dgh, sfTensor dh_direct, int32_t dtype,
+                                    sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_convgru_bwd_gates: dtype %d not built", dtype);
+  SF_REQUIRE(hidp % SF_CPAD == 0 && hidp > 0, "gru bwd_gates: hidp=%d", hidp);
+  SF_REQUIRE(dh0.ptr && gates.ptr && dgx.ptr && dgh.ptr, "gru bwd_gates: dh0, gates, dgx, dgh must be non-null");
+  SF_REQUIRE(ok4(dh0) && ok4(dh1) && ok4(dh2) && ok4(gates) && ok4(h_prev) && ok4(dgx) && ok4(dgh) && ok4(dh_direct),
+             "gru bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0");
+  GruBwdParams p{};
+  p.dh0 = (const float*)dh0.ptr; p.dh1 = (const float*)dh1.ptr; p.dh2 = (const float*)dh2.ptr;
+  p.s0 = dh0.stride; p.s1 = dh1.stride; p.s2 = dh2.stride;
+  p.gates = (const float*)gates.ptr; p.s_g = gates.stride;
+  p.h_prev = (const float*)h_prev.ptr; p.s_hp = h_prev.stride;
+  p.dgx = (float*)dgx.ptr; p.s_dgx = dgx.stride;
+  p.dgh = (float*)dgh.ptr; p.s_dgh = dgh.stride;
+  p.dh_direct = (float*)dh_direct.ptr; p.s_dd = dh_direct.stride;
+  p.pixels = pixels; p.hidp = hidp;
+  const long long total = pixels * (hidp / 4);
+  if (total == 0) return 0;
+  const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
+  hipLaunchKernelGGL(gru_bwd_gates_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  SF_CHECK_LAUNCH("gru_bwd_gates");
+  return 0;
+}

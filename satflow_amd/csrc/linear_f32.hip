@@ -1,0 +1,188 @@
+// Pointwise (1x1) linear maps over NHWC pixels on the fp32 matrix cores: the q/kv/out projections
+// of the axial attention (lucidrains SelfAttention.to_q/to_kv/to_out) and
+// MetNet's Conv2d(hid, out, 1x1) head (A.6; reference call site satflow/models/pl_metnet.py:46-59).
+//
+//   fwd :  y[p][n]  = sum_k x[p][k] * W[n][k] + b[n]           (also the input gradient, with W^T)
+//   wgrad: dW[n][k] = sum_p dy[p][n] * x[p][k],  db[n] = sum_p dy[p][n]
+//
+// These are tall-skinny GEMMs (P ~ 25k pixels, N, K <= 384): no LDS staging; every lane loads its
+// MFMA operand element(s) straight from global memory (16-byte loads in fwd, coalesced 128-byte
+// rows in wgrad), weights stay L2/L1 resident.  v_mfma_f32_32x32x2_f32, exact fp32.
+#include "sf_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+
+template <int NF>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict__ x, int xs, long long rows, int K,
+                                                         const float* __restrict__ W, int N, const float* __restrict__ bias,
+                                                         float* __restrict__ y, int ys, int yc) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh = lane >> 5;
+  const long long row0 = (long long)blockIdx.x * 128 + wave * 32;
+  const int n0 = blockIdx.y * 32 * NF;
+  f32x16 acc[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+  const long long row = row0 + r;
+  const float* xr = x + row * xs + kh * 4;
+  for (int q = 0; q < K / 8; ++q) {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    if (row < rows) a = ld4(xr + q * 8);
+    f32x4 b[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int n = n0 + nf * 32 + r;
+      b[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
+      if (n < N) b[nf] = ld4(W + (long long)n * K + q * 8 + kh * 4);
+    }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[nf][j], acc[nf], 0, 0, 0);
+  }
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int n = n0 + nf * 32 + r;
+    if (n < yc) {
+      const float bv = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const long long orow = row0 + frag_row(reg, kh);
+        if (orow < rows) y[orow * ys + n] = acc[nf][reg] + bv;
+      }
+    }
+  }
+}
+
+// dW partial: grid (KS, ceil(N/128)); wave w owns n rows 32w..32w+31 of the block's 128, all K/32 column fragments.
+template <int KF>
+__global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, int dys, int N, const float* __restrict__ x,
+                                                           int xs, int K, long long rows, int KS, float* __restrict__ partial,
+                                                           float* __restrict__ partial_db, int Npad) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh = lane >> 5;
+  const int n = blockIdx.y * 128 + wave * 32 + r;
+  f32x16 acc[KF];
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[kf][i] = 0.f;
+  float asum = 0.f;
+  const long long chunk = ((rows + KS - 1) / KS + 1) & ~1LL;  // even
+  const long long p0 = (long long)blockIdx.x * chunk;
+  const long long p1 = p0 + chunk < rows ? p0 + chunk : rows;
+  for (long long p = p0; p < p1; p += 2) {
+    const long long pp = p + kh;
+    float a = 0.f;
+    if (pp < p1 && n < N) a = dy[pp * dys + n];
+    asum += a;
+#pragma unroll
+    for (int kf = 0; kf < KF; ++kf) {
+      float b = 0.f;
+      if (pp < p1 && kf * 32 + r < K) b = x[pp * xs + kf * 32 + r];
+      acc[kf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kf], 0, 0, 0);
+    }
+  }
+  const int Kpad = KF * 32;
+#pragma unroll
+  for (int kf = 0; kf < KF; ++kf)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int nn = blockIdx.y * 128 + wave * 32 + frag_row(reg, kh);
+      partial[((size_t)blockIdx.x * Npad + nn) * Kpad + kf * 32 + r] = acc[kf][reg];
+    }
+  const float tot = asum + __shfl_xor(asum, 32);
+  if (kh == 0) partial_db[(size_t)blockIdx.x * Npad + blockIdx.y * 128 + wave * 32 + r] = tot;
+}
+
+__global__ void linear_wgrad_reduce_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db, int KS, int Npad,
+                                           int Kpad, int N, int K, float* __restrict__ dW, float* __restrict__ db) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  const size_t slab = (size_t)Npad * Kpad;
+  if (gid < slab) {
+    const int k = gid % Kpad, n = gid / Kpad;
+    if (n < N && k < K) {
+      float s = 0.f;
+      for (int i = 0; i < KS; ++i) s += partial[i * slab + gid];
+      dW[(size_t)n * K + k] = s;
+    }
+  }
+  if (db && gid < (size_t)N) {
+    float s = 0.f;
+    for (int i = 0; i < KS; ++i) s += partial_db[(size_t)i * Npad + gid];
+    db[gid] = s;
+  }
+}
+
+struct WPlan { int KS, nblk, Npad, KF, Kpad; size_t floats; };
+WPlan wplan(int N, int K, long long rows) {
+  WPlan pl;
+  pl.nblk = (N + 127) / 128; pl.Npad = pl.nblk * 128;
+  pl.KF = (K + 31) / 32; pl.Kpad = pl.KF * 32;
+  long long ks = 512 / pl.nblk;
+  if (ks > rows / 64) ks = rows / 64;
+  if (ks < 1) ks = 1;
+  pl.KS = (int)ks;
+  pl.floats = (size_t)pl.KS * ((size_t)pl.Npad * pl.Kpad + pl.Npad);
+  return pl;
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const float* bias, sfTensor y, int32_t dtype,
+                  sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_linear_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(x.c % 8 == 0 && x.stride % 4 == 0 && (((uintptr_t)x.ptr) & 15) == 0 && (((uintptr_t)W) & 15) == 0,
+             "linear: K=%d must be a multiple of 8 and 16-byte aligned", x.c);
+  SF_REQUIRE(N >= 1 && y.c >= 1, "linear: N=%d y.c=%d", N, y.c);
+  if (rows == 0) return 0;
+  const int lanes = y.c > N ? y.c : N;
+  int nf = (lanes + 31) / 32;
+  if (nf > 4) nf = 4;
+  dim3 grid((unsigned)((rows + 127) / 128), (lanes + 32 * nf - 1) / (32 * nf));
+  hipStream_t st = (hipStream_t)stream;
+#define SF_LIN(NFV)                                                                                                         \
+  hipLaunchKernelGGL((linear_fwd_kernel<NFV>), grid, dim3(256), 0, st, (const float*)x.ptr, x.stride, (long long)rows, x.c, W, N, \
+                     bias, (float*)y.ptr, y.stride, y.c)
+  switch (nf) { case 1: SF_LIN(1); break; case 2: SF_LIN(2); break; case 3: SF_LIN(3); break; default: SF_LIN(4); break; }
+#undef SF_LIN
+  SF_CHECK_LAUNCH("linear_fwd");
+  return 0;
+}
+
+size_t sf_linear_bwd_weight_workspace_bytes(int32_t N, int32_t K, int64_t rows) { return wplan(N, K, rows).floats * sizeof(float); }
+
+int sf_linear_bwd_weight(sfTensor dy, int32_t N, sfTensor x, int64_t rows, float* dW, float* db, void* workspace,
+                         size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_linear_bwd_weight: dtype %d not built", dtype);
+  const int K = x.c;
+  SF_REQUIRE(K >= 1 && K <= 256 && N >= 1 && dy.c >= N, "linear wgrad: N=%d K=%d (K <= 256)", N, K);
+  const WPlan pl = wplan(N, K, rows);
+  SF_REQUIRE(workspace && workspace_bytes >= pl.floats * sizeof(float), "linear wgrad: workspace too small");
+  float* partial = (float*)workspace;
+  float* pdb = partial + (size_t)pl.KS * pl.Npad * pl.Kpad;
+  dim3 grid(pl.KS, pl.nblk);
+  hipStream_t st = (hipStream_t)stream;
+#define SF_LW(KFV)                                                                                                               \
+  hipLaunchKernelGGL((linear_wgrad_kernel<KFV>), grid, dim3(256), 0, st, (const float*)dy.ptr, dy.stride, N, (const float*)x.ptr, \
+                     x.stride, K, (long long)rows, pl.KS, partial, pdb, pl.Npad)
+  switch (pl.KF) {
+    case 1: SF_LW(1); break; case 2: SF_LW(2); break; case 3: SF_LW(3); break; case 4: SF_LW(4); break;
+    case 5: SF_LW(5); break; case 6: SF_LW(6); break; case 7: SF_LW(7); break; default: SF_LW(8); break;
+  }
+#undef SF_LW
+  SF_CHECK_LAUNCH("linear_wgrad");
+  const size_t slab = (size_t)pl.Npad * pl.Kpad;
+  hipLaunchKernelGGL(linear_wgrad_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, partial, pdb, pl.KS, pl.Npad,
+                     pl.Kpad, N, K, dW, db);
+  SF_CHECK_LAUNCH("linear_wgrad_reduce");
+  return 0;
+}
+
+}  // extern "C"

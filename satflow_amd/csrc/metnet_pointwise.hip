@@ -1,0 +1,374 @@
+// HBM-bound kernels of the MetNet image encoder (upstream metnet MetNetPreprocessor / DownSampler,
+// SURVEY Appendix A; reference call site satflow/models/pl_metnet.py:46-59,65):
+//   - preprocessing: pixel-unshuffle(2) + centre crop, 2x2 means, concat -> NHWC frames
+//   - 2x2/stride-2 max pooling, forward and backward (argmax recomputed, no index tensor)
+//   - training-mode BatchNorm2d with statistics per lead-time group of frames:
+//     reduce (fp64 accumulation across blocks) -> finalize (scale/shift, running stats) ->
+//     apply; backward = reduce + apply.
+// All NHWC, 16-byte accesses along the channel axis, one pass each.
+#include "sf_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ---------------------------------------------------------------------------------------------
+// preprocessing.  imgs[B][T][C][H][W] -> out frame j = t*B + b, [S][S][Cp], S = H/4 = W/4:
+//   lanes [0, 4*sat)        sat channel c, sub-pixel (dh,dw) -> lane c*4 + dh*2 + dw, centre crop of the H/2 map
+//   lanes [4*sat, 8*sat)    the same unshuffled channels, 2x2 mean
+//   lanes [8*sat, 8*sat+C-sat) other channels: 2x2 mean of the raw image, centre crop
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ imgs, int B, int T, int C, int sat, int H, int W,
+                                                         int S, float* __restrict__ out, int oc, int os) {
+  const long long total = (long long)B * T * S * S;
+  // torchvision CenterCrop: int(round(d / 2.0)) with Python's round-half-to-even
+  const int dT = H / 2 - S, dL = W / 2 - S;
+  const int top = (dT & 1) ? ((dT / 2) & 1 ? dT / 2 + 1 : dT / 2) : dT / 2;
+  const int left = (dL & 1) ? ((dL / 2) & 1 ? dL / 2 + 1 : dL / 2) : dL / 2;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x = idx % S, y = (idx / S) % S;
+    const long long j = idx / ((long long)S * S);
+    const int b = j % B, t = j / B;
+    const float* src = imgs + ((long long)b * T + t) * C * H * W;
+    float* dst = out + idx * os;
+    for (int c = 0; c < sat; ++c) {
+      const float* ch = src + (long long)c * H * W;
+      f32x4 ctr, mean;
+#pragma unroll
+      for (int d = 0; d < 4; ++d) {
+        const int dh = d >> 1, dw = d & 1;
+        ctr[d] = ch[(long long)(2 * (y + top) + dh) * W + 2 * (x + left) + dw];
+        float s = 0.f;
+#pragma unroll
+        for (int a = 0; a < 2; ++a)
+#pragma unroll
+          for (int bb = 0; bb < 2; ++bb) s += ch[(long long)(4 * y + 2 * a + dh) * W + 4 * x + 2 * bb + dw];
+        mean[d] = s * 0.25f;
+      }
+      st4(dst + c * 4, ctr);
+      st4(dst + 4 * sat + c * 4, mean);
+    }
+    for (int c = sat; c < C; ++c) {
+      const float* ch = src + (long long)c * H * W;
+      const int yy = 2 * (y + top), xx = 2 * (x + left);
+      dst[8 * sat + (c - sat)] = 0.25f * (ch[(long long)yy * W + xx] + ch[(long long)yy * W + xx + 1] +
+                                          ch[(long long)(yy + 1) * W + xx] + ch[(long long)(yy + 1) * W + xx + 1]);
+    }
+    for (int c = 8 * sat + (C - sat); c < oc; ++c) dst[c] = 0.f;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// max pooling 2x2 stride 2
+// ---------------------------------------------------------------------------------------------
+struct OuterPerm { int L, T, B; };  // L == 0: identity.  pooled image of input image (l*T+t)*B+b is (t*L+l)*B+b
+__device__ __forceinline__ long long perm_image(long long n, const OuterPerm& pm) {
+  if (pm.L == 0) return n;
+  const long long b = n % pm.B, t = (n / pm.B) % pm.T, l = n / ((long long)pm.B * pm.T);
+  return (t * pm.L + l) * pm.B + b;
+}
+
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, int is, long long N, int H, int W, int C,
+                                                          float* __restrict__ out, int os, const OuterPerm pm) {
+  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const long long total = N * Ho * Wo * q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (idx % q) * 4;
+    const long long op = idx / q;
+    const int xo = op % Wo, yo = (op / Wo) % Ho;
+    const long long n = op / ((long long)Wo * Ho);
+    const float* p = in + ((n * H + 2 * yo) * W + 2 * xo) * is + c;
+    f32x4 m = ld4(p);
+    const f32x4 v1 = ld4(p + is), v2 = ld4(p + (long long)W * is), v3 = ld4(p + (long long)W * is + is);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
+    st4(out + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * os + c, m);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ in, int is, const float* __restrict__ dout, int dos,
+                                                          long long N, int H, int W, int C, float* __restrict__ din, int dis,
+                                                          const OuterPerm pm) {
+  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const long long total = N * Ho * Wo * q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (idx % q) * 4;
+    const long long op = idx / q;
+    const int xo = op % Wo, yo = (op / Wo) % Ho;
+    const long long n = op / ((long long)Wo * Ho);
+    const long long base = (n * H + 2 * yo) * W + 2 * xo;
+    const float* p = in + base * is + c;
+    const f32x4 v0 = ld4(p), v1 = ld4(p + is), v2 = ld4(p + (long long)W * is), v3 = ld4(p + (long long)W * is + is);
+    const f32x4 g = ld4(dout + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * dos + c);
+    f32x4 g0, g1, g2, g3;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      // first maximum in row-major window order (the order torch's max_pool2d scans)
+      int am = 0; float m = v0[j];
+      if (v1[j] > m) { m = v1[j]; am = 1; }
+      if (v2[j] > m) { m = v2[j]; am = 2; }
+      if (v3[j] > m) { m = v3[j]; am = 3; }
+      g0[j] = am == 0 ? g[j] : 0.f; g1[j] = am == 1 ? g[j] : 0.f; g2[j] = am == 2 ? g[j] : 0.f; g3[j] = am == 3 ? g[j] : 0.f;
+    }
+    float* d = din + base * dis + c;
+    st4(d, g0); st4(d + dis, g1); st4(d + (long long)W * dis, g2); st4(d + (long long)W * dis + dis, g3);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// BatchNorm: per (group, channel) reductions.  MODE 0: sum x, sum x^2.  MODE 1: sum dy, sum dy*xhat.
+// Grid: (chunks, groups).  A block walks its pixel chunk with threads laid out [pixel][channel quad].
+// ---------------------------------------------------------------------------------------------
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, int dys,
+                                                        long long pix_per_group, int C, const float* __restrict__ mean,
+                                                        const float* __restrict__ rstd, double* __restrict__ sums /*[G][2][C]*/) {
+  extern __shared__ float red[];  // [2][rows][C]
+  const int q = C / 4;
+  const int rows = 256 / q > 0 ? 256 / q : 1;  // pixel rows handled concurrently
+  const int g = blockIdx.y;
+  const int cq = threadIdx.x % q, row = threadIdx.x / q;
+  const bool active = row < rows;
+  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
+  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
+  if (MODE == 1 && active) { mu = ld4(mean + (long long)g * C + cq * 4); rs = ld4(rstd + (long long)g * C + cq * 4); }
+  const long long chunk = (pix_per_group + gridDim.x - 1) / gridDim.x;
+  const long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk < pix_per_group ? p0 + chunk : pix_per_group;
+  if (active)
+    for (long long p = p0 + row; p < p1; p += rows) {
+      const long long gp = (long long)g * pix_per_group + p;
+      const f32x4 v = ld4(x + gp * xs + cq * 4);
+      if (MODE == 0) { s0 += v; s1 += v * v; }
+      else { const f32x4 d = ld4(dy + gp * dys + cq * 4); s0 += d; s1 += d * ((v - mu) * rs); }
+    }
+  if (active) { st4(red + (0 * rows + row) * C + cq * 4, s0); st4(red + (1 * rows + row) * C + cq * 4, s1); }
+  __syncthreads();
+  for (int i = threadIdx.x; i < 2 * C; i += 256) {
+    const int which = i / C, c = i % C;
+    float s = 0.f;
+    for (int r2 = 0; r2 < rows; ++r2) s += red[(which * rows + r2) * C + c];
+    atomicAdd(sums + ((long long)g * 2 + which) * C + c, (double)s);
+  }
+}
+
+// finalize forward statistics: mean/rstd per (group, channel), affine a = gamma*rstd, b = beta - mean*a;
+// running stats updated group after group (the reference calls the module once per lead time, in order).
+__global__ void bn_finalize_kernel(const double* __restrict__ sums, int G, int C, int Creal, double count, float eps, float momentum,
+                                   const float* __restrict__ gamma, const float* __restrict__ beta, float* __restrict__ mean,
+                                   float* __restrict__ rstd, float* __restrict__ a, float* __restrict__ b,
+                                   float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float rm = 0.f, rv = 0.f;
+  const bool real = c < Creal;
+  if (real && running_mean) { rm = running_mean[c]; rv = running_var[c]; }
+  for (int g = 0; g < G; ++g) {
+    const double m = sums[((long long)g * 2 + 0) * C + c] / count;
+    double var = sums[((long long)g * 2 + 1) * C + c] / count - m * m;
+    if (var < 0) var = 0;
+    const float r = (float)(1.0 / sqrt(var + (double)eps));
+    mean[(long long)g * C + c] = (float)m;
+    rstd[(long long)g * C + c] = r;
+    const float ga = real ? gamma[c] : 0.f, be = real ? beta[c] : 0.f;
+    a[(long long)g * C + c] = ga * r;
+    b[(long long)g * C + c] = be - (float)m * ga * r;
+    if (real && running_mean) {
+      const double unbiased = count > 1 ? var * count / (count - 1) : var;
+      rm = (1.f - momentum) * rm + momentum * (float)m;
+      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+    }
+  }
+  if (real && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
+}
+
+// eval mode: a, b from running statistics (one group)
+__global__ void bn_eval_affine_kernel(int C, int Creal, float eps, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                      const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                      float* __restrict__ a, float* __restrict__ b) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  if (c < Creal) {
+    const float r = 1.f / sqrtf(running_var[c] + eps);
+    a[c] = gamma[c] * r; b[c] = beta[c] - running_mean[c] * gamma[c] * r;
+  } else { a[c] = 0.f; b[c] = 0.f; }
+}
+
+// y = x*a[g] + b[g]
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int xs, long long pixels, long long pix_per_group, int C,
+                                                       const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int ys) {
+  const int q = C / 4;
+  const long long total = pixels * q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long p = idx / q;
+    const int c = (idx % q) * 4;
+    const long long g = p / pix_per_group;
+    st4(y + p * ys + c, ld4(x + p * xs + c) * ld4(a + g * C + c) + ld4(b + g * C + c));
+  }
+}
+
+// dx = gamma*rstd * (dy - sum_dy/N - xhat * sum_dyxhat/N)
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, int dys,
+                                                           long long pixels, long long pix_per_group, int C, int Creal,
+                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
+                                                           const float* __restrict__ rstd, const double* __restrict__ sums,
+                                                           float* __restrict__ dx, int dxs) {
+  const int q = C / 4;
+  const long long total = pixels * q;
+  const float invn = 1.f / (float)pix_per_group;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const long long p = idx / q;
+    const int c = (idx % q) * 4;
+    const long long g = p / pix_per_group;
+    const f32x4 v = ld4(x + p * xs + c), d = ld4(dy + p * dys + c);
+    const f32x4 mu = ld4(mean + g * C + c), rs = ld4(rstd + g * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float ga = (c + j < Creal) ? gamma[c + j] : 0.f;
+      const float xh = (v[j] - mu[j]) * rs[j];
+      const float sd = (float)sums[(g * 2 + 0) * C + c + j], sdx = (float)sums[(g * 2 + 1) * C + c + j];
+      o[j] = ga * rs[j] * (d[j] - sd * invn - xh * sdx * invn);
+    }
+    st4(dx + p * dxs + c, o);
+  }
+}
+
+// dgamma[c] (+)= sum_g sum_dyxhat, dbeta[c] (+)= sum_g sum_dy
+__global__ void bn_param_grad_kernel(const double* __restrict__ sums, int G, int C, int Creal, float* __restrict__ dgamma,
+                                     float* __restrict__ dbeta) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= Creal) return;
+  double sb = 0, sg = 0;
+  for (int g = 0; g < G; ++g) { sb += sums[((long long)g * 2 + 0) * C + c]; sg += sums[((long long)g * 2 + 1) * C + c]; }
+  dgamma[c] = (float)sg; dbeta[c] = (float)sb;
+}
+
+int grid_for(long long total) { return (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384); }
+bool ok4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.c % 4 == 0); }
+
+}  // namespace
+
+extern "C" {
+
+int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C, int32_t sat, int32_t H, int32_t W, int32_t crop,
+                             sfTensor out, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_metnet_preprocess_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(H % 4 == 0 && W % 4 == 0 && H / 4 == crop && W / 4 == crop,
+             "preprocess: raw size %dx%d must be 4x input_size=%d (reference tests/test_models.py:46-49)", H, W, crop);
+  SF_REQUIRE(sat >= 0 && sat <= C && out.c >= 8 * sat + (C - sat) && ok4(out), "preprocess: output lanes %d < %d", out.c, 8 * sat + C - sat);
+  const long long total = (long long)B * T * crop * crop;
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, imgs, B, T, C, sat, H, W, crop,
+                     (float*)out.ptr, out.c, out.stride);
+  SF_CHECK_LAUNCH("metnet_preprocess");
+  return 0;
+}
+
+int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, int32_t dtype,
+                    sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == out.c && ok4(in) && ok4(out), "maxpool2: needs even H,W and matching 4-aligned channels");
+  OuterPerm pm{0, 0, 0};
+  if (perm_l > 0) {
+    SF_REQUIRE(perm_t > 0 && n % ((long long)perm_l * perm_t) == 0, "maxpool2: n=%lld not divisible by perm dims %d x %d", (long long)n, perm_l, perm_t);
+    pm = OuterPerm{perm_l, perm_t, (int)(n / ((long long)perm_l * perm_t))};
+  }
+  const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)in.ptr, in.stride, n, h, w,
+                     in.c, (float*)out.ptr, out.stride, pm);
+  SF_CHECK_LAUNCH("maxpool2_fwd");
+  return 0;
+}
+
+int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
+                    int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_bwd: dtype %d not built", dtype);
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == dout.c && in.c == din.c && ok4(in) && ok4(dout) && ok4(din), "maxpool2 bwd: shape/alignment");
+  OuterPerm pm{0, 0, 0};
+  if (perm_l > 0) {
+    SF_REQUIRE(perm_t > 0 && n % ((long long)perm_l * perm_t) == 0, "maxpool2: n=%lld not divisible by perm dims %d x %d", (long long)n, perm_l, perm_t);
+    pm = OuterPerm{perm_l, perm_t, (int)(n / ((long long)perm_l * perm_t))};
+  }
+  const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)in.ptr, in.stride,
+                     (const float*)dout.ptr, dout.stride, n, h, w, in.c, (float*)din.ptr, din.stride, pm);
+  SF_CHECK_LAUNCH("maxpool2_bwd");
+  return 0;
+}
+
+static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, const float* mean,
+                            const float* rstd, double* sums, hipStream_t st) {
+  const int C = x.c;
+  SF_REQUIRE(C % 4 == 0 && C <= 1024 && ok4(x) && ok4(dy), "batchnorm: channels %d", C);
+  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * groups, st);
+  SF_REQUIRE(e == hipSuccess, "batchnorm: memset failed");
+  const int q = C / 4, rows = 256 / q > 0 ? 256 / q : 1;
+  long long chunks = pix_per_group / (rows * 16);
+  if (chunks < 1) chunks = 1;
+  if (chunks > 256) chunks = 256;
+  const size_t shmem = sizeof(float) * 2 * rows * C;
+  dim3 grid((unsigned)chunks, groups);
+  if (mode == 0)
+    hipLaunchKernelGGL((bn_reduce_kernel<0>), grid, dim3(256), shmem, st, (const float*)x.ptr, x.stride, nullptr, 0, pix_per_group, C,
+                       nullptr, nullptr, sums);
+  else
+    hipLaunchKernelGGL((bn_reduce_kernel<1>), grid, dim3(256), shmem, st, (const float*)x.ptr, x.stride, (const float*)dy.ptr, dy.stride,
+                       pix_per_group, C, mean, rstd, sums);
+  SF_CHECK_LAUNCH("bn_reduce");
+  return 0;
+}
+
+int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma, const float* beta,
+                           float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                           float* scale, float* shift, double* sums, sfTensor y, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(x.c == y.c && ok4(y) && creal <= x.c, "batchnorm: y channels");
+  hipStream_t st = (hipStream_t)stream;
+  sfTensor none{nullptr, 0, 0, 0, 0};
+  if (int rc = bn_reduce_launch(0, x, none, pix_per_group, groups, nullptr, nullptr, sums, st)) return rc;
+  hipLaunchKernelGGL(bn_finalize_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, (double)pix_per_group, eps,
+                     momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
+  SF_CHECK_LAUNCH("bn_finalize");
+  const long long pixels = pix_per_group * groups;
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride, pixels,
+                     pix_per_group, x.c, scale, shift, (float*)y.ptr, y.stride);
+  SF_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float* gamma, const float* beta, float eps,
+                          const float* running_mean, const float* running_var, float* scale, float* shift, sfTensor y,
+                          int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_eval_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(x.c == y.c && ok4(x) && ok4(y) && creal <= x.c, "batchnorm eval: channels");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, x.c, creal, eps, gamma, beta, running_mean,
+                     running_var, scale, shift);
+  SF_CHECK_LAUNCH("bn_eval_affine");
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride, (long long)pixels,
+                     (long long)pixels, x.c, scale, shift, (float*)y.ptr, y.stride);
+  SF_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma,
+                           const float* mean, const float* rstd, double* sums, sfTensor dx, float* dgamma, float* dbeta,
+                           int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_bwd: dtype %d not built", dtype);
+  SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok4(dx), "batchnorm bwd: channels");
+  hipStream_t st = (hipStream_t)stream;
+  if (int rc = bn_reduce_launch(1, x, dy, pix_per_group, groups, mean, rstd, sums, st)) return rc;
+  const long long pixels = pix_per_group * groups;
+  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride,
+                     (const float*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, creal, gamma, mean, rstd, sums,
+                     (float*)dx.ptr, dx.stride);
+  SF_CHECK_LAUNCH("bn_bwd_apply");
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, dgamma, dbeta);
+  SF_CHECK_LAUNCH("bn_param_grad");
+  return 0;
+}
+
+}  // extern "C"

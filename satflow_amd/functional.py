@@ -1,0 +1,430 @@
+"""Autograd-aware ops over the C ABI, all on time-major NHWC fp32 tensors with padded channels.
+
+Each ``torch.autograd.Function`` here is plumbing only: it allocates outputs, hands raw pointers
+to libsatflow_hip.so on the current stream and wires the matching backward kernels.  No tensor
+arithmetic happens in PyTorch on the hot path except where a comment says so.
+"""
+from __future__ import annotations
+
+from typing import List, Optional, Sequence, Tuple
+
+import torch
+
+from . import kernels as K
+from ._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, SF_F32, T, check, cpad, generation, lib, require_device, sfTensor, stream_ptr
+
+Tensor = torch.Tensor
+
+
+# ----------------------------------------------------------------------------------------------
+# layout ops: NCHW-side tensors <-> time-major NHWC
+# ----------------------------------------------------------------------------------------------
+class _ToNHWC(torch.autograd.Function):
+    """``src`` addressed as [nb][nt] images with element strides ``(sb, st, sc)`` -> ``[nt*nb,H,W,Cp]``."""
+
+    @staticmethod
+    def forward(ctx, src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
+        src = src.contiguous()
+        ctx.meta = (src.shape, nb, nt, c, h, w, strides)
+        return K.to_nhwc(src, nb, nt, c, h, w, strides)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        shape, nb, nt, c, h, w, strides = ctx.meta
+        out = torch.empty(shape, dtype=torch.float32, device=g.device)
+        K.from_nhwc(g.contiguous(), nb, nt, c, h, w, out, strides)
+        return out, None, None, None, None, None, None
+
+
+class _FromNHWC(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, src: Tensor, shape: Tuple[int, ...], nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
+        ctx.meta = (nb, nt, c, h, w, strides, src.shape[-1])
+        out = torch.empty(shape, dtype=torch.float32, device=src.device)
+        return K.from_nhwc(src.contiguous(), nb, nt, c, h, w, out, strides)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        nb, nt, c, h, w, strides, cp = ctx.meta
+        return K.to_nhwc(g.contiguous(), nb, nt, c, h, w, strides, cp), None, None, None, None, None, None, None
+
+
+def nchw_to_nhwc(x: Tensor) -> Tensor:
+    """``[N,C,H,W] -> [N,H,W,Cp]``."""
+    n, c, h, w = x.shape
+    return _ToNHWC.apply(x, n, 1, c, h, w, (c * h * w, 0, h * w))
+
+
+def nhwc_to_nchw(x: Tensor, c: int) -> Tensor:
+    """``[N,H,W,Cp] -> [N,c,H,W]``."""
+    n, h, w, _ = x.shape
+    return _FromNHWC.apply(x, (n, c, h, w), n, 1, c, h, w, (c * h * w, 0, h * w))
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 convolution (one or two channel-concatenated sources, optional image-index remap per source)
+# ----------------------------------------------------------------------------------------------
+class ConvEngine:
+    """Index maps + packed-weight cache of one ``nn.Conv2d(k=3, padding=1)`` over ``cat(sources)``."""
+
+    def __init__(self, cins: Sequence[int], cout: int) -> None:
+        self.cins, self.cout = list(cins), cout
+        self.coutp = cpad(cout)
+        self.fwd_map = K.linear_map(self.cins, cout)
+        self.wgrad_map = K.GemmMap(K._padded(cout), list(self.fwd_map.kmap), 0, self.coutp)
+        self._bwd_maps = {}
+        self._key, self._packed = None, {}
+
+    def bwd_map(self, need: Tuple[bool, ...]) -> K.GemmMap:
+        if need not in self._bwd_maps:
+            self._bwd_maps[need] = K.linear_bwd_map(self.cins, self.cout, need)
+        return self._bwd_maps[need]
+
+    def packed(self, weight: Tensor, bias: Optional[Tensor], kind, need: Tuple[bool, ...] = ()):
+        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), generation())
+        if key != self._key:
+            self._key, self._packed = key, {}
+        k = (kind, need)
+        if k not in self._packed:
+            w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
+            if kind == "fwd":
+                self._packed[k] = K.pack_weights(w4, bias, self.fwd_map, transpose=False)
+            else:
+                self._packed[k] = K.pack_weights(w4, None, self.bwd_map(need), transpose=True)
+        return self._packed[k]
+
+
+class _ConvFn(torch.autograd.Function):
+    """``y = act(conv3x3(cat(x0, x1)) + b)``: x_i ``[N_i,H,W,C_ip]`` -> ``[n,H,W,Coutp]``.
+
+    ``remap_i = (idiv, imod)``: kernel image j reads image ``(j // idiv) % imod`` of source i, so a
+    source with fewer images is broadcast (MetNet's lead-time axis) instead of copied.  Gradients
+    are produced only for non-remapped sources (the remapped ones here are inputs / constants).
+    """
+
+    @staticmethod
+    def forward(ctx, eng: ConvEngine, x0: Tensor, x1: Optional[Tensor], weight: Tensor, bias: Optional[Tensor], n: int,
+                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool):
+        H, W = x0.shape[1], x0.shape[2]
+        packed, bp = eng.packed(weight, bias, "fwd")
+        y = torch.empty(n, H, W, eng.coutp, dtype=torch.float32, device=x0.device)
+        s0 = T(x0, idiv=remap0[0], imod=remap0[1])
+        s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if x1 is not None else NULL
+        K.conv3x3(s0, s1, n, H, W, packed, bp, eng.fwd_map, T(y), SF_EPI_SIGMOID if sigmoid else SF_EPI_LINEAR)
+        ctx.eng, ctx.sigmoid, ctx.n, ctx.remaps = eng, sigmoid, n, (remap0, remap1)
+        ctx.has = (x1 is not None, bias is not None)
+        ctx.save_for_backward(x0, x1 if x1 is not None else x0.new_empty(0), y if sigmoid else x0.new_empty(0), weight)
+        ctx.bias = bias  # only to keep the packed-weight cache key stable in backward
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        eng: ConvEngine = ctx.eng
+        x0, x1, y, weight = ctx.saved_tensors
+        has_x1, has_bias = ctx.has
+        n, (remap0, remap1) = ctx.n, ctx.remaps
+        H, W = x0.shape[1], x0.shape[2]
+        gy = gy.contiguous()
+        if ctx.sigmoid:
+            gy = gy * y * (1.0 - y)  # pointwise torch op on the small head tensor only
+        need = (ctx.needs_input_grad[1], has_x1 and ctx.needs_input_grad[2])
+        if (need[0] and remap0 != (0, 0)) or (need[1] and remap1 != (0, 0)):
+            raise RuntimeError("gradient wrt a broadcast (image-remapped) convolution source is not implemented")
+        d0 = d1 = None
+        if any(need):
+            needk = need if has_x1 else need[:1]
+            gm = eng.bwd_map(tuple(needk))
+            lanes = sum(cpad(c) for c, nd in zip(eng.cins, needk) if nd)
+            dcat = torch.empty(n, H, W, lanes, dtype=torch.float32, device=gy.device)
+            K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, ctx.bias, "bwd", tuple(needk))[0], None, gm, T(dcat))
+            if need[0] and need[1]:
+                c0p = cpad(eng.cins[0])
+                d0, d1 = dcat[..., :c0p].contiguous(), dcat[..., c0p:].contiguous()
+            elif need[0]:
+                d0 = dcat
+            else:
+                d1 = dcat
+        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=gy.device)
+        db = torch.empty(weight.shape[0], dtype=torch.float32, device=gy.device) if has_bias else None
+        s0 = T(x0, idiv=remap0[0], imod=remap0[1])
+        s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
+        K.conv3x3_bwd_weight(s0, s1, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
+        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None
+
+
+def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False) -> Tensor:
+    return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid)
+
+
+def conv3x3_broadcast(eng: ConvEngine, x0: Tensor, x1: Tensor, weight: Tensor, bias: Optional[Tensor], n: int,
+                      remap0: Tuple[int, int], remap1: Tuple[int, int]) -> Tensor:
+    return _ConvFn.apply(eng, x0, x1, weight, bias, n, remap0, remap1, False)
+
+
+# ----------------------------------------------------------------------------------------------
+# max pooling / batch norm
+# ----------------------------------------------------------------------------------------------
+class _MaxPoolFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, perm: Optional[Tuple[int, int]]):
+        ctx.perm = perm
+        ctx.save_for_backward(x)
+        return K.maxpool2_fwd(x, perm)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        (x,) = ctx.saved_tensors
+        return K.maxpool2_bwd(x, gy.contiguous(), ctx.perm), None
+
+
+def maxpool2(x: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
+    return _MaxPoolFn.apply(x, perm)
+
+
+class _BatchNormTrainFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d with ``groups`` independent statistics sets (one per lead time)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                groups: int, eps: float, momentum: float):
+        C = x.shape[-1]
+        creal = gamma.shape[0]
+        pixels = x.numel() // C
+        assert pixels % groups == 0
+        dev = x.device
+        stats = torch.empty(4, groups, C, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
+        sums = torch.empty(groups, 2, C, dtype=torch.float64, device=dev)
+        y = torch.empty_like(x)
+        check(lib().sf_batchnorm_train_fwd(T(x), pixels // groups, groups, creal, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
+                                           running_mean.data_ptr() if running_mean is not None else None,
+                                           running_var.data_ptr() if running_var is not None else None,
+                                           stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
+                                           sums.data_ptr(), T(y), SF_F32, stream_ptr()), "sf_batchnorm_train_fwd")
+        ctx.groups, ctx.creal = groups, creal
+        ctx.save_for_backward(x, gamma, stats)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, gamma, stats = ctx.saved_tensors
+        C = x.shape[-1]
+        pixels = x.numel() // C
+        gy = gy.contiguous()
+        dx = torch.empty_like(x)
+        sums = torch.empty(ctx.groups, 2, C, dtype=torch.float64, device=x.device)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        check(lib().sf_batchnorm_train_bwd(T(x), T(gy), pixels // ctx.groups, ctx.groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
+                                           stats[1].data_ptr(), sums.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32,
+                                           stream_ptr()), "sf_batchnorm_train_bwd")
+        return dx, dgamma, dbeta, None, None, None, None, None
+
+
+def batchnorm(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, training: bool) -> Tensor:
+    """``bn(x)`` on NHWC ``x``; in training mode with ``groups`` separate batches (and running-stat updates in order)."""
+    if training:
+        if bn.track_running_stats and bn.num_batches_tracked is not None:
+            bn.num_batches_tracked += groups
+        return _BatchNormTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups, bn.eps,
+                                       bn.momentum if bn.momentum is not None else 0.1)
+    C = x.shape[-1]
+    ab = torch.empty(2, C, dtype=torch.float32, device=x.device)
+    y = torch.empty_like(x)
+    check(lib().sf_batchnorm_eval_fwd(T(x), x.numel() // C, bn.weight.shape[0], bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps,
+                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), ab[0].data_ptr(), ab[1].data_ptr(), T(y),
+                                      SF_F32, stream_ptr()), "sf_batchnorm_eval_fwd")
+    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
+        raise RuntimeError("eval-mode BatchNorm has no backward kernel (the reference trains in train mode)")
+    return y
+
+
+# ----------------------------------------------------------------------------------------------
+# pointwise linear map (1x1 conv) and axial attention core
+# ----------------------------------------------------------------------------------------------
+class _LinearFn(torch.autograd.Function):
+    """``y[..., :N] = x @ W.T + b`` with ``W [N, Kp]`` (zero-padded columns); output lanes ``out_lanes``."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int):
+        W = W.contiguous()
+        ctx.save_for_backward(x, W)
+        ctx.has_bias = bias is not None
+        return K.linear_fwd(x, W, bias, out_lanes)
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, W = ctx.saved_tensors
+        gy = gy.contiguous()
+        N, Kp = W.shape
+        dx = None
+        if ctx.needs_input_grad[0]:
+            # dx = gy[..., :N] @ W : the same kernel with the transposed weight (tiny host-side transpose)
+            Wt = torch.zeros(Kp, gy.shape[-1], dtype=torch.float32, device=W.device)
+            Wt[:, :N] = W.t()
+            dx = K.linear_fwd(gy, Wt, None, Kp)
+        dW, db = K.linear_bwd_weight(gy, x, N, ctx.has_bias)
+        return dx, dW, db, None
+
+
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], out_lanes: Optional[int] = None) -> Tensor:
+    """Pointwise linear map; ``weight [N, K]`` with K <= x lanes (padded with zero columns here, autograd-tracked)."""
+    Kp = x.shape[-1]
+    if weight.shape[1] != Kp:
+        weight = torch.nn.functional.pad(weight, (0, Kp - weight.shape[1]))
+    return _LinearFn.apply(x, weight, bias, out_lanes or cpad(weight.shape[0]))
+
+
+class _AttnCoreFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, qkv: Tensor, hid: int, heads: int):
+        ctx.save_for_backward(qkv)
+        ctx.meta = (hid, heads)
+        return K.attention_core_fwd(qkv, hid, heads)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (qkv,) = ctx.saved_tensors
+        return K.attention_core_bwd(qkv, g.contiguous(), *ctx.meta), None, None
+
+
+def attention_core(qkv: Tensor, hid: int, heads: int) -> Tensor:
+    return _AttnCoreFn.apply(qkv, hid, heads)
+
+
+# ----------------------------------------------------------------------------------------------
+# ConvGRU over a whole sequence (one autograd node per layer)
+# ----------------------------------------------------------------------------------------------
+class GRUEngine:
+    """Maps + packed caches of one ConvGRUCell(input_dim, hidden_dim, 3x3).
+
+    The cell's three convolutions are regrouped (the caller concatenates the reference parameters,
+    autograd-tracked): ``Wx [3*hid, cin]`` = [conv_zr[:, :cin] ; conv_h1] applied to ALL timesteps in
+    one convolution, and ``Wh [3*hid, hid]`` = [conv_zr[:, cin:] ; conv_h2] applied per step.
+    """
+
+    def __init__(self, cin: int, hid: int) -> None:
+        self.cin, self.hid = cin, hid
+        self.cinp, self.hidp = cpad(cin), cpad(hid)
+        gm3 = K.gate_major(hid, 3)
+        self.x_fwd = K.custom_map(gm3, K._padded(cin))                 # x -> gx [3*hidp]
+        self.x_bwd = K.custom_map(K._padded(cin), gm3)                 # dgx -> dx
+        self.x_wgrad = K.GemmMap(gm3, K._padded(cin), 0, 3 * self.hidp)
+        self.h_fwd = K.gru_rec_map(hid)                                # h -> [z_h|r_h|h2], fused epilogue
+        self.h_bwd = K.custom_map(K._padded(hid), gm3)                 # dgh -> dh_prev
+        self.h_wgrad = K.GemmMap(gm3, K._padded(hid), 0, 3 * self.hidp)
+        self._key, self._packed = None, {}
+
+    def packed(self, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor):
+        key = (Wx.data_ptr(), Wx._version, Wh.data_ptr(), Wh._version, bx.data_ptr(), bh.data_ptr(), generation())
+        if key != self._key:
+            self._key = key
+            self._packed = {
+                "x_fwd": K.pack_weights(Wx, bx, self.x_fwd, False),
+                "x_bwd": K.pack_weights(Wx, None, self.x_bwd, True)[0],
+                "h_fwd": K.pack_weights(Wh, bh, self.h_fwd, False),
+                "h_bwd": K.pack_weights(Wh, None, self.h_bwd, True)[0],
+            }
+        return self._packed
+
+
+class _ConvGRUSeqFn(torch.autograd.Function):
+    """x ``[T*n,H,W,Cinp]`` (time-major) -> (all hidden states ``[T*n,H,W,hidp]``, last state ``[n,H,W,hidp]``)."""
+
+    @staticmethod
+    def forward(ctx, eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor):
+        N, H, W, _ = x.shape
+        n = N // Tn
+        hidp, dev = eng.hidp, x.device
+        pk = eng.packed(Wx, bx, Wh, bh)
+        keep = any(ctx.needs_input_grad)
+        gx = torch.empty(N, H, W, 3 * hidp, dtype=torch.float32, device=dev)
+        K.conv3x3(T(x), NULL, N, H, W, pk["x_fwd"][0], pk["x_fwd"][1], eng.x_fwd, T(gx))
+        hs = torch.empty(Tn, n, H, W, hidp, dtype=torch.float32, device=dev)
+        gates = torch.empty(Tn, n, H, W, 4 * hidp, dtype=torch.float32, device=dev) if keep else None
+        gxs = gx.view(Tn, n, H, W, 3 * hidp)
+        for t in range(Tn):
+            K.convgru_step_fwd(T(gxs[t]), hs[t - 1] if t else None, n, H, W, pk["h_fwd"][0], pk["h_fwd"][1], hidp, hs[t],
+                               gates[t] if keep else None)
+        ctx.eng, ctx.Tn = eng, Tn
+        ctx.set_materialize_grads(False)
+        if keep:
+            ctx.save_for_backward(x, hs, gates, Wx, Wh)
+        return hs.view(N, H, W, hidp), hs[Tn - 1]
+
+    @staticmethod
+    def backward(ctx, g_seq: Optional[Tensor], g_last: Optional[Tensor]):
+        eng: GRUEngine = ctx.eng
+        Tn = ctx.Tn
+        x, hs, gates, Wx, Wh = ctx.saved_tensors
+        _, n, H, W, hidp = hs.shape
+        N, dev = Tn * n, x.device
+        # the parameters cannot have changed between forward and backward of one step; reuse the cache
+        pk = eng._packed
+        g_seq = g_seq.contiguous().view(Tn, n, H, W, hidp) if g_seq is not None else None
+        g_last = g_last.contiguous() if g_last is not None else None
+        dgx = torch.empty(Tn, n, H, W, 3 * hidp, dtype=torch.float32, device=dev)
+        dgh = torch.empty(Tn, n, H, W, 3 * hidp, dtype=torch.float32, device=dev)
+        direct = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)  # dh * z of the step above
+        carry = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)   # conv^T(dgh) of the step above
+        zeros = None
+        have_carry = False
+        for t in range(Tn - 1, -1, -1):
+            src: List[sfTensor] = []
+            if g_seq is not None:
+                src.append(T(g_seq[t]))
+            if t == Tn - 1 and g_last is not None:
+                src.append(T(g_last))
+            if have_carry:
+                src += [T(direct), T(carry)]
+            if not src:
+                zeros = zeros if zeros is not None else torch.zeros(n, H, W, hidp, dtype=torch.float32, device=dev)
+                src = [T(zeros)]
+            if len(src) > 3:  # g_seq + direct + carry (+ g_last only at the last step where there is no carry) <= 3
+                raise RuntimeError("unexpected number of gradient sources")
+            K.convgru_bwd_gates(src, gates[t], hs[t - 1] if t else None, hidp, dgx[t], dgh[t], direct if t else None)
+            if t:
+                K.conv3x3(T(dgh[t]), NULL, n, H, W, pk["h_bwd"], None, eng.h_bwd, T(carry))
+                have_carry = True
+        dx = None
+        if ctx.needs_input_grad[1]:
+            dx = torch.empty_like(x)
+            K.conv3x3(T(dgx.view(N, H, W, 3 * hidp)), NULL, N, H, W, pk["x_bwd"], None, eng.x_bwd, T(dx))
+        dWx, dbx = torch.empty_like(Wx), torch.empty(Wx.shape[0], dtype=torch.float32, device=dev)
+        K.conv3x3_bwd_weight(T(x), NULL, T(dgx.view(N, H, W, 3 * hidp)), N, H, W, eng.x_wgrad, dWx, dbx, False)
+        dWh, dbh = torch.empty_like(Wh), torch.empty(Wh.shape[0], dtype=torch.float32, device=dev)
+        if Tn > 1:
+            K.conv3x3_bwd_weight(T(hs[: Tn - 1]), NULL, T(dgh[1:]), (Tn - 1) * n, H, W, eng.h_wgrad, dWh, dbh, False)
+            # bias of the h-part also acts at t = 0 (zero state, bias only): add that step's column sums (tiny torch op)
+            dbh = (dbh + dgh[0].sum(dim=(0, 1, 2))[K_bias_index(eng, dev)]) * K_bias_mask(eng, dev)
+        else:
+            dWh.zero_()
+            dbh.copy_(dgh[0].sum(dim=(0, 1, 2))[K_bias_index(eng, dev)] * K_bias_mask(eng, dev))
+        return None, dx, None, dWx, dbx, dWh, dbh
+
+
+_BIAS_CACHE = {}
+
+
+def _bias_tables(eng: GRUEngine, dev):
+    key = (eng.hid, str(dev))
+    if key not in _BIAS_CACHE:
+        lanes = K.gate_major(eng.hid, 3)  # padded lane -> row
+        idx = torch.zeros(3 * eng.hid, dtype=torch.long)
+        for lane, row in enumerate(lanes):
+            if row >= 0:
+                idx[row] = lane
+        mask = torch.zeros(3 * eng.hid, dtype=torch.float32)
+        mask[2 * eng.hid:] = 1.0  # the step kernel adds the bias to the h2 map only (z/r biases ride on the x-part)
+        _BIAS_CACHE[key] = (idx.to(dev), mask.to(dev))
+    return _BIAS_CACHE[key]
+
+
+def K_bias_index(eng: GRUEngine, dev):
+    return _bias_tables(eng, dev)[0]
+
+
+def K_bias_mask(eng: GRUEngine, dev):
+    return _bias_tables(eng, dev)[1]
+
+
+def convgru_sequence(eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor) -> Tuple[Tensor, Tensor]:
+    return _ConvGRUSeqFn.apply(eng, x, Tn, Wx, bx, Wh, bh)

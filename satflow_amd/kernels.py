@@ -200,3 +200,109 @@ def from_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, dst: Tensor
     """Time-major NHWC -> NCHW-side tensor ``dst`` addressed with ``strides=(b,t,c)``.  sf_nhwc_to_nchw."""
     check(lib().sf_nhwc_to_nchw(T(src), nb, nt, c, h, w, dst.data_ptr(), *strides, SF_F32, stream_ptr()), "sf_nhwc_to_nchw")
     return dst
+
+
+# ----------------------------------------------------------------------------------------------
+# MetNet stack
+# ----------------------------------------------------------------------------------------------
+def gru_rec_map(hid: int) -> GemmMap:
+    """Recurrent ConvGRU conv h -> [z_h | r_h | h2]: each N block = 3 maps x 32 hidden channels."""
+    hidp = cpad(hid)
+    nblk = -(-hidp // 32)
+    nmap = []
+    for nb in range(nblk):
+        for g in range(3):
+            for j in range(32):
+                hc = nb * 32 + j
+                nmap.append(g * hid + hc if hc < hid else -1)
+    return GemmMap(nmap, _padded(hid), 3, nblk * 96)
+
+
+def gate_major(hid: int, gates: int) -> List[int]:
+    """Padded gate-major lanes [g*hidp + j] -> rows g*hid + j."""
+    hidp = cpad(hid)
+    return [g * hid + j if j < hid else -1 for g in range(gates) for j in range(hidp)]
+
+
+def custom_map(nlanes: List[int], klanes: List[int], nf: Optional[int] = None) -> GemmMap:
+    return _finish(list(nlanes), list(klanes), nf)
+
+
+def metnet_preprocess(imgs: Tensor, sat: int, crop: int) -> Tensor:
+    """imgs[B,T,C,H,W] -> frames [T*B, crop, crop, Cp] (time-major).  sf_metnet_preprocess_fwd."""
+    _hip.require_device(imgs, "imgs")
+    imgs = imgs.contiguous()
+    B, Tn, C, H, W = imgs.shape
+    cp = cpad(8 * sat + (C - sat))
+    out = torch.empty(Tn * B, crop, crop, cp, dtype=torch.float32, device=imgs.device)
+    check(lib().sf_metnet_preprocess_fwd(imgs.data_ptr(), B, Tn, C, sat, H, W, crop, T(out), SF_F32, stream_ptr()), "sf_metnet_preprocess_fwd")
+    return out
+
+
+def maxpool2_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
+    n, h, w, c = x.shape
+    y = torch.empty(n, h // 2, w // 2, c, dtype=torch.float32, device=x.device)
+    pl, pt = perm or (0, 0)
+    check(lib().sf_maxpool2_fwd(T(x), n, h, w, T(y), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_fwd")
+    return y
+
+
+def maxpool2_bwd(x: Tensor, gy: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
+    n, h, w, c = x.shape
+    gx = torch.empty_like(x)
+    pl, pt = perm or (0, 0)
+    check(lib().sf_maxpool2_bwd(T(x), T(gy), n, h, w, T(gx), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_bwd")
+    return gx
+
+
+def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int) -> Tensor:
+    """y[..., n] = x[..., :] @ W[n, :] + b.  x [..., Kp], W [N, Kp] -> y [..., out_lanes].  sf_linear_fwd."""
+    rows = x.numel() // x.shape[-1]
+    assert W.shape[1] == x.shape[-1] and W.is_contiguous()
+    y = torch.empty(*x.shape[:-1], out_lanes, dtype=torch.float32, device=x.device)
+    check(lib().sf_linear_fwd(T(x), rows, W.data_ptr(), W.shape[0], bias.data_ptr() if bias is not None else None, T(y), SF_F32,
+                              stream_ptr()), "sf_linear_fwd")
+    return y
+
+
+def linear_bwd_weight(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    rows = x.numel() // x.shape[-1]
+    K = x.shape[-1]
+    nbytes = lib().sf_linear_bwd_weight_workspace_bytes(N, K, rows)
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
+    check(lib().sf_linear_bwd_weight(T(dy), N, T(x), rows, dW.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(),
+                                     nbytes, SF_F32, stream_ptr()), "sf_linear_bwd_weight")
+    return dW, db
+
+
+def attention_core_fwd(qkv: Tensor, hid: int, heads: int) -> Tensor:
+    n, h, w, c6 = qkv.shape
+    hidp = c6 // 6
+    att = torch.empty(n, h, w, 2 * hidp, dtype=torch.float32, device=qkv.device)
+    check(lib().sf_axial_attention_core_fwd(T(qkv), n, h, w, hid, hidp, heads, T(att), SF_F32, stream_ptr()), "sf_axial_attention_core_fwd")
+    return att
+
+
+def attention_core_bwd(qkv: Tensor, datt: Tensor, hid: int, heads: int) -> Tensor:
+    n, h, w, c6 = qkv.shape
+    hidp = c6 // 6
+    dqkv = torch.empty_like(qkv)
+    check(lib().sf_axial_attention_core_bwd(T(qkv), T(datt), n, h, w, hid, hidp, heads, T(dqkv), SF_F32, stream_ptr()),
+          "sf_axial_attention_core_bwd")
+    return dqkv
+
+
+def convgru_step_fwd(gx: sfTensor, h_prev: Optional[Tensor], n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor],
+                     hidp: int, h_out: Tensor, gates: Optional[Tensor]) -> None:
+    check(lib().sf_convgru_step_fwd(gx, T(h_prev, hidp), n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
+                                    hidp, T(h_out), T(gates) if gates is not None else NULL, SF_F32, stream_ptr()), "sf_convgru_step_fwd")
+
+
+def convgru_bwd_gates(dh: Sequence[sfTensor], gates: Tensor, h_prev: Optional[Tensor], hidp: int, dgx: Tensor, dgh: Tensor,
+                      dh_direct: Optional[Tensor]) -> None:
+    dh = list(dh) + [NULL] * (3 - len(dh))
+    pixels = gates.numel() // gates.shape[-1]
+    check(lib().sf_convgru_bwd_gates(dh[0], dh[1], dh[2], T(gates), T(h_prev, hidp), pixels, hidp, T(dgx), T(dgh), T(dh_direct, hidp),
+                                     SF_F32, stream_ptr()), "sf_convgru_bwd_gates")

@@ -23,112 +23,12 @@ import torch
 from torch import nn
 
 from .. import kernels as K
+from ..functional import ConvEngine, _FromNHWC, _ToNHWC, conv3x3, nchw_to_nhwc, nhwc_to_nchw  # noqa: F401 (re-exported)
 from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, generation, require_device, sfTensor
 from .base import LightningModule, get_loss, register_model
 from .layers.ConvLSTM import CellEngine, ConvLSTMCell
 
 Tensor = torch.Tensor
-
-
-# ----------------------------------------------------------------------------------------------
-# layout ops (autograd-aware): NCHW-side tensors <-> time-major NHWC
-# ----------------------------------------------------------------------------------------------
-class _ToNHWC(torch.autograd.Function):
-    """``src`` addressed as [nb][nt] images with element strides ``(sb, st, sc)`` -> ``[nt*nb,H,W,Cp]``."""
-
-    @staticmethod
-    def forward(ctx, src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
-        src = src.contiguous()
-        ctx.meta = (src.shape, nb, nt, c, h, w, strides)
-        return K.to_nhwc(src, nb, nt, c, h, w, strides)
-
-    @staticmethod
-    def backward(ctx, g: Tensor):
-        shape, nb, nt, c, h, w, strides = ctx.meta
-        out = torch.empty(shape, dtype=torch.float32, device=g.device)
-        K.from_nhwc(g.contiguous(), nb, nt, c, h, w, out, strides)
-        return out, None, None, None, None, None, None
-
-
-class _FromNHWC(torch.autograd.Function):
-    @staticmethod
-    def forward(ctx, src: Tensor, shape: Tuple[int, ...], nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
-        ctx.meta = (nb, nt, c, h, w, strides, src.shape[-1])
-        out = torch.empty(shape, dtype=torch.float32, device=src.device)
-        return K.from_nhwc(src.contiguous(), nb, nt, c, h, w, out, strides)
-
-    @staticmethod
-    def backward(ctx, g: Tensor):
-        nb, nt, c, h, w, strides, cp = ctx.meta
-        return K.to_nhwc(g.contiguous(), nb, nt, c, h, w, strides, cp), None, None, None, None, None, None, None
-
-
-def nchw_to_nhwc(x: Tensor) -> Tensor:
-    """``[N,C,H,W] -> [N,H,W,Cp]``."""
-    n, c, h, w = x.shape
-    return _ToNHWC.apply(x, n, 1, c, h, w, (c * h * w, 0, h * w))
-
-
-def nhwc_to_nchw(x: Tensor, c: int) -> Tensor:
-    """``[N,H,W,Cp] -> [N,c,H,W]``."""
-    n, h, w, _ = x.shape
-    return _FromNHWC.apply(x, (n, c, h, w), n, 1, c, h, w, (c * h * w, 0, h * w))
-
-
-# ----------------------------------------------------------------------------------------------
-# 3x3 convolution on NHWC with fused epilogue (the Conv3d(1,3,3)+Sigmoid head, conv_lstm.py:164-169,200-201)
-# ----------------------------------------------------------------------------------------------
-class Conv3x3Engine:
-    def __init__(self, cin: int, cout: int) -> None:
-        self.cin, self.cout = cin, cout
-        self.fwd_map = K.linear_map([cin], cout)
-        self.bwd_map = K.linear_bwd_map([cin], cout, [True])
-        self.wgrad_map = K.GemmMap(K._padded(cout), K._padded(cin), 0, cpad(cout))
-        self._key, self._packed = None, {}
-
-    def packed(self, weight: Tensor, bias: Optional[Tensor], kind: str):
-        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), generation())
-        if key != self._key:
-            self._key, self._packed = key, {}
-        if kind not in self._packed:
-            w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
-            if kind == "fwd":
-                self._packed[kind] = K.pack_weights(w4, bias, self.fwd_map, transpose=False)
-            else:
-                self._packed[kind] = K.pack_weights(w4, None, self.bwd_map, transpose=True)
-        return self._packed[kind]
-
-
-class _Conv3x3Fn(torch.autograd.Function):
-    """``y = act(conv3x3(x) + b)`` on ``x[N,H,W,Cinp]`` -> ``[N,H,W,Coutp]``; act in {identity, sigmoid}."""
-
-    @staticmethod
-    def forward(ctx, eng: Conv3x3Engine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool):
-        n, H, W, _ = x.shape
-        packed, bp = eng.packed(weight, bias, "fwd")
-        y = torch.empty(n, H, W, cpad(eng.cout), dtype=torch.float32, device=x.device)
-        K.conv3x3(T(x), NULL, n, H, W, packed, bp, eng.fwd_map, T(y), SF_EPI_SIGMOID if sigmoid else SF_EPI_LINEAR)
-        ctx.eng, ctx.sigmoid = eng, sigmoid
-        ctx.save_for_backward(x, y if sigmoid else x.new_empty(0), weight, bias if bias is not None else x.new_empty(0))
-        ctx.has_bias = bias is not None
-        return y
-
-    @staticmethod
-    def backward(ctx, gy: Tensor):
-        eng: Conv3x3Engine = ctx.eng
-        x, y, weight, bias = ctx.saved_tensors
-        n, H, W, _ = x.shape
-        gy = gy.contiguous()
-        if ctx.sigmoid:
-            gy = gy * y * (1.0 - y)  # pointwise; pad lanes carry gy == 0 from the layout op
-        dx = None
-        if ctx.needs_input_grad[1]:
-            dx = torch.empty_like(x)
-            K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, None, "bwd")[0], None, eng.bwd_map, T(dx))
-        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=x.device)
-        db = torch.empty(weight.shape[0], dtype=torch.float32, device=x.device) if ctx.has_bias else None
-        K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
-        return None, dx, dw4.reshape(weight.shape), db, None
 
 
 # ----------------------------------------------------------------------------------------------
@@ -260,7 +160,7 @@ class ConvLSTM(nn.Module):
         self.decoder_2_convlstm = cell(hidden_dim)
         self.decoder_CNN = nn.Conv3d(in_channels=hidden_dim, out_channels=out_channels, kernel_size=(1, 3, 3), padding=(0, 1, 1))
         self.hidden_dim, self.out_channels, self.input_channels = hidden_dim, out_channels, input_channels
-        self._head = Conv3x3Engine(hidden_dim, out_channels)
+        self._head = ConvEngine([hidden_dim], out_channels)
 
     def cells(self) -> List[ConvLSTMCell]:
         return [self.encoder_1_convlstm, self.encoder_2_convlstm, self.decoder_1_convlstm, self.decoder_2_convlstm]
@@ -282,7 +182,7 @@ class ConvLSTM(nn.Module):
         cells = self.cells()
         params = [p for c in cells for p in (c.conv.weight, c.conv.bias)]
         hseq = _StackFn.apply([c.engine for c in cells], B, T_in, forecast_steps, xs, *params)
-        y = _Conv3x3Fn.apply(self._head, hseq, self.decoder_CNN.weight, self.decoder_CNN.bias, True)
+        y = conv3x3(self._head, hseq, self.decoder_CNN.weight, self.decoder_CNN.bias, sigmoid=True)
         O, To = self.out_channels, forecast_steps
         return _FromNHWC.apply(y, (B, O, To, H, W), B, To, O, H, W, (O * To * H * W, H * W, To * H * W))
 
@@ -333,8 +233,8 @@ class EncoderDecoderConvLSTM(LightningModule):
         return ((y_hat.detach() - y) ** 2).mean(dim=(0, 2, 3, 4))
 
     def _log_frames(self, prefix: str, frames: Tensor) -> None:
-        vals = frames.tolist()  # one sync
-        self.log_dict({f"{prefix}/frame_{f}_loss": v for f, v in enumerate(vals)}, on_step=False, on_epoch=True)
+        # logged as 0-dim device tensors: no host sync in the step (Lightning reduces them at epoch end)
+        self.log_dict({f"{prefix}/frame_{f}_loss": v for f, v in enumerate(frames.unbind(0))}, on_step=False, on_epoch=True)
 
     def training_step(self, batch, batch_idx):
         x, y = batch

@@ -1,4 +1,6 @@
 """Layer surface (mirrors reference ``satflow/models/layers/__init__.py:1-6`` for the hot-path layers)."""
+from .ConditionTime import ConditionTime
 from .ConvLSTM import ConvLSTMCell
+from .TimeDistributed import TimeDistributed
 
-__all__ = ["ConvLSTMCell"]
+__all__ = ["ConditionTime", "ConvLSTMCell", "TimeDistributed"]

@@ -1,0 +1,288 @@
+"""MetNet (preprocessor -> ConditionTime -> DownSampler -> ConvGRU -> axial attention -> 1x1 head) on the HIP kernels.
+
+The reference does not contain this network: ``LitMetNet`` wraps ``from metnet import MetNet``
+(``satflow/models/pl_metnet.py:6,46-59``), an un-vendored package.  This module supplies the same
+constructor surface and the upstream ``state_dict`` key names (``image_encoder.module.module.0.weight``
+... ``temporal_enc.rnn.cell_list.0.conv_zr.weight`` ... ``temporal_agg.0.axial_attentions.0.fn.to_q.weight``
+... ``head.bias``) following SURVEY.md Appendix A; numerical parity for it is "unpinned" (oracle/metnet.py).
+
+Execution (differs from upstream by design, same results):
+  * all ``forecast_steps`` lead times are ONE batch (upstream loops and recomputes everything per lead
+    time); BatchNorm keeps upstream's per-call statistics by reducing per lead-time group;
+  * the preprocessed frames are computed once and broadcast over the lead-time axis by the
+    convolution kernel's image-index remap; the one-hot ConditionTime planes are a tiny constant
+    second source of conv1 instead of ``forecast_steps`` materialised copies of the sequence;
+  * the ConvGRU's input convolutions run for all timesteps in one launch; only the hidden-state
+    convolution is sequential, fused with the gate arithmetic.
+"""
+from __future__ import annotations
+
+import math
+from typing import List, Optional
+
+import torch
+from torch import nn
+
+from .. import functional as F
+from .._hip import cpad, require_device
+from ..functional import ConvEngine, GRUEngine
+from .layers.ConditionTime import ConditionTime
+from .layers.TimeDistributed import TimeDistributed
+from .utils import get_conv_layer
+
+Tensor = torch.Tensor
+
+
+class MetNetPreprocessor(nn.Module):
+    """Upstream ``MetNetPreprocessor(sat_channels, crop_size, use_space2depth=True, split_input=True)`` (no parameters)."""
+
+    def __init__(self, sat_channels: int = 12, crop_size: int = 256, use_space2depth: bool = True, split_input: bool = True):
+        super().__init__()
+        if not (use_space2depth and split_input):
+            raise NotImplementedError("only the configuration MetNet itself uses (space2depth + split input) is on the path")
+        self.sat_channels, self.crop_size = sat_channels, crop_size
+
+    def forward(self, x: Tensor) -> Tensor:
+        """``x[B,T,C,H,W] -> [B,T,8*sat+(C-sat),crop,crop]`` (module-surface form; MetNet itself stays in NHWC)."""
+        from .. import kernels as K
+
+        B, T, C, H, W = x.shape
+        frames = K.metnet_preprocess(x.float(), self.sat_channels, self.crop_size)  # [T*B, S, S, Cp]
+        c = 8 * self.sat_channels + (C - self.sat_channels)
+        S = self.crop_size
+        return F._FromNHWC.apply(frames, (B, T, c, S, S), B, T, c, S, S, (T * c * S * S, c * S * S, S * S))
+
+
+class DownSampler(nn.Module):
+    """Parameter container with upstream's ``nn.Sequential`` indices (0 conv, 3 BN, 4 conv, 5 BN, 6 conv, 7 BN, 8 conv)."""
+
+    def __init__(self, in_channels: int, output_channels: int = 256, conv_type: str = "standard"):
+        super().__init__()
+        conv2d = get_conv_layer(conv_type)
+        self.output_channels = output_channels
+        self.in_channels = in_channels
+        self.module = nn.Sequential(
+            conv2d(in_channels, 160, 3, padding=1),
+            nn.MaxPool2d((2, 2), stride=2),
+            nn.Identity(),
+            nn.BatchNorm2d(160),
+            conv2d(160, output_channels, 3, padding=1),
+            nn.BatchNorm2d(output_channels),
+            conv2d(output_channels, output_channels, 3, padding=1),
+            nn.BatchNorm2d(output_channels),
+            conv2d(output_channels, output_channels, 3, padding=1),
+            nn.MaxPool2d((2, 2), stride=2),
+            nn.Identity(),
+        )
+        oc = output_channels
+        self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
+
+    def run(self, x: Tensor, groups: int, first: Optional[Tensor] = None, perm=None) -> Tensor:
+        """NHWC pipeline from conv1's output (``first``) or input ``x``; ``groups`` BatchNorm batches."""
+        m = self.module
+        y = first if first is not None else F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias)
+        y = F.batchnorm(F.maxpool2(y), m[3], groups, self.training)
+        y = F.batchnorm(F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias), m[5], groups, self.training)
+        y = F.batchnorm(F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias), m[7], groups, self.training)
+        return F.maxpool2(F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias), perm)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """``[N,C,H,W] -> [N,out,H/4,W/4]`` (module-surface form, one BatchNorm batch)."""
+        require_device(x, "x")
+        return F.nhwc_to_nchw(self.run(F.nchw_to_nhwc(x.float()), 1), self.output_channels)
+
+
+class ConvGRUCell(nn.Module):
+    """Parameter container of upstream ``ConvGRUCell`` (conv_zr over [x;h] -> z,r; conv_h1(x); conv_h2(h))."""
+
+    def __init__(self, input_dim: int, hidden_dim: int, kernel_size=(3, 3), bias: bool = True):
+        super().__init__()
+        if tuple(kernel_size) != (3, 3) or not bias:
+            raise NotImplementedError("the HIP ConvGRU implements the 3x3 / bias=True cell MetNet uses (kernel_size: 3 in metnet.yaml)")
+        self.input_dim, self.hidden_dim = input_dim, hidden_dim
+        self.conv_zr = nn.Conv2d(input_dim + hidden_dim, 2 * hidden_dim, 3, padding=1)
+        self.conv_h1 = nn.Conv2d(input_dim, hidden_dim, 3, padding=1)
+        self.conv_h2 = nn.Conv2d(hidden_dim, hidden_dim, 3, padding=1)
+        self.reset_parameters()
+        self._eng = GRUEngine(input_dim, hidden_dim)
+
+    def reset_parameters(self) -> None:
+        gain = nn.init.calculate_gain("tanh")
+        for conv in (self.conv_zr, self.conv_h1, self.conv_h2):
+            nn.init.xavier_uniform_(conv.weight, gain=gain)
+            conv.bias.data.zero_()
+
+    def regrouped(self):
+        """(Wx, bx, Wh, bh): x-part [z|r|n] and h-part [z|r|h2] of the three convolutions (autograd-tracked cats)."""
+        ci, hid = self.input_dim, self.hidden_dim
+        wzr = self.conv_zr.weight
+        Wx = torch.cat((wzr[:, :ci], self.conv_h1.weight), 0)
+        bx = torch.cat((self.conv_zr.bias, self.conv_h1.bias), 0)
+        Wh = torch.cat((wzr[:, ci:], self.conv_h2.weight), 0)
+        bh = torch.cat((torch.zeros_like(self.conv_zr.bias), self.conv_h2.bias), 0)
+        return Wx.contiguous(), bx, Wh.contiguous(), bh
+
+    def run_sequence(self, x: Tensor, T_steps: int):
+        return F.convgru_sequence(self._eng, x, T_steps, *self.regrouped())
+
+
+class ConvGRU(nn.Module):
+    def __init__(self, input_dim: int, hidden_dim: int, kernel_size=(3, 3), n_layers: int = 1, batch_first: bool = True,
+                 bias: bool = True, input_p: float = 0.2, hidden_p: float = 0.1):
+        super().__init__()
+        self.n_layers, self.batch_first, self.hidden_dim = n_layers, batch_first, hidden_dim
+        self.input_p, self.hidden_p = input_p, hidden_p
+        self.cell_list = nn.ModuleList(
+            [ConvGRUCell(input_dim if i == 0 else hidden_dim, hidden_dim, kernel_size, bias) for i in range(n_layers)]
+        )
+
+    def run(self, x: Tensor, T_steps: int, n: int):
+        """x ``[T*n,h,w,Cp]`` time-major -> (last layer's states ``[T*n,h,w,hidp]``, [last state per layer])."""
+        if self.training and self.input_p > 0:  # sequence-consistent ("RNN") dropout on the input [RECALLED upstream]
+            N, h, w, C = x.shape
+            mask = torch.nn.functional.dropout(torch.ones(1, n, h, w, C, device=x.device), self.input_p, True)
+            x = (x.view(T_steps, n, h, w, C) * mask).view(N, h, w, C)
+        last: List[Tensor] = []
+        seq = x
+        for i, cell in enumerate(self.cell_list):
+            seq, h_last = cell.run_sequence(seq, T_steps)
+            last.append(h_last)
+            if self.training and self.hidden_p > 0 and i + 1 < self.n_layers:
+                seq = torch.nn.functional.dropout(seq, self.hidden_p, True)
+        return seq, last
+
+
+class TemporalEncoder(nn.Module):
+    def __init__(self, in_channels: int, out_channels: int = 384, ks: int = 3, n_layers: int = 1):
+        super().__init__()
+        self.rnn = ConvGRU(in_channels, out_channels, (ks, ks), n_layers, batch_first=True)
+
+
+class SelfAttention(nn.Module):
+    """Parameter container of lucidrains ``SelfAttention(dim, heads)``."""
+
+    def __init__(self, dim: int, heads: int):
+        super().__init__()
+        self.heads, self.dim_heads = heads, dim // heads
+        self.to_q = nn.Linear(dim, dim, bias=False)
+        self.to_kv = nn.Linear(dim, 2 * dim, bias=False)
+        self.to_out = nn.Linear(dim, dim)
+
+
+class PermuteToFrom(nn.Module):
+    def __init__(self, permutation, fn):
+        super().__init__()
+        self.fn = fn
+        self.permutation = list(permutation)
+
+
+class AxialAttention(nn.Module):
+    """``AxialAttention(dim, dim_index=1, heads=8, num_dimensions=2)``: attention along H plus attention along W, summed."""
+
+    def __init__(self, dim: int, num_dimensions: int = 2, heads: int = 8, dim_heads=None, dim_index: int = 1, sum_axial_out: bool = True):
+        super().__init__()
+        if num_dimensions != 2 or dim_index != 1 or not sum_axial_out or dim_heads is not None:
+            raise NotImplementedError("only the configuration MetNet uses is on the path")
+        assert dim % heads == 0, "hidden_dim must be divisible by the number of heads (8)"
+        self.dim, self.heads = dim, heads
+        # upstream permutations for dim_index=1: axis H first ([0,3,2,1]), then axis W ([0,2,3,1])
+        self.axial_attentions = nn.ModuleList([PermuteToFrom(p, SelfAttention(dim, heads)) for p in ([0, 3, 2, 1], [0, 2, 3, 1])])
+
+    def run(self, x: Tensor) -> Tensor:
+        """NHWC ``[n,h,w,hidp] -> [n,h,w,hidp]``: one projection GEMM, the attention core, one output GEMM."""
+        a0, a1 = self.axial_attentions[0].fn, self.axial_attentions[1].fn
+        hid, hidp = self.dim, x.shape[-1]
+
+        def lanes(w: Tensor, parts: int) -> Tensor:  # [parts*hid, K] -> [parts*hidp, K] (pad each part's rows)
+            if hid == hidp:
+                return w
+            w = w.view(parts, hid, w.shape[1])
+            return torch.nn.functional.pad(w, (0, 0, 0, hidp - hid)).reshape(parts * hidp, -1)
+
+        w_in = torch.cat((lanes(a0.to_q.weight, 1), lanes(a0.to_kv.weight, 2), lanes(a1.to_q.weight, 1), lanes(a1.to_kv.weight, 2)), 0)
+        qkv = F.linear(x, w_in, None, 6 * hidp)
+        att = F.attention_core(qkv, hid, self.heads)  # [n,h,w,2*hidp] = [axis0 | axis1]
+        pad_k = lambda w: w if hid == hidp else torch.nn.functional.pad(w, (0, hidp - hid))
+        w_out = torch.cat((pad_k(a0.to_out.weight), pad_k(a1.to_out.weight)), 1)  # [hid, 2*hidp]
+        return F.linear(att, w_out, a0.to_out.bias + a1.to_out.bias, hidp)
+
+    def forward(self, x: Tensor) -> Tensor:
+        """``[B,C,H,W] -> [B,C,H,W]`` (module-surface form)."""
+        require_device(x, "x")
+        return F.nhwc_to_nchw(self.run(F.nchw_to_nhwc(x.float())), self.dim)
+
+
+class MetNet(nn.Module):
+    def __init__(
+        self,
+        image_encoder: str = "downsampler",
+        input_channels: int = 12,
+        sat_channels: int = 12,
+        input_size: int = 256,
+        output_channels: int = 12,
+        hidden_dim: int = 64,
+        kernel_size: int = 3,
+        num_layers: int = 1,
+        num_att_layers: int = 1,
+        forecast_steps: int = 48,
+        temporal_dropout: float = 0.2,
+        **kwargs,
+    ):
+        """Keyword surface of upstream ``metnet.MetNet`` as called from reference ``pl_metnet.py:46-59``
+        (``head=`` and other extras are swallowed by ``**kwargs`` as upstream does)."""
+        super().__init__()
+        if image_encoder not in ("downsampler", "default"):
+            raise NotImplementedError(f"image_encoder={image_encoder!r}: only the DownSampler encoder is on the hot path")
+        self.forecast_steps, self.input_channels, self.output_channels = forecast_steps, input_channels, output_channels
+        self.sat_channels, self.input_size, self.hidden_dim = sat_channels, input_size, hidden_dim
+        self.preprocessor = MetNetPreprocessor(sat_channels=sat_channels, crop_size=input_size, use_space2depth=True, split_input=True)
+        self.image_channels = input_channels - sat_channels + sat_channels * 8
+        self.drop = nn.Dropout(temporal_dropout)
+        encoder = DownSampler(self.image_channels + forecast_steps)
+        self.image_encoder = TimeDistributed(encoder)
+        self.ct = ConditionTime(forecast_steps)
+        self.temporal_enc = TemporalEncoder(encoder.output_channels, hidden_dim, ks=kernel_size, n_layers=num_layers)
+        self.temporal_agg = nn.Sequential(*[AxialAttention(dim=hidden_dim, dim_index=1, heads=8, num_dimensions=2) for _ in range(num_att_layers)])
+        self.head = nn.Conv2d(hidden_dim, output_channels, kernel_size=(1, 1))
+        # conv1 over [image lanes ; one-hot lead-time lanes]
+        self._conv1 = ConvEngine([self.image_channels, forecast_steps], 160)
+        self._onehot = {}
+
+    def _onehot_planes(self, S: int, device) -> Tensor:
+        """ConditionTime planes (reference ``layers/ConditionTime.py:5-10``): ``[L, S, S, cpad(L)]``, lane i of image i is 1."""
+        key = (S, str(device))
+        if key not in self._onehot:
+            L = self.forecast_steps
+            planes = torch.zeros(L, S, S, cpad(L), dtype=torch.float32, device=device)
+            planes[torch.arange(L), :, :, torch.arange(L)] = 1.0
+            self._onehot[key] = planes
+        return self._onehot[key]
+
+    def forward(self, imgs: Tensor, lead_time: int = 0) -> Tensor:
+        """``imgs[B,T,C,4*input_size,4*input_size] -> [B, forecast_steps, output_channels, input_size//4, input_size//4]``."""
+        from .. import kernels as K
+
+        require_device(imgs, "imgs")
+        B, Tn, C, H, W = imgs.shape
+        if C != self.input_channels:
+            raise RuntimeError(f"expected {self.input_channels} input channels, got {C}")
+        L, S = self.forecast_steps, self.input_size
+        enc: DownSampler = self.image_encoder.module
+        F_ = Tn * B
+        frames = K.metnet_preprocess(imgs.float(), self.sat_channels, S)  # [T*B, S, S, Cimg_p], computed once
+        # conv1 for every (lead time, frame): image (l*F + f) reads frame f and one-hot plane l
+        c1 = enc.module[0]
+        y1 = F.conv3x3_broadcast(self._conv1, frames, self._onehot_planes(S, imgs.device), c1.weight, c1.bias, L * F_, (0, F_), (F_, 0))
+        # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
+        # images from [lead][time][batch] to [time][lead][batch] for the recurrent part
+        feat = enc.run(None, L, first=y1, perm=(L, Tn))  # [T*L*B, S/4, S/4, 256]
+        if self.training and self.drop.p > 0:
+            feat = torch.nn.functional.dropout(feat, self.drop.p, True)
+        _, last = self.temporal_enc.rnn.run(feat, Tn, L * B)
+        a = last[-1]  # [L*B, s, s, hidp]
+        for layer in self.temporal_agg:
+            a = layer.run(a)
+        hw = self.head.weight.view(self.output_channels, self.hidden_dim)
+        o = F.linear(a, hw, self.head.bias)  # [L*B, s, s, outp]
+        s, O = S // 4, self.output_channels
+        return F._FromNHWC.apply(o, (B, L, O, s, s), B, L, O, s, s, (L * O * s * s, O * s * s, s * s))

@@ -50,4 +50,5 @@ def assert_close(actual, expected, name, rtol=RTOL, atol=ATOL, grad=False):
         f"{name}: {int(bad.sum())}/{a.numel()} elements outside rtol={rtol} atol={atol}; "
         f"max abs err {err.max():.3e} at |ref| {e.flatten()[err.argmax()].abs():.3e}; rel L2 {rel_l2:.3e}"
     )
-    assert rel_l2 < 10 * rtol, f"{name}: relative L2 error {rel_l2:.3e}"
+    if float(e.norm()) > 100 * atol * e.numel() ** 0.5:  # skip for tensors that are numerically zero (e.g. d(bias) in front of BatchNorm)
+        assert rel_l2 <= 10 * rtol, f"{name}: relative L2 error {rel_l2:.3e}"

@@ -28,7 +28,7 @@ def test_library_loaded():
 @pytest.mark.parametrize("sigmoid", [False, True])
 def test_conv3x3_vs_oracle(device, cin, cout, n, h, w, sigmoid):
     """sf_conv3x3_fwd / bwd-data / sf_conv3x3_bwd_weight vs torch CPU conv2d (fp32)."""
-    from satflow_amd.models.conv_lstm import Conv3x3Engine, _Conv3x3Fn, nchw_to_nhwc, nhwc_to_nchw
+    from satflow_amd.functional import ConvEngine, conv3x3, nchw_to_nhwc, nhwc_to_nchw
 
     g = torch.Generator().manual_seed(cin * 1000 + cout)
     x = torch.randn(n, cin, h, w, generator=g)
@@ -41,8 +41,8 @@ def test_conv3x3_vs_oracle(device, cin, cout, n, h, w, sigmoid):
     (ref * cot).sum().backward()
 
     xd, wd, bd = (t.to(device).requires_grad_() for t in (x, wt, b))
-    eng = Conv3x3Engine(cin, cout)
-    y = nhwc_to_nchw(_Conv3x3Fn.apply(eng, nchw_to_nhwc(xd), wd, bd, sigmoid), cout)
+    eng = ConvEngine([cin], cout)
+    y = nhwc_to_nchw(conv3x3(eng, nchw_to_nhwc(xd), wd, bd, sigmoid), cout)
     (y * cot.to(device)).sum().backward()
     assert_close(y, ref, "conv3x3 out")
     assert_close(xd.grad, xr.grad, "conv3x3 dx", grad=True)

@@ -1,0 +1,290 @@
+"""GPU parity of the MetNet stack: every HIP op and the whole model against oracle/metnet.py (torch CPU fp32).
+
+Parity for these blocks is "unpinned" (the upstream packages are not importable, see oracle/metnet.py):
+the oracle restates the published algorithm; the reference-held shape/NaN test is reproduced at the end.
+fp32, rtol 1e-4 / atol 1e-5.
+"""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import assert_close
+from oracle import metnet as M
+
+pytestmark = pytest.mark.gpu
+
+
+def _g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+@pytest.mark.parametrize("B,T,C,sat,raw", [(2, 3, 13, 12, 64), (1, 2, 5, 4, 32), (1, 1, 12, 12, 128)])
+def test_preprocess(device, B, T, C, sat, raw):
+    from satflow_amd.models.metnet import MetNetPreprocessor
+
+    x = torch.randn(B, T, C, raw, raw, generator=_g(1))
+    ref = M.preprocess(x, sat, raw // 4)
+    out = MetNetPreprocessor(sat, raw // 4)(x.to(device))
+    assert_close(out, ref, "preprocess", rtol=1e-6, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,h,w,c", [(3, 8, 8, 16), (2, 16, 32, 160), (4, 6, 10, 48)])
+def test_maxpool(device, n, h, w, c):
+    from satflow_amd import functional as F
+
+    x = torch.randn(n, c, h, w, generator=_g(2))
+    cot = torch.randn(n, c, h // 2, w // 2, generator=_g(3))
+    xr = x.clone().requires_grad_()
+    ref = TF.max_pool2d(xr, 2)
+    (ref * cot).sum().backward()
+    xd = x.to(device).requires_grad_()
+    y = F.nhwc_to_nchw(F.maxpool2(F.nchw_to_nhwc(xd)), c)
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "maxpool", rtol=0, atol=0)
+    assert_close(xd.grad, xr.grad, "maxpool dx", rtol=0, atol=0)
+
+
+def test_maxpool_permutation(device):
+    from satflow_amd import functional as F
+
+    L, T, B, c = 3, 2, 2, 16
+    x = torch.randn(L * T * B, c, 4, 4, generator=_g(4))
+    cot = torch.randn(T * L * B, c, 2, 2, generator=_g(5))
+    xr = x.clone().requires_grad_()
+    ref = TF.max_pool2d(xr, 2).view(L, T, B, c, 2, 2).transpose(0, 1).reshape(T * L * B, c, 2, 2)
+    (ref * cot).sum().backward()
+    xd = x.to(device).requires_grad_()
+    y = F.nhwc_to_nchw(F.maxpool2(F.nchw_to_nhwc(xd), (L, T)), c)
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "maxpool perm", rtol=0, atol=0)
+    assert_close(xd.grad, xr.grad, "maxpool perm dx", rtol=0, atol=0)
+
+
+@pytest.mark.parametrize("groups,n,h,w,c", [(1, 4, 8, 8, 16), (3, 6, 16, 16, 160), (4, 8, 4, 4, 40)])
+def test_batchnorm_train(device, groups, n, h, w, c):
+    from satflow_amd import functional as F
+
+    x = torch.randn(n, c, h, w, generator=_g(5)) * 2 + 0.7
+    cot = torch.randn(n, c, h, w, generator=_g(6))
+    bn_ref = torch.nn.BatchNorm2d(c)
+    with torch.no_grad():
+        bn_ref.weight.copy_(torch.rand(c, generator=_g(7)) + 0.5)
+        bn_ref.bias.copy_(torch.randn(c, generator=_g(8)))
+    bn_dev = torch.nn.BatchNorm2d(c)
+    bn_dev.load_state_dict(bn_ref.state_dict())
+    bn_dev = bn_dev.to(device)
+    xr = x.clone().requires_grad_()
+    per = n // groups
+    ref = torch.cat([bn_ref(xr[g * per:(g + 1) * per]) for g in range(groups)], 0)  # one call per lead-time group, in order
+    (ref * cot).sum().backward()
+    xd = x.to(device).requires_grad_()
+    y = F.nhwc_to_nchw(F.batchnorm(F.nchw_to_nhwc(xd), bn_dev, groups, True), c)
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "bn out")
+    assert_close(xd.grad, xr.grad, "bn dx", grad=True)
+    assert_close(bn_dev.weight.grad, bn_ref.weight.grad, "bn dgamma", grad=True)
+    assert_close(bn_dev.bias.grad, bn_ref.bias.grad, "bn dbeta", grad=True)
+    assert_close(bn_dev.running_mean, bn_ref.running_mean, "running_mean")
+    assert_close(bn_dev.running_var, bn_ref.running_var, "running_var")
+    assert int(bn_dev.num_batches_tracked) == groups
+    # eval mode uses the running statistics
+    bn_ref.eval()
+    with torch.no_grad():
+        ye = F.nhwc_to_nchw(F.batchnorm(F.nchw_to_nhwc(x.to(device)), bn_dev, 1, False), c)
+        assert_close(ye, bn_ref(x), "bn eval")
+
+
+@pytest.mark.parametrize("rows,K,N", [(300, 16, 12), (1000, 64, 384), (77, 128, 64), (4096, 32, 96)])
+def test_linear(device, rows, K, N):
+    from satflow_amd import functional as F
+
+    x = torch.randn(rows, K, generator=_g(9))
+    w = torch.randn(N, K, generator=_g(10)) / K**0.5
+    b = torch.randn(N, generator=_g(11))
+    cot = torch.randn(rows, N, generator=_g(12))
+    xr, wr, br = (t.clone().requires_grad_() for t in (x, w, b))
+    ref = xr @ wr.t() + br
+    (ref * cot).sum().backward()
+    xd, wd, bd = (t.to(device).requires_grad_() for t in (x, w, b))
+    y = F.linear(xd, wd, bd)[..., :N]
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "linear")
+    assert_close(xd.grad, xr.grad, "linear dx", grad=True)
+    assert_close(wd.grad, wr.grad, "linear dW", grad=True)
+    assert_close(bd.grad, br.grad, "linear db", grad=True)
+
+
+def _attn_params(module, prefix="temporal_agg.0"):
+    return {f"{prefix}.{k}": v.detach().cpu().clone().requires_grad_() for k, v in module.state_dict().items()}
+
+
+@pytest.mark.parametrize("n,hid,h,w", [(2, 64, 16, 16), (3, 32, 4, 6), (1, 16, 2, 2), (2, 40, 5, 3)])
+def test_axial_attention(device, n, hid, h, w):
+    from satflow_amd.models.metnet import AxialAttention
+
+    torch.manual_seed(n * 100 + hid)
+    layer = AxialAttention(hid)
+    with torch.no_grad():
+        for p in layer.parameters():
+            p.mul_(3.0)  # sharpen the softmax so its gradient matters
+    x = torch.randn(n, hid, h, w, generator=_g(13))
+    cot = torch.randn(n, hid, h, w, generator=_g(14))
+    P = _attn_params(layer)
+    xr = x.clone().requires_grad_()
+    ref = M.axial_attention(xr, P, "temporal_agg.0")
+    (ref * cot).sum().backward()
+    layer = layer.to(device)
+    xd = x.to(device).requires_grad_()
+    y = layer(xd)
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "attention out")
+    assert_close(xd.grad, xr.grad, "attention dx", grad=True)
+    for k, p in layer.named_parameters():
+        assert_close(p.grad, P[f"temporal_agg.0.{k}"].grad, f"attention d{k}", grad=True)
+
+
+@pytest.mark.parametrize("B,T,cin,hid,h,w,layers", [(2, 3, 16, 16, 4, 4, 1), (1, 4, 40, 24, 5, 7, 2), (3, 2, 256, 64, 16, 16, 1)])
+def test_convgru_sequence(device, B, T, cin, hid, h, w, layers):
+    from satflow_amd import functional as F
+    from satflow_amd.models.metnet import ConvGRU
+
+    torch.manual_seed(B + cin)
+    rnn = ConvGRU(cin, hid, (3, 3), layers)
+    with torch.no_grad():
+        for name, p in rnn.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=_g(15)) * 0.3)
+    rnn.eval()  # dropouts off
+    x = torch.randn(B, T, cin, h, w, generator=_g(16))
+    cot_last = torch.randn(B, hid, h, w, generator=_g(17))
+    cot_seq = torch.randn(B, T, hid, h, w, generator=_g(18)) * 0.5
+    P = {f"rnn.{k}": v.detach().clone().requires_grad_() for k, v in rnn.state_dict().items()}
+    xr = x.clone().requires_grad_()
+    seq_ref, last_ref = M.convgru(xr, P, "rnn", layers)
+    ((last_ref[-1] * cot_last).sum() + (seq_ref * cot_seq).sum()).backward()
+
+    rnn = rnn.to(device)
+    xd = x.to(device).requires_grad_()
+    xs = F._ToNHWC.apply(xd, B, T, cin, h, w, (T * cin * h * w, cin * h * w, h * w))  # [T*B, h, w, Cp]
+    seq, last = rnn.run(xs, T, B)
+    seq_nchw = F._FromNHWC.apply(seq, (B, T, hid, h, w), B, T, hid, h, w, (T * hid * h * w, hid * h * w, h * w))
+    last_nchw = F.nhwc_to_nchw(last[-1], hid)
+    ((last_nchw * cot_last.to(device)).sum() + (seq_nchw * cot_seq.to(device)).sum()).backward()
+    assert_close(seq_nchw, seq_ref, "gru seq")
+    assert_close(last_nchw, last_ref[-1], "gru last")
+    assert_close(xd.grad, xr.grad, "gru dx", grad=True)
+    for k, p in rnn.named_parameters():
+        assert_close(p.grad, P[f"rnn.{k}"].grad, f"gru d{k}", grad=True)
+
+
+def _metnet_pair(device, cfg, seed=0):
+    from satflow_amd.models import MetNet
+
+    torch.manual_seed(seed)
+    net = MetNet(**cfg, temporal_dropout=0.0)
+    net.temporal_enc.rnn.input_p = 0.0
+    with torch.no_grad():  # non-trivial BN affine + GRU biases
+        for name, p in net.named_parameters():
+            if "module.module" in name and p.dim() == 1 and name.endswith("weight"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape, generator=_g(19)))
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=_g(20)))
+    P = {k: v.detach().clone().requires_grad_() for k, v in net.state_dict().items() if v.dtype == torch.float32 and "running" not in k}
+    return net.to(device), P
+
+
+class _PoolMargins:
+    """Records the smallest top-1/top-2 gap of every 2x2 max-pool window the oracle evaluates.
+
+    Max pooling has a discontinuous gradient: when two candidates of a window agree to ~1e-6 relative,
+    fp32 rounding decides the argmax and BatchNorm spreads that one flip over the whole batch (observed:
+    one flipped window in 24576 -> 1e-3 relative change of every encoder gradient, on CPU fp32 vs fp64 just
+    the same).  A parity comparison is only well posed on inputs without such near-ties.
+    """
+
+    def __enter__(self):
+        self.min_gap, self._orig = float("inf"), TF.max_pool2d
+
+        def rec(t, k, *a, **kw):
+            n, c, h, w = t.shape
+            win = t.detach().view(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
+            top = win.topk(2, dim=-1).values
+            self.min_gap = min(self.min_gap, float(((top[..., 0] - top[..., 1]) / top[..., 0].abs().clamp_min(1.0)).min()))
+            return self._orig(t, k, *a, **kw)
+
+        M.F.max_pool2d = rec
+        return self
+
+    def __exit__(self, *exc):
+        M.F.max_pool2d = self._orig
+
+
+@pytest.mark.parametrize(
+    "cfg,B,T",
+    [
+        (dict(input_channels=5, sat_channels=4, input_size=8, output_channels=2, hidden_dim=16, forecast_steps=3), 1, 2),
+        (dict(input_channels=13, sat_channels=12, input_size=16, output_channels=3, hidden_dim=32, forecast_steps=4, num_att_layers=2), 1, 2),
+    ],
+)
+def test_metnet_train_step_vs_oracle(device, cfg, B, T):
+    """Whole MetNet forward + backward (training-mode BatchNorm, dropout off) vs the oracle; every parameter gradient."""
+    net, P = _metnet_pair(device, cfg)
+    raw = cfg["input_size"] * 4
+    s = cfg["input_size"] // 4
+    cot = torch.randn(B, cfg["forecast_steps"], cfg["output_channels"], s, s, generator=_g(22))
+    for seed in range(21, 40):  # first seeded input whose pooling windows have no fp32-level near-tie
+        x = torch.randn(B, T, cfg["input_channels"], raw, raw, generator=_g(seed))
+        for p in P.values():
+            p.grad = None
+        with _PoolMargins() as pm:
+            ref = M.metnet_forward(x, P, sat_channels=cfg["sat_channels"], input_size=cfg["input_size"],
+                                   forecast_steps=cfg["forecast_steps"], num_att_layers=cfg.get("num_att_layers", 1))
+        if pm.min_gap > 1e-5:  # ~10x the fp32 rounding noise of the convolution outputs
+            break
+    else:
+        pytest.fail("no well-posed input found")
+    (ref * cot).sum().backward()
+    net.train()
+    out = net(x.to(device))
+    assert out.shape == ref.shape
+    assert_close(out, ref, "metnet out")
+    (out * cot.to(device)).sum().backward()
+    for k, p in net.named_parameters():
+        assert_close(p.grad, P[k].grad, f"d{k}", grad=True)
+
+
+def test_metnet_eval_and_reference_shape_pin(device):
+    """Reference tests/test_models.py:42-61: metnet.yaml config, x[2,12,16,256,256] -> (2,24,1,16,16), eval, no NaN;
+    plus eval-mode (running-statistics BatchNorm) parity with the oracle on a reduced size."""
+    import os
+
+    from conftest import GOLDEN
+    from satflow_amd.config import load_config
+    from satflow_amd.models import LitMetNet
+
+    config = load_config(os.path.join(GOLDEN, "configs", "metnet.yaml"))
+    config.pop("_target_")
+    model = LitMetNet(**config).to(device)
+    x = torch.randn((2, 12, config["input_channels"], config["input_size"] * 4, config["input_size"] * 4))
+    model.eval()
+    with torch.no_grad():
+        out = model(x.to(device))
+    assert out.size() == (2, config["forecast_steps"], config["output_channels"], config["input_size"] // 4, config["input_size"] // 4)
+    assert not torch.isnan(out).any(), "Output included NaNs"
+
+    cfg = dict(input_channels=5, sat_channels=4, input_size=8, output_channels=2, hidden_dim=16, forecast_steps=3)
+    net, P = _metnet_pair(device, cfg, seed=5)
+    sd = net.state_dict()
+    stats = {}
+    for i in ("3", "5", "7"):
+        pre = f"image_encoder.module.module.{i}"
+        with torch.no_grad():
+            sd[f"{pre}.running_mean"].copy_(0.3 * torch.randn(sd[f"{pre}.running_mean"].shape, generator=_g(int(i))))
+            sd[f"{pre}.running_var"].copy_(0.5 + torch.rand(sd[f"{pre}.running_var"].shape, generator=_g(10 + int(i))))
+        stats[i] = (sd[f"{pre}.running_mean"].cpu(), sd[f"{pre}.running_var"].cpu())
+    xs = torch.randn(2, 2, 5, 32, 32, generator=_g(23))
+    net.eval()
+    with torch.no_grad():
+        got = net(xs.to(device))
+        ref = M.metnet_forward(xs, {k: v.detach() for k, v in P.items()}, sat_channels=4, input_size=8, forecast_steps=3, bn_stats=stats)
+    assert_close(got, ref, "metnet eval")
