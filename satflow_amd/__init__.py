@@ -1,3 +1,5 @@
 """satflow_amd: MI355X-native hot path of openclimatefix/satflow (ConvLSTM encoder-decoder and the
 MetNet-style stack) behind the reference's model surface.  See DESIGN.md / INTEGRATION.md."""
 __version__ = "0.1.0"
+
+from ._hip import compute_dtype_name, set_compute_dtype  # noqa: E402,F401

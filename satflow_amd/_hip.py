@@ -130,8 +130,27 @@ def bump_generation() -> None:
     _GENERATION[0] += 1
 
 
-def generation() -> int:
-    return _GENERATION[0]
+def generation():
+    """Cache key component: parameter generation + the compute dtype the packed images were built for."""
+    return (_GENERATION[0], _COMPUTE[0])
+
+
+# Compute dtype of the convolution kernels: SF_F32 = exact-fp32 MFMA (parity mode, rtol 1e-4);
+# SF_BF16 = bf16 operands / fp32 accumulate / fp32 storage (the arithmetic of torch.autocast(bfloat16)
+# around the reference's Conv2d; throughput mode).  Weight gradients stay on the fp32 pipe.
+_COMPUTE = [SF_F32]
+
+
+def set_compute_dtype(name: str) -> None:
+    _COMPUTE[0] = {"f32": SF_F32, "fp32": SF_F32, "float32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16}[name]
+
+
+def compute_dtype() -> int:
+    return _COMPUTE[0]
+
+
+def compute_dtype_name() -> str:
+    return "bf16" if _COMPUTE[0] == SF_BF16 else "f32"
 
 
 def cpad(c: int) -> int:

@@ -1,0 +1,228 @@
+// 3x3 "same" convolution as an implicit GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16),
+// fp32 activations in HBM (NHWC), bf16 operands, fp32 accumulate, fp32 outputs - the arithmetic of
+// torch.autocast(bfloat16) around the reference's Conv2d, with the epilogues of conv_common.h.
+//
+// Workgroup = WAVES waves (8 for large images: a 32x16-pixel tile; 4: 16x16), each wave owns 4 tile
+// rows = two 32-pixel M fragments and all NF 32-channel N fragments (2*NF accumulator tiles).
+// K loop over 16-channel chunks; per chunk ALL 9 taps are resident in LDS:
+//   * weights: the packed bf16 image is already the LDS image (32-byte rows, 16-byte halves swapped
+//     on rows with bit 3 set so that a ds_read_b128 lane group hits 16 distinct bank slots); it is
+//     streamed by LDS-DMA (global_load_lds_dwordx4, no VGPRs) into the other half of a double buffer
+//     while the current chunk computes;
+//   * input halo tile: fp32 global loads issued before the chunk's MFMAs, converted to bf16
+//     (v_cvt_pk_bf16_f32, RNE) and written after them into the other input buffer (halves swapped on
+//     odd halo rows - conflict-free for the 2-rows-per-fragment access pattern).
+// One barrier per chunk; 18*NF MFMAs (32 cycles each) per wave between barriers.
+#include "conv_common.h"
+
+namespace {
+
+using namespace sfconv;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+constexpr int HALO_W = TILE_W + 2;  // 18
+constexpr int PIX_B = 32;           // bytes per pixel / per weight row in LDS (16 bf16)
+
+template <int WAVES, int NF, int EPI>
+__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
+  constexpr int NB = 32 * NF;
+  constexpr int THREADS = WAVES * 64;
+  constexpr int TH = 4 * WAVES;            // tile rows
+  constexpr int HALO_H = TH + 2;
+  constexpr int IN_B = HALO_H * HALO_W * PIX_B;
+  constexpr int W_B = 9 * NB * PIX_B;
+  constexpr int PIECES = HALO_H * HALO_W * 2;                 // 16-byte bf16 pieces of the halo tile
+  constexpr int NPIECE = (PIECES + THREADS - 1) / THREADS;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * W_B + 2 * IN_B];
+  char* lds_w = lds;
+  char* lds_in = lds + 2 * W_B;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, kh = lane >> 5;
+  int tile = blockIdx.x;
+  const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+  const int ty = tile % p.tiles_y;
+  const int n = tile / p.tiles_y;
+  const int nb = blockIdx.y;
+  const int x0 = tx * TILE_W, y0 = ty * TH;
+
+  f32x16 acc[2][NF];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+
+  const int ch0 = p.src0 ? p.c0 / KC : 0;
+  const int ch1 = p.src1 ? p.c1 / KC : 0;
+  const int c0_chunks = p.c0 / KC;
+  const int nch = ch0 + ch1;
+
+  f32x8 inreg[NPIECE];
+
+  auto issue_weights = [&](int ci, int buf) {
+    const int chunk = ci < ch0 ? ci : c0_chunks + (ci - ch0);
+    const char* src = (const char*)p.wp + ((size_t)nb * p.chunks_total + chunk) * W_B + lane * 16;
+    char* dst = lds_w + buf * W_B;
+    for (int i = wave; i < 9 * NF; i += WAVES)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+  };
+  auto load_input = [&](int ci) {
+    const float* src; int cbase, stride, ns;
+    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
+    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int pc = tid + j * THREADS;
+      const int pix = pc >> 1, half = pc & 1;
+      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        v = *reinterpret_cast<const f32x8*>(src + ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + half * 8);
+      inreg[j] = v;
+    }
+  };
+  auto store_input = [&](int buf) {
+    char* dst = lds_in + buf * IN_B;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int pc = tid + j * THREADS;
+      const int pix = pc >> 1, half = pc & 1;
+      const int iy = pix / HALO_W;
+      if (pc < PIECES)
+        *reinterpret_cast<bf16x8*>(dst + pix * PIX_B + 16 * (half ^ (iy & 1))) = __builtin_convertvector(inreg[j], bf16x8);
+    }
+  };
+
+  if (nch > 0) {
+    issue_weights(0, 0);
+    load_input(0);
+    store_input(0);
+  }
+
+  // per-lane LDS offsets
+  const int rowpar = (r >> 4) & 1;
+  const int a_lane = ((4 * wave + (r >> 4)) * HALO_W + (r & 15)) * PIX_B;
+  const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);  // by parity of ky
+  const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
+
+  for (int ci = 0; ci < nch; ++ci) {
+    const int cur = ci & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weight DMA has landed (LDS-DMA is not covered by the barrier)
+    __syncthreads();
+    if (ci + 1 < nch) {
+      issue_weights(ci + 1, cur ^ 1);
+      load_input(ci + 1);
+    }
+    const char* inb = lds_in + cur * IN_B + a_lane;
+    const char* wb = lds_w + cur * W_B + b_lane;
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int ky = tap / 3, kx = tap % 3;
+      bf16x8 a[2], b[NF];
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+        a[mf] = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO_W + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+    }
+    if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
+  }
+
+  conv_epilogue<NF, EPI>(acc, p, n, nb, y0, x0, wave, r, kh);
+}
+
+// ---- weight repack (bf16 LDS image) ----------------------------------------------------------
+__global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int I, const int* __restrict__ nmap, int Np,
+                                         const int* __restrict__ kmap, int Kp, int NB, int transpose, __bf16* __restrict__ packed,
+                                         const float* __restrict__ bias, float* __restrict__ bias_packed) {
+  const size_t total = (size_t)Np * Kp * 9;
+  const int chunks = Kp / KC;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
+    // logical element e -> [nblk][chunk][tap][row][k16]
+    size_t t = e;
+    const int k16 = t % KC; t /= KC;
+    const int row = t % NB; t /= NB;
+    const int tap = t % 9; t /= 9;
+    const int chunk = t % chunks;
+    const int nblk = t / chunks;
+    const int nn = nmap[nblk * NB + row];
+    const int kk = kmap[chunk * KC + k16];
+    float v = 0.f;
+    if (nn >= 0 && kk >= 0) v = transpose ? w[((size_t)kk * I + nn) * 9 + (8 - tap)] : w[((size_t)nn * I + kk) * 9 + tap];
+    // physical position: the two 8-element halves of a row are swapped on rows with bit 3 set
+    const int half = (k16 >> 3) ^ ((row >> 3) & 1);
+    const size_t base = e - k16;
+    packed[base + half * 8 + (k16 & 7)] = (__bf16)v;
+  }
+  if (bias_packed && blockIdx.x == 0)
+    for (int i = threadIdx.x; i < Np; i += blockDim.x) {
+      const int nn = nmap[i];
+      bias_packed[i] = (bias && nn >= 0) ? bias[nn] : 0.f;
+    }
+}
+
+template <int WAVES, int EPI>
+int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
+  ConvParams p = p0;
+  constexpr int TH = 4 * WAVES;
+  p.tiles_x = (p.W + TILE_W - 1) / TILE_W;
+  p.tiles_y = (p.H + TH - 1) / TH;
+  dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(WAVES * 64);
+  if constexpr (EPI == EPI_LSTM) {
+    if (nf != 4) { sf_set_error("bf16 conv: LSTM epilogue needs nf=4"); return 1; }
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI>), grid, block, 0, st, p);
+  } else if constexpr (EPI == EPI_GRU) {
+    if (nf != 3) { sf_set_error("bf16 conv: GRU epilogue needs nf=3"); return 1; }
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI>), grid, block, 0, st, p);
+  } else {
+    switch (nf) {
+      case 1: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 1, EPI>), grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 2, EPI>), grid, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI>), grid, block, 0, st, p); break;
+      case 4: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI>), grid, block, 0, st, p); break;
+      case 5: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 5, EPI>), grid, block, 0, st, p); break;
+      default: sf_set_error("bf16 conv: unsupported nf=%d", nf); return 1;
+    }
+  }
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { sf_set_error("conv3x3_bf16: launch failed: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}
+
+template <int EPI>
+int launch_e(const ConvParams& p, int nf, int nblk, hipStream_t st) {
+  // 8-wave 32x16 tiles when the image has at least 32 rows to fill them, else 4-wave 16x16 tiles
+  return p.H > 16 ? launch_w<8, EPI>(p, nf, nblk, st) : launch_w<4, EPI>(p, nf, nblk, st);
+}
+
+}  // namespace
+
+int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st) {
+  switch (epi) {
+    case EPI_LINEAR: return launch_e<EPI_LINEAR>(p, nf, nblk, st);
+    case EPI_SIGMOID: return launch_e<EPI_SIGMOID>(p, nf, nblk, st);
+    case EPI_LSTM: return launch_e<EPI_LSTM>(p, nf, nblk, st);
+    case EPI_GRU: return launch_e<EPI_GRU>(p, nf, nblk, st);
+  }
+  sf_set_error("bf16 conv: unknown epilogue %d", epi);
+  return 1;
+}
+
+void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
+                          void* packed, const float* bias, float* bias_packed, hipStream_t st) {
+  const size_t total = (size_t)Np * Kp * 9;
+  const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+  hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, O, I, nmap, Np, kmap, Kp, NB, transpose,
+                     (__bf16*)packed, bias, bias_packed);
+}

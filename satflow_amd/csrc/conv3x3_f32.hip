@@ -14,37 +14,15 @@
 //
 // Exact fp32: the MFMA is a k-ordered fmaf chain (no reduced precision anywhere), which is what
 // lets this path meet the reference's rtol 1e-4 / atol 1e-5 through an 18-step recurrence.
-#include "sf_common.h"
+#include "conv_common.h"
 
 namespace {
 
+using namespace sfconv;
+
 constexpr int TILE = 16;          // output tile edge (pixels)
 constexpr int HALO = TILE + 2;    // staged tile edge
-constexpr int KC = 16;            // input channels per K chunk
 constexpr int PITCH = KC + 4;     // LDS floats per pixel / per weight row (80 B)
-
-enum { EPI_LINEAR = 0, EPI_SIGMOID = 1, EPI_LSTM = 2, EPI_GRU = 3 };
-
-struct ConvParams {
-  const float* src0; const float* src1;
-  int c0, c1, s0, s1;
-  int idiv0, imod0, idiv1, imod1;  // image-index remap of the sources (see sfTensor)
-  int N, H, W, tiles_x, tiles_y;
-  const float* wp;     // [nblk][chunks][9][32*NF][16]
-  const float* bias;   // [nblk*32*NF] or null
-  int chunks_total;    // (c0_decl + c1_decl)/16 of the packed image
-  // linear / sigmoid epilogue
-  float* out; int out_c, out_s;
-  // lstm epilogue
-  const float* c_prev; int cprev_s;
-  float* c_out; int cout_s;
-  float* h_out; int hout_s;
-  float* gates; int gates_s;
-  int hidp;
-  // gru epilogue (h_out / gates / hidp shared with lstm): precomputed x-part [z|r|n] and previous state
-  const float* gx; int gx_s;
-  const float* h_prev; int hprev_s;
-};
 
 template <int NF, int EPI>
 __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvParams p) {
@@ -86,7 +64,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvParams p)
   };
   auto load_w = [&](int s) {
     const int tap = s % 9;
-    const float* wsrc = p.wp + (((size_t)nb * p.chunks_total + chunk_of(s)) * 9 + tap) * (NB * KC);
+    const float* wsrc = (const float*)p.wp + (((size_t)nb * p.chunks_total + chunk_of(s)) * 9 + tap) * (NB * KC);
 #pragma unroll
     for (int j = 0; j < WPIECES; ++j) {
       const int pc = tid + j * 256;
@@ -149,87 +127,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_f32_kernel(const ConvParams p)
     }
   }
 
-  // ---- epilogue ----
-  if constexpr (EPI == EPI_LSTM) {
-    static_assert(NF == 4, "LSTM epilogue needs the 4 gates in one wave");
-    const int hc = nb * 32 + r;
-    if (hc < p.hidp) {
-      float bi = 0.f, bf = 0.f, bo = 0.f, bg = 0.f;
-      if (p.bias) {
-        bi = p.bias[nb * NB + r]; bf = p.bias[nb * NB + 32 + r];
-        bo = p.bias[nb * NB + 64 + r]; bg = p.bias[nb * NB + 96 + r];
-      }
-#pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int rr = frag_row(reg, kh);
-          const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
-          if (py < p.H && px < p.W) {
-            const size_t pix = (size_t)(n * p.H + py) * p.W + px;
-            const float gi = sf_sigmoid(acc[mf][0][reg] + bi);
-            const float gf = sf_sigmoid(acc[mf][1][reg] + bf);
-            const float go = sf_sigmoid(acc[mf][2][reg] + bo);
-            const float gg = tanhf(acc[mf][3][reg] + bg);
-            const float cp = p.c_prev ? p.c_prev[pix * p.cprev_s + hc] : 0.f;
-            const float cn = gf * cp + gi * gg;
-            p.c_out[pix * p.cout_s + hc] = cn;
-            p.h_out[pix * p.hout_s + hc] = go * tanhf(cn);
-            if (p.gates) {
-              float* gp = p.gates + pix * p.gates_s + hc;
-              gp[0] = gi; gp[p.hidp] = gf; gp[2 * p.hidp] = go; gp[3 * p.hidp] = gg;
-            }
-          }
-        }
-    }
-  } else if constexpr (EPI == EPI_GRU) {
-    static_assert(NF == 3, "GRU epilogue: z, r and the candidate's h-part in one wave");
-    const int hc = nb * 32 + r;
-    if (hc < p.hidp) {
-      const float b2 = p.bias ? p.bias[nb * NB + 64 + r] : 0.f;
-#pragma unroll
-      for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-        for (int reg = 0; reg < 16; ++reg) {
-          const int rr = frag_row(reg, kh);
-          const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
-          if (py < p.H && px < p.W) {
-            const size_t pix = (size_t)(n * p.H + py) * p.W + px;
-            const float* gx = p.gx + pix * p.gx_s + hc;
-            const float z = sf_sigmoid(acc[mf][0][reg] + gx[0]);
-            const float rg = sf_sigmoid(acc[mf][1][reg] + gx[p.hidp]);
-            const float h2 = acc[mf][2][reg] + b2;
-            const float cand = tanhf(gx[2 * p.hidp] + rg * h2);
-            const float hp = p.h_prev ? p.h_prev[pix * p.hprev_s + hc] : 0.f;
-            p.h_out[pix * p.hout_s + hc] = (1.f - z) * cand + z * hp;
-            if (p.gates) {
-              float* gp = p.gates + pix * p.gates_s + hc;
-              gp[0] = z; gp[p.hidp] = rg; gp[2 * p.hidp] = cand; gp[3 * p.hidp] = h2;
-            }
-          }
-        }
-    }
-  } else {
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int co = nb * NB + nf * 32 + r;
-      if (co < p.out_c) {
-        const float bv = p.bias ? p.bias[co] : 0.f;
-#pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
-#pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int rr = frag_row(reg, kh);
-            const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
-            if (py < p.H && px < p.W) {
-              float v = acc[mf][nf][reg] + bv;
-              if constexpr (EPI == EPI_SIGMOID) v = sf_sigmoid(v);
-              p.out[((size_t)(n * p.H + py) * p.W + px) * p.out_s + co] = v;
-            }
-          }
-      }
-    }
-  }
+  conv_epilogue<NF, EPI>(acc, p, n, nb, y0, x0, wave, r, kh);
 }
 
 // ---- weight repack ---------------------------------------------------------------------------
@@ -275,17 +173,6 @@ int launch_conv(const ConvParams& p, int nf, int nblk, hipStream_t st) {
   return 0;
 }
 
-void set_remap(ConvParams& p, const sfTensor& a, const sfTensor& b) {
-  p.idiv0 = a.idiv > 1 ? a.idiv : 1; p.imod0 = a.imod > 0 ? a.imod : 0;
-  p.idiv1 = b.idiv > 1 ? b.idiv : 1; p.imod1 = b.imod > 0 ? b.imod : 0;
-}
-
-int check_src(const sfTensor& t, const char* name) {
-  if (t.c % SF_CPAD != 0 || t.c < 0) { sf_set_error("%s: channels %d not a multiple of %d", name, t.c, SF_CPAD); return 1; }
-  if (t.ptr && (t.stride % 4 != 0 || ((uintptr_t)t.ptr & 15))) { sf_set_error("%s: needs 16-byte aligned pixels (stride %d)", name, t.stride); return 1; }
-  return 0;
-}
-
 }  // namespace
 
 extern "C" {
@@ -295,9 +182,14 @@ size_t sf_conv3x3_packed_elems(int32_t Np, int32_t Kp) { return (size_t)Np * Kp 
 int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t* nmap, int32_t Np, const int32_t* kmap,
                             int32_t Kp, int32_t nf, int32_t transpose, void* packed, const float* bias,
                             float* bias_packed, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_conv3x3_pack_weights: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_pack_weights: dtype %d not built", dtype);
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0, "pack: Np=%d must be a multiple of 32*nf (nf=%d)", Np, nf);
   SF_REQUIRE(Kp % KC == 0, "pack: Kp=%d must be a multiple of %d", Kp, KC);
+  if (dtype == SF_BF16) {
+    sf_pack_weights_bf16(w, O, I, nmap, Np, kmap, Kp, 32 * nf, transpose, packed, bias, bias_packed, (hipStream_t)stream);
+    SF_CHECK_LAUNCH("pack_weights_bf16");
+    return 0;
+  }
   const size_t total = (size_t)Np * Kp * 9;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weights_f32_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, O, I, nmap, Np, kmap,
@@ -309,7 +201,7 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
 int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
                    const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, int32_t dtype,
                    sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_conv3x3_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_fwd: dtype %d not built", dtype);
   if (check_src(src0, "conv3x3 src0") || check_src(src1, "conv3x3 src1")) return 1;
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && out.c <= Np, "conv3x3: bad Np=%d nf=%d out.c=%d", Np, nf, out.c);
   ConvParams p{};
@@ -320,6 +212,10 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
   p.wp = (const float*)wpacked; p.bias = bias_packed; p.chunks_total = (src0.c + src1.c) / KC;
   p.out = (float*)out.ptr; p.out_c = out.c; p.out_s = out.stride;
   const int nblk = Np / (32 * nf);
+  if (dtype == SF_BF16) {
+    SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
+    return sf_launch_conv_bf16(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
+  }
   if (epilogue == SF_EPI_LINEAR) return launch_conv<EPI_LINEAR>(p, nf, nblk, (hipStream_t)stream);
   if (epilogue == SF_EPI_SIGMOID) return launch_conv<EPI_SIGMOID>(p, nf, nblk, (hipStream_t)stream);
   sf_set_error("conv3x3: unknown epilogue %d", epilogue);
@@ -329,7 +225,7 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
 int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n, int32_t h, int32_t w,
                          const void* wpacked, const float* bias_packed, int32_t hidp, sfTensor h_out, sfTensor c_out,
                          sfTensor gates, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
   if (check_src(x, "convlstm x") || check_src(h_prev, "convlstm h_prev")) return 1;
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp, "convlstm: hidp=%d h_prev.c=%d", hidp, h_prev.c);
   SF_REQUIRE(x.ptr && h_out.ptr && c_out.ptr, "convlstm: x, h_out, c_out must be non-null");
@@ -345,6 +241,7 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   p.gates = (float*)gates.ptr; p.gates_s = gates.stride;
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
+  if (dtype == SF_BF16) return sf_launch_conv_bf16(p, 4, nblk, EPI_LSTM, (hipStream_t)stream);
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
   hipLaunchKernelGGL((conv3x3_f32_kernel<4, EPI_LSTM>), grid, block, 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("convlstm_cell_fwd");
@@ -354,7 +251,7 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
 int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int32_t w, const void* wpacked,
                         const float* bias_packed, int32_t hidp, sfTensor h_out, sfTensor gates, int32_t dtype,
                         sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_convgru_step_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convgru_step_fwd: dtype %d not built", dtype);
   if (check_src(h_prev, "convgru h_prev")) return 1;
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp && gx.c == 3 * hidp, "convgru: hidp=%d h_prev.c=%d gx.c=%d", hidp, h_prev.c, gx.c);
   SF_REQUIRE(gx.ptr && h_out.ptr, "convgru: gx and h_out must be non-null");
@@ -369,6 +266,7 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
   p.h_prev = (const float*)h_prev.ptr; p.hprev_s = h_prev.stride;
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
+  if (dtype == SF_BF16) return sf_launch_conv_bf16(p, 3, nblk, EPI_GRU, (hipStream_t)stream);
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
   hipLaunchKernelGGL((conv3x3_f32_kernel<3, EPI_GRU>), grid, block, 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("convgru_step_fwd");

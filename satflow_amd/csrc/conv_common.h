@@ -1,0 +1,138 @@
+// Shared by the fp32 and bf16 implicit-GEMM convolution kernels: parameter block, fused epilogues
+// (the MFMA C/D fragment layout is dtype independent on gfx950), host-side parameter helpers.
+#pragma once
+#include "sf_common.h"
+
+namespace sfconv {
+
+constexpr int TILE_W = 16;        // output tile width (pixels); tile height = 4 rows per wave
+constexpr int KC = 16;            // input channels per K chunk
+
+enum { EPI_LINEAR = 0, EPI_SIGMOID = 1, EPI_LSTM = 2, EPI_GRU = 3 };
+
+struct ConvParams {
+  const float* src0; const float* src1;
+  int c0, c1, s0, s1;
+  int idiv0, imod0, idiv1, imod1;  // image-index remap of the sources (see sfTensor)
+  int N, H, W, tiles_x, tiles_y;
+  const void* wp;      // packed image [nblk][chunks][9][32*NF][16] (fp32 or bf16)
+  const float* bias;   // [nblk*32*NF] or null
+  int chunks_total;    // (c0_decl + c1_decl)/16 of the packed image
+  // linear / sigmoid epilogue
+  float* out; int out_c, out_s;
+  // lstm epilogue
+  const float* c_prev; int cprev_s;
+  float* c_out; int cout_s;
+  float* h_out; int hout_s;
+  float* gates; int gates_s;
+  int hidp;
+  // gru epilogue (h_out / gates / hidp shared with lstm): precomputed x-part [z|r|n] and previous state
+  const float* gx; int gx_s;
+  const float* h_prev; int hprev_s;
+};
+
+
+// acc[mf][nf][reg]: wave `wave` owns tile rows 4*wave..4*wave+3; M fragment mf = rows 2*mf, 2*mf+1 (16 px each).
+template <int NF, int EPI>
+__device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0,
+                                              int wave, int r, int kh) {
+  constexpr int NB = 32 * NF;
+  if constexpr (EPI == EPI_LSTM) {
+    static_assert(NF == 4, "LSTM epilogue needs the 4 gates in one wave");
+    const int hc = nb * 32 + r;
+    if (hc < p.hidp) {
+      float bi = 0.f, bf = 0.f, bo = 0.f, bg = 0.f;
+      if (p.bias) {
+        bi = p.bias[nb * NB + r]; bf = p.bias[nb * NB + 32 + r];
+        bo = p.bias[nb * NB + 64 + r]; bg = p.bias[nb * NB + 96 + r];
+      }
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rr = frag_row(reg, kh);
+          const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
+          if (py < p.H && px < p.W) {
+            const size_t pix = (size_t)(n * p.H + py) * p.W + px;
+            const float gi = sf_sigmoid(acc[mf][0][reg] + bi);
+            const float gf = sf_sigmoid(acc[mf][1][reg] + bf);
+            const float go = sf_sigmoid(acc[mf][2][reg] + bo);
+            const float gg = tanhf(acc[mf][3][reg] + bg);
+            const float cp = p.c_prev ? p.c_prev[pix * p.cprev_s + hc] : 0.f;
+            const float cn = gf * cp + gi * gg;
+            p.c_out[pix * p.cout_s + hc] = cn;
+            p.h_out[pix * p.hout_s + hc] = go * tanhf(cn);
+            if (p.gates) {
+              float* gp = p.gates + pix * p.gates_s + hc;
+              gp[0] = gi; gp[p.hidp] = gf; gp[2 * p.hidp] = go; gp[3 * p.hidp] = gg;
+            }
+          }
+        }
+    }
+  } else if constexpr (EPI == EPI_GRU) {
+    static_assert(NF == 3, "GRU epilogue: z, r and the candidate's h-part in one wave");
+    const int hc = nb * 32 + r;
+    if (hc < p.hidp) {
+      const float b2 = p.bias ? p.bias[nb * NB + 64 + r] : 0.f;
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) {
+          const int rr = frag_row(reg, kh);
+          const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
+          if (py < p.H && px < p.W) {
+            const size_t pix = (size_t)(n * p.H + py) * p.W + px;
+            const float* gx = p.gx + pix * p.gx_s + hc;
+            const float z = sf_sigmoid(acc[mf][0][reg] + gx[0]);
+            const float rg = sf_sigmoid(acc[mf][1][reg] + gx[p.hidp]);
+            const float h2 = acc[mf][2][reg] + b2;
+            const float cand = tanhf(gx[2 * p.hidp] + rg * h2);
+            const float hp = p.h_prev ? p.h_prev[pix * p.hprev_s + hc] : 0.f;
+            p.h_out[pix * p.hout_s + hc] = (1.f - z) * cand + z * hp;
+            if (p.gates) {
+              float* gp = p.gates + pix * p.gates_s + hc;
+              gp[0] = z; gp[p.hidp] = rg; gp[2 * p.hidp] = cand; gp[3 * p.hidp] = h2;
+            }
+          }
+        }
+    }
+  } else {
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int co = nb * NB + nf * 32 + r;
+      if (co < p.out_c) {
+        const float bv = p.bias ? p.bias[co] : 0.f;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int rr = frag_row(reg, kh);
+            const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
+            if (py < p.H && px < p.W) {
+              float v = acc[mf][nf][reg] + bv;
+              if constexpr (EPI == EPI_SIGMOID) v = sf_sigmoid(v);
+              p.out[((size_t)(n * p.H + py) * p.W + px) * p.out_s + co] = v;
+            }
+          }
+      }
+    }
+  }
+}
+
+inline void set_remap(ConvParams& p, const sfTensor& a, const sfTensor& b) {
+  p.idiv0 = a.idiv > 1 ? a.idiv : 1; p.imod0 = a.imod > 0 ? a.imod : 0;
+  p.idiv1 = b.idiv > 1 ? b.idiv : 1; p.imod1 = b.imod > 0 ? b.imod : 0;
+}
+
+inline int check_src(const sfTensor& t, const char* name) {
+  if (t.c % SF_CPAD != 0 || t.c < 0) { sf_set_error("%s: channels %d not a multiple of %d", name, t.c, SF_CPAD); return 1; }
+  if (t.ptr && (t.stride % 4 != 0 || ((uintptr_t)t.ptr & 15))) { sf_set_error("%s: needs 16-byte aligned pixels (stride %d)", name, t.stride); return 1; }
+  return 0;
+}
+
+}  // namespace sfconv
+
+// bf16-MFMA launcher (conv3x3_bf16.hip); epi is one of sfconv::EPI_*
+int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
+void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
+                          void* packed, const float* bias, float* bias_packed, hipStream_t st);

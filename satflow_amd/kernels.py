@@ -128,13 +128,14 @@ def pack_weights(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, transpose:
     O, I = w.shape[0], w.shape[1]
     assert w.shape[2:] == (3, 3), "only 3x3 kernels are on the path"
     nmap, kmap = gm.tables(w.device)
-    packed = torch.empty(gm.Np * gm.Kp * 9, dtype=torch.float32, device=w.device)
+    dt = _hip.compute_dtype()
+    packed = torch.empty(gm.Np * gm.Kp * 9, dtype=torch.bfloat16 if dt == _hip.SF_BF16 else torch.float32, device=w.device)
     bp = torch.empty(gm.Np, dtype=torch.float32, device=w.device) if (bias is not None and not transpose) else None
     check(
         lib().sf_conv3x3_pack_weights(
             w.data_ptr(), O, I, nmap.data_ptr(), gm.Np, kmap.data_ptr(), gm.Kp, gm.nf, int(transpose), packed.data_ptr(),
             bias.detach().contiguous().data_ptr() if bp is not None else None, bp.data_ptr() if bp is not None else None,
-            SF_F32, stream_ptr(),
+            dt, stream_ptr(),
         ),
         "sf_conv3x3_pack_weights",
     )
@@ -145,7 +146,7 @@ def conv3x3(src0: sfTensor, src1: sfTensor, n: int, h: int, w: int, packed: Tens
             gm: GemmMap, out: sfTensor, epilogue: int = SF_EPI_LINEAR) -> None:
     check(
         lib().sf_conv3x3_fwd(src0, src1, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
-                             gm.Np, gm.nf, epilogue, out, SF_F32, stream_ptr()),
+                             gm.Np, gm.nf, epilogue, out, _hip.compute_dtype(), stream_ptr()),
         "sf_conv3x3_fwd",
     )
 
@@ -155,7 +156,7 @@ def convlstm_cell_fwd(x: sfTensor, h_prev: sfTensor, c_prev: sfTensor, n: int, h
     check(
         lib().sf_convlstm_cell_fwd(x, h_prev, c_prev, n, h, w, packed.data_ptr(),
                                    bias_packed.data_ptr() if bias_packed is not None else None, hidp, h_out, c_out, gates,
-                                   SF_F32, stream_ptr()),
+                                   _hip.compute_dtype(), stream_ptr()),
         "sf_convlstm_cell_fwd",
     )
 
@@ -297,7 +298,7 @@ def attention_core_bwd(qkv: Tensor, datt: Tensor, hid: int, heads: int) -> Tenso
 def convgru_step_fwd(gx: sfTensor, h_prev: Optional[Tensor], n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor],
                      hidp: int, h_out: Tensor, gates: Optional[Tensor]) -> None:
     check(lib().sf_convgru_step_fwd(gx, T(h_prev, hidp), n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
-                                    hidp, T(h_out), T(gates) if gates is not None else NULL, SF_F32, stream_ptr()), "sf_convgru_step_fwd")
+                                    hidp, T(h_out), T(gates) if gates is not None else NULL, _hip.compute_dtype(), stream_ptr()), "sf_convgru_step_fwd")
 
 
 def convgru_bwd_gates(dh: Sequence[sfTensor], gates: Tensor, h_prev: Optional[Tensor], hidp: int, dgx: Tensor, dgh: Tensor,

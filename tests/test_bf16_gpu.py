@@ -1,0 +1,100 @@
+"""GPU: the bf16-MFMA compute mode (bf16 operands, fp32 accumulate, fp32 storage).
+
+Two checks per kernel: (1) EXACTNESS of the kernel's own arithmetic - against the fp32 oracle evaluated on
+bf16-rounded inputs and weights the result must agree to fp32-accumulation noise (rtol 1e-4); (2) the distance
+to the plain fp32 oracle, i.e. the price of bf16 operands, asserted at 2e-2 of the tensor scale and printed.
+"""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import satflow_amd
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16_mode():
+    satflow_amd.set_compute_dtype("bf16")
+    yield
+    satflow_amd.set_compute_dtype("f32")
+
+
+def _r(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 40, 33), (256, 256, 2, 32, 32), (48, 96, 1, 64, 20)])
+def test_conv3x3_bf16(device, bf16_mode, cin, cout, n, h, w):
+    from satflow_amd.functional import ConvEngine, conv3x3, nchw_to_nhwc, nhwc_to_nchw
+
+    g = torch.Generator().manual_seed(cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin**0.5)
+    b = torch.randn(cout, generator=g)
+    cot = torch.randn(n, cout, h, w, generator=g)
+    xr, wr = _r(x).requires_grad_(), _r(wt).requires_grad_()
+    ref = TF.conv2d(xr, wr, b, padding=1)
+    xd, wd, bd = (t.to(device).requires_grad_() for t in (x, wt, b))
+    y = nhwc_to_nchw(conv3x3(ConvEngine([cin], cout), nchw_to_nhwc(xd), wd, bd), cout)
+    assert_close(y, ref, "bf16 conv vs oracle on bf16-rounded operands")
+    # input gradient: bf16(cotangent) x bf16(W^T); weight gradient stays on the exact fp32 pipe
+    (y * cot.to(device)).sum().backward()
+    dx_ref = torch.autograd.grad(TF.conv2d(xr, wr, None, padding=1), xr, _r(cot))[0]
+    assert_close(xd.grad, dx_ref, "bf16 dgrad", grad=True)
+    xf, wf = x.clone().requires_grad_(), wt.clone().requires_grad_()
+    full = TF.conv2d(xf, wf, b, padding=1)
+    full.backward(cot)
+    assert_close(wd.grad, wf.grad, "dW (fp32 pipe)", grad=True)
+    scale = float(full.abs().max())
+    err = float((y.detach().cpu() - full.detach()).abs().max())
+    print(f"bf16 conv cin={cin}: max abs err vs fp32 {err:.3e} (scale {scale:.2f})")
+    assert err < 2e-2 * scale
+
+
+@pytest.mark.parametrize("case", ["a", "b", "odd", "hot"])
+def test_cell_bf16_vs_golden(device, bf16_mode, case):
+    """ConvLSTM cell in bf16 mode: exact vs oracle-on-rounded-operands; close to the reference golden."""
+    import os
+
+    import numpy as np
+    from conftest import GOLDEN
+    from oracle import convlstm as O
+    from satflow_amd.models.layers import ConvLSTMCell
+
+    G = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, f"convlstm_cell_{case}.npz")).items()}
+    hid, cin = G["h"].shape[1], G["x"].shape[1]
+    cell = ConvLSTMCell(cin, hid, (3, 3), True).to(device)
+    with torch.no_grad():
+        cell.conv.weight.copy_(G["weight"])
+        cell.conv.bias.copy_(G["bias"])
+    h1, c1 = cell(G["x"].to(device), (G["h"].to(device), G["c"].to(device)))
+    rh, rc = O.convlstm_cell(_r(G["x"]), _r(G["h"]), G["c"], _r(G["weight"]), G["bias"])
+    assert_close(h1, rh, "h' (rounded-operand oracle)")
+    assert_close(c1, rc, "c' (rounded-operand oracle)")
+    err = max(float((h1.cpu() - G["h_out"]).abs().max()), float((c1.cpu() - G["c_out"]).abs().max()))
+    print(f"bf16 cell {case}: max abs err vs reference golden {err:.3e}")
+    assert err < 3e-2
+
+
+@pytest.mark.parametrize("case", ["cfg1_h8", "cfg1_h32_hot", "rect_h16_o12"])
+def test_model_bf16_vs_golden(device, bf16_mode, case):
+    """Whole ConvLSTM in bf16 mode vs the reference golden: error of the same order as the reference's own
+    bf16-autocast run (stored in the golden as pred_bf16_autocast)."""
+    from test_convlstm_gpu import _load, _model_from_golden
+
+    G = _load(f"convlstm_model_{case}.npz")
+    m, fs = _model_from_golden(G, device)
+    x = G["x"].to(device).requires_grad_()
+    pred = m(x, fs)
+    (pred * G["cot"].to(device)).sum().backward()
+    ours = float((pred.detach().cpu() - G["pred"]).abs().max())
+    theirs = float((G["pred_bf16_autocast"] - G["pred"]).abs().max())
+    print(f"bf16 model {case}: max abs err ours {ours:.3e} vs reference autocast {theirs:.3e}")
+    assert ours <= max(2 * theirs, 5e-3)
+    g = dict(m.model.named_parameters())["decoder_CNN.weight"].grad.cpu()
+    ref = G["grad.decoder_CNN.weight"]
+    rel = float((g - ref).norm() / ref.norm())
+    print(f"   decoder_CNN.weight grad rel L2 {rel:.3e}")
+    assert rel < 5e-2
