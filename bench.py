@@ -28,7 +28,8 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-PEAK_F32_TFLOPS = 157.3  # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
+PEAK_F32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
+PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
 
 
@@ -109,9 +110,12 @@ class ConvLSTMWorkload:
         t = event_time(lambda: eng.step(T(x), h, c, B, H, W, ho, co, g), iters=20)
         flops = 2 * 9 * (hid + hid) * 4 * hid * H * W * B
         alg_bytes = (hid + 2 * hid + 2 * hid) * H * W * B * 4 + 9 * 2 * hid * 4 * hid * 4
-        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / t / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
-                "kernel": "conv3x3_f32_kernel<4,LSTM> (sf_convlstm_cell_fwd, 128->256 ch, 128x128, B=%d)" % B,
+        import satflow_amd
+        bf16 = satflow_amd.compute_dtype_name() == "bf16"
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / t / 1e12 / peak, "traffic": None,
+                "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, 128->256 ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", B),
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
                 "note": "fp32 parity mode: exact-f32 MFMA, bound by the 157.3 TF fp32 matrix pipe (intensity 461 F/B >> ridge 20 F/B)"}
@@ -180,13 +184,18 @@ class MetNetWorkload:
         t = event_time(lambda: K.conv3x3(T(x), NULL, n, H, W, packed, bp, eng.fwd_map, T(y)), iters=10)
         flops = 2 * 9 * C * C * H * W * n
         alg_bytes = 2 * C * H * W * n * 4 + 9 * C * C * 4
-        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": PEAK_F32_TFLOPS, "unit": "TFLOP/s",
-                "frac": flops / t / 1e12 / PEAK_F32_TFLOPS, "traffic": None,
-                "kernel": f"conv3x3_f32_kernel<4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)",
+        import satflow_amd
+        bf16 = satflow_amd.compute_dtype_name() == "bf16"
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
+                "frac": flops / t / 1e12 / peak, "traffic": None,
+                "kernel": f"conv3x3_{'bf16' if bf16 else 'f32'}_kernel<NF=4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)",
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
-                "note": "fp32 path: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bound by the 157.3 TF fp32 matrix pipe "
-                        "(intensity 1150 F/B >> ridge 20 F/B)"}
+                "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), fp32 activations in HBM: intensity 575 F/B vs "
+                         "ridge 312 F/B -> MFMA-bound" if bf16 else
+                         "fp32 path: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bound by the 157.3 TF fp32 matrix pipe "
+                         "(intensity 1150 F/B >> ridge 20 F/B)")}
 
     def cpu_baseline(self):
         from oracle import metnet as M  # checker/baseline only
@@ -225,6 +234,8 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm"])
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16"), choices=["bf16", "f32"],
+                    help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default) or exact fp32 (parity mode)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -233,6 +244,9 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    import satflow_amd
+
+    satflow_amd.set_compute_dtype(args.dtype)
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     if world > 1:
@@ -266,7 +280,7 @@ def main():
             "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else "samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6",
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32", "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
+            "dtype": args.dtype, "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
             "config": wl.config(world), "final_loss": final_loss,
         }
         out["roofline"] = wl.roofline()

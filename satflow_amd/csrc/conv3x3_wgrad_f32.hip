@@ -12,25 +12,17 @@
 // Split-K partial slabs go to a workspace and are reduced (deterministically, no atomics) by a
 // second kernel that also scatters to the reference's OIHW gradient layout and sums the bias
 // gradient, which the main kernel gets for free from the A operand it already holds.
-#include "sf_common.h"
+#include "wgrad_common.h"
 
 namespace {
 
-constexpr int KT_H = 4, KT_W = 16;                 // K tile (pixels)
+using namespace sfwgrad;
+
+constexpr int KT_H = 4;                            // K tile height (pixels); width KT_W = 16
 constexpr int KT_PIX = KT_H * KT_W;                // 64
 constexpr int HALO_H = KT_H + 2, HALO_W = KT_W + 2;
-constexpr int CO_T = 128, CI_T = 32;
 constexpr int PA = CO_T;                           // LDS floats per dout pixel
 constexpr int PB = CI_T;                           // LDS floats per input pixel
-
-struct WgradParams {
-  const float* src0; const float* src1; int c0, c1, s0, s1;
-  int idiv0, imod0, idiv1, imod1;
-  const float* dout; int dc, ds;
-  int N, H, W, tiles_x, tiles_y, ntiles, KS;
-  float* partial; float* partial_db;
-  int NpT, KpT;
-};
 
 __global__ __launch_bounds__(256, 2) void wgrad_f32_kernel(const WgradParams p) {
   __shared__ __attribute__((aligned(16))) float lds[KT_PIX * PA + HALO_H * HALO_W * PB];
@@ -143,41 +135,24 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
   }
 }
 
-struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; };
-
-Plan make_plan(int Np, int Kp, int n, int h, int w) {
-  Plan pl;
-  pl.tiles_x = (w + KT_W - 1) / KT_W;
-  pl.tiles_y = (h + KT_H - 1) / KT_H;
-  pl.ntiles = pl.tiles_x * pl.tiles_y * n;
-  pl.cot = (Np + CO_T - 1) / CO_T;
-  pl.cit = (Kp + CI_T - 1) / CI_T;
-  int want = 1024 / (pl.cot * pl.cit);
-  if (want < 8) want = 8;
-  if (want > 256) want = 256;
-  pl.KS = pl.ntiles < want ? pl.ntiles : want;
-  if (pl.KS < 1) pl.KS = 1;
-  pl.ws_floats = (size_t)pl.KS * ((size_t)9 * pl.cot * CO_T * pl.cit * CI_T + (size_t)pl.cot * CO_T);
-  return pl;
-}
-
 }  // namespace
 
 extern "C" {
 
 size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w) {
-  return make_plan(Np, Kp, n, h, w).ws_floats * sizeof(float);
+  // the bf16 variant uses taller K tiles, i.e. never more tiles / a larger KS than this plan
+  return make_plan(Np, Kp, n, h, w, KT_H).ws_floats * sizeof(float);
 }
 
 int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h, int32_t w,
                           const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I, float* dw, float* db,
                           int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_conv3x3_bwd_weight: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_bwd_weight: dtype %d not built", dtype);
   SF_REQUIRE(src0.c % SF_CPAD == 0 && src1.c % SF_CPAD == 0 && dout.c % 4 == 0, "bwd_weight: channel padding");
   SF_REQUIRE(src0.ptr || src0.c == 0, "bwd_weight: src0 null");
   SF_REQUIRE(src1.ptr || src1.c == 0, "bwd_weight: src1 null with c=%d (pass c=0)", src1.c);
   const int Np = dout.c, Kp = src0.c + src1.c;
-  const Plan pl = make_plan(Np, Kp, n, h, w);
+  const Plan pl = make_plan(Np, Kp, n, h, w, dtype == SF_BF16 ? 8 : KT_H);
   SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
              workspace_bytes, pl.ws_floats * sizeof(float));
   WgradParams p{};
@@ -190,8 +165,12 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   p.NpT = pl.cot * CO_T; p.KpT = pl.cit * CI_T;
   p.partial = (float*)workspace;
   p.partial_db = p.partial + (size_t)pl.KS * 9 * p.NpT * p.KpT;
-  hipLaunchKernelGGL(wgrad_f32_kernel, dim3(pl.KS, pl.cot, pl.cit), dim3(256), 0, (hipStream_t)stream, p);
-  SF_CHECK_LAUNCH("wgrad_f32");
+  if (dtype == SF_BF16) {
+    if (int rc = sf_launch_wgrad_bf16(p, pl, (hipStream_t)stream)) return rc;
+  } else {
+    hipLaunchKernelGGL(wgrad_f32_kernel, dim3(pl.KS, pl.cot, pl.cit), dim3(256), 0, (hipStream_t)stream, p);
+    SF_CHECK_LAUNCH("wgrad_f32");
+  }
   const size_t slab = (size_t)9 * p.NpT * p.KpT;
   hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      p.partial, p.partial_db, pl.KS, p.NpT, p.KpT, Np, Kp, nmap, kmap, I, dw, db, accumulate);

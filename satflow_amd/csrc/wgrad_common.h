@@ -1,0 +1,42 @@
+// Shared by the fp32 and bf16 weight-gradient kernels: parameter block and split-K plan.
+#pragma once
+#include "sf_common.h"
+
+namespace sfwgrad {
+
+constexpr int CO_T = 128, CI_T = 32;   // dW slab per workgroup: 128 (co) x 32 (ci) x 9 taps
+constexpr int KT_W = 16;               // K tile width (pixels)
+
+struct WgradParams {
+  const float* src0; const float* src1; int c0, c1, s0, s1;
+  int idiv0, imod0, idiv1, imod1;
+  const float* dout; int dc, ds;
+  int N, H, W, tiles_x, tiles_y, ntiles, KS;
+  float* partial; float* partial_db;
+  int NpT, KpT;
+};
+
+
+struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; };
+
+// kt_h: K-tile height of the kernel variant (4 rows fp32, 8 rows bf16)
+inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
+  Plan pl;
+  pl.tiles_x = (w + KT_W - 1) / KT_W;
+  pl.tiles_y = (h + kt_h - 1) / kt_h;
+  pl.ntiles = pl.tiles_x * pl.tiles_y * n;
+  pl.cot = (Np + CO_T - 1) / CO_T;
+  pl.cit = (Kp + CI_T - 1) / CI_T;
+  int want = 1024 / (pl.cot * pl.cit);
+  if (want < 8) want = 8;
+  if (want > 256) want = 256;
+  pl.KS = pl.ntiles < want ? pl.ntiles : want;
+  if (pl.KS < 1) pl.KS = 1;
+  pl.ws_floats = (size_t)pl.KS * ((size_t)9 * pl.cot * CO_T * pl.cit * CI_T + (size_t)pl.cot * CO_T);
+  return pl;
+}
+
+}  // namespace sfwgrad
+
+// bf16-MFMA variant (conv3x3_wgrad_bf16.hip): fills the same partial slabs
+int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);

@@ -182,8 +182,8 @@ def conv3x3_bwd_weight(src0: sfTensor, src1: sfTensor, dout: sfTensor, n: int, h
     assert dw.is_contiguous() and (db is None or db.is_contiguous())
     check(
         lib().sf_conv3x3_bwd_weight(src0, src1, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), O, I, dw.data_ptr(),
-                                    db.data_ptr() if db is not None else None, int(accumulate), ws.data_ptr(), nbytes, SF_F32,
-                                    stream_ptr()),
+                                    db.data_ptr() if db is not None else None, int(accumulate), ws.data_ptr(), nbytes,
+                                    _hip.compute_dtype(), stream_ptr()),
         "sf_conv3x3_bwd_weight",
     )
 

@@ -39,14 +39,20 @@ def test_conv3x3_bf16(device, bf16_mode, cin, cout, n, h, w):
     xd, wd, bd = (t.to(device).requires_grad_() for t in (x, wt, b))
     y = nhwc_to_nchw(conv3x3(ConvEngine([cin], cout), nchw_to_nhwc(xd), wd, bd), cout)
     assert_close(y, ref, "bf16 conv vs oracle on bf16-rounded operands")
-    # input gradient: bf16(cotangent) x bf16(W^T); weight gradient stays on the exact fp32 pipe
+    # input gradient: bf16(cotangent) x bf16(W^T)
     (y * cot.to(device)).sum().backward()
     dx_ref = torch.autograd.grad(TF.conv2d(xr, wr, None, padding=1), xr, _r(cot))[0]
     assert_close(xd.grad, dx_ref, "bf16 dgrad", grad=True)
+    # weight gradient: bf16(cotangent)^T x bf16(x), fp32 accumulate; bias gradient summed in fp32 from the unrounded cotangent
+    dw_ref = torch.autograd.grad(TF.conv2d(xr, wr, None, padding=1), wr, _r(cot))[0]
+    assert_close(wd.grad, dw_ref, "bf16 wgrad", grad=True)
+    assert_close(bd.grad, cot.sum(dim=(0, 2, 3)), "db", grad=True)
     xf, wf = x.clone().requires_grad_(), wt.clone().requires_grad_()
     full = TF.conv2d(xf, wf, b, padding=1)
     full.backward(cot)
-    assert_close(wd.grad, wf.grad, "dW (fp32 pipe)", grad=True)
+    rel = float((wd.grad.cpu() - wf.grad).norm() / wf.grad.norm())
+    print(f"   bf16 dW rel L2 vs fp32 {rel:.3e}")
+    assert rel < 1e-2
     scale = float(full.abs().max())
     err = float((y.detach().cpu() - full.detach()).abs().max())
     print(f"bf16 conv cin={cin}: max abs err vs fp32 {err:.3e} (scale {scale:.2f})")

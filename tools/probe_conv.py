@@ -29,6 +29,14 @@ def conv(n, cin, cout, H, W):
     fl = 2 * 9 * cin * cout * H * W * n
     print(f"  conv {cin}->{cout} {H}x{W} n={n} nf={eng.fwd_map.nf}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s  alg {(cin+cout)*H*W*n*4/t/1e9:7.0f} GB/s")
 
+def wgrad(n, cin, cout, H, W):
+    eng = ConvEngine([cin], cout)
+    x = torch.randn(n, H, W, cpad(cin), device=dev); gy = torch.randn(n, H, W, cpad(cout), device=dev)
+    dw = torch.empty(cout, cin, 3, 3, device=dev); db = torch.empty(cout, device=dev)
+    t = timeit(lambda: K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw, db, False), iters=5)
+    fl = 2 * 9 * cin * cout * H * W * n
+    print(f"  wgrad {cin}->{cout} {H}x{W} n={n}: {t*1e3:8.3f} ms  {fl/t/1e12:7.1f} TF/s")
+
 def cell(B, cin, hid, H, W):
     c = nn.Conv2d(cin + hid, 4 * hid, 3, padding=1).to(dev)
     eng = CellEngine(c, cin, hid)
@@ -48,5 +56,9 @@ for mode in ("f32", "bf16"):
     conv(2304, 256, 160, 32, 32)
     conv(2304, 112, 160, 64, 64)
     conv(2304, 256, 192, 16, 16)
+    wgrad(2304, 256, 256, 32, 32)
+    wgrad(2304, 160, 256, 32, 32)
+    wgrad(2304, 112, 160, 64, 64)
+    wgrad(96 * 12, 128, 256, 128, 128) if False else None
     cell(8, 64, 64, 128, 128)
     cell(8, 12, 64, 128, 128)
