@@ -193,6 +193,21 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
                            double* sums, sfTensor dx, float* dgamma, float* dbeta, int32_t dtype,
                            sfStream stream);
 
+/* Lead-time de-duplication of MetNet's first convolution (ConditionTime planes are constant one-hot images and
+ * conv1 is linear): with base = conv1_image(frame) + b computed ONCE per frame,
+ *   pooled[(l*frames + f)] = maxpool2( base[f] + P_l ),  P_l[y][x][co] = sum of the in-image taps of w1[co][cimg + l]
+ * (9 border classes).  Replaces ConditionTime (satflow/models/layers/ConditionTime.py:22-33) + the one-hot part of
+ * conv1 + the first MaxPool2d of the DownSampler for all L lead times.  w1: conv1 weight [O][I][3][3] (fp32, OIHW).
+ * bwd: dbase[f] = sum_l unpool(dout[l*frames+f]); dw1[:, cimg:cimg+L] = border-aware sums of the routed gradient
+ * (other columns of dw1 are left untouched).  workspace: sf_leadtime_pool_workspace_floats(L, base.c) floats. */
+size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C);
+int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O,
+                         int32_t I, int32_t cimg, int32_t L, float* workspace, sfTensor out,
+                         int32_t dtype, sfStream stream);
+int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h, int32_t w,
+                         const float* w1, int32_t O, int32_t I, int32_t cimg, int32_t L,
+                         float* workspace, sfTensor dbase, float* dw1, int32_t dtype, sfStream stream);
+
 /* ConvGRUCell step, recurrent half:  given gx = conv_x(x_t) = [z_x | r_x | n_x] (+ their biases; one
  * sf_conv3x3_fwd over all timesteps at once) and h_prev (NULL ptr = zero state):
  *   [z_h | r_h | h2] = conv3x3(h_prev) (+ bias on h2);  z = sig(z_x+z_h), r = sig(r_x+r_h),

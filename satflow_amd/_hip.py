@@ -48,6 +48,9 @@ PROTOTYPES = {
     "sf_metnet_preprocess_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_maxpool2_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, _i32, _vp]),
     "sf_maxpool2_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, _i32, _vp]),
+    "sf_leadtime_pool_workspace_floats": (_sz, [_i32, _i32]),
+    "sf_leadtime_pool_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, sfTensor, _i32, _vp]),
+    "sf_leadtime_pool_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, sfTensor, _vp, _i32, _vp]),
     "sf_batchnorm_train_fwd": (
         C.c_int,
         [sfTensor, _i64, _i32, _i32, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, sfTensor, _i32, _vp],

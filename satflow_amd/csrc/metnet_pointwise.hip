@@ -372,3 +372,196 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
 }
 
 }  // extern "C"
+
+// =============================================================================================
+// Lead-time de-duplication of MetNet's first convolution.
+//
+// conv1 is linear, and the ConditionTime planes are constant one-hot images, so for lead time l
+//   conv1([frame ; onehot_l]) = conv1_image(frame) + b + P_l,
+//   P_l[y][x][co] = sum of the taps of W1[co][Cimg + l] whose input pixel lies inside the image,
+// which takes only 9 values per (l, co): one per border class (top/interior/bottom x left/interior/right).
+// The image part ("base") is computed ONCE per frame instead of once per (frame, lead time); the kernels
+// below fuse "+ P_l" with the DownSampler's first 2x2 max-pool, forward and backward, so the per-lead-time
+// full-resolution tensor is never materialised.
+// =============================================================================================
+namespace {
+
+__device__ __forceinline__ int border_class(int y, int x, int H, int W) {
+  const int ry = y == 0 ? 0 : (y == H - 1 ? 2 : 1), rx = x == 0 ? 0 : (x == W - 1 ? 2 : 1);
+  return ry * 3 + rx;
+}
+
+// ptab[l][cls][c] from w1 [O][I][3][3]; columns Cimg + l.  Pad lanes c >= O are zero.
+__global__ void leadbias_table_kernel(const float* __restrict__ w1, int O, int I, int cimg, int L, int Cp, float* __restrict__ ptab) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L * 9 * Cp) return;
+  const int c = idx % Cp, cls = (idx / Cp) % 9, l = idx / (9 * Cp);
+  float s = 0.f;
+  if (c < O) {
+    const int ry = cls / 3, rx = cls % 3;
+    const float* w = w1 + ((size_t)c * I + cimg + l) * 9;
+    for (int ky = 0; ky < 3; ++ky) {
+      if ((ry == 0 && ky == 0) || (ry == 2 && ky == 2)) continue;  // input row y+ky-1 outside the image
+      for (int kx = 0; kx < 3; ++kx) {
+        if ((rx == 0 && kx == 0) || (rx == 2 && kx == 2)) continue;
+        s += w[ky * 3 + kx];
+      }
+    }
+  }
+  ptab[idx] = s;
+}
+
+// pooled[(l*F + f)][yo][xo][c] = max over the 2x2 window of base[f] + ptab[l][class]
+__global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const float* __restrict__ base, int bs, long long F, int H, int W, int C,
+                                                                int L, const float* __restrict__ ptab, float* __restrict__ out, int os) {
+  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const long long total = F * Ho * Wo * q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (idx % q) * 4;
+    const long long op = idx / q;
+    const int xo = op % Wo, yo = (op / Wo) % Ho;
+    const long long f = op / ((long long)Wo * Ho);
+    const float* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
+    const f32x4 v0 = ld4(p), v1 = ld4(p + bs), v2 = ld4(p + (long long)W * bs), v3 = ld4(p + (long long)W * bs + bs);
+    const int k0 = border_class(2 * yo, 2 * xo, H, W), k1 = border_class(2 * yo, 2 * xo + 1, H, W);
+    const int k2 = border_class(2 * yo + 1, 2 * xo, H, W), k3 = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+    for (int l = 0; l < L; ++l) {
+      const float* pt = ptab + (size_t)l * 9 * C + c;
+      const f32x4 a0 = v0 + ld4(pt + k0 * C), a1 = v1 + ld4(pt + k1 * C), a2 = v2 + ld4(pt + k2 * C), a3 = v3 + ld4(pt + k3 * C);
+      f32x4 m;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a0[j], a1[j]), fmaxf(a2[j], a3[j]));
+      st4(out + (((l * F + f) * Ho + yo) * Wo + xo) * os + c, m);
+    }
+  }
+}
+
+// dbase[f] = sum_l unpool(dpooled[l*F+f]);  partial class sums cls_part[block][l][cls][c] (deterministic 2-stage reduce).
+// Persistent grid; each block keeps S[l][cls][c] in LDS (ds_add_f32), flushed once at the end.
+__global__ __launch_bounds__(256) void leadbias_pool_bwd_kernel(const float* __restrict__ base, int bs, const float* __restrict__ dout, int dos,
+                                                                long long F, int H, int W, int C, int L, const float* __restrict__ ptab,
+                                                                float* __restrict__ dbase, int dbs, float* __restrict__ cls_part) {
+  extern __shared__ float S[];  // [L][9][C]
+  const int nS = L * 9 * C;
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const long long total = F * Ho * Wo * q;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int c = (idx % q) * 4;
+    const long long op = idx / q;
+    const int xo = op % Wo, yo = (op / Wo) % Ho;
+    const long long f = op / ((long long)Wo * Ho);
+    const long long b0 = (f * H + 2 * yo) * W + 2 * xo;
+    const float* p = base + b0 * bs + c;
+    const f32x4 v0 = ld4(p), v1 = ld4(p + bs), v2 = ld4(p + (long long)W * bs), v3 = ld4(p + (long long)W * bs + bs);
+    int k[4];
+    k[0] = border_class(2 * yo, 2 * xo, H, W); k[1] = border_class(2 * yo, 2 * xo + 1, H, W);
+    k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+    const bool interior = k[0] == 4 && k[3] == 4;
+    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+    for (int l = 0; l < L; ++l) {
+      const float* pt = ptab + (size_t)l * 9 * C + c;
+      const f32x4 a0 = v0 + ld4(pt + k[0] * C), a1 = v1 + ld4(pt + k[1] * C), a2 = v2 + ld4(pt + k[2] * C), a3 = v3 + ld4(pt + k[3] * C);
+      const f32x4 g = ld4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
+      float* Sl = S + (size_t)l * 9 * C + c;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int am = 0; float m = a0[j];  // first maximum in row-major window order, as max_pool2d
+        if (a1[j] > m) { m = a1[j]; am = 1; }
+        if (a2[j] > m) { m = a2[j]; am = 2; }
+        if (a3[j] > m) { m = a3[j]; am = 3; }
+        g0[j] += am == 0 ? g[j] : 0.f; g1[j] += am == 1 ? g[j] : 0.f; g2[j] += am == 2 ? g[j] : 0.f; g3[j] += am == 3 ? g[j] : 0.f;
+        // class sums: interior windows all land in class 4 (accumulated per thread below), border windows go to LDS
+        if (!interior) atomicAdd(Sl + k[am] * C + j, g[j]);
+      }
+      if (interior) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(Sl + 4 * C + j, g[j]);
+      }
+    }
+    float* d = dbase + b0 * dbs + c;
+    st4(d, g0); st4(d + dbs, g1); st4(d + (long long)W * dbs, g2); st4(d + (long long)W * dbs + dbs, g3);
+  }
+  __syncthreads();
+  float* dstp = cls_part + (size_t)blockIdx.x * nS;
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
+}
+
+// dw1[co][cimg + l][ky][kx] = sum over classes where the tap is inside the image of sum_blocks cls_part[..][l][cls][co]
+__global__ void leadbias_wgrad_kernel(const float* __restrict__ cls_part, int nblocks, int L, int C, int O, int I, int cimg,
+                                      float* __restrict__ dw1) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= L * O) return;
+  const int co = idx % O, l = idx / O;
+  float s[9];
+  for (int cls = 0; cls < 9; ++cls) {
+    float a = 0.f;
+    for (int b = 0; b < nblocks; ++b) a += cls_part[((size_t)b * L + l) * 9 * C + cls * C + co];
+    s[cls] = a;
+  }
+  float* w = dw1 + ((size_t)co * I + cimg + l) * 9;
+  for (int ky = 0; ky < 3; ++ky)
+    for (int kx = 0; kx < 3; ++kx) {
+      float a = 0.f;
+      for (int ry = 0; ry < 3; ++ry) {
+        if ((ry == 0 && ky == 0) || (ry == 2 && ky == 2)) continue;
+        for (int rx = 0; rx < 3; ++rx) {
+          if ((rx == 0 && kx == 0) || (rx == 2 && kx == 2)) continue;
+          a += s[ry * 3 + rx];
+        }
+      }
+      w[ky * 3 + kx] = a;
+    }
+}
+
+constexpr int LEADBIAS_BLOCKS = 512;
+
+}  // namespace
+
+extern "C" {
+
+size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C) { return (size_t)L * 9 * C * (1 + LEADBIAS_BLOCKS); }
+
+int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I, int32_t cimg,
+                         int32_t L, float* workspace, sfTensor out, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_leadtime_pool_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && h >= 2 && w >= 2 && base.c == out.c && ok4(base) && ok4(out) && O <= base.c && cimg + L <= I,
+             "leadtime_pool: shapes (h=%d w=%d C=%d O=%d I=%d cimg=%d L=%d)", h, w, base.c, O, I, cimg, L);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = base.c, nt = L * 9 * C;
+  hipLaunchKernelGGL(leadbias_table_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w1, O, I, cimg, L, C, workspace);
+  SF_CHECK_LAUNCH("leadbias_table");
+  const long long total = frames * (h / 2) * (w / 2) * (C / 4);
+  if (total == 0) return 0;
+  hipLaunchKernelGGL(leadbias_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)base.ptr, base.stride, (long long)frames,
+                     h, w, C, L, workspace, (float*)out.ptr, out.stride);
+  SF_CHECK_LAUNCH("leadbias_pool_fwd");
+  return 0;
+}
+
+int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I,
+                         int32_t cimg, int32_t L, float* workspace, sfTensor dbase, float* dw1, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_leadtime_pool_bwd: dtype %d not built", dtype);
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && base.c == dout.c && base.c == dbase.c && ok4(base) && ok4(dout) && ok4(dbase), "leadtime_pool bwd: shapes");
+  hipStream_t st = (hipStream_t)stream;
+  const int C = base.c, nt = L * 9 * C;
+  SF_REQUIRE((size_t)nt * sizeof(float) <= 160 * 1024, "leadtime_pool bwd: L*9*C floats exceed LDS");
+  hipLaunchKernelGGL(leadbias_table_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w1, O, I, cimg, L, C, workspace);
+  SF_CHECK_LAUNCH("leadbias_table");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  float* cls_part = workspace + nt;
+  hipLaunchKernelGGL(leadbias_pool_bwd_kernel, dim3(LEADBIAS_BLOCKS), dim3(256), (size_t)nt * sizeof(float), st, (const float*)base.ptr,
+                     base.stride, (const float*)dout.ptr, dout.stride, (long long)frames, h, w, C, L, workspace, (float*)dbase.ptr,
+                     dbase.stride, cls_part);
+  SF_CHECK_LAUNCH("leadbias_pool_bwd");
+  hipLaunchKernelGGL(leadbias_wgrad_kernel, dim3((L * O + 127) / 128), dim3(128), 0, st, cls_part, LEADBIAS_BLOCKS, L, C, O, I, cimg, dw1);
+  SF_CHECK_LAUNCH("leadbias_wgrad");
+  return 0;
+}
+
+}  // extern "C"

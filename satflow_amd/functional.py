@@ -181,6 +181,39 @@ def maxpool2(x: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
     return _MaxPoolFn.apply(x, perm)
 
 
+class _LeadTimePoolFn(torch.autograd.Function):
+    """``pooled[l*F + f] = maxpool2(base[f] + P_l(w1))`` for all lead times l (see ``sf_leadtime_pool_fwd``)."""
+
+    @staticmethod
+    def forward(ctx, base: Tensor, w1: Tensor, cimg: int, L: int):
+        Fr, H, W, C = base.shape
+        w1 = w1.contiguous()
+        ws = torch.empty(lib().sf_leadtime_pool_workspace_floats(L, C), dtype=torch.float32, device=base.device)
+        out = torch.empty(L * Fr, H // 2, W // 2, C, dtype=torch.float32, device=base.device)
+        check(lib().sf_leadtime_pool_fwd(T(base), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(out), SF_F32,
+                                         stream_ptr()), "sf_leadtime_pool_fwd")
+        ctx.meta = (cimg, L)
+        ctx.save_for_backward(base, w1)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        base, w1 = ctx.saved_tensors
+        cimg, L = ctx.meta
+        Fr, H, W, C = base.shape
+        g = g.contiguous()
+        ws = torch.empty(lib().sf_leadtime_pool_workspace_floats(L, C), dtype=torch.float32, device=base.device)
+        dbase = torch.empty_like(base)
+        dw1 = torch.zeros_like(w1)  # only the one-hot columns cimg..cimg+L-1 are written
+        check(lib().sf_leadtime_pool_bwd(T(base), T(g), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(dbase),
+                                         dw1.data_ptr(), SF_F32, stream_ptr()), "sf_leadtime_pool_bwd")
+        return dbase, dw1, None, None
+
+
+def leadtime_pool(base: Tensor, w1: Tensor, cimg: int, L: int) -> Tensor:
+    return _LeadTimePoolFn.apply(base, w1, cimg, L)
+
+
 class _BatchNormTrainFn(torch.autograd.Function):
     """Training-mode BatchNorm2d with ``groups`` independent statistics sets (one per lead time)."""
 

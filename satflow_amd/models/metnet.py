@@ -9,9 +9,10 @@ constructor surface and the upstream ``state_dict`` key names (``image_encoder.m
 Execution (differs from upstream by design, same results):
   * all ``forecast_steps`` lead times are ONE batch (upstream loops and recomputes everything per lead
     time); BatchNorm keeps upstream's per-call statistics by reducing per lead-time group;
-  * the preprocessed frames are computed once and broadcast over the lead-time axis by the
-    convolution kernel's image-index remap; the one-hot ConditionTime planes are a tiny constant
-    second source of conv1 instead of ``forecast_steps`` materialised copies of the sequence;
+  * conv1 is linear and the ConditionTime planes are constant one-hot images, so its image part is
+    computed once per frame (not once per frame and lead time) and the per-lead-time contribution - a
+    border-aware constant per output channel - is added inside the fused first max-pooling
+    (``sf_leadtime_pool_fwd/bwd``); the sequence is never replicated ``forecast_steps`` times;
   * the ConvGRU's input convolutions run for all timesteps in one launch; only the hidden-state
     convolution is sequential, fused with the gate arithmetic.
 """
@@ -77,11 +78,11 @@ class DownSampler(nn.Module):
         oc = output_channels
         self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
 
-    def run(self, x: Tensor, groups: int, first: Optional[Tensor] = None, perm=None) -> Tensor:
-        """NHWC pipeline from conv1's output (``first``) or input ``x``; ``groups`` BatchNorm batches."""
+    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None) -> Tensor:
+        """NHWC pipeline from the first pooling's output (``pooled``) or from the input ``x``; ``groups`` BatchNorm batches."""
         m = self.module
-        y = first if first is not None else F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias)
-        y = F.batchnorm(F.maxpool2(y), m[3], groups, self.training)
+        y = pooled if pooled is not None else F.maxpool2(F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias))
+        y = F.batchnorm(y, m[3], groups, self.training)
         y = F.batchnorm(F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias), m[5], groups, self.training)
         y = F.batchnorm(F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias), m[7], groups, self.training)
         return F.maxpool2(F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias), perm)
@@ -244,19 +245,8 @@ class MetNet(nn.Module):
         self.temporal_enc = TemporalEncoder(encoder.output_channels, hidden_dim, ks=kernel_size, n_layers=num_layers)
         self.temporal_agg = nn.Sequential(*[AxialAttention(dim=hidden_dim, dim_index=1, heads=8, num_dimensions=2) for _ in range(num_att_layers)])
         self.head = nn.Conv2d(hidden_dim, output_channels, kernel_size=(1, 1))
-        # conv1 over [image lanes ; one-hot lead-time lanes]
-        self._conv1 = ConvEngine([self.image_channels, forecast_steps], 160)
-        self._onehot = {}
-
-    def _onehot_planes(self, S: int, device) -> Tensor:
-        """ConditionTime planes (reference ``layers/ConditionTime.py:5-10``): ``[L, S, S, cpad(L)]``, lane i of image i is 1."""
-        key = (S, str(device))
-        if key not in self._onehot:
-            L = self.forecast_steps
-            planes = torch.zeros(L, S, S, cpad(L), dtype=torch.float32, device=device)
-            planes[torch.arange(L), :, :, torch.arange(L)] = 1.0
-            self._onehot[key] = planes
-        return self._onehot[key]
+        # conv1 restricted to the image lanes (the one-hot lead-time lanes are folded into the first pooling)
+        self._conv1 = ConvEngine([self.image_channels], 160)
 
     def forward(self, imgs: Tensor, lead_time: int = 0) -> Tensor:
         """``imgs[B,T,C,4*input_size,4*input_size] -> [B, forecast_steps, output_channels, input_size//4, input_size//4]``."""
@@ -270,12 +260,15 @@ class MetNet(nn.Module):
         enc: DownSampler = self.image_encoder.module
         F_ = Tn * B
         frames = K.metnet_preprocess(imgs.float(), self.sat_channels, S)  # [T*B, S, S, Cimg_p], computed once
-        # conv1 for every (lead time, frame): image (l*F + f) reads frame f and one-hot plane l
+        # conv1: its image part once per frame; ConditionTime's one-hot planes (reference layers/ConditionTime.py:22-33)
+        # contribute a per-lead-time, border-aware constant that is added inside the fused first pooling
         c1 = enc.module[0]
-        y1 = F.conv3x3_broadcast(self._conv1, frames, self._onehot_planes(S, imgs.device), c1.weight, c1.bias, L * F_, (0, F_), (F_, 0))
+        cimg = self.image_channels
+        base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias)  # [T*B, S, S, 160]
+        p1 = F.leadtime_pool(base, c1.weight, cimg, L)  # [L*T*B, S/2, S/2, 160], image (l*F + f)
         # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
         # images from [lead][time][batch] to [time][lead][batch] for the recurrent part
-        feat = enc.run(None, L, first=y1, perm=(L, Tn))  # [T*L*B, S/4, S/4, 256]
+        feat = enc.run(None, L, pooled=p1, perm=(L, Tn))  # [T*L*B, S/4, S/4, 256]
         if self.training and self.drop.p > 0:
             feat = torch.nn.functional.dropout(feat, self.drop.p, True)
         _, last = self.temporal_enc.rnn.run(feat, Tn, L * B)
