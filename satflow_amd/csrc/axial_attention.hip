@@ -122,6 +122,75 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
   }
 }
 
+
+// Backward, block-per-image form: one thread per pixel, loop over (axis, head).  Each thread computes ITS query row's
+// softmax P and dS once, parks both rows in LDS, and after a barrier gathers the columns it needs as key/value
+// position - L x less arithmetic than the gather-from-scratch kernel above (which stays as the fallback for
+// images with more than 1024 pixels).  Deterministic (no atomics).
+__global__ void attn_bwd_block_kernel(const AttnParams p) {
+  extern __shared__ float sm[];  // P rows [pix][LS] then dS rows [pix][LS]
+  const int e = p.hid / p.heads;
+  const int npix = p.H * p.W;
+  const int LS = (p.H > p.W ? p.H : p.W) + 1;
+  float* Pl = sm;
+  float* Dl = sm + (size_t)npix * LS;
+  const long long img = blockIdx.x;
+  const int t = threadIdx.x;
+  const bool live = t < npix;
+  const int x = live ? t % p.W : 0, y = live ? t / p.W : 0;
+  const long long pix = img * npix + t;
+  for (int ah = 0; ah < 2 * p.heads; ++ah) {
+    const int axis = ah / p.heads, head = ah % p.heads;
+    const Line ln = line_of(img, y, x, axis, p.H, p.W);
+    const int off = axis * 3 * p.hidp + head * e;
+    const int doff = axis * p.hidp + head * e;
+    if (live) {
+      float q[MAXE], g[MAXE];
+      for (int j = 0; j < e; ++j) { q[j] = p.qkv[pix * p.qs + off + j]; g[j] = p.datt[pix * p.das + doff + j]; }
+      float s[MAXL], dP[MAXL];
+      float m = -INFINITY;
+      for (int i = 0; i < ln.len; ++i) {
+        const float* kv = p.qkv + (ln.base + (long long)i * ln.step) * p.qs + off;
+        float d = 0.f, dp = 0.f;
+        for (int j = 0; j < e; ++j) { d += q[j] * kv[p.hidp + j]; dp += g[j] * kv[2 * p.hidp + j]; }
+        s[i] = d * p.scale; dP[i] = dp; m = fmaxf(m, s[i]);
+      }
+      float z = 0.f;
+      for (int i = 0; i < ln.len; ++i) { s[i] = expf(s[i] - m); z += s[i]; }
+      const float inv = 1.f / z;
+      float spd = 0.f;
+      for (int i = 0; i < ln.len; ++i) { s[i] *= inv; spd += s[i] * dP[i]; }
+      float dq[MAXE];
+      for (int j = 0; j < e; ++j) dq[j] = 0.f;
+      for (int i = 0; i < ln.len; ++i) {
+        const float ds = s[i] * (dP[i] - spd) * p.scale;
+        Pl[t * LS + i] = s[i];
+        Dl[t * LS + i] = ds;
+        const float* k = p.qkv + (ln.base + (long long)i * ln.step) * p.qs + off + p.hidp;
+        for (int j = 0; j < e; ++j) dq[j] += ds * k[j];
+      }
+      float* d = p.dqkv + pix * p.dqs + off;
+      for (int j = 0; j < e; ++j) d[j] = dq[j];
+    }
+    __syncthreads();
+    if (live) {
+      float dk[MAXE], dv[MAXE];
+      for (int j = 0; j < e; ++j) dk[j] = dv[j] = 0.f;
+      for (int rq = 0; rq < ln.len; ++rq) {
+        const long long rp = ln.base + (long long)rq * ln.step;      // global pixel of query row rq
+        const int rt = (int)(rp - img * npix);                        // its thread / LDS row
+        const float pj = Pl[rt * LS + ln.pos], dsj = Dl[rt * LS + ln.pos];
+        const float* qr = p.qkv + rp * p.qs + off;
+        const float* gr = p.datt + rp * p.das + doff;
+        for (int j = 0; j < e; ++j) { dv[j] += pj * gr[j]; dk[j] += dsj * qr[j]; }
+      }
+      float* d = p.dqkv + pix * p.dqs + off;
+      for (int j = 0; j < e; ++j) { d[p.hidp + j] = dk[j]; d[2 * p.hidp + j] = dv[j]; }
+    }
+    __syncthreads();
+  }
+}
+
 int check(const AttnParams& p, sfTensor qkv, int c_other, const char* what) {
   if (p.hid % p.heads != 0 || p.hid / p.heads > MAXE || p.H > MAXL || p.W > MAXL || p.hid > p.hidp || qkv.c < 6 * p.hidp || c_other < 2 * p.hidp) {
     sf_set_error("%s: unsupported shape hid=%d heads=%d H=%d W=%d (need hid%%heads==0, hid/heads<=%d, H,W<=%d)", what, p.hid, p.heads, p.H,
@@ -165,7 +234,16 @@ int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32
   const long long total = nimg * h * w * 2 * heads;
   if (total == 0) return 0;
   if (hid < hidp) SF_REQUIRE(hipMemsetAsync(dqkv.ptr, 0, (size_t)nimg * h * w * dqkv.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
-  hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  const int npix = h * w;
+  if (npix <= 1024) {
+    const int threads = (npix + 63) / 64 * 64;
+    const int LS = (h > w ? h : w) + 1;
+    const size_t shmem = (size_t)2 * npix * LS * sizeof(float);
+    if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    hipLaunchKernelGGL(attn_bwd_block_kernel, dim3((unsigned)nimg), dim3(threads), shmem, (hipStream_t)stream, p);
+  } else {
+    hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
+  }
   SF_CHECK_LAUNCH("axial_attention_bwd");
   return 0;
 }

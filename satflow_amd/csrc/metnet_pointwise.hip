@@ -488,18 +488,22 @@ __global__ __launch_bounds__(256) void leadbias_pool_bwd_kernel(const float* __r
   for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
 }
 
-// dw1[co][cimg + l][ky][kx] = sum over classes where the tap is inside the image of sum_blocks cls_part[..][l][cls][co]
-__global__ void leadbias_wgrad_kernel(const float* __restrict__ cls_part, int nblocks, int L, int C, int O, int I, int cimg,
-                                      float* __restrict__ dw1) {
+// stage 1: cls_sum[l][cls][c] = sum over blocks of cls_part[block][l][cls][c]   (coalesced along c)
+__global__ void leadbias_reduce_kernel(const float* __restrict__ cls_part, int nblocks, int n, float* __restrict__ cls_sum) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  float a = 0.f;
+  for (int b = 0; b < nblocks; ++b) a += cls_part[(size_t)b * n + i];
+  cls_sum[i] = a;
+}
+
+// stage 2: dw1[co][cimg + l][ky][kx] = sum over the border classes for which that tap lies inside the image
+__global__ void leadbias_wgrad_kernel(const float* __restrict__ cls_sum, int L, int C, int O, int I, int cimg, float* __restrict__ dw1) {
   const int idx = blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= L * O) return;
   const int co = idx % O, l = idx / O;
   float s[9];
-  for (int cls = 0; cls < 9; ++cls) {
-    float a = 0.f;
-    for (int b = 0; b < nblocks; ++b) a += cls_part[((size_t)b * L + l) * 9 * C + cls * C + co];
-    s[cls] = a;
-  }
+  for (int cls = 0; cls < 9; ++cls) s[cls] = cls_sum[((size_t)l * 9 + cls) * C + co];
   float* w = dw1 + ((size_t)co * I + cimg + l) * 9;
   for (int ky = 0; ky < 3; ++ky)
     for (int kx = 0; kx < 3; ++kx) {
@@ -521,7 +525,7 @@ constexpr int LEADBIAS_BLOCKS = 512;
 
 extern "C" {
 
-size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C) { return (size_t)L * 9 * C * (1 + LEADBIAS_BLOCKS); }
+size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C) { return (size_t)L * 9 * C * (2 + LEADBIAS_BLOCKS); }
 
 int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I, int32_t cimg,
                          int32_t L, float* workspace, sfTensor out, int32_t dtype, sfStream stream) {
@@ -559,7 +563,10 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
                      base.stride, (const float*)dout.ptr, dout.stride, (long long)frames, h, w, C, L, workspace, (float*)dbase.ptr,
                      dbase.stride, cls_part);
   SF_CHECK_LAUNCH("leadbias_pool_bwd");
-  hipLaunchKernelGGL(leadbias_wgrad_kernel, dim3((L * O + 127) / 128), dim3(128), 0, st, cls_part, LEADBIAS_BLOCKS, L, C, O, I, cimg, dw1);
+  float* cls_sum = cls_part + (size_t)LEADBIAS_BLOCKS * nt;
+  hipLaunchKernelGGL(leadbias_reduce_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, cls_part, LEADBIAS_BLOCKS, nt, cls_sum);
+  SF_CHECK_LAUNCH("leadbias_reduce");
+  hipLaunchKernelGGL(leadbias_wgrad_kernel, dim3((L * O + 127) / 128), dim3(128), 0, st, cls_sum, L, C, O, I, cimg, dw1);
   SF_CHECK_LAUNCH("leadbias_wgrad");
   return 0;
 }
