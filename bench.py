@@ -187,8 +187,13 @@ class MetNetWorkload:
         import satflow_amd
         bf16 = satflow_amd.compute_dtype_name() == "bf16"
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r01_metnet_bf16_pmc_conv256.json")
+        if bf16 and n == 2304 and os.path.exists(pmc):  # PMC pass of this very launch shape (tools/prof_pmc.sh), per launch
+            rec = json.load(open(pmc))
+            traffic, traffic_src = rec["traffic_bytes"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; profiles/r01_metnet_bf16_pmc_conv256.json"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": flops / t / 1e12 / peak, "traffic": None,
+                "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"conv3x3_{'bf16' if bf16 else 'f32'}_kernel<NF=4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)",
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
