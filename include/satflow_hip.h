@@ -241,6 +241,20 @@ int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32
                                 int32_t hid, int32_t hidp, int32_t heads, sfTensor dqkv,
                                 int32_t dtype, sfStream stream);
 
+/* MSE loss, its gradient and the per-forecast-frame losses in one pass.  pred/target: n contiguous floats viewed as
+ * [outer][frames][inner] (frame index = (i / inner) % frames).  out[0] = mean (pred-target)^2, out[1+f] = mean over frame f,
+ * grad (nullable) = 2 (pred - target) / n.  sums: 1+frames doubles of scratch.  Replaces nn.MSELoss and the per-frame
+ * `.item()` loop of the Lightning steps (satflow/models/conv_lstm.py:63-69,79-84; pl_metnet.py:118-124). */
+int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner, int32_t frames, float* grad,
+                double* sums, float* out, sfStream stream);
+
+/* Fused dropouts of the MetNet encoder output: y = x * m1(i) * m2(i % period) with keep-scaling; m1 = nn.Dropout(
+ * temporal_dropout) (pl_metnet.py:58), m2 = the ConvGRU's sequence-consistent input dropout (time-major layout, period =
+ * elements of one timestep).  Masks are a counter-based hash of (seed, index): the backward calls the same function on the
+ * gradient with the same seeds. */
+int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
+                float* y, sfStream stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -11,7 +11,7 @@ from typing import Optional
 
 import torch
 
-_LIB_PATH = os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatflow_hip.so")
+_LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatflow_hip.so")
 
 SF_F32, SF_BF16 = 0, 1
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
@@ -67,6 +67,8 @@ PROTOTYPES = {
     "sf_linear_bwd_weight": (C.c_int, [sfTensor, _i32, sfTensor, _i64, _vp, _vp, _vp, _sz, _i32, _vp]),
     "sf_axial_attention_core_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_axial_attention_core_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_mse_loss": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
+    "sf_dropout2": (C.c_int, [_vp, _i64, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp, _vp]),
     "sf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, C.c_float, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),
 }

@@ -124,27 +124,46 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     const int cur = ci & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weight DMA has landed (LDS-DMA is not covered by the barrier)
     __syncthreads();
+#ifndef SF_EXP_NOSTAGE
     if (ci + 1 < nch) {
+#ifndef SF_EXP_NOWEIGHTS
       issue_weights(ci + 1, cur ^ 1);
+#endif
+#ifndef SF_EXP_NOINPUT
       load_input(ci + 1);
+#endif
     }
+#endif
     const char* inb = lds_in + cur * IN_B + a_lane;
     const char* wb = lds_w + cur * W_B + b_lane;
-#pragma unroll
-    for (int tap = 0; tap < 9; ++tap) {
+    auto load_tap = [&](int tap, bf16x8 (&a)[2], bf16x8 (&b)[NF]) {
       const int ky = tap / 3, kx = tap % 3;
-      bf16x8 a[2], b[NF];
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf)
         a[mf] = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO_W + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
+    };
+    bf16x8 fa[2][2], fb[2][NF];
+    load_tap(0, fa[0], fb[0]);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+      __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-        for (int nf = 0; nf < NF; ++nf) acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a[mf], b[nf], acc[mf][nf], 0, 0, 0);
+        for (int nf = 0; nf < NF; ++nf)
+#ifdef SF_EXP_NOMFMA
+          acc[mf][nf][0] += (float)fa[tap & 1][mf][0] * (float)fb[tap & 1][nf][0];
+#else
+          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
+#endif
+      __builtin_amdgcn_sched_barrier(0);
     }
+#ifndef SF_EXP_NOSTAGE
     if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
+#endif
   }
 
   conv_epilogue<NF, EPI>(acc, p, n, nb, y0, x0, wave, r, kh);

@@ -1,0 +1,126 @@
+// Training-step glue that the reference leaves to ATen and that sits on the hot path:
+//   * MSE loss with its gradient and the per-forecast-frame losses in ONE pass (reference: nn.MSELoss +
+//     a loop of `forecast_steps` extra MSE evaluations with .item() host syncs, satflow/models/conv_lstm.py:63-69,
+//     pl_metnet.py:118-124);
+//   * dropout on the encoder output (nn.Dropout(temporal_dropout), pl_metnet.py:58 -> metnet.MetNet) and the
+//     sequence-consistent "RNN" dropout of the ConvGRU input, fused into one pass; masks are a counter-based hash of
+//     (seed, element index), so the backward regenerates them instead of storing them.
+#include "sf_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// loss_sums[0] = sum (p-y)^2 ; loss_sums[1 + f] = per-frame sums; grad = 2 (p - y) / n
+__global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, long long n,
+                                                  long long inner, int frames, float gscale, float* __restrict__ grad,
+                                                  double* __restrict__ sums) {
+  __shared__ double red[64];
+  double tot = 0.0;
+  const bool vec = (inner & 3) == 0;  // 16-byte accesses need every slab base 4-aligned
+  // each block walks whole `inner`-sized frame slabs so that a block-level partial belongs to one frame
+  const long long slabs = n / inner;
+  for (long long s = blockIdx.x; s < slabs; s += gridDim.x) {
+    double acc = 0.0;
+    const long long base = s * inner;
+    for (long long i = threadIdx.x * 4; i < inner; i += 256 * 4) {
+      if (vec && i + 3 < inner) {
+        const f32x4 d = ld4(pred + base + i) - ld4(target + base + i);
+        if (grad) st4(grad + base + i, d * gscale);
+        acc += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
+      } else {
+        for (long long j = i; j < inner && j < i + 4; ++j) {
+          const float d = pred[base + j] - target[base + j];
+          if (grad) grad[base + j] = d * gscale;
+          acc += (double)(d * d);
+        }
+      }
+    }
+    // block reduce
+    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      const double a = red[0] + red[1] + red[2] + red[3];
+      atomicAdd(sums + 1 + (s % frames), a);
+      tot += a;
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0 && tot != 0.0) atomicAdd(sums, tot);
+}
+
+__global__ void mse_finalize_kernel(const double* __restrict__ sums, long long n, int frames, float* __restrict__ out) {
+  const int i = threadIdx.x;
+  if (i == 0) out[0] = (float)(sums[0] / (double)n);
+  if (i < frames) out[1 + i] = (float)(sums[1 + i] / ((double)n / frames));
+}
+
+__device__ __forceinline__ unsigned mix(unsigned long long x) {
+  // splitmix64 finaliser
+  x += 0x9E3779B97F4A7C15ull;
+  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
+  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
+  x ^= x >> 31;
+  return (unsigned)(x >> 32);
+}
+__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
+  // uniform in [0,1) from the top 24 bits
+  const float u = (float)(mix(seed ^ (idx * 0xD6E8FEB86659FD93ull)) >> 8) * (1.0f / 16777216.0f);
+  return u < p ? 0.f : inv_keep;
+}
+
+// y = x * m1(idx) * m2(idx % period); either probability may be 0 (mask == 1)
+__global__ __launch_bounds__(256) void dropout2_kernel(const float* __restrict__ x, long long n, float p1, float p2, long long period,
+                                                       unsigned long long seed1, unsigned long long seed2, float* __restrict__ y) {
+  const float k1 = p1 > 0.f ? 1.f / (1.f - p1) : 1.f, k2 = p2 > 0.f ? 1.f / (1.f - p2) : 1.f;
+  const long long n4 = n >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
+    f32x4 v = ld4(x + i * 4);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const unsigned long long idx = (unsigned long long)(i * 4 + j);
+      float s = 1.f;
+      if (p1 > 0.f) s *= keep_scale(seed1, idx, p1, k1);
+      if (p2 > 0.f) s *= keep_scale(seed2, idx % (unsigned long long)period, p2, k2);
+      v[j] *= s;
+    }
+    st4(y + i * 4, v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner, int32_t frames, float* grad, double* sums,
+                float* out, sfStream stream) {
+  SF_REQUIRE(n > 0 && inner > 0 && n % inner == 0 && frames >= 1 && frames <= 1023 && (n / inner) % frames == 0,
+             "mse: n=%lld inner=%lld frames=%d", (long long)n, (long long)inner, frames);
+  SF_REQUIRE(((((uintptr_t)pred) | ((uintptr_t)target) | ((uintptr_t)grad)) & 15) == 0, "mse: buffers must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  SF_REQUIRE(hipMemsetAsync(sums, 0, sizeof(double) * (1 + frames), st) == hipSuccess, "mse: memset");
+  const long long slabs = n / inner;
+  const int blocks = (int)(slabs < 2048 ? slabs : 2048);
+  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long long)n, (long long)inner, frames, 2.0f / (float)n, grad, sums);
+  SF_CHECK_LAUNCH("mse");
+  hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, (long long)n, frames, out);
+  SF_CHECK_LAUNCH("mse_finalize");
+  return 0;
+}
+
+int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, float* y,
+                sfStream stream) {
+  SF_REQUIRE(n % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && period > 0,
+             "dropout2: n=%lld p1=%f p2=%f period=%lld", (long long)n, p1, p2, (long long)period);
+  if (n == 0) return 0;
+  const long long n4 = n >> 2;
+  const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
+  hipLaunchKernelGGL(dropout2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, p1, p2, (long long)period,
+                     (unsigned long long)seed1, (unsigned long long)seed2, y);
+  SF_CHECK_LAUNCH("dropout2");
+  return 0;
+}
+
+}  // extern "C"

@@ -461,3 +461,65 @@ def K_bias_mask(eng: GRUEngine, dev):
 
 def convgru_sequence(eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor) -> Tuple[Tensor, Tensor]:
     return _ConvGRUSeqFn.apply(eng, x, Tn, Wx, bx, Wh, bh)
+
+
+# ----------------------------------------------------------------------------------------------
+# loss / dropout
+# ----------------------------------------------------------------------------------------------
+class _MSEFn(torch.autograd.Function):
+    """(mean squared error, per-frame means) with the gradient produced in the same pass."""
+
+    @staticmethod
+    def forward(ctx, pred: Tensor, target: Tensor, frames: int, inner: int):
+        pred, target = pred.contiguous(), target.contiguous()
+        n = pred.numel()
+        grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        sums = torch.empty(1 + frames, dtype=torch.float64, device=pred.device)
+        out = torch.empty(1 + frames, dtype=torch.float32, device=pred.device)
+        check(lib().sf_mse_loss(pred.data_ptr(), target.data_ptr(), n, inner, frames, grad.data_ptr() if grad is not None else None,
+                                sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_mse_loss")
+        ctx.save_for_backward(grad if grad is not None else pred.new_empty(0))
+        ctx.mark_non_differentiable(out[1:])
+        return out[0], out[1:]
+
+    @staticmethod
+    def backward(ctx, g_loss: Tensor, _g_frames):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss, None, None, None
+
+
+def mse_loss_with_frames(pred: Tensor, target: Tensor, frame_dim: int = 1) -> Tuple[Tensor, Tensor]:
+    """``(F.mse_loss(pred, target), per-frame losses)`` for contiguous tensors whose ``frame_dim`` indexes the forecast frame."""
+    require_device(pred, "pred")
+    if pred.shape != target.shape:
+        raise RuntimeError(f"mse: shape mismatch {tuple(pred.shape)} vs {tuple(target.shape)}")
+    frames = pred.shape[frame_dim]
+    inner = 1
+    for d in pred.shape[frame_dim + 1:]:
+        inner *= d
+    return _MSEFn.apply(pred.float(), target.float(), frames, inner)
+
+
+class _Dropout2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, p1: float, p2: float, period: int, seed1: int, seed2: int):
+        ctx.meta = (p1, p2, period, seed1, seed2)
+        y = torch.empty_like(x)
+        check(lib().sf_dropout2(x.data_ptr(), x.numel(), p1, p2, period, seed1, seed2, y.data_ptr(), stream_ptr()), "sf_dropout2")
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        p1, p2, period, seed1, seed2 = ctx.meta
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        check(lib().sf_dropout2(g.data_ptr(), g.numel(), p1, p2, period, seed1, seed2, gx.data_ptr(), stream_ptr()), "sf_dropout2")
+        return gx, None, None, None, None, None
+
+
+def dropout2(x: Tensor, p1: float, p2: float, period: int) -> Tensor:
+    """Elementwise dropout ``p1`` fused with a dropout ``p2`` whose mask repeats every ``period`` elements (shared over time)."""
+    if p1 <= 0 and p2 <= 0:
+        return x
+    seeds = torch.randint(0, 2**62, (2,), dtype=torch.int64).tolist()  # host RNG: follows torch.manual_seed, no device sync
+    return _Dropout2Fn.apply(x.contiguous(), float(p1), float(p2), int(period), seeds[0], seeds[1])

@@ -76,6 +76,24 @@ class BaseModel(LightningModule):
     """Placeholder for ``nowcasting_utils.models.base.BaseModel`` (``pl_metnet.py:16``)."""
 
 
+class MSELoss(nn.Module):
+    """``nn.MSELoss()`` (mean reduction) on the fused HIP kernel: loss, its gradient and the per-frame losses of dim 1
+    in one pass (``sf_mse_loss``).  ``last_frame_losses`` holds the per-frame means of the latest call (device tensor)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+        self.last_frame_losses = None
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        from ..functional import mse_loss_with_frames
+
+        if pred.dim() < 2:
+            pred, target = pred.reshape(1, -1), target.reshape(1, -1)
+        loss, frames = mse_loss_with_frames(pred, target, frame_dim=1)
+        self.last_frame_losses = frames
+        return loss
+
+
 def get_loss(loss: Union[str, nn.Module, Callable] = "mse", **kwargs: Any) -> nn.Module:
     """``nowcasting_utils.models.loss.get_loss``: only ``"mse"`` is on the hot path."""
     if isinstance(loss, nn.Module):
@@ -83,5 +101,5 @@ def get_loss(loss: Union[str, nn.Module, Callable] = "mse", **kwargs: Any) -> nn
     if callable(loss) and not isinstance(loss, str):
         return loss
     if loss in ("mse", "MSE"):
-        return nn.MSELoss()
+        return MSELoss()
     raise ValueError(f"loss {loss!r} is outside the hot-path scope (only 'mse'; see DESIGN.md)")

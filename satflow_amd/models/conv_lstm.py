@@ -230,7 +230,8 @@ class EncoderDecoderConvLSTM(LightningModule):
     #    per-frame losses come from ONE reduction and ONE host sync instead of forecast_steps .item() calls
     #    (reference conv_lstm.py:66-68,80-82).
     def _frame_losses(self, y_hat: Tensor, y: Tensor) -> Tensor:
-        return ((y_hat.detach() - y) ** 2).mean(dim=(0, 2, 3, 4))
+        frames = getattr(self.criterion, "last_frame_losses", None)  # produced by the fused loss kernel in the same pass
+        return frames if frames is not None else ((y_hat.detach() - y) ** 2).mean(dim=(0, 2, 3, 4))
 
     def _log_frames(self, prefix: str, frames: Tensor) -> None:
         # logged as 0-dim device tensors: no host sync in the step (Lightning reduces them at epoch end)

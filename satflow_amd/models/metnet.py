@@ -137,19 +137,18 @@ class ConvGRU(nn.Module):
             [ConvGRUCell(input_dim if i == 0 else hidden_dim, hidden_dim, kernel_size, bias) for i in range(n_layers)]
         )
 
-    def run(self, x: Tensor, T_steps: int, n: int):
+    def run(self, x: Tensor, T_steps: int, n: int, input_dropout_done: bool = False):
         """x ``[T*n,h,w,Cp]`` time-major -> (last layer's states ``[T*n,h,w,hidp]``, [last state per layer])."""
-        if self.training and self.input_p > 0:  # sequence-consistent ("RNN") dropout on the input [RECALLED upstream]
-            N, h, w, C = x.shape
-            mask = torch.nn.functional.dropout(torch.ones(1, n, h, w, C, device=x.device), self.input_p, True)
-            x = (x.view(T_steps, n, h, w, C) * mask).view(N, h, w, C)
+        if self.training and self.input_p > 0 and not input_dropout_done:
+            # sequence-consistent ("RNN") dropout on the input [RECALLED upstream]: one mask shared by all timesteps
+            x = F.dropout2(x, 0.0, self.input_p, x.numel() // T_steps)
         last: List[Tensor] = []
         seq = x
         for i, cell in enumerate(self.cell_list):
             seq, h_last = cell.run_sequence(seq, T_steps)
             last.append(h_last)
             if self.training and self.hidden_p > 0 and i + 1 < self.n_layers:
-                seq = torch.nn.functional.dropout(seq, self.hidden_p, True)
+                seq = F.dropout2(seq, self.hidden_p, 0.0, seq.numel())
         return seq, last
 
 
@@ -269,9 +268,10 @@ class MetNet(nn.Module):
         # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
         # images from [lead][time][batch] to [time][lead][batch] for the recurrent part
         feat = enc.run(None, L, pooled=p1, perm=(L, Tn))  # [T*L*B, S/4, S/4, 256]
-        if self.training and self.drop.p > 0:
-            feat = torch.nn.functional.dropout(feat, self.drop.p, True)
-        _, last = self.temporal_enc.rnn.run(feat, Tn, L * B)
+        rnn = self.temporal_enc.rnn
+        if self.training:  # nn.Dropout(temporal_dropout) and the ConvGRU's sequence-consistent input dropout, one fused pass
+            feat = F.dropout2(feat, self.drop.p, rnn.input_p, feat.numel() // Tn)
+        _, last = rnn.run(feat, Tn, L * B, input_dropout_done=True)
         a = last[-1]  # [L*B, s, s, hidp]
         for layer in self.temporal_agg:
             a = layer.run(a)

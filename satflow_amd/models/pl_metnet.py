@@ -92,7 +92,9 @@ class LitMetNet(BaseModel):
         tag = "train" if is_training else "val"
         loss = self.criterion(y_hat, y)
         self.log(f"{tag}/loss", loss, prog_bar=True)
-        frames = ((y_hat.detach() - y) ** 2).mean(dim=tuple(d for d in range(y.dim()) if d != 1))
+        frames = getattr(self.criterion, "last_frame_losses", None)  # from the fused loss kernel, same pass
+        if frames is None:
+            frames = ((y_hat.detach() - y) ** 2).mean(dim=tuple(d for d in range(y.dim()) if d != 1))
         self.log_dict({f"{tag}/frame_{f}_loss": v for f, v in enumerate(frames.unbind(0))})
         return loss
 

@@ -288,3 +288,41 @@ def test_metnet_eval_and_reference_shape_pin(device):
         got = net(xs.to(device))
         ref = M.metnet_forward(xs, {k: v.detach() for k, v in P.items()}, sat_channels=4, input_size=8, forecast_steps=3, bn_stats=stats)
     assert_close(got, ref, "metnet eval")
+
+
+def test_mse_loss_kernel(device):
+    from satflow_amd.models.base import get_loss
+
+    crit = get_loss("mse")
+    for shape in [(2, 3, 4, 8, 8), (3, 5, 7, 9), (1, 12, 12, 16, 16)]:
+        p = torch.randn(*shape, generator=_g(31))
+        y = torch.randn(*shape, generator=_g(32))
+        pr = p.clone().requires_grad_()
+        ref = TF.mse_loss(pr, y)
+        (ref * 3.0).backward()
+        pd = p.to(device).requires_grad_()
+        loss = crit(pd, y.to(device))
+        (loss * 3.0).backward()
+        assert_close(loss, ref, "mse", rtol=1e-6, atol=1e-7)
+        assert_close(pd.grad, pr.grad, "mse grad", rtol=1e-6, atol=1e-9)
+        frames = ((p - y) ** 2).mean(dim=tuple(d for d in range(p.dim()) if d != 1))
+        assert_close(crit.last_frame_losses, frames, "frame losses", rtol=1e-5, atol=1e-7)
+
+
+def test_dropout2_kernel(device):
+    from satflow_amd import functional as F
+
+    torch.manual_seed(0)
+    T, per = 4, 2048
+    x = torch.ones(T * per, device=device, requires_grad=True)
+    y = F.dropout2(x, 0.2, 0.25, per)
+    keep = (y != 0).float()
+    # keep probability ~ 0.8 * 0.75, surviving values scaled by 1/(0.8*0.75)
+    assert abs(float(keep.mean()) - 0.6) < 0.03
+    assert torch.allclose(y[y != 0], torch.full_like(y[y != 0], 1 / 0.6), rtol=1e-6)
+    # the second mask repeats with the period (sequence-consistent): a position dropped by it is dropped at every timestep
+    y2 = F.dropout2(torch.ones(T * per, device=device), 0.0, 0.5, per).view(T, per)
+    assert torch.equal(y2[0] != 0, y2[1] != 0) and torch.equal(y2[0] != 0, y2[3] != 0)
+    # backward applies the very same mask
+    y.sum().backward()
+    assert torch.equal(x.grad, y.detach())
