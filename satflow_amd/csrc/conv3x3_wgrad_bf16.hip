@@ -85,69 +85,76 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const bool a_ok = aco < p.dc;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    for (int i = 0; i <= my_tiles; ++i) {
-      if (i < my_tiles) {
-        int t = ks + i * p.KS;
-        const int tx = t % p.tiles_x; t /= p.tiles_x;
-        const int ty = t % p.tiles_y;
-        const int n = t / p.tiles_y;
-        const int x0 = tx * KT_W, y0 = ty * KR;
-        char* la = lds + (i & 1) * BUF;
-        char* lb = la + A_BYTES;
-        char* lh = lb + B_BYTES;
-        // All global loads of this thread's share of the tile are issued before any conversion so that one memory
-        // latency is exposed per tile (2 dout items of 8 pixels + 1 input item of 10 pixels = 26 float4 in flight).
-        // dout tile: items (cq 32, row 8, half 2) -> item = lt and lt + 256
-        f32x4 va[2][8];
+    // Register-staged software pipeline: the global loads of tile i+1 are issued right after tile i has been written
+    // to LDS and stay in flight across the barrier, i.e. during the compute waves' work on tile i.
+    const bool b_item = lt < 8 * HR * 2;
+    const int brest = lt / 8, bhalf = brest & 1, bhrow = brest >> 1;
+    f32x4 va[2][8], vb[10];
+    auto load_tile = [&](int i) {
+      int t = ks + i * p.KS;
+      const int tx = t % p.tiles_x; t /= p.tiles_x;
+      const int ty = t % p.tiles_y;
+      const int n = t / p.tiles_y;
+      const int x0 = tx * KT_W, y0 = ty * KR;
+      // dout tile: items (cq 32, row 8, half 2) -> item = lt and lt + 256.  One row pointer per item, pixel j at
+      // a constant stride from it (address arithmetic was the loaders' bottleneck: ~600 VALU per tile per wave).
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
-          const int gy = y0 + row;
+      for (int u = 0; u < 2; ++u) {
+        const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
+        const int gy = y0 + row, gx0 = x0 + 8 * half;
+        const float* prow = p.dout + ((size_t)(n * p.H + gy) * p.W + gx0) * p.ds + aco;
+        const int lim = (a_ok && gy < p.H) ? p.W - gx0 : 0;  // pixels j < lim are inside the image
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const int gx = x0 + 8 * half + j;
-            va[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (a_ok && gy < p.H && gx < p.W) va[u][j] = *reinterpret_cast<const f32x4*>(p.dout + ((size_t)(n * p.H + gy) * p.W + gx) * p.ds + aco);
-          }
-        }
-        // input halo tile: items (cq 8, halo row 10, half 2) = 160 items; pixels x0-1+8*half .. +9
-        int ns = n / bdiv; if (bmod) ns %= bmod;
-        const bool b_item = lt < 8 * HR * 2;
-        const int brest = lt / 8, bhalf = brest & 1, bhrow = brest >> 1;
-        f32x4 vb[10];
-        {
-          const int gy = y0 + bhrow - 1;
-#pragma unroll
-          for (int j = 0; j < 10; ++j) {
-            const int gx = x0 - 1 + 8 * bhalf + j;
-            vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-            if (b_item && bsrc && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-              vb[j] = *reinterpret_cast<const f32x4*>(bsrc + ((size_t)(ns * p.H + gy) * p.W + gx) * bstride + bch);
-          }
-        }
-#pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
-          char* dst = la + a_cq * A_S + (row * 2 + half) * 64;
-#pragma unroll
-          for (int j = 0; j < 8; ++j) bsum += va[u][j];
-#pragma unroll
-          for (int c = 0; c < 4; ++c)
-            *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
-                pack8(va[u][0][c], va[u][1][c], va[u][2][c], va[u][3][c], va[u][4][c], va[u][5][c], va[u][6][c], va[u][7][c]);
-        }
-        if (b_item) {
-          char* dst = lb + b_cq * B_S + (bhrow * 2 + bhalf) * 64;
-#pragma unroll
-          for (int c = 0; c < 4; ++c) {
-            *reinterpret_cast<bf16x8*>(dst + quad_slot(b_cq, c)) = pack8(vb[1][c], vb[2][c], vb[3][c], vb[4][c], vb[5][c], vb[6][c], vb[7][c], vb[8][c]);
-            // halo pixels: left neighbour in the HIGH half of its dword, right neighbour in the LOW half
-            unsigned* hp = reinterpret_cast<unsigned*>(lh + (b_cq * 4 + c) * H_P + bhrow * 8);
-            if (bhalf == 0) hp[0] = bf16_bits(vb[0][c]) << 16;
-            else            hp[1] = bf16_bits(vb[9][c]);
-          }
+        for (int j = 0; j < 8; ++j) {
+          va[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (j < lim) va[u][j] = *reinterpret_cast<const f32x4*>(prow + (size_t)j * p.ds);
         }
       }
+      // input halo tile: items (cq 8, halo row 10, half 2) = 160 items; pixels x0-1+8*half .. +9
+      int ns = n / bdiv; if (bmod) ns %= bmod;
+      const int gy = y0 + bhrow - 1, gx0 = x0 - 1 + 8 * bhalf;
+      const float* prow = bsrc + ((long long)(ns * p.H + gy) * p.W + gx0) * bstride + bch;
+      const bool rok = b_item && bsrc && gy >= 0 && gy < p.H;
+      const int lo = rok ? -gx0 : 99, hi = rok ? p.W - gx0 : 0;  // pixels lo <= j < hi are inside the image
+#pragma unroll
+      for (int j = 0; j < 10; ++j) {
+        vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (j >= lo && j < hi) vb[j] = *reinterpret_cast<const f32x4*>(prow + (long long)j * bstride);
+      }
+    };
+    auto store_tile = [&](int i) {
+      char* la = lds + (i & 1) * BUF;
+      char* lb = la + A_BYTES;
+      char* lh = lb + B_BYTES;
+#pragma unroll
+      for (int u = 0; u < 2; ++u) {
+        const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
+        char* dst = la + a_cq * A_S + (row * 2 + half) * 64;
+        if (cit == 0) {  // block-uniform: only the first ci tile's blocks report the bias gradient
+#pragma unroll
+          for (int j = 0; j < 8; ++j) bsum += va[u][j];
+        }
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
+              pack8(va[u][0][c], va[u][1][c], va[u][2][c], va[u][3][c], va[u][4][c], va[u][5][c], va[u][6][c], va[u][7][c]);
+      }
+      if (b_item) {
+        char* dst = lb + b_cq * B_S + (bhrow * 2 + bhalf) * 64;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          *reinterpret_cast<bf16x8*>(dst + quad_slot(b_cq, c)) = pack8(vb[1][c], vb[2][c], vb[3][c], vb[4][c], vb[5][c], vb[6][c], vb[7][c], vb[8][c]);
+          // halo pixels: left neighbour in the HIGH half of its dword, right neighbour in the LOW half
+          unsigned* hp = reinterpret_cast<unsigned*>(lh + (b_cq * 4 + c) * H_P + bhrow * 8);
+          if (bhalf == 0) hp[0] = bf16_bits(vb[0][c]) << 16;
+          else            hp[1] = bf16_bits(vb[9][c]);
+        }
+      }
+    };
+    if (my_tiles > 0) load_tile(0);
+    for (int i = 0; i <= my_tiles; ++i) {
+      if (i < my_tiles) store_tile(i);
+      if (i + 1 < my_tiles) load_tile(i + 1);
       __syncthreads();
     }
     // bias gradient: 8 loader threads share a channel quad
