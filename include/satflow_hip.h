@@ -190,8 +190,8 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
                           int32_t dtype, sfStream stream);
 int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups,
                            int32_t creal, const float* gamma, const float* mean, const float* rstd,
-                           double* sums, sfTensor dx, float* dgamma, float* dbeta, int32_t dtype,
-                           sfStream stream);
+                           double* sums, float* coef /* scratch [groups][3][C] */, sfTensor dx,
+                           float* dgamma, float* dbeta, int32_t dtype, sfStream stream);
 
 /* Lead-time de-duplication of MetNet's first convolution (ConditionTime planes are constant one-hot images and
  * conv1 is linear): with base = conv1_image(frame) + b computed ONCE per frame,

@@ -207,30 +207,32 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
   }
 }
 
-// dx = gamma*rstd * (dy - sum_dy/N - xhat * sum_dyxhat/N)
+// dx = gamma*rstd * (dy - sum_dy/N - xhat * sum_dyxhat/N)  ==  A*dy + B*x + K  per (group, channel):
+//   A = gamma*rstd,  B = -gamma*rstd^2*m2,  K = -gamma*rstd*m1 + gamma*rstd^2*m2*mean,   m1 = sum_dy/N, m2 = sum_dyxhat/N
+__global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int G, int C, int Creal, double count, const float* __restrict__ gamma,
+                                   const float* __restrict__ mean, const float* __restrict__ rstd, float* __restrict__ coef /*[G][3][C]*/) {
+  const int idx = blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= G * C) return;
+  const int c = idx % C, g = idx / C;
+  float A = 0.f, B = 0.f, K = 0.f;
+  if (c < Creal) {
+    const double m1 = sums[((size_t)g * 2 + 0) * C + c] / count, m2 = sums[((size_t)g * 2 + 1) * C + c] / count;
+    const double ga = gamma[c], r = rstd[(size_t)g * C + c], mu = mean[(size_t)g * C + c];
+    A = (float)(ga * r); B = (float)(-ga * r * r * m2); K = (float)(-ga * r * m1 + ga * r * r * m2 * mu);
+  }
+  coef[((size_t)g * 3 + 0) * C + c] = A; coef[((size_t)g * 3 + 1) * C + c] = B; coef[((size_t)g * 3 + 2) * C + c] = K;
+}
+
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, int dys,
-                                                           long long pixels, long long pix_per_group, int C, int Creal,
-                                                           const float* __restrict__ gamma, const float* __restrict__ mean,
-                                                           const float* __restrict__ rstd, const double* __restrict__ sums,
+                                                           long long pixels, long long pix_per_group, int C, const float* __restrict__ coef,
                                                            float* __restrict__ dx, int dxs) {
   const int q = C / 4;
   const long long total = pixels * q;
-  const float invn = 1.f / (float)pix_per_group;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long p = idx / q;
     const int c = (idx % q) * 4;
-    const long long g = p / pix_per_group;
-    const f32x4 v = ld4(x + p * xs + c), d = ld4(dy + p * dys + c);
-    const f32x4 mu = ld4(mean + g * C + c), rs = ld4(rstd + g * C + c);
-    f32x4 o;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const float ga = (c + j < Creal) ? gamma[c + j] : 0.f;
-      const float xh = (v[j] - mu[j]) * rs[j];
-      const float sd = (float)sums[(g * 2 + 0) * C + c + j], sdx = (float)sums[(g * 2 + 1) * C + c + j];
-      o[j] = ga * rs[j] * (d[j] - sd * invn - xh * sdx * invn);
-    }
-    st4(dx + p * dxs + c, o);
+    const float* k = coef + (p / pix_per_group) * 3 * C + c;
+    st4(dx + p * dxs + c, ld4(k) * ld4(dy + p * dys + c) + ld4(k + C) * ld4(x + p * xs + c) + ld4(k + 2 * C));
   }
 }
 
@@ -355,16 +357,18 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
 }
 
 int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma,
-                           const float* mean, const float* rstd, double* sums, sfTensor dx, float* dgamma, float* dbeta,
+                           const float* mean, const float* rstd, double* sums, float* coef, sfTensor dx, float* dgamma, float* dbeta,
                            int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_bwd: dtype %d not built", dtype);
   SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok4(dx), "batchnorm bwd: channels");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = bn_reduce_launch(1, x, dy, pix_per_group, groups, mean, rstd, sums, st)) return rc;
   const long long pixels = pix_per_group * groups;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((groups * x.c + 255) / 256), dim3(256), 0, st, sums, groups, x.c, creal, (double)pix_per_group,
+                     gamma, mean, rstd, coef);
+  SF_CHECK_LAUNCH("bn_bwd_coef");
   hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride,
-                     (const float*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, creal, gamma, mean, rstd, sums,
-                     (float*)dx.ptr, dx.stride);
+                     (const float*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, coef, (float*)dx.ptr, dx.stride);
   SF_CHECK_LAUNCH("bn_bwd_apply");
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, dgamma, dbeta);
   SF_CHECK_LAUNCH("bn_param_grad");
@@ -438,7 +442,7 @@ __global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const float* __r
 
 // dbase[f] = sum_l unpool(dpooled[l*F+f]);  partial class sums cls_part[block][l][cls][c] (deterministic 2-stage reduce).
 // Persistent grid; each block keeps S[l][cls][c] in LDS (ds_add_f32), flushed once at the end.
-__global__ __launch_bounds__(256) void leadbias_pool_bwd_kernel(const float* __restrict__ base, int bs, const float* __restrict__ dout, int dos,
+__global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const float* __restrict__ base, int bs, const float* __restrict__ dout, int dos,
                                                                 long long F, int H, int W, int C, int L, const float* __restrict__ ptab,
                                                                 float* __restrict__ dbase, int dbs, float* __restrict__ cls_part) {
   extern __shared__ float S[];  // [L][9][C]
@@ -460,6 +464,7 @@ __global__ __launch_bounds__(256) void leadbias_pool_bwd_kernel(const float* __r
     k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
     const bool interior = k[0] == 4 && k[3] == 4;
     f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+#pragma unroll 4
     for (int l = 0; l < L; ++l) {
       const float* pt = ptab + (size_t)l * 9 * C + c;
       const f32x4 a0 = v0 + ld4(pt + k[0] * C), a1 = v1 + ld4(pt + k[1] * C), a2 = v2 + ld4(pt + k[2] * C), a3 = v3 + ld4(pt + k[3] * C);
@@ -559,7 +564,7 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
     attr_set = true;
   }
   float* cls_part = workspace + nt;
-  hipLaunchKernelGGL(leadbias_pool_bwd_kernel, dim3(LEADBIAS_BLOCKS), dim3(256), (size_t)nt * sizeof(float), st, (const float*)base.ptr,
+  hipLaunchKernelGGL(leadbias_pool_bwd_kernel, dim3(LEADBIAS_BLOCKS), dim3(1024), (size_t)nt * sizeof(float), st, (const float*)base.ptr,
                      base.stride, (const float*)dout.ptr, dout.stride, (long long)frames, h, w, C, L, workspace, (float*)dbase.ptr,
                      dbase.stride, cls_part);
   SF_CHECK_LAUNCH("leadbias_pool_bwd");

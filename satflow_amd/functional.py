@@ -246,9 +246,10 @@ class _BatchNormTrainFn(torch.autograd.Function):
         dx = torch.empty_like(x)
         sums = torch.empty(ctx.groups, 2, C, dtype=torch.float64, device=x.device)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        coef = torch.empty(ctx.groups, 3, C, dtype=torch.float32, device=x.device)
         check(lib().sf_batchnorm_train_bwd(T(x), T(gy), pixels // ctx.groups, ctx.groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
-                                           stats[1].data_ptr(), sums.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32,
-                                           stream_ptr()), "sf_batchnorm_train_bwd")
+                                           stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
+                                           SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
         return dx, dgamma, dbeta, None, None, None, None, None
 
 
