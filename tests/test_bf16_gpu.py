@@ -104,3 +104,66 @@ def test_model_bf16_vs_golden(device, bf16_mode, case):
     rel = float((g - ref).norm() / ref.norm())
     print(f"   decoder_CNN.weight grad rel L2 {rel:.3e}")
     assert rel < 5e-2
+
+
+def test_metnet_bf16_train_step(device, bf16_mode):
+    """Whole MetNet training step in bf16-MFMA mode against the fp32 oracle: output and every parameter gradient within
+    bf16-operand tolerance (relative L2), printed for the record."""
+    from oracle import metnet as M
+    from test_metnet_gpu import _g, _metnet_pair
+
+    cfg = dict(input_channels=13, sat_channels=12, input_size=16, output_channels=3, hidden_dim=32, forecast_steps=4)
+    net, P = _metnet_pair(device, cfg)
+    x = torch.randn(2, 3, 13, 64, 64, generator=_g(51))
+    cot = torch.randn(2, 4, 3, 4, 4, generator=_g(52))
+    ref = M.metnet_forward(x, P, sat_channels=12, input_size=16, forecast_steps=4)
+    (ref * cot).sum().backward()
+    net.train()
+    out = net(x.to(device))
+    (out * cot.to(device)).sum().backward()
+    # yardstick: the same oracle under torch.autocast(bfloat16) on the CPU, i.e. what the reference's own bf16 path costs.
+    # (deep encoder gradients are ill-conditioned here: 3 training-mode BatchNorms over ~100 samples per channel and two
+    # max-pools whose argmax can flip under bf16 rounding)
+    P2 = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref16 = M.metnet_forward(x, P2, sat_channels=12, input_size=16, forecast_steps=4)
+    (ref16.float() * cot).sum().backward()
+    rel = lambda a, b: float((a.detach().cpu().float() - b.detach()).norm() / (b.detach().norm() + 1e-30))
+    ours_out, theirs_out = rel(out, ref), rel(ref16, ref)
+    assert ours_out < max(2 * theirs_out, 2e-2), (ours_out, theirs_out)
+    worst = ("out", 0.0, 0.0)
+    for k, p in net.named_parameters():
+        if k in ("image_encoder.module.module.0.bias", "image_encoder.module.module.4.bias", "image_encoder.module.module.6.bias"):
+            continue  # convolution biases in front of a training-mode BatchNorm: the true gradient is zero
+        ours, theirs = rel(p.grad, P[k].grad), rel(P2[k].grad, P[k].grad)
+        if ours > worst[1]:
+            worst = (k, ours, theirs)
+        assert ours < max(2 * theirs, 3e-2), (k, ours, theirs)
+    print(f"bf16 MetNet step: output rel L2 ours {ours_out:.2e} / CPU autocast {theirs_out:.2e}; worst gradient {worst[0]}: ours {worst[1]:.2e} / autocast {worst[2]:.2e}")
+
+
+def test_conv_broadcast_sources(device):
+    """Two-source convolution with the image-index remap of sfTensor (a source shared by all lead times + a per-lead
+    constant source), fp32 mode, against conv2d on the materialised concatenation."""
+    import satflow_amd
+    from satflow_amd.functional import ConvEngine, conv3x3_broadcast, nchw_to_nhwc, nhwc_to_nchw
+
+    satflow_amd.set_compute_dtype("f32")
+    g = torch.Generator().manual_seed(7)
+    F_, L, c0, c1, co, S = 3, 4, 20, 4, 24, 12
+    frames = torch.randn(F_, c0, S, S, generator=g)
+    planes = torch.randn(L, c1, S, S, generator=g)
+    w = torch.randn(co, c0 + c1, 3, 3, generator=g) * 0.1
+    b = torch.randn(co, generator=g)
+    full = torch.cat([torch.cat((frames, planes[l : l + 1].expand(F_, -1, -1, -1)), 1) for l in range(L)], 0)
+    wr = w.clone().requires_grad_()
+    ref = TF.conv2d(full, wr, b, padding=1)
+    cot = torch.randn(ref.shape, generator=g)
+    (ref * cot).sum().backward()
+    wd = w.to(device).requires_grad_()
+    y = conv3x3_broadcast(ConvEngine([c0, c1], co), nchw_to_nhwc(frames.to(device)), nchw_to_nhwc(planes.to(device)), wd, b.to(device),
+                          L * F_, (0, F_), (F_, 0))
+    y = nhwc_to_nchw(y, co)
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "broadcast conv")
+    assert_close(wd.grad, wr.grad, "broadcast conv dW", grad=True)
