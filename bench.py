@@ -111,7 +111,7 @@ class ConvLSTMWorkload:
         flops = 2 * 9 * (hid + hid) * 4 * hid * H * W * B
         alg_bytes = (hid + 2 * hid + 2 * hid) * H * W * B * 4 + 9 * 2 * hid * 4 * hid * 4
         import satflow_amd
-        bf16 = satflow_amd.compute_dtype_name() == "bf16"
+        bf16 = satflow_amd.compute_dtype_name() in ("bf16", "bf16a")
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": None,
@@ -179,25 +179,30 @@ class MetNetWorkload:
         w = torch.randn(C, C, 3, 3, device=self.dev) * 0.02
         b = torch.randn(C, device=self.dev)
         packed, bp = K.pack_weights(w, b, eng.fwd_map, False)
-        x = torch.randn(n, H, W, C, device=self.dev)
-        y = torch.empty(n, H, W, C, device=self.dev)
+        import satflow_amd
+        mode = satflow_amd.compute_dtype_name()
+        bf16, act16 = mode in ("bf16", "bf16a"), mode == "bf16a"
+        st = torch.bfloat16 if act16 else torch.float32  # storage of the encoder activations this convolution reads / writes
+        x = torch.randn(n, H, W, C, device=self.dev).to(st)
+        y = torch.empty(n, H, W, C, device=self.dev, dtype=st)
         t = event_time(lambda: K.conv3x3(T(x), NULL, n, H, W, packed, bp, eng.fwd_map, T(y)), iters=10)
         flops = 2 * 9 * C * C * H * W * n
-        alg_bytes = 2 * C * H * W * n * 4 + 9 * C * C * 4
-        import satflow_amd
-        bf16 = satflow_amd.compute_dtype_name() == "bf16"
+        esz = 2 if act16 else 4
+        alg_bytes = 2 * C * H * W * n * esz + 9 * C * C * (2 if bf16 else 4)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r01_metnet_bf16_pmc_conv256.json")
-        if bf16 and n == 2304 and os.path.exists(pmc):  # PMC pass of this very launch shape (tools/prof_pmc.sh), per launch
+        pmc = os.path.join(ROOT, "profiles", f"r01_metnet_{mode}_pmc_conv256.json")
+        if n == 2304 and os.path.exists(pmc):  # PMC pass of this very launch shape (tools/prof_pmc.sh), per launch
             rec = json.load(open(pmc))
-            traffic, traffic_src = rec["traffic_bytes"], "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; profiles/r01_metnet_bf16_pmc_conv256.json"
+            traffic, traffic_src = rec["traffic_bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; profiles/r01_metnet_{mode}_pmc_conv256.json"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"conv3x3_{'bf16' if bf16 else 'f32'}_kernel<NF=4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)",
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
-                "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), fp32 activations in HBM: intensity 575 F/B vs "
+                "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM: intensity 1150 F/B vs "
+                         "ridge 312 F/B -> MFMA-bound" if act16 else
+                         "bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), fp32 activations in HBM: intensity 575 F/B vs "
                          "ridge 312 F/B -> MFMA-bound" if bf16 else
                          "fp32 path: exact-f32 MFMA (v_mfma_f32_32x32x2_f32), bound by the 157.3 TF fp32 matrix pipe "
                          "(intensity 1150 F/B >> ridge 20 F/B)")}
@@ -239,8 +244,9 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm"])
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16"), choices=["bf16", "f32"],
-                    help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default) or exact fp32 (parity mode)")
+    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16"), choices=["bf16", "bf16a", "f32"],
+                    help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default), the same with the MetNet "
+                         "encoder's activations also STORED as bf16 (bf16a), or exact fp32 (parity mode)")
     args = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", "1"))

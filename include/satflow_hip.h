@@ -58,6 +58,9 @@ typedef struct {
   int32_t stride; /* elements per pixel                        */
   int32_t idiv;   /* image-index divisor (0/1 = none)          */
   int32_t imod;   /* image-index modulus (0 = none)            */
+  int32_t dtype;  /* element storage: SF_F32 (default) or SF_BF16.  bf16 storage is accepted by the MetNet encoder
+                     kernels (sf_metnet_preprocess_fwd, sf_conv3x3_fwd / _bwd_weight with the SF_BF16 kernels,
+                     sf_leadtime_pool_*, sf_batchnorm_*, sf_maxpool2_*); everything else requires SF_F32 */
 } sfTensor;
 
 /* ---------------------------------------------------------------------------------------------

@@ -20,7 +20,8 @@ ABI_VERSION = 1
 
 
 class sfTensor(C.Structure):
-    _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32), ("idiv", C.c_int32), ("imod", C.c_int32)]
+    _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32), ("idiv", C.c_int32), ("imod", C.c_int32),
+                ("dtype", C.c_int32)]
 
 
 # name -> (restype, argtypes); mirrors include/satflow_hip.h one to one
@@ -112,7 +113,7 @@ def require_device(t: torch.Tensor, name: str) -> None:
         )
 
 
-NULL = sfTensor(None, 0, 0, 0, 0)
+NULL = sfTensor(None, 0, 0, 0, 0, 0)
 
 
 def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0, idiv: int = 0, imod: int = 0) -> sfTensor:
@@ -120,10 +121,11 @@ def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0, idiv:
 
     ``idiv`` / ``imod``: image-index remap for convolution inputs (see ``sfTensor`` in the header)."""
     if t is None:
-        return sfTensor(None, c or 0, 0, 0, 0)
-    assert t.is_contiguous() and t.dtype == torch.float32, (t.shape, t.dtype, t.is_contiguous())
+        return sfTensor(None, c or 0, 0, 0, 0, 0)
+    assert t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16), (t.shape, t.dtype, t.is_contiguous())
     stride = t.shape[-1]
-    return sfTensor(t.data_ptr() + 4 * offset, stride - offset if c is None else c, stride, idiv, imod)
+    return sfTensor(t.data_ptr() + t.element_size() * offset, stride - offset if c is None else c, stride, idiv, imod,
+                    SF_BF16 if t.dtype == torch.bfloat16 else SF_F32)
 
 
 # Parameter generation: bumped whenever parameters are rewritten through raw pointers (sf_adam_step),
@@ -143,11 +145,16 @@ def generation():
 # Compute dtype of the convolution kernels: SF_F32 = exact-fp32 MFMA (parity mode, rtol 1e-4);
 # SF_BF16 = bf16 operands / fp32 accumulate / fp32 storage (the arithmetic of torch.autocast(bfloat16)
 # around the reference's Conv2d; throughput mode).  Weight gradients stay on the fp32 pipe.
+# "bf16a" = SF_BF16 kernels AND bf16 storage of the MetNet image encoder's activations and their gradients
+# (what torch.autocast(bfloat16) leaves in memory between the reference's Conv2d layers); everything from the
+# encoder's last pooling on (ConvGRU, attention, head, loss, parameters, optimizer state) stays fp32.
 _COMPUTE = [SF_F32]
+_ENCODER_BF16 = [False]
 
 
 def set_compute_dtype(name: str) -> None:
-    _COMPUTE[0] = {"f32": SF_F32, "fp32": SF_F32, "float32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16}[name]
+    _COMPUTE[0] = {"f32": SF_F32, "fp32": SF_F32, "float32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "bf16a": SF_BF16}[name]
+    _ENCODER_BF16[0] = name == "bf16a"
 
 
 def compute_dtype() -> int:
@@ -155,7 +162,14 @@ def compute_dtype() -> int:
 
 
 def compute_dtype_name() -> str:
-    return "bf16" if _COMPUTE[0] == SF_BF16 else "f32"
+    if _COMPUTE[0] == SF_BF16:
+        return "bf16a" if _ENCODER_BF16[0] else "bf16"
+    return "f32"
+
+
+def encoder_storage_dtype():
+    """torch dtype the MetNet image encoder keeps its activations in (bf16 only in "bf16a" mode)."""
+    return torch.bfloat16 if _ENCODER_BF16[0] else torch.float32
 
 
 def cpad(c: int) -> int:

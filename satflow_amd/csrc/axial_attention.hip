@@ -207,6 +207,8 @@ extern "C" {
 int sf_axial_attention_core_fwd(sfTensor qkv, int64_t nimg, int32_t h, int32_t w, int32_t hid, int32_t hidp, int32_t heads, sfTensor att,
                                 int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_axial_attention_core_fwd: dtype %d not built", dtype);
+  SF_F32_ONLY(qkv, "sf_axial_attention_core_fwd");
+  SF_F32_ONLY(att, "sf_axial_attention_core_fwd");
   AttnParams p{};
   p.qkv = (const float*)qkv.ptr; p.qs = qkv.stride; p.att = (float*)att.ptr; p.as = att.stride;
   p.nimg = nimg; p.H = h; p.W = w; p.hid = hid; p.hidp = hidp; p.heads = heads;
@@ -224,6 +226,9 @@ int sf_axial_attention_core_fwd(sfTensor qkv, int64_t nimg, int32_t h, int32_t w
 int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32_t h, int32_t w, int32_t hid, int32_t hidp, int32_t heads,
                                 sfTensor dqkv, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_axial_attention_core_bwd: dtype %d not built", dtype);
+  SF_F32_ONLY(qkv, "sf_axial_attention_core_bwd");
+  SF_F32_ONLY(datt, "sf_axial_attention_core_bwd");
+  SF_F32_ONLY(dqkv, "sf_axial_attention_core_bwd");
   AttnParams p{};
   p.qkv = (const float*)qkv.ptr; p.qs = qkv.stride; p.datt = (const float*)datt.ptr; p.das = datt.stride;
   p.dqkv = (float*)dqkv.ptr; p.dqs = dqkv.stride;

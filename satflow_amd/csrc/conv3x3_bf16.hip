@@ -1,6 +1,8 @@
 // 3x3 "same" convolution as an implicit GEMM on the bf16 matrix cores (v_mfma_f32_32x32x16_bf16),
 // fp32 activations in HBM (NHWC), bf16 operands, fp32 accumulate, fp32 outputs - the arithmetic of
 // torch.autocast(bfloat16) around the reference's Conv2d, with the epilogues of conv_common.h.
+// Sources / the linear output may also be STORED as bf16 (sfTensor.dtype, the MetNet encoder's "bf16a" mode):
+// the staging then copies 16-byte pieces unconverted and the epilogue rounds once (RNE) on the way out.
 //
 // Workgroup = WAVES waves (8 for large images: a 32x16-pixel tile; 4: 16x16), each wave owns 4 tile
 // rows = two 32-pixel M fragments and all NF 32-channel N fragments (2*NF accumulator tiles).
@@ -71,6 +73,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   const int nch = ch0 + ch1;
 
   f32x8 inreg[NPIECE];
+  int staged_bf = 0;  // storage type of the chunk held in inreg (block-uniform)
 
   auto issue_weights = [&](int ci, int buf) {
     const int chunk = ci < ch0 ? ci : c0_chunks + (ci - ch0);
@@ -82,8 +85,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   };
   auto load_input = [&](int ci) {
     const float* src; int cbase, stride, ns;
-    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
-    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
+    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; staged_bf = p.bf0; }
+    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; staged_bf = p.bf1; }
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;
@@ -91,8 +94,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
       const int gy = y0 + iy - 1, gx = x0 + ix - 1;
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-        v = *reinterpret_cast<const f32x8*>(src + ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + half * 8);
+      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+        const size_t e = ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + half * 8;
+        if (staged_bf) {  // 8 bf16 = one 16-byte piece, carried in the low half of the staging registers
+          const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(src) + e);
+          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+        } else {
+          v = *reinterpret_cast<const f32x8*>(src + e);
+        }
+      }
       inreg[j] = v;
     }
   };
@@ -103,8 +113,11 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       const int pc = tid + j * THREADS;
       const int pix = pc >> 1, half = pc & 1;
       const int iy = pix / HALO_W;
-      if (pc < PIECES)
-        *reinterpret_cast<bf16x8*>(dst + pix * PIX_B + 16 * (half ^ (iy & 1))) = __builtin_convertvector(inreg[j], bf16x8);
+      if (pc < PIECES) {
+        char* d = dst + pix * PIX_B + 16 * (half ^ (iy & 1));
+        if (staged_bf) *reinterpret_cast<f32x4*>(d) = f32x4{inreg[j][0], inreg[j][1], inreg[j][2], inreg[j][3]};
+        else *reinterpret_cast<bf16x8*>(d) = __builtin_convertvector(inreg[j], bf16x8);
+      }
     }
   };
 

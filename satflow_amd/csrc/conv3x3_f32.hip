@@ -220,6 +220,8 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
   p.wp = (const float*)wpacked; p.bias = bias_packed; p.chunks_total = (src0.c + src1.c) / KC;
   p.out = (float*)out.ptr; p.out_c = out.c; p.out_s = out.stride;
   const int nblk = Np / (32 * nf);
+  p.bf0 = src0.ptr && src0.dtype == SF_BF16; p.bf1 = src1.ptr && src1.dtype == SF_BF16; p.out_bf = out.dtype == SF_BF16;
+  SF_REQUIRE(dtype == SF_BF16 || !(p.bf0 || p.bf1 || p.out_bf), "conv3x3: bf16-stored tensors need the SF_BF16 kernel");
   if (dtype == SF_BF16) {
     SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
     return sf_launch_conv_bf16(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
@@ -235,6 +237,8 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
                          sfTensor gates, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
   if (check_src(x, "convlstm x") || check_src(h_prev, "convlstm h_prev")) return 1;
+  SF_F32_ONLY(x, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_prev, "sf_convlstm_cell_fwd");
+  SF_F32_ONLY(h_out, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_out, "sf_convlstm_cell_fwd"); SF_F32_ONLY(gates, "sf_convlstm_cell_fwd");
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp, "convlstm: hidp=%d h_prev.c=%d", hidp, h_prev.c);
   SF_REQUIRE(x.ptr && h_out.ptr && c_out.ptr, "convlstm: x, h_out, c_out must be non-null");
   ConvParams p{};
@@ -261,6 +265,8 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
                         sfStream stream) {
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convgru_step_fwd: dtype %d not built", dtype);
   if (check_src(h_prev, "convgru h_prev")) return 1;
+  SF_F32_ONLY(gx, "sf_convgru_step_fwd"); SF_F32_ONLY(h_prev, "sf_convgru_step_fwd"); SF_F32_ONLY(h_out, "sf_convgru_step_fwd");
+  SF_F32_ONLY(gates, "sf_convgru_step_fwd");
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp && gx.c == 3 * hidp, "convgru: hidp=%d h_prev.c=%d gx.c=%d", hidp, h_prev.c, gx.c);
   SF_REQUIRE(gx.ptr && h_out.ptr, "convgru: gx and h_out must be non-null");
   ConvParams p{};

@@ -10,15 +10,20 @@
 //     of one image row (coalesced along the channel axis across lanes), converts to bf16 and writes one
 //     16-byte run of 8 pixels per channel into channel-major LDS tiles of the NEXT K tile
 //     (A: dout [co][8 rows][16 px];  B: in [ci][10 halo rows][16 px] + one halo pixel left/right);
-//   * 4 COMPUTE waves (one per SIMD, co fragment w) run the CURRENT K tile: per tile row (= one K step of
-//     16 pixels) 1 A read + 3 B reads feed 9 MFMAs; the two horizontally shifted taps are built from the
-//     aligned 16-byte run plus one neighbour dword with 4 v_alignbit each - no shifted LDS copies.
+//   * 4 COMPUTE waves (one per SIMD, co fragment w) run the CURRENT K tile halo-row by halo-row: one B read
+//     feeds up to 9 MFMAs (3 taps ky x 3 taps kx) against a 3-row register window of dout fragments; the two
+//     horizontally shifted taps are built from the aligned 16-byte run plus one neighbour dword with v_alignbit
+//     - no shifted LDS copies.
 // LDS layout (found by exhaustive search over pitch / xor patterns): the 4 channels of a quad sit in
 // adjacent 16-byte slots, slot index xor-ed with (quad>>1)&3, quad pitch = 68 (A) / 84 (B) slots:
 // conflict-free for the loaders' ds_write_b128 (8-lane groups along the quad axis) AND for the compute
 // waves' ds_read_b128 lane groups.  Two LDS buffers, one barrier per K tile.
 // Split-K partial slabs in the fp32 kernel's layout; the shared reduce kernel finishes (the bias gradient
 // is summed in fp32 by the loaders from the unrounded values).
+// BF = true: the tensors are already stored as bf16 - the loaders fetch 8-byte channel quads and transpose
+// with v_perm_b32 (one per LDS dword) instead of converting.
+#include <type_traits>
+
 #include "wgrad_common.h"
 
 namespace {
@@ -28,6 +33,7 @@ using namespace sfwgrad;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 
 constexpr int KR = 8;                          // K-tile rows
 constexpr int HR = KR + 2;                     // halo rows
@@ -46,12 +52,26 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
   f32x8 v = {a0, a1, a2, a3, a4, a5, a6, a7};
   return __builtin_convertvector(v, bf16x8);
 }
+__device__ __forceinline__ float F(unsigned bits) { return __builtin_bit_cast(float, bits); }
 __device__ __forceinline__ unsigned bf16_bits(float x) {
   __bf16 b = (__bf16)x;
   return (unsigned)__builtin_bit_cast(unsigned short, b);
 }
+// bf16 storage: pixel j of a channel quad is {ch0 | ch1 << 16, ch2 | ch3 << 16}.  One LDS dword of channel c holds pixels
+// (2k, 2k+1): v_perm_b32 picks the low (even c) or high (odd c) halves of the two pixels' dwords.
+__device__ __forceinline__ unsigned pair_bf(u32x2 even_px, u32x2 odd_px, int c) {
+  const unsigned lo = (c & 2) ? even_px[1] : even_px[0], hi = (c & 2) ? odd_px[1] : odd_px[0];
+  return __builtin_amdgcn_perm(hi, lo, (c & 1) ? 0x07060302u : 0x05040100u);
+}
+__device__ __forceinline__ unsigned chan_bits(u32x2 px, int c) {  // bf16 bits of channel c in the low half
+  const unsigned d = (c & 2) ? px[1] : px[0];
+  return (c & 1) ? d >> 16 : d & 0xffffu;
+}
 
+template <bool BF, bool MIXED>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParams p, const int xcd_groups) {
+  using VT = std::conditional_t<BF, u32x2, u32x4>;   // one pixel's channel quad as loaded (raw bits)
+  using ET = std::conditional_t<BF, __bf16, float>;  // element type behind the tensor pointers
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -78,51 +98,89 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const int lt = tid - LOADERS;
     const int a_cq = lt % 32, b_cq = lt % 8;
     const int kcb = cit * CI_T + b_cq * 4;  // input channel (concatenated padded K space)
-    const float* bsrc = nullptr; int bstride = 0, bdiv = 1, bmod = 0, bch = 0;
-    if (kcb < p.c0) { bsrc = p.src0; bstride = p.s0; bdiv = p.idiv0; bmod = p.imod0; bch = kcb; }
-    else if (kcb - p.c0 < p.c1) { bsrc = p.src1; bstride = p.s1; bdiv = p.idiv1; bmod = p.imod1; bch = kcb - p.c0; }
     const int aco = cot * CO_T + a_cq * 4;
     const bool a_ok = aco < p.dc;
     f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
 
-    // Register-staged software pipeline: the global loads of tile i+1 are issued right after tile i has been written
-    // to LDS and stay in flight across the barrier, i.e. during the compute waves' work on tile i.
+    // Register-staged software pipeline: global loads stay in flight across the barrier, i.e. during the compute waves' work.
+    // Loads are raw BUFFER loads: one descriptor per tensor image (scalar, rebuilt per tile), a per-lane byte offset that
+    // is constant for the whole kernel, and the tile / pixel position in the scalar offset - no per-load 64-bit VALU
+    // address arithmetic (that, not bandwidth, set the loaders' pace).  Out-of-image pixels get an out-of-range
+    // voffset and come back as zeros from the hardware range check, so the loads are unconditional and countable
+    // (s_waitcnt vmcnt(N)): BF (8-byte quads, half the registers) keeps two tiles in flight.
     const bool b_item = lt < 8 * HR * 2;
     const int brest = lt / 8, bhalf = brest & 1, bhrow = brest >> 1;
-    f32x4 va[2][8], vb[10];
-    auto load_tile = [&](int i) {
+    constexpr unsigned SENT = 0x80000000u;  // >= any descriptor's num_records (host checks image bytes < 2^31)
+    constexpr int ESZ = sizeof(ET);
+    const unsigned a_px = (unsigned)p.ds * ESZ;
+    unsigned a_const[2]; int a_row[2], a_half[2];
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int rest = (lt + u * LOADERS) / 32;
+      a_half[u] = rest & 1; a_row[u] = rest >> 1;
+      a_const[u] = (unsigned)((a_row[u] * p.W + 8 * a_half[u]) * p.ds + aco) * ESZ;
+    }
+    // The block's 32 input channels come from ONE source unless c0 is not a multiple of 32 (MIXED kernels: the ConvLSTM's
+    // 16-lane x source).  Plain kernels pick the source with scalar selects - no branch near the loads; MIXED kernels
+    // load from both descriptors (a lane's foreign source gets the out-of-range offset, a missing source a
+    // zero-length descriptor) and OR the two results when the tile is written to LDS.
+    const bool from0 = cit * CI_T < p.c0;  // block-uniform; exact for plain kernels
+    const bool lane0 = b_item && kcb < p.c0, lane1 = b_item && kcb >= p.c0 && kcb - p.c0 < p.c1;
+    const unsigned b_px0 = (unsigned)p.s0 * ESZ, b_px1 = (unsigned)p.s1 * ESZ;
+    const unsigned b_const0 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s0 + kcb) * ESZ;
+    const unsigned b_const1 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s1 + (kcb - p.c0)) * ESZ;
+    struct Stage { VT va[2][8], vb[10], vb1[MIXED ? 10 : 1]; };
+    auto ld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) -> VT {
+      if constexpr (BF) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+      else return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
+    };
+    // descriptor of image `ns` of a source, starting one image row + one pixel BEFORE the image so that lane offsets are
+    // non-negative (nothing is read there); a null source gives a zero-length descriptor (every load returns zeros)
+    auto halo_srd = [&](const float* src, int n, int idiv, int imod, unsigned px) {
+      int ns = n / idiv; if (imod) ns %= imod;
+      const char* base = (const char*)src + ((long long)ns * p.H * p.W - (p.W + 1)) * px;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(src ? base : nullptr), 0, src ? (int)((unsigned)(p.H * p.W + p.W + 1) * px) : 0, 0x00020000);
+    };
+    auto load_tile = [&](int i, Stage& s) {
       int t = ks + i * p.KS;
       const int tx = t % p.tiles_x; t /= p.tiles_x;
       const int ty = t % p.tiles_y;
       const int n = t / p.tiles_y;
       const int x0 = tx * KT_W, y0 = ty * KR;
-      // dout tile: items (cq 32, row 8, half 2) -> item = lt and lt + 256.  One row pointer per item, pixel j at
-      // a constant stride from it (address arithmetic was the loaders' bottleneck: ~600 VALU per tile per wave).
+      const unsigned tile_px = (unsigned)(y0 * p.W + x0);
+      // dout tile: items (cq 32, row 8, half 2) -> item = lt and lt + 256
+      {
+        const char* base = (const char*)p.dout + (long long)n * p.H * p.W * a_px;
+        const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)(p.H * p.W) * a_px), 0x00020000);
+        const unsigned so = tile_px * a_px;
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
-        const int gy = y0 + row, gx0 = x0 + 8 * half;
-        const float* prow = p.dout + ((size_t)(n * p.H + gy) * p.W + gx0) * p.ds + aco;
-        const int lim = (a_ok && gy < p.H) ? p.W - gx0 : 0;  // pixels j < lim are inside the image
+        for (int u = 0; u < 2; ++u) {
+          const int lim = (a_ok && y0 + a_row[u] < p.H) ? p.W - x0 - 8 * a_half[u] : 0;  // pixels j < lim are inside the image
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          va[u][j] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (j < lim) va[u][j] = *reinterpret_cast<const f32x4*>(prow + (size_t)j * p.ds);
+          for (int j = 0; j < 8; ++j) s.va[u][j] = ld(rs, j < lim ? a_const[u] : SENT, so + j * a_px);
         }
       }
       // input halo tile: items (cq 8, halo row 10, half 2) = 160 items; pixels x0-1+8*half .. +9
-      int ns = n / bdiv; if (bmod) ns %= bmod;
       const int gy = y0 + bhrow - 1, gx0 = x0 - 1 + 8 * bhalf;
-      const float* prow = bsrc + ((long long)(ns * p.H + gy) * p.W + gx0) * bstride + bch;
-      const bool rok = b_item && bsrc && gy >= 0 && gy < p.H;
+      const bool rok = gy >= 0 && gy < p.H;
       const int lo = rok ? -gx0 : 99, hi = rok ? p.W - gx0 : 0;  // pixels lo <= j < hi are inside the image
+      if constexpr (MIXED) {
+        const __amdgpu_buffer_rsrc_t rs0 = halo_srd(p.src0, n, p.idiv0, p.imod0, b_px0), rs1 = halo_srd(p.src1, n, p.idiv1, p.imod1, b_px1);
 #pragma unroll
-      for (int j = 0; j < 10; ++j) {
-        vb[j] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (j >= lo && j < hi) vb[j] = *reinterpret_cast<const f32x4*>(prow + (long long)j * bstride);
+        for (int j = 0; j < 10; ++j) {
+          const bool in = j >= lo && j < hi;
+          s.vb[j] = ld(rs0, (lane0 && in) ? b_const0 : SENT, (tile_px + j) * b_px0);
+          s.vb1[j] = ld(rs1, (lane1 && in) ? b_const1 : SENT, (tile_px + j) * b_px1);
+        }
+      } else {
+        const unsigned px = from0 ? b_px0 : b_px1, bc = from0 ? b_const0 : b_const1;
+        const bool lane = from0 ? lane0 : lane1;
+        const __amdgpu_buffer_rsrc_t rs = halo_srd(from0 ? p.src0 : p.src1, n, from0 ? p.idiv0 : p.idiv1, from0 ? p.imod0 : p.imod1, px);
+#pragma unroll
+        for (int j = 0; j < 10; ++j) s.vb[j] = ld(rs, (lane && j >= lo && j < hi) ? bc : SENT, (tile_px + j) * px);
       }
     };
-    auto store_tile = [&](int i) {
+    auto store_tile = [&](int i, Stage& s) {
       char* la = lds + (i & 1) * BUF;
       char* lb = la + A_BYTES;
       char* lh = lb + B_BYTES;
@@ -130,32 +188,75 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       for (int u = 0; u < 2; ++u) {
         const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
         char* dst = la + a_cq * A_S + (row * 2 + half) * 64;
+        const VT (&va)[8] = s.va[u];
         if (cit == 0) {  // block-uniform: only the first ci tile's blocks report the bias gradient
 #pragma unroll
-          for (int j = 0; j < 8; ++j) bsum += va[u][j];
+          for (int j = 0; j < 8; ++j) {
+            if constexpr (BF) {
+#pragma unroll
+              for (int c = 0; c < 4; ++c) bsum[c] += __builtin_bit_cast(float, chan_bits(va[j], c) << 16);
+            } else {
+              bsum += __builtin_bit_cast(f32x4, va[j]);
+            }
+          }
         }
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
-              pack8(va[u][0][c], va[u][1][c], va[u][2][c], va[u][3][c], va[u][4][c], va[u][5][c], va[u][6][c], va[u][7][c]);
+        for (int c = 0; c < 4; ++c) {
+          if constexpr (BF)
+            *reinterpret_cast<u32x4*>(dst + quad_slot(a_cq, c)) = u32x4{pair_bf(va[0], va[1], c), pair_bf(va[2], va[3], c),
+                                                                        pair_bf(va[4], va[5], c), pair_bf(va[6], va[7], c)};
+          else
+            *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
+                pack8(F(va[0][c]), F(va[1][c]), F(va[2][c]), F(va[3][c]), F(va[4][c]), F(va[5][c]), F(va[6][c]), F(va[7][c]));
+        }
       }
       if (b_item) {
         char* dst = lb + b_cq * B_S + (bhrow * 2 + bhalf) * 64;
+        VT vb[10];
+#pragma unroll
+        for (int j = 0; j < 10; ++j) {
+          if constexpr (MIXED) vb[j] = s.vb[j] | s.vb1[j];  // a lane belongs to one source; the other load returned zeros
+          else vb[j] = s.vb[j];
+        }
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          *reinterpret_cast<bf16x8*>(dst + quad_slot(b_cq, c)) = pack8(vb[1][c], vb[2][c], vb[3][c], vb[4][c], vb[5][c], vb[6][c], vb[7][c], vb[8][c]);
           // halo pixels: left neighbour in the HIGH half of its dword, right neighbour in the LOW half
           unsigned* hp = reinterpret_cast<unsigned*>(lh + (b_cq * 4 + c) * H_P + bhrow * 8);
-          if (bhalf == 0) hp[0] = bf16_bits(vb[0][c]) << 16;
-          else            hp[1] = bf16_bits(vb[9][c]);
+          if constexpr (BF) {
+            *reinterpret_cast<u32x4*>(dst + quad_slot(b_cq, c)) = u32x4{pair_bf(vb[1], vb[2], c), pair_bf(vb[3], vb[4], c),
+                                                                        pair_bf(vb[5], vb[6], c), pair_bf(vb[7], vb[8], c)};
+            hp[bhalf] = bhalf ? chan_bits(vb[9], c) : chan_bits(vb[0], c) << 16;
+          } else {
+            *reinterpret_cast<bf16x8*>(dst + quad_slot(b_cq, c)) =
+                pack8(F(vb[1][c]), F(vb[2][c]), F(vb[3][c]), F(vb[4][c]), F(vb[5][c]), F(vb[6][c]), F(vb[7][c]), F(vb[8][c]));
+            hp[bhalf] = bhalf ? bf16_bits(F(vb[9][c])) : bf16_bits(F(vb[0][c])) << 16;
+          }
         }
       }
     };
-    if (my_tiles > 0) load_tile(0);
-    for (int i = 0; i <= my_tiles; ++i) {
-      if (i < my_tiles) store_tile(i);
-      if (i + 1 < my_tiles) load_tile(i + 1);
-      __syncthreads();
+    // my_tiles + 1 barriers in every variant (the compute waves count the same)
+    if constexpr (BF && !MIXED) {
+      Stage s0, s1;
+      if (my_tiles > 0) load_tile(0, s0);
+      if (my_tiles > 1) load_tile(1, s1);
+      for (int i = 0; i <= my_tiles; i += 2) {
+        if (i < my_tiles) store_tile(i, s0);
+        if (i + 2 < my_tiles) load_tile(i + 2, s0);
+        __syncthreads();
+        if (i + 1 <= my_tiles) {
+          if (i + 1 < my_tiles) store_tile(i + 1, s1);
+          if (i + 3 < my_tiles) load_tile(i + 3, s1);
+          __syncthreads();
+        }
+      }
+    } else {
+      Stage s0;
+      if (my_tiles > 0) load_tile(0, s0);
+      for (int i = 0; i <= my_tiles; ++i) {
+        if (i < my_tiles) store_tile(i, s0);
+        if (i + 1 < my_tiles) load_tile(i + 1, s0);
+        __syncthreads();
+      }
     }
     // bias gradient: 8 loader threads share a channel quad
     if (cit == 0) {
@@ -176,34 +277,48 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const int b_q = (r >> 2) * B_S + quad_slot(r >> 2, r & 3);
     const int h_off = r * H_P;
 
+    // neighbour dwords of the 16-byte run: kh = 0 -> left halo dword / first dword of the upper half;
+    // kh = 1 -> last dword of the lower half / right halo dword.  One per-lane address + per-lane row pitch each.
+    const int l_off = kh ? A_BYTES + b_q + 12 : A_BYTES + B_BYTES + h_off, l_pitch = kh ? 128 : 8;
+    const int r_off = kh ? A_BYTES + B_BYTES + h_off + 4 : A_BYTES + b_q + 64, r_pitch = kh ? 8 : 128;
+
     __syncthreads();  // tile 0 staged
     for (int i = 0; i < my_tiles; ++i) {
       const char* la = lds + (i & 1) * BUF;
       const char* lb = la + A_BYTES;
-      const char* lh = lb + B_BYTES;
+      // Halo-row major: input row hrow is read and shifted ONCE and feeds the taps ky = 0..2 of the output rows
+      // hrow, hrow-1, hrow-2, whose dout fragments sit in a 3-row register window (72 MFMAs per tile either way,
+      // but 10 instead of 24 B-row reads / shift sequences).
+      bf16x8 arow[3];
 #pragma unroll
-      for (int row = 0; row < KR; ++row) {
-        const bf16x8 a = *reinterpret_cast<const bf16x8*>(la + a_off + row * 128);
+      for (int hrow = 0; hrow < HR; ++hrow) {
+        if (hrow < KR) arow[hrow % 3] = *reinterpret_cast<const bf16x8*>(la + a_off + hrow * 128);
+        const u32x4 mid = *reinterpret_cast<const u32x4*>(lb + b_q + hrow * 128 + kh * 64);
+        const unsigned left = *reinterpret_cast<const unsigned*>(la + l_off + hrow * l_pitch);
+        const unsigned right = *reinterpret_cast<const unsigned*>(la + r_off + hrow * r_pitch);
+        u32x4 b0, b2;
+        b0[0] = __builtin_amdgcn_alignbit(mid[0], left, 16);
+        b0[1] = __builtin_amdgcn_alignbit(mid[1], mid[0], 16);
+        b0[2] = __builtin_amdgcn_alignbit(mid[2], mid[1], 16);
+        b0[3] = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
+        b2[0] = b0[1];
+        b2[1] = b0[2];
+        b2[2] = b0[3];
+        b2[3] = __builtin_amdgcn_alignbit(right, mid[3], 16);
 #pragma unroll
         for (int ky = 0; ky < 3; ++ky) {
-          const int hrow = row + ky;
-          const char* rowp = lb + b_q + hrow * 128;
-          const u32x4 mid = *reinterpret_cast<const u32x4*>(rowp + kh * 64);
-          // neighbours: kh = 0 -> left halo dword / first dword of the upper half; kh = 1 -> last dword of the lower half / right halo dword
-          const unsigned left = kh ? *reinterpret_cast<const unsigned*>(rowp + 12) : *reinterpret_cast<const unsigned*>(lh + h_off + hrow * 8);
-          const unsigned right = kh ? *reinterpret_cast<const unsigned*>(lh + h_off + hrow * 8 + 4) : *reinterpret_cast<const unsigned*>(rowp + 64);
-          u32x4 b0, b2;
-          b0[0] = __builtin_amdgcn_alignbit(mid[0], left, 16);
-          b0[1] = __builtin_amdgcn_alignbit(mid[1], mid[0], 16);
-          b0[2] = __builtin_amdgcn_alignbit(mid[2], mid[1], 16);
-          b0[3] = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
-          b2[0] = __builtin_amdgcn_alignbit(mid[1], mid[0], 16);
-          b2[1] = __builtin_amdgcn_alignbit(mid[2], mid[1], 16);
-          b2[2] = __builtin_amdgcn_alignbit(mid[3], mid[2], 16);
-          b2[3] = __builtin_amdgcn_alignbit(right, mid[3], 16);
+          const int row = hrow - ky;
+          if (row < 0 || row >= KR) continue;
+          const bf16x8 a = arow[row % 3];
+#ifdef SF_EXP_WG_NOMFMA
+          acc[ky * 3 + 0][0] += (float)a[0] * __builtin_bit_cast(float, b0[0]);
+          acc[ky * 3 + 1][0] += (float)a[1] * __builtin_bit_cast(float, mid[1]);
+          acc[ky * 3 + 2][0] += (float)a[2] * __builtin_bit_cast(float, b2[3]);
+#else
           acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0], 0, 0, 0);
           acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, mid), acc[ky * 3 + 1], 0, 0, 0);
           acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2], 0, 0, 0);
+#endif
         }
       }
       __syncthreads();
@@ -236,8 +351,18 @@ int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl,
     sf_set_error("wgrad_bf16: tensors must be 16-byte aligned with 4-aligned strides");
     return 1;
   }
+  {
+    const long long esz = p.bf ? 2 : 4, px = (long long)p.H * p.W + p.W + 1;
+    const long long smax = p.ds > p.s0 ? (p.ds > p.s1 ? p.ds : p.s1) : (p.s0 > p.s1 ? p.s0 : p.s1);
+    if (px * smax * esz >= (1ll << 31)) { sf_set_error("wgrad_bf16: one image of a tensor must be smaller than 2 GiB"); return 1; }
+  }
   const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
-  hipLaunchKernelGGL(wgrad_bf16_kernel, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, xcd_groups);
+  const bool mixed = p.src0 && p.src1 && p.c1 > 0 && p.c0 % CI_T != 0;  // some block's 32 input channels straddle the two sources
+  const dim3 grid(pl.KS, pl.cot, pl.cit), block(THREADS);
+  if (p.bf && mixed) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, block, 0, st, p, xcd_groups);
+  else if (p.bf) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, block, 0, st, p, xcd_groups);
+  else if (mixed) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, block, 0, st, p, xcd_groups);
+  else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, block, 0, st, p, xcd_groups);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("wgrad_bf16: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;

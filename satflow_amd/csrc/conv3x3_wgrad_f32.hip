@@ -156,6 +156,12 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
              workspace_bytes, pl.ws_floats * sizeof(float));
   WgradParams p{};
+  {
+    const int nbf = (src0.ptr && src0.dtype == SF_BF16) + (src1.ptr && src1.dtype == SF_BF16) + (dout.dtype == SF_BF16);
+    const int nten = (src0.ptr != nullptr) + (src1.ptr != nullptr) + 1;
+    SF_REQUIRE(nbf == 0 || (nbf == nten && dtype == SF_BF16), "bwd_weight: bf16 storage needs the SF_BF16 kernel and ALL of src0/src1/dout in bf16");
+    p.bf = nbf != 0;
+  }
   p.src0 = (const float*)src0.ptr; p.src1 = (const float*)src1.ptr;
   p.c0 = src0.c; p.c1 = src1.c; p.s0 = src0.stride; p.s1 = src1.stride;
   p.idiv0 = src0.idiv > 1 ? src0.idiv : 1; p.imod0 = src0.imod > 0 ? src0.imod : 0;

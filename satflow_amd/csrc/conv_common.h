@@ -29,6 +29,8 @@ struct ConvParams {
   // gru epilogue (h_out / gates / hidp shared with lstm): precomputed x-part [z|r|n] and previous state
   const float* gx; int gx_s;
   const float* h_prev; int hprev_s;
+  // storage types (bf16 kernel only; linear / sigmoid epilogues): non-zero = bf16 elements behind src0 / src1 / out
+  int bf0, bf1, out_bf;
 };
 
 
@@ -100,20 +102,45 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf) {
       const int co = nb * NB + nf * 32 + r;
-      if (co < p.out_c) {
+      if (co < p.out_c) {  // out_c is a multiple of 16: both lanes of an (even, odd) channel pair take the same side
         const float bv = p.bias ? p.bias[co] : 0.f;
+        if (p.out_bf) {
+          // bf16 output: registers 2k / 2k+1 are horizontally adjacent pixels P / P+1 of channel `co`.  Lane pairs swap one
+          // value (DPP quad_perm [1,0,3,2]) so that the even lane owns channels (co, co+1) of P and the odd lane channels
+          // (co-1, co) of P+1: one packed 4-byte store per lane and register pair instead of two 2-byte stores.
+          __bf16* ob = reinterpret_cast<__bf16*>(p.out);
+          const int odd = r & 1;
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+          for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
-          for (int reg = 0; reg < 16; ++reg) {
-            const int rr = frag_row(reg, kh);
-            const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
-            if (py < p.H && px < p.W) {
-              float v = acc[mf][nf][reg] + bv;
-              if constexpr (EPI == EPI_SIGMOID) v = sf_sigmoid(v);
-              p.out[((size_t)(n * p.H + py) * p.W + px) * p.out_s + co] = v;
+            for (int k = 0; k < 8; ++k) {
+              float a = acc[mf][nf][2 * k] + bv, b = acc[mf][nf][2 * k + 1] + bv;
+              if constexpr (EPI == EPI_SIGMOID) { a = sf_sigmoid(a); b = sf_sigmoid(b); }
+              const float send = odd ? a : b;
+              const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
+              const int rr = frag_row(2 * k + odd, kh);
+              const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
+              if (py < p.H && px < p.W) {
+                typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+                typedef float f32x2_t __attribute__((ext_vector_type(2)));
+                const f32x2_t pr = odd ? f32x2_t{recv, b} : f32x2_t{a, recv};
+                *reinterpret_cast<bf16x2_t*>(ob + ((size_t)(n * p.H + py) * p.W + px) * p.out_s + (co - odd)) = __builtin_convertvector(pr, bf16x2_t);
+              }
             }
-          }
+        } else {
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+              const int rr = frag_row(reg, kh);
+              const int py = y0 + 4 * wave + 2 * mf + (rr >> 4), px = x0 + (rr & 15);
+              if (py < p.H && px < p.W) {
+                float v = acc[mf][nf][reg] + bv;
+                if constexpr (EPI == EPI_SIGMOID) v = sf_sigmoid(v);
+                p.out[((size_t)(n * p.H + py) * p.W + px) * p.out_s + co] = v;
+              }
+            }
+        }
       }
     }
   }
@@ -126,7 +153,8 @@ inline void set_remap(ConvParams& p, const sfTensor& a, const sfTensor& b) {
 
 inline int check_src(const sfTensor& t, const char* name) {
   if (t.c % SF_CPAD != 0 || t.c < 0) { sf_set_error("%s: channels %d not a multiple of %d", name, t.c, SF_CPAD); return 1; }
-  if (t.ptr && (t.stride % 4 != 0 || ((uintptr_t)t.ptr & 15))) { sf_set_error("%s: needs 16-byte aligned pixels (stride %d)", name, t.stride); return 1; }
+  if (t.ptr && (t.stride % (t.dtype == SF_BF16 ? 8 : 4) != 0 || ((uintptr_t)t.ptr & 15))) { sf_set_error("%s: needs 16-byte aligned pixels (stride %d)", name, t.stride); return 1; }
+  if (t.ptr && t.dtype != SF_F32 && t.dtype != SF_BF16) { sf_set_error("%s: unknown storage type %d", name, t.dtype); return 1; }
   return 0;
 }
 

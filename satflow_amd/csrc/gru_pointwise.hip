@@ -54,7 +54,7 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p
   }
 }
 
-bool ok4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0); }
+bool ok4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.dtype == SF_F32); }  // fp32 storage only
 
 }  // namespace
 

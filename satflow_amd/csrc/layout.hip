@@ -46,6 +46,7 @@ extern "C" {
 int sf_nchw_to_nhwc(const float* src, int64_t stride_b, int64_t stride_t, int64_t stride_c, int32_t nb, int32_t nt,
                     int32_t c, int32_t h, int32_t w, sfTensor dst, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_nchw_to_nhwc: dtype %d not built", dtype);
+  SF_F32_ONLY(dst, "sf_nchw_to_nhwc");
   SF_REQUIRE(dst.c % 4 == 0 && dst.stride % 4 == 0 && (((uintptr_t)dst.ptr) & 15) == 0 && dst.c >= c,
              "nchw_to_nhwc: dst channels %d / stride %d", dst.c, dst.stride);
   LayoutParams p{stride_b, stride_t, stride_c, (long long)h * w, (long long)h * w * nb * nt, nb, c};
@@ -59,6 +60,7 @@ int sf_nchw_to_nhwc(const float* src, int64_t stride_b, int64_t stride_t, int64_
 int sf_nhwc_to_nchw(sfTensor src, int32_t nb, int32_t nt, int32_t c, int32_t h, int32_t w, float* dst,
                     int64_t stride_b, int64_t stride_t, int64_t stride_c, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_nhwc_to_nchw: dtype %d not built", dtype);
+  SF_F32_ONLY(src, "sf_nhwc_to_nchw");
   SF_REQUIRE(src.c >= c, "nhwc_to_nchw: src channels %d < %d", src.c, c);
   LayoutParams p{stride_b, stride_t, stride_c, (long long)h * w, (long long)h * w * nb * nt, nb, c};
   if (p.pixels == 0) return 0;

@@ -138,6 +138,8 @@ extern "C" {
 int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const float* bias, sfTensor y, int32_t dtype,
                   sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_linear_fwd: dtype %d not built", dtype);
+  SF_F32_ONLY(x, "sf_linear_fwd");
+  SF_F32_ONLY(y, "sf_linear_fwd");
   SF_REQUIRE(x.c % 8 == 0 && x.stride % 4 == 0 && (((uintptr_t)x.ptr) & 15) == 0 && (((uintptr_t)W) & 15) == 0,
              "linear: K=%d must be a multiple of 8 and 16-byte aligned", x.c);
   SF_REQUIRE(N >= 1 && y.c >= 1, "linear: N=%d y.c=%d", N, y.c);
@@ -161,6 +163,8 @@ size_t sf_linear_bwd_weight_workspace_bytes(int32_t N, int32_t K, int64_t rows) 
 int sf_linear_bwd_weight(sfTensor dy, int32_t N, sfTensor x, int64_t rows, float* dW, float* db, void* workspace,
                          size_t workspace_bytes, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_linear_bwd_weight: dtype %d not built", dtype);
+  SF_F32_ONLY(dy, "sf_linear_bwd_weight");
+  SF_F32_ONLY(x, "sf_linear_bwd_weight");
   const int K = x.c;
   SF_REQUIRE(K >= 1 && K <= 256 && N >= 1 && dy.c >= N, "linear wgrad: N=%d K=%d (K <= 256)", N, K);
   const WPlan pl = wplan(N, K, rows);

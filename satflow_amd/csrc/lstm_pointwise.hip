@@ -56,7 +56,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
   }
 }
 
-bool aligned4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0); }
+bool aligned4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.dtype == SF_F32); }  // fp32 storage only
 
 }  // namespace
 

@@ -13,14 +13,22 @@ namespace {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// activation storage dispatch: TA = float or __bf16 (sfTensor.dtype); arithmetic is fp32 either way
+#define SF_DISPATCH_ACT(dt, ...)                       \
+  do {                                                 \
+    if ((dt) == SF_BF16) { using TA = __bf16; __VA_ARGS__; } \
+    else { using TA = float; __VA_ARGS__; }            \
+  } while (0)
+
 // ---------------------------------------------------------------------------------------------
 // preprocessing.  imgs[B][T][C][H][W] -> out frame j = t*B + b, [S][S][Cp], S = H/4 = W/4:
 //   lanes [0, 4*sat)        sat channel c, sub-pixel (dh,dw) -> lane c*4 + dh*2 + dw, centre crop of the H/2 map
 //   lanes [4*sat, 8*sat)    the same unshuffled channels, 2x2 mean
 //   lanes [8*sat, 8*sat+C-sat) other channels: 2x2 mean of the raw image, centre crop
 // ---------------------------------------------------------------------------------------------
+template <typename TO>
 __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict__ imgs, int B, int T, int C, int sat, int H, int W,
-                                                         int S, float* __restrict__ out, int oc, int os) {
+                                                         int S, TO* __restrict__ out, int oc, int os) {
   const long long total = (long long)B * T * S * S;
   // torchvision CenterCrop: int(round(d / 2.0)) with Python's round-half-to-even
   const int dT = H / 2 - S, dL = W / 2 - S;
@@ -31,7 +39,7 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
     const long long j = idx / ((long long)S * S);
     const int b = j % B, t = j / B;
     const float* src = imgs + ((long long)b * T + t) * C * H * W;
-    float* dst = out + idx * os;
+    TO* dst = out + idx * os;
     for (int c = 0; c < sat; ++c) {
       const float* ch = src + (long long)c * H * W;
       f32x4 ctr, mean;
@@ -46,16 +54,16 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
           for (int bb = 0; bb < 2; ++bb) s += ch[(long long)(4 * y + 2 * a + dh) * W + 4 * x + 2 * bb + dw];
         mean[d] = s * 0.25f;
       }
-      st4(dst + c * 4, ctr);
-      st4(dst + 4 * sat + c * 4, mean);
+      stv4(dst + c * 4, ctr);
+      stv4(dst + 4 * sat + c * 4, mean);
     }
     for (int c = sat; c < C; ++c) {
       const float* ch = src + (long long)c * H * W;
       const int yy = 2 * (y + top), xx = 2 * (x + left);
-      dst[8 * sat + (c - sat)] = 0.25f * (ch[(long long)yy * W + xx] + ch[(long long)yy * W + xx + 1] +
-                                          ch[(long long)(yy + 1) * W + xx] + ch[(long long)(yy + 1) * W + xx + 1]);
+      dst[8 * sat + (c - sat)] = (TO)(0.25f * (ch[(long long)yy * W + xx] + ch[(long long)yy * W + xx + 1] +
+                                               ch[(long long)(yy + 1) * W + xx] + ch[(long long)(yy + 1) * W + xx + 1]));
     }
-    for (int c = 8 * sat + (C - sat); c < oc; ++c) dst[c] = 0.f;
+    for (int c = 8 * sat + (C - sat); c < oc; ++c) dst[c] = (TO)0.f;
   }
 }
 
@@ -69,8 +77,9 @@ __device__ __forceinline__ long long perm_image(long long n, const OuterPerm& pm
   return (t * pm.L + l) * pm.B + b;
 }
 
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ in, int is, long long N, int H, int W, int C,
-                                                          float* __restrict__ out, int os, const OuterPerm pm) {
+template <typename TI, typename TO>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__ in, int is, long long N, int H, int W, int C,
+                                                          TO* __restrict__ out, int os, const OuterPerm pm) {
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -78,17 +87,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const long long op = idx / q;
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long n = op / ((long long)Wo * Ho);
-    const float* p = in + ((n * H + 2 * yo) * W + 2 * xo) * is + c;
-    f32x4 m = ld4(p);
-    const f32x4 v1 = ld4(p + is), v2 = ld4(p + (long long)W * is), v3 = ld4(p + (long long)W * is + is);
+    const TI* p = in + ((n * H + 2 * yo) * W + 2 * xo) * is + c;
+    f32x4 m = ldv4(p);
+    const f32x4 v1 = ldv4(p + is), v2 = ldv4(p + (long long)W * is), v3 = ldv4(p + (long long)W * is + is);
 #pragma unroll
     for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
-    st4(out + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * os + c, m);
+    stv4(out + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * os + c, m);
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ in, int is, const float* __restrict__ dout, int dos,
-                                                          long long N, int H, int W, int C, float* __restrict__ din, int dis,
+template <typename TI, typename TO>  // TI: input and its gradient, TO: pooled output's gradient
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__ in, int is, const TO* __restrict__ dout, int dos,
+                                                          long long N, int H, int W, int C, TI* __restrict__ din, int dis,
                                                           const OuterPerm pm) {
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const long long total = N * Ho * Wo * q;
@@ -98,9 +108,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long n = op / ((long long)Wo * Ho);
     const long long base = (n * H + 2 * yo) * W + 2 * xo;
-    const float* p = in + base * is + c;
-    const f32x4 v0 = ld4(p), v1 = ld4(p + is), v2 = ld4(p + (long long)W * is), v3 = ld4(p + (long long)W * is + is);
-    const f32x4 g = ld4(dout + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * dos + c);
+    const TI* p = in + base * is + c;
+    const f32x4 v0 = ldv4(p), v1 = ldv4(p + is), v2 = ldv4(p + (long long)W * is), v3 = ldv4(p + (long long)W * is + is);
+    const f32x4 g = ldv4(dout + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * dos + c);
     f32x4 g0, g1, g2, g3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -111,8 +121,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
       if (v3[j] > m) { m = v3[j]; am = 3; }
       g0[j] = am == 0 ? g[j] : 0.f; g1[j] = am == 1 ? g[j] : 0.f; g2[j] = am == 2 ? g[j] : 0.f; g3[j] = am == 3 ? g[j] : 0.f;
     }
-    float* d = din + base * dis + c;
-    st4(d, g0); st4(d + dis, g1); st4(d + (long long)W * dis, g2); st4(d + (long long)W * dis + dis, g3);
+    TI* d = din + base * dis + c;
+    stv4(d, g0); stv4(d + dis, g1); stv4(d + (long long)W * dis, g2); stv4(d + (long long)W * dis + dis, g3);
   }
 }
 
@@ -120,8 +130,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
 // BatchNorm: per (group, channel) reductions.  MODE 0: sum x, sum x^2.  MODE 1: sum dy, sum dy*xhat.
 // Grid: (chunks, groups).  A block walks its pixel chunk with threads laid out [pixel][channel quad].
 // ---------------------------------------------------------------------------------------------
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, int dys,
+template <int MODE, typename TA>
+__global__ __launch_bounds__(256) void bn_reduce_kernel(const TA* __restrict__ x, int xs, const TA* __restrict__ dy, int dys,
                                                         long long pix_per_group, int C, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, double* __restrict__ sums /*[G][2][C]*/) {
   extern __shared__ float red[];  // [2][rows][C]
@@ -138,9 +148,9 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const float* __restrict_
   if (active)
     for (long long p = p0 + row; p < p1; p += rows) {
       const long long gp = (long long)g * pix_per_group + p;
-      const f32x4 v = ld4(x + gp * xs + cq * 4);
+      const f32x4 v = ldv4(x + gp * xs + cq * 4);
       if (MODE == 0) { s0 += v; s1 += v * v; }
-      else { const f32x4 d = ld4(dy + gp * dys + cq * 4); s0 += d; s1 += d * ((v - mu) * rs); }
+      else { const f32x4 d = ldv4(dy + gp * dys + cq * 4); s0 += d; s1 += d * ((v - mu) * rs); }
     }
   if (active) { st4(red + (0 * rows + row) * C + cq * 4, s0); st4(red + (1 * rows + row) * C + cq * 4, s1); }
   __syncthreads();
@@ -195,15 +205,16 @@ __global__ void bn_eval_affine_kernel(int C, int Creal, float eps, const float* 
 }
 
 // y = x*a[g] + b[g]
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int xs, long long pixels, long long pix_per_group, int C,
-                                                       const float* __restrict__ a, const float* __restrict__ b, float* __restrict__ y, int ys) {
+template <typename TA>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const TA* __restrict__ x, int xs, long long pixels, long long pix_per_group, int C,
+                                                       const float* __restrict__ a, const float* __restrict__ b, TA* __restrict__ y, int ys) {
   const int q = C / 4;
   const long long total = pixels * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long p = idx / q;
     const int c = (idx % q) * 4;
     const long long g = p / pix_per_group;
-    st4(y + p * ys + c, ld4(x + p * xs + c) * ld4(a + g * C + c) + ld4(b + g * C + c));
+    stv4(y + p * ys + c, ldv4(x + p * xs + c) * ld4(a + g * C + c) + ld4(b + g * C + c));
   }
 }
 
@@ -223,16 +234,17 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int G, int C
   coef[((size_t)g * 3 + 0) * C + c] = A; coef[((size_t)g * 3 + 1) * C + c] = B; coef[((size_t)g * 3 + 2) * C + c] = K;
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* __restrict__ x, int xs, const float* __restrict__ dy, int dys,
+template <typename TA>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TA* __restrict__ x, int xs, const TA* __restrict__ dy, int dys,
                                                            long long pixels, long long pix_per_group, int C, const float* __restrict__ coef,
-                                                           float* __restrict__ dx, int dxs) {
+                                                           TA* __restrict__ dx, int dxs) {
   const int q = C / 4;
   const long long total = pixels * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long p = idx / q;
     const int c = (idx % q) * 4;
     const float* k = coef + (p / pix_per_group) * 3 * C + c;
-    st4(dx + p * dxs + c, ld4(k) * ld4(dy + p * dys + c) + ld4(k + C) * ld4(x + p * xs + c) + ld4(k + 2 * C));
+    stv4(dx + p * dxs + c, ld4(k) * ldv4(dy + p * dys + c) + ld4(k + C) * ldv4(x + p * xs + c) + ld4(k + 2 * C));
   }
 }
 
@@ -247,7 +259,11 @@ __global__ void bn_param_grad_kernel(const double* __restrict__ sums, int G, int
 }
 
 int grid_for(long long total) { return (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384); }
-bool ok4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.c % 4 == 0); }
+bool ok4(const sfTensor& t) {
+  return t.ptr == nullptr || ((((uintptr_t)t.ptr) & (t.dtype == SF_BF16 ? 7 : 15)) == 0 && t.stride % 4 == 0 && t.c % 4 == 0 &&
+                              (t.dtype == SF_F32 || t.dtype == SF_BF16));
+}
+bool same_dtype(const sfTensor& a, const sfTensor& b) { return a.ptr == nullptr || b.ptr == nullptr || a.dtype == b.dtype; }
 
 }  // namespace
 
@@ -261,8 +277,8 @@ int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C,
   SF_REQUIRE(sat >= 0 && sat <= C && out.c >= 8 * sat + (C - sat) && ok4(out), "preprocess: output lanes %d < %d", out.c, 8 * sat + C - sat);
   const long long total = (long long)B * T * crop * crop;
   if (total == 0) return 0;
-  hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, imgs, B, T, C, sat, H, W, crop,
-                     (float*)out.ptr, out.c, out.stride);
+  SF_DISPATCH_ACT(out.dtype, hipLaunchKernelGGL((preprocess_kernel<TA>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, imgs, B, T,
+                                                C, sat, H, W, crop, (TA*)out.ptr, out.c, out.stride));
   SF_CHECK_LAUNCH("metnet_preprocess");
   return 0;
 }
@@ -278,8 +294,14 @@ int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, 
   }
   const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)in.ptr, in.stride, n, h, w,
-                     in.c, (float*)out.ptr, out.stride, pm);
+  SF_REQUIRE(in.dtype == out.dtype || (in.dtype == SF_BF16 && out.dtype == SF_F32), "maxpool2: unsupported storage pair %d -> %d", in.dtype, out.dtype);
+#define SF_MP_FWD(TI_, TO_)                                                                                                               \
+  hipLaunchKernelGGL((maxpool_fwd_kernel<TI_, TO_>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI_*)in.ptr, in.stride, \
+                     (long long)n, h, w, in.c, (TO_*)out.ptr, out.stride, pm)
+  if (in.dtype == SF_F32) SF_MP_FWD(float, float);
+  else if (out.dtype == SF_BF16) SF_MP_FWD(__bf16, __bf16);
+  else SF_MP_FWD(__bf16, float);
+#undef SF_MP_FWD
   SF_CHECK_LAUNCH("maxpool2_fwd");
   return 0;
 }
@@ -295,8 +317,15 @@ int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w,
   }
   const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const float*)in.ptr, in.stride,
-                     (const float*)dout.ptr, dout.stride, n, h, w, in.c, (float*)din.ptr, din.stride, pm);
+  SF_REQUIRE(in.dtype == din.dtype && (in.dtype == dout.dtype || (in.dtype == SF_BF16 && dout.dtype == SF_F32)),
+             "maxpool2 bwd: unsupported storage combination in=%d dout=%d din=%d", in.dtype, dout.dtype, din.dtype);
+#define SF_MP_BWD(TI_, TO_)                                                                                                               \
+  hipLaunchKernelGGL((maxpool_bwd_kernel<TI_, TO_>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI_*)in.ptr, in.stride, \
+                     (const TO_*)dout.ptr, dout.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm)
+  if (in.dtype == SF_F32) SF_MP_BWD(float, float);
+  else if (dout.dtype == SF_BF16) SF_MP_BWD(__bf16, __bf16);
+  else SF_MP_BWD(__bf16, float);
+#undef SF_MP_BWD
   SF_CHECK_LAUNCH("maxpool2_bwd");
   return 0;
 }
@@ -304,7 +333,7 @@ int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w,
 static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, const float* mean,
                             const float* rstd, double* sums, hipStream_t st) {
   const int C = x.c;
-  SF_REQUIRE(C % 4 == 0 && C <= 1024 && ok4(x) && ok4(dy), "batchnorm: channels %d", C);
+  SF_REQUIRE(C % 4 == 0 && C <= 1024 && ok4(x) && ok4(dy) && same_dtype(x, dy), "batchnorm: channels %d / storage types", C);
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * groups, st);
   SF_REQUIRE(e == hipSuccess, "batchnorm: memset failed");
   const int q = C / 4, rows = 256 / q > 0 ? 256 / q : 1;
@@ -314,11 +343,11 @@ static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_g
   const size_t shmem = sizeof(float) * 2 * rows * C;
   dim3 grid((unsigned)chunks, groups);
   if (mode == 0)
-    hipLaunchKernelGGL((bn_reduce_kernel<0>), grid, dim3(256), shmem, st, (const float*)x.ptr, x.stride, nullptr, 0, pix_per_group, C,
-                       nullptr, nullptr, sums);
+    SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_reduce_kernel<0, TA>), grid, dim3(256), shmem, st, (const TA*)x.ptr, x.stride, (const TA*)nullptr, 0,
+                                                (long long)pix_per_group, C, (const float*)nullptr, (const float*)nullptr, sums));
   else
-    hipLaunchKernelGGL((bn_reduce_kernel<1>), grid, dim3(256), shmem, st, (const float*)x.ptr, x.stride, (const float*)dy.ptr, dy.stride,
-                       pix_per_group, C, mean, rstd, sums);
+    SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_reduce_kernel<1, TA>), grid, dim3(256), shmem, st, (const TA*)x.ptr, x.stride, (const TA*)dy.ptr,
+                                                dy.stride, (long long)pix_per_group, C, mean, rstd, sums));
   SF_CHECK_LAUNCH("bn_reduce");
   return 0;
 }
@@ -327,16 +356,16 @@ int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, in
                            float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
                            float* scale, float* shift, double* sums, sfTensor y, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_fwd: dtype %d not built", dtype);
-  SF_REQUIRE(x.c == y.c && ok4(y) && creal <= x.c, "batchnorm: y channels");
+  SF_REQUIRE(x.c == y.c && ok4(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm: y channels / storage type");
   hipStream_t st = (hipStream_t)stream;
-  sfTensor none{nullptr, 0, 0, 0, 0};
+  sfTensor none{nullptr, 0, 0, 0, 0, 0};
   if (int rc = bn_reduce_launch(0, x, none, pix_per_group, groups, nullptr, nullptr, sums, st)) return rc;
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, (double)pix_per_group, eps,
                      momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
   SF_CHECK_LAUNCH("bn_finalize");
   const long long pixels = pix_per_group * groups;
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride, pixels,
-                     pix_per_group, x.c, scale, shift, (float*)y.ptr, y.stride);
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+                                              pixels, (long long)pix_per_group, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));
   SF_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -345,13 +374,13 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
                           const float* running_mean, const float* running_var, float* scale, float* shift, sfTensor y,
                           int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_eval_fwd: dtype %d not built", dtype);
-  SF_REQUIRE(x.c == y.c && ok4(x) && ok4(y) && creal <= x.c, "batchnorm eval: channels");
+  SF_REQUIRE(x.c == y.c && ok4(x) && ok4(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm eval: channels / storage type");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, x.c, creal, eps, gamma, beta, running_mean,
                      running_var, scale, shift);
   SF_CHECK_LAUNCH("bn_eval_affine");
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride, (long long)pixels,
-                     (long long)pixels, x.c, scale, shift, (float*)y.ptr, y.stride);
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+                                              (long long)pixels, (long long)pixels, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));
   SF_CHECK_LAUNCH("bn_apply");
   return 0;
 }
@@ -360,15 +389,16 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
                            const float* mean, const float* rstd, double* sums, float* coef, sfTensor dx, float* dgamma, float* dbeta,
                            int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_bwd: dtype %d not built", dtype);
-  SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok4(dx), "batchnorm bwd: channels");
+  SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok4(dx) && x.dtype == dx.dtype, "batchnorm bwd: channels / storage type");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = bn_reduce_launch(1, x, dy, pix_per_group, groups, mean, rstd, sums, st)) return rc;
   const long long pixels = pix_per_group * groups;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((groups * x.c + 255) / 256), dim3(256), 0, st, sums, groups, x.c, creal, (double)pix_per_group,
                      gamma, mean, rstd, coef);
   SF_CHECK_LAUNCH("bn_bwd_coef");
-  hipLaunchKernelGGL(bn_bwd_apply_kernel, dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const float*)x.ptr, x.stride,
-                     (const float*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, coef, (float*)dx.ptr, dx.stride);
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+                                              (const TA*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, (const float*)coef, (TA*)dx.ptr,
+                                              dx.stride));
   SF_CHECK_LAUNCH("bn_bwd_apply");
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, dgamma, dbeta);
   SF_CHECK_LAUNCH("bn_param_grad");
@@ -416,8 +446,9 @@ __global__ void leadbias_table_kernel(const float* __restrict__ w1, int O, int I
 }
 
 // pooled[(l*F + f)][yo][xo][c] = max over the 2x2 window of base[f] + ptab[l][class]
-__global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const float* __restrict__ base, int bs, long long F, int H, int W, int C,
-                                                                int L, const float* __restrict__ ptab, float* __restrict__ out, int os) {
+template <typename TA>
+__global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const TA* __restrict__ base, int bs, long long F, int H, int W, int C,
+                                                                int L, const float* __restrict__ ptab, TA* __restrict__ out, int os) {
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const long long total = F * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -425,8 +456,8 @@ __global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const float* __r
     const long long op = idx / q;
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long f = op / ((long long)Wo * Ho);
-    const float* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
-    const f32x4 v0 = ld4(p), v1 = ld4(p + bs), v2 = ld4(p + (long long)W * bs), v3 = ld4(p + (long long)W * bs + bs);
+    const TA* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
+    const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
     const int k0 = border_class(2 * yo, 2 * xo, H, W), k1 = border_class(2 * yo, 2 * xo + 1, H, W);
     const int k2 = border_class(2 * yo + 1, 2 * xo, H, W), k3 = border_class(2 * yo + 1, 2 * xo + 1, H, W);
     for (int l = 0; l < L; ++l) {
@@ -435,16 +466,17 @@ __global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const float* __r
       f32x4 m;
 #pragma unroll
       for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a0[j], a1[j]), fmaxf(a2[j], a3[j]));
-      st4(out + (((l * F + f) * Ho + yo) * Wo + xo) * os + c, m);
+      stv4(out + (((l * F + f) * Ho + yo) * Wo + xo) * os + c, m);
     }
   }
 }
 
 // dbase[f] = sum_l unpool(dpooled[l*F+f]);  partial class sums cls_part[block][l][cls][c] (deterministic 2-stage reduce).
 // Persistent grid; each block keeps S[l][cls][c] in LDS (ds_add_f32), flushed once at the end.
-__global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const float* __restrict__ base, int bs, const float* __restrict__ dout, int dos,
+template <typename TA>
+__global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
                                                                 long long F, int H, int W, int C, int L, const float* __restrict__ ptab,
-                                                                float* __restrict__ dbase, int dbs, float* __restrict__ cls_part) {
+                                                                TA* __restrict__ dbase, int dbs, float* __restrict__ cls_part) {
   extern __shared__ float S[];  // [L][9][C]
   const int nS = L * 9 * C;
   for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
@@ -457,8 +489,8 @@ __global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const float* __
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long f = op / ((long long)Wo * Ho);
     const long long b0 = (f * H + 2 * yo) * W + 2 * xo;
-    const float* p = base + b0 * bs + c;
-    const f32x4 v0 = ld4(p), v1 = ld4(p + bs), v2 = ld4(p + (long long)W * bs), v3 = ld4(p + (long long)W * bs + bs);
+    const TA* p = base + b0 * bs + c;
+    const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
     int k[4];
     k[0] = border_class(2 * yo, 2 * xo, H, W); k[1] = border_class(2 * yo, 2 * xo + 1, H, W);
     k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
@@ -468,7 +500,7 @@ __global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const float* __
     for (int l = 0; l < L; ++l) {
       const float* pt = ptab + (size_t)l * 9 * C + c;
       const f32x4 a0 = v0 + ld4(pt + k[0] * C), a1 = v1 + ld4(pt + k[1] * C), a2 = v2 + ld4(pt + k[2] * C), a3 = v3 + ld4(pt + k[3] * C);
-      const f32x4 g = ld4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
+      const f32x4 g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
       float* Sl = S + (size_t)l * 9 * C + c;
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
@@ -485,8 +517,8 @@ __global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const float* __
         for (int j = 0; j < 4; ++j) atomicAdd(Sl + 4 * C + j, g[j]);
       }
     }
-    float* d = dbase + b0 * dbs + c;
-    st4(d, g0); st4(d + dbs, g1); st4(d + (long long)W * dbs, g2); st4(d + (long long)W * dbs + dbs, g3);
+    TA* d = dbase + b0 * dbs + c;
+    stv4(d, g0); stv4(d + dbs, g1); stv4(d + (long long)W * dbs, g2); stv4(d + (long long)W * dbs + dbs, g3);
   }
   __syncthreads();
   float* dstp = cls_part + (size_t)blockIdx.x * nS;
@@ -535,7 +567,7 @@ size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C) { return (size_t)
 int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I, int32_t cimg,
                          int32_t L, float* workspace, sfTensor out, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_leadtime_pool_fwd: dtype %d not built", dtype);
-  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && h >= 2 && w >= 2 && base.c == out.c && ok4(base) && ok4(out) && O <= base.c && cimg + L <= I,
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && h >= 2 && w >= 2 && base.c == out.c && ok4(base) && ok4(out) && base.dtype == out.dtype && O <= base.c && cimg + L <= I,
              "leadtime_pool: shapes (h=%d w=%d C=%d O=%d I=%d cimg=%d L=%d)", h, w, base.c, O, I, cimg, L);
   hipStream_t st = (hipStream_t)stream;
   const int C = base.c, nt = L * 9 * C;
@@ -543,8 +575,8 @@ int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, co
   SF_CHECK_LAUNCH("leadbias_table");
   const long long total = frames * (h / 2) * (w / 2) * (C / 4);
   if (total == 0) return 0;
-  hipLaunchKernelGGL(leadbias_pool_fwd_kernel, dim3(grid_for(total)), dim3(256), 0, st, (const float*)base.ptr, base.stride, (long long)frames,
-                     h, w, C, L, workspace, (float*)out.ptr, out.stride);
+  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_kernel<TA>), dim3(grid_for(total)), dim3(256), 0, st, (const TA*)base.ptr, base.stride,
+                                                 (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride));
   SF_CHECK_LAUNCH("leadbias_pool_fwd");
   return 0;
 }
@@ -552,7 +584,8 @@ int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, co
 int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I,
                          int32_t cimg, int32_t L, float* workspace, sfTensor dbase, float* dw1, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_leadtime_pool_bwd: dtype %d not built", dtype);
-  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && base.c == dout.c && base.c == dbase.c && ok4(base) && ok4(dout) && ok4(dbase), "leadtime_pool bwd: shapes");
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && base.c == dout.c && base.c == dbase.c && ok4(base) && ok4(dout) && ok4(dbase) &&
+                 base.dtype == dout.dtype && base.dtype == dbase.dtype, "leadtime_pool bwd: shapes / storage types");
   hipStream_t st = (hipStream_t)stream;
   const int C = base.c, nt = L * 9 * C;
   SF_REQUIRE((size_t)nt * sizeof(float) <= 160 * 1024, "leadtime_pool bwd: L*9*C floats exceed LDS");
@@ -560,13 +593,14 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
   SF_CHECK_LAUNCH("leadbias_table");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   float* cls_part = workspace + nt;
-  hipLaunchKernelGGL(leadbias_pool_bwd_kernel, dim3(LEADBIAS_BLOCKS), dim3(1024), (size_t)nt * sizeof(float), st, (const float*)base.ptr,
-                     base.stride, (const float*)dout.ptr, dout.stride, (long long)frames, h, w, C, L, workspace, (float*)dbase.ptr,
-                     dbase.stride, cls_part);
+  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(1024), (size_t)nt * sizeof(float), st,
+                                                 (const TA*)base.ptr, base.stride, (const TA*)dout.ptr, dout.stride, (long long)frames, h, w, C, L,
+                                                 (const float*)workspace, (TA*)dbase.ptr, dbase.stride, cls_part));
   SF_CHECK_LAUNCH("leadbias_pool_bwd");
   float* cls_sum = cls_part + (size_t)LEADBIAS_BLOCKS * nt;
   hipLaunchKernelGGL(leadbias_reduce_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, cls_part, LEADBIAS_BLOCKS, nt, cls_sum);

@@ -14,6 +14,7 @@ struct WgradParams {
   int N, H, W, tiles_x, tiles_y, ntiles, KS;
   float* partial; float* partial_db;
   int NpT, KpT;
+  int bf;  // bf16 kernel only: src0 / src1 / dout are all stored as bf16 (MetNet encoder "bf16a" mode)
 };
 
 

@@ -104,10 +104,10 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: ConvEngine, x0: Tensor, x1: Optional[Tensor], weight: Tensor, bias: Optional[Tensor], n: int,
-                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool):
+                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool, out_dtype=None):
         H, W = x0.shape[1], x0.shape[2]
         packed, bp = eng.packed(weight, bias, "fwd")
-        y = torch.empty(n, H, W, eng.coutp, dtype=torch.float32, device=x0.device)
+        y = torch.empty(n, H, W, eng.coutp, dtype=out_dtype or torch.float32, device=x0.device)
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if x1 is not None else NULL
         K.conv3x3(s0, s1, n, H, W, packed, bp, eng.fwd_map, T(y), SF_EPI_SIGMOID if sigmoid else SF_EPI_LINEAR)
@@ -135,7 +135,7 @@ class _ConvFn(torch.autograd.Function):
             needk = need if has_x1 else need[:1]
             gm = eng.bwd_map(tuple(needk))
             lanes = sum(cpad(c) for c, nd in zip(eng.cins, needk) if nd)
-            dcat = torch.empty(n, H, W, lanes, dtype=torch.float32, device=gy.device)
+            dcat = torch.empty(n, H, W, lanes, dtype=x0.dtype, device=gy.device)  # a gradient is stored like its tensor
             K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, ctx.bias, "bwd", tuple(needk))[0], None, gm, T(dcat))
             if need[0] and need[1]:
                 c0p = cpad(eng.cins[0])
@@ -149,11 +149,12 @@ class _ConvFn(torch.autograd.Function):
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
         K.conv3x3_bwd_weight(s0, s1, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
-        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None
+        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None, None
 
 
-def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False) -> Tensor:
-    return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid)
+def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False, out_dtype=None) -> Tensor:
+    """``out_dtype=torch.bfloat16`` stores the result as bf16 (SF_BF16 kernels only; "bf16a" encoder mode)."""
+    return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype)
 
 
 def conv3x3_broadcast(eng: ConvEngine, x0: Tensor, x1: Tensor, weight: Tensor, bias: Optional[Tensor], n: int,
@@ -166,19 +167,20 @@ def conv3x3_broadcast(eng: ConvEngine, x0: Tensor, x1: Tensor, weight: Tensor, b
 # ----------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, perm: Optional[Tuple[int, int]]):
+    def forward(ctx, x: Tensor, perm: Optional[Tuple[int, int]], out_dtype=None):
         ctx.perm = perm
         ctx.save_for_backward(x)
-        return K.maxpool2_fwd(x, perm)
+        return K.maxpool2_fwd(x, perm, out_dtype)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
         (x,) = ctx.saved_tensors
-        return K.maxpool2_bwd(x, gy.contiguous(), ctx.perm), None
+        return K.maxpool2_bwd(x, gy.contiguous(), ctx.perm), None, None
 
 
-def maxpool2(x: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
-    return _MaxPoolFn.apply(x, perm)
+def maxpool2(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None) -> Tensor:
+    """``out_dtype=torch.float32`` on a bf16 input is the encoder's exit back to fp32 storage (max is exact in either type)."""
+    return _MaxPoolFn.apply(x, perm, out_dtype)
 
 
 class _LeadTimePoolFn(torch.autograd.Function):
@@ -189,7 +191,7 @@ class _LeadTimePoolFn(torch.autograd.Function):
         Fr, H, W, C = base.shape
         w1 = w1.contiguous()
         ws = torch.empty(lib().sf_leadtime_pool_workspace_floats(L, C), dtype=torch.float32, device=base.device)
-        out = torch.empty(L * Fr, H // 2, W // 2, C, dtype=torch.float32, device=base.device)
+        out = torch.empty(L * Fr, H // 2, W // 2, C, dtype=base.dtype, device=base.device)
         check(lib().sf_leadtime_pool_fwd(T(base), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(out), SF_F32,
                                          stream_ptr()), "sf_leadtime_pool_fwd")
         ctx.meta = (cimg, L)

@@ -229,20 +229,20 @@ def custom_map(nlanes: List[int], klanes: List[int], nf: Optional[int] = None) -
     return _finish(list(nlanes), list(klanes), nf)
 
 
-def metnet_preprocess(imgs: Tensor, sat: int, crop: int) -> Tensor:
-    """imgs[B,T,C,H,W] -> frames [T*B, crop, crop, Cp] (time-major).  sf_metnet_preprocess_fwd."""
+def metnet_preprocess(imgs: Tensor, sat: int, crop: int, out_dtype=torch.float32) -> Tensor:
+    """imgs[B,T,C,H,W] -> frames [T*B, crop, crop, Cp] (time-major), stored as ``out_dtype``.  sf_metnet_preprocess_fwd."""
     _hip.require_device(imgs, "imgs")
     imgs = imgs.contiguous()
     B, Tn, C, H, W = imgs.shape
     cp = cpad(8 * sat + (C - sat))
-    out = torch.empty(Tn * B, crop, crop, cp, dtype=torch.float32, device=imgs.device)
+    out = torch.empty(Tn * B, crop, crop, cp, dtype=out_dtype, device=imgs.device)
     check(lib().sf_metnet_preprocess_fwd(imgs.data_ptr(), B, Tn, C, sat, H, W, crop, T(out), SF_F32, stream_ptr()), "sf_metnet_preprocess_fwd")
     return out
 
 
-def maxpool2_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
+def maxpool2_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None) -> Tensor:
     n, h, w, c = x.shape
-    y = torch.empty(n, h // 2, w // 2, c, dtype=torch.float32, device=x.device)
+    y = torch.empty(n, h // 2, w // 2, c, dtype=out_dtype or x.dtype, device=x.device)
     pl, pt = perm or (0, 0)
     check(lib().sf_maxpool2_fwd(T(x), n, h, w, T(y), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_fwd")
     return y

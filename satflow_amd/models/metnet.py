@@ -25,7 +25,7 @@ import torch
 from torch import nn
 
 from .. import functional as F
-from .._hip import cpad, require_device
+from .._hip import cpad, encoder_storage_dtype, require_device
 from ..functional import ConvEngine, GRUEngine
 from .layers.ConditionTime import ConditionTime
 from .layers.TimeDistributed import TimeDistributed
@@ -79,13 +79,17 @@ class DownSampler(nn.Module):
         self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
 
     def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None) -> Tensor:
-        """NHWC pipeline from the first pooling's output (``pooled``) or from the input ``x``; ``groups`` BatchNorm batches."""
+        """NHWC pipeline from the first pooling's output (``pooled``) or from the input ``x``; ``groups`` BatchNorm batches.
+
+        The activations keep the storage type they arrive in (fp32, or bf16 in "bf16a" mode); the last pooling always
+        returns fp32."""
         m = self.module
-        y = pooled if pooled is not None else F.maxpool2(F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias))
+        y = pooled if pooled is not None else F.maxpool2(F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias, out_dtype=x.dtype))
+        st = y.dtype
         y = F.batchnorm(y, m[3], groups, self.training)
-        y = F.batchnorm(F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias), m[5], groups, self.training)
-        y = F.batchnorm(F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias), m[7], groups, self.training)
-        return F.maxpool2(F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias), perm)
+        y = F.batchnorm(F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias, out_dtype=st), m[5], groups, self.training)
+        y = F.batchnorm(F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias, out_dtype=st), m[7], groups, self.training)
+        return F.maxpool2(F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias, out_dtype=st), perm, out_dtype=torch.float32)
 
     def forward(self, x: Tensor) -> Tensor:
         """``[N,C,H,W] -> [N,out,H/4,W/4]`` (module-surface form, one BatchNorm batch)."""
@@ -258,12 +262,13 @@ class MetNet(nn.Module):
         L, S = self.forecast_steps, self.input_size
         enc: DownSampler = self.image_encoder.module
         F_ = Tn * B
-        frames = K.metnet_preprocess(imgs.float(), self.sat_channels, S)  # [T*B, S, S, Cimg_p], computed once
+        st = encoder_storage_dtype()  # fp32, or bf16 in "bf16a" mode (encoder activations only)
+        frames = K.metnet_preprocess(imgs.float(), self.sat_channels, S, st)  # [T*B, S, S, Cimg_p], computed once
         # conv1: its image part once per frame; ConditionTime's one-hot planes (reference layers/ConditionTime.py:22-33)
         # contribute a per-lead-time, border-aware constant that is added inside the fused first pooling
         c1 = enc.module[0]
         cimg = self.image_channels
-        base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias)  # [T*B, S, S, 160]
+        base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias, out_dtype=st)  # [T*B, S, S, 160]
         p1 = F.leadtime_pool(base, c1.weight, cimg, L)  # [L*T*B, S/2, S/2, 160], image (l*F + f)
         # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
         # images from [lead][time][batch] to [time][lead][batch] for the recurrent part

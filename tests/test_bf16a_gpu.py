@@ -1,0 +1,208 @@
+"""GPU: "bf16a" mode - bf16 kernels AND bf16 storage of the MetNet image encoder's activations / gradients.
+
+Every kernel that accepts bf16-stored tensors (sfTensor.dtype = SF_BF16) is checked against the SAME computation on
+the fp32 widening of the same bf16 inputs: the arithmetic is fp32 (or exact-product bf16 MFMA with fp32 accumulate)
+either way, so the only admissible difference is the final round-to-nearest-even to bf16, i.e. <= 1 bf16 ulp
+(2^-8 relative) plus accumulation-order noise.  Max pooling must agree exactly.  The whole-model test uses the CPU
+autocast oracle as the yardstick, as tests/test_bf16_gpu.py does.
+"""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+import satflow_amd
+from conftest import assert_close
+
+pytestmark = pytest.mark.gpu
+
+ULP = 2.0**-8
+
+
+@pytest.fixture()
+def bf16a_mode():
+    satflow_amd.set_compute_dtype("bf16a")
+    yield
+    satflow_amd.set_compute_dtype("f32")
+
+
+def _r(t):
+    return t.bfloat16().float()
+
+
+def _within_ulp(got, ref, what, extra=1e-6):
+    """got (bf16 storage) vs ref (fp32): one bf16 ulp of the value + `extra` of the tensor scale (accumulation noise that can
+    move a value across a rounding boundary is covered by the full ulp; a half ulp is the rounding itself)."""
+    got, ref = got.detach().float().cpu(), ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = float(ref.abs().max()) + 1e-30
+    excess = (got - ref).abs() - (ULP * ref.abs() + extra * scale)
+    assert float(excess.max()) <= 0, f"{what}: exceeds 1 bf16 ulp by {float(excess.max()):.3e} (scale {scale:.3e})"
+
+
+def _nhwc_b(x, device):
+    """NCHW fp32 (CPU) -> padded NHWC bf16 leaf on the device, plus its exact fp32 NCHW widening on the CPU."""
+    from satflow_amd.functional import nchw_to_nhwc
+
+    xb = nchw_to_nhwc(x.to(device)).bfloat16().requires_grad_()
+    return xb, _r(x)
+
+
+def _nchw(t, c):
+    from satflow_amd.functional import nhwc_to_nchw
+
+    return nhwc_to_nchw(t.detach().float().contiguous(), c).cpu()
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 40, 33), (256, 256, 2, 32, 32), (160, 256, 3, 24, 40)])
+def test_conv3x3_bf16_storage(device, bf16a_mode, cin, cout, n, h, w):
+    from satflow_amd.functional import ConvEngine, conv3x3
+
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin**0.5)
+    b = torch.randn(cout, generator=g)
+    cot = torch.randn(n, cout, h, w, generator=g)
+    xb, xr = _nhwc_b(x, device)
+    cb, cr = _nhwc_b(cot, device)
+    xr.requires_grad_()
+    wr = _r(wt).requires_grad_()
+    ref = TF.conv2d(xr, wr, b, padding=1)
+    wd, bd = wt.to(device).requires_grad_(), b.to(device).requires_grad_()
+    y = conv3x3(ConvEngine([cin], cout), xb, wd, bd, out_dtype=torch.bfloat16)
+    assert y.dtype == torch.bfloat16
+    _within_ulp(_nchw(y, cout), ref, "bf16-stored conv output")
+    y.backward(cb.detach())
+    assert xb.grad.dtype == torch.bfloat16
+    dx_ref, dw_ref = torch.autograd.grad(TF.conv2d(xr, wr, None, padding=1), (xr, wr), cr)
+    _within_ulp(_nchw(xb.grad, cin), dx_ref, "bf16-stored dgrad")
+    assert_close(wd.grad, dw_ref, "wgrad from bf16-stored tensors", grad=True)
+    assert_close(bd.grad, cr.sum(dim=(0, 2, 3)), "db from bf16-stored cotangent", grad=True)
+
+
+def test_conv3x3_bf16_source_fp32_out(device, bf16a_mode):
+    """bf16-stored source, fp32 output (the storage type is per tensor)."""
+    from satflow_amd.functional import ConvEngine, conv3x3
+
+    g = torch.Generator().manual_seed(5)
+    x, wt = torch.randn(2, 48, 20, 18, generator=g), torch.randn(40, 48, 3, 3, generator=g) * 0.05
+    xb, xr = _nhwc_b(x, device)
+    y = conv3x3(ConvEngine([48], 40), xb, wt.to(device), None)
+    assert y.dtype == torch.float32
+    assert_close(_nchw(y, 40), TF.conv2d(xr, _r(wt), None, padding=1), "bf16 source -> fp32 output")
+
+
+def test_bf16_storage_needs_bf16_kernels(device):
+    from satflow_amd.functional import ConvEngine, conv3x3
+
+    satflow_amd.set_compute_dtype("f32")
+    xb, _ = _nhwc_b(torch.randn(1, 16, 8, 8), device)
+    with pytest.raises(RuntimeError, match="bf16"):
+        conv3x3(ConvEngine([16], 16), xb, torch.randn(16, 16, 3, 3, device=device), None)
+    # entry points without a bf16 instantiation refuse bf16 storage instead of misreading it
+    from satflow_amd import kernels as K
+
+    with pytest.raises(RuntimeError, match="bf16"):
+        K.linear_fwd(xb.detach(), torch.randn(16, 16, device=device), None, 16)
+
+
+@pytest.mark.parametrize("perm", [None, (3, 2)])
+@pytest.mark.parametrize("out_dtype", [torch.bfloat16, torch.float32])
+def test_maxpool_bf16_storage(device, perm, out_dtype):
+    from satflow_amd.functional import maxpool2
+
+    g = torch.Generator().manual_seed(11)
+    xb = torch.randn(12, 10, 14, 32, generator=g).to(device).bfloat16().requires_grad_()
+    xf = xb.detach().float().requires_grad_()
+    yb, yf = maxpool2(xb, perm, out_dtype=out_dtype), maxpool2(xf, perm)
+    assert yb.dtype == out_dtype
+    assert torch.equal(yb.float(), yf), "max pooling of bf16 values is exact"
+    cot = torch.randn(yf.shape, generator=g).to(device).to(out_dtype)
+    yb.backward(cot)
+    yf.backward(cot.float())
+    assert xb.grad.dtype == torch.bfloat16
+    assert torch.equal(xb.grad, xf.grad.bfloat16()), "routing is exact; an fp32 cotangent is rounded once on the way into the bf16 gradient"
+
+
+def test_batchnorm_bf16_storage(device):
+    from satflow_amd.functional import batchnorm
+
+    g = torch.Generator().manual_seed(12)
+    C, groups = 48, 3
+    xb = (torch.randn(6, 9, 7, C, generator=g) * 2 + 0.5).to(device).bfloat16().requires_grad_()
+    xf = xb.detach().float().requires_grad_()
+    bn_b, bn_f = torch.nn.BatchNorm2d(40).to(device), torch.nn.BatchNorm2d(40).to(device)
+    with torch.no_grad():
+        bn_b.weight.copy_(torch.randn(40, generator=g)); bn_b.bias.copy_(torch.randn(40, generator=g))
+    bn_f.load_state_dict(bn_b.state_dict())
+    yb, yf = batchnorm(xb, bn_b, groups, True), batchnorm(xf, bn_f, groups, True)
+    assert yb.dtype == torch.bfloat16
+    _within_ulp(yb[..., :40], yf[..., :40], "BatchNorm output")
+    assert_close(bn_b.running_var, bn_f.running_var, "running_var")
+    cot = torch.randn(yf.shape, generator=g).to(device).bfloat16()
+    yb.backward(cot)
+    yf.backward(cot.float())
+    _within_ulp(xb.grad[..., :40], xf.grad[..., :40], "BatchNorm dx", extra=1e-5)
+    assert_close(bn_b.weight.grad, bn_f.weight.grad, "dgamma", grad=True)
+    assert_close(bn_b.bias.grad, bn_f.bias.grad, "dbeta", grad=True)
+
+
+def test_leadtime_pool_bf16_storage(device):
+    from satflow_amd.functional import leadtime_pool
+
+    g = torch.Generator().manual_seed(13)
+    Fr, S, C, cimg, L = 4, 12, 32, 20, 5
+    base_b = torch.randn(Fr, S, S, C, generator=g).to(device).bfloat16().requires_grad_()
+    base_f = base_b.detach().float().requires_grad_()
+    w_b = (torch.randn(28, cimg + L, 3, 3, generator=g) * 0.3).to(device).requires_grad_()
+    w_f = w_b.detach().clone().requires_grad_()
+    pb, pf = leadtime_pool(base_b, w_b, cimg, L), leadtime_pool(base_f, w_f, cimg, L)
+    assert pb.dtype == torch.bfloat16
+    _within_ulp(pb, pf, "lead-time pooling output", extra=0.0)
+    cot = torch.randn(pf.shape, generator=g).to(device).bfloat16()
+    pb.backward(cot)
+    pf.backward(cot.float())
+    _within_ulp(base_b.grad, base_f.grad, "lead-time pooling d(base)", extra=1e-6)
+    assert_close(w_b.grad, w_f.grad, "lead-time pooling dW1", grad=True)
+
+
+def test_preprocess_bf16_storage(device):
+    from satflow_amd import kernels as K
+
+    x = torch.randn(2, 3, 13, 32, 32, generator=torch.Generator().manual_seed(14)).to(device)
+    fb, ff = K.metnet_preprocess(x, 12, 8, torch.bfloat16), K.metnet_preprocess(x, 12, 8)
+    assert fb.dtype == torch.bfloat16 and torch.equal(fb, ff.bfloat16())
+
+
+def test_metnet_bf16a_train_step(device, bf16a_mode):
+    """Whole MetNet training step with bf16-stored encoder activations against the fp32 oracle; yardstick = the same
+    oracle under torch.autocast(bfloat16) on the CPU (which also leaves bf16 tensors between the encoder's layers)."""
+    from oracle import metnet as M
+    from test_metnet_gpu import _g, _metnet_pair
+
+    cfg = dict(input_channels=13, sat_channels=12, input_size=16, output_channels=3, hidden_dim=32, forecast_steps=4)
+    net, P = _metnet_pair(device, cfg)
+    x = torch.randn(2, 3, 13, 64, 64, generator=_g(51))
+    cot = torch.randn(2, 4, 3, 4, 4, generator=_g(52))
+    ref = M.metnet_forward(x, P, sat_channels=12, input_size=16, forecast_steps=4)
+    (ref * cot).sum().backward()
+    net.train()
+    out = net(x.to(device))
+    assert out.dtype == torch.float32
+    (out * cot.to(device)).sum().backward()
+    P2 = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
+    with torch.autocast("cpu", dtype=torch.bfloat16):
+        ref16 = M.metnet_forward(x, P2, sat_channels=12, input_size=16, forecast_steps=4)
+    (ref16.float() * cot).sum().backward()
+    rel = lambda a, b: float((a.detach().cpu().float() - b.detach()).norm() / (b.detach().norm() + 1e-30))
+    ours_out, theirs_out = rel(out, ref), rel(ref16, ref)
+    assert ours_out < max(2 * theirs_out, 3e-2), (ours_out, theirs_out)
+    worst = ("out", 0.0, 0.0)
+    for k, p in net.named_parameters():
+        if k in ("image_encoder.module.module.0.bias", "image_encoder.module.module.4.bias", "image_encoder.module.module.6.bias"):
+            continue  # convolution biases in front of a training-mode BatchNorm: the true gradient is zero
+        assert p.grad.dtype == torch.float32
+        ours, theirs = rel(p.grad, P[k].grad), rel(P2[k].grad, P[k].grad)
+        if ours > worst[1]:
+            worst = (k, ours, theirs)
+        assert ours < max(2 * theirs, 5e-2), (k, ours, theirs)
+    print(f"bf16a MetNet step: output rel L2 ours {ours_out:.2e} / CPU autocast {theirs_out:.2e}; worst gradient {worst[0]}: ours {worst[1]:.2e} / autocast {worst[2]:.2e}")

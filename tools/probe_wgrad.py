@@ -1,3 +1,4 @@
+"""Timing probe of sf_conv3x3_bwd_weight at the MetNet shapes.  SF_ACT=bf16 stores the tensors as bf16 ("bf16a" mode)."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch, satflow_amd
@@ -6,10 +7,17 @@ from satflow_amd._hip import T, NULL
 from satflow_amd.functional import ConvEngine
 satflow_amd.set_compute_dtype("bf16")
 dev = torch.device("cuda:0")
-n, cin, cout, H, W = 2304, 256, 256, 32, 32
-eng = ConvEngine([cin], cout)
-x = torch.randn(n, H, W, cin, device=dev); gy = torch.randn(n, H, W, cout, device=dev)
-dw = torch.empty(cout, cin, 3, 3, device=dev); db = torch.empty(cout, device=dev)
-for _ in range(4):
-    K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw, db, False)
-torch.cuda.synchronize()
+st = torch.bfloat16 if os.environ.get("SF_ACT", "f32") == "bf16" else torch.float32
+for (n, cin, cout, H, W) in ((2304, 256, 256, 32, 32), (2304, 160, 256, 32, 32), (192, 96, 160, 64, 64)):
+    eng = ConvEngine([cin], cout)
+    x = torch.randn(n, H, W, eng.fwd_map.Kp, device=dev).to(st); gy = torch.randn(n, H, W, eng.coutp, device=dev).to(st)
+    dw = torch.empty(cout, cin, 3, 3, device=dev); db = torch.empty(cout, device=dev)
+    f = lambda: K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw, db, False)
+    for _ in range(3): f()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(10): f()
+    e1.record(); torch.cuda.synchronize()
+    ms = e0.elapsed_time(e1) / 10
+    fl = 2 * 9 * cin * cout * H * W * n
+    print(f"{os.environ.get('SATFLOW_HIP_LIB','default')[-24:]:>24} act={st} wgrad {cin}->{cout} {H}x{W} n={n}: {ms:.3f} ms  {fl/ms/1e9:.0f} TF/s", flush=True)
