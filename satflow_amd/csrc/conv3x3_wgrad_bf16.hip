@@ -131,6 +131,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const unsigned b_const1 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s1 + (kcb - p.c0)) * ESZ;
     struct Stage { VT va[2][8], vb[10], vb1[MIXED ? 10 : 1]; };
     auto ld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) -> VT {
+#ifdef SF_EXP_WG_NOLOAD
+      return VT{};
+#endif
       if constexpr (BF) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
       else return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
@@ -181,6 +184,13 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       }
     };
     auto store_tile = [&](int i, Stage& s) {
+#ifdef SF_EXP_WG_NOSTORE
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { asm volatile("" ::"v"(s.va[0][j]), "v"(s.va[1][j])); }
+#pragma unroll
+      for (int j = 0; j < 10; ++j) { asm volatile("" ::"v"(s.vb[j])); }
+      return;
+#endif
       char* la = lds + (i & 1) * BUF;
       char* lb = la + A_BYTES;
       char* lh = lb + B_BYTES;
@@ -290,6 +300,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       // hrow, hrow-1, hrow-2, whose dout fragments sit in a 3-row register window (72 MFMAs per tile either way,
       // but 10 instead of 24 B-row reads / shift sequences).
       bf16x8 arow[3];
+#ifdef SF_EXP_WG_NOCOMPUTE
+      if (i >= 0) { __syncthreads(); continue; }
+#endif
 #pragma unroll
       for (int hrow = 0; hrow < HR; ++hrow) {
         if (hrow < KR) arow[hrow % 3] = *reinterpret_cast<const bf16x8*>(la + a_off + hrow * 128);

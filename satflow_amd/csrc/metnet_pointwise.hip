@@ -471,10 +471,13 @@ __global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const TA* __rest
   }
 }
 
-// dbase[f] = sum_l unpool(dpooled[l*F+f]);  partial class sums cls_part[block][l][cls][c] (deterministic 2-stage reduce).
-// Persistent grid; each block keeps S[l][cls][c] in LDS (ds_add_f32), flushed once at the end.
+// dbase[f] = sum_l unpool(dpooled[l*F+f]);  partial class sums cls_part[block][l][cls][c] (2-stage reduce).
+// Persistent grid.  A thread owns ONE channel quad for the whole kernel and walks pooling windows, so the sums of the
+// interior border class (class 4: ~90 % of all windows) stay in registers for the first LEAD_REG lead times and reach
+// LDS once, at the end; only border windows (and lead times beyond LEAD_REG) use LDS atomics (ds_add_f32) per element.
+constexpr int LEAD_REG = 12;
 template <typename TA>
-__global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
+__global__ __launch_bounds__(512) void leadbias_pool_bwd_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
                                                                 long long F, int H, int W, int C, int L, const float* __restrict__ ptab,
                                                                 TA* __restrict__ dbase, int dbs, float* __restrict__ cls_part) {
   extern __shared__ float S[];  // [L][9][C]
@@ -482,44 +485,66 @@ __global__ __launch_bounds__(1024) void leadbias_pool_bwd_kernel(const TA* __res
   for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
   __syncthreads();
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
-  const long long total = F * Ho * Wo * q;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (idx % q) * 4;
-    const long long op = idx / q;
-    const int xo = op % Wo, yo = (op / Wo) % Ho;
-    const long long f = op / ((long long)Wo * Ho);
-    const long long b0 = (f * H + 2 * yo) * W + 2 * xo;
-    const TA* p = base + b0 * bs + c;
-    const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
-    int k[4];
-    k[0] = border_class(2 * yo, 2 * xo, H, W); k[1] = border_class(2 * yo, 2 * xo + 1, H, W);
-    k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
-    const bool interior = k[0] == 4 && k[3] == 4;
-    f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
-#pragma unroll 4
-    for (int l = 0; l < L; ++l) {
-      const float* pt = ptab + (size_t)l * 9 * C + c;
-      const f32x4 a0 = v0 + ld4(pt + k[0] * C), a1 = v1 + ld4(pt + k[1] * C), a2 = v2 + ld4(pt + k[2] * C), a3 = v3 + ld4(pt + k[3] * C);
-      const f32x4 g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
-      float* Sl = S + (size_t)l * 9 * C + c;
+  const int lanes = blockDim.x / q;  // windows in flight per block
+  const int cq = threadIdx.x % q, wl = threadIdx.x / q;
+  const int c = cq * 4;
+  const long long windows = F * Ho * Wo;
+  f32x4 s4[LEAD_REG];
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        int am = 0; float m = a0[j];  // first maximum in row-major window order, as max_pool2d
-        if (a1[j] > m) { m = a1[j]; am = 1; }
-        if (a2[j] > m) { m = a2[j]; am = 2; }
-        if (a3[j] > m) { m = a3[j]; am = 3; }
-        g0[j] += am == 0 ? g[j] : 0.f; g1[j] += am == 1 ? g[j] : 0.f; g2[j] += am == 2 ? g[j] : 0.f; g3[j] += am == 3 ? g[j] : 0.f;
-        // class sums: interior windows all land in class 4 (accumulated per thread below), border windows go to LDS
-        if (!interior) atomicAdd(Sl + k[am] * C + j, g[j]);
-      }
-      if (interior) {
+  for (int l = 0; l < LEAD_REG; ++l) s4[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wl < lanes)
+    for (long long op = (long long)blockIdx.x * lanes + wl; op < windows; op += (long long)gridDim.x * lanes) {
+      const int xo = op % Wo, yo = (op / Wo) % Ho;
+      const long long f = op / ((long long)Wo * Ho);
+      const long long b0 = (f * H + 2 * yo) * W + 2 * xo;
+      const TA* p = base + b0 * bs + c;
+      const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
+      int k[4];
+      k[0] = border_class(2 * yo, 2 * xo, H, W); k[1] = border_class(2 * yo, 2 * xo + 1, H, W);
+      k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+      const bool interior = k[0] == 4 && k[3] == 4;
+      f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
+      auto lead = [&](int l, f32x4& reg_sum, bool use_reg) {
+        const float* pt = ptab + (size_t)l * 9 * C + c;
+        f32x4 a0, a1, a2, a3;
+        if (interior) {  // all four positions share one table row: one load instead of four, same sums
+          const f32x4 t = ld4(pt + 4 * C);
+          a0 = v0 + t; a1 = v1 + t; a2 = v2 + t; a3 = v3 + t;
+        } else {
+          a0 = v0 + ld4(pt + k[0] * C); a1 = v1 + ld4(pt + k[1] * C); a2 = v2 + ld4(pt + k[2] * C); a3 = v3 + ld4(pt + k[3] * C);
+        }
+        const f32x4 g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
+        float* Sl = S + (size_t)l * 9 * C + c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(Sl + 4 * C + j, g[j]);
-      }
+        for (int j = 0; j < 4; ++j) {
+          int am = 0; float m = a0[j];  // first maximum in row-major window order, as max_pool2d
+          if (a1[j] > m) { m = a1[j]; am = 1; }
+          if (a2[j] > m) { m = a2[j]; am = 2; }
+          if (a3[j] > m) { m = a3[j]; am = 3; }
+          g0[j] += am == 0 ? g[j] : 0.f; g1[j] += am == 1 ? g[j] : 0.f; g2[j] += am == 2 ? g[j] : 0.f; g3[j] += am == 3 ? g[j] : 0.f;
+          if (!interior) atomicAdd(Sl + k[am] * C + j, g[j]);
+        }
+        if (interior) {
+          if (use_reg) reg_sum += g;
+          else {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) atomicAdd(Sl + 4 * C + j, g[j]);
+          }
+        }
+      };
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l)
+        if (l < L) lead(l, s4[l], true);
+      for (int l = LEAD_REG; l < L; ++l) { f32x4 unused; lead(l, unused, false); }
+      TA* d = dbase + b0 * dbs + c;
+      stv4(d, g0); stv4(d + dbs, g1); stv4(d + (long long)W * dbs, g2); stv4(d + (long long)W * dbs + dbs, g3);
     }
-    TA* d = dbase + b0 * dbs + c;
-    stv4(d, g0); stv4(d + dbs, g1); stv4(d + (long long)W * dbs, g2); stv4(d + (long long)W * dbs + dbs, g3);
-  }
+#pragma unroll
+  for (int l = 0; l < LEAD_REG; ++l)
+    if (l < L && wl < lanes) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) atomicAdd(S + ((size_t)l * 9 + 4) * C + c + j, s4[l][j]);
+    }
   __syncthreads();
   float* dstp = cls_part + (size_t)blockIdx.x * nS;
   for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
@@ -598,7 +623,7 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
     attr_set = true;
   }
   float* cls_part = workspace + nt;
-  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(1024), (size_t)nt * sizeof(float), st,
+  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(512), (size_t)nt * sizeof(float), st,
                                                  (const TA*)base.ptr, base.stride, (const TA*)dout.ptr, dout.stride, (long long)frames, h, w, C, L,
                                                  (const float*)workspace, (TA*)dbase.ptr, dbase.stride, cls_part));
   SF_CHECK_LAUNCH("leadbias_pool_bwd");
