@@ -133,10 +133,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);  // by parity of ky
   const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
 
+#ifdef SF_EXP_NOLDS
+  bf16x8 fa[2][2], fb[2][NF];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+#pragma unroll
+    for (int m = 0; m < 2; ++m) fa[i][m] = __builtin_bit_cast(bf16x8, f32x4{1.f + lane, 2.f, 3.f + i, 4.f + m});
+#pragma unroll
+    for (int m = 0; m < NF; ++m) fb[i][m] = __builtin_bit_cast(bf16x8, f32x4{1.5f + lane, 2.5f, 3.f + i, 4.f + m});
+  }
+#endif
   for (int ci = 0; ci < nch; ++ci) {
     const int cur = ci & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weight DMA has landed (LDS-DMA is not covered by the barrier)
+#ifndef SF_EXP_NOBARRIER
     __syncthreads();
+#endif
 #ifndef SF_EXP_NOSTAGE
     if (ci + 1 < nch) {
 #ifndef SF_EXP_NOWEIGHTS
@@ -157,12 +169,15 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
     };
+#ifndef SF_EXP_NOLDS
     bf16x8 fa[2][2], fb[2][NF];
     load_tap(0, fa[0], fb[0]);
+#endif
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
+#ifndef SF_EXP_NOLDS
       if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
-      __builtin_amdgcn_sched_barrier(0);
+#endif
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -172,6 +187,18 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #else
           acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
 #endif
+      // scheduling: one LDS read (the next tap's operands) after each of the first MFMAs of this tap, the remaining
+      // MFMAs behind them - a clump of 2+NF reads between two MFMA groups measured 2 % (NF=4) to 15 % (NF=5) slower
+      if (tap + 1 < 9) {
+        constexpr int READS = 2 + NF, MFMAS = 2 * NF, PAIRS = READS < MFMAS ? READS : MFMAS;
+#pragma unroll
+        for (int k = 0; k < PAIRS; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        if constexpr (MFMAS > PAIRS) __builtin_amdgcn_sched_group_barrier(0x008, MFMAS - PAIRS, 0);
+        if constexpr (READS > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, READS - PAIRS, 0);
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
 #ifndef SF_EXP_NOSTAGE
