@@ -83,10 +83,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
                                        (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
   };
-  auto load_input = [&](int ci) {
+  auto load_input = [&](int ci) {  // fp32-stored source: registers now, bf16 conversion + ds_write after the chunk's MFMAs
     const float* src; int cbase, stride, ns;
-    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; staged_bf = p.bf0; }
-    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; staged_bf = p.bf1; }
+    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
+    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;
@@ -94,36 +94,66 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
       const int gy = y0 + iy - 1, gx = x0 + ix - 1;
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-        const size_t e = ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + half * 8;
-        if (staged_bf) {  // 8 bf16 = one 16-byte piece, carried in the low half of the staging registers
-          const f32x4 q = *reinterpret_cast<const f32x4*>(reinterpret_cast<const __bf16*>(src) + e);
-          v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
-        } else {
-          v = *reinterpret_cast<const f32x8*>(src + e);
-        }
-      }
+      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        v = *reinterpret_cast<const f32x8*>(src + ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + half * 8);
       inreg[j] = v;
     }
   };
   auto store_input = [&](int buf) {
+    if (staged_bf) return;  // bf16-stored sources went straight to LDS (dma_input)
     char* dst = lds_in + buf * IN_B;
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;
       const int pix = pc >> 1, half = pc & 1;
       const int iy = pix / HALO_W;
-      if (pc < PIECES) {
-        char* d = dst + pix * PIX_B + 16 * (half ^ (iy & 1));
-        if (staged_bf) *reinterpret_cast<f32x4*>(d) = f32x4{inreg[j][0], inreg[j][1], inreg[j][2], inreg[j][3]};
-        else *reinterpret_cast<bf16x8*>(d) = __builtin_convertvector(inreg[j], bf16x8);
-      }
+      if (pc < PIECES) *reinterpret_cast<bf16x8*>(dst + pix * PIX_B + 16 * (half ^ (iy & 1))) = __builtin_convertvector(inreg[j], bf16x8);
     }
   };
+  // bf16-STORED sources need no conversion: their halo tile goes HBM -> LDS by LDS-DMA like the weights (no staging
+  // registers, no ds_write, nothing to wait for before the next barrier's vmcnt(0)).  The DMA writes lane-linearly, so
+  // piece pc = (pixel, physical half) lands in 16-byte slot pc and fetches the LOGICAL half (physical ^ row parity,
+  // the bank swizzle of the register path).  Halo pixels outside the image are never written by the DMA (lanes
+  // masked off): their slots are zeroed once per block, below.
+  auto dma_input = [&](int ci, int buf) {
+    const float* src; int cbase, stride, ns;
+    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
+    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
+    const __bf16* img = reinterpret_cast<const __bf16*>(src) + (size_t)ns * p.H * p.W * stride + cbase;
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int pc = tid + j * THREADS;  // = (wave + j*WAVES) * 64 + lane: one wave-instruction fills 64 consecutive slots
+      const int pix = pc >> 1, hphys = pc & 1;
+      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(img + (size_t)(gy * p.W + gx) * stride + 8 * (hphys ^ (iy & 1))),
+            (__attribute__((address_space(3))) void*)(lds_in + buf * IN_B + (wave + j * WAVES) * 1024), 16, 0, 0);
+    }
+  };
+  auto stage_input = [&](int ci) {  // issue side of the next chunk's input staging
+    staged_bf = ci < ch0 ? p.bf0 : p.bf1;
+    if (staged_bf) dma_input(ci, ci & 1);
+    else load_input(ci);
+  };
+  if (p.bf0 || p.bf1) {  // zero the out-of-image halo slots of both buffers (the same slots for every chunk of this block)
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int pc = tid + j * THREADS;
+      const int pix = pc >> 1;
+      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      if (pc < PIECES && !(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) {
+        *reinterpret_cast<f32x4*>(lds_in + pc * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+        *reinterpret_cast<f32x4*>(lds_in + IN_B + pc * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+    }
+  }
 
   if (nch > 0) {
     issue_weights(0, 0);
-    load_input(0);
+    stage_input(0);
     store_input(0);
   }
 
@@ -155,7 +185,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       issue_weights(ci + 1, cur ^ 1);
 #endif
 #ifndef SF_EXP_NOINPUT
-      load_input(ci + 1);
+      stage_input(ci + 1);
 #endif
     }
 #endif
