@@ -244,7 +244,7 @@ def main():
     ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm"])
     ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16"), choices=["bf16", "bf16a", "f32"],
+    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f32"],
                     help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default), the same with the MetNet "
                          "encoder's activations also STORED as bf16 (bf16a), or exact fp32 (parity mode)")
     args = ap.parse_args()
@@ -291,9 +291,18 @@ def main():
             "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else "samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6",
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": args.dtype, "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
+            "dtype": "f32" if args.dtype == "f32" else "bf16",
+            "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
             "config": wl.config(world), "final_loss": final_loss,
         }
+        out["config"]["arithmetic"] = {
+            "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",
+            "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 storage of all activations",
+            "bf16a": "bf16 MFMA operands, fp32 accumulate; MetNet image-encoder activations and their gradients stored as bf16 "
+                     "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers); parameters, ConvGRU, attention, "
+                     "loss and optimizer state fp32",
+        }[args.dtype]
+        out["config"]["mode"] = args.dtype
         out["roofline"] = wl.roofline()
         if not args.no_cpu_baseline and world == 1:
             out["cpu_baseline"] = wl.cpu_baseline()
