@@ -96,3 +96,43 @@ def test_product_never_imports_oracle():
             if f.endswith(".py"):
                 src = open(os.path.join(dirpath, f)).read()
                 assert not re.search(r"^\s*(from|import)\s+oracle\b", src, re.M), f"{f} imports the oracle"
+
+
+def test_tensor_descriptor_matches_header():
+    """ctypes `sfTensor` mirrors include/satflow_hip.h field for field (incl. the storage dtype), and `T()` fills byte offsets
+    and the storage type from the torch tensor."""
+    import ctypes as C
+    import re
+
+    import torch
+    from satflow_amd import _hip
+
+    hdr = open(os.path.join(ROOT, "include", "satflow_hip.h")).read()
+    body = re.search(r"typedef struct \{(.*?)\} sfTensor;", hdr, re.S).group(1)
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    fields = re.findall(r"(?:void\*|int32_t)\s+(\w+);", body)
+    assert fields == [f[0] for f in _hip.sfTensor._fields_], (fields, _hip.sfTensor._fields_)
+    assert C.sizeof(_hip.sfTensor) == 32  # 8-byte pointer + 5 x int32, padded to the pointer's alignment
+    a = torch.zeros(2, 3, 32, dtype=torch.float32)
+    b = torch.zeros(2, 3, 32, dtype=torch.bfloat16)
+    ta, tb = _hip.T(a, c=16, offset=16), _hip.T(b, c=16, offset=16)
+    assert (ta.dtype, tb.dtype) == (_hip.SF_F32, _hip.SF_BF16)
+    assert ta.ptr - a.data_ptr() == 64 and tb.ptr - b.data_ptr() == 32
+    assert (ta.c, ta.stride, tb.c, tb.stride) == (16, 32, 16, 32)
+
+
+def test_compute_modes():
+    import torch
+    import satflow_amd
+    from satflow_amd import _hip
+
+    try:
+        for name, (comp, enc) in {"f32": (_hip.SF_F32, torch.float32), "bf16": (_hip.SF_BF16, torch.float32),
+                                  "bf16a": (_hip.SF_BF16, torch.bfloat16)}.items():
+            satflow_amd.set_compute_dtype(name)
+            assert _hip.compute_dtype() == comp and _hip.encoder_storage_dtype() == enc and satflow_amd.compute_dtype_name() == name
+        import pytest
+        with pytest.raises(KeyError):
+            satflow_amd.set_compute_dtype("fp8")
+    finally:
+        satflow_amd.set_compute_dtype("f32")
