@@ -471,18 +471,38 @@ __global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const TA* __rest
   }
 }
 
-// dbase[f] = sum_l unpool(dpooled[l*F+f]);  partial class sums cls_part[block][l][cls][c] (2-stage reduce).
-// Persistent grid.  A thread owns ONE channel quad for the whole kernel and walks pooling windows, so the sums of the
-// interior border class (class 4: ~90 % of all windows) stay in registers for the first LEAD_REG lead times and reach
-// LDS once, at the end; only border windows (and lead times beyond LEAD_REG) use LDS atomics (ds_add_f32) per element.
+// dbase[f] = sum_l unpool(dpooled[l*F+f]);  class sums for the one-hot weight columns by a 2-stage reduce.
+// Two kernels:
+//  * the MAIN kernel (persistent grid) writes dbase for every window.  A thread owns ONE channel quad for the whole
+//    kernel and walks pooling windows; its class sums cover the INTERIOR class only (class 4: ~90 % of all windows, all
+//    four positions of the window share it), kept in registers for the first LEAD_REG lead times and flushed to LDS
+//    once at the end - the loop body has no divergent branch and no atomics.  Slab: main_part[block][L][C];
+//  * the BORDER kernel revisits only the windows that touch the image border, recomputes their argmax and adds the
+//    gradient to the class of the winning position with LDS atomics (ds_add_f32).  Slab: border_part[block][L][9][C].
+// Both request all lead times' gradients before using the first (12 independent HBM streams; a load under `l < L` is
+// emitted as load + vmcnt(0) one by one, hence the clamped unconditional form) and read the border table from LDS
+// when it fits next to the sums.
 constexpr int LEAD_REG = 12;
-template <typename TA>
+constexpr int LEADBIAS_BLOCKS = 512, LEADBIAS_BORDER_BLOCKS = 128;
+
+__device__ __forceinline__ int argmax4(float a0, float a1, float a2, float a3) {
+  int am = 0; float m = a0;  // first maximum in row-major window order, as max_pool2d
+  if (a1 > m) { m = a1; am = 1; }
+  if (a2 > m) { m = a2; am = 2; }
+  if (a3 > m) { m = a3; am = 3; }
+  return am;
+}
+
+template <typename TA, bool PLDS>
 __global__ __launch_bounds__(512) void leadbias_pool_bwd_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
-                                                                long long F, int H, int W, int C, int L, const float* __restrict__ ptab,
-                                                                TA* __restrict__ dbase, int dbs, float* __restrict__ cls_part) {
-  extern __shared__ float S[];  // [L][9][C]
-  const int nS = L * 9 * C;
+                                                               long long F, int H, int W, int C, int L, const float* __restrict__ ptab_g,
+                                                               TA* __restrict__ dbase, int dbs, float* __restrict__ main_part) {
+  extern __shared__ float S[];  // [L][C] interior-class sums (+ [L][9][C] table copy)
+  const int nS = L * C, nP = L * 9 * C;
   for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
+  if (PLDS)
+    for (int i = threadIdx.x; i < nP; i += blockDim.x) S[nS + i] = ptab_g[i];
+  const float* ptab = PLDS ? S + nS : ptab_g;
   __syncthreads();
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const int lanes = blockDim.x / q;  // windows in flight per block
@@ -499,43 +519,30 @@ __global__ __launch_bounds__(512) void leadbias_pool_bwd_kernel(const TA* __rest
       const long long b0 = (f * H + 2 * yo) * W + 2 * xo;
       const TA* p = base + b0 * bs + c;
       const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
-      int k[4];
-      k[0] = border_class(2 * yo, 2 * xo, H, W); k[1] = border_class(2 * yo, 2 * xo + 1, H, W);
-      k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
-      const bool interior = k[0] == 4 && k[3] == 4;
+      const int k0 = border_class(2 * yo, 2 * xo, H, W), k1 = border_class(2 * yo, 2 * xo + 1, H, W);
+      const int k2 = border_class(2 * yo + 1, 2 * xo, H, W), k3 = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+      const float interior = (k0 == 4 && k3 == 4) ? 1.f : 0.f;
       f32x4 g0 = {0.f, 0.f, 0.f, 0.f}, g1 = g0, g2 = g0, g3 = g0;
-      auto lead = [&](int l, f32x4& reg_sum, bool use_reg) {
+      auto lead = [&](int l, f32x4 g) -> f32x4 {
         const float* pt = ptab + (size_t)l * 9 * C + c;
-        f32x4 a0, a1, a2, a3;
-        if (interior) {  // all four positions share one table row: one load instead of four, same sums
-          const f32x4 t = ld4(pt + 4 * C);
-          a0 = v0 + t; a1 = v1 + t; a2 = v2 + t; a3 = v3 + t;
-        } else {
-          a0 = v0 + ld4(pt + k[0] * C); a1 = v1 + ld4(pt + k[1] * C); a2 = v2 + ld4(pt + k[2] * C); a3 = v3 + ld4(pt + k[3] * C);
-        }
-        const f32x4 g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
-        float* Sl = S + (size_t)l * 9 * C + c;
+        const f32x4 a0 = v0 + ld4(pt + k0 * C), a1 = v1 + ld4(pt + k1 * C), a2 = v2 + ld4(pt + k2 * C), a3 = v3 + ld4(pt + k3 * C);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          int am = 0; float m = a0[j];  // first maximum in row-major window order, as max_pool2d
-          if (a1[j] > m) { m = a1[j]; am = 1; }
-          if (a2[j] > m) { m = a2[j]; am = 2; }
-          if (a3[j] > m) { m = a3[j]; am = 3; }
+          const int am = argmax4(a0[j], a1[j], a2[j], a3[j]);
           g0[j] += am == 0 ? g[j] : 0.f; g1[j] += am == 1 ? g[j] : 0.f; g2[j] += am == 2 ? g[j] : 0.f; g3[j] += am == 3 ? g[j] : 0.f;
-          if (!interior) atomicAdd(Sl + k[am] * C + j, g[j]);
         }
-        if (interior) {
-          if (use_reg) reg_sum += g;
-          else {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) atomicAdd(Sl + 4 * C + j, g[j]);
-          }
-        }
+        return g * interior;
       };
+      f32x4 gl[LEAD_REG];
 #pragma unroll
-      for (int l = 0; l < LEAD_REG; ++l)
-        if (l < L) lead(l, s4[l], true);
-      for (int l = LEAD_REG; l < L; ++l) { f32x4 unused; lead(l, unused, false); }
+      for (int l = 0; l < LEAD_REG; ++l) gl[l] = ldv4(dout + ((((l < L ? l : 0) * F + f) * Ho + yo) * Wo + xo) * dos + c);
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l) s4[l] += lead(l < L ? l : 0, l < L ? gl[l] : f32x4{0.f, 0.f, 0.f, 0.f});
+      for (int l = LEAD_REG; l < L; ++l) {
+        const f32x4 gi = lead(l, ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c));
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(S + (size_t)l * C + c + j, gi[j]);
+      }
       TA* d = dbase + b0 * dbs + c;
       stv4(d, g0); stv4(d + dbs, g1); stv4(d + (long long)W * dbs, g2); stv4(d + (long long)W * dbs + dbs, g3);
     }
@@ -543,20 +550,133 @@ __global__ __launch_bounds__(512) void leadbias_pool_bwd_kernel(const TA* __rest
   for (int l = 0; l < LEAD_REG; ++l)
     if (l < L && wl < lanes) {
 #pragma unroll
-      for (int j = 0; j < 4; ++j) atomicAdd(S + ((size_t)l * 9 + 4) * C + c + j, s4[l][j]);
+      for (int j = 0; j < 4; ++j) atomicAdd(S + (size_t)l * C + c + j, s4[l][j]);
     }
   __syncthreads();
-  float* dstp = cls_part + (size_t)blockIdx.x * nS;
+  float* dstp = main_part + (size_t)blockIdx.x * nS;
   for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
 }
 
-// stage 1: cls_sum[l][cls][c] = sum over blocks of cls_part[block][l][cls][c]   (coalesced along c)
-__global__ void leadbias_reduce_kernel(const float* __restrict__ cls_part, int nblocks, int n, float* __restrict__ cls_sum) {
-  const int i = blockIdx.x * blockDim.x + threadIdx.x;
-  if (i >= n) return;
+// Border windows.  Blocks take roles: 4 x EDGE blocks (top / bottom / left / right edge without the corners: the two
+// positions on the image border share one class, the two inner ones are class 4, so two register sums per lead time
+// suffice and the loop is atomics-free like the main kernel's) and the last LEADBIAS_CORNER_BLOCKS blocks for the corner
+// windows (4 classes; LDS atomics) - or for every border window when the image is too small to have plain edges.
+constexpr int LEADBIAS_CORNER_BLOCKS = 8;
+template <typename TA, bool PLDS>
+__global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
+                                                             long long F, int H, int W, int C, int L, const float* __restrict__ ptab_g,
+                                                             float* __restrict__ border_part) {
+  extern __shared__ float S[];  // [L][9][C] (+ table copy)
+  const int nS = L * 9 * C;
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
+  if (PLDS)
+    for (int i = threadIdx.x; i < nS; i += blockDim.x) S[nS + i] = ptab_g[i];
+  const float* ptab = PLDS ? S + nS : ptab_g;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const int lanes = blockDim.x / q;
+  const int cq = threadIdx.x % q, wl = threadIdx.x / q;
+  const int c = cq * 4;
+  const bool edges = Ho >= 3 && Wo >= 3 && L <= LEAD_REG;
+  const int edge_blocks = ((int)gridDim.x - LEADBIAS_CORNER_BLOCKS) / 4;  // per edge type
+  const int role = (int)blockIdx.x < 4 * edge_blocks ? (int)blockIdx.x / edge_blocks : 4;
+  auto window = [&](long long f, int yo, int xo, f32x4 (&v)[4], int (&k)[4]) {
+    const TA* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
+    v[0] = ldv4(p); v[1] = ldv4(p + bs); v[2] = ldv4(p + (long long)W * bs); v[3] = ldv4(p + (long long)W * bs + bs);
+    k[0] = border_class(2 * yo, 2 * xo, H, W); k[1] = border_class(2 * yo, 2 * xo + 1, H, W);
+    k[2] = border_class(2 * yo + 1, 2 * xo, H, W); k[3] = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+  };
+  if (role < 4) {
+    if (edges && wl < lanes) {
+      const int n_t = role < 2 ? Wo - 2 : Ho - 2;                       // edge windows of this type per frame
+      const int outer_mask = role == 0 ? 0x3 : role == 1 ? 0xC : role == 2 ? 0x5 : 0xA;  // positions on the image border
+      const int ko = role == 0 ? 1 : role == 1 ? 7 : role == 2 ? 3 : 5;  // their class; the inner positions are class 4
+      f32x4 so[LEAD_REG], si[LEAD_REG];
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l) so[l] = si[l] = f32x4{0.f, 0.f, 0.f, 0.f};
+      const long long total = F * n_t;
+      for (long long e = (long long)(blockIdx.x - role * edge_blocks) * lanes + wl; e < total; e += (long long)edge_blocks * lanes) {
+        const long long f = e / n_t;
+        const int i = 1 + (int)(e - f * n_t);
+        const int yo = role == 0 ? 0 : role == 1 ? Ho - 1 : i, xo = role == 2 ? 0 : role == 3 ? Wo - 1 : i;
+        f32x4 v[4]; int k[4];
+        window(f, yo, xo, v, k);
+        f32x4 gl[LEAD_REG];
+#pragma unroll
+        for (int l = 0; l < LEAD_REG; ++l) gl[l] = ldv4(dout + ((((l < L ? l : 0) * F + f) * Ho + yo) * Wo + xo) * dos + c);
+#pragma unroll
+        for (int l = 0; l < LEAD_REG; ++l) {
+          const float* pt = ptab + (size_t)(l < L ? l : 0) * 9 * C + c;
+          const f32x4 a0 = v[0] + ld4(pt + k[0] * C), a1 = v[1] + ld4(pt + k[1] * C), a2 = v[2] + ld4(pt + k[2] * C), a3 = v[3] + ld4(pt + k[3] * C);
+          const f32x4 g = l < L ? gl[l] : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const bool outer = (outer_mask >> argmax4(a0[j], a1[j], a2[j], a3[j])) & 1;
+            so[l][j] += outer ? g[j] : 0.f; si[l][j] += outer ? 0.f : g[j];
+          }
+        }
+      }
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l)
+        if (l < L) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            atomicAdd(S + ((size_t)l * 9 + ko) * C + c + j, so[l][j]);
+            atomicAdd(S + ((size_t)l * 9 + 4) * C + c + j, si[l][j]);
+          }
+        }
+    }
+  } else if (wl < lanes) {
+    // corners (or, without plain edges, every border window: top row, bottom row, then left / right of the rows between)
+    const int per_frame = edges ? 4 : (Ho > 1 ? 2 * Wo : Wo) + (Ho > 2 ? (Wo > 1 ? 2 : 1) * (Ho - 2) : 0);
+    const long long total = F * per_frame;
+    const int cb = (int)blockIdx.x - 4 * edge_blocks, ncb = (int)gridDim.x - 4 * edge_blocks;
+    for (long long bw = (long long)cb * lanes + wl; bw < total; bw += (long long)ncb * lanes) {
+      const long long f = bw / per_frame;
+      int r = (int)(bw - f * per_frame), yo, xo;
+      if (edges) { yo = (r & 2) ? Ho - 1 : 0; xo = (r & 1) ? Wo - 1 : 0; }
+      else if (r < Wo) { yo = 0; xo = r; }
+      else if (Ho > 1 && r < 2 * Wo) { yo = Ho - 1; xo = r - Wo; }
+      else { r -= 2 * Wo; const int per_row = Wo > 1 ? 2 : 1; yo = 1 + r / per_row; xo = (r % per_row) ? Wo - 1 : 0; }
+      f32x4 v[4]; int k[4];
+      window(f, yo, xo, v, k);
+      for (int l = 0; l < L; ++l) {
+        const float* pt = ptab + (size_t)l * 9 * C + c;
+        const f32x4 a0 = v[0] + ld4(pt + k[0] * C), a1 = v[1] + ld4(pt + k[1] * C), a2 = v[2] + ld4(pt + k[2] * C), a3 = v[3] + ld4(pt + k[3] * C);
+        const f32x4 g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
+        float* Sl = S + (size_t)l * 9 * C + c;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) atomicAdd(Sl + k[argmax4(a0[j], a1[j], a2[j], a3[j])] * C + j, g[j]);
+      }
+    }
+  }
+  __syncthreads();
+  float* dstp = border_part + (size_t)blockIdx.x * nS;
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
+}
+
+// stage 1: cls_sum[l][cls][c] = sum of the border slabs (+ the main slabs for the interior class).  grid (ceil(n/64), 1),
+// block (64, 8): 8 slab groups per element, combined through LDS.
+__global__ __launch_bounds__(512) void leadbias_reduce_kernel(const float* __restrict__ main_part, int nmain, const float* __restrict__ border_part,
+                                                             int nborder, int L, int C, float* __restrict__ cls_sum) {
+  __shared__ float red[8][64];
+  const int n = L * 9 * C;
+  const int i = blockIdx.x * 64 + threadIdx.x, grp = threadIdx.y;
   float a = 0.f;
-  for (int b = 0; b < nblocks; ++b) a += cls_part[(size_t)b * n + i];
-  cls_sum[i] = a;
+  if (i < n) {
+    for (int b = grp; b < nborder; b += 8) a += border_part[(size_t)b * n + i];
+    const int c = i % C, cls = (i / C) % 9, l = i / (9 * C);
+    if (cls == 4)
+      for (int b = grp; b < nmain; b += 8) a += main_part[((size_t)b * L + l) * C + c];
+  }
+  red[grp][threadIdx.x] = a;
+  __syncthreads();
+  if (grp == 0 && i < n) {
+    float t = 0.f;
+#pragma unroll
+    for (int g = 0; g < 8; ++g) t += red[g][threadIdx.x];
+    cls_sum[i] = t;
+  }
 }
 
 // stage 2: dw1[co][cimg + l][ky][kx] = sum over the border classes for which that tap lies inside the image
@@ -581,13 +701,12 @@ __global__ void leadbias_wgrad_kernel(const float* __restrict__ cls_sum, int L, 
     }
 }
 
-constexpr int LEADBIAS_BLOCKS = 512;
 
 }  // namespace
 
 extern "C" {
 
-size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C) { return (size_t)L * 9 * C * (2 + LEADBIAS_BLOCKS); }
+size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C) { return (size_t)L * 9 * C * (2 + LEADBIAS_BORDER_BLOCKS) + (size_t)L * C * LEADBIAS_BLOCKS; }
 
 int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I, int32_t cimg,
                          int32_t L, float* workspace, sfTensor out, int32_t dtype, sfStream stream) {
@@ -618,17 +737,39 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
   SF_CHECK_LAUNCH("leadbias_table");
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<__bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_border_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_border_kernel<__bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_border_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_border_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  float* cls_part = workspace + nt;
-  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(512), (size_t)nt * sizeof(float), st,
-                                                 (const TA*)base.ptr, base.stride, (const TA*)dout.ptr, dout.stride, (long long)frames, h, w, C, L,
-                                                 (const float*)workspace, (TA*)dbase.ptr, dbase.stride, cls_part));
+  // workspace: [table nt][border slabs 128 x nt][main slabs 512 x L*C][cls_sum nt]
+  float* border_part = workspace + nt;
+  float* main_part = border_part + (size_t)LEADBIAS_BORDER_BLOCKS * nt;
+  float* cls_sum = main_part + (size_t)LEADBIAS_BLOCKS * L * C;
+  const size_t f4 = sizeof(float), lds_main = (size_t)L * C * f4, lds_border = (size_t)nt * f4, lds_tab = (size_t)nt * f4;
+#define SF_LB_ARGS (const TA*)base.ptr, base.stride, (const TA*)dout.ptr, dout.stride, (long long)frames, h, w, C, L, (const float*)workspace
+  if (lds_main + lds_tab <= 160 * 1024)
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA, true>), dim3(LEADBIAS_BLOCKS), dim3(512), lds_main + lds_tab, st,
+                                                   SF_LB_ARGS, (TA*)dbase.ptr, dbase.stride, main_part));
+  else
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA, false>), dim3(LEADBIAS_BLOCKS), dim3(512), lds_main, st,
+                                                   SF_LB_ARGS, (TA*)dbase.ptr, dbase.stride, main_part));
   SF_CHECK_LAUNCH("leadbias_pool_bwd");
-  float* cls_sum = cls_part + (size_t)LEADBIAS_BLOCKS * nt;
-  hipLaunchKernelGGL(leadbias_reduce_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, cls_part, LEADBIAS_BLOCKS, nt, cls_sum);
+  if (lds_border + lds_tab <= 160 * 1024)
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, true>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(256), lds_border + lds_tab, st,
+                                                   SF_LB_ARGS, border_part));
+  else
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, false>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(256), lds_border, st,
+                                                   SF_LB_ARGS, border_part));
+#undef SF_LB_ARGS
+  SF_CHECK_LAUNCH("leadbias_border");
+  hipLaunchKernelGGL(leadbias_reduce_kernel, dim3((nt + 63) / 64), dim3(64, 8), 0, st, main_part, LEADBIAS_BLOCKS, border_part, LEADBIAS_BORDER_BLOCKS, L,
+                     C, cls_sum);
   SF_CHECK_LAUNCH("leadbias_reduce");
   hipLaunchKernelGGL(leadbias_wgrad_kernel, dim3((L * O + 127) / 128), dim3(128), 0, st, cls_sum, L, C, O, I, cimg, dw1);
   SF_CHECK_LAUNCH("leadbias_wgrad");
