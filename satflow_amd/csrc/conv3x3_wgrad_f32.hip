@@ -117,8 +117,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
     if (co < Np && ci < Kp) {
       const int o = nmap[co], i = kmap[ci];
       if (o >= 0 && i >= 0) {
-        float s = 0.f;
-        for (int k = 0; k < KS; ++k) s += partial[k * slab + gid];
+        // 8 independent partial sums: 8 slab reads in flight instead of a load -> wait -> add chain (fixed order: deterministic)
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int k = 0;
+        for (; k + 8 <= KS; k += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) s8[u] += partial[(size_t)(k + u) * slab + gid];
+        }
+        for (; k < KS; ++k) s8[0] += partial[(size_t)k * slab + gid];
+        const float s = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
         float* d = dw + ((size_t)o * I + i) * 9 + tap;
         *d = accumulate ? *d + s : s;
       }

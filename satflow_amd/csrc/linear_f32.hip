@@ -106,9 +106,14 @@ __global__ void linear_wgrad_reduce_kernel(const float* __restrict__ partial, co
   if (gid < slab) {
     const int k = gid % Kpad, n = gid / Kpad;
     if (n < N && k < K) {
-      float s = 0.f;
-      for (int i = 0; i < KS; ++i) s += partial[i * slab + gid];
-      dW[(size_t)n * K + k] = s;
+      float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};  // 8 slab reads in flight (fixed order: deterministic)
+      int i = 0;
+      for (; i + 8 <= KS; i += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) s8[u] += partial[(size_t)(i + u) * slab + gid];
+      }
+      for (; i < KS; ++i) s8[0] += partial[(size_t)i * slab + gid];
+      dW[(size_t)n * K + k] = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
     }
   }
   if (db && gid < (size_t)N) {

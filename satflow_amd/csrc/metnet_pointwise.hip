@@ -446,9 +446,15 @@ __global__ void leadbias_table_kernel(const float* __restrict__ w1, int O, int I
 }
 
 // pooled[(l*F + f)][yo][xo][c] = max over the 2x2 window of base[f] + ptab[l][class]
-template <typename TA>
-__global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const TA* __restrict__ base, int bs, long long F, int H, int W, int C,
-                                                                int L, const float* __restrict__ ptab, TA* __restrict__ out, int os) {
+template <typename TA, bool PLDS>  // PLDS: border table staged in LDS (no global loads inside the lead-time loop, only stores)
+__global__ __launch_bounds__(1024) void leadbias_pool_fwd_kernel(const TA* __restrict__ base, int bs, long long F, int H, int W, int C,
+                                                                 int L, const float* __restrict__ ptab_g, TA* __restrict__ out, int os) {
+  extern __shared__ float P[];
+  if (PLDS) {
+    for (int i = threadIdx.x; i < L * 9 * C; i += blockDim.x) P[i] = ptab_g[i];
+    __syncthreads();
+  }
+  const float* ptab = PLDS ? P : ptab_g;
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const long long total = F * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -460,6 +466,7 @@ __global__ __launch_bounds__(256) void leadbias_pool_fwd_kernel(const TA* __rest
     const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
     const int k0 = border_class(2 * yo, 2 * xo, H, W), k1 = border_class(2 * yo, 2 * xo + 1, H, W);
     const int k2 = border_class(2 * yo + 1, 2 * xo, H, W), k3 = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+#pragma unroll 4
     for (int l = 0; l < L; ++l) {
       const float* pt = ptab + (size_t)l * 9 * C + c;
       const f32x4 a0 = v0 + ld4(pt + k0 * C), a1 = v1 + ld4(pt + k1 * C), a2 = v2 + ld4(pt + k2 * C), a3 = v3 + ld4(pt + k3 * C);
@@ -719,8 +726,21 @@ int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, co
   SF_CHECK_LAUNCH("leadbias_table");
   const long long total = frames * (h / 2) * (w / 2) * (C / 4);
   if (total == 0) return 0;
-  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_kernel<TA>), dim3(grid_for(total)), dim3(256), 0, st, (const TA*)base.ptr, base.stride,
-                                                 (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride));
+  const size_t tab_bytes = (size_t)nt * sizeof(float);
+  const int blocks = (int)((total + 1023) / 1024 < 512 ? (total + 1023) / 1024 : 512);
+  if (tab_bytes <= 76 * 1024) {  // two 1024-thread workgroups per CU keep their copies of the table
+    static bool attr_set = false;
+    if (!attr_set) {
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024);
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 76 * 1024);
+      attr_set = true;
+    }
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_kernel<TA, true>), dim3(blocks), dim3(1024), tab_bytes, st, (const TA*)base.ptr,
+                                                   base.stride, (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride));
+  } else {
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_kernel<TA, false>), dim3(blocks), dim3(1024), 0, st, (const TA*)base.ptr,
+                                                   base.stride, (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride));
+  }
   SF_CHECK_LAUNCH("leadbias_pool_fwd");
   return 0;
 }
