@@ -123,7 +123,7 @@ __global__ __launch_bounds__(256) void attn_bwd_kernel(const AttnParams p) {
 }
 
 
-// Backward, block-per-image form: one thread per pixel, loop over (axis, head).  Each thread computes ITS query row's
+// Backward, block per (image, axis, head): one thread per pixel.  Each thread computes ITS query row's
 // softmax P and dS once, parks both rows in LDS, and after a barrier gathers the columns it needs as key/value
 // position - L x less arithmetic than the gather-from-scratch kernel above (which stays as the fallback for
 // images with more than 1024 pixels).  Deterministic (no atomics).
@@ -139,7 +139,8 @@ __global__ void attn_bwd_block_kernel(const AttnParams p) {
   const bool live = t < npix;
   const int x = live ? t % p.W : 0, y = live ? t / p.W : 0;
   const long long pix = img * npix + t;
-  for (int ah = 0; ah < 2 * p.heads; ++ah) {
+  {
+    const int ah = blockIdx.y;  // (axis, head) pairs are independent: 2*heads workgroups per image instead of a serial loop
     const int axis = ah / p.heads, head = ah % p.heads;
     const Line ln = line_of(img, y, x, axis, p.H, p.W);
     const int off = axis * 3 * p.hidp + head * e;
@@ -187,7 +188,6 @@ __global__ void attn_bwd_block_kernel(const AttnParams p) {
       float* d = p.dqkv + pix * p.dqs + off;
       for (int j = 0; j < e; ++j) { d[p.hidp + j] = dk[j]; d[2 * p.hidp + j] = dv[j]; }
     }
-    __syncthreads();
   }
 }
 
@@ -245,7 +245,7 @@ int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32
     const int LS = (h > w ? h : w) + 1;
     const size_t shmem = (size_t)2 * npix * LS * sizeof(float);
     if (shmem > 64 * 1024) (void)hipFuncSetAttribute((const void*)attn_bwd_block_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-    hipLaunchKernelGGL(attn_bwd_block_kernel, dim3((unsigned)nimg), dim3(threads), shmem, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(attn_bwd_block_kernel, dim3((unsigned)nimg, 2 * heads), dim3(threads), shmem, (hipStream_t)stream, p);
   } else {
     hipLaunchKernelGGL(attn_bwd_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p);
   }
