@@ -326,3 +326,30 @@ def test_dropout2_kernel(device):
     # backward applies the very same mask
     y.sum().backward()
     assert torch.equal(x.grad, y.detach())
+
+
+@pytest.mark.parametrize("Fr,S,O,cimg,L", [(3, 12, 28, 20, 5), (2, 4, 16, 8, 3), (2, 6, 20, 4, 14), (1, 2, 8, 4, 2), (2, 8, 160, 96, 12), (1, 6, 12, 4, 26)])
+def test_leadtime_pool_vs_oracle(device, Fr, S, O, cimg, L):
+    """`sf_leadtime_pool_fwd/bwd` = ConditionTime planes + the one-hot columns of conv1 + the first max-pool, for all lead
+    times at once - against conv2d on the materialised one-hot planes (reference layers/ConditionTime.py:22-33) followed by
+    max_pool2d.  Covers: more lead times than the kernels keep in registers, images whose windows all touch the border
+    (S = 2, 4), three-window-wide images (S = 6: one interior window), the BASELINE channel count."""
+    from satflow_amd.functional import leadtime_pool, nchw_to_nhwc, nhwc_to_nchw
+
+    g = _g(Fr * 100 + S * 10 + L)
+    base = torch.randn(Fr, O, S, S, generator=g)
+    w1 = torch.randn(O, cimg + L, 3, 3, generator=g) * 0.5
+    cot = torch.randn(L * Fr, O, S // 2, S // 2, generator=g)
+    br, wr = base.clone().requires_grad_(), w1.clone().requires_grad_()
+    planes = torch.eye(L).view(L, L, 1, 1).expand(L, L, S, S)                      # plane l of lead time l is all ones
+    P = TF.conv2d(planes, wr[:, cimg:], None, padding=1)                            # [L, O, S, S]
+    ref = TF.max_pool2d((br.unsqueeze(0) + P.unsqueeze(1)).reshape(L * Fr, O, S, S), 2)
+    (ref * cot).sum().backward()
+    bd = nchw_to_nhwc(base.to(device)).requires_grad_()
+    wd = w1.to(device).requires_grad_()
+    out = leadtime_pool(bd, wd, cimg, L)
+    assert_close(nhwc_to_nchw(out, O), ref, "lead-time pooling")
+    (nhwc_to_nchw(out, O) * cot.to(device)).sum().backward()
+    assert_close(nhwc_to_nchw(bd.grad, O), br.grad, "d(base)", grad=True)
+    assert_close(wd.grad[:, cimg:], wr.grad[:, cimg:], "dW1 one-hot columns", grad=True)
+    assert float(wd.grad[:, :cimg].abs().max()) == 0.0  # the image columns get their gradient from the convolution itself
