@@ -176,6 +176,16 @@ int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, 
                     int32_t perm_t, int32_t dtype, sfStream stream);
 int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din,
                     int32_t perm_l, int32_t perm_t, int32_t dtype, sfStream stream);
+/* The encoder's LAST max-pool fused with the dropouts that follow it in MetNet (nn.Dropout(temporal_dropout),
+ * pl_metnet.py:58, and the ConvGRU's sequence-consistent input dropout): out = sf_dropout2(maxpool(in)) with the masks
+ * of sf_dropout2 for the same (p1, p2, period, seeds), indexed by the flat element index of the contiguous pooled tensor;
+ * the backward masks the incoming gradient the same way before routing it.  `period` must be a whole number of pooled images. */
+int sf_maxpool2_dropout_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t,
+                            float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype,
+                            sfStream stream);
+int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l,
+                            int32_t perm_t, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
+                            int32_t dtype, sfStream stream);
 
 /* nn.BatchNorm2d of the DownSampler.  Training mode: `groups` independent batches of
  * pix_per_group pixels each (one per lead time: the reference calls the encoder once per lead
@@ -253,8 +263,8 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
 
 /* Fused dropouts of the MetNet encoder output: y = x * m1(i) * m2(i % period) with keep-scaling; m1 = nn.Dropout(
  * temporal_dropout) (pl_metnet.py:58), m2 = the ConvGRU's sequence-consistent input dropout (time-major layout, period =
- * elements of one timestep).  Masks are a counter-based hash of (seed, index): the backward calls the same function on the
- * gradient with the same seeds. */
+ * elements of one timestep, a multiple of 4).  Masks are a counter-based hash of (seed, index / 4) giving four 16-bit uniforms per
+ * channel quad: the backward calls the same function on the gradient with the same seeds. */
 int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
                 float* y, sfStream stream);
 

@@ -57,36 +57,14 @@ __global__ void mse_finalize_kernel(const double* __restrict__ sums, long long n
   if (i < frames) out[1 + i] = (float)(sums[1 + i] / ((double)n / frames));
 }
 
-__device__ __forceinline__ unsigned mix(unsigned long long x) {
-  // splitmix64 finaliser
-  x += 0x9E3779B97F4A7C15ull;
-  x = (x ^ (x >> 30)) * 0xBF58476D1CE4E5B9ull;
-  x = (x ^ (x >> 27)) * 0x94D049BB133111EBull;
-  x ^= x >> 31;
-  return (unsigned)(x >> 32);
-}
-__device__ __forceinline__ float keep_scale(unsigned long long seed, unsigned long long idx, float p, float inv_keep) {
-  // uniform in [0,1) from the top 24 bits
-  const float u = (float)(mix(seed ^ (idx * 0xD6E8FEB86659FD93ull)) >> 8) * (1.0f / 16777216.0f);
-  return u < p ? 0.f : inv_keep;
-}
-
-// y = x * m1(idx) * m2(idx % period); either probability may be 0 (mask == 1)
-__global__ __launch_bounds__(256) void dropout2_kernel(const float* __restrict__ x, long long n, float p1, float p2, long long period,
-                                                       unsigned long long seed1, unsigned long long seed2, float* __restrict__ y) {
-  const float k1 = p1 > 0.f ? 1.f / (1.f - p1) : 1.f, k2 = p2 > 0.f ? 1.f / (1.f - p2) : 1.f;
-  const long long n4 = n >> 2;
+// y = x * m1(idx) * m2(idx % period); either probability may be 0 (mask == 1).  Masks: sf_drop_scales (sf_common.h), the same
+// function the fused max-pool kernels use.
+__global__ __launch_bounds__(256) void dropout2_kernel(const float* __restrict__ x, long long n, const sfDrop d, long long period,
+                                                       float* __restrict__ y) {
+  const long long n4 = n >> 2, per4 = period >> 2;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (long long)gridDim.x * blockDim.x) {
-    f32x4 v = ld4(x + i * 4);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const unsigned long long idx = (unsigned long long)(i * 4 + j);
-      float s = 1.f;
-      if (p1 > 0.f) s *= keep_scale(seed1, idx, p1, k1);
-      if (p2 > 0.f) s *= keep_scale(seed2, idx % (unsigned long long)period, p2, k2);
-      v[j] *= s;
-    }
-    st4(y + i * 4, v);
+    const f32x4 sc = sf_drop_scales(d, (unsigned long long)i, (unsigned long long)(d.p2 > 0.f ? i % per4 : 0));
+    st4(y + i * 4, ld4(x + i * 4) * sc);
   }
 }
 
@@ -112,13 +90,13 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
 
 int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, float* y,
                 sfStream stream) {
-  SF_REQUIRE(n % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && period > 0,
-             "dropout2: n=%lld p1=%f p2=%f period=%lld", (long long)n, p1, p2, (long long)period);
+  SF_REQUIRE(n % 4 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && period > 0 &&
+                 period % 4 == 0, "dropout2: n=%lld p1=%f p2=%f period=%lld (n and period must be multiples of 4)", (long long)n, p1, p2, (long long)period);
   if (n == 0) return 0;
   const long long n4 = n >> 2;
   const int blocks = (int)((n4 + 255) / 256 < 16384 ? (n4 + 255) / 256 : 16384);
-  hipLaunchKernelGGL(dropout2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, p1, p2, (long long)period,
-                     (unsigned long long)seed1, (unsigned long long)seed2, y);
+  hipLaunchKernelGGL(dropout2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, sf_make_drop(p1, p2, seed1, seed2),
+                     (long long)period, y);
   SF_CHECK_LAUNCH("dropout2");
   return 0;
 }

@@ -77,9 +77,11 @@ __device__ __forceinline__ long long perm_image(long long n, const OuterPerm& pm
   return (t * pm.L + l) * pm.B + b;
 }
 
-template <typename TI, typename TO>
+// DROP: the encoder-output dropouts (sf_dropout2's masks, indexed by the flat element index of the contiguous pooled tensor;
+// npt = pooled images per timestep for the period-reduced index of the sequence-consistent mask) applied on the way out
+template <typename TI, typename TO, bool DROP>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__ in, int is, long long N, int H, int W, int C,
-                                                          TO* __restrict__ out, int os, const OuterPerm pm) {
+                                                          TO* __restrict__ out, int os, const OuterPerm pm, const sfDrop dr, long long npt) {
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -92,14 +94,19 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__
     const f32x4 v1 = ldv4(p + is), v2 = ldv4(p + (long long)W * is), v3 = ldv4(p + (long long)W * is + is);
 #pragma unroll
     for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
-    stv4(out + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * os + c, m);
+    const long long no = perm_image(n, pm);
+    if constexpr (DROP) {
+      const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * q + c / 4), imgq = (unsigned long long)Ho * Wo * q;
+      m = m * sf_drop_scales(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
+    }
+    stv4(out + ((no * Ho + yo) * Wo + xo) * os + c, m);
   }
 }
 
-template <typename TI, typename TO>  // TI: input and its gradient, TO: pooled output's gradient
+template <typename TI, typename TO, bool DROP>  // TI: input and its gradient, TO: pooled output's gradient
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__ in, int is, const TO* __restrict__ dout, int dos,
                                                           long long N, int H, int W, int C, TI* __restrict__ din, int dis,
-                                                          const OuterPerm pm) {
+                                                          const OuterPerm pm, const sfDrop dr, long long npt) {
   const int Ho = H / 2, Wo = W / 2, q = C / 4;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -110,7 +117,12 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
     const long long base = (n * H + 2 * yo) * W + 2 * xo;
     const TI* p = in + base * is + c;
     const f32x4 v0 = ldv4(p), v1 = ldv4(p + is), v2 = ldv4(p + (long long)W * is), v3 = ldv4(p + (long long)W * is + is);
-    const f32x4 g = ldv4(dout + ((perm_image(n, pm) * Ho + yo) * Wo + xo) * dos + c);
+    const long long no = perm_image(n, pm);
+    f32x4 g = ldv4(dout + ((no * Ho + yo) * Wo + xo) * dos + c);
+    if constexpr (DROP) {
+      const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * q + c / 4), imgq = (unsigned long long)Ho * Wo * q;
+      g = g * sf_drop_scales(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
+    }
     f32x4 g0, g1, g2, g3;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
@@ -283,10 +295,13 @@ int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C,
   return 0;
 }
 
-int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, int32_t dtype,
-                    sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_fwd: dtype %d not built", dtype);
-  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == out.c && ok4(in) && ok4(out), "maxpool2: needs even H,W and matching 4-aligned channels");
+static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
+                          const sfDrop* drop, int64_t period, hipStream_t st) {
+  sfTensor& out = dout_or_out;
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == out.c && ok4(in) && ok4(out) && (!bwd || (in.c == din.c && ok4(din))),
+             "maxpool2: needs even H,W and matching 4-aligned channels");
+  SF_REQUIRE(in.dtype == out.dtype || (in.dtype == SF_BF16 && out.dtype == SF_F32), "maxpool2: unsupported storage pair %d -> %d", in.dtype, out.dtype);
+  SF_REQUIRE(!bwd || in.dtype == din.dtype, "maxpool2 bwd: din must be stored like the input");
   OuterPerm pm{0, 0, 0};
   if (perm_l > 0) {
     SF_REQUIRE(perm_t > 0 && n % ((long long)perm_l * perm_t) == 0, "maxpool2: n=%lld not divisible by perm dims %d x %d", (long long)n, perm_l, perm_t);
@@ -294,40 +309,66 @@ int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, 
   }
   const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
   if (total == 0) return 0;
-  SF_REQUIRE(in.dtype == out.dtype || (in.dtype == SF_BF16 && out.dtype == SF_F32), "maxpool2: unsupported storage pair %d -> %d", in.dtype, out.dtype);
-#define SF_MP_FWD(TI_, TO_)                                                                                                               \
-  hipLaunchKernelGGL((maxpool_fwd_kernel<TI_, TO_>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI_*)in.ptr, in.stride, \
-                     (long long)n, h, w, in.c, (TO_*)out.ptr, out.stride, pm)
-  if (in.dtype == SF_F32) SF_MP_FWD(float, float);
-  else if (out.dtype == SF_BF16) SF_MP_FWD(__bf16, __bf16);
-  else SF_MP_FWD(__bf16, float);
-#undef SF_MP_FWD
-  SF_CHECK_LAUNCH("maxpool2_fwd");
+  sfDrop dr{};
+  long long npt = 1;
+  if (drop) {
+    dr = *drop;
+    const long long img = (long long)(h / 2) * (w / 2) * out.c;
+    SF_REQUIRE(out.stride == out.c && period > 0 && period % img == 0, "maxpool2+dropout: the pooled tensor must be contiguous and the period (%lld) a whole number of images", (long long)period);
+    npt = period / img;
+  }
+  const dim3 grid(grid_for(total)), block(256);
+#define SF_MP(TI_, TO_, DROP_)                                                                                                                   \
+  do {                                                                                                                                            \
+    if (bwd) hipLaunchKernelGGL((maxpool_bwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (const TO_*)out.ptr,   \
+                                out.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm, dr, npt);                                    \
+    else hipLaunchKernelGGL((maxpool_fwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (long long)n, h, w, in.c,   \
+                            (TO_*)out.ptr, out.stride, pm, dr, npt);                                                                              \
+  } while (0)
+#define SF_MP_T(DROP_)                                         \
+  do {                                                         \
+    if (in.dtype == SF_F32) SF_MP(float, float, DROP_);        \
+    else if (out.dtype == SF_BF16) SF_MP(__bf16, __bf16, DROP_); \
+    else SF_MP(__bf16, float, DROP_);                          \
+  } while (0)
+  if (drop) SF_MP_T(true); else SF_MP_T(false);
+#undef SF_MP_T
+#undef SF_MP
+  SF_CHECK_LAUNCH(bwd ? "maxpool2_bwd" : "maxpool2_fwd");
   return 0;
+}
+
+int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, int32_t dtype,
+                    sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_fwd: dtype %d not built", dtype);
+  return maxpool_launch(false, in, out, n, h, w, sfTensor{}, perm_l, perm_t, nullptr, 0, (hipStream_t)stream);
 }
 
 int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
                     int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_bwd: dtype %d not built", dtype);
-  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == dout.c && in.c == din.c && ok4(in) && ok4(dout) && ok4(din), "maxpool2 bwd: shape/alignment");
-  OuterPerm pm{0, 0, 0};
-  if (perm_l > 0) {
-    SF_REQUIRE(perm_t > 0 && n % ((long long)perm_l * perm_t) == 0, "maxpool2: n=%lld not divisible by perm dims %d x %d", (long long)n, perm_l, perm_t);
-    pm = OuterPerm{perm_l, perm_t, (int)(n / ((long long)perm_l * perm_t))};
-  }
-  const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
-  if (total == 0) return 0;
-  SF_REQUIRE(in.dtype == din.dtype && (in.dtype == dout.dtype || (in.dtype == SF_BF16 && dout.dtype == SF_F32)),
-             "maxpool2 bwd: unsupported storage combination in=%d dout=%d din=%d", in.dtype, dout.dtype, din.dtype);
-#define SF_MP_BWD(TI_, TO_)                                                                                                               \
-  hipLaunchKernelGGL((maxpool_bwd_kernel<TI_, TO_>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, (const TI_*)in.ptr, in.stride, \
-                     (const TO_*)dout.ptr, dout.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm)
-  if (in.dtype == SF_F32) SF_MP_BWD(float, float);
-  else if (dout.dtype == SF_BF16) SF_MP_BWD(__bf16, __bf16);
-  else SF_MP_BWD(__bf16, float);
-#undef SF_MP_BWD
-  SF_CHECK_LAUNCH("maxpool2_bwd");
+  return maxpool_launch(true, in, dout, n, h, w, din, perm_l, perm_t, nullptr, 0, (hipStream_t)stream);
+}
+
+static int check_drop(float p1, float p2) {
+  SF_REQUIRE(p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f, "maxpool2+dropout: p1=%f p2=%f", p1, p2);
   return 0;
+}
+
+int sf_maxpool2_dropout_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, float p1, float p2,
+                            int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_dropout_fwd: dtype %d not built", dtype);
+  if (int rc = check_drop(p1, p2)) return rc;
+  const sfDrop d = sf_make_drop(p1, p2, seed1, seed2);
+  return maxpool_launch(false, in, out, n, h, w, sfTensor{}, perm_l, perm_t, &d, period, (hipStream_t)stream);
+}
+
+int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
+                            float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_dropout_bwd: dtype %d not built", dtype);
+  if (int rc = check_drop(p1, p2)) return rc;
+  const sfDrop d = sf_make_drop(p1, p2, seed1, seed2);
+  return maxpool_launch(true, in, dout, n, h, w, din, perm_l, perm_t, &d, period, (hipStream_t)stream);
 }
 
 static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, const float* mean,

@@ -47,3 +47,37 @@ template <> __device__ __forceinline__ void stv4<float>(float* p, f32x4 v) { *re
 template <> __device__ __forceinline__ void stv4<__bf16>(__bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
 
 #define SF_F32_ONLY(t, name) SF_REQUIRE((t).ptr == nullptr || (t).dtype == SF_F32, "%s: bf16 storage is not supported by this entry point", name)
+
+// ---- counter-based dropout masks ---------------------------------------------------------------------------------
+// Elements are masked in groups of 4 consecutive indices (a channel quad): two 32-bit hashes give four 16-bit uniforms.
+// keep-scale of element 4*g + j under probability p:  u16 < thr(p) ? 0 : 1/(1-p),  thr = round(p * 65536).
+struct sfDrop { float p1, p2; unsigned thr1, thr2; float k1, k2; unsigned s1lo, s1hi, s2lo, s2hi; };
+__host__ inline sfDrop sf_make_drop(float p1, float p2, unsigned long long seed1, unsigned long long seed2) {
+  sfDrop d;
+  d.p1 = p1; d.p2 = p2;
+  d.thr1 = (unsigned)(p1 * 65536.f + 0.5f); d.thr2 = (unsigned)(p2 * 65536.f + 0.5f);
+  d.k1 = p1 > 0.f ? 1.f / (1.f - p1) : 1.f; d.k2 = p2 > 0.f ? 1.f / (1.f - p2) : 1.f;
+  d.s1lo = (unsigned)seed1; d.s1hi = (unsigned)(seed1 >> 32); d.s2lo = (unsigned)seed2; d.s2hi = (unsigned)(seed2 >> 32);
+  return d;
+}
+__device__ __forceinline__ unsigned sf_hash32(unsigned slo, unsigned shi, unsigned long long ctr) {
+  unsigned h = ((unsigned)ctr * 0x9E3779B1u) ^ slo;
+  h += ((unsigned)(ctr >> 32) ^ shi) * 0x85EBCA77u;
+  h ^= h >> 16; h *= 0x85EBCA6Bu; h ^= h >> 13; h *= 0xC2B2AE35u; h ^= h >> 16;  // murmur3 finaliser
+  return h;
+}
+// scales of the 4 elements of group g (mask 1) times those of group g2 (mask 2, the period-reduced index)
+__device__ __forceinline__ f32x4 sf_drop_scales(const sfDrop& d, unsigned long long g, unsigned long long g2) {
+  f32x4 s = {1.f, 1.f, 1.f, 1.f};
+  if (d.p1 > 0.f) {
+    const unsigned a = sf_hash32(d.s1lo, d.s1hi, 2 * g), b = sf_hash32(d.s1lo, d.s1hi, 2 * g + 1);
+    s[0] = (a & 0xffffu) < d.thr1 ? 0.f : d.k1; s[1] = (a >> 16) < d.thr1 ? 0.f : d.k1;
+    s[2] = (b & 0xffffu) < d.thr1 ? 0.f : d.k1; s[3] = (b >> 16) < d.thr1 ? 0.f : d.k1;
+  }
+  if (d.p2 > 0.f) {
+    const unsigned a = sf_hash32(d.s2lo, d.s2hi, 2 * g2), b = sf_hash32(d.s2lo, d.s2hi, 2 * g2 + 1);
+    s[0] *= (a & 0xffffu) < d.thr2 ? 0.f : d.k2; s[1] *= (a >> 16) < d.thr2 ? 0.f : d.k2;
+    s[2] *= (b & 0xffffu) < d.thr2 ? 0.f : d.k2; s[3] *= (b >> 16) < d.thr2 ? 0.f : d.k2;
+  }
+  return s;
+}

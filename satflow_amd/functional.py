@@ -167,20 +167,29 @@ def conv3x3_broadcast(eng: ConvEngine, x0: Tensor, x1: Tensor, weight: Tensor, b
 # ----------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x: Tensor, perm: Optional[Tuple[int, int]], out_dtype=None):
-        ctx.perm = perm
+    def forward(ctx, x: Tensor, perm: Optional[Tuple[int, int]], out_dtype=None, drop=None):
+        ctx.perm, ctx.drop = perm, drop
         ctx.save_for_backward(x)
-        return K.maxpool2_fwd(x, perm, out_dtype)
+        return K.maxpool2_fwd(x, perm, out_dtype, drop)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
         (x,) = ctx.saved_tensors
-        return K.maxpool2_bwd(x, gy.contiguous(), ctx.perm), None, None
+        return K.maxpool2_bwd(x, gy.contiguous(), ctx.perm, ctx.drop), None, None, None
 
 
-def maxpool2(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None) -> Tensor:
-    """``out_dtype=torch.float32`` on a bf16 input is the encoder's exit back to fp32 storage (max is exact in either type)."""
-    return _MaxPoolFn.apply(x, perm, out_dtype)
+def _draw_seeds() -> Tuple[int, int]:
+    seeds = torch.randint(0, 2**62, (2,), dtype=torch.int64).tolist()  # host RNG: follows torch.manual_seed, no device sync
+    return seeds[0], seeds[1]
+
+
+def maxpool2(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None, dropout: Optional[Tuple[float, float, int]] = None) -> Tensor:
+    """``out_dtype=torch.float32`` on a bf16 input is the encoder's exit back to fp32 storage (max is exact in either type).
+    ``dropout=(p1, p2, period)``: ``dropout2(maxpool2(x), p1, p2, period)`` in the same pass (fresh seeds from the torch RNG)."""
+    drop = None
+    if dropout is not None and (dropout[0] > 0 or dropout[1] > 0):
+        drop = (float(dropout[0]), float(dropout[1]), int(dropout[2]), *_draw_seeds())
+    return _MaxPoolFn.apply(x, perm, out_dtype, drop)
 
 
 class _LeadTimePoolFn(torch.autograd.Function):
@@ -524,5 +533,4 @@ def dropout2(x: Tensor, p1: float, p2: float, period: int) -> Tensor:
     """Elementwise dropout ``p1`` fused with a dropout ``p2`` whose mask repeats every ``period`` elements (shared over time)."""
     if p1 <= 0 and p2 <= 0:
         return x
-    seeds = torch.randint(0, 2**62, (2,), dtype=torch.int64).tolist()  # host RNG: follows torch.manual_seed, no device sync
-    return _Dropout2Fn.apply(x.contiguous(), float(p1), float(p2), int(period), seeds[0], seeds[1])
+    return _Dropout2Fn.apply(x.contiguous(), float(p1), float(p2), int(period), *_draw_seeds())

@@ -240,19 +240,26 @@ def metnet_preprocess(imgs: Tensor, sat: int, crop: int, out_dtype=torch.float32
     return out
 
 
-def maxpool2_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None) -> Tensor:
+def maxpool2_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None, drop=None) -> Tensor:
+    """``drop = (p1, p2, period, seed1, seed2)``: the encoder-output dropouts fused into the pooling (sf_maxpool2_dropout_fwd)."""
     n, h, w, c = x.shape
     y = torch.empty(n, h // 2, w // 2, c, dtype=out_dtype or x.dtype, device=x.device)
     pl, pt = perm or (0, 0)
-    check(lib().sf_maxpool2_fwd(T(x), n, h, w, T(y), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_fwd")
+    if drop is None:
+        check(lib().sf_maxpool2_fwd(T(x), n, h, w, T(y), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_fwd")
+    else:
+        check(lib().sf_maxpool2_dropout_fwd(T(x), n, h, w, T(y), pl, pt, *drop, SF_F32, stream_ptr()), "sf_maxpool2_dropout_fwd")
     return y
 
 
-def maxpool2_bwd(x: Tensor, gy: Tensor, perm: Optional[Tuple[int, int]] = None) -> Tensor:
+def maxpool2_bwd(x: Tensor, gy: Tensor, perm: Optional[Tuple[int, int]] = None, drop=None) -> Tensor:
     n, h, w, c = x.shape
     gx = torch.empty_like(x)
     pl, pt = perm or (0, 0)
-    check(lib().sf_maxpool2_bwd(T(x), T(gy), n, h, w, T(gx), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_bwd")
+    if drop is None:
+        check(lib().sf_maxpool2_bwd(T(x), T(gy), n, h, w, T(gx), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_bwd")
+    else:
+        check(lib().sf_maxpool2_dropout_bwd(T(x), T(gy), n, h, w, T(gx), pl, pt, *drop, SF_F32, stream_ptr()), "sf_maxpool2_dropout_bwd")
     return gx
 
 

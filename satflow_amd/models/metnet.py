@@ -78,7 +78,7 @@ class DownSampler(nn.Module):
         oc = output_channels
         self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
 
-    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None) -> Tensor:
+    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None, dropout=None) -> Tensor:
         """NHWC pipeline from the first pooling's output (``pooled``) or from the input ``x``; ``groups`` BatchNorm batches.
 
         The activations keep the storage type they arrive in (fp32, or bf16 in "bf16a" mode); the last pooling always
@@ -89,7 +89,11 @@ class DownSampler(nn.Module):
         y = F.batchnorm(y, m[3], groups, self.training)
         y = F.batchnorm(F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias, out_dtype=st), m[5], groups, self.training)
         y = F.batchnorm(F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias, out_dtype=st), m[7], groups, self.training)
-        return F.maxpool2(F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias, out_dtype=st), perm, out_dtype=torch.float32)
+        y = F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias, out_dtype=st)
+        if dropout is not None:  # (p1, p2, timesteps): period = elements of one timestep of the pooled tensor
+            n, h, w, c = y.shape
+            dropout = (dropout[0], dropout[1], (n // dropout[2]) * (h // 2) * (w // 2) * c)
+        return F.maxpool2(y, perm, out_dtype=torch.float32, dropout=dropout)
 
     def forward(self, x: Tensor) -> Tensor:
         """``[N,C,H,W] -> [N,out,H/4,W/4]`` (module-surface form, one BatchNorm batch)."""
@@ -272,10 +276,10 @@ class MetNet(nn.Module):
         p1 = F.leadtime_pool(base, c1.weight, cimg, L)  # [L*T*B, S/2, S/2, 160], image (l*F + f)
         # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
         # images from [lead][time][batch] to [time][lead][batch] for the recurrent part
-        feat = enc.run(None, L, pooled=p1, perm=(L, Tn))  # [T*L*B, S/4, S/4, 256]
         rnn = self.temporal_enc.rnn
-        if self.training:  # nn.Dropout(temporal_dropout) and the ConvGRU's sequence-consistent input dropout, one fused pass
-            feat = F.dropout2(feat, self.drop.p, rnn.input_p, feat.numel() // Tn)
+        # nn.Dropout(temporal_dropout) and the ConvGRU's sequence-consistent input dropout ride on the encoder's last pooling
+        drop = (self.drop.p, rnn.input_p, Tn) if self.training else None
+        feat = enc.run(None, L, pooled=p1, perm=(L, Tn), dropout=drop)  # [T*L*B, S/4, S/4, 256]
         _, last = rnn.run(feat, Tn, L * B, input_dropout_done=True)
         a = last[-1]  # [L*B, s, s, hidp]
         for layer in self.temporal_agg:

@@ -353,3 +353,29 @@ def test_leadtime_pool_vs_oracle(device, Fr, S, O, cimg, L):
     assert_close(nhwc_to_nchw(bd.grad, O), br.grad, "d(base)", grad=True)
     assert_close(wd.grad[:, cimg:], wr.grad[:, cimg:], "dW1 one-hot columns", grad=True)
     assert float(wd.grad[:, :cimg].abs().max()) == 0.0  # the image columns get their gradient from the convolution itself
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+def test_maxpool_fused_dropout(device, storage):
+    """The encoder's last pooling with MetNet's two dropouts fused in == max-pool followed by sf_dropout2 with the same seeds,
+    forward and backward, bit for bit (same masks, same scaling), incl. the lead-time/time permutation."""
+    from satflow_amd.functional import _Dropout2Fn, _MaxPoolFn
+
+    L, Tn, B, c, h, w = 3, 4, 2, 32, 8, 6
+    g = _g(77)
+    x1 = torch.randn(L * Tn * B, h, w, c, generator=g).to(device).to(storage).requires_grad_()
+    x2 = x1.detach().clone().requires_grad_()
+    period = (L * B) * (h // 2) * (w // 2) * c  # one timestep of the pooled, time-major tensor
+    drop = (0.2, 0.25, period, 1234567, 7654321)
+    fused = _MaxPoolFn.apply(x1, (L, Tn), torch.float32, drop)
+    plain = _Dropout2Fn.apply(_MaxPoolFn.apply(x2, (L, Tn), torch.float32, None), *drop)
+    assert torch.equal(fused, plain)
+    keep = (fused != 0).float().mean()
+    assert abs(float(keep) - 0.6) < 0.03
+    # sequence-consistent mask: what the second dropout removes is removed at every timestep
+    only2 = _MaxPoolFn.apply(torch.ones_like(x1), (L, Tn), torch.float32, (0.0, 0.5, period, 1, 2)).view(Tn, -1)
+    assert torch.equal(only2[0] != 0, only2[1] != 0) and torch.equal(only2[0] != 0, only2[Tn - 1] != 0)
+    cot = torch.randn(fused.shape, generator=g).to(device)
+    fused.backward(cot)
+    plain.backward(cot)
+    assert torch.equal(x1.grad, x2.grad)
