@@ -91,6 +91,14 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
 int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w,
                    const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
                    int32_t epilogue, sfTensor out, int32_t dtype, sfStream stream);
+/* The same convolution (SF_BF16 kernels, linear epilogue) that also emits what the BatchNorm2d behind it in the DownSampler
+ * needs: per pixel tile, the sum and the sum of squares of every output channel's STORED values,
+ * stats[(image * sf_conv3x3_stats_tiles(h, w) + tile)][Np][2] fp32 - consumed by sf_batchnorm_train_fwd_stats, which then
+ * does not have to read the activation a first time. */
+int32_t sf_conv3x3_stats_tiles(int32_t h, int32_t w);
+int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w,
+                         const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
+                         sfTensor out, float* stats, int32_t dtype, sfStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ConvLSTM cell step.  Replaces ConvLSTMCell.forward,
@@ -197,6 +205,12 @@ int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, in
                            float* running_mean, float* running_var, float* mean, float* rstd,
                            float* scale, float* shift, double* sums, sfTensor y, int32_t dtype,
                            sfStream stream);
+/* sf_batchnorm_train_fwd with the statistics taken from the producing convolution's per-tile records
+ * (sf_conv3x3_fwd_stats): group g owns tiles [g*tiles_per_group, (g+1)*tiles_per_group), stats_np = the convolution's Np. */
+int sf_batchnorm_train_fwd_stats(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma,
+                                 const float* beta, float eps, float momentum, float* running_mean, float* running_var,
+                                 float* mean, float* rstd, float* scale, float* shift, double* sums, const float* stats,
+                                 int32_t tiles_per_group, int32_t stats_np, sfTensor y, int32_t dtype, sfStream stream);
 int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float* gamma,
                           const float* beta, float eps, const float* running_mean,
                           const float* running_var, float* scale, float* shift, sfTensor y,

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "sf_conv3x3_packed_elems": (_sz, [_i32, _i32]),
     "sf_conv3x3_pack_weights": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "sf_conv3x3_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_conv3x3_stats_tiles": (_i32, [_i32, _i32]),
+    "sf_conv3x3_fwd_stats": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, sfTensor, _vp, _i32, _vp]),
     "sf_convlstm_cell_fwd": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
@@ -59,6 +61,10 @@ PROTOTYPES = {
     "sf_batchnorm_train_fwd": (
         C.c_int,
         [sfTensor, _i64, _i32, _i32, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, sfTensor, _i32, _vp],
+    ),
+    "sf_batchnorm_train_fwd_stats": (
+        C.c_int,
+        [sfTensor, _i64, _i32, _i32, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, sfTensor, _i32, _vp],
     ),
     "sf_batchnorm_eval_fwd": (C.c_int, [sfTensor, _i64, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, sfTensor, _i32, _vp]),
     "sf_batchnorm_train_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),

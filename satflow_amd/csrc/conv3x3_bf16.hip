@@ -236,7 +236,26 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #endif
   }
 
-  conv_epilogue<NF, EPI>(acc, p, n, nb, y0, x0, wave, r, kh);
+  // optional per-tile BatchNorm statistics of the stored outputs (linear epilogue): lane sums -> LDS (the operand
+  // buffers are free once every wave has left the K loop) -> one [32*NF][2] record per workgroup
+  float* lds_stats = nullptr;
+  if constexpr (EPI == EPI_LINEAR) {
+    if (p.stats) {
+      __syncthreads();
+      lds_stats = reinterpret_cast<float*>(lds);
+      for (int i = tid; i < 2 * NB; i += THREADS) lds_stats[i] = 0.f;
+      __syncthreads();
+    }
+  }
+  conv_epilogue<NF, EPI>(acc, p, n, nb, y0, x0, wave, r, kh, lds_stats);
+  if constexpr (EPI == EPI_LINEAR) {
+    if (lds_stats) {
+      __syncthreads();
+      const size_t tile_lin = (size_t)(n * p.tiles_y + ty) * p.tiles_x + tx;
+      for (int i = tid; i < 2 * NB; i += THREADS)
+        p.stats[(tile_lin * p.stats_np + nb * NB + (i % NB)) * 2 + i / NB] = lds_stats[i];
+    }
+  }
 }
 
 // ---- weight repack (bf16 LDS image) ----------------------------------------------------------
@@ -304,6 +323,11 @@ int launch_e(const ConvParams& p, int nf, int nblk, hipStream_t st) {
 }
 
 }  // namespace
+
+int sf_conv_bf16_tiles(int h, int w) {
+  const int th = h > 16 ? 32 : 16;
+  return ((w + TILE_W - 1) / TILE_W) * ((h + th - 1) / th);
+}
 
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st) {
   switch (epi) {

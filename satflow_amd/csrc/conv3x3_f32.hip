@@ -206,9 +206,9 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
   return 0;
 }
 
-int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
-                   const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, int32_t dtype,
-                   sfStream stream) {
+static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
+                            const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, float* stats, int32_t dtype,
+                            sfStream stream) {
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_fwd: dtype %d not built", dtype);
   if (check_src(src0, "conv3x3 src0") || check_src(src1, "conv3x3 src1")) return 1;
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && out.c <= Np, "conv3x3: bad Np=%d nf=%d out.c=%d", Np, nf, out.c);
@@ -222,6 +222,8 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
   const int nblk = Np / (32 * nf);
   p.bf0 = src0.ptr && src0.dtype == SF_BF16; p.bf1 = src1.ptr && src1.dtype == SF_BF16; p.out_bf = out.dtype == SF_BF16;
   SF_REQUIRE(dtype == SF_BF16 || !(p.bf0 || p.bf1 || p.out_bf), "conv3x3: bf16-stored tensors need the SF_BF16 kernel");
+  SF_REQUIRE(!stats || (dtype == SF_BF16 && epilogue == SF_EPI_LINEAR), "conv3x3: output statistics need the SF_BF16 kernel with the linear epilogue");
+  p.stats = stats; p.stats_np = Np;
   if (dtype == SF_BF16) {
     SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
     return sf_launch_conv_bf16(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
@@ -230,6 +232,21 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
   if (epilogue == SF_EPI_SIGMOID) return launch_conv<EPI_SIGMOID>(p, nf, nblk, (hipStream_t)stream);
   sf_set_error("conv3x3: unknown epilogue %d", epilogue);
   return 1;
+}
+
+int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
+                   const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, int32_t dtype,
+                   sfStream stream) {
+  return conv3x3_fwd_impl(src0, src1, n, h, w, wpacked, bias_packed, Np, nf, epilogue, out, nullptr, dtype, stream);
+}
+
+int32_t sf_conv3x3_stats_tiles(int32_t h, int32_t w) { return sf_conv_bf16_tiles(h, w); }
+
+int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
+                         const float* bias_packed, int32_t Np, int32_t nf, sfTensor out, float* stats, int32_t dtype,
+                         sfStream stream) {
+  SF_REQUIRE(stats != nullptr, "sf_conv3x3_fwd_stats: stats must not be null");
+  return conv3x3_fwd_impl(src0, src1, n, h, w, wpacked, bias_packed, Np, nf, SF_EPI_LINEAR, out, stats, dtype, stream);
 }
 
 int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n, int32_t h, int32_t w,

@@ -31,13 +31,15 @@ struct ConvParams {
   const float* h_prev; int hprev_s;
   // storage types (bf16 kernel only; linear / sigmoid epilogues): non-zero = bf16 elements behind src0 / src1 / out
   int bf0, bf1, out_bf;
+  // bf16 kernel, linear epilogue: per-tile sum / sum of squares of the stored outputs, [tile][stats_np][2] (or null)
+  float* stats; int stats_np;
 };
 
 
 // acc[mf][nf][reg]: wave `wave` owns tile rows 4*wave..4*wave+3; M fragment mf = rows 2*mf, 2*mf+1 (16 px each).
 template <int NF, int EPI>
 __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0,
-                                              int wave, int r, int kh) {
+                                              int wave, int r, int kh, float* lds_stats = nullptr) {
   constexpr int NB = 32 * NF;
   // The recurrent epilogues read state / pre-activations per output element.  All reads of one M fragment (16 elements)
   // are issued first, from clamped in-image addresses and without per-element conditions, then the arithmetic, then
@@ -139,6 +141,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
       const int co = nb * NB + nf * 32 + r;
       if (co < p.out_c) {  // out_c is a multiple of 16: both lanes of an (even, odd) channel pair take the same side
         const float bv = p.bias ? p.bias[co] : 0.f;
+        float s1 = 0.f, s2 = 0.f;  // BatchNorm statistics of THIS lane's channel over its valid pixels (stored, i.e. rounded, values)
         if (p.out_bf) {
           // bf16 output: registers 2k / 2k+1 are horizontally adjacent pixels P / P+1 of channel `co`.  Lane pairs swap one
           // value (DPP quad_perm [1,0,3,2]) so that the even lane owns channels (co, co+1) of P and the odd lane channels
@@ -151,6 +154,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
             for (int k = 0; k < 8; ++k) {
               float a = acc[mf][nf][2 * k] + bv, b = acc[mf][nf][2 * k + 1] + bv;
               if constexpr (EPI == EPI_SIGMOID) { a = sf_sigmoid(a); b = sf_sigmoid(b); }
+              a = (float)(__bf16)a; b = (float)(__bf16)b;  // the stored values (packing them below is exact)
+              if (lds_stats) {
+                const int ra = frag_row(2 * k, kh), rb = frag_row(2 * k + 1, kh);
+                const bool va = y0 + 4 * wave + 2 * mf + (ra >> 4) < p.H && x0 + (ra & 15) < p.W;
+                const bool vb = y0 + 4 * wave + 2 * mf + (rb >> 4) < p.H && x0 + (rb & 15) < p.W;
+                s1 += (va ? a : 0.f) + (vb ? b : 0.f); s2 += (va ? a * a : 0.f) + (vb ? b * b : 0.f);
+              }
               const float send = odd ? a : b;
               const float recv = __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, send), 0xB1, 0xF, 0xF, true));
               const int rr = frag_row(2 * k + odd, kh);
@@ -172,9 +182,14 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
               if (py < p.H && px < p.W) {
                 float v = acc[mf][nf][reg] + bv;
                 if constexpr (EPI == EPI_SIGMOID) v = sf_sigmoid(v);
+                s1 += v; s2 += v * v;
                 p.out[((size_t)(n * p.H + py) * p.W + px) * p.out_s + co] = v;
               }
             }
+        }
+        if (lds_stats) {  // block-uniform; lanes r and r+32 hold the same channel
+          s1 += __shfl_xor(s1, 32); s2 += __shfl_xor(s2, 32);
+          if (kh == 0) { atomicAdd(lds_stats + nf * 32 + r, s1); atomicAdd(lds_stats + NB + nf * 32 + r, s2); }
         }
       }
     }
@@ -195,6 +210,8 @@ inline int check_src(const sfTensor& t, const char* name) {
 
 }  // namespace sfconv
 
+// pixel tiles per image of the bf16 kernels (32x16 tiles when H > 16, else 16x16)
+int sf_conv_bf16_tiles(int h, int w);
 // bf16-MFMA launcher (conv3x3_bf16.hip); epi is one of sfconv::EPI_*
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
 void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,

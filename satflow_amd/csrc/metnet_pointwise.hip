@@ -174,6 +174,21 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TA* __restrict__ x
   }
 }
 
+// sums[g][2][C] (fp64) from the convolution's per-tile records stats[tile][np][2] (fp32), tiles of group g = [g*tpg, (g+1)*tpg)
+__global__ void bn_sum_tiles_kernel(const float* __restrict__ stats, int tpg, int np, int C, double* __restrict__ sums) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, which = blockIdx.z;
+  if (c >= C) return;
+  const float* p = stats + ((size_t)g * tpg * np + c) * 2 + which;
+  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 8 independent chains: 8 loads in flight (fixed order: deterministic)
+  int t = 0;
+  for (; t + 8 <= tpg; t += 8) {
+#pragma unroll
+    for (int u = 0; u < 8; ++u) a[u] += (double)p[(size_t)(t + u) * np * 2];
+  }
+  for (; t < tpg; ++t) a[0] += (double)p[(size_t)t * np * 2];
+  sums[((size_t)g * 2 + which) * C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+}
+
 // finalize forward statistics: mean/rstd per (group, channel), affine a = gamma*rstd, b = beta - mean*a;
 // running stats updated group after group (the reference calls the module once per lead time, in order).
 __global__ void bn_finalize_kernel(const double* __restrict__ sums, int G, int C, int Creal, double count, float eps, float momentum,
@@ -393,14 +408,19 @@ static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_g
   return 0;
 }
 
-int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma, const float* beta,
-                           float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
-                           float* scale, float* shift, double* sums, sfTensor y, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_fwd: dtype %d not built", dtype);
+static int bn_train_fwd_impl(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma, const float* beta,
+                             float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                             float* scale, float* shift, double* sums, const float* stats, int32_t tiles_per_group, int32_t stats_np,
+                             sfTensor y, hipStream_t st) {
   SF_REQUIRE(x.c == y.c && ok4(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm: y channels / storage type");
-  hipStream_t st = (hipStream_t)stream;
-  sfTensor none{nullptr, 0, 0, 0, 0, 0};
-  if (int rc = bn_reduce_launch(0, x, none, pix_per_group, groups, nullptr, nullptr, sums, st)) return rc;
+  if (stats) {
+    SF_REQUIRE(tiles_per_group > 0 && stats_np >= x.c, "batchnorm: tiles_per_group=%d stats_np=%d", tiles_per_group, stats_np);
+    hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3((x.c + 127) / 128, groups, 2), dim3(128), 0, st, stats, tiles_per_group, stats_np, x.c, sums);
+    SF_CHECK_LAUNCH("bn_sum_tiles");
+  } else {
+    sfTensor none{nullptr, 0, 0, 0, 0, 0};
+    if (int rc = bn_reduce_launch(0, x, none, pix_per_group, groups, nullptr, nullptr, sums, st)) return rc;
+  }
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, (double)pix_per_group, eps,
                      momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
   SF_CHECK_LAUNCH("bn_finalize");
@@ -409,6 +429,24 @@ int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, in
                                               pixels, (long long)pix_per_group, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));
   SF_CHECK_LAUNCH("bn_apply");
   return 0;
+}
+
+int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma, const float* beta,
+                           float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                           float* scale, float* shift, double* sums, sfTensor y, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_fwd: dtype %d not built", dtype);
+  return bn_train_fwd_impl(x, pix_per_group, groups, creal, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, sums,
+                           nullptr, 0, 0, y, (hipStream_t)stream);
+}
+
+int sf_batchnorm_train_fwd_stats(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal, const float* gamma, const float* beta,
+                                 float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
+                                 float* scale, float* shift, double* sums, const float* stats, int32_t tiles_per_group, int32_t stats_np,
+                                 sfTensor y, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_fwd_stats: dtype %d not built", dtype);
+  SF_REQUIRE(stats != nullptr, "sf_batchnorm_train_fwd_stats: stats must not be null");
+  return bn_train_fwd_impl(x, pix_per_group, groups, creal, gamma, beta, eps, momentum, running_mean, running_var, mean, rstd, scale, shift, sums,
+                           stats, tiles_per_group, stats_np, y, (hipStream_t)stream);
 }
 
 int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float* gamma, const float* beta, float eps,

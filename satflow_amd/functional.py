@@ -104,13 +104,13 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: ConvEngine, x0: Tensor, x1: Optional[Tensor], weight: Tensor, bias: Optional[Tensor], n: int,
-                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool, out_dtype=None):
+                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool, out_dtype=None, stats: Optional[Tensor] = None):
         H, W = x0.shape[1], x0.shape[2]
         packed, bp = eng.packed(weight, bias, "fwd")
         y = torch.empty(n, H, W, eng.coutp, dtype=out_dtype or torch.float32, device=x0.device)
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if x1 is not None else NULL
-        K.conv3x3(s0, s1, n, H, W, packed, bp, eng.fwd_map, T(y), SF_EPI_SIGMOID if sigmoid else SF_EPI_LINEAR)
+        K.conv3x3(s0, s1, n, H, W, packed, bp, eng.fwd_map, T(y), SF_EPI_SIGMOID if sigmoid else SF_EPI_LINEAR, stats)
         ctx.eng, ctx.sigmoid, ctx.n, ctx.remaps = eng, sigmoid, n, (remap0, remap1)
         ctx.has = (x1 is not None, bias is not None)
         ctx.save_for_backward(x0, x1 if x1 is not None else x0.new_empty(0), y if sigmoid else x0.new_empty(0), weight)
@@ -149,12 +149,32 @@ class _ConvFn(torch.autograd.Function):
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
         K.conv3x3_bwd_weight(s0, s1, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
-        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None, None
+        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None, None, None
 
 
-def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False, out_dtype=None) -> Tensor:
-    """``out_dtype=torch.bfloat16`` stores the result as bf16 (SF_BF16 kernels only; "bf16a" encoder mode)."""
-    return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype)
+class ConvStats:
+    """Per-tile output statistics of a convolution (see ``sf_conv3x3_fwd_stats``), handed to the BatchNorm behind it."""
+
+    def __init__(self, n: int, h: int, w: int, np_: int, device) -> None:
+        self.tiles = int(lib().sf_conv3x3_stats_tiles(h, w))
+        self.np, self.n = np_, n
+        self.data = torch.empty(n * self.tiles, np_, 2, dtype=torch.float32, device=device)
+
+
+def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False, out_dtype=None,
+            want_stats: Optional[bool] = None):
+    """``out_dtype=torch.bfloat16`` stores the result as bf16 (SF_BF16 kernels only; "bf16a" encoder mode).
+    ``want_stats`` not None: returns ``(y, stats)`` with ``stats`` a ``ConvStats`` for ``batchnorm(..., stats=)`` when it is
+    true and the bf16 kernels run, else None."""
+    if want_stats is None:
+        return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype)
+    from ._hip import SF_BF16, compute_dtype
+
+    st = None
+    if want_stats and compute_dtype() == SF_BF16 and not sigmoid:
+        st = ConvStats(x.shape[0], x.shape[1], x.shape[2], eng.fwd_map.Np, x.device)
+    y = _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype, st.data if st is not None else None)
+    return y, st
 
 
 def conv3x3_broadcast(eng: ConvEngine, x0: Tensor, x1: Tensor, weight: Tensor, bias: Optional[Tensor], n: int,
@@ -230,7 +250,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
-                groups: int, eps: float, momentum: float):
+                groups: int, eps: float, momentum: float, conv_stats=None):
         C = x.shape[-1]
         creal = gamma.shape[0]
         pixels = x.numel() // C
@@ -239,11 +259,18 @@ class _BatchNormTrainFn(torch.autograd.Function):
         stats = torch.empty(4, groups, C, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
         sums = torch.empty(groups, 2, C, dtype=torch.float64, device=dev)
         y = torch.empty_like(x)
-        check(lib().sf_batchnorm_train_fwd(T(x), pixels // groups, groups, creal, gamma.data_ptr(), beta.data_ptr(), eps, momentum,
-                                           running_mean.data_ptr() if running_mean is not None else None,
-                                           running_var.data_ptr() if running_var is not None else None,
-                                           stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(),
-                                           sums.data_ptr(), T(y), SF_F32, stream_ptr()), "sf_batchnorm_train_fwd")
+        rm = running_mean.data_ptr() if running_mean is not None else None
+        rv = running_var.data_ptr() if running_var is not None else None
+        stat_ptrs = (stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+        if conv_stats is None:
+            check(lib().sf_batchnorm_train_fwd(T(x), pixels // groups, groups, creal, gamma.data_ptr(), beta.data_ptr(), eps, momentum, rm, rv,
+                                               *stat_ptrs, sums.data_ptr(), T(y), SF_F32, stream_ptr()), "sf_batchnorm_train_fwd")
+        else:  # statistics from the producing convolution's epilogue: x is not read a first time
+            assert conv_stats.n % groups == 0 and conv_stats.np >= C
+            check(lib().sf_batchnorm_train_fwd_stats(T(x), pixels // groups, groups, creal, gamma.data_ptr(), beta.data_ptr(), eps, momentum, rm, rv,
+                                                     *stat_ptrs, sums.data_ptr(), conv_stats.data.data_ptr(),
+                                                     conv_stats.tiles * (conv_stats.n // groups), conv_stats.np, T(y), SF_F32, stream_ptr()),
+                  "sf_batchnorm_train_fwd_stats")
         ctx.groups, ctx.creal = groups, creal
         ctx.save_for_backward(x, gamma, stats)
         return y
@@ -261,16 +288,17 @@ class _BatchNormTrainFn(torch.autograd.Function):
         check(lib().sf_batchnorm_train_bwd(T(x), T(gy), pixels // ctx.groups, ctx.groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
                                            stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
                                            SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None
+        return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
-def batchnorm(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, training: bool) -> Tensor:
-    """``bn(x)`` on NHWC ``x``; in training mode with ``groups`` separate batches (and running-stat updates in order)."""
+def batchnorm(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, training: bool, stats: Optional["ConvStats"] = None) -> Tensor:
+    """``bn(x)`` on NHWC ``x``; in training mode with ``groups`` separate batches (and running-stat updates in order).
+    ``stats``: the producing convolution's ``ConvStats`` (training mode) - saves the statistics pass over ``x``."""
     if training:
         if bn.track_running_stats and bn.num_batches_tracked is not None:
             bn.num_batches_tracked += groups
         return _BatchNormTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups, bn.eps,
-                                       bn.momentum if bn.momentum is not None else 0.1)
+                                       bn.momentum if bn.momentum is not None else 0.1, stats)
     C = x.shape[-1]
     ab = torch.empty(2, C, dtype=torch.float32, device=x.device)
     y = torch.empty_like(x)

@@ -143,7 +143,16 @@ def pack_weights(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, transpose:
 
 
 def conv3x3(src0: sfTensor, src1: sfTensor, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor],
-            gm: GemmMap, out: sfTensor, epilogue: int = SF_EPI_LINEAR) -> None:
+            gm: GemmMap, out: sfTensor, epilogue: int = SF_EPI_LINEAR, stats: Optional[Tensor] = None) -> None:
+    """``stats`` ([n * sf_conv3x3_stats_tiles(h, w), Np, 2] fp32): also emit the per-tile output statistics (sf_conv3x3_fwd_stats)."""
+    if stats is not None:
+        assert epilogue == SF_EPI_LINEAR and stats.is_contiguous() and stats.dtype == torch.float32
+        check(
+            lib().sf_conv3x3_fwd_stats(src0, src1, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
+                                       gm.Np, gm.nf, out, stats.data_ptr(), _hip.compute_dtype(), stream_ptr()),
+            "sf_conv3x3_fwd_stats",
+        )
+        return
     check(
         lib().sf_conv3x3_fwd(src0, src1, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
                              gm.Np, gm.nf, epilogue, out, _hip.compute_dtype(), stream_ptr()),

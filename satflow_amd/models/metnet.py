@@ -87,8 +87,11 @@ class DownSampler(nn.Module):
         y = pooled if pooled is not None else F.maxpool2(F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias, out_dtype=x.dtype))
         st = y.dtype
         y = F.batchnorm(y, m[3], groups, self.training)
-        y = F.batchnorm(F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias, out_dtype=st), m[5], groups, self.training)
-        y = F.batchnorm(F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias, out_dtype=st), m[7], groups, self.training)
+        # the two convolutions that feed a BatchNorm also emit its statistics from their epilogue (bf16 kernels, training)
+        y, cs = F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias, out_dtype=st, want_stats=self.training)
+        y = F.batchnorm(y, m[5], groups, self.training, cs)
+        y, cs = F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias, out_dtype=st, want_stats=self.training)
+        y = F.batchnorm(y, m[7], groups, self.training, cs)
         y = F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias, out_dtype=st)
         if dropout is not None:  # (p1, p2, timesteps): period = elements of one timestep of the pooled tensor
             n, h, w, c = y.shape

@@ -167,3 +167,36 @@ def test_conv_broadcast_sources(device):
     (y * cot.to(device)).sum().backward()
     assert_close(y, ref, "broadcast conv")
     assert_close(wd.grad, wr.grad, "broadcast conv dW", grad=True)
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,n,h,w,groups", [(16, 40, 4, 16, 16, 2), (160, 256, 6, 32, 32, 3), (32, 48, 2, 40, 20, 1)])
+def test_conv_epilogue_statistics_feed_batchnorm(device, storage, cin, cout, n, h, w, groups):
+    """`sf_conv3x3_fwd_stats` + `sf_batchnorm_train_fwd_stats` == convolution followed by the BatchNorm that computes its own
+    statistics (same kernels otherwise): the per-tile sums replace the statistics pass, nothing else changes."""
+    import satflow_amd
+    from satflow_amd.functional import ConvEngine, batchnorm, conv3x3, nchw_to_nhwc
+
+    satflow_amd.set_compute_dtype("bf16a" if storage == torch.bfloat16 else "bf16")
+    try:
+        g = torch.Generator().manual_seed(cin + h)
+        x = nchw_to_nhwc(torch.randn(n, cin, h, w, generator=g).to(device)).to(storage)
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin**0.5)).to(device)
+        b = torch.randn(cout, generator=g).to(device)
+        eng = ConvEngine([cin], cout)
+        bn1, bn2 = torch.nn.BatchNorm2d(cout).to(device), torch.nn.BatchNorm2d(cout).to(device)
+        y1, st = conv3x3(eng, x, wt, b, out_dtype=storage, want_stats=True)
+        assert st is not None and st.data.shape == (n * st.tiles, eng.fwd_map.Np, 2)
+        y2 = conv3x3(eng, x, wt, b, out_dtype=storage)
+        assert torch.equal(y1, y2)
+        o1, o2 = batchnorm(y1, bn1, groups, True, st), batchnorm(y2, bn2, groups, True)
+        # statistics: fp32 per-tile sums of the same stored values, then fp64 - vs fp32 per-row sums, then fp64
+        assert_close(bn1.running_mean, bn2.running_mean, "running_mean from epilogue statistics", rtol=1e-5, atol=1e-6)
+        assert_close(bn1.running_var, bn2.running_var, "running_var from epilogue statistics", rtol=1e-5, atol=1e-6)
+        if storage == torch.float32:
+            assert_close(o1, o2, "BatchNorm output", rtol=1e-5, atol=1e-5)
+        else:
+            d = (o1.float() - o2.float()).abs()
+            assert float((d > 2.0**-7 * o2.float().abs() + 1e-6).float().mean()) == 0.0  # at most 1 bf16 ulp apart
+    finally:
+        satflow_amd.set_compute_dtype("f32")
