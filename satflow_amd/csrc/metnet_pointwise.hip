@@ -235,13 +235,13 @@ __global__ void bn_eval_affine_kernel(int C, int Creal, float eps, const float* 
 template <typename TA>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const TA* __restrict__ x, int xs, long long pixels, long long pix_per_group, int C,
                                                        const float* __restrict__ a, const float* __restrict__ b, TA* __restrict__ y, int ys) {
-  const int q = C / 4;
+  const int q = C / 8;  // 8 channels per thread: one 16-byte access per bf16 tensor (C is a multiple of 16)
   const long long total = pixels * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long p = idx / q;
-    const int c = (idx % q) * 4;
+    const int c = (idx % q) * 8;
     const long long g = p / pix_per_group;
-    stv4(y + p * ys + c, ldv4(x + p * xs + c) * ld4(a + g * C + c) + ld4(b + g * C + c));
+    stv8(y + p * ys + c, ldv8(x + p * xs + c) * ldv8(a + g * C + c) + ldv8(b + g * C + c));
   }
 }
 
@@ -265,13 +265,13 @@ template <typename TA>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TA* __restrict__ x, int xs, const TA* __restrict__ dy, int dys,
                                                            long long pixels, long long pix_per_group, int C, const float* __restrict__ coef,
                                                            TA* __restrict__ dx, int dxs) {
-  const int q = C / 4;
+  const int q = C / 8;
   const long long total = pixels * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long p = idx / q;
-    const int c = (idx % q) * 4;
+    const int c = (idx % q) * 8;
     const float* k = coef + (p / pix_per_group) * 3 * C + c;
-    stv4(dx + p * dxs + c, ld4(k) * ldv4(dy + p * dys + c) + ld4(k + C) * ldv4(x + p * xs + c) + ld4(k + 2 * C));
+    stv8(dx + p * dxs + c, ldv8(k) * ldv8(dy + p * dys + c) + ldv8(k + C) * ldv8(x + p * xs + c) + ldv8(k + 2 * C));
   }
 }
 
@@ -290,6 +290,8 @@ bool ok4(const sfTensor& t) {
   return t.ptr == nullptr || ((((uintptr_t)t.ptr) & (t.dtype == SF_BF16 ? 7 : 15)) == 0 && t.stride % 4 == 0 && t.c % 4 == 0 &&
                               (t.dtype == SF_F32 || t.dtype == SF_BF16));
 }
+// 8-channel accesses of the BatchNorm apply kernels: 16-byte aligned pixels in either storage type
+bool ok8(const sfTensor& t) { return ok4(t) && (t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.c % 8 == 0 && t.stride % 8 == 0)); }
 bool same_dtype(const sfTensor& a, const sfTensor& b) { return a.ptr == nullptr || b.ptr == nullptr || a.dtype == b.dtype; }
 
 }  // namespace
@@ -412,7 +414,7 @@ static int bn_train_fwd_impl(sfTensor x, int64_t pix_per_group, int32_t groups, 
                              float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
                              float* scale, float* shift, double* sums, const float* stats, int32_t tiles_per_group, int32_t stats_np,
                              sfTensor y, hipStream_t st) {
-  SF_REQUIRE(x.c == y.c && ok4(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm: y channels / storage type");
+  SF_REQUIRE(x.c == y.c && ok8(x) && ok8(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm: channels (multiple of 8, 16-byte aligned) / storage type");
   if (stats) {
     SF_REQUIRE(tiles_per_group > 0 && stats_np >= x.c, "batchnorm: tiles_per_group=%d stats_np=%d", tiles_per_group, stats_np);
     hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3((x.c + 127) / 128, groups, 2), dim3(128), 0, st, stats, tiles_per_group, stats_np, x.c, sums);
@@ -425,7 +427,7 @@ static int bn_train_fwd_impl(sfTensor x, int64_t pix_per_group, int32_t groups, 
                      momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
   SF_CHECK_LAUNCH("bn_finalize");
   const long long pixels = pix_per_group * groups;
-  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               pixels, (long long)pix_per_group, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));
   SF_CHECK_LAUNCH("bn_apply");
   return 0;
@@ -453,12 +455,12 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
                           const float* running_mean, const float* running_var, float* scale, float* shift, sfTensor y,
                           int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_eval_fwd: dtype %d not built", dtype);
-  SF_REQUIRE(x.c == y.c && ok4(x) && ok4(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm eval: channels / storage type");
+  SF_REQUIRE(x.c == y.c && ok8(x) && ok8(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm eval: channels (multiple of 8, 16-byte aligned) / storage type");
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(bn_eval_affine_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, x.c, creal, eps, gamma, beta, running_mean,
                      running_var, scale, shift);
   SF_CHECK_LAUNCH("bn_eval_affine");
-  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               (long long)pixels, (long long)pixels, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));
   SF_CHECK_LAUNCH("bn_apply");
   return 0;
@@ -468,14 +470,14 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
                            const float* mean, const float* rstd, double* sums, float* coef, sfTensor dx, float* dgamma, float* dbeta,
                            int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_bwd: dtype %d not built", dtype);
-  SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok4(dx) && x.dtype == dx.dtype, "batchnorm bwd: channels / storage type");
+  SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok8(x) && ok8(dy) && ok8(dx) && x.dtype == dx.dtype, "batchnorm bwd: channels (multiple of 8, 16-byte aligned) / storage type");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = bn_reduce_launch(1, x, dy, pix_per_group, groups, mean, rstd, sums, st)) return rc;
   const long long pixels = pix_per_group * groups;
   hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((groups * x.c + 255) / 256), dim3(256), 0, st, sums, groups, x.c, creal, (double)pix_per_group,
                      gamma, mean, rstd, coef);
   SF_CHECK_LAUNCH("bn_bwd_coef");
-  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 4))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               (const TA*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, (const float*)coef, (TA*)dx.ptr,
                                               dx.stride));
   SF_CHECK_LAUNCH("bn_bwd_apply");

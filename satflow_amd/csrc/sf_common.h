@@ -46,6 +46,23 @@ template <typename T> __device__ __forceinline__ void stv4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void stv4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void stv4<__bf16>(__bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }
 
+// 8-channel forms (one 16-byte access for bf16 storage)
+typedef float f32x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+template <typename T> __device__ __forceinline__ f32x8_t ldv8(const T* p);
+template <> __device__ __forceinline__ f32x8_t ldv8<float>(const float* p) {
+  const f32x4 a = *reinterpret_cast<const f32x4*>(p), b = *reinterpret_cast<const f32x4*>(p + 4);
+  return f32x8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+template <> __device__ __forceinline__ f32x8_t ldv8<__bf16>(const __bf16* p) {
+  return __builtin_convertvector(*reinterpret_cast<const bf16x8_t*>(p), f32x8_t);
+}
+template <typename T> __device__ __forceinline__ void stv8(T* p, f32x8_t v);
+template <> __device__ __forceinline__ void stv8<float>(float* p, f32x8_t v) {
+  *reinterpret_cast<f32x4*>(p) = f32x4{v[0], v[1], v[2], v[3]}; *reinterpret_cast<f32x4*>(p + 4) = f32x4{v[4], v[5], v[6], v[7]};
+}
+template <> __device__ __forceinline__ void stv8<__bf16>(__bf16* p, f32x8_t v) { *reinterpret_cast<bf16x8_t*>(p) = __builtin_convertvector(v, bf16x8_t); }
+
 #define SF_F32_ONLY(t, name) SF_REQUIRE((t).ptr == nullptr || (t).dtype == SF_F32, "%s: bf16 storage is not supported by this entry point", name)
 
 // ---- counter-based dropout masks ---------------------------------------------------------------------------------
