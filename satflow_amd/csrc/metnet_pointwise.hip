@@ -79,27 +79,33 @@ __device__ __forceinline__ long long perm_image(long long n, const OuterPerm& pm
 
 // DROP: the encoder-output dropouts (sf_dropout2's masks, indexed by the flat element index of the contiguous pooled tensor;
 // npt = pooled images per timestep for the period-reduced index of the sequence-consistent mask) applied on the way out
+// 8 channels per thread (one 16-byte access per bf16 tensor); the dropout masks are defined per channel quad: two per thread
+__device__ __forceinline__ f32x8_t drop_scales8(const sfDrop& dr, unsigned long long g, unsigned long long g2) {
+  const f32x4 a = sf_drop_scales(dr, g, g2), b = sf_drop_scales(dr, g + 1, g2 + 1);
+  return f32x8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+}
+
 template <typename TI, typename TO, bool DROP>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__ in, int is, long long N, int H, int W, int C,
                                                           TO* __restrict__ out, int os, const OuterPerm pm, const sfDrop dr, long long npt) {
-  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const int Ho = H / 2, Wo = W / 2, q = C / 8;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (idx % q) * 4;
+    const int c = (idx % q) * 8;
     const long long op = idx / q;
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long n = op / ((long long)Wo * Ho);
     const TI* p = in + ((n * H + 2 * yo) * W + 2 * xo) * is + c;
-    f32x4 m = ldv4(p);
-    const f32x4 v1 = ldv4(p + is), v2 = ldv4(p + (long long)W * is), v3 = ldv4(p + (long long)W * is + is);
+    f32x8_t m = ldv8(p);
+    const f32x8_t v1 = ldv8(p + is), v2 = ldv8(p + (long long)W * is), v3 = ldv8(p + (long long)W * is + is);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
+    for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
     const long long no = perm_image(n, pm);
     if constexpr (DROP) {
-      const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * q + c / 4), imgq = (unsigned long long)Ho * Wo * q;
-      m = m * sf_drop_scales(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
+      const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * (C / 4) + c / 4), imgq = (unsigned long long)Ho * Wo * (C / 4);
+      m = m * drop_scales8(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
     }
-    stv4(out + ((no * Ho + yo) * Wo + xo) * os + c, m);
+    stv8(out + ((no * Ho + yo) * Wo + xo) * os + c, m);
   }
 }
 
@@ -107,25 +113,25 @@ template <typename TI, typename TO, bool DROP>  // TI: input and its gradient, T
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__ in, int is, const TO* __restrict__ dout, int dos,
                                                           long long N, int H, int W, int C, TI* __restrict__ din, int dis,
                                                           const OuterPerm pm, const sfDrop dr, long long npt) {
-  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const int Ho = H / 2, Wo = W / 2, q = C / 8;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
-    const int c = (idx % q) * 4;
+    const int c = (idx % q) * 8;
     const long long op = idx / q;
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long n = op / ((long long)Wo * Ho);
     const long long base = (n * H + 2 * yo) * W + 2 * xo;
     const TI* p = in + base * is + c;
-    const f32x4 v0 = ldv4(p), v1 = ldv4(p + is), v2 = ldv4(p + (long long)W * is), v3 = ldv4(p + (long long)W * is + is);
+    const f32x8_t v0 = ldv8(p), v1 = ldv8(p + is), v2 = ldv8(p + (long long)W * is), v3 = ldv8(p + (long long)W * is + is);
     const long long no = perm_image(n, pm);
-    f32x4 g = ldv4(dout + ((no * Ho + yo) * Wo + xo) * dos + c);
+    f32x8_t g = ldv8(dout + ((no * Ho + yo) * Wo + xo) * dos + c);
     if constexpr (DROP) {
-      const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * q + c / 4), imgq = (unsigned long long)Ho * Wo * q;
-      g = g * sf_drop_scales(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
+      const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * (C / 4) + c / 4), imgq = (unsigned long long)Ho * Wo * (C / 4);
+      g = g * drop_scales8(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
     }
-    f32x4 g0, g1, g2, g3;
+    f32x8_t g0, g1, g2, g3;
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
+    for (int j = 0; j < 8; ++j) {
       // first maximum in row-major window order (the order torch's max_pool2d scans)
       int am = 0; float m = v0[j];
       if (v1[j] > m) { m = v1[j]; am = 1; }
@@ -134,7 +140,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
       g0[j] = am == 0 ? g[j] : 0.f; g1[j] = am == 1 ? g[j] : 0.f; g2[j] = am == 2 ? g[j] : 0.f; g3[j] = am == 3 ? g[j] : 0.f;
     }
     TI* d = din + base * dis + c;
-    stv4(d, g0); stv4(d + dis, g1); stv4(d + (long long)W * dis, g2); stv4(d + (long long)W * dis + dis, g3);
+    stv8(d, g0); stv8(d + dis, g1); stv8(d + (long long)W * dis, g2); stv8(d + (long long)W * dis + dis, g3);
   }
 }
 
@@ -147,24 +153,23 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TA* __restrict__ x
                                                         long long pix_per_group, int C, const float* __restrict__ mean,
                                                         const float* __restrict__ rstd, double* __restrict__ sums /*[G][2][C]*/) {
   extern __shared__ float red[];  // [2][rows][C]
-  const int q = C / 4;
+  const int q = C / 8;  // 8 channels per thread (one 16-byte access per bf16 tensor)
   const int rows = 256 / q > 0 ? 256 / q : 1;  // pixel rows handled concurrently
   const int g = blockIdx.y;
   const int cq = threadIdx.x % q, row = threadIdx.x / q;
   const bool active = row < rows;
-  f32x4 s0 = {0.f, 0.f, 0.f, 0.f}, s1 = {0.f, 0.f, 0.f, 0.f};
-  f32x4 mu = {0.f, 0.f, 0.f, 0.f}, rs = {1.f, 1.f, 1.f, 1.f};
-  if (MODE == 1 && active) { mu = ld4(mean + (long long)g * C + cq * 4); rs = ld4(rstd + (long long)g * C + cq * 4); }
+  f32x8_t s0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, s1 = s0, mu = s0, rs = s0;
+  if (MODE == 1 && active) { mu = ldv8(mean + (long long)g * C + cq * 8); rs = ldv8(rstd + (long long)g * C + cq * 8); }
   const long long chunk = (pix_per_group + gridDim.x - 1) / gridDim.x;
   const long long p0 = (long long)blockIdx.x * chunk, p1 = p0 + chunk < pix_per_group ? p0 + chunk : pix_per_group;
   if (active)
     for (long long p = p0 + row; p < p1; p += rows) {
       const long long gp = (long long)g * pix_per_group + p;
-      const f32x4 v = ldv4(x + gp * xs + cq * 4);
+      const f32x8_t v = ldv8(x + gp * xs + cq * 8);
       if (MODE == 0) { s0 += v; s1 += v * v; }
-      else { const f32x4 d = ldv4(dy + gp * dys + cq * 4); s0 += d; s1 += d * ((v - mu) * rs); }
+      else { const f32x8_t d = ldv8(dy + gp * dys + cq * 8); s0 += d; s1 += d * ((v - mu) * rs); }
     }
-  if (active) { st4(red + (0 * rows + row) * C + cq * 4, s0); st4(red + (1 * rows + row) * C + cq * 4, s1); }
+  if (active) { stv8(red + (0 * rows + row) * C + cq * 8, s0); stv8(red + (1 * rows + row) * C + cq * 8, s1); }
   __syncthreads();
   for (int i = threadIdx.x; i < 2 * C; i += 256) {
     const int which = i / C, c = i % C;
@@ -315,8 +320,8 @@ int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C,
 static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
                           const sfDrop* drop, int64_t period, hipStream_t st) {
   sfTensor& out = dout_or_out;
-  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == out.c && ok4(in) && ok4(out) && (!bwd || (in.c == din.c && ok4(din))),
-             "maxpool2: needs even H,W and matching 4-aligned channels");
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == out.c && ok8(in) && ok8(out) && (!bwd || (in.c == din.c && ok8(din))),
+             "maxpool2: needs even H,W and matching channels (multiple of 8, 16-byte aligned pixels)");
   SF_REQUIRE(in.dtype == out.dtype || (in.dtype == SF_BF16 && out.dtype == SF_F32), "maxpool2: unsupported storage pair %d -> %d", in.dtype, out.dtype);
   SF_REQUIRE(!bwd || in.dtype == din.dtype, "maxpool2 bwd: din must be stored like the input");
   OuterPerm pm{0, 0, 0};
@@ -324,7 +329,7 @@ static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n
     SF_REQUIRE(perm_t > 0 && n % ((long long)perm_l * perm_t) == 0, "maxpool2: n=%lld not divisible by perm dims %d x %d", (long long)n, perm_l, perm_t);
     pm = OuterPerm{perm_l, perm_t, (int)(n / ((long long)perm_l * perm_t))};
   }
-  const long long total = n * (h / 2) * (w / 2) * (in.c / 4);
+  const long long total = n * (h / 2) * (w / 2) * (in.c / 8);
   if (total == 0) return 0;
   sfDrop dr{};
   long long npt = 1;
@@ -391,10 +396,10 @@ int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, in
 static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, const float* mean,
                             const float* rstd, double* sums, hipStream_t st) {
   const int C = x.c;
-  SF_REQUIRE(C % 4 == 0 && C <= 1024 && ok4(x) && ok4(dy) && same_dtype(x, dy), "batchnorm: channels %d / storage types", C);
+  SF_REQUIRE(C % 8 == 0 && C <= 2048 && ok8(x) && ok8(dy) && same_dtype(x, dy), "batchnorm: channels %d (multiple of 8, 16-byte aligned) / storage types", C);
   hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * groups, st);
   SF_REQUIRE(e == hipSuccess, "batchnorm: memset failed");
-  const int q = C / 4, rows = 256 / q > 0 ? 256 / q : 1;
+  const int q = C / 8, rows = 256 / q > 0 ? 256 / q : 1;
   long long chunks = pix_per_group / (rows * 16);
   if (chunks < 1) chunks = 1;
   if (chunks > 256) chunks = 256;
