@@ -129,7 +129,13 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const unsigned b_px0 = (unsigned)p.s0 * ESZ, b_px1 = (unsigned)p.s1 * ESZ;
     const unsigned b_const0 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s0 + kcb) * ESZ;
     const unsigned b_const1 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s1 + (kcb - p.c0)) * ESZ;
-    struct Stage { VT va[2][8], vb[10], vb1[MIXED ? 10 : 1]; };
+    // bf16 storage: dout is fetched as 16-byte channel OCTETS, one item (octet 16, row 8, half 2) per loader thread - half
+    // the load instructions of the quad form for the same registers; fp32 storage keeps two quad items per thread.
+    struct Stage { VT va[2][8]; u32x4 va8[BF ? 8 : 1]; VT vb[10], vb1[MIXED ? 10 : 1]; };
+    const int o_oct = lt % 16, o_rest = lt / 16, o_half = o_rest & 1, o_row = o_rest >> 1;
+    const int oco = cot * CO_T + o_oct * 8;
+    const unsigned o_const = (unsigned)((o_row * p.W + 8 * o_half) * p.ds + oco) * ESZ;
+    float bsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto ld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) -> VT {
 #ifdef SF_EXP_WG_NOLOAD
       return VT{};
@@ -156,11 +162,18 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
         const char* base = (const char*)p.dout + (long long)n * p.H * p.W * a_px;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)(p.H * p.W) * a_px), 0x00020000);
         const unsigned so = tile_px * a_px;
+        if constexpr (BF) {
+          const int lim = (oco < p.dc && y0 + o_row < p.H) ? p.W - x0 - 8 * o_half : 0;  // pixels j < lim are inside the image
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-          const int lim = (a_ok && y0 + a_row[u] < p.H) ? p.W - x0 - 8 * a_half[u] : 0;  // pixels j < lim are inside the image
+          for (int j = 0; j < 8; ++j)
+            s.va8[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, j < lim ? o_const : SENT, so + j * a_px, 0));
+        } else {
 #pragma unroll
-          for (int j = 0; j < 8; ++j) s.va[u][j] = ld(rs, j < lim ? a_const[u] : SENT, so + j * a_px);
+          for (int u = 0; u < 2; ++u) {
+            const int lim = (a_ok && y0 + a_row[u] < p.H) ? p.W - x0 - 8 * a_half[u] : 0;  // pixels j < lim are inside the image
+#pragma unroll
+            for (int j = 0; j < 8; ++j) s.va[u][j] = ld(rs, j < lim ? a_const[u] : SENT, so + j * a_px);
+          }
         }
       }
       // input halo tile: items (cq 8, halo row 10, half 2) = 160 items; pixels x0-1+8*half .. +9
@@ -194,6 +207,26 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       char* la = lds + (i & 1) * BUF;
       char* lb = la + A_BYTES;
       char* lh = lb + B_BYTES;
+      if constexpr (BF) {
+        const u32x4 (&v8)[8] = s.va8;
+        if (cit == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j)
+#pragma unroll
+            for (int c8 = 0; c8 < 8; ++c8) {
+              const unsigned d = v8[j][c8 >> 1];
+              bsum8[c8] += __builtin_bit_cast(float, (c8 & 1) ? (d & 0xffff0000u) : (d << 16));
+            }
+        }
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) {
+          const int quad = 2 * o_oct + (c8 >> 2), d = c8 >> 1;
+          const unsigned sel = (c8 & 1) ? 0x07060302u : 0x05040100u;
+          char* dst = la + quad * A_S + (o_row * 2 + o_half) * 64 + quad_slot(quad, c8 & 3);
+          *reinterpret_cast<u32x4*>(dst) = u32x4{__builtin_amdgcn_perm(v8[1][d], v8[0][d], sel), __builtin_amdgcn_perm(v8[3][d], v8[2][d], sel),
+                                                 __builtin_amdgcn_perm(v8[5][d], v8[4][d], sel), __builtin_amdgcn_perm(v8[7][d], v8[6][d], sel)};
+        }
+      } else
 #pragma unroll
       for (int u = 0; u < 2; ++u) {
         const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
@@ -271,7 +304,12 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     // bias gradient: 8 loader threads share a channel quad
     if (cit == 0) {
       float* red = reinterpret_cast<float*>(lds);
-      *reinterpret_cast<f32x4*>(red + lt * 4) = bsum;
+      if constexpr (BF) {  // [rest 16][channel 128]
+#pragma unroll
+        for (int c8 = 0; c8 < 8; ++c8) red[o_rest * CO_T + o_oct * 8 + c8] = bsum8[c8];
+      } else {
+        *reinterpret_cast<f32x4*>(red + lt * 4) = bsum;
+      }
     }
     __syncthreads();
   } else {
@@ -350,7 +388,11 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       const float* red = reinterpret_cast<const float*>(lds);
       const int cq = tid / 4, c = tid % 4;
       float s = 0.f;
-      for (int k = 0; k < LOADERS / 32; ++k) s += red[(k * 32 + cq) * 4 + c];
+      if constexpr (BF) {
+        for (int k = 0; k < LOADERS / 16; ++k) s += red[k * CO_T + tid];
+      } else {
+        for (int k = 0; k < LOADERS / 32; ++k) s += red[(k * 32 + cq) * 4 + c];
+      }
       p.partial_db[(size_t)ks * p.NpT + cot * CO_T + tid] = s;
     }
   }
