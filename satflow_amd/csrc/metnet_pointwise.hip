@@ -40,22 +40,35 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
     const int b = j % B, t = j / B;
     const float* src = imgs + ((long long)b * T + t) * C * H * W;
     TO* dst = out + idx * os;
-    for (int c = 0; c < sat; ++c) {
-      const float* ch = src + (long long)c * H * W;
-      f32x4 ctr, mean;
+    // 4 satellite channels per round: all their loads (4 float4 rows of the 4x4 raw window + 2 float2 rows of the centre-crop
+    // window each, channel index clamped) are issued before the first store - hipcc otherwise serialises load -> wait -> store
+    // per channel, and vmcnt counts the stores too
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    for (int c0 = 0; c0 < sat; c0 += 4) {
+      f32x4 R[4][4]; f32x2_t Ct[4][2];
 #pragma unroll
-      for (int d = 0; d < 4; ++d) {
-        const int dh = d >> 1, dw = d & 1;
-        ctr[d] = ch[(long long)(2 * (y + top) + dh) * W + 2 * (x + left) + dw];
-        float s = 0.f;
+      for (int u = 0; u < 4; ++u) {
+        const float* ch = src + (long long)(c0 + u < sat ? c0 + u : sat - 1) * H * W;
 #pragma unroll
-        for (int a = 0; a < 2; ++a)
+        for (int a = 0; a < 4; ++a) R[u][a] = *reinterpret_cast<const f32x4*>(ch + (long long)(4 * y + a) * W + 4 * x);
 #pragma unroll
-          for (int bb = 0; bb < 2; ++bb) s += ch[(long long)(4 * y + 2 * a + dh) * W + 4 * x + 2 * bb + dw];
-        mean[d] = s * 0.25f;
+        for (int dh = 0; dh < 2; ++dh) Ct[u][dh] = *reinterpret_cast<const f32x2_t*>(ch + (long long)(2 * (y + top) + dh) * W + 2 * (x + left));
       }
-      stv4(dst + c * 4, ctr);
-      stv4(dst + 4 * sat + c * 4, mean);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (c0 + u < sat) {
+          const int c = c0 + u;
+          f32x4 ctr, mean;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const int dh = d >> 1, dw = d & 1;
+            ctr[d] = Ct[u][dh][dw];
+            mean[d] = ((R[u][dh][dw] + R[u][dh][2 + dw]) + (R[u][2 + dh][dw] + R[u][2 + dh][2 + dw])) * 0.25f;
+          }
+          stv4(dst + c * 4, ctr);
+          stv4(dst + 4 * sat + c * 4, mean);
+        }
+      }
     }
     for (int c = sat; c < C; ++c) {
       const float* ch = src + (long long)c * H * W;
