@@ -27,12 +27,16 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int HALO_W = TILE_W + 2;  // 18
 constexpr int PIX_B = 32;           // bytes per pixel / per weight row in LDS (16 bf16)
 
-template <int WAVES, int NF, int EPI>
+// DUAL (8 waves, images of at most 16x16 pixels): the 32x16 tile is TWO consecutive images, waves 0-3 on the first and
+// 4-7 on the second, each image with its own halo rows in LDS (2 x 18 rows) - small images keep the 8-wave workgroup's
+// weight reuse and occupancy instead of dropping to the 4-wave 16x16 kernel.
+template <int WAVES, int NF, int EPI, bool DUAL = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
+  static_assert(!DUAL || WAVES == 8, "dual-image tiles are an 8-wave layout");
   constexpr int NB = 32 * NF;
   constexpr int THREADS = WAVES * 64;
   constexpr int TH = 4 * WAVES;            // tile rows
-  constexpr int HALO_H = TH + 2;
+  constexpr int HALO_H = DUAL ? 36 : TH + 2;
   constexpr int IN_B = HALO_H * HALO_W * PIX_B;
   constexpr int W_B = 9 * NB * PIX_B;
   constexpr int PIECES = HALO_H * HALO_W * 2;                 // 16-byte bf16 pieces of the halo tile
@@ -54,10 +58,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     tile = (j / (int)gridDim.y) * 8 + xcd;
     nb = j % (int)gridDim.y;
   } else { tile = blockIdx.x; nb = blockIdx.y; }
-  const int tx = tile % p.tiles_x; tile /= p.tiles_x;
-  const int ty = tile % p.tiles_y;
-  const int n = tile / p.tiles_y;
+  const int tx = DUAL ? 0 : tile % p.tiles_x; if (!DUAL) tile /= p.tiles_x;
+  const int ty = DUAL ? 0 : tile % p.tiles_y;
+  const int n = DUAL ? 2 * tile : tile / p.tiles_y;  // (first) image of the tile
   const int x0 = tx * TILE_W, y0 = ty * TH;
+  const int img = DUAL ? wave >> 2 : 0, wl = DUAL ? wave & 3 : wave;  // this wave's image within the tile / its 4-row band
+  const int n_w = n + img;
+  // halo-tile pixel -> source pixel; false outside the image (or past the last image of a dual tile)
+  auto halo = [&](int pix, int& ni, int& gy, int& gx, int& iy) -> bool {
+    iy = pix / HALO_W;
+    const int ix = pix - iy * HALO_W;
+    const int sel = DUAL ? (iy >= 18 ? 1 : 0) : 0;
+    ni = n + sel; gy = y0 + (iy - 18 * sel) - 1; gx = x0 + ix - 1;
+    return ni < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+  };
 
   f32x16 acc[2][NF];
 #pragma unroll
@@ -84,18 +98,19 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
                                        (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
   };
   auto load_input = [&](int ci) {  // fp32-stored source: registers now, bf16 conversion + ds_write after the chunk's MFMAs
-    const float* src; int cbase, stride, ns;
-    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
-    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
+    const float* src; int cbase, stride, idiv, imod;
+    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; idiv = p.idiv0; imod = p.imod0; }
+    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; idiv = p.idiv1; imod = p.imod1; }
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;
-      const int pix = pc >> 1, half = pc & 1;
-      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
-      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      int ni, gy, gx, iy;
+      const bool ok = halo(pc >> 1, ni, gy, gx, iy) && pc < PIECES;
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
-        v = *reinterpret_cast<const f32x8*>(src + ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + half * 8);
+      if (ok) {
+        int ns = ni / idiv; if (imod) ns %= imod;
+        v = *reinterpret_cast<const f32x8*>(src + ((size_t)(ns * p.H + gy) * p.W + gx) * stride + cbase + (pc & 1) * 8);
+      }
       inreg[j] = v;
     }
   };
@@ -116,20 +131,20 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   // the bank swizzle of the register path).  Halo pixels outside the image are never written by the DMA (lanes
   // masked off): their slots are zeroed once per block, below.
   auto dma_input = [&](int ci, int buf) {
-    const float* src; int cbase, stride, ns;
-    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; ns = n / p.idiv0; if (p.imod0) ns %= p.imod0; }
-    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; ns = n / p.idiv1; if (p.imod1) ns %= p.imod1; }
-    const __bf16* img = reinterpret_cast<const __bf16*>(src) + (size_t)ns * p.H * p.W * stride + cbase;
+    const float* src; int cbase, stride, idiv, imod;
+    if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; idiv = p.idiv0; imod = p.imod0; }
+    else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; idiv = p.idiv1; imod = p.imod1; }
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;  // = (wave + j*WAVES) * 64 + lane: one wave-instruction fills 64 consecutive slots
-      const int pix = pc >> 1, hphys = pc & 1;
-      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
-      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
-      if (pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)
+      int ni, gy, gx, iy;
+      if (halo(pc >> 1, ni, gy, gx, iy) && pc < PIECES) {
+        int ns = ni / idiv; if (imod) ns %= imod;
+        const __bf16* img_p = reinterpret_cast<const __bf16*>(src) + (size_t)ns * p.H * p.W * stride + cbase;
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(img + (size_t)(gy * p.W + gx) * stride + 8 * (hphys ^ (iy & 1))),
+            (const __attribute__((address_space(1))) void*)(img_p + (size_t)(gy * p.W + gx) * stride + 8 * ((pc & 1) ^ (iy & 1))),
             (__attribute__((address_space(3))) void*)(lds_in + buf * IN_B + (wave + j * WAVES) * 1024), 16, 0, 0);
+      }
     }
   };
   auto stage_input = [&](int ci) {  // issue side of the next chunk's input staging
@@ -141,10 +156,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;
-      const int pix = pc >> 1;
-      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
-      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
-      if (pc < PIECES && !(gy >= 0 && gy < p.H && gx >= 0 && gx < p.W)) {
+      int ni, gy, gx, iy;
+      if (!halo(pc >> 1, ni, gy, gx, iy) && pc < PIECES) {
         *reinterpret_cast<f32x4*>(lds_in + pc * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
         *reinterpret_cast<f32x4*>(lds_in + IN_B + pc * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
       }
@@ -159,7 +172,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 
   // per-lane LDS offsets
   const int rowpar = (r >> 4) & 1;
-  const int a_lane = ((4 * wave + (r >> 4)) * HALO_W + (r & 15)) * PIX_B;
+  const int a_lane = (((DUAL ? 18 * img : 0) + 4 * wl + (r >> 4)) * HALO_W + (r & 15)) * PIX_B;
   const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);  // by parity of ky
   const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
 
@@ -239,7 +252,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   // optional per-tile BatchNorm statistics of the stored outputs (linear epilogue): lane sums -> LDS (the operand
   // buffers are free once every wave has left the K loop) -> one [32*NF][2] record per workgroup
   float* lds_stats = nullptr;
-  if constexpr (EPI == EPI_LINEAR) {
+  if constexpr (EPI == EPI_LINEAR && !DUAL) {
     if (p.stats) {
       __syncthreads();
       lds_stats = reinterpret_cast<float*>(lds);
@@ -247,8 +260,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       __syncthreads();
     }
   }
-  conv_epilogue<NF, EPI>(acc, p, n, nb, y0, x0, wave, r, kh, lds_stats);
-  if constexpr (EPI == EPI_LINEAR) {
+  if (!DUAL || n_w < p.N) conv_epilogue<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh, lds_stats);
+  if constexpr (EPI == EPI_LINEAR && !DUAL) {
     if (lds_stats) {
       __syncthreads();
       const size_t tile_lin = (size_t)(n * p.tiles_y + ty) * p.tiles_x + tx;
@@ -288,26 +301,26 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int
     }
 }
 
-template <int WAVES, int EPI>
+template <int WAVES, int EPI, bool DUAL = false>
 int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
   ConvParams p = p0;
   constexpr int TH = 4 * WAVES;
-  p.tiles_x = (p.W + TILE_W - 1) / TILE_W;
-  p.tiles_y = (p.H + TH - 1) / TH;
-  dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(WAVES * 64);
+  p.tiles_x = DUAL ? 1 : (p.W + TILE_W - 1) / TILE_W;
+  p.tiles_y = DUAL ? 1 : (p.H + TH - 1) / TH;
+  dim3 grid(DUAL ? (p.N + 1) / 2 : p.tiles_x * p.tiles_y * p.N, nblk), block(WAVES * 64);
   if constexpr (EPI == EPI_LSTM) {
     if (nf != 4) { sf_set_error("bf16 conv: LSTM epilogue needs nf=4"); return 1; }
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL>), grid, block, 0, st, p);
   } else if constexpr (EPI == EPI_GRU) {
     if (nf != 3) { sf_set_error("bf16 conv: GRU epilogue needs nf=3"); return 1; }
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL>), grid, block, 0, st, p);
   } else {
     switch (nf) {
-      case 1: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 1, EPI>), grid, block, 0, st, p); break;
-      case 2: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 2, EPI>), grid, block, 0, st, p); break;
-      case 3: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI>), grid, block, 0, st, p); break;
-      case 4: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI>), grid, block, 0, st, p); break;
-      case 5: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 5, EPI>), grid, block, 0, st, p); break;
+      case 1: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 1, EPI, DUAL>), grid, block, 0, st, p); break;
+      case 2: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 2, EPI, DUAL>), grid, block, 0, st, p); break;
+      case 3: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL>), grid, block, 0, st, p); break;
+      case 4: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL>), grid, block, 0, st, p); break;
+      case 5: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 5, EPI, DUAL>), grid, block, 0, st, p); break;
       default: sf_set_error("bf16 conv: unsupported nf=%d", nf); return 1;
     }
   }
@@ -318,8 +331,13 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
 
 template <int EPI>
 int launch_e(const ConvParams& p, int nf, int nblk, hipStream_t st) {
-  // 8-wave 32x16 tiles when the image has at least 32 rows to fill them, else 4-wave 16x16 tiles
-  return p.H > 16 ? launch_w<8, EPI>(p, nf, nblk, st) : launch_w<4, EPI>(p, nf, nblk, st);
+  // 8-wave 32x16 tiles when the image has more than 16 rows.  Images of at most 16x16 pixels: 4-wave 16x16 tiles, except
+  // where that kernel fits only one workgroup per CU (NF >= 4: 94 KB LDS) and there are enough images to fill the chip
+  // with 8-wave workgroups holding two images each (measured 192->256 @16x16 x 2304: 811 -> 574 us; NF = 3 and the
+  // 96-image ConvGRU steps are faster on the 4-wave kernel)
+  if (p.H > 16) return launch_w<8, EPI>(p, nf, nblk, st);
+  if (p.W <= 16 && !p.stats && nf >= 4 && p.N >= 512) return launch_w<8, EPI, true>(p, nf, nblk, st);
+  return launch_w<4, EPI>(p, nf, nblk, st);
 }
 
 }  // namespace

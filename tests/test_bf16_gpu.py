@@ -200,3 +200,36 @@ def test_conv_epilogue_statistics_feed_batchnorm(device, storage, cin, cout, n, 
             assert float((d > 2.0**-7 * o2.float().abs() + 1e-6).float().mean()) == 0.0  # at most 1 bf16 ulp apart
     finally:
         satflow_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("storage", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("cin,cout,n,h,w", [(32, 128, 513, 16, 16), (16, 256, 512, 9, 12)])
+def test_conv3x3_dual_image_tiles(device, storage, cin, cout, n, h, w):
+    """Many small images with >= 128 output channels take the dual-image layout of the 8-wave kernel (two images per 32x16
+    tile; odd image count: the last tile is half empty).  Forward and input gradient against the oracle on rounded operands."""
+    import satflow_amd
+    from satflow_amd.functional import ConvEngine, conv3x3, nchw_to_nhwc, nhwc_to_nchw
+
+    satflow_amd.set_compute_dtype("bf16a" if storage == torch.bfloat16 else "bf16")
+    try:
+        g = torch.Generator().manual_seed(n + cin)
+        x = torch.randn(n, cin, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin**0.5)
+        b = torch.randn(cout, generator=g)
+        cot = torch.randn(n, cout, h, w, generator=g)
+        xr, wr = _r(x).requires_grad_(), _r(wt)
+        ref = TF.conv2d(xr, wr, b, padding=1)
+        dx_ref = torch.autograd.grad(TF.conv2d(xr, wr, None, padding=1), xr, _r(cot))[0]
+        xd = nchw_to_nhwc(x.to(device)).to(storage).requires_grad_()
+        y = conv3x3(ConvEngine([cin], cout), xd, wt.to(device), b.to(device), out_dtype=storage)
+        y.backward(nchw_to_nhwc(cot.to(device)).to(storage))  # dgrad: cout -> cin (NF = 1: not dual) - checks the pair
+        yn, dxn = nhwc_to_nchw(y.detach().float().contiguous(), cout).cpu(), nhwc_to_nchw(xd.grad.float().contiguous(), cin).cpu()
+        if storage == torch.float32:
+            assert_close(yn, ref, "dual-tile conv")
+            assert_close(dxn, dx_ref, "its dgrad", grad=True)
+        else:
+            for got, want in ((yn, ref.detach()), (dxn, dx_ref)):
+                scale = float(want.abs().max())
+                assert float(((got - want).abs() - (2.0**-8 * want.abs() + 1e-6 * scale)).max()) <= 0
+    finally:
+        satflow_amd.set_compute_dtype("f32")
