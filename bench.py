@@ -85,7 +85,7 @@ class ConvLSTMWorkload:
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # per-rank data shard
         self.x = torch.rand(self.B, self.T, self.C, self.H, self.W, generator=g).to(dev)
         self.y = torch.rand(self.B, self.fs, self.out, self.H, self.W, generator=g).to(dev)
-        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr)
+        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr, overlap=not os.environ.get("SF_NO_OVERLAP"))
         self.dev = dev
 
     def step(self):
@@ -98,7 +98,7 @@ class ConvLSTMWorkload:
     def config(self, world):
         return {"workload": "EncoderDecoderConvLSTM 12ch 128x128 T=12->6 hidden=64 out=12 (BASELINE configs[1])",
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
-                "step": "fwd + mse + bwd + allreduce + adam"}
+                "step": "fwd + mse + bwd (gradient slices all-reduced from autograd hooks as they complete) + adam"}
 
     def roofline(self):
         """Dominant kernel: the fused 128->256 ConvLSTM cell step (3 of the 4 cells, 24 of 36 launches)."""
@@ -151,7 +151,7 @@ class MetNetWorkload:
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.x = torch.randn(self.B, self.T, self.C, self.raw, self.raw, generator=g).to(dev)
         self.y = torch.randn(self.B, self.L, self.out, 16, 16, generator=g).to(dev)
-        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr)
+        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr, overlap=not os.environ.get("SF_NO_OVERLAP"))
         self.dev, self.dropout = dev, dropout
 
     def step(self):
@@ -165,7 +165,7 @@ class MetNetWorkload:
         return {"workload": "LitMetNet 12ch 256x256 T=24 -> 12 lead times, hidden 64, downsampler encoder, 1 ConvGRU layer, "
                             "1 axial-attention layer (BASELINE configs[2]; configs[3] at 8 GPUs)",
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
-                "temporal_dropout": self.dropout, "step": "fwd + mse + bwd + allreduce + adam"}
+                "temporal_dropout": self.dropout, "step": "fwd + mse + bwd (gradient slices all-reduced from autograd hooks as they complete) + adam"}
 
     def roofline(self):
         """Dominant kernel: the 256->256 3x3 convolution at 32x32 (DownSampler conv3/conv4 forward and their

@@ -25,7 +25,8 @@ class FlatAdam:
     gradient mean when a process group is given (SUM all-reduce, 1/world folded into the update)."""
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
-                 process_group: Optional["dist.ProcessGroup"] = None, distributed: Optional[bool] = None) -> None:
+                 process_group: Optional["dist.ProcessGroup"] = None, distributed: Optional[bool] = None,
+                 overlap: bool = False, buckets: int = 3) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert self.params, "no parameters"
         dev = self.params[0].device
@@ -49,17 +50,72 @@ class FlatAdam:
         self.group = process_group
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
         self.world = dist.get_world_size(process_group) if self.distributed else 1
+        # Overlap of the gradient exchange with the backward pass (reference: Lightning DDP's bucketed all-reduce fired from
+        # autograd hooks).  The flat gradient is cut at parameter boundaries into `buckets` contiguous slices of about
+        # equal size; parameters sit in the buffer in module order, the backward pass finishes them in reverse order, so the
+        # LAST slice (head / attention / recurrent cells) completes first and its all-reduce runs on RCCL's stream while
+        # the encoder's backward is still computing.  A slice is launched when every parameter in it has received its
+        # gradient (post-accumulate hooks); `step()` waits for the launched ones and reduces whatever was not launched.
+        self.overlap = bool(overlap) and self.distributed and self.world > 1
+        self._bucket_of: List[int] = []
+        self._bucket_range: List[List[int]] = []
+        self._pending: List[int] = []
+        self._work: dict = {}
+        self._done = False
+        if self.overlap:
+            nb = max(1, min(int(buckets), len(self.params)))
+            target, b, lo = total / nb, 0, 0
+            for i, (p, off) in enumerate(zip(self.params, self.offsets)):
+                end = off + _round_up(p.numel(), 4)
+                self._bucket_of.append(b)
+                last = i + 1 == len(self.params)
+                if last or (end >= (b + 1) * target and b + 1 < nb):
+                    self._bucket_range.append([lo, end])
+                    lo, b = end, b + 1
+            self._count = [self._bucket_of.count(k) for k in range(len(self._bucket_range))]
+            self._pending = list(self._count)
+            self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(self._bucket_of[i])) for i, p in enumerate(self.params)]
+
+    def disable_overlap(self) -> None:
+        """Back to one all-reduce after the backward pass (removes the autograd hooks)."""
+        for h in getattr(self, "_hooks", []):
+            h.remove()
+        self._hooks, self._work, self.overlap = [], {}, False
+
+    def _make_hook(self, k: int):
+        def hook(_param) -> None:
+            self._pending[k] -= 1
+            if self._pending[k] == 0 and k not in self._work:
+                lo, hi = self._bucket_range[k]
+                self._work[k] = dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
+        return hook
 
     def zero_grad(self) -> None:
         self.flat_g.zero_()
+        if self.overlap:
+            self._pending, self._work, self._done = list(self._count), {}, False
         for p, off in zip(self.params, self.offsets):  # re-attach if autograd replaced .grad
             if p.grad is None or p.grad.data_ptr() != self.flat_g.data_ptr() + 4 * off:
                 p.grad = self.flat_g[off : off + p.numel()].view(p.shape)
 
     def allreduce_grads(self) -> None:
-        """One SUM all-reduce of the whole gradient (4-9 MB: latency-bound, one bucket)."""
-        if self.distributed and self.world > 1:
+        """SUM all-reduce of the gradient: one call over the whole flat buffer (4-9 MB: latency-bound), or - with
+        ``overlap`` - completion of the per-slice reductions the backward pass already launched."""
+        if not (self.distributed and self.world > 1):
+            return
+        if not self.overlap:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
+            return
+        if self._done:
+            return
+        self._done = True
+        for k, (lo, hi) in enumerate(self._bucket_range):
+            if k in self._work:
+                self._work[k].wait()
+            else:  # some parameter of the slice got no gradient this step (unused): reduce it now
+                dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
+        self._work = {}
 
     def step(self) -> None:
         if not self.flat_p.is_cuda:

@@ -61,3 +61,53 @@ def test_flat_gradient_allreduce_world2():
             p.join(120)
             assert p.exitcode == 0
         assert dict(out) == {0: True, 1: True}
+
+
+def _worker_overlap(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from satflow_amd.optim import FlatAdam
+
+    torch.manual_seed(0)  # identical replicas
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.Tanh(), torch.nn.Linear(16, 16), torch.nn.Tanh(), torch.nn.Linear(16, 3),
+                              torch.nn.Linear(3, 2))
+    unused = torch.nn.Parameter(torch.ones(5))  # never receives a gradient: its slice must still be reduced (as zeros)
+    opt = FlatAdam(list(net.parameters()) + [unused], lr=1e-3, overlap=True, buckets=3)
+    ok = opt.overlap and len(opt._bucket_range) == 3 and opt._bucket_range[0][0] == 0 and opt._bucket_range[-1][1] == opt.numel
+    ok = ok and all(a[1] == b[0] for a, b in zip(opt._bucket_range, opt._bucket_range[1:]))
+    for step in range(2):  # two steps: the launch bookkeeping must reset
+        opt.zero_grad()
+        x = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + rank))  # this rank's shard
+        net(x).square().sum().backward()  # hooks fire here: slices are reduced while the backward is still running
+        launched = sorted(opt._work)
+        ok = ok and len(launched) >= 2  # every slice made only of `net` parameters went out during backward
+        opt.allreduce_grads()
+        opt.allreduce_grads()  # idempotent until the next zero_grad
+        # reference: plain autograd on both shards
+        ref = torch.nn.Sequential(*[type(m)(*((m.in_features, m.out_features) if isinstance(m, torch.nn.Linear) else ())) for m in net])
+        ref.load_state_dict(net.state_dict())
+        for r in range(world):
+            xr = torch.randn(4, 6, generator=torch.Generator().manual_seed(10 * step + r))
+            ref(xr).square().sum().backward()
+        for p, q in zip(net.parameters(), ref.parameters()):
+            ok = ok and torch.allclose(p.grad, q.grad, rtol=1e-5, atol=1e-6)
+        ok = ok and float(unused.grad.abs().max()) == 0.0
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_overlapped_bucketed_allreduce_world2():
+    """`FlatAdam(overlap=True)`: gradient slices are all-reduced from autograd hooks while the backward pass runs (the
+    reference's Lightning-DDP behaviour, configs/trainer/ddp.yaml:4-5); result == sum of the per-rank gradients."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_worker_overlap, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert dict(out) == {0: True, 1: True}
