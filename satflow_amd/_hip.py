@@ -177,6 +177,12 @@ def compute_dtype_name() -> str:
     return "f32"
 
 
+def gate_storage_dtype():
+    """torch dtype the ConvLSTM stack keeps its saved gates / gate gradients in (bf16 in "bf16a" mode; they are read by the
+    backward pass only: forward results do not depend on it).  Hidden and cell states stay fp32."""
+    return torch.bfloat16 if _ENCODER_BF16[0] else torch.float32
+
+
 def encoder_storage_dtype():
     """torch dtype the MetNet image encoder keeps its activations in (bf16 only in "bf16a" mode)."""
     return torch.bfloat16 if _ENCODER_BF16[0] else torch.float32

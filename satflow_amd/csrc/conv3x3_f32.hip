@@ -255,7 +255,8 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
   if (check_src(x, "convlstm x") || check_src(h_prev, "convlstm h_prev")) return 1;
   SF_F32_ONLY(x, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_prev, "sf_convlstm_cell_fwd");
-  SF_F32_ONLY(h_out, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_out, "sf_convlstm_cell_fwd"); SF_F32_ONLY(gates, "sf_convlstm_cell_fwd");
+  SF_F32_ONLY(h_out, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_out, "sf_convlstm_cell_fwd");
+  SF_REQUIRE(!gates.ptr || gates.dtype == SF_F32 || gates.dtype == SF_BF16, "sf_convlstm_cell_fwd: gates storage type %d", gates.dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp, "convlstm: hidp=%d h_prev.c=%d", hidp, h_prev.c);
   SF_REQUIRE(x.ptr && h_out.ptr && c_out.ptr, "convlstm: x, h_out, c_out must be non-null");
   ConvParams p{};
@@ -267,7 +268,7 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   p.c_prev = (const float*)c_prev.ptr; p.cprev_s = c_prev.stride;
   p.c_out = (float*)c_out.ptr; p.cout_s = c_out.stride;
   p.h_out = (float*)h_out.ptr; p.hout_s = h_out.stride;
-  p.gates = (float*)gates.ptr; p.gates_s = gates.stride;
+  p.gates = (float*)gates.ptr; p.gates_s = gates.stride; p.gates_bf = gates.ptr && gates.dtype == SF_BF16;
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
   if (dtype == SF_BF16) return sf_launch_conv_bf16(p, 4, nblk, EPI_LSTM, (hipStream_t)stream);

@@ -68,10 +68,12 @@ __device__ __forceinline__ unsigned chan_bits(u32x2 px, int c) {  // bf16 bits o
   return (c & 1) ? d >> 16 : d & 0xffffu;
 }
 
-template <bool BF, bool MIXED>
+// ABF / BBF: storage type of dout (the A operand) / of the input sources (the B operand).  (true, false) is the ConvLSTM's
+// "bf16a" combination: bf16-stored gate gradients against fp32 inputs and hidden states.
+template <bool ABF, bool BBF, bool MIXED>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParams p, const int xcd_groups) {
-  using VT = std::conditional_t<BF, u32x2, u32x4>;   // one pixel's channel quad as loaded (raw bits)
-  using ET = std::conditional_t<BF, __bf16, float>;  // element type behind the tensor pointers
+  using VA = u32x4;                                    // fp32 dout: one pixel's channel quad (raw bits); bf16 dout uses octets
+  using VT = std::conditional_t<BBF, u32x2, u32x4>;   // input source: one pixel's channel quad as loaded (raw bits)
   __shared__ __attribute__((aligned(16))) char lds[2 * BUF];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -111,14 +113,14 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const bool b_item = lt < 8 * HR * 2;
     const int brest = lt / 8, bhalf = brest & 1, bhrow = brest >> 1;
     constexpr unsigned SENT = 0x80000000u;  // >= any descriptor's num_records (host checks image bytes < 2^31)
-    constexpr int ESZ = sizeof(ET);
-    const unsigned a_px = (unsigned)p.ds * ESZ;
+    constexpr int ESZ = BBF ? 2 : 4, ESZ_A = ABF ? 2 : 4;
+    const unsigned a_px = (unsigned)p.ds * ESZ_A;
     unsigned a_const[2]; int a_row[2], a_half[2];
 #pragma unroll
     for (int u = 0; u < 2; ++u) {
       const int rest = (lt + u * LOADERS) / 32;
       a_half[u] = rest & 1; a_row[u] = rest >> 1;
-      a_const[u] = (unsigned)((a_row[u] * p.W + 8 * a_half[u]) * p.ds + aco) * ESZ;
+      a_const[u] = (unsigned)((a_row[u] * p.W + 8 * a_half[u]) * p.ds + aco) * ESZ_A;
     }
     // The block's 32 input channels come from ONE source unless c0 is not a multiple of 32 (MIXED kernels: the ConvLSTM's
     // 16-lane x source).  Plain kernels pick the source with scalar selects - no branch near the loads; MIXED kernels
@@ -131,16 +133,16 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const unsigned b_const1 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s1 + (kcb - p.c0)) * ESZ;
     // bf16 storage: dout is fetched as 16-byte channel OCTETS, one item (octet 16, row 8, half 2) per loader thread - half
     // the load instructions of the quad form for the same registers; fp32 storage keeps two quad items per thread.
-    struct Stage { VT va[2][8]; u32x4 va8[BF ? 8 : 1]; VT vb[10], vb1[MIXED ? 10 : 1]; };
+    struct Stage { VA va[ABF ? 1 : 2][ABF ? 1 : 8]; u32x4 va8[ABF ? 8 : 1]; VT vb[10], vb1[MIXED ? 10 : 1]; };
     const int o_oct = lt % 16, o_rest = lt / 16, o_half = o_rest & 1, o_row = o_rest >> 1;
     const int oco = cot * CO_T + o_oct * 8;
-    const unsigned o_const = (unsigned)((o_row * p.W + 8 * o_half) * p.ds + oco) * ESZ;
+    const unsigned o_const = (unsigned)((o_row * p.W + 8 * o_half) * p.ds + oco) * ESZ_A;
     float bsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto ld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) -> VT {
 #ifdef SF_EXP_WG_NOLOAD
       return VT{};
 #endif
-      if constexpr (BF) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
+      if constexpr (BBF) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
       else return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
     // descriptor of image `ns` of a source, starting one image row + one pixel BEFORE the image so that lane offsets are
@@ -162,7 +164,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
         const char* base = (const char*)p.dout + (long long)n * p.H * p.W * a_px;
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)base, 0, (int)((unsigned)(p.H * p.W) * a_px), 0x00020000);
         const unsigned so = tile_px * a_px;
-        if constexpr (BF) {
+        if constexpr (ABF) {
           const int lim = (oco < p.dc && y0 + o_row < p.H) ? p.W - x0 - 8 * o_half : 0;  // pixels j < lim are inside the image
 #pragma unroll
           for (int j = 0; j < 8; ++j)
@@ -172,7 +174,8 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
           for (int u = 0; u < 2; ++u) {
             const int lim = (a_ok && y0 + a_row[u] < p.H) ? p.W - x0 - 8 * a_half[u] : 0;  // pixels j < lim are inside the image
 #pragma unroll
-            for (int j = 0; j < 8; ++j) s.va[u][j] = ld(rs, j < lim ? a_const[u] : SENT, so + j * a_px);
+            for (int j = 0; j < 8; ++j)
+              s.va[u][j] = __builtin_bit_cast(VA, __builtin_amdgcn_raw_buffer_load_b128(rs, j < lim ? a_const[u] : SENT, so + j * a_px, 0));
           }
         }
       }
@@ -199,7 +202,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     auto store_tile = [&](int i, Stage& s) {
 #ifdef SF_EXP_WG_NOSTORE
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { asm volatile("" ::"v"(s.va[0][j]), "v"(s.va[1][j])); }
+      for (int j = 0; j < 8; ++j) { asm volatile("" ::"v"(s.va8[ABF ? j : 0])); }
 #pragma unroll
       for (int j = 0; j < 10; ++j) { asm volatile("" ::"v"(s.vb[j])); }
       return;
@@ -207,7 +210,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       char* la = lds + (i & 1) * BUF;
       char* lb = la + A_BYTES;
       char* lh = lb + B_BYTES;
-      if constexpr (BF) {
+      if constexpr (ABF) {
         const u32x4 (&v8)[8] = s.va8;
         if (cit == 0) {
 #pragma unroll
@@ -226,29 +229,18 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
           *reinterpret_cast<u32x4*>(dst) = u32x4{__builtin_amdgcn_perm(v8[1][d], v8[0][d], sel), __builtin_amdgcn_perm(v8[3][d], v8[2][d], sel),
                                                  __builtin_amdgcn_perm(v8[5][d], v8[4][d], sel), __builtin_amdgcn_perm(v8[7][d], v8[6][d], sel)};
         }
-      } else
+      } else {
 #pragma unroll
-      for (int u = 0; u < 2; ++u) {
-        const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
-        char* dst = la + a_cq * A_S + (row * 2 + half) * 64;
-        const VT (&va)[8] = s.va[u];
-        if (cit == 0) {  // block-uniform: only the first ci tile's blocks report the bias gradient
+        for (int u = 0; u < 2; ++u) {
+          const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
+          char* dst = la + a_cq * A_S + (row * 2 + half) * 64;
+          const VA (&va)[8] = s.va[u];
+          if (cit == 0) {  // block-uniform: only the first ci tile's blocks report the bias gradient
 #pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            if constexpr (BF) {
-#pragma unroll
-              for (int c = 0; c < 4; ++c) bsum[c] += __builtin_bit_cast(float, chan_bits(va[j], c) << 16);
-            } else {
-              bsum += __builtin_bit_cast(f32x4, va[j]);
-            }
+            for (int j = 0; j < 8; ++j) bsum += __builtin_bit_cast(f32x4, va[j]);
           }
-        }
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          if constexpr (BF)
-            *reinterpret_cast<u32x4*>(dst + quad_slot(a_cq, c)) = u32x4{pair_bf(va[0], va[1], c), pair_bf(va[2], va[3], c),
-                                                                        pair_bf(va[4], va[5], c), pair_bf(va[6], va[7], c)};
-          else
+          for (int c = 0; c < 4; ++c)
             *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
                 pack8(F(va[0][c]), F(va[1][c]), F(va[2][c]), F(va[3][c]), F(va[4][c]), F(va[5][c]), F(va[6][c]), F(va[7][c]));
         }
@@ -265,7 +257,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
         for (int c = 0; c < 4; ++c) {
           // halo pixels: left neighbour in the HIGH half of its dword, right neighbour in the LOW half
           unsigned* hp = reinterpret_cast<unsigned*>(lh + (b_cq * 4 + c) * H_P + bhrow * 8);
-          if constexpr (BF) {
+          if constexpr (BBF) {
             *reinterpret_cast<u32x4*>(dst + quad_slot(b_cq, c)) = u32x4{pair_bf(vb[1], vb[2], c), pair_bf(vb[3], vb[4], c),
                                                                         pair_bf(vb[5], vb[6], c), pair_bf(vb[7], vb[8], c)};
             hp[bhalf] = bhalf ? chan_bits(vb[9], c) : chan_bits(vb[0], c) << 16;
@@ -278,7 +270,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       }
     };
     // my_tiles + 1 barriers in every variant (the compute waves count the same)
-    if constexpr (BF && !MIXED) {
+    if constexpr (ABF && !MIXED) {  // octet dout + quad inputs: two stages fit the register budget for either input type
       Stage s0, s1;
       if (my_tiles > 0) load_tile(0, s0);
       if (my_tiles > 1) load_tile(1, s1);
@@ -304,7 +296,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     // bias gradient: 8 loader threads share a channel quad
     if (cit == 0) {
       float* red = reinterpret_cast<float*>(lds);
-      if constexpr (BF) {  // [rest 16][channel 128]
+      if constexpr (ABF) {  // [rest 16][channel 128]
 #pragma unroll
         for (int c8 = 0; c8 < 8; ++c8) red[o_rest * CO_T + o_oct * 8 + c8] = bsum8[c8];
       } else {
@@ -388,7 +380,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       const float* red = reinterpret_cast<const float*>(lds);
       const int cq = tid / 4, c = tid % 4;
       float s = 0.f;
-      if constexpr (BF) {
+      if constexpr (ABF) {
         for (int k = 0; k < LOADERS / 16; ++k) s += red[k * CO_T + tid];
       } else {
         for (int k = 0; k < LOADERS / 32; ++k) s += red[(k * 32 + cq) * 4 + c];
@@ -407,17 +399,23 @@ int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl,
     return 1;
   }
   {
-    const long long esz = p.bf ? 2 : 4, px = (long long)p.H * p.W + p.W + 1;
+    const long long esz = 4, px = (long long)p.H * p.W + p.W + 1;  // bound for either storage type
     const long long smax = p.ds > p.s0 ? (p.ds > p.s1 ? p.ds : p.s1) : (p.s0 > p.s1 ? p.s0 : p.s1);
     if (px * smax * esz >= (1ll << 31)) { sf_set_error("wgrad_bf16: one image of a tensor must be smaller than 2 GiB"); return 1; }
   }
   const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
   const bool mixed = p.src0 && p.src1 && p.c1 > 0 && p.c0 % CI_T != 0;  // some block's 32 input channels straddle the two sources
   const dim3 grid(pl.KS, pl.cot, pl.cit), block(THREADS);
-  if (p.bf && mixed) hipLaunchKernelGGL((wgrad_bf16_kernel<true, true>), grid, block, 0, st, p, xcd_groups);
-  else if (p.bf) hipLaunchKernelGGL((wgrad_bf16_kernel<true, false>), grid, block, 0, st, p, xcd_groups);
-  else if (mixed) hipLaunchKernelGGL((wgrad_bf16_kernel<false, true>), grid, block, 0, st, p, xcd_groups);
-  else hipLaunchKernelGGL((wgrad_bf16_kernel<false, false>), grid, block, 0, st, p, xcd_groups);
+#define SF_WG(A_, B_)                                                                                             \
+  do {                                                                                                            \
+    if (mixed) hipLaunchKernelGGL((wgrad_bf16_kernel<A_, B_, true>), grid, block, 0, st, p, xcd_groups);          \
+    else hipLaunchKernelGGL((wgrad_bf16_kernel<A_, B_, false>), grid, block, 0, st, p, xcd_groups);               \
+  } while (0)
+  if (p.bf_dout && p.bf) SF_WG(true, true);
+  else if (p.bf_dout) SF_WG(true, false);
+  else if (!p.bf) SF_WG(false, false);
+  else { sf_set_error("wgrad_bf16: bf16-stored inputs with an fp32-stored output gradient are not built"); return 1; }
+#undef SF_WG
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("wgrad_bf16: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;

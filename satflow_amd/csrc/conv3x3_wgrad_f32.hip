@@ -164,10 +164,12 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
              workspace_bytes, pl.ws_floats * sizeof(float));
   WgradParams p{};
   {
-    const int nbf = (src0.ptr && src0.dtype == SF_BF16) + (src1.ptr && src1.dtype == SF_BF16) + (dout.dtype == SF_BF16);
-    const int nten = (src0.ptr != nullptr) + (src1.ptr != nullptr) + 1;
-    SF_REQUIRE(nbf == 0 || (nbf == nten && dtype == SF_BF16), "bwd_weight: bf16 storage needs the SF_BF16 kernel and ALL of src0/src1/dout in bf16");
-    p.bf = nbf != 0;
+    const int nsrc = (src0.ptr != nullptr) + (src1.ptr != nullptr);
+    const int nbf = (src0.ptr && src0.dtype == SF_BF16) + (src1.ptr && src1.dtype == SF_BF16);
+    SF_REQUIRE(nbf == 0 || nbf == nsrc, "bwd_weight: src0 and src1 must share one storage type");
+    p.bf = nbf != 0; p.bf_dout = dout.dtype == SF_BF16;
+    SF_REQUIRE(!(p.bf || p.bf_dout) || dtype == SF_BF16, "bwd_weight: bf16-stored tensors need the SF_BF16 kernel");
+    SF_REQUIRE(!p.bf || p.bf_dout, "bwd_weight: bf16-stored inputs need a bf16-stored output gradient");
   }
   p.src0 = (const float*)src0.ptr; p.src1 = (const float*)src1.ptr;
   p.c0 = src0.c; p.c1 = src1.c; p.s0 = src0.stride; p.s1 = src1.stride;

@@ -31,6 +31,7 @@ struct ConvParams {
   const float* h_prev; int hprev_s;
   // storage types (bf16 kernel only; linear / sigmoid epilogues): non-zero = bf16 elements behind src0 / src1 / out
   int bf0, bf1, out_bf;
+  int gates_bf;  // lstm epilogue: the saved gates are stored as bf16 (they are read by the backward pass only)
   // bf16 kernel, linear epilogue: per-tile sum / sum of squares of the stored outputs, [tile][stats_np][2] (or null)
   float* stats; int stats_np;
 };
@@ -84,8 +85,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
             p.c_out[pix[reg] * p.cout_s + hc] = cn;
             p.h_out[pix[reg] * p.hout_s + hc] = go * tanhf(cn);
             if (p.gates) {
-              float* gp = p.gates + pix[reg] * p.gates_s + hc;
-              gp[0] = gi; gp[p.hidp] = gf; gp[2 * p.hidp] = go; gp[3 * p.hidp] = gg;
+              if (p.gates_bf) {
+                __bf16* gp = reinterpret_cast<__bf16*>(p.gates) + pix[reg] * p.gates_s + hc;
+                gp[0] = (__bf16)gi; gp[p.hidp] = (__bf16)gf; gp[2 * p.hidp] = (__bf16)go; gp[3 * p.hidp] = (__bf16)gg;
+              } else {
+                float* gp = p.gates + pix[reg] * p.gates_s + hc;
+                gp[0] = gi; gp[p.hidp] = gf; gp[2 * p.hidp] = go; gp[3 * p.hidp] = gg;
+              }
             }
           }
         }

@@ -9,16 +9,18 @@ namespace {
 struct GateBwdParams {
   const float* dh0; const float* dh1; const float* dh2; int s_dh0, s_dh1, s_dh2;
   const float* dc_next; int s_dcn;
-  const float* gates; int s_g;
+  const void* gates; int s_g;
   const float* c_prev; int s_cp;
   const float* c_new; int s_cn;
-  float* dz; int s_dz;
+  void* dz; int s_dz;
   float* dc_prev; int s_dcp;
   long long pixels; int hidp;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 
+// TG: storage type of the saved gates and of dz (which overwrites them in place): fp32, or bf16 in "bf16a" mode
+template <typename TG>
 __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams p) {
   const int q = p.hidp >> 2;
   const long long total = p.pixels * q;
@@ -28,8 +30,8 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
     f32x4 dh = ld4(p.dh0 + pix * p.s_dh0 + c);
     if (p.dh1) dh += ld4(p.dh1 + pix * p.s_dh1 + c);
     if (p.dh2) dh += ld4(p.dh2 + pix * p.s_dh2 + c);
-    const float* g = p.gates + pix * p.s_g + c;
-    const f32x4 gi = ld4(g), gf = ld4(g + p.hidp), go = ld4(g + 2 * p.hidp), gg = ld4(g + 3 * p.hidp);
+    const TG* g = reinterpret_cast<const TG*>(p.gates) + pix * p.s_g + c;
+    const f32x4 gi = ldv4(g), gf = ldv4(g + p.hidp), go = ldv4(g + 2 * p.hidp), gg = ldv4(g + 3 * p.hidp);
     const f32x4 cn = ld4(p.c_new + pix * p.s_cn + c);
     f32x4 cp = {0.f, 0.f, 0.f, 0.f};
     if (p.c_prev) cp = ld4(p.c_prev + pix * p.s_cp + c);
@@ -47,16 +49,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
       zg[j] = d_c * gi[j] * (1.f - gg[j] * gg[j]);
       dcp[j] = d_c * gf[j];
     }
-    float* z = p.dz + pix * p.s_dz + c;
-    *reinterpret_cast<f32x4*>(z) = zi;
-    *reinterpret_cast<f32x4*>(z + p.hidp) = zf;
-    *reinterpret_cast<f32x4*>(z + 2 * p.hidp) = zo;
-    *reinterpret_cast<f32x4*>(z + 3 * p.hidp) = zg;
+    TG* z = reinterpret_cast<TG*>(p.dz) + pix * p.s_dz + c;
+    stv4(z, zi); stv4(z + p.hidp, zf); stv4(z + 2 * p.hidp, zo); stv4(z + 3 * p.hidp, zg);
     if (p.dc_prev) *reinterpret_cast<f32x4*>(p.dc_prev + pix * p.s_dcp + c) = dcp;
   }
 }
 
 bool aligned4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.dtype == SF_F32); }  // fp32 storage only
+bool aligned4g(const sfTensor& t) {  // gates / dz: fp32 or bf16 storage
+  return ((((uintptr_t)t.ptr) & (t.dtype == SF_BF16 ? 7 : 15)) == 0 && t.stride % 4 == 0 && (t.dtype == SF_F32 || t.dtype == SF_BF16));
+}
 
 }  // namespace
 
@@ -66,23 +68,24 @@ extern "C" int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor d
   SF_REQUIRE(dtype == SF_F32, "sf_convlstm_cell_bwd_gates: dtype %d not built", dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && hidp > 0, "bwd_gates: hidp=%d", hidp);
   SF_REQUIRE(dh0.ptr && gates.ptr && c_new.ptr && dz.ptr, "bwd_gates: dh0, gates, c_new, dz must be non-null");
-  SF_REQUIRE(aligned4(dh0) && aligned4(dh1) && aligned4(dh2) && aligned4(dc_next) && aligned4(gates) && aligned4(c_prev) &&
-                 aligned4(c_new) && aligned4(dz) && aligned4(dc_prev),
-             "bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0");
+  SF_REQUIRE(aligned4(dh0) && aligned4(dh1) && aligned4(dh2) && aligned4(dc_next) && aligned4g(gates) && aligned4(c_prev) &&
+                 aligned4(c_new) && aligned4g(dz) && aligned4(dc_prev) && gates.dtype == dz.dtype,
+             "bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0, fp32 (gates / dz: fp32 or bf16, both alike)");
   GateBwdParams p{};
   p.dh0 = (const float*)dh0.ptr; p.dh1 = (const float*)dh1.ptr; p.dh2 = (const float*)dh2.ptr;
   p.s_dh0 = dh0.stride; p.s_dh1 = dh1.stride; p.s_dh2 = dh2.stride;
   p.dc_next = (const float*)dc_next.ptr; p.s_dcn = dc_next.stride;
-  p.gates = (const float*)gates.ptr; p.s_g = gates.stride;
+  p.gates = gates.ptr; p.s_g = gates.stride;
   p.c_prev = (const float*)c_prev.ptr; p.s_cp = c_prev.stride;
   p.c_new = (const float*)c_new.ptr; p.s_cn = c_new.stride;
-  p.dz = (float*)dz.ptr; p.s_dz = dz.stride;
+  p.dz = dz.ptr; p.s_dz = dz.stride;
   p.dc_prev = (float*)dc_prev.ptr; p.s_dcp = dc_prev.stride;
   p.pixels = pixels; p.hidp = hidp;
   const long long total = pixels * (hidp / 4);
   if (total == 0) return 0;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(lstm_bwd_gates_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  if (gates.dtype == SF_BF16) hipLaunchKernelGGL(lstm_bwd_gates_kernel<__bf16>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL(lstm_bwd_gates_kernel<float>, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("lstm_bwd_gates");
   return 0;
 }

@@ -14,7 +14,8 @@ struct WgradParams {
   int N, H, W, tiles_x, tiles_y, ntiles, KS;
   float* partial; float* partial_db;
   int NpT, KpT;
-  int bf;  // bf16 kernel only: src0 / src1 / dout are all stored as bf16 (MetNet encoder "bf16a" mode)
+  int bf;       // bf16 kernel only: the input sources src0 / src1 are stored as bf16
+  int bf_dout;  // bf16 kernel only: dout is stored as bf16 (with fp32 sources: the ConvLSTM's bf16-stored gate gradients)
 };
 
 

@@ -24,7 +24,7 @@ from torch import nn
 
 from .. import kernels as K
 from ..functional import ConvEngine, _FromNHWC, _ToNHWC, conv3x3, nchw_to_nhwc, nhwc_to_nchw  # noqa: F401 (re-exported)
-from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, generation, require_device, sfTensor
+from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, gate_storage_dtype, generation, require_device, sfTensor
 from .base import LightningModule, get_loss, register_model
 from .layers.ConvLSTM import CellEngine, ConvLSTMCell
 
@@ -50,13 +50,14 @@ class _StackFn(torch.autograd.Function):
         dev = x.device
         keep = any(ctx.needs_input_grad)  # False under no_grad / inference: no gates are written
 
-        def seq(steps: int, ch: int) -> Tensor:
-            return torch.empty(steps, B, H, W, ch, dtype=torch.float32, device=dev)
+        def seq(steps: int, ch: int, dtype=torch.float32) -> Tensor:
+            return torch.empty(steps, B, H, W, ch, dtype=dtype, device=dev)
 
         steps = (T_in, T_in, T_out, T_out)
         Hs = [seq(s, hidp) for s in steps]
         Cs = [seq(s, hidp) for s in steps]
-        Gs = [seq(s, 4 * hidp) if keep else None for s in steps]
+        # saved gates (later overwritten by dz): backward-only data, bf16 in "bf16a" mode - half of the stack's HBM traffic
+        Gs = [seq(s, 4 * hidp, gate_storage_dtype()) if keep else None for s in steps]
         xs = x.view(T_in, B, H, W, x.shape[-1])
 
         def run(k: int, eng: CellEngine, inp: Tensor, t: int) -> None:

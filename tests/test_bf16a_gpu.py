@@ -206,3 +206,56 @@ def test_metnet_bf16a_train_step(device, bf16a_mode):
             worst = (k, ours, theirs)
         assert ours < max(2 * theirs, 5e-2), (k, ours, theirs)
     print(f"bf16a MetNet step: output rel L2 ours {ours_out:.2e} / CPU autocast {theirs_out:.2e}; worst gradient {worst[0]}: ours {worst[1]:.2e} / autocast {worst[2]:.2e}")
+
+
+@pytest.mark.parametrize("case", ["cfg1_h8", "cfg1_h32_hot", "rect_h16_o12", "cfg1_h64_hot"])
+def test_convlstm_bf16a_vs_bf16(device, case):
+    """ConvLSTM stack with bf16-STORED gates / gate gradients ("bf16a") against the same stack with fp32-stored ones ("bf16"):
+    the forward pass never reads the stored gates, so predictions are bit-identical; every parameter gradient and the
+    input gradient stay within a few bf16 ulps (relative L2) of the fp32-storage run and as close to the reference golden."""
+    from test_convlstm_gpu import _load, _model_from_golden
+
+    G = _load(f"convlstm_model_{case}.npz")
+    res = {}
+    for mode in ("bf16", "bf16a"):
+        satflow_amd.set_compute_dtype(mode)
+        try:
+            m, fs = _model_from_golden(G, device)
+            x = G["x"].to(device).requires_grad_()
+            pred = m(x, fs)
+            (pred * G["cot"].to(device)).sum().backward()
+            res[mode] = (pred.detach().cpu(), x.grad.cpu(), {k: p.grad.cpu() for k, p in m.model.named_parameters()})
+        finally:
+            satflow_amd.set_compute_dtype("f32")
+    assert torch.equal(res["bf16"][0], res["bf16a"][0]), "forward must not depend on the gate storage type"
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    worst = max([rel(res["bf16a"][1], res["bf16"][1])] + [rel(res["bf16a"][2][k], res["bf16"][2][k]) for k in res["bf16"][2]])
+    print(f"bf16a ConvLSTM {case}: worst gradient rel L2 vs fp32-stored gates {worst:.2e}")
+    assert worst < 1e-2
+    for k, g in res["bf16a"][2].items():
+        if f"grad.{k}" not in G:  # the large fixture keeps only the small gradients
+            continue
+        ref = G[f"grad.{k}"]
+        assert rel(g, ref) < max(2 * rel(res["bf16"][2][k], ref), 2e-2), k
+
+
+def test_wgrad_bf16_dout_fp32_sources(device, bf16a_mode):
+    """Weight gradient with a bf16-stored output gradient against fp32-stored sources (two sources, the first 16 lanes
+    wide: the ConvLSTM cell's layout) == the all-fp32-storage kernel fed the widened gradient."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T
+    from satflow_amd.functional import nchw_to_nhwc
+
+    g = torch.Generator().manual_seed(21)
+    n, h, w, c0, c1, co = 3, 20, 24, 12, 64, 256
+    x0 = nchw_to_nhwc(torch.randn(n, c0, h, w, generator=g).to(device))
+    x1 = nchw_to_nhwc(torch.randn(n, c1, h, w, generator=g).to(device))
+    dz_b = nchw_to_nhwc(torch.randn(n, co, h, w, generator=g).to(device)).bfloat16()
+    gm = K.lstm_wgrad_map(c0, c1)
+    out = []
+    for dz in (dz_b, dz_b.float()):
+        dw, db = torch.empty(co, c0 + c1, 3, 3, device=device), torch.empty(co, device=device)
+        K.conv3x3_bwd_weight(T(x0), T(x1), T(dz), n, h, w, gm, dw, db, False)
+        out.append((dw, db))
+    assert_close(out[0][0], out[1][0], "dW: bf16 vs widened fp32 dout", grad=True)
+    assert_close(out[0][1], out[1][1], "db", grad=True)
