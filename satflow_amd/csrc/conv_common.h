@@ -79,11 +79,11 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
           const float gi = sf_sigmoid(acc[mf][0][reg] + bi);
           const float gf = sf_sigmoid(acc[mf][1][reg] + bf);
           const float go = sf_sigmoid(acc[mf][2][reg] + bo);
-          const float gg = tanhf(acc[mf][3][reg] + bg);
+          const float gg = sf_tanh(acc[mf][3][reg] + bg);
           const float cn = gf * cp[reg] + gi * gg;
           if (ok[reg]) {
             p.c_out[pix[reg] * p.cout_s + hc] = cn;
-            p.h_out[pix[reg] * p.hout_s + hc] = go * tanhf(cn);
+            p.h_out[pix[reg] * p.hout_s + hc] = go * sf_tanh(cn);
             if (p.gates) {
               if (p.gates_bf) {
                 __bf16* gp = reinterpret_cast<__bf16*>(p.gates) + pix[reg] * p.gates_s + hc;
@@ -130,7 +130,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
           const float z = sf_sigmoid(acc[mf][0][reg] + gz[reg]);
           const float rg = sf_sigmoid(acc[mf][1][reg] + gr[reg]);
           const float h2 = acc[mf][2][reg] + b2;
-          const float cand = tanhf(gn[reg] + rg * h2);
+          const float cand = sf_tanh(gn[reg] + rg * h2);
           if (ok[reg]) {
             p.h_out[pix[reg] * p.hout_s + hc] = (1.f - z) * cand + z * hp[reg];
             if (p.gates) {

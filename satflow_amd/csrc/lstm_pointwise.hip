@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
     f32x4 zi, zf, zo, zg, dcp;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float tc = tanhf(cn[j]);
+      const float tc = sf_tanh(cn[j]);
       const float d_o = dh[j] * tc;
       const float d_c = dc[j] + dh[j] * go[j] * (1.f - tc * tc);
       zi[j] = d_c * gg[j] * gi[j] * (1.f - gi[j]);

@@ -33,7 +33,16 @@ void sf_set_error(const char* fmt, ...);
 // acc[reg] of lane l holds C[row][col] with col = l & 31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 __device__ __forceinline__ int frag_row(int reg, int lane_hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * lane_hi; }
 
-__device__ __forceinline__ float sf_sigmoid(float v) { return 1.0f / (1.0f + expf(-v)); }
+// Gate nonlinearities on the hardware transcendentals (v_exp_f32 / v_rcp_f32, ~1 ulp each): absolute error ~1e-7, two orders
+// below the parity gate, for 4 instructions instead of the ~25 (sigmoid) / ~40 (tanh) of the libm forms - the fused
+// cells evaluate 5 of them per output element in their epilogue.
+__device__ __forceinline__ float sf_sigmoid(float v) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.44269504088896341f * v));
+}
+__device__ __forceinline__ float sf_tanh(float v) {
+  const float t = __builtin_amdgcn_exp2f(-2.88539008177792681f * fabsf(v));  // e^(-2|v|) in (0, 1]
+  return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
+}
 
 // ---- storage-typed 4-channel access (fp32 or bf16 activations) ---------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
