@@ -299,8 +299,9 @@ def main():
             "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",
             "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 storage of all activations",
             "bf16a": "bf16 MFMA operands, fp32 accumulate; MetNet image-encoder activations and their gradients stored as bf16 "
-                     "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers); parameters, ConvGRU, attention, "
-                     "loss and optimizer state fp32",
+                     "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers), ConvLSTM saved gates / gate "
+                     "gradients stored as bf16 (backward-only data); parameters, hidden / cell states, ConvGRU, attention, loss "
+                     "and optimizer state fp32",
         }[args.dtype]
         out["config"]["mode"] = args.dtype
         out["roofline"] = wl.roofline()
