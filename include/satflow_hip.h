@@ -59,8 +59,10 @@ typedef struct {
   int32_t idiv;   /* image-index divisor (0/1 = none)          */
   int32_t imod;   /* image-index modulus (0 = none)            */
   int32_t dtype;  /* element storage: SF_F32 (default) or SF_BF16.  bf16 storage is accepted by the MetNet encoder
-                     kernels (sf_metnet_preprocess_fwd, sf_conv3x3_fwd / _bwd_weight with the SF_BF16 kernels,
-                     sf_leadtime_pool_*, sf_batchnorm_*, sf_maxpool2_*); everything else requires SF_F32 */
+                     kernels (sf_metnet_preprocess_fwd, sf_conv3x3_fwd[_stats] / _bwd_weight with the SF_BF16 kernels,
+                     sf_leadtime_pool_*, sf_batchnorm_*, sf_maxpool2_*) and for the ConvLSTM's saved gates / gate
+                     gradients (`gates` of sf_convlstm_cell_fwd, `gates` and `dz` of sf_convlstm_cell_bwd_gates, `dout`
+                     of sf_conv3x3_bwd_weight against fp32 sources); everything else requires SF_F32 */
 } sfTensor;
 
 /* ---------------------------------------------------------------------------------------------
@@ -108,6 +110,7 @@ int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int
  *             i.e. init_hidden, layers/ConvLSTM.py:59-64, without materialising them)
  *   c_prev  : previous cell state (ptr NULL == zeros);  h_out, c_out : new states
  *   gates   : nullable; receives post-activation i,f,o,g as [.., 4*hidp] (gate-major) for backward
+ *             (SF_F32 or SF_BF16 storage: backward-only data, the outputs do not depend on it)
  *   wpacked : image from sf_conv3x3_pack_weights with the LSTM nmap (32 hidden channels x 4 gates
  *             per N-block, nf == 4), bias_packed likewise.  hidp = padded hidden channels.
  * ------------------------------------------------------------------------------------------- */
@@ -119,7 +122,8 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
 /* Pointwise part of the cell's backward (autograd of layers/ConvLSTM.py:48-55):
  *   dh = sum of up to three incoming hidden-state gradients (NULL ptr = absent)
  *   dc_next (nullable) gradient flowing into c'; gates = saved i,f,o,g; c_prev nullable (zeros)
- *   -> dz [.., 4*hidp] gradient wrt the pre-activation conv output, dc_prev (nullable out). */
+ *   -> dz [.., 4*hidp] gradient wrt the pre-activation conv output, dc_prev (nullable out).
+ *   gates and dz share one storage type (SF_F32 or SF_BF16; dz may overwrite gates in place). */
 int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor dc_next,
                                sfTensor gates, sfTensor c_prev, sfTensor c_new, int64_t pixels,
                                int32_t hidp, sfTensor dz, sfTensor dc_prev, int32_t dtype,
@@ -131,6 +135,7 @@ int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTenso
  * in = [src0 ; src1] (padded channels), dout.c = padded output channels.  nmap/kmap translate the
  * padded indices to rows/columns of the OIHW gradient ( -1 = skip ).  `accumulate` != 0 adds into
  * dw/db.  workspace: sf_conv3x3_bwd_weight_workspace_bytes() bytes of scratch.
+ * Storage (SF_BF16 kernels): all fp32; all bf16; or bf16 dout with fp32 sources.  src0 and src1 share one type.
  * ------------------------------------------------------------------------------------------- */
 size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w);
 int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h,
