@@ -29,7 +29,7 @@ inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
   pl.ntiles = pl.tiles_x * pl.tiles_y * n;
   pl.cot = (Np + CO_T - 1) / CO_T;
   pl.cit = (Kp + CI_T - 1) / CI_T;
-  int want = 1024 / (pl.cot * pl.cit);
+  int want = 512 / (pl.cot * pl.cit);  // ~2 workgroups per CU in total: fewer, longer K slices than 1024 measured faster (less split-K reduce)
   if (want < 8) want = 8;
   if (want > 256) want = 256;
   pl.KS = pl.ntiles < want ? pl.ntiles : want;
