@@ -24,6 +24,10 @@ class FlatAdam:
     """Adam over a module's parameters, flattened.  ``step()`` also performs the data-parallel
     gradient mean when a process group is given (SUM all-reduce, 1/world folded into the update)."""
 
+    # Smallest group size that exchanges gradients.  2 in production (a single rank has nothing to exchange); the
+    # single-GPU RCCL test lowers it to 1 so that the hook / async all-reduce / stream-ordering path runs on a 1-GPU box.
+    MIN_EXCHANGE_WORLD = 2
+
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group: Optional["dist.ProcessGroup"] = None, distributed: Optional[bool] = None,
                  overlap: bool = False, buckets: int = 3) -> None:
@@ -56,7 +60,8 @@ class FlatAdam:
         # LAST slice (head / attention / recurrent cells) completes first and its all-reduce runs on RCCL's stream while
         # the encoder's backward is still computing.  A slice is launched when every parameter in it has received its
         # gradient (post-accumulate hooks); `step()` waits for the launched ones and reduces whatever was not launched.
-        self.overlap = bool(overlap) and self.distributed and self.world > 1
+        self.exchange = self.distributed and self.world >= self.MIN_EXCHANGE_WORLD
+        self.overlap = bool(overlap) and self.exchange
         self._bucket_of: List[int] = []
         self._bucket_range: List[List[int]] = []
         self._pending: List[int] = []
@@ -102,7 +107,7 @@ class FlatAdam:
     def allreduce_grads(self) -> None:
         """SUM all-reduce of the gradient: one call over the whole flat buffer (4-9 MB: latency-bound), or - with
         ``overlap`` - completion of the per-slice reductions the backward pass already launched."""
-        if not (self.distributed and self.world > 1):
+        if not self.exchange:
             return
         if not self.overlap:
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
