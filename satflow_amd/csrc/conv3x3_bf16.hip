@@ -30,7 +30,7 @@ constexpr int PIX_B = 32;           // bytes per pixel / per weight row in LDS (
 // DUAL (8 waves, images of at most 16x16 pixels): the 32x16 tile is TWO consecutive images, waves 0-3 on the first and
 // 4-7 on the second, each image with its own halo rows in LDS (2 x 18 rows) - small images keep the 8-wave workgroup's
 // weight reuse and occupancy instead of dropping to the 4-wave 16x16 kernel.
-template <int WAVES, int NF, int EPI, bool DUAL = false>
+template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
   static_assert(!DUAL || WAVES == 8, "dual-image tiles are an 8-wave layout");
   constexpr int NB = 32 * NF;
@@ -192,16 +192,24 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #ifndef SF_EXP_NOBARRIER
     __syncthreads();
 #endif
+    // Staging of the NEXT chunk (weight DMA + input DMA / loads) is issued at a different tap by the two waves that
+    // share a SIMD (wave w and w + 4 of an 8-wave workgroup): a wave stalls for a few hundred cycles while it issues its
+    // ~7 LDS-DMA pieces, and when both partners do that at the same moment the SIMD's matrix pipe idles.  Out of phase,
+    // the partner's MFMAs cover the stall (measured 256->256@32x32: 2.56 -> 2.42 ms; splitting by wave parity instead,
+    // which pairs waves of different SIMDs, gains nothing; spreading the pieces over the taps loses the gain).
+    const bool stage_late = WAVES == 8 && wave >= 4;
+    auto stage_next = [&]() {
 #ifndef SF_EXP_NOSTAGE
-    if (ci + 1 < nch) {
+      if (ci + 1 < nch) {
 #ifndef SF_EXP_NOWEIGHTS
-      issue_weights(ci + 1, cur ^ 1);
+        issue_weights(ci + 1, cur ^ 1);
 #endif
 #ifndef SF_EXP_NOINPUT
-      stage_input(ci + 1);
+        stage_input(ci + 1);
 #endif
-    }
+      }
 #endif
+    };
     const char* inb = lds_in + cur * IN_B + a_lane;
     const char* wb = lds_w + cur * W_B + b_lane;
     auto load_tap = [&](int tap, bf16x8 (&a)[2], bf16x8 (&b)[NF]) {
@@ -228,7 +236,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #ifdef SF_EXP_NOMFMA
           acc[mf][nf][0] += (float)fa[tap & 1][mf][0] * (float)fb[tap & 1][nf][0];
 #else
-          acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
+          acc[mf][nf] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1][mf], acc[mf][nf], 0, 0, 0)
+                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
 #endif
       // scheduling: one LDS read (the next tap's operands) after each of the first MFMAs of this tap, the remaining
       // MFMAs behind them - a clump of 2+NF reads between two MFMA groups measured 2 % (NF=4) to 15 % (NF=5) slower
@@ -243,6 +252,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
         if constexpr (READS > PAIRS) __builtin_amdgcn_sched_group_barrier(0x100, READS - PAIRS, 0);
       }
       __builtin_amdgcn_sched_barrier(0);
+      if (tap == 0 || tap == 5) {
+        if (stage_late == (tap == 5)) stage_next();
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
 #ifndef SF_EXP_NOSTAGE
     if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
@@ -260,7 +273,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       __syncthreads();
     }
   }
-  if (!DUAL || n_w < p.N) conv_epilogue<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh, lds_stats);
+  if constexpr (TR) {
+    if (!DUAL || n_w < p.N) conv_epilogue_tr<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh);
+    return;
+  } else {
+    if (!DUAL || n_w < p.N) conv_epilogue<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh, lds_stats);
+  }
   if constexpr (EPI == EPI_LINEAR && !DUAL) {
     if (lds_stats) {
       __syncthreads();
@@ -315,14 +333,19 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
     if (nf != 3) { sf_set_error("bf16 conv: GRU epilogue needs nf=3"); return 1; }
     hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL>), grid, block, 0, st, p);
   } else {
+    // without BatchNorm statistics the product is computed transposed (pixel-per-lane epilogue with 16-byte stores)
+    const bool tr = p.stats == nullptr;
+#define SF_CONV_CASE(NFV)                                                                                              \
+  case NFV:                                                                                                            \
+    if (tr) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);             \
+    else if constexpr (EPI == EPI_LINEAR && !DUAL) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, false>), grid, block, 0, st, p); \
+    else { sf_set_error("bf16 conv: statistics need the linear epilogue on single-image tiles"); return 1; }          \
+    break;
     switch (nf) {
-      case 1: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 1, EPI, DUAL>), grid, block, 0, st, p); break;
-      case 2: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 2, EPI, DUAL>), grid, block, 0, st, p); break;
-      case 3: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL>), grid, block, 0, st, p); break;
-      case 4: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL>), grid, block, 0, st, p); break;
-      case 5: hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 5, EPI, DUAL>), grid, block, 0, st, p); break;
+      SF_CONV_CASE(1) SF_CONV_CASE(2) SF_CONV_CASE(3) SF_CONV_CASE(4) SF_CONV_CASE(5)
       default: sf_set_error("bf16 conv: unsupported nf=%d", nf); return 1;
     }
+#undef SF_CONV_CASE
   }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("conv3x3_bf16: launch failed: %s", hipGetErrorString(e)); return 2; }

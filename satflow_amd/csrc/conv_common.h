@@ -202,6 +202,61 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
   }
 }
 
+// Linear / sigmoid epilogue of the TRANSPOSED product (bf16 kernel without BatchNorm statistics: the MFMA is issued with
+// the weight fragment as its A operand, so D[i][j] has i = output channel, j = pixel): lane (r, kh) owns ONE pixel of
+// each M fragment and, per 32-channel N fragment, the four channel quads 8g + 4kh .. +3 (g = reg / 4).  Outputs leave as
+// 16-byte stores: fp32 a quad at a time; bf16 after `v_permlane32_swap` pairs quad g of the two half-waves into the
+// octets 8g..8g+7 (lower lanes) and 8g+8..8g+15 (upper lanes) - 2*NF*2 `dwordx4` stores per lane instead of the
+// 2*NF*8 4-byte stores of the channel-per-lane layout (the store tail is issue-bound, not bandwidth-bound).
+template <int NF, int EPI>
+__device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0,
+                                                 int wave, int r, int kh) {
+  static_assert(EPI == EPI_LINEAR || EPI == EPI_SIGMOID, "transposed epilogue: linear / sigmoid only");
+  constexpr int NB = 32 * NF;
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  auto pk = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); };
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
+    const bool ok = py < p.H && px < p.W;
+    const size_t pix = ok ? (size_t)(n * p.H + py) * p.W + px : 0;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int cb = nb * NB + nf * 32;  // out_c is a multiple of 16: a 16-channel half of the fragment is in or out as a whole
+      float v[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+        if (p.bias) bv = *reinterpret_cast<const f32x4*>(p.bias + cb + 8 * g + 4 * kh);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float t = acc[mf][nf][4 * g + c] + bv[c];
+          if constexpr (EPI == EPI_SIGMOID) t = sf_sigmoid(t);
+          v[4 * g + c] = t;
+        }
+      }
+      if (p.out_bf) {
+        __bf16* ob = reinterpret_cast<__bf16*>(p.out) + pix * p.out_s + cb + 8 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          unsigned ax = pk(v[4 * g], v[4 * g + 1]), ay = pk(v[4 * g + 2], v[4 * g + 3]);
+          unsigned bx = pk(v[4 * g + 4], v[4 * g + 5]), by = pk(v[4 * g + 6], v[4 * g + 7]);
+          auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          if (ok && cb + 8 * g < p.out_c) *reinterpret_cast<u32x4_t*>(ob + 8 * g) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+        }
+      } else {
+        float* of = p.out + pix * p.out_s + cb + 4 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          if (ok && cb + 8 * g < p.out_c) *reinterpret_cast<f32x4*>(of + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      }
+    }
+  }
+}
+
 inline void set_remap(ConvParams& p, const sfTensor& a, const sfTensor& b) {
   p.idiv0 = a.idiv > 1 ? a.idiv : 1; p.imod0 = a.imod > 0 ? a.imod : 0;
   p.idiv1 = b.idiv > 1 ? b.idiv : 1; p.imod1 = b.imod > 0 ? b.imod : 0;
