@@ -328,10 +328,10 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
   dim3 grid(DUAL ? (p.N + 1) / 2 : p.tiles_x * p.tiles_y * p.N, nblk), block(WAVES * 64);
   if constexpr (EPI == EPI_LSTM) {
     if (nf != 4) { sf_set_error("bf16 conv: LSTM epilogue needs nf=4"); return 1; }
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL, true>), grid, block, 0, st, p);
   } else if constexpr (EPI == EPI_GRU) {
     if (nf != 3) { sf_set_error("bf16 conv: GRU epilogue needs nf=3"); return 1; }
-    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL>), grid, block, 0, st, p);
+    hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL, true>), grid, block, 0, st, p);
   } else {
     // without BatchNorm statistics the product is computed transposed (pixel-per-lane epilogue with 16-byte stores)
     const bool tr = p.stats == nullptr;

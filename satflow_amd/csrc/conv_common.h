@@ -211,12 +211,132 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
 template <int NF, int EPI>
 __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0,
                                                  int wave, int r, int kh) {
-  static_assert(EPI == EPI_LINEAR || EPI == EPI_SIGMOID, "transposed epilogue: linear / sigmoid only");
+  if constexpr (EPI == EPI_GRU) {
+    // fragments 0..2 = z, r and the candidate's h-part of hidden channels nb*32 + 8g + 4kh + c of this lane's pixel
+    static_assert(NF == 3, "GRU epilogue: z, r and the candidate's h-part in one wave");
+    const int hb = nb * 32 + 4 * kh;
+    const size_t pix_safe = (size_t)(n * p.H + y0) * p.W + x0;
+    f32x4 b2[4];
+#pragma unroll
+    for (int g = 0; g < 4; ++g) b2[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb * 96 + 64 + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
+      const bool ok = py < p.H && px < p.W;
+      const size_t pix = ok ? (size_t)(n * p.H + py) * p.W + px : pix_safe;
+      f32x4 gz[4], gr[4], gn[4], hp[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // unconditional loads from clamped addresses
+        const int hq = (hb + 8 * g < p.hidp) ? hb + 8 * g : 0;
+        const float* gx = p.gx + pix * p.gx_s + hq;
+        gz[g] = *reinterpret_cast<const f32x4*>(gx);
+        gr[g] = *reinterpret_cast<const f32x4*>(gx + p.hidp);
+        gn[g] = *reinterpret_cast<const f32x4*>(gx + 2 * p.hidp);
+        hp[g] = p.h_prev ? *reinterpret_cast<const f32x4*>(p.h_prev + pix * p.hprev_s + hq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 z, rg, h2, cand, hn;
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          z[c] = sf_sigmoid(acc[mf][0][4 * g + c] + gz[g][c]);
+          rg[c] = sf_sigmoid(acc[mf][1][4 * g + c] + gr[g][c]);
+          h2[c] = acc[mf][2][4 * g + c] + b2[g][c];
+          cand[c] = sf_tanh(gn[g][c] + rg[c] * h2[c]);
+          hn[c] = (1.f - z[c]) * cand[c] + z[c] * hp[g][c];
+        }
+        if (ok && hb + 8 * g < p.hidp) {
+          *reinterpret_cast<f32x4*>(p.h_out + pix * p.hout_s + hb + 8 * g) = hn;
+          if (p.gates) {
+            float* gp = p.gates + pix * p.gates_s + hb + 8 * g;
+            *reinterpret_cast<f32x4*>(gp) = z;
+            *reinterpret_cast<f32x4*>(gp + p.hidp) = rg;
+            *reinterpret_cast<f32x4*>(gp + 2 * p.hidp) = cand;
+            *reinterpret_cast<f32x4*>(gp + 3 * p.hidp) = h2;
+          }
+        }
+      }
+    }
+    return;
+  }
+  static_assert(EPI == EPI_LINEAR || EPI == EPI_SIGMOID || EPI == EPI_LSTM || EPI == EPI_GRU, "transposed epilogue");
   constexpr int NB = 32 * NF;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   auto pk = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); };
+  if constexpr (EPI == EPI_LSTM) {
+    // Fragments 0..3 are the gates i, f, o, g of hidden channels nb*32 + 8g + 4kh + c of this lane's pixel: previous cell
+    // state, new cell / hidden state and the saved gates all move as 16-byte quads (bf16 gates as octets after the
+    // half-wave swap) - 20 memory instructions per M fragment where the channel-per-lane layout needs 112.
+    static_assert(NF == 4, "LSTM epilogue needs the 4 gates in one wave");
+    const int hb = nb * 32 + 4 * kh;
+    const size_t pix_safe = (size_t)(n * p.H + y0) * p.W + x0;  // the tile origin is always inside the image
+    f32x4 bias[4][4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        bias[q][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb * NB + 32 * q + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
+      const bool ok = py < p.H && px < p.W;
+      const size_t pix = ok ? (size_t)(n * p.H + py) * p.W + px : pix_safe;
+      f32x4 cp[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {  // unconditional loads from clamped addresses (see conv_epilogue)
+        const int hq = (hb + 8 * g < p.hidp) ? hb + 8 * g : 0;
+        cp[g] = p.c_prev ? *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.cprev_s + hq) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      f32x4 gi[4], gf[4], go[4], gg[4], cn[4], hn[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          gi[g][c] = sf_sigmoid(acc[mf][0][4 * g + c] + bias[0][g][c]);
+          gf[g][c] = sf_sigmoid(acc[mf][1][4 * g + c] + bias[1][g][c]);
+          go[g][c] = sf_sigmoid(acc[mf][2][4 * g + c] + bias[2][g][c]);
+          gg[g][c] = sf_tanh(acc[mf][3][4 * g + c] + bias[3][g][c]);
+          cn[g][c] = gf[g][c] * cp[g][c] + gi[g][c] * gg[g][c];
+          hn[g][c] = go[g][c] * sf_tanh(cn[g][c]);
+        }
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        if (ok && hb + 8 * g < p.hidp) {
+          *reinterpret_cast<f32x4*>(p.c_out + pix * p.cout_s + hb + 8 * g) = cn[g];
+          *reinterpret_cast<f32x4*>(p.h_out + pix * p.hout_s + hb + 8 * g) = hn[g];
+        }
+      if (p.gates) {
+        if (p.gates_bf) {
+          __bf16* gp = reinterpret_cast<__bf16*>(p.gates) + pix * p.gates_s + nb * 32 + 8 * kh;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4* v = q == 0 ? gi : q == 1 ? gf : q == 2 ? go : gg;
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+              unsigned ax = pk(v[g][0], v[g][1]), ay = pk(v[g][2], v[g][3]);
+              unsigned bx = pk(v[g + 1][0], v[g + 1][1]), by = pk(v[g + 1][2], v[g + 1][3]);
+              auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+              auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+              if (ok && nb * 32 + 8 * g < p.hidp) *reinterpret_cast<u32x4_t*>(gp + q * p.hidp + 8 * g) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+            }
+          }
+        } else {
+          float* gp = p.gates + pix * p.gates_s + hb;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            if (ok && hb + 8 * g < p.hidp) {
+              *reinterpret_cast<f32x4*>(gp + 8 * g) = gi[g];
+              *reinterpret_cast<f32x4*>(gp + p.hidp + 8 * g) = gf[g];
+              *reinterpret_cast<f32x4*>(gp + 2 * p.hidp + 8 * g) = go[g];
+              *reinterpret_cast<f32x4*>(gp + 3 * p.hidp + 8 * g) = gg[g];
+            }
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
     const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
