@@ -60,9 +60,11 @@ typedef struct {
   int32_t imod;   /* image-index modulus (0 = none)            */
   int32_t dtype;  /* element storage: SF_F32 (default) or SF_BF16.  bf16 storage is accepted by the MetNet encoder
                      kernels (sf_metnet_preprocess_fwd, sf_conv3x3_fwd[_stats] / _bwd_weight with the SF_BF16 kernels,
-                     sf_leadtime_pool_*, sf_batchnorm_*, sf_maxpool2_*) and for the ConvLSTM's saved gates / gate
+                     sf_leadtime_pool_*, sf_batchnorm_*, sf_maxpool2_*), for the ConvLSTM's saved gates / gate
                      gradients (`gates` of sf_convlstm_cell_fwd, `gates` and `dz` of sf_convlstm_cell_bwd_gates, `dout`
-                     of sf_conv3x3_bwd_weight against fp32 sources); everything else requires SF_F32 */
+                     of sf_conv3x3_bwd_weight against fp32 sources) and for the ConvLSTM's layer inputs / hidden states
+                     (`x`, `h_prev`, `h_out` of sf_convlstm_cell_fwd with the SF_BF16 kernel); everything else
+                     requires SF_F32 */
 } sfTensor;
 
 /* ---------------------------------------------------------------------------------------------
@@ -108,7 +110,10 @@ int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int
  * c' = f*c + i*g -> h' = o*tanh(c')), one launch instead of ~11 ATen kernels.
  *   x       : layer input (src0), h_prev : previous hidden state (src1; ptr NULL == zeros,
  *             i.e. init_hidden, layers/ConvLSTM.py:59-64, without materialising them)
- *   c_prev  : previous cell state (ptr NULL == zeros);  h_out, c_out : new states
+ *   c_prev  : previous cell state (ptr NULL == zeros);  h_out, c_out : new states (cell states fp32; with the
+ *             SF_BF16 kernel x / h_prev / h_out may each be SF_BF16-stored: a hidden state is only ever read
+ *             as a bf16 MFMA operand, so storing the rounded value changes no result).  SF_BF16 kernel:
+ *             every state / gate tensor needs 16-byte aligned pixels (pointer and stride)
  *   gates   : nullable; receives post-activation i,f,o,g as [.., 4*hidp] (gate-major) for backward
  *             (SF_F32 or SF_BF16 storage: backward-only data, the outputs do not depend on it)
  *   wpacked : image from sf_conv3x3_pack_weights with the LSTM nmap (32 hidden channels x 4 gates

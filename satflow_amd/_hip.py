@@ -179,7 +179,15 @@ def compute_dtype_name() -> str:
 
 def gate_storage_dtype():
     """torch dtype the ConvLSTM stack keeps its saved gates / gate gradients in (bf16 in "bf16a" mode; they are read by the
-    backward pass only: forward results do not depend on it).  Hidden and cell states stay fp32."""
+    backward pass only: forward results do not depend on it)."""
+    return torch.bfloat16 if _ENCODER_BF16[0] else torch.float32
+
+
+def state_storage_dtype():
+    """torch dtype the ConvLSTM stack keeps its HIDDEN states in (bf16 in "bf16a" mode).  A hidden state is only ever read as
+    an MFMA operand (next cell's convolution, the output convolution, the weight gradient), which rounds it to bf16 anyway:
+    storing the rounded value changes no result of the "bf16" mode, halves its traffic and lets the kernels stage it by
+    LDS-DMA.  Cell states stay fp32."""
     return torch.bfloat16 if _ENCODER_BF16[0] else torch.float32
 
 

@@ -254,8 +254,11 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
                          sfTensor gates, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
   if (check_src(x, "convlstm x") || check_src(h_prev, "convlstm h_prev")) return 1;
-  SF_F32_ONLY(x, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_prev, "sf_convlstm_cell_fwd");
-  SF_F32_ONLY(h_out, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_out, "sf_convlstm_cell_fwd");
+  SF_F32_ONLY(c_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_out, "sf_convlstm_cell_fwd");
+  if (dtype != SF_BF16) {  // bf16-stored x / hidden states: SF_BF16 kernel only
+    SF_F32_ONLY(x, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_out, "sf_convlstm_cell_fwd");
+  }
+  SF_REQUIRE(h_out.dtype == SF_F32 || h_out.dtype == SF_BF16, "sf_convlstm_cell_fwd: h_out storage type %d", h_out.dtype);
   SF_REQUIRE(!gates.ptr || gates.dtype == SF_F32 || gates.dtype == SF_BF16, "sf_convlstm_cell_fwd: gates storage type %d", gates.dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp, "convlstm: hidp=%d h_prev.c=%d", hidp, h_prev.c);
   SF_REQUIRE(x.ptr && h_out.ptr && c_out.ptr, "convlstm: x, h_out, c_out must be non-null");
@@ -269,6 +272,8 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   p.c_out = (float*)c_out.ptr; p.cout_s = c_out.stride;
   p.h_out = (float*)h_out.ptr; p.hout_s = h_out.stride;
   p.gates = (float*)gates.ptr; p.gates_s = gates.stride; p.gates_bf = gates.ptr && gates.dtype == SF_BF16;
+  p.hout_bf = h_out.dtype == SF_BF16;
+  p.bf0 = x.dtype == SF_BF16; p.bf1 = h_prev.ptr && h_prev.dtype == SF_BF16;
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
   if (dtype == SF_BF16) {  // pixel-per-lane epilogue: states and gates move as 16-byte quads / octets

@@ -32,6 +32,7 @@ struct ConvParams {
   // storage types (bf16 kernel only; linear / sigmoid epilogues): non-zero = bf16 elements behind src0 / src1 / out
   int bf0, bf1, out_bf;
   int gates_bf;  // lstm epilogue: the saved gates are stored as bf16 (they are read by the backward pass only)
+  int hout_bf;   // lstm epilogue (bf16 kernel): the new hidden state is stored as bf16 (it is only ever read as an MFMA operand)
   // bf16 kernel, linear epilogue: per-tile sum / sum of squares of the stored outputs, [tile][stats_np][2] (or null)
   float* stats; int stats_np;
 };
@@ -305,8 +306,19 @@ __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const Con
       for (int g = 0; g < 4; ++g)
         if (ok && hb + 8 * g < p.hidp) {
           *reinterpret_cast<f32x4*>(p.c_out + pix * p.cout_s + hb + 8 * g) = cn[g];
-          *reinterpret_cast<f32x4*>(p.h_out + pix * p.hout_s + hb + 8 * g) = hn[g];
+          if (!p.hout_bf) *reinterpret_cast<f32x4*>(p.h_out + pix * p.hout_s + hb + 8 * g) = hn[g];
         }
+      if (p.hout_bf) {
+        __bf16* hp = reinterpret_cast<__bf16*>(p.h_out) + pix * p.hout_s + nb * 32 + 8 * kh;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          unsigned ax = pk(hn[g][0], hn[g][1]), ay = pk(hn[g][2], hn[g][3]);
+          unsigned bx = pk(hn[g + 1][0], hn[g + 1][1]), by = pk(hn[g + 1][2], hn[g + 1][3]);
+          auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          if (ok && nb * 32 + 8 * g < p.hidp) *reinterpret_cast<u32x4_t*>(hp + 8 * g) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+        }
+      }
       if (p.gates) {
         if (p.gates_bf) {
           __bf16* gp = reinterpret_cast<__bf16*>(p.gates) + pix * p.gates_s + nb * 32 + 8 * kh;

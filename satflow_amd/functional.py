@@ -127,6 +127,10 @@ class _ConvFn(torch.autograd.Function):
         gy = gy.contiguous()
         if ctx.sigmoid:
             gy = gy * y * (1.0 - y)  # pointwise torch op on the small head tensor only
+        if x0.dtype == torch.bfloat16 and gy.dtype != torch.bfloat16:
+            # bf16-stored sources take a bf16-stored output gradient (weight-gradient kernel).  Exact: both kernels below
+            # round the gradient to bf16 when they build their MFMA operands anyway.
+            gy = gy.to(torch.bfloat16)
         need = (ctx.needs_input_grad[1], has_x1 and ctx.needs_input_grad[2])
         if (need[0] and remap0 != (0, 0)) or (need[1] and remap1 != (0, 0)):
             raise RuntimeError("gradient wrt a broadcast (image-remapped) convolution source is not implemented")

@@ -24,7 +24,8 @@ from torch import nn
 
 from .. import kernels as K
 from ..functional import ConvEngine, _FromNHWC, _ToNHWC, conv3x3, nchw_to_nhwc, nhwc_to_nchw  # noqa: F401 (re-exported)
-from .._hip import NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, gate_storage_dtype, generation, require_device, sfTensor
+from .._hip import (NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, gate_storage_dtype, generation, require_device, sfTensor,
+                     state_storage_dtype)
 from .base import LightningModule, get_loss, register_model
 from .layers.ConvLSTM import CellEngine, ConvLSTMCell
 
@@ -54,7 +55,13 @@ class _StackFn(torch.autograd.Function):
             return torch.empty(steps, B, H, W, ch, dtype=dtype, device=dev)
 
         steps = (T_in, T_in, T_out, T_out)
-        Hs = [seq(s, hidp) for s in steps]
+        # hidden states: fp32, or bf16 in "bf16a" mode (they are only ever read as bf16 MFMA operands: same results, half
+        # the traffic, LDS-DMA staging); the input frames follow them so that every convolution source has one storage type
+        st = state_storage_dtype()
+        need_dx = x.requires_grad
+        if x.dtype != st:
+            x = x.to(st)
+        Hs = [seq(s, hidp, st) for s in steps]
         Cs = [seq(s, hidp) for s in steps]
         # saved gates (later overwritten by dz): backward-only data, bf16 in "bf16a" mode - half of the stack's HBM traffic
         Gs = [seq(s, 4 * hidp, gate_storage_dtype()) if keep else None for s in steps]
@@ -72,7 +79,7 @@ class _StackFn(torch.autograd.Function):
             run(3, d2, Hs[2][s], s)
 
         ctx.engines, ctx.dims = engines, (B, T_in, T_out, H, W)
-        ctx.need_dx = x.requires_grad
+        ctx.need_dx = need_dx
         if keep:
             ctx.save_for_backward(x, *Hs, *Cs, *Gs)
         return Hs[3].view(T_out * B, H, W, hidp)
@@ -85,14 +92,14 @@ class _StackFn(torch.autograd.Function):
         x, Hs, Cs, Gs = saved[0], saved[1:5], saved[5:9], saved[9:13]
         hidp = e1.hidp
         dev = x.device
-        g_out = g_out.contiguous().view(T_out, B, H, W, hidp)
+        g_out = g_out.contiguous().float().view(T_out, B, H, W, hidp)  # gradients of the states are fp32 throughout
         xs = x.view(T_in, B, H, W, x.shape[-1])
         need_dx = [ctx.need_dx, True, True, True]
         # per cell: [dx (if needed) ; dh_prev] scratch of the input-gradient conv, and the dc carry
         widths = [(eng.cinp if nd else 0) + hidp for eng, nd in zip(engines, need_dx)]
         dcat = [torch.empty(B, H, W, wd, dtype=torch.float32, device=dev) for wd in widths]
         dc = [torch.empty(B, H, W, hidp, dtype=torch.float32, device=dev) for _ in range(4)]
-        dxs = torch.empty_like(xs) if ctx.need_dx else None
+        dxs = torch.empty(xs.shape, dtype=torch.float32, device=dev) if ctx.need_dx else None
 
         def dx_of(k: int) -> sfTensor:  # gradient wrt the cell's layer input, left by its last bwd_data
             return T(dcat[k], engines[k].cinp, 0)
@@ -125,7 +132,7 @@ class _StackFn(torch.autograd.Function):
 
         # weight gradients: one split-K GEMM per cell over all of its timesteps (Gs now hold dz)
         grads: List[Optional[Tensor]] = []
-        zeros = torch.zeros(B, H, W, hidp, dtype=torch.float32, device=dev)
+        zeros = torch.zeros(B, H, W, hidp, dtype=Hs[0].dtype, device=dev)
 
         def wgrad(eng: CellEngine, inp: sfTensor, hprev: sfTensor, dz: Tensor, steps: int, dw: Tensor, db: Tensor, acc: bool):
             eng.bwd_weight(inp, hprev, T(dz), steps * B, H, W, dw, db, acc)

@@ -210,8 +210,9 @@ def test_metnet_bf16a_train_step(device, bf16a_mode):
 
 @pytest.mark.parametrize("case", ["cfg1_h8", "cfg1_h32_hot", "rect_h16_o12", "cfg1_h64_hot"])
 def test_convlstm_bf16a_vs_bf16(device, case):
-    """ConvLSTM stack with bf16-STORED gates / gate gradients ("bf16a") against the same stack with fp32-stored ones ("bf16"):
-    the forward pass never reads the stored gates, so predictions are bit-identical; every parameter gradient and the
+    """ConvLSTM stack with bf16-STORED hidden states, gates and gate gradients ("bf16a") against the same stack with fp32-stored
+    ones ("bf16"): the forward pass never reads the stored gates and reads a hidden state only as a bf16 MFMA operand (the
+    stored value IS that operand), so predictions are bit-identical; every parameter gradient and the
     input gradient stay within a few bf16 ulps (relative L2) of the fp32-storage run and as close to the reference golden."""
     from test_convlstm_gpu import _load, _model_from_golden
 
