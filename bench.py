@@ -105,12 +105,16 @@ class ConvLSTMWorkload:
         from satflow_amd._hip import T
         eng = self.model.model.encoder_2_convlstm.engine
         B, H, W, hid = self.B, self.H, self.W, self.hid
-        mk = lambda c: torch.randn(B, H, W, c, device=self.dev)
-        x, h, c, ho, co, g = mk(hid), mk(hid), mk(hid), mk(hid), mk(hid), mk(4 * hid)
+        import satflow_amd
+        from satflow_amd._hip import gate_storage_dtype, state_storage_dtype
+        st, gt = state_storage_dtype(), gate_storage_dtype()  # the storage types the training step uses in this mode
+        mk = lambda c, dt=torch.float32: torch.randn(B, H, W, c, device=self.dev).to(dt)
+        x, h, c, ho, co, g = mk(hid, st), mk(hid, st), mk(hid), mk(hid, st), mk(hid), mk(4 * hid, gt)
         t = event_time(lambda: eng.step(T(x), h, c, B, H, W, ho, co, g), iters=20)
         flops = 2 * 9 * (hid + hid) * 4 * hid * H * W * B
-        alg_bytes = (hid + 2 * hid + 2 * hid) * H * W * B * 4 + 9 * 2 * hid * 4 * hid * 4
-        import satflow_amd
+        sb = 2 if st == torch.bfloat16 else 4
+        # read x, h, c; write h', c'; weights once (the saved gates of the training step are extra)
+        alg_bytes = ((hid + hid + hid) * sb + 2 * hid * 4) * H * W * B + 9 * 2 * hid * 4 * hid * 4
         bf16 = satflow_amd.compute_dtype_name() in ("bf16", "bf16a")
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
@@ -299,9 +303,9 @@ def main():
             "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",
             "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 storage of all activations",
             "bf16a": "bf16 MFMA operands, fp32 accumulate; MetNet image-encoder activations and their gradients stored as bf16 "
-                     "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers), ConvLSTM saved gates / gate "
-                     "gradients stored as bf16 (backward-only data); parameters, hidden / cell states, ConvGRU, attention, loss "
-                     "and optimizer state fp32",
+                     "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers), ConvLSTM hidden states (only ever read as bf16 "
+                     "MFMA operands: bit-identical predictions) and saved gates / gate gradients (backward-only data) stored as "
+                     "bf16; parameters, cell states, state gradients, ConvGRU, attention, loss and optimizer state fp32",
         }[args.dtype]
         out["config"]["mode"] = args.dtype
         out["roofline"] = wl.roofline()
