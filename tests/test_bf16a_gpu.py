@@ -260,3 +260,37 @@ def test_wgrad_bf16_dout_fp32_sources(device, bf16a_mode):
         out.append((dw, db))
     assert_close(out[0][0], out[1][0], "dW: bf16 vs widened fp32 dout", grad=True)
     assert_close(out[0][1], out[1][1], "db", grad=True)
+
+
+@pytest.mark.parametrize("cin,hid,n,h,w", [(12, 64, 2, 32, 32), (4, 8, 2, 20, 24), (64, 64, 1, 40, 33)])
+def test_convlstm_cell_bf16_states(device, bf16a_mode, cin, hid, n, h, w):
+    """sf_convlstm_cell_fwd with bf16-STORED x / h_prev / h_out and bf16 gates against the same call on the fp32 widening of
+    the same (bf16-representable) inputs: the cell state must agree bit for bit (the MFMA operands are identical), the stored
+    hidden state and gates must be the round-to-nearest-even of the fp32-stored ones."""
+    from satflow_amd._hip import T
+    from satflow_amd.models.layers.ConvLSTM import ConvLSTMCell
+
+    g = torch.Generator().manual_seed(5)
+    cell = ConvLSTMCell(cin, hid, (3, 3), True)
+    with torch.no_grad():
+        cell.conv.weight.mul_(4.0)
+        cell.conv.bias.uniform_(-1, 1, generator=g)
+    cell = cell.to(device)
+    eng = cell.engine
+    rnd = lambda *s: _r(torch.randn(*s, generator=g)).to(device)
+    x, h0 = rnd(n, h, w, eng.cinp), rnd(n, h, w, eng.hidp)
+    x[..., cin:] = 0; h0[..., hid:] = 0
+    c0 = torch.randn(n, h, w, eng.hidp, generator=g).to(device)
+    out = {}
+    for st in (torch.float32, torch.bfloat16):
+        h1 = torch.empty(n, h, w, eng.hidp, device=device, dtype=st)
+        c1 = torch.empty(n, h, w, eng.hidp, device=device)
+        gates = torch.empty(n, h, w, 4 * eng.hidp, device=device, dtype=st)
+        xs, hs = x.to(st), h0.to(st)  # keep the converted copies alive: a descriptor does not own its tensor
+        eng.step(T(xs), hs, c0, n, h, w, h1, c1, gates)
+        out[st] = (h1, c1, gates)
+    f, b = out[torch.float32], out[torch.bfloat16]
+    assert torch.equal(f[1], b[1]), "cell state depends on the storage type of x / h"
+    assert torch.equal(f[0].bfloat16()[..., :hid], b[0][..., :hid]), "bf16-stored hidden state is not the rounded fp32 one"
+    assert torch.equal(f[2].bfloat16(), b[2]), "bf16-stored gates are not the rounded fp32 ones"
+    assert float(f[1].abs().max()) > 0.5 and torch.isfinite(f[0]).all()
