@@ -90,7 +90,9 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
  * (satflow/models/conv_lstm.py:164-169,200-201), the DownSampler convolutions of metnet.MetNet
  * (call site satflow/models/pl_metnet.py:46-59) and, with a transpose==1 weight image, the
  * input-gradient of every convolution on the path.
- * out.c output channels are written (pad lanes included); Np >= out.c.
+ * out.c output channels are written (pad lanes included); Np >= out.c.  The SF_BF16 kernel stores 16-byte
+ * channel groups per pixel: out.ptr and bias_packed 16-byte aligned, out.stride a multiple of 4 (fp32) / 8 (bf16
+ * storage), out.c a multiple of 8.
  * ------------------------------------------------------------------------------------------- */
 int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w,
                    const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,

@@ -226,6 +226,10 @@ static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, 
   p.stats = stats; p.stats_np = Np;
   if (dtype == SF_BF16) {
     SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
+    // the SF_BF16 kernel stores 16-byte channel quads (fp32) / octets (bf16) per pixel
+    SF_REQUIRE(out.ptr && ((uintptr_t)out.ptr & 15) == 0 && out.stride % (p.out_bf ? 8 : 4) == 0 && out.c % 8 == 0,
+               "conv3x3: the SF_BF16 kernel needs a 16-byte aligned output (pointer, stride %d, channels %d)", out.stride, out.c);
+    SF_REQUIRE(!bias_packed || ((uintptr_t)bias_packed & 15) == 0, "conv3x3: bias_packed must be 16-byte aligned");
     return sf_launch_conv_bf16(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
   }
   if (epilogue == SF_EPI_LINEAR) return launch_conv<EPI_LINEAR>(p, nf, nblk, (hipStream_t)stream);

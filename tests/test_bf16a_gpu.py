@@ -91,6 +91,25 @@ def test_conv3x3_bf16_source_fp32_out(device, bf16a_mode):
     assert_close(_nchw(y, 40), TF.conv2d(xr, _r(wt), None, padding=1), "bf16 source -> fp32 output")
 
 
+def test_conv3x3_bf16_kernel_rejects_misaligned_output(device, bf16a_mode):
+    """The SF_BF16 kernel writes 16-byte channel groups: a channel-slice output that starts on a 4-channel boundary of a
+    bf16 tensor (8 bytes) must be refused by the C entry, not written with misaligned stores."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import NULL, T
+    from satflow_amd.functional import ConvEngine
+
+    eng = ConvEngine([16], 16)
+    w = torch.randn(16, 16, 3, 3, device=device); b = torch.randn(16, device=device)
+    packed, bp = K.pack_weights(w, b, eng.fwd_map, False)
+    x = torch.randn(1, 8, 8, 16, device=device).bfloat16()
+    y = torch.zeros(1, 8, 8, 32, device=device, dtype=torch.bfloat16)
+    with pytest.raises(RuntimeError, match="16-byte aligned output"):
+        K.conv3x3(T(x), NULL, 1, 8, 8, packed, bp, eng.fwd_map, T(y, 16, 4))
+    K.conv3x3(T(x), NULL, 1, 8, 8, packed, bp, eng.fwd_map, T(y, 16, 8))  # an 8-channel (16-byte) offset is fine
+    torch.cuda.synchronize()
+    assert float(y[..., 8:24].float().abs().max()) > 0 and float(y[..., :8].float().abs().max()) == 0
+
+
 def test_bf16_storage_needs_bf16_kernels(device):
     from satflow_amd.functional import ConvEngine, conv3x3
 
