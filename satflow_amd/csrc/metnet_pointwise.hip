@@ -193,18 +193,41 @@ __global__ __launch_bounds__(256) void bn_reduce_kernel(const TA* __restrict__ x
 }
 
 // sums[g][2][C] (fp64) from the convolution's per-tile records stats[tile][np][2] (fp32), tiles of group g = [g*tpg, (g+1)*tpg)
-__global__ void bn_sum_tiles_kernel(const float* __restrict__ stats, int tpg, int np, int C, double* __restrict__ sums) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x, g = blockIdx.y, which = blockIdx.z;
-  if (c >= C) return;
-  const float* p = stats + ((size_t)g * tpg * np + c) * 2 + which;
-  double a[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // 8 independent chains: 8 loads in flight (fixed order: deterministic)
-  int t = 0;
-  for (; t + 8 <= tpg; t += 8) {
+// 8 threads share a (group, channel): each walks every 8th tile record (sum and sum of squares in one 8-byte load, 8 loads in
+// flight) and the 8 partial sums are combined through LDS in a fixed order.  (One thread per output walking all 384 tiles
+// was 48 workgroups of pure load latency: 31 us.)
+__global__ __launch_bounds__(256) void bn_sum_tiles_kernel(const float* __restrict__ stats, int tpg, int np, int C, double* __restrict__ sums) {
+  __shared__ double red[8][32][2];
+  const int lc = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lc, g = blockIdx.y;
+  double a0 = 0, a1 = 0;
+  if (c < C) {
+    typedef float f32x2_t __attribute__((ext_vector_type(2)));
+    const f32x2_t* p = reinterpret_cast<const f32x2_t*>(stats + ((size_t)g * tpg * np + c) * 2);
+    double s1[8] = {0, 0, 0, 0, 0, 0, 0, 0}, s2[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    int t = part;
+    for (; t + 56 < tpg; t += 64) {
 #pragma unroll
-    for (int u = 0; u < 8; ++u) a[u] += (double)p[(size_t)(t + u) * np * 2];
+      for (int u = 0; u < 8; ++u) {
+        const f32x2_t v = p[(size_t)(t + 8 * u) * np];
+        s1[u] += (double)v[0]; s2[u] += (double)v[1];
+      }
+    }
+    for (; t < tpg; t += 8) {
+      const f32x2_t v = p[(size_t)t * np];
+      s1[0] += (double)v[0]; s2[0] += (double)v[1];
+    }
+    a0 = ((s1[0] + s1[1]) + (s1[2] + s1[3])) + ((s1[4] + s1[5]) + (s1[6] + s1[7]));
+    a1 = ((s2[0] + s2[1]) + (s2[2] + s2[3])) + ((s2[4] + s2[5]) + (s2[6] + s2[7]));
   }
-  for (; t < tpg; ++t) a[0] += (double)p[(size_t)t * np * 2];
-  sums[((size_t)g * 2 + which) * C + c] = ((a[0] + a[1]) + (a[2] + a[3])) + ((a[4] + a[5]) + (a[6] + a[7]));
+  red[part][lc][0] = a0; red[part][lc][1] = a1;
+  __syncthreads();
+  if (part < 2 && c < C) {  // part 0 -> sum, part 1 -> sum of squares
+    double t = 0;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) t += red[q][lc][part];
+    sums[((size_t)g * 2 + part) * C + c] = t;
+  }
 }
 
 // finalize forward statistics: mean/rstd per (group, channel), affine a = gamma*rstd, b = beta - mean*a;
@@ -435,7 +458,7 @@ static int bn_train_fwd_impl(sfTensor x, int64_t pix_per_group, int32_t groups, 
   SF_REQUIRE(x.c == y.c && ok8(x) && ok8(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm: channels (multiple of 8, 16-byte aligned) / storage type");
   if (stats) {
     SF_REQUIRE(tiles_per_group > 0 && stats_np >= x.c, "batchnorm: tiles_per_group=%d stats_np=%d", tiles_per_group, stats_np);
-    hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3((x.c + 127) / 128, groups, 2), dim3(128), 0, st, stats, tiles_per_group, stats_np, x.c, sums);
+    hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3((x.c + 31) / 32, groups), dim3(256), 0, st, stats, tiles_per_group, stats_np, x.c, sums);
     SF_CHECK_LAUNCH("bn_sum_tiles");
   } else {
     sfTensor none{nullptr, 0, 0, 0, 0, 0};
