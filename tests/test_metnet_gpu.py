@@ -118,7 +118,7 @@ def _attn_params(module, prefix="temporal_agg.0"):
     return {f"{prefix}.{k}": v.detach().cpu().clone().requires_grad_() for k, v in module.state_dict().items()}
 
 
-@pytest.mark.parametrize("n,hid,h,w", [(2, 64, 16, 16), (3, 32, 4, 6), (1, 16, 2, 2), (2, 40, 5, 3)])
+@pytest.mark.parametrize("n,hid,h,w", [(2, 64, 16, 16), (3, 32, 16, 16), (3, 32, 4, 6), (1, 16, 2, 2), (2, 40, 5, 3), (1, 64, 16, 12)])
 def test_axial_attention(device, n, hid, h, w):
     from satflow_amd.models.metnet import AxialAttention
 
