@@ -27,32 +27,51 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+  // loads are unconditional from clamped rows and selected afterwards: a load under `if (row < rows)` is emitted as
+  // load -> s_waitcnt vmcnt(0) -> use, one K step at a time (compiler lesson)
   const long long row = row0 + r;
-  const float* xr = x + row * xs + kh * 4;
-  for (int q = 0; q < K / 8; ++q) {
-    f32x4 a = {0.f, 0.f, 0.f, 0.f};
-    if (row < rows) a = ld4(xr + q * 8);
-    f32x4 b[NF];
-#pragma unroll
-    for (int nf = 0; nf < NF; ++nf) {
-      const int n = n0 + nf * 32 + r;
-      b[nf] = f32x4{0.f, 0.f, 0.f, 0.f};
-      if (n < N) b[nf] = ld4(W + (long long)n * K + q * 8 + kh * 4);
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-#pragma unroll
-      for (int nf = 0; nf < NF; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[j], b[nf][j], acc[nf], 0, 0, 0);
-  }
+  const bool row_ok = row < rows;
+  const bool vec_out = (((uintptr_t)y) & 15) == 0 && ys % 4 == 0;
+  const float* xr = x + (row_ok ? row : rows - 1) * xs + kh * 4;
+  const float* wr[NF]; bool n_ok[NF];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
     const int n = n0 + nf * 32 + r;
-    if (n < yc) {
-      const float bv = (bias && n < N) ? bias[n] : 0.f;
+    n_ok[nf] = n < N;
+    wr[nf] = W + (long long)(n_ok[nf] ? n : N - 1) * K + kh * 4;
+  }
+  const f32x4 zero = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 2
+  for (int q = 0; q < K / 8; ++q) {
+    f32x4 a = ld4(xr + q * 8);
+    f32x4 b[NF];
 #pragma unroll
-      for (int reg = 0; reg < 16; ++reg) {
-        const long long orow = row0 + frag_row(reg, kh);
-        if (orow < rows) y[orow * ys + n] = acc[nf][reg] + bv;
+    for (int nf = 0; nf < NF; ++nf) b[nf] = ld4(wr[nf] + q * 8);
+    a = row_ok ? a : zero;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) b[nf] = n_ok[nf] ? b[nf] : zero;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nf][j], a[j], acc[nf], 0, 0, 0);  // transposed product
+  }
+  // D[i][j]: i = output column within the fragment (8g + 4kh + c), j = this lane's row: 16-byte stores of column quads
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + nf * 32 + 8 * g + 4 * kh;
+      if (row_ok && n < yc) {
+        f32x4 v = {acc[nf][4 * g], acc[nf][4 * g + 1], acc[nf][4 * g + 2], acc[nf][4 * g + 3]};
+        if (bias) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += (n + c < N) ? bias[n + c] : 0.f;
+        }
+        if (vec_out && n + 3 < yc) *reinterpret_cast<f32x4*>(y + row * ys + n) = v;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) if (n + c < yc) y[row * ys + n + c] = v[c];
+        }
       }
     }
   }
@@ -75,16 +94,31 @@ __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restri
   const long long chunk = ((rows + KS - 1) / KS + 1) & ~1LL;  // even
   const long long p0 = (long long)blockIdx.x * chunk;
   const long long p1 = p0 + chunk < rows ? p0 + chunk : rows;
-  for (long long p = p0; p < p1; p += 2) {
-    const long long pp = p + kh;
-    float a = 0.f;
-    if (pp < p1 && n < N) a = dy[pp * dys + n];
-    asum += a;
+  // unconditional loads from clamped addresses, selected afterwards, 4 pixel pairs in flight (see linear_fwd_kernel)
+  const int nc = n < N ? n : N - 1;
+  int kc[KF]; bool k_ok[KF];
 #pragma unroll
-    for (int kf = 0; kf < KF; ++kf) {
-      float b = 0.f;
-      if (pp < p1 && kf * 32 + r < K) b = x[pp * xs + kf * 32 + r];
-      acc[kf] = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc[kf], 0, 0, 0);
+  for (int kf = 0; kf < KF; ++kf) { k_ok[kf] = kf * 32 + r < K; kc[kf] = k_ok[kf] ? kf * 32 + r : K - 1; }
+  if (p0 < p1) {
+    for (long long p = p0; p < p1; p += 8) {
+      float a[4], b[4][KF]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long pp = p + 2 * u + kh;
+        ok[u] = pp < p1;
+        const long long pc = ok[u] ? pp : p1 - 1;
+        a[u] = dy[pc * dys + nc];
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf) b[u][kf] = x[pc * xs + kc[kf]];
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const float av = (ok[u] && n < N) ? a[u] : 0.f;
+        asum += av;
+#pragma unroll
+        for (int kf = 0; kf < KF; ++kf)
+          acc[kf] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, (ok[u] && k_ok[kf]) ? b[u][kf] : 0.f, acc[kf], 0, 0, 0);
+      }
     }
   }
   const int Kpad = KF * 32;
