@@ -13,42 +13,53 @@ __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
 // loss_sums[0] = sum (p-y)^2 ; loss_sums[1 + f] = per-frame sums; grad = 2 (p - y) / n
+// A workgroup owns one piece (1/pieces) of one `inner`-sized frame slab, so its partial sum belongs to one frame.  In the
+// 16-byte path the loads of four 1024-element strides are issued together from clamped offsets and selected afterwards
+// (a load under a per-element condition is emitted as load -> vmcnt(0) -> store, one element at a time).
 __global__ __launch_bounds__(256) void mse_kernel(const float* __restrict__ pred, const float* __restrict__ target, long long n,
                                                   long long inner, int frames, float gscale, float* __restrict__ grad,
-                                                  double* __restrict__ sums) {
-  __shared__ double red[64];
-  double tot = 0.0;
+                                                  double* __restrict__ sums, int pieces, long long piece_len) {
+  __shared__ double red[4];
   const bool vec = (inner & 3) == 0;  // 16-byte accesses need every slab base 4-aligned
-  // each block walks whole `inner`-sized frame slabs so that a block-level partial belongs to one frame
-  const long long slabs = n / inner;
-  for (long long s = blockIdx.x; s < slabs; s += gridDim.x) {
-    double acc = 0.0;
-    const long long base = s * inner;
-    for (long long i = threadIdx.x * 4; i < inner; i += 256 * 4) {
-      if (vec && i + 3 < inner) {
-        const f32x4 d = ld4(pred + base + i) - ld4(target + base + i);
-        if (grad) st4(grad + base + i, d * gscale);
-        acc += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
-      } else {
-        for (long long j = i; j < inner && j < i + 4; ++j) {
-          const float d = pred[base + j] - target[base + j];
-          if (grad) grad[base + j] = d * gscale;
-          acc += (double)(d * d);
+  const long long s = blockIdx.x / pieces;
+  const int piece = blockIdx.x % pieces;
+  const long long base = s * inner;
+  const long long lo = piece * piece_len, hi = lo + piece_len < inner ? lo + piece_len : inner;
+  double acc = 0.0;
+  if (vec) {
+    for (long long i0 = lo + threadIdx.x * 4; i0 < hi; i0 += 4096) {
+      f32x4 a[4], b[4]; bool ok[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long i = i0 + u * 1024;
+        ok[u] = i < hi;  // hi and i are multiples of 4
+        const long long ic = ok[u] ? i : lo;
+        a[u] = ld4(pred + base + ic); b[u] = ld4(target + base + ic);
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        if (ok[u]) {
+          const f32x4 d = a[u] - b[u];
+          if (grad) st4(grad + base + i0 + u * 1024, d * gscale);
+          acc += (double)(d[0] * d[0] + d[1] * d[1] + d[2] * d[2] + d[3] * d[3]);
         }
       }
     }
-    // block reduce
-    for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
-    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-      const double a = red[0] + red[1] + red[2] + red[3];
-      atomicAdd(sums + 1 + (s % frames), a);
-      tot += a;
+  } else {
+    for (long long j = lo + threadIdx.x; j < hi; j += 256) {
+      const float d = pred[base + j] - target[base + j];
+      if (grad) grad[base + j] = d * gscale;
+      acc += (double)(d * d);
     }
-    __syncthreads();
   }
-  if (threadIdx.x == 0 && tot != 0.0) atomicAdd(sums, tot);
+  for (int o = 32; o > 0; o >>= 1) acc += __shfl_down(acc, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const double t = red[0] + red[1] + red[2] + red[3];
+    atomicAdd(sums + 1 + (s % frames), t);
+    atomicAdd(sums, t);
+  }
 }
 
 __global__ void mse_finalize_kernel(const double* __restrict__ sums, long long n, int frames, float* __restrict__ out) {
@@ -80,8 +91,12 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
   hipStream_t st = (hipStream_t)stream;
   SF_REQUIRE(hipMemsetAsync(sums, 0, sizeof(double) * (1 + frames), st) == hipSuccess, "mse: memset");
   const long long slabs = n / inner;
-  const int blocks = (int)(slabs < 2048 ? slabs : 2048);
-  hipLaunchKernelGGL(mse_kernel, dim3(blocks), dim3(256), 0, st, pred, target, (long long)n, (long long)inner, frames, 2.0f / (float)n, grad, sums);
+  int pieces = (int)(inner / 4096 < 16 ? inner / 4096 : 16);
+  if (pieces < 1) pieces = 1;
+  long long piece_len = ((inner + pieces - 1) / pieces + 1023) / 1024 * 1024;  // multiple of 1024: pieces stay 16-byte aligned
+  SF_REQUIRE(slabs * pieces < (1ll << 31), "mse: too many slabs (%lld)", (long long)slabs);
+  hipLaunchKernelGGL(mse_kernel, dim3((unsigned)(slabs * pieces)), dim3(256), 0, st, pred, target, (long long)n, (long long)inner, frames,
+                     2.0f / (float)n, grad, sums, pieces, piece_len);
   SF_CHECK_LAUNCH("mse");
   hipLaunchKernelGGL(mse_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, (long long)n, frames, out);
   SF_CHECK_LAUNCH("mse_finalize");
