@@ -134,8 +134,15 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
   if (db && gid < (size_t)NpT) {
     const int co = (int)gid;
     if (co < Np && nmap[co] >= 0) {
-      float s = 0.f;
-      for (int k = 0; k < KS; ++k) s += partial_db[(size_t)k * NpT + co];
+      // same 8-chain form as above: a serial walk over KS slabs by this one workgroup was the tail of the whole kernel
+      float t8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int k = 0;
+      for (; k + 8 <= KS; k += 8) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) t8[u] += partial_db[(size_t)(k + u) * NpT + co];
+      }
+      for (; k < KS; ++k) t8[0] += partial_db[(size_t)k * NpT + co];
+      const float s = ((t8[0] + t8[1]) + (t8[2] + t8[3])) + ((t8[4] + t8[5]) + (t8[6] + t8[7]));
       float* d = db + nmap[co];
       *d = accumulate ? *d + s : s;
     }
