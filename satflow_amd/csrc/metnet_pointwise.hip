@@ -793,10 +793,23 @@ __global__ __launch_bounds__(512) void leadbias_reduce_kernel(const float* __res
   const int i = blockIdx.x * 64 + threadIdx.x, grp = threadIdx.y;
   float a = 0.f;
   if (i < n) {
-    for (int b = grp; b < nborder; b += 8) a += border_part[(size_t)b * n + i];
+    float a4[4] = {0.f, 0.f, 0.f, 0.f};  // 4 loads in flight per chain (fixed order: deterministic)
+    int b = grp;
+    for (; b + 24 < nborder; b += 32) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) a4[u] += border_part[(size_t)(b + 8 * u) * n + i];
+    }
+    for (; b < nborder; b += 8) a4[0] += border_part[(size_t)b * n + i];
     const int c = i % C, cls = (i / C) % 9, l = i / (9 * C);
-    if (cls == 4)
-      for (int b = grp; b < nmain; b += 8) a += main_part[((size_t)b * L + l) * C + c];
+    if (cls == 4) {
+      b = grp;
+      for (; b + 24 < nmain; b += 32) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a4[u] += main_part[((size_t)(b + 8 * u) * L + l) * C + c];
+      }
+      for (; b < nmain; b += 8) a4[0] += main_part[((size_t)b * L + l) * C + c];
+    }
+    a = (a4[0] + a4[1]) + (a4[2] + a4[3]);
   }
   red[grp][threadIdx.x] = a;
   __syncthreads();
