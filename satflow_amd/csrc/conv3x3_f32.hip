@@ -311,11 +311,7 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
   p.h_prev = (const float*)h_prev.ptr; p.hprev_s = h_prev.stride;
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
-  if (dtype == SF_BF16) {  // pixel-per-lane epilogue: pre-activations, states and gates move as 16-byte quads
-    auto quad = [](const sfTensor& t) { return !t.ptr || (((uintptr_t)t.ptr & 15) == 0 && t.stride % 4 == 0); };
-    SF_REQUIRE(quad(gx) && quad(h_prev) && quad(h_out) && quad(gates), "sf_convgru_step_fwd: states / gates need 16-byte aligned pixels");
-    return sf_launch_conv_bf16(p, 3, nblk, EPI_GRU, (hipStream_t)stream);
-  }
+  if (dtype == SF_BF16) return sf_launch_conv_bf16(p, 3, nblk, EPI_GRU, (hipStream_t)stream);
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
   hipLaunchKernelGGL((conv3x3_f32_kernel<3, EPI_GRU>), grid, block, 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("convgru_step_fwd");

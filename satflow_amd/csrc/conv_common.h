@@ -212,55 +212,7 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
 template <int NF, int EPI>
 __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0,
                                                  int wave, int r, int kh) {
-  if constexpr (EPI == EPI_GRU) {
-    // fragments 0..2 = z, r and the candidate's h-part of hidden channels nb*32 + 8g + 4kh + c of this lane's pixel
-    static_assert(NF == 3, "GRU epilogue: z, r and the candidate's h-part in one wave");
-    const int hb = nb * 32 + 4 * kh;
-    const size_t pix_safe = (size_t)(n * p.H + y0) * p.W + x0;
-    f32x4 b2[4];
-#pragma unroll
-    for (int g = 0; g < 4; ++g) b2[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb * 96 + 64 + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
-      const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
-      const bool ok = py < p.H && px < p.W;
-      const size_t pix = ok ? (size_t)(n * p.H + py) * p.W + px : pix_safe;
-      f32x4 gz[4], gr[4], gn[4], hp[4];
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {  // unconditional loads from clamped addresses
-        const int hq = (hb + 8 * g < p.hidp) ? hb + 8 * g : 0;
-        const float* gx = p.gx + pix * p.gx_s + hq;
-        gz[g] = *reinterpret_cast<const f32x4*>(gx);
-        gr[g] = *reinterpret_cast<const f32x4*>(gx + p.hidp);
-        gn[g] = *reinterpret_cast<const f32x4*>(gx + 2 * p.hidp);
-        hp[g] = p.h_prev ? *reinterpret_cast<const f32x4*>(p.h_prev + pix * p.hprev_s + hq) : f32x4{0.f, 0.f, 0.f, 0.f};
-      }
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 z, rg, h2, cand, hn;
-#pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          z[c] = sf_sigmoid(acc[mf][0][4 * g + c] + gz[g][c]);
-          rg[c] = sf_sigmoid(acc[mf][1][4 * g + c] + gr[g][c]);
-          h2[c] = acc[mf][2][4 * g + c] + b2[g][c];
-          cand[c] = sf_tanh(gn[g][c] + rg[c] * h2[c]);
-          hn[c] = (1.f - z[c]) * cand[c] + z[c] * hp[g][c];
-        }
-        if (ok && hb + 8 * g < p.hidp) {
-          *reinterpret_cast<f32x4*>(p.h_out + pix * p.hout_s + hb + 8 * g) = hn;
-          if (p.gates) {
-            float* gp = p.gates + pix * p.gates_s + hb + 8 * g;
-            *reinterpret_cast<f32x4*>(gp) = z;
-            *reinterpret_cast<f32x4*>(gp + p.hidp) = rg;
-            *reinterpret_cast<f32x4*>(gp + 2 * p.hidp) = cand;
-            *reinterpret_cast<f32x4*>(gp + 3 * p.hidp) = h2;
-          }
-        }
-      }
-    }
-    return;
-  }
-  static_assert(EPI == EPI_LINEAR || EPI == EPI_SIGMOID || EPI == EPI_LSTM || EPI == EPI_GRU, "transposed epilogue");
+  static_assert(EPI == EPI_LINEAR || EPI == EPI_SIGMOID || EPI == EPI_LSTM, "transposed epilogue: linear / sigmoid / lstm");
   constexpr int NB = 32 * NF;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
