@@ -19,7 +19,7 @@ for i,r in enumerate(step):
     gap=st-prev_end
     if gap>0: gaps+=gap
     name=r["Kernel_Name"]
-    if "copyBuffer" in name or "elementwise" in name or gap>20000:
+    if "copyBuffer" in name or gap>20000:
         print(f'{(st-t0)/1e3:9.1f}us dur {(en-st)/1e3:7.1f} gap {gap/1e3:6.1f} grid {r["Grid_Size_X"]:>9} {name[:70]}  | prev: {step[i-1]["Kernel_Name"][:40] if i else ""}')
     prev_end=max(prev_end,en)
 print("step span ms",(prev_end-t0)/1e6,"sum gaps ms",gaps/1e6,"kernels",len(step))
