@@ -62,7 +62,8 @@ typedef struct {
                      kernels (sf_metnet_preprocess_fwd, sf_conv3x3_fwd[_stats] / _bwd_weight with the SF_BF16 kernels,
                      sf_leadtime_pool_*, sf_batchnorm_*, sf_maxpool2_*), for the ConvLSTM's saved gates / gate
                      gradients (`gates` of sf_convlstm_cell_fwd, `gates` and `dz` of sf_convlstm_cell_bwd_gates, `dout`
-                     of sf_conv3x3_bwd_weight against fp32 sources) and for the ConvLSTM's layer inputs / hidden states
+                     of sf_conv3x3_bwd_weight against fp32 sources; `gates` of sf_convgru_step_fwd, `gates`, `dgx`,
+                     `dgh` of sf_convgru_bwd_gates) and for the ConvLSTM's layer inputs / hidden states
                      (`x`, `h_prev`, `h_out` of sf_convlstm_cell_fwd with the SF_BF16 kernel); everything else
                      requires SF_F32 */
 } sfTensor;
@@ -250,13 +251,15 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
 /* ConvGRUCell step, recurrent half:  given gx = conv_x(x_t) = [z_x | r_x | n_x] (+ their biases; one
  * sf_conv3x3_fwd over all timesteps at once) and h_prev (NULL ptr = zero state):
  *   [z_h | r_h | h2] = conv3x3(h_prev) (+ bias on h2);  z = sig(z_x+z_h), r = sig(r_x+r_h),
- *   n = tanh(n_x + r*h2),  h' = (1-z)*n + z*h_prev.   gates (nullable) <- [z | r | n | h2].
+ *   n = tanh(n_x + r*h2),  h' = (1-z)*n + z*h_prev.   gates (nullable) <- [z | r | n | h2] (SF_F32, or SF_BF16
+ *   storage with the SF_BF16 kernel: backward-only data, the states do not depend on it).
  * wpacked: GRU nmap (32 hidden channels x 3 maps per N block, nf == 3). */
 int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int32_t w,
                         const void* wpacked, const float* bias_packed, int32_t hidp, sfTensor h_out,
                         sfTensor gates, int32_t dtype, sfStream stream);
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
- * dh_direct = dh*z (nullable). */
+ * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
+ * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */
 int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor gates, sfTensor h_prev,
                          int64_t pixels, int32_t hidp, sfTensor dgx, sfTensor dgh,
                          sfTensor dh_direct, int32_t dtype, sfStream stream);

@@ -297,7 +297,7 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convgru_step_fwd: dtype %d not built", dtype);
   if (check_src(h_prev, "convgru h_prev")) return 1;
   SF_F32_ONLY(gx, "sf_convgru_step_fwd"); SF_F32_ONLY(h_prev, "sf_convgru_step_fwd"); SF_F32_ONLY(h_out, "sf_convgru_step_fwd");
-  SF_F32_ONLY(gates, "sf_convgru_step_fwd");
+  SF_REQUIRE(!gates.ptr || gates.dtype == SF_F32 || (gates.dtype == SF_BF16 && dtype == SF_BF16), "sf_convgru_step_fwd: gates storage type %d", gates.dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp && gx.c == 3 * hidp, "convgru: hidp=%d h_prev.c=%d gx.c=%d", hidp, h_prev.c, gx.c);
   SF_REQUIRE(gx.ptr && h_out.ptr, "convgru: gx and h_out must be non-null");
   ConvParams p{};
@@ -306,7 +306,7 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
   p.N = n; p.H = h; p.W = w; p.tiles_x = (w + TILE - 1) / TILE; p.tiles_y = (h + TILE - 1) / TILE;
   p.wp = (const float*)wpacked; p.bias = bias_packed; p.chunks_total = h_prev.c / KC;
   p.h_out = (float*)h_out.ptr; p.hout_s = h_out.stride;
-  p.gates = (float*)gates.ptr; p.gates_s = gates.stride;
+  p.gates = (float*)gates.ptr; p.gates_s = gates.stride; p.gates_bf = gates.ptr && gates.dtype == SF_BF16;
   p.gx = (const float*)gx.ptr; p.gx_s = gx.stride;
   p.h_prev = (const float*)h_prev.ptr; p.hprev_s = h_prev.stride;
   p.hidp = hidp;

@@ -135,8 +135,13 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
           if (ok[reg]) {
             p.h_out[pix[reg] * p.hout_s + hc] = (1.f - z) * cand + z * hp[reg];
             if (p.gates) {
-              float* gp = p.gates + pix[reg] * p.gates_s + hc;
-              gp[0] = z; gp[p.hidp] = rg; gp[2 * p.hidp] = cand; gp[3 * p.hidp] = h2;
+              if (p.gates_bf) {
+                __bf16* gp = reinterpret_cast<__bf16*>(p.gates) + pix[reg] * p.gates_s + hc;
+                gp[0] = (__bf16)z; gp[p.hidp] = (__bf16)rg; gp[2 * p.hidp] = (__bf16)cand; gp[3 * p.hidp] = (__bf16)h2;
+              } else {
+                float* gp = p.gates + pix[reg] * p.gates_s + hc;
+                gp[0] = z; gp[p.hidp] = rg; gp[2 * p.hidp] = cand; gp[3 * p.hidp] = h2;
+              }
             }
           }
         }

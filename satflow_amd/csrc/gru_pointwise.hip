@@ -11,10 +11,10 @@ namespace {
 
 struct GruBwdParams {
   const float* dh0; const float* dh1; const float* dh2; int s0, s1, s2;
-  const float* gates; int s_g;
+  const void* gates; int s_g;
   const float* h_prev; int s_hp;
-  float* dgx; int s_dgx;
-  float* dgh; int s_dgh;
+  void* dgx; int s_dgx;
+  void* dgh; int s_dgh;
   float* dh_direct; int s_dd;
   long long pixels; int hidp;
 };
@@ -22,6 +22,9 @@ struct GruBwdParams {
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 
+// TG: storage of the saved gates, TD: storage of dgx / dgh (fp32, or bf16 in "bf16a" mode: the gates are backward-only data
+// and the two gradient tensors are only ever read as bf16 MFMA operands by the convolutions behind them)
+template <typename TG, typename TD>
 __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p) {
   const int q = p.hidp >> 2;
   const long long total = p.pixels * q;
@@ -31,8 +34,8 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p
     f32x4 dh = ld4(p.dh0 + pix * p.s0 + c);
     if (p.dh1) dh += ld4(p.dh1 + pix * p.s1 + c);
     if (p.dh2) dh += ld4(p.dh2 + pix * p.s2 + c);
-    const float* g = p.gates + pix * p.s_g + c;
-    const f32x4 z = ld4(g), r = ld4(g + p.hidp), n = ld4(g + 2 * p.hidp), h2 = ld4(g + 3 * p.hidp);
+    const TG* g = reinterpret_cast<const TG*>(p.gates) + pix * p.s_g + c;
+    const f32x4 z = ldv4(g), r = ldv4(g + p.hidp), n = ldv4(g + 2 * p.hidp), h2 = ldv4(g + 3 * p.hidp);
     f32x4 hp = {0.f, 0.f, 0.f, 0.f};
     if (p.h_prev) hp = ld4(p.h_prev + pix * p.s_hp + c);
     f32x4 az, ar, an, d2, dd;
@@ -46,15 +49,18 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p
       az[j] = dz * z[j] * (1.f - z[j]);
       dd[j] = dh[j] * z[j];
     }
-    float* a = p.dgx + pix * p.s_dgx + c;
-    st4(a, az); st4(a + p.hidp, ar); st4(a + 2 * p.hidp, an);
-    float* b = p.dgh + pix * p.s_dgh + c;
-    st4(b, az); st4(b + p.hidp, ar); st4(b + 2 * p.hidp, d2);
+    TD* a = reinterpret_cast<TD*>(p.dgx) + pix * p.s_dgx + c;
+    stv4(a, az); stv4(a + p.hidp, ar); stv4(a + 2 * p.hidp, an);
+    TD* b = reinterpret_cast<TD*>(p.dgh) + pix * p.s_dgh + c;
+    stv4(b, az); stv4(b + p.hidp, ar); stv4(b + 2 * p.hidp, d2);
     if (p.dh_direct) st4(p.dh_direct + pix * p.s_dd + c, dd);
   }
 }
 
 bool ok4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.dtype == SF_F32); }  // fp32 storage only
+bool ok4s(const sfTensor& t) {  // fp32 or bf16 storage, channel quads on 8- / 16-byte boundaries
+  return t.ptr == nullptr || ((t.dtype == SF_F32 || t.dtype == SF_BF16) && (((uintptr_t)t.ptr) & (t.dtype == SF_BF16 ? 7 : 15)) == 0 && t.stride % 4 == 0);
+}
 
 }  // namespace
 
@@ -64,21 +70,25 @@ extern "C" int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sf
   SF_REQUIRE(dtype == SF_F32, "sf_convgru_bwd_gates: dtype %d not built", dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && hidp > 0, "gru bwd_gates: hidp=%d", hidp);
   SF_REQUIRE(dh0.ptr && gates.ptr && dgx.ptr && dgh.ptr, "gru bwd_gates: dh0, gates, dgx, dgh must be non-null");
-  SF_REQUIRE(ok4(dh0) && ok4(dh1) && ok4(dh2) && ok4(gates) && ok4(h_prev) && ok4(dgx) && ok4(dgh) && ok4(dh_direct),
-             "gru bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0");
+  SF_REQUIRE(ok4(dh0) && ok4(dh1) && ok4(dh2) && ok4s(gates) && ok4(h_prev) && ok4s(dgx) && ok4s(dgh) && ok4(dh_direct) && dgx.dtype == dgh.dtype,
+             "gru bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0 (fp32; gates and dgx / dgh may be bf16-stored, dgx and dgh alike)");
   GruBwdParams p{};
   p.dh0 = (const float*)dh0.ptr; p.dh1 = (const float*)dh1.ptr; p.dh2 = (const float*)dh2.ptr;
   p.s0 = dh0.stride; p.s1 = dh1.stride; p.s2 = dh2.stride;
-  p.gates = (const float*)gates.ptr; p.s_g = gates.stride;
+  p.gates = gates.ptr; p.s_g = gates.stride;
   p.h_prev = (const float*)h_prev.ptr; p.s_hp = h_prev.stride;
-  p.dgx = (float*)dgx.ptr; p.s_dgx = dgx.stride;
-  p.dgh = (float*)dgh.ptr; p.s_dgh = dgh.stride;
+  p.dgx = dgx.ptr; p.s_dgx = dgx.stride;
+  p.dgh = dgh.ptr; p.s_dgh = dgh.stride;
   p.dh_direct = (float*)dh_direct.ptr; p.s_dd = dh_direct.stride;
   p.pixels = pixels; p.hidp = hidp;
   const long long total = pixels * (hidp / 4);
   if (total == 0) return 0;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);
-  hipLaunchKernelGGL(gru_bwd_gates_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  const bool gb = gates.dtype == SF_BF16, db = dgx.dtype == SF_BF16;
+  if (gb && db) hipLaunchKernelGGL((gru_bwd_gates_kernel<__bf16, __bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else if (gb) hipLaunchKernelGGL((gru_bwd_gates_kernel<__bf16, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else if (db) hipLaunchKernelGGL((gru_bwd_gates_kernel<float, __bf16>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
+  else hipLaunchKernelGGL((gru_bwd_gates_kernel<float, float>), dim3(blocks), dim3(256), 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("gru_bwd_gates");
   return 0;
 }

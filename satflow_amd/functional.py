@@ -416,7 +416,9 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         gx = torch.empty(N, H, W, 3 * hidp, dtype=torch.float32, device=dev)
         K.conv3x3(T(x), NULL, N, H, W, pk["x_fwd"][0], pk["x_fwd"][1], eng.x_fwd, T(gx))
         hs = torch.empty(Tn, n, H, W, hidp, dtype=torch.float32, device=dev)
-        gates = torch.empty(Tn, n, H, W, 4 * hidp, dtype=torch.float32, device=dev) if keep else None
+        # saved gates: backward-only data, bf16 in "bf16a" mode (as the ConvLSTM's)
+        from ._hip import gate_storage_dtype
+        gates = torch.empty(Tn, n, H, W, 4 * hidp, dtype=gate_storage_dtype(), device=dev) if keep else None
         gxs = gx.view(Tn, n, H, W, 3 * hidp)
         for t in range(Tn):
             K.convgru_step_fwd(T(gxs[t]), hs[t - 1] if t else None, n, H, W, pk["h_fwd"][0], pk["h_fwd"][1], hidp, hs[t],
@@ -438,8 +440,11 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         pk = eng._packed
         g_seq = g_seq.contiguous().view(Tn, n, H, W, hidp) if g_seq is not None else None
         g_last = g_last.contiguous() if g_last is not None else None
-        dgx = torch.empty(Tn, n, H, W, 3 * hidp, dtype=torch.float32, device=dev)
-        dgh = torch.empty(Tn, n, H, W, 3 * hidp, dtype=torch.float32, device=dev)
+        # gradients wrt the two convolutions' outputs: only ever read as bf16 MFMA operands (input / weight gradient
+        # convolutions), so "bf16a" stores them as bf16 like the gates they were computed from
+        gdt = gates.dtype
+        dgx = torch.empty(Tn, n, H, W, 3 * hidp, dtype=gdt, device=dev)
+        dgh = torch.empty(Tn, n, H, W, 3 * hidp, dtype=gdt, device=dev)
         direct = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)  # dh * z of the step above
         carry = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)   # conv^T(dgh) of the step above
         zeros = None
@@ -463,7 +468,7 @@ class _ConvGRUSeqFn(torch.autograd.Function):
                 have_carry = True
         dx = None
         if ctx.needs_input_grad[1]:
-            dx = torch.empty_like(x)
+            dx = torch.empty_like(x)  # stored like x (fp32: the encoder's last pooling returns fp32)
             K.conv3x3(T(dgx.view(N, H, W, 3 * hidp)), NULL, N, H, W, pk["x_bwd"], None, eng.x_bwd, T(dx))
         dWx, dbx = torch.empty_like(Wx), torch.empty(Wx.shape[0], dtype=torch.float32, device=dev)
         K.conv3x3_bwd_weight(T(x), NULL, T(dgx.view(N, H, W, 3 * hidp)), N, H, W, eng.x_wgrad, dWx, dbx, False)
@@ -471,10 +476,10 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         if Tn > 1:
             K.conv3x3_bwd_weight(T(hs[: Tn - 1]), NULL, T(dgh[1:]), (Tn - 1) * n, H, W, eng.h_wgrad, dWh, dbh, False)
             # bias of the h-part also acts at t = 0 (zero state, bias only): add that step's column sums (tiny torch op)
-            dbh = (dbh + dgh[0].sum(dim=(0, 1, 2))[K_bias_index(eng, dev)]) * K_bias_mask(eng, dev)
+            dbh = (dbh + dgh[0].float().sum(dim=(0, 1, 2))[K_bias_index(eng, dev)]) * K_bias_mask(eng, dev)
         else:
             dWh.zero_()
-            dbh.copy_(dgh[0].sum(dim=(0, 1, 2))[K_bias_index(eng, dev)] * K_bias_mask(eng, dev))
+            dbh.copy_(dgh[0].float().sum(dim=(0, 1, 2))[K_bias_index(eng, dev)] * K_bias_mask(eng, dev))
         return None, dx, None, dWx, dbx, dWh, dbh
 
 

@@ -313,3 +313,44 @@ def test_convlstm_cell_bf16_states(device, bf16a_mode, cin, hid, n, h, w):
     assert torch.equal(f[0].bfloat16()[..., :hid], b[0][..., :hid]), "bf16-stored hidden state is not the rounded fp32 one"
     assert torch.equal(f[2].bfloat16(), b[2]), "bf16-stored gates are not the rounded fp32 ones"
     assert float(f[1].abs().max()) > 0.5 and torch.isfinite(f[0]).all()
+
+
+@pytest.mark.parametrize("B,T,cin,hid,h,w,layers", [(2, 3, 16, 16, 4, 4, 1), (1, 4, 40, 24, 5, 7, 2), (3, 5, 256, 64, 16, 16, 1)])
+def test_convgru_bf16a_vs_bf16(device, B, T, cin, hid, h, w, layers):
+    """ConvGRU sequence with bf16-STORED saved gates and gate gradients ("bf16a") against fp32-stored ones ("bf16"): the forward
+    pass never reads them, so the states are bit-identical; the gradients differ by the rounding of the saved gates (the
+    rounding of dgx / dgh themselves is what their consumers' MFMA operands do anyway)."""
+    from satflow_amd import functional as F
+    from satflow_amd.models.metnet import ConvGRU
+
+    g = lambda s: torch.Generator().manual_seed(s)
+    torch.manual_seed(B + cin)
+    rnn = ConvGRU(cin, hid, (3, 3), layers)
+    with torch.no_grad():
+        for name, p in rnn.named_parameters():
+            if name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g(15)) * 0.3)
+    rnn.eval()
+    rnn = rnn.to(device)
+    x = torch.randn(B, T, cin, h, w, generator=g(16)).to(device)
+    cot_last = torch.randn(B, hid, h, w, generator=g(17)).to(device)
+    cot_seq = (torch.randn(B, T, hid, h, w, generator=g(18)) * 0.5).to(device)
+    res = {}
+    try:
+        for mode in ("bf16", "bf16a"):
+            satflow_amd.set_compute_dtype(mode)
+            rnn.zero_grad()
+            xd = x.clone().requires_grad_()
+            xs = F._ToNHWC.apply(xd, B, T, cin, h, w, (T * cin * h * w, cin * h * w, h * w))
+            seq, last = rnn.run(xs, T, B)
+            seq_nchw = F._FromNHWC.apply(seq, (B, T, hid, h, w), B, T, hid, h, w, (T * hid * h * w, hid * h * w, h * w))
+            last_nchw = F.nhwc_to_nchw(last[-1], hid)
+            ((last_nchw * cot_last).sum() + (seq_nchw * cot_seq).sum()).backward()
+            res[mode] = (seq_nchw.detach().clone(), {"dx": xd.grad.clone(), **{k: p.grad.clone() for k, p in rnn.named_parameters()}})
+    finally:
+        satflow_amd.set_compute_dtype("f32")
+    assert torch.equal(res["bf16"][0], res["bf16a"][0]), "forward must not depend on the gate storage type"
+    rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    worst = max(rel(res["bf16a"][1][k], res["bf16"][1][k]) for k in res["bf16"][1])
+    print(f"bf16a ConvGRU: worst gradient rel L2 vs fp32-stored gates {worst:.2e}")
+    assert worst < 1e-2
