@@ -305,7 +305,7 @@ def main():
             "bf16a": "bf16 MFMA operands, fp32 accumulate; MetNet image-encoder activations and their gradients stored as bf16 "
                      "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers), ConvLSTM hidden states (only ever read as bf16 "
                      "MFMA operands: bit-identical predictions) and the saved gates / gate gradients of both recurrent cells "
-                     "(backward-only data) stored as bf16; parameters, states, state gradients, attention, loss and optimizer state fp32",
+                     "(backward-only data) stored as bf16; parameters, cell states, the ConvGRU state, state gradients, attention, loss and optimizer state fp32",
         }[args.dtype]
         out["config"]["mode"] = args.dtype
         out["roofline"] = wl.roofline()
