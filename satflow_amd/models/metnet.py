@@ -78,11 +78,12 @@ class DownSampler(nn.Module):
         oc = output_channels
         self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
 
-    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None, dropout=None) -> Tensor:
+    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None, dropout=None, out_dtype=torch.float32) -> Tensor:
         """NHWC pipeline from the first pooling's output (``pooled``) or from the input ``x``; ``groups`` BatchNorm batches.
 
-        The activations keep the storage type they arrive in (fp32, or bf16 in "bf16a" mode); the last pooling always
-        returns fp32."""
+        The activations keep the storage type they arrive in (fp32, or bf16 in "bf16a" mode); the last pooling returns
+        ``out_dtype`` (fp32 at the module surface; MetNet keeps the encoder's storage type - its only consumers are the
+        ConvGRU's input convolution and weight gradient, i.e. bf16 MFMA operands)."""
         m = self.module
         y = pooled if pooled is not None else F.maxpool2(F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias, out_dtype=x.dtype))
         st = y.dtype
@@ -96,7 +97,7 @@ class DownSampler(nn.Module):
         if dropout is not None:  # (p1, p2, timesteps): period = elements of one timestep of the pooled tensor
             n, h, w, c = y.shape
             dropout = (dropout[0], dropout[1], (n // dropout[2]) * (h // 2) * (w // 2) * c)
-        return F.maxpool2(y, perm, out_dtype=torch.float32, dropout=dropout)
+        return F.maxpool2(y, perm, out_dtype=out_dtype, dropout=dropout)
 
     def forward(self, x: Tensor) -> Tensor:
         """``[N,C,H,W] -> [N,out,H/4,W/4]`` (module-surface form, one BatchNorm batch)."""
@@ -282,7 +283,7 @@ class MetNet(nn.Module):
         rnn = self.temporal_enc.rnn
         # nn.Dropout(temporal_dropout) and the ConvGRU's sequence-consistent input dropout ride on the encoder's last pooling
         drop = (self.drop.p, rnn.input_p, Tn) if self.training else None
-        feat = enc.run(None, L, pooled=p1, perm=(L, Tn), dropout=drop)  # [T*L*B, S/4, S/4, 256]
+        feat = enc.run(None, L, pooled=p1, perm=(L, Tn), dropout=drop, out_dtype=st)  # [T*L*B, S/4, S/4, 256]
         _, last = rnn.run(feat, Tn, L * B, input_dropout_done=True)
         a = last[-1]  # [L*B, s, s, hidp]
         for layer in self.temporal_agg:
