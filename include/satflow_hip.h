@@ -211,7 +211,8 @@ int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, in
 /* nn.BatchNorm2d of the DownSampler.  Training mode: `groups` independent batches of
  * pix_per_group pixels each (one per lead time: the reference calls the encoder once per lead
  * time, so statistics are per call), biased variance, running stats updated group after group with
- * `momentum` (unbiased variance).  Scratch: sums [groups][2][C] doubles; mean/rstd/scale/shift
+ * `momentum` (unbiased variance; momentum < 0 selects torch's cumulative average of momentum=None with
+ * -momentum - 1 = batches tracked before this call).  Scratch: sums [groups][2][C] doubles; mean/rstd/scale/shift
  * [groups][C] floats (mean, rstd are what the backward needs).  creal = real channels of gamma/beta. */
 int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal,
                            const float* gamma, const float* beta, float eps, float momentum,
@@ -228,6 +229,11 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
                           const float* beta, float eps, const float* running_mean,
                           const float* running_var, float* scale, float* shift, sfTensor y,
                           int32_t dtype, sfStream stream);
+/* Backward of the eval-mode BatchNorm (frozen running statistics: fine-tuning / saliency with model.eval()):
+ * dx = gamma*rstd*dy, dgamma = sum dy*(x-rm)*rstd, dbeta = sum dy.  scratch: 5*x.c floats; sums: 2*x.c doubles. */
+int sf_batchnorm_eval_bwd(sfTensor x, sfTensor dy, int64_t pixels, int32_t creal, const float* gamma, float eps,
+                          const float* running_mean, const float* running_var, double* sums, float* scratch,
+                          sfTensor dx, float* dgamma, float* dbeta, int32_t dtype, sfStream stream);
 int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups,
                            int32_t creal, const float* gamma, const float* mean, const float* rstd,
                            double* sums, float* coef /* scratch [groups][3][C] */, sfTensor dx,

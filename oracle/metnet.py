@@ -93,12 +93,25 @@ def batch_norm_train(x: Tensor, weight: Tensor, bias: Tensor, eps: float = 1e-5)
     return F.batch_norm(x, None, None, weight, bias, training=True, eps=eps)
 
 
-def downsampler(x: Tensor, p: Params, prefix: str, bn_stats: Dict[str, Tuple[Tensor, Tensor]] | None) -> Tensor:
+def max_pool2(t: Tensor, routing: Tensor | None = None) -> Tensor:
+    """``nn.MaxPool2d(2, stride 2)``.  ``routing`` (bool, shape of ``t``, exactly one True per 2x2 window): the window
+    element to take instead of recomputing the argmax - used by the tie-aware parity tests, which inject the routing the
+    implementation under test actually chose (max-pooling's gradient is discontinuous where two candidates of a window
+    agree to rounding; the VALUE taken is the same to rounding either way, the gradient then follows the same path)."""
+    if routing is None:
+        return F.max_pool2d(t, 2)
+    n, c, h, w = t.shape
+    picked = (t * routing.to(t.dtype)).view(n, c, h // 2, 2, w // 2, 2)
+    return picked.sum(dim=(3, 5))
+
+
+def downsampler(x: Tensor, p: Params, prefix: str, bn_stats: Dict[str, Tuple[Tensor, Tensor]] | None,
+                routing: Tuple[Tensor | None, Tensor | None] = (None, None)) -> Tensor:
     """``DownSampler``: conv3x3 -> maxpool2 -> BN -> conv -> BN -> conv -> BN -> conv -> maxpool2.
 
     No activation functions.  ``bn_stats=None`` selects training-mode batch
     statistics; otherwise ``{"3": (mean, var), ...}`` gives eval-mode running
-    statistics per BatchNorm index.
+    statistics per BatchNorm index.  ``routing``: see ``max_pool2`` (first / last pooling).
     """
 
     def conv(i: int, t: Tensor) -> Tensor:
@@ -111,10 +124,10 @@ def downsampler(x: Tensor, p: Params, prefix: str, bn_stats: Dict[str, Tuple[Ten
         mean, var = bn_stats[str(i)]
         return F.batch_norm(t, mean, var, w, b, training=False, eps=1e-5)
 
-    t = bn(3, F.max_pool2d(conv(0, x), 2))
+    t = bn(3, max_pool2(conv(0, x), routing[0]))
     t = bn(5, conv(4, t))
     t = bn(7, conv(6, t))
-    return F.max_pool2d(conv(8, t), 2)
+    return max_pool2(conv(8, t), routing[1])
 
 
 def convgru_cell(x: Tensor, h: Tensor, p: Params, prefix: str) -> Tensor:
@@ -194,8 +207,12 @@ def metnet_forward(
     num_layers: int = 1,
     num_att_layers: int = 1,
     bn_stats: Dict[str, Tuple[Tensor, Tensor]] | None = None,
+    pool_routing: Dict[Tuple[str, int], Tensor] | None = None,
 ) -> Tensor:
     """``MetNet.forward(imgs[B,T,C,H,W]) -> [B, forecast_steps, out, input_size//4, input_size//4]``.
+
+    ``pool_routing`` (tests only): ``{("p1", lead): bool[B*T,160,S,S], ("p2", lead): bool[B*T,256,S/2,S/2]}`` - the
+    max-pool routing to follow per lead time (frames in ``b*T + t`` order), see ``max_pool2``.
 
     Per lead time ``i`` (upstream recomputes everything per lead time, SURVEY
     3.2): preprocess -> ConditionTime(i) -> TimeDistributed(DownSampler) ->
@@ -206,7 +223,8 @@ def metnet_forward(
     base = preprocess(imgs, sat_channels, input_size)
     for i in range(forecast_steps):
         t = condition_time(base, i, forecast_steps)
-        t = time_distributed(lambda f: downsampler(f, p, "image_encoder.module.module", bn_stats), t)
+        rt = (None, None) if pool_routing is None else (pool_routing.get(("p1", i)), pool_routing.get(("p2", i)))
+        t = time_distributed(lambda f: downsampler(f, p, "image_encoder.module.module", bn_stats, rt), t)
         _, last = convgru(t, p, "temporal_enc.rnn", num_layers)
         a = last[-1]
         for layer in range(num_att_layers):

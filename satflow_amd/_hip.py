@@ -67,6 +67,7 @@ PROTOTYPES = {
         [sfTensor, _i64, _i32, _i32, _vp, _vp, C.c_float, C.c_float, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _i32, sfTensor, _i32, _vp],
     ),
     "sf_batchnorm_eval_fwd": (C.c_int, [sfTensor, _i64, _i32, _vp, _vp, C.c_float, _vp, _vp, _vp, _vp, sfTensor, _i32, _vp]),
+    "sf_batchnorm_eval_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),
     "sf_batchnorm_train_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),
     "sf_convgru_step_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_convgru_bwd_gates": (

@@ -273,8 +273,10 @@ __global__ void bn_finalize_kernel(const double* __restrict__ sums, int G, int C
     b[(long long)g * C + c] = be - (float)m * ga * r;
     if (real && running_mean) {
       const double unbiased = count > 1 ? var * count / (count - 1) : var;
-      rm = (1.f - momentum) * rm + momentum * (float)m;
-      rv = (1.f - momentum) * rv + momentum * (float)unbiased;
+      // momentum < 0: cumulative moving average (nn.BatchNorm2d(momentum=None)); -momentum - 1 batches were tracked before group 0
+      const float mom = momentum >= 0.f ? momentum : 1.f / (-momentum + (float)g);
+      rm = (1.f - mom) * rm + mom * (float)m;
+      rv = (1.f - mom) * rv + mom * (float)unbiased;
     }
   }
   if (real && running_mean) { running_mean[c] = rm; running_var[c] = rv; }
@@ -290,6 +292,21 @@ __global__ void bn_eval_affine_kernel(int C, int Creal, float eps, const float* 
     const float r = 1.f / sqrtf(running_var[c] + eps);
     a[c] = gamma[c] * r; b[c] = beta[c] - running_mean[c] * gamma[c] * r;
   } else { a[c] = 0.f; b[c] = 0.f; }
+}
+
+// eval-mode backward: the statistics are constants, so dx = gamma*rstd * dy; mean / rstd feed the MODE 1 reduction
+// (dgamma = sum dy*xhat, dbeta = sum dy).  scratch = [mean | rstd | A | B | K] x C.
+__global__ void bn_eval_bwd_prep_kernel(int C, int Creal, float eps, const float* __restrict__ gamma, const float* __restrict__ running_mean,
+                                        const float* __restrict__ running_var, float* __restrict__ scratch) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const bool real = c < Creal;
+  const float r = real ? 1.f / sqrtf(running_var[c] + eps) : 0.f;
+  scratch[c] = real ? running_mean[c] : 0.f;
+  scratch[C + c] = r;
+  scratch[2 * C + c] = real ? gamma[c] * r : 0.f;
+  scratch[3 * C + c] = 0.f;
+  scratch[4 * C + c] = 0.f;
 }
 
 // y = x*a[g] + b[g]
@@ -524,6 +541,26 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
   SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               (long long)pixels, (long long)pixels, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));
   SF_CHECK_LAUNCH("bn_apply");
+  return 0;
+}
+
+int sf_batchnorm_eval_bwd(sfTensor x, sfTensor dy, int64_t pixels, int32_t creal, const float* gamma, float eps, const float* running_mean,
+                          const float* running_var, double* sums, float* scratch, sfTensor dx, float* dgamma, float* dbeta, int32_t dtype,
+                          sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_eval_bwd: dtype %d not built", dtype);
+  SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok8(x) && ok8(dy) && ok8(dx) && x.dtype == dx.dtype && creal <= x.c,
+             "batchnorm eval bwd: channels (multiple of 8, 16-byte aligned) / storage type");
+  hipStream_t st = (hipStream_t)stream;
+  const int C = x.c;
+  hipLaunchKernelGGL(bn_eval_bwd_prep_kernel, dim3((C + 127) / 128), dim3(128), 0, st, C, creal, eps, gamma, running_mean, running_var, scratch);
+  SF_CHECK_LAUNCH("bn_eval_bwd_prep");
+  if (int rc = bn_reduce_launch(1, x, dy, pixels, 1, scratch, scratch + C, sums, st)) return rc;
+  SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<TA>), dim3(grid_for(pixels * (C / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
+                                              (const TA*)dy.ptr, dy.stride, (long long)pixels, (long long)pixels, C, (const float*)(scratch + 2 * C),
+                                              (TA*)dx.ptr, dx.stride));
+  SF_CHECK_LAUNCH("bn_bwd_apply");
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, 1, C, creal, dgamma, dbeta);
+  SF_CHECK_LAUNCH("bn_param_grad");
   return 0;
 }
 

@@ -74,6 +74,10 @@ class ConvEngine:
         self.wgrad_map = K.GemmMap(K._padded(cout), list(self.fwd_map.kmap), 0, self.coutp)
         self._bwd_maps = {}
         self._key, self._packed = None, {}
+        # Parameters a DERIVED weight (slice / cat: a fresh tensor every call) was built from.  When set, the cache keys on
+        # their identity + version instead of on the derived tensor's (whose version is always 0 and whose address the
+        # caching allocator may hand back unchanged after the source changed).
+        self.key_tensors: Optional[Tuple[Tensor, ...]] = None
 
     def bwd_map(self, need: Tuple[bool, ...]) -> K.GemmMap:
         if need not in self._bwd_maps:
@@ -81,7 +85,8 @@ class ConvEngine:
         return self._bwd_maps[need]
 
     def packed(self, weight: Tensor, bias: Optional[Tensor], kind, need: Tuple[bool, ...] = ()):
-        key = (weight.data_ptr(), weight._version, None if bias is None else (bias.data_ptr(), bias._version), generation())
+        src = self.key_tensors if self.key_tensors is not None else (weight, bias)
+        key = (tuple(None if t is None else (t.data_ptr(), t._version) for t in src), generation())
         if key != self._key:
             self._key, self._packed = key, {}
         k = (kind, need)
@@ -295,23 +300,52 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BatchNormEvalFn(torch.autograd.Function):
+    """Eval-mode BatchNorm2d (running statistics are constants): ``y = a*x + b``; backward ``dx = a*dy``, ``dgamma``, ``dbeta``."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Tensor, running_var: Tensor, eps: float):
+        C = x.shape[-1]
+        ab = torch.empty(2, C, dtype=torch.float32, device=x.device)
+        y = torch.empty_like(x)
+        check(lib().sf_batchnorm_eval_fwd(T(x), x.numel() // C, gamma.shape[0], gamma.data_ptr(), beta.data_ptr(), eps, running_mean.data_ptr(),
+                                          running_var.data_ptr(), ab[0].data_ptr(), ab[1].data_ptr(), T(y), SF_F32, stream_ptr()),
+              "sf_batchnorm_eval_fwd")
+        ctx.eps = eps
+        ctx.save_for_backward(x, gamma, running_mean, running_var)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, gamma, rm, rv = ctx.saved_tensors
+        C = x.shape[-1]
+        gy = gy.contiguous()
+        if gy.dtype != x.dtype:
+            gy = gy.to(x.dtype)
+        dx = torch.empty_like(x)
+        sums = torch.empty(2, C, dtype=torch.float64, device=x.device)
+        scratch = torch.empty(5, C, dtype=torch.float32, device=x.device)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        check(lib().sf_batchnorm_eval_bwd(T(x), T(gy), x.numel() // C, gamma.shape[0], gamma.data_ptr(), ctx.eps, rm.data_ptr(), rv.data_ptr(),
+                                          sums.data_ptr(), scratch.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32, stream_ptr()),
+              "sf_batchnorm_eval_bwd")
+        return dx, dgamma, dbeta, None, None, None
+
+
 def batchnorm(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, training: bool, stats: Optional["ConvStats"] = None) -> Tensor:
     """``bn(x)`` on NHWC ``x``; in training mode with ``groups`` separate batches (and running-stat updates in order).
     ``stats``: the producing convolution's ``ConvStats`` (training mode) - saves the statistics pass over ``x``."""
     if training:
+        momentum = bn.momentum
         if bn.track_running_stats and bn.num_batches_tracked is not None:
+            if momentum is None:  # torch's cumulative moving average: factor 1/num_batches_tracked, group after group
+                momentum = -(float(bn.num_batches_tracked) + 1.0)  # (host read: only for momentum=None modules)
             bn.num_batches_tracked += groups
         return _BatchNormTrainFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups, bn.eps,
-                                       bn.momentum if bn.momentum is not None else 0.1, stats)
-    C = x.shape[-1]
-    ab = torch.empty(2, C, dtype=torch.float32, device=x.device)
-    y = torch.empty_like(x)
-    check(lib().sf_batchnorm_eval_fwd(T(x), x.numel() // C, bn.weight.shape[0], bn.weight.data_ptr(), bn.bias.data_ptr(), bn.eps,
-                                      bn.running_mean.data_ptr(), bn.running_var.data_ptr(), ab[0].data_ptr(), ab[1].data_ptr(), T(y),
-                                      SF_F32, stream_ptr()), "sf_batchnorm_eval_fwd")
-    if torch.is_grad_enabled() and (x.requires_grad or bn.weight.requires_grad):
-        raise RuntimeError("eval-mode BatchNorm has no backward kernel (the reference trains in train mode)")
-    return y
+                                       momentum if momentum is not None else 0.0, stats)
+    if bn.running_mean is None:  # track_running_stats=False: torch normalises with batch statistics in eval mode too
+        return _BatchNormTrainFn.apply(x, bn.weight, bn.bias, None, None, groups, bn.eps, 0.0, stats)
+    return _BatchNormEvalFn.apply(x, bn.weight, bn.bias, bn.running_mean, bn.running_var, bn.eps)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -390,9 +424,12 @@ class GRUEngine:
         self.h_wgrad = K.GemmMap(gm3, K._padded(hid), 0, 3 * self.hidp)
         self._key, self._packed = None, {}
 
-    def packed(self, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor):
-        key = (Wx.data_ptr(), Wx._version, Wh.data_ptr(), Wh._version, bx.data_ptr(), bh.data_ptr(), generation())
-        if key != self._key:
+    def packed(self, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor, src_key=None):
+        """``src_key``: identity + version of the SOURCE parameters the regrouped tensors were concatenated from (the cats
+        are fresh tensors every forward - version 0, and the caching allocator hands the same addresses back - so they
+        cannot key the cache themselves).  Without it nothing is cached."""
+        key = None if src_key is None else (src_key, generation())
+        if key is None or key != self._key:
             self._key = key
             self._packed = {
                 "x_fwd": K.pack_weights(Wx, bx, self.x_fwd, False),
@@ -407,11 +444,11 @@ class _ConvGRUSeqFn(torch.autograd.Function):
     """x ``[T*n,H,W,Cinp]`` (time-major) -> (all hidden states ``[T*n,H,W,hidp]``, last state ``[n,H,W,hidp]``)."""
 
     @staticmethod
-    def forward(ctx, eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor):
+    def forward(ctx, eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor, src_key=None):
         N, H, W, _ = x.shape
         n = N // Tn
         hidp, dev = eng.hidp, x.device
-        pk = eng.packed(Wx, bx, Wh, bh)
+        pk = eng.packed(Wx, bx, Wh, bh, src_key)
         keep = any(ctx.needs_input_grad)
         gx = torch.empty(N, H, W, 3 * hidp, dtype=torch.float32, device=dev)
         K.conv3x3(T(x), NULL, N, H, W, pk["x_fwd"][0], pk["x_fwd"][1], eng.x_fwd, T(gx))
@@ -424,6 +461,7 @@ class _ConvGRUSeqFn(torch.autograd.Function):
             K.convgru_step_fwd(T(gxs[t]), hs[t - 1] if t else None, n, H, W, pk["h_fwd"][0], pk["h_fwd"][1], hidp, hs[t],
                                gates[t] if keep else None)
         ctx.eng, ctx.Tn = eng, Tn
+        ctx.pk = pk  # the packed images this forward used (the engine's cache may be rebuilt before the backward runs)
         ctx.set_materialize_grads(False)
         if keep:
             ctx.save_for_backward(x, hs, gates, Wx, Wh)
@@ -436,8 +474,7 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         x, hs, gates, Wx, Wh = ctx.saved_tensors
         _, n, H, W, hidp = hs.shape
         N, dev = Tn * n, x.device
-        # the parameters cannot have changed between forward and backward of one step; reuse the cache
-        pk = eng._packed
+        pk = ctx.pk
         g_seq = g_seq.contiguous().view(Tn, n, H, W, hidp) if g_seq is not None else None
         g_last = g_last.contiguous() if g_last is not None else None
         # gradients wrt the two convolutions' outputs: only ever read as bf16 MFMA operands (input / weight gradient
@@ -480,7 +517,7 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         else:
             dWh.zero_()
             dbh.copy_(dgh[0].float().sum(dim=(0, 1, 2))[K_bias_index(eng, dev)] * K_bias_mask(eng, dev))
-        return None, dx, None, dWx, dbx, dWh, dbh
+        return None, dx, None, dWx, dbx, dWh, dbh, None
 
 
 _BIAS_CACHE = {}
@@ -508,8 +545,8 @@ def K_bias_mask(eng: GRUEngine, dev):
     return _bias_tables(eng, dev)[1]
 
 
-def convgru_sequence(eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor) -> Tuple[Tensor, Tensor]:
-    return _ConvGRUSeqFn.apply(eng, x, Tn, Wx, bx, Wh, bh)
+def convgru_sequence(eng: GRUEngine, x: Tensor, Tn: int, Wx: Tensor, bx: Tensor, Wh: Tensor, bh: Tensor, src_key=None) -> Tuple[Tensor, Tensor]:
+    return _ConvGRUSeqFn.apply(eng, x, Tn, Wx, bx, Wh, bh, src_key)
 
 
 # ----------------------------------------------------------------------------------------------

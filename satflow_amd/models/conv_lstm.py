@@ -88,6 +88,11 @@ class _StackFn(torch.autograd.Function):
     def backward(ctx, g_out: Tensor):
         e1, e2, d1, d2 = engines = ctx.engines
         B, T_in, T_out, H, W = ctx.dims
+        if getattr(ctx, "consumed", False):
+            # the saved gates were overwritten in place by dz through raw pointers (invisible to autograd's version check)
+            raise RuntimeError("ConvLSTM stack: backward was already run on this graph; its saved gate buffers were consumed in place. "
+                               "A second backward over a retained graph is not supported - run the forward again.")
+        ctx.consumed = True
         saved = ctx.saved_tensors
         x, Hs, Cs, Gs = saved[0], saved[1:5], saved[5:9], saved[9:13]
         hidp = e1.hidp

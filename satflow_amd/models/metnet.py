@@ -76,6 +76,7 @@ class DownSampler(nn.Module):
             nn.Identity(),
         )
         oc = output_channels
+        self.capture = None  # tests set a dict: receives the tensor in front of the last pooling ("y4")
         self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
 
     def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None, dropout=None, out_dtype=torch.float32) -> Tensor:
@@ -94,6 +95,8 @@ class DownSampler(nn.Module):
         y, cs = F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias, out_dtype=st, want_stats=self.training)
         y = F.batchnorm(y, m[7], groups, self.training, cs)
         y = F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias, out_dtype=st)
+        if self.capture is not None:
+            self.capture["y4"] = y.detach()
         if dropout is not None:  # (p1, p2, timesteps): period = elements of one timestep of the pooled tensor
             n, h, w, c = y.shape
             dropout = (dropout[0], dropout[1], (n // dropout[2]) * (h // 2) * (w // 2) * c)
@@ -136,7 +139,9 @@ class ConvGRUCell(nn.Module):
         return Wx.contiguous(), bx, Wh.contiguous(), bh
 
     def run_sequence(self, x: Tensor, T_steps: int):
-        return F.convgru_sequence(self._eng, x, T_steps, *self.regrouped())
+        # packed-weight cache key: the six source parameters (the regrouped cats are new tensors every call)
+        src = tuple((p.data_ptr(), p._version) for conv in (self.conv_zr, self.conv_h1, self.conv_h2) for p in (conv.weight, conv.bias))
+        return F.convgru_sequence(self._eng, x, T_steps, *self.regrouped(), src_key=src)
 
 
 class ConvGRU(nn.Module):
@@ -258,6 +263,8 @@ class MetNet(nn.Module):
         self.head = nn.Conv2d(hidden_dim, output_channels, kernel_size=(1, 1))
         # conv1 restricted to the image lanes (the one-hot lead-time lanes are folded into the first pooling)
         self._conv1 = ConvEngine([self.image_channels], 160)
+        c1 = encoder.module[0]
+        self._conv1.key_tensors = (c1.weight, c1.bias)  # forward() hands it a fresh slice of c1.weight every call
 
     def forward(self, imgs: Tensor, lead_time: int = 0) -> Tensor:
         """``imgs[B,T,C,4*input_size,4*input_size] -> [B, forecast_steps, output_channels, input_size//4, input_size//4]``."""
@@ -277,6 +284,8 @@ class MetNet(nn.Module):
         c1 = enc.module[0]
         cimg = self.image_channels
         base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias, out_dtype=st)  # [T*B, S, S, 160]
+        if enc.capture is not None:
+            enc.capture["base"] = base.detach()
         p1 = F.leadtime_pool(base, c1.weight, cimg, L)  # [L*T*B, S/2, S/2, 160], image (l*F + f)
         # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
         # images from [lead][time][batch] to [time][lead][batch] for the recurrent part

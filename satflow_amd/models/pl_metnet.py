@@ -79,7 +79,8 @@ class LitMetNet(BaseModel):
         """Concatenate satellite, time-repeated topographic and NWP data on dim 1 (reference ``:90-107``)."""
         timesteps = x[SATELLITE_DATA].shape[2]
         topo = x[TOPOGRAPHIC_DATA].unsqueeze(2).expand(-1, -1, timesteps, -1, -1)
-        to_concat = [x[SATELLITE_DATA], topo] + list(x.get(NWP_DATA, []))
+        nwp = x.get(NWP_DATA, [])
+        to_concat = [x[SATELLITE_DATA], topo] + ([nwp] if isinstance(nwp, torch.Tensor) else list(nwp))
         return torch.cat(to_concat, dim=1).float()
 
     def _train_or_validate_step(self, batch, batch_idx, is_training: bool = True):

@@ -8,6 +8,7 @@ view into the flat buffer.
 """
 from __future__ import annotations
 
+import contextlib
 from typing import Iterable, List, Optional
 
 import torch
@@ -20,9 +21,14 @@ def _round_up(n: int, k: int) -> int:
     return (n + k - 1) // k * k
 
 
-class FlatAdam:
+class FlatAdam(torch.optim.Optimizer):
     """Adam over a module's parameters, flattened.  ``step()`` also performs the data-parallel
-    gradient mean when a process group is given (SUM all-reduce, 1/world folded into the update)."""
+    gradient mean when a process group is given (SUM all-reduce, 1/world folded into the update).
+
+    A ``torch.optim.Optimizer``: ``param_groups[0]["lr"]`` is what ``step()`` uses, so torch lr schedulers (the reference
+    steps a warm-up/cosine schedule every step, ``pl_metnet.py:71-77``) drive it; ``state_dict()`` carries the moments.
+    Like DDP it broadcasts rank 0's parameters (and the given ``buffers``, e.g. BatchNorm running statistics) at
+    construction, and ``no_sync()`` defers the exchange over gradient-accumulation backward passes."""
 
     # Smallest group size that exchanges gradients.  2 in production (a single rank has nothing to exchange); the
     # single-GPU RCCL test lowers it to 1 so that the hook / async all-reduce / stream-ordering path runs on a 1-GPU box.
@@ -30,11 +36,12 @@ class FlatAdam:
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group: Optional["dist.ProcessGroup"] = None, distributed: Optional[bool] = None,
-                 overlap: bool = False, buckets: int = 3) -> None:
+                 overlap: bool = False, buckets: int = 3, buffers: Optional[Iterable[torch.Tensor]] = None) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert self.params, "no parameters"
         dev = self.params[0].device
-        self.lr, self.betas, self.eps = lr, betas, eps
+        super().__init__(self.params, dict(lr=lr, betas=betas, eps=eps))
+        self.betas, self.eps = betas, eps
         self.offsets, total = [], 0
         for p in self.params:
             assert p.dtype == torch.float32 and p.device == dev
@@ -61,6 +68,13 @@ class FlatAdam:
         # the encoder's backward is still computing.  A slice is launched when every parameter in it has received its
         # gradient (post-accumulate hooks); `step()` waits for the launched ones and reduces whatever was not launched.
         self.exchange = self.distributed and self.world >= self.MIN_EXCHANGE_WORLD
+        if self.distributed and self.world > 1:
+            # replicas start identical (what DDP's constructor does): rank 0's parameters and buffers win
+            dist.broadcast(self.flat_p, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+            for b in (buffers or []):
+                dist.broadcast(b, src=dist.get_global_rank(process_group, 0) if process_group is not None else 0, group=process_group)
+        self._sync = True        # False inside no_sync(): backward passes only accumulate
+        self._reduced = False    # a syncing backward has already launched / completed this step's exchange
         self.overlap = bool(overlap) and self.exchange
         self._bucket_of: List[int] = []
         self._bucket_range: List[List[int]] = []
@@ -87,17 +101,43 @@ class FlatAdam:
             h.remove()
         self._hooks, self._work, self.overlap = [], {}, False
 
+    @property
+    def lr(self) -> float:
+        return self.param_groups[0]["lr"]
+
+    @lr.setter
+    def lr(self, value: float) -> None:
+        self.param_groups[0]["lr"] = value
+
+    @contextlib.contextmanager
+    def no_sync(self):
+        """Gradient accumulation (DDP's ``no_sync``): backward passes inside only add into the flat gradient; the next
+        backward outside exchanges the accumulated sum."""
+        old, self._sync = self._sync, False
+        try:
+            yield
+        finally:
+            self._sync = old
+
     def _make_hook(self, k: int):
         def hook(_param) -> None:
+            if not self._sync:
+                return
+            if self._pending[k] <= 0 or k in self._work:
+                # the slice was already exchanged by an earlier backward of this step: adding local gradients on top of the
+                # reduced sum would be silently wrong (and different per rank)
+                raise RuntimeError("FlatAdam(overlap=True): a second backward pass reached an already exchanged gradient slice. "
+                                   "Wrap all but the last backward of a step in `optimizer.no_sync()`, or call zero_grad().")
             self._pending[k] -= 1
-            if self._pending[k] == 0 and k not in self._work:
+            if self._pending[k] == 0:
                 lo, hi = self._bucket_range[k]
                 self._work[k] = dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
 
         return hook
 
-    def zero_grad(self) -> None:
+    def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 (gradients are views of the flat buffer)
         self.flat_g.zero_()
+        self._reduced = False
         if self.overlap:
             self._pending, self._work, self._done = list(self._count), {}, False
         for p, off in zip(self.params, self.offsets):  # re-attach if autograd replaced .grad
@@ -110,6 +150,9 @@ class FlatAdam:
         if not self.exchange:
             return
         if not self.overlap:
+            if self._reduced:  # idempotent within a step (step() calls it again after an explicit call)
+                return
+            self._reduced = True
             dist.all_reduce(self.flat_g, op=dist.ReduceOp.SUM, group=self.group)
             return
         if self._done:
@@ -122,7 +165,22 @@ class FlatAdam:
                 dist.all_reduce(self.flat_g[lo:hi], op=dist.ReduceOp.SUM, group=self.group)
         self._work = {}
 
-    def step(self) -> None:
+    # ---- checkpoint / resume: Adam moments, step count and lr travel with the optimizer state ----
+    def state_dict(self) -> dict:
+        return {"flat_m": self.flat_m.clone(), "flat_v": self.flat_v.clone(), "t": self.t, "lr": self.lr, "betas": tuple(self.betas),
+                "eps": self.eps, "numel": self.numel}
+
+    def load_state_dict(self, state: dict) -> None:
+        if int(state["numel"]) != self.numel:
+            raise ValueError(f"FlatAdam.load_state_dict: {state['numel']} elements saved, {self.numel} here")
+        self.flat_m.copy_(state["flat_m"])
+        self.flat_v.copy_(state["flat_v"])
+        self.t, self.lr = int(state["t"]), float(state["lr"])
+        self.betas, self.eps = tuple(state["betas"]), float(state["eps"])
+
+    def step(self, closure=None) -> None:
+        if closure is not None:
+            raise RuntimeError("FlatAdam.step: closures are not supported")
         if not self.flat_p.is_cuda:
             raise RuntimeError("FlatAdam.step: parameters are not on a HIP device; there is no CPU optimizer path")
         self.allreduce_grads()

@@ -95,7 +95,8 @@ def test_model_golden(device, case):
     pred = m(x, fs)
     assert_close(pred, G["pred"], "pred")
     (pred * G["cot"].to(device)).sum().backward()
-    assert_close(x.grad, G["dx"], "dx", grad=True)
+    # default-init fixtures have |dx|max ~ 4e-5: only a relative check carries evidence there
+    assert_close(x.grad, G["dx"], "dx", grad=True, force_rel=True)
     for k, v in G.items():
         if k.startswith("grad."):
             p = dict(m.model.named_parameters())[k[len("grad."):]]

@@ -111,3 +111,97 @@ def test_overlapped_bucketed_allreduce_world2():
             p.join(120)
             assert p.exitcode == 0
         assert dict(out) == {0: True, 1: True}
+
+
+def _worker_accum(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from satflow_amd.optim import FlatAdam
+
+    torch.manual_seed(rank)  # DIFFERENT replicas: the constructor must broadcast rank 0's parameters and buffers (as DDP does)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 16), torch.nn.BatchNorm1d(16), torch.nn.Linear(16, 3))
+    with torch.no_grad():
+        net[1].running_mean.fill_(float(rank + 1))
+    opt = FlatAdam(net.parameters(), lr=1e-2, overlap=True, buckets=2, buffers=list(net.buffers()))
+    flat = [opt.flat_p.clone(), net[1].running_mean.clone()]
+    for t in flat:
+        both = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(both, t)
+        ok = torch.equal(both[0], both[1])
+        if not ok:
+            out[rank] = "broadcast"
+            return
+    ok = float(net[1].running_mean[0]) == 1.0
+    # gradient accumulation: two micro-batches, only the second backward exchanges
+    xs = [torch.randn(4, 6, generator=torch.Generator().manual_seed(7 * k + rank)) for k in range(2)]
+    opt.zero_grad()
+    with opt.no_sync():
+        net(xs[0]).square().sum().backward()
+    ok = ok and not opt._work  # nothing was launched inside no_sync
+    net(xs[1]).square().sum().backward()
+    opt.allreduce_grads()
+    got = opt.flat_g.clone()
+    # reference: sum over ranks of the locally accumulated gradient (computed without hooks)
+    opt.disable_overlap()
+    opt.zero_grad()
+    net[1].running_mean.copy_(flat[1])
+    for x in xs:
+        net(x).square().sum().backward()
+    local = opt.flat_g.clone()
+    both = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(both, local)
+    ok = ok and torch.allclose(got, both[0] + both[1], rtol=1e-5, atol=1e-6)
+    out[rank] = bool(ok)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_broadcast_and_gradient_accumulation_world2():
+    """FlatAdam broadcasts rank 0's parameters/buffers at construction and supports accumulation via no_sync()."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_worker_accum, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(120)
+            assert p.exitcode == 0
+        assert dict(out) == {0: True, 1: True}
+
+
+def test_second_backward_without_no_sync_raises():
+    """a second backward onto an already exchanged slice must not silently add local gradients to reduced sums."""
+    from satflow_amd.optim import FlatAdam
+
+    net = torch.nn.Linear(3, 2)
+    opt = FlatAdam(net.parameters(), lr=1e-3)
+    # emulate an active 2-rank exchange without a process group: hooks + a fake "work" entry
+    opt.exchange = opt.overlap = True
+    opt._bucket_of, opt._bucket_range, opt._count = [0, 0], [[0, opt.numel]], [2]
+    opt._pending, opt._work = [0], {0: object()}
+    hook = opt._make_hook(0)
+    with pytest.raises(RuntimeError, match="no_sync"):
+        hook(None)
+    with opt.no_sync():
+        hook(None)  # accumulation passes do not touch the bookkeeping
+
+
+def test_flat_adam_is_a_torch_optimizer_with_state():
+    """lr schedulers drive it (the reference steps warm-up/cosine per step, pl_metnet.py:71-77); moments survive a checkpoint."""
+    from satflow_amd.models.pl_metnet import LinearWarmupCosineAnnealingLR
+    from satflow_amd.optim import FlatAdam
+
+    net = torch.nn.Linear(3, 2)
+    opt = FlatAdam(net.parameters(), lr=1e-3)
+    assert isinstance(opt, torch.optim.Optimizer)
+    sched = LinearWarmupCosineAnnealingLR(opt, warmup_epochs=10, max_epochs=100)
+    assert opt.lr == 0.0  # warm-up starts at 0
+    opt.flat_m.fill_(0.5), opt.flat_v.fill_(0.25)
+    opt.t = 7
+    sd = opt.state_dict()
+    opt2 = FlatAdam(torch.nn.Linear(3, 2).parameters(), lr=5.0)
+    opt2.load_state_dict(sd)
+    assert opt2.t == 7 and opt2.lr == opt.lr and torch.equal(opt2.flat_m, opt.flat_m) and torch.equal(opt2.flat_v, opt.flat_v)
+    del sched

@@ -193,64 +193,47 @@ def _metnet_pair(device, cfg, seed=0):
     return net.to(device), P
 
 
-class _PoolMargins:
-    """Records the smallest top-1/top-2 gap of every 2x2 max-pool window the oracle evaluates.
-
-    Max pooling has a discontinuous gradient: when two candidates of a window agree to ~1e-6 relative,
-    fp32 rounding decides the argmax and BatchNorm spreads that one flip over the whole batch (observed:
-    one flipped window in 24576 -> 1e-3 relative change of every encoder gradient, on CPU fp32 vs fp64 just
-    the same).  A parity comparison is only well posed on inputs without such near-ties.
-    """
-
-    def __enter__(self):
-        self.min_gap, self._orig = float("inf"), TF.max_pool2d
-
-        def rec(t, k, *a, **kw):
-            n, c, h, w = t.shape
-            win = t.detach().view(n, c, h // 2, 2, w // 2, 2).permute(0, 1, 2, 4, 3, 5).reshape(n, c, h // 2, w // 2, 4)
-            top = win.topk(2, dim=-1).values
-            self.min_gap = min(self.min_gap, float(((top[..., 0] - top[..., 1]) / top[..., 0].abs().clamp_min(1.0)).min()))
-            return self._orig(t, k, *a, **kw)
-
-        M.F.max_pool2d = rec
-        return self
-
-    def __exit__(self, *exc):
-        M.F.max_pool2d = self._orig
-
-
 @pytest.mark.parametrize(
     "cfg,B,T",
     [
         (dict(input_channels=5, sat_channels=4, input_size=8, output_channels=2, hidden_dim=16, forecast_steps=3), 1, 2),
         (dict(input_channels=13, sat_channels=12, input_size=16, output_channels=3, hidden_dim=32, forecast_steps=4, num_att_layers=2), 1, 2),
+        (dict(input_channels=13, sat_channels=12, input_size=16, output_channels=3, hidden_dim=32, forecast_steps=4), 2, 3),
     ],
 )
-def test_metnet_train_step_vs_oracle(device, cfg, B, T):
-    """Whole MetNet forward + backward (training-mode BatchNorm, dropout off) vs the oracle; every parameter gradient."""
+@pytest.mark.parametrize("seed", [21, 22, 23])
+def test_metnet_train_step_vs_oracle(device, cfg, B, T, seed):
+    """Whole MetNet forward + backward (training-mode BatchNorm, dropout off) vs the oracle; every parameter gradient.
+
+    Tie-aware: max pooling has a discontinuous gradient - when two candidates of a window agree to ~1e-6
+    relative, fp32 rounding decides the argmax and training-mode BatchNorm spreads that one flip over the whole batch
+    (observed: one flipped window in 24576 -> 1e-3 relative change of every encoder gradient, CPU fp32 vs fp64 just the
+    same).  Instead of curating inputs without near-ties, the oracle follows the routing the HIP kernels chose (read back
+    from the backward kernels, tests/parity_util.py): values and gradients are then comparable on ANY input."""
+    from parity_util import gpu_pool_routing
+
     net, P = _metnet_pair(device, cfg)
     raw = cfg["input_size"] * 4
     s = cfg["input_size"] // 4
     cot = torch.randn(B, cfg["forecast_steps"], cfg["output_channels"], s, s, generator=_g(22))
-    for seed in range(21, 40):  # first seeded input whose pooling windows have no fp32-level near-tie
-        x = torch.randn(B, T, cfg["input_channels"], raw, raw, generator=_g(seed))
-        for p in P.values():
-            p.grad = None
-        with _PoolMargins() as pm:
-            ref = M.metnet_forward(x, P, sat_channels=cfg["sat_channels"], input_size=cfg["input_size"],
-                                   forecast_steps=cfg["forecast_steps"], num_att_layers=cfg.get("num_att_layers", 1))
-        if pm.min_gap > 1e-5:  # ~10x the fp32 rounding noise of the convolution outputs
-            break
-    else:
-        pytest.fail("no well-posed input found")
-    (ref * cot).sum().backward()
+    x = torch.randn(B, T, cfg["input_channels"], raw, raw, generator=_g(seed))
     net.train()
+    net.image_encoder.module.capture = {}
     out = net(x.to(device))
+    (out * cot.to(device)).sum().backward()
+    routing = gpu_pool_routing(net, B, T)
+    ref = M.metnet_forward(x, P, sat_channels=cfg["sat_channels"], input_size=cfg["input_size"], forecast_steps=cfg["forecast_steps"],
+                           num_att_layers=cfg.get("num_att_layers", 1), pool_routing=routing)
+    (ref * cot).sum().backward()
     assert out.shape == ref.shape
     assert_close(out, ref, "metnet out")
-    (out * cot.to(device)).sum().backward()
     for k, p in net.named_parameters():
         assert_close(p.grad, P[k].grad, f"d{k}", grad=True)
+    # the injected routing is the argmax up to rounding: it may differ from the oracle's own argmax only in near-tie windows
+    with torch.no_grad():
+        plain = M.metnet_forward(x, {k: v.detach() for k, v in P.items()}, sat_channels=cfg["sat_channels"], input_size=cfg["input_size"],
+                                 forecast_steps=cfg["forecast_steps"], num_att_layers=cfg.get("num_att_layers", 1))
+    assert_close(ref, plain, "routed vs plain max-pool forward", rtol=1e-4, atol=1e-5)
 
 
 def test_metnet_eval_and_reference_shape_pin(device):
