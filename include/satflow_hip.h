@@ -190,6 +190,11 @@ int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C,
                              int32_t H, int32_t W, int32_t crop, sfTensor out, int32_t dtype,
                              sfStream stream);
 
+/* Gradient of the above wrt the raw images (what autograd produces through the reference's preprocessor when imgs
+ * requires grad: saliency maps, adversarial inputs): dimgs[B][T][C][H][W] fp32, written completely. */
+int sf_metnet_preprocess_bwd(sfTensor dout, int32_t B, int32_t T, int32_t C, int32_t sat, int32_t H, int32_t W,
+                             int32_t crop, float* dimgs, int32_t dtype, sfStream stream);
+
 /* nn.MaxPool2d(2, stride 2) of the DownSampler, forward / backward (argmax recomputed from `in`).
  * perm_l > 0: images are reordered on the pooled side, input image (l*perm_t + t)*B + b <->
  * pooled image (t*perm_l + l)*B + b (lead-time-major encoder order -> time-major ConvGRU order). */

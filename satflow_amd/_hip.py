@@ -49,6 +49,7 @@ PROTOTYPES = {
     ),
     "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_metnet_preprocess_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_metnet_preprocess_bwd": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),
     "sf_maxpool2_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, _i32, _vp]),
     "sf_maxpool2_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, _i32, _vp]),
     "sf_maxpool2_dropout_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64,

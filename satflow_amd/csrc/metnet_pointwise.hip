@@ -100,6 +100,45 @@ __global__ __launch_bounds__(256) void preprocess_kernel(const float* __restrict
   }
 }
 
+// Gradient of the preprocessing wrt the raw images (a gather: every raw pixel feeds at most two output lanes).
+// One thread per 4 horizontally consecutive raw pixels (one 16-byte store); dimgs is written completely.
+template <typename TO>
+__global__ __launch_bounds__(256) void preprocess_bwd_kernel(const TO* __restrict__ dout, int os, int B, int T, int C, int sat, int H, int W,
+                                                             int S, float* __restrict__ dimgs) {
+  const int W4 = W / 4;
+  const long long total = (long long)B * T * C * H * W4;
+  const int dT = H / 2 - S, dL = W / 2 - S;
+  const int top = (dT & 1) ? ((dT / 2) & 1 ? dT / 2 + 1 : dT / 2) : dT / 2;
+  const int left = (dL & 1) ? ((dL / 2) & 1 ? dL / 2 + 1 : dL / 2) : dL / 2;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
+    const int x4 = idx % W4;
+    long long r = idx / W4;
+    const int Y = r % H; r /= H;
+    const int c = r % C; r /= C;
+    const int t = r % T, b = r / T;
+    const long long frame = (long long)t * B + b;
+    const TO* fr = dout + frame * S * S * os;
+    f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int yc = Y / 2 - top;  // row of the centre-cropped half-resolution map
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      const int X = 4 * x4 + k;
+      const int xc = X / 2 - left;
+      const bool in_crop = yc >= 0 && yc < S && xc >= 0 && xc < S;
+      const int sub = (Y & 1) * 2 + (X & 1);
+      float v = 0.f;
+      if (c < sat) {
+        v = 0.25f * (float)fr[((long long)(Y / 4) * S + x4) * os + 4 * sat + c * 4 + sub];
+        if (in_crop) v += (float)fr[((long long)yc * S + xc) * os + c * 4 + sub];
+      } else if (in_crop) {
+        v = 0.25f * (float)fr[((long long)yc * S + xc) * os + 8 * sat + (c - sat)];
+      }
+      g[k] = v;
+    }
+    *reinterpret_cast<f32x4*>(dimgs + (((long long)b * T + t) * C + c) * H * W + (long long)Y * W + 4 * x4) = g;
+  }
+}
+
 // ---------------------------------------------------------------------------------------------
 // max pooling 2x2 stride 2
 // ---------------------------------------------------------------------------------------------
@@ -387,6 +426,20 @@ int sf_metnet_preprocess_fwd(const float* imgs, int32_t B, int32_t T, int32_t C,
   SF_DISPATCH_ACT(out.dtype, hipLaunchKernelGGL((preprocess_kernel<TA>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream, imgs, B, T,
                                                 C, sat, H, W, crop, (TA*)out.ptr, out.c, out.stride));
   SF_CHECK_LAUNCH("metnet_preprocess");
+  return 0;
+}
+
+int sf_metnet_preprocess_bwd(sfTensor dout, int32_t B, int32_t T, int32_t C, int32_t sat, int32_t H, int32_t W, int32_t crop, float* dimgs,
+                             int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_metnet_preprocess_bwd: dtype %d not built", dtype);
+  SF_REQUIRE(H % 4 == 0 && W % 4 == 0 && H / 4 == crop && W / 4 == crop, "preprocess bwd: raw size %dx%d must be 4x input_size=%d", H, W, crop);
+  SF_REQUIRE(sat >= 0 && sat <= C && dout.c >= 8 * sat + (C - sat) && ok4(dout) && (((uintptr_t)dimgs) & 15) == 0,
+             "preprocess bwd: gradient lanes %d < %d or misaligned", dout.c, 8 * sat + C - sat);
+  const long long total = (long long)B * T * C * H * (W / 4);
+  if (total == 0) return 0;
+  SF_DISPATCH_ACT(dout.dtype, hipLaunchKernelGGL((preprocess_bwd_kernel<TA>), dim3(grid_for(total)), dim3(256), 0, (hipStream_t)stream,
+                                                 (const TA*)dout.ptr, dout.stride, B, T, C, sat, H, W, crop, dimgs));
+  SF_CHECK_LAUNCH("metnet_preprocess_bwd");
   return 0;
 }
 

@@ -61,6 +61,27 @@ def nhwc_to_nchw(x: Tensor, c: int) -> Tensor:
     return _FromNHWC.apply(x, (n, c, h, w), n, 1, c, h, w, (c * h * w, 0, h * w))
 
 
+class _PreprocessFn(torch.autograd.Function):
+    """MetNetPreprocessor: ``imgs[B,T,C,H,W] -> frames [T*B, crop, crop, Cp]`` (time-major NHWC), differentiable wrt ``imgs``."""
+
+    @staticmethod
+    def forward(ctx, imgs: Tensor, sat: int, crop: int, out_dtype):
+        ctx.meta = (imgs.shape, sat, crop)
+        return K.metnet_preprocess(imgs, sat, crop, out_dtype)
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (B, Tn, C, H, W), sat, crop = ctx.meta
+        g = g.contiguous()
+        dimgs = torch.empty(B, Tn, C, H, W, dtype=torch.float32, device=g.device)
+        check(lib().sf_metnet_preprocess_bwd(T(g), B, Tn, C, sat, H, W, crop, dimgs.data_ptr(), SF_F32, stream_ptr()), "sf_metnet_preprocess_bwd")
+        return dimgs, None, None, None
+
+
+def metnet_preprocess(imgs: Tensor, sat: int, crop: int, out_dtype=torch.float32) -> Tensor:
+    return _PreprocessFn.apply(imgs.contiguous(), sat, crop, out_dtype)
+
+
 # ----------------------------------------------------------------------------------------------
 # 3x3 convolution (one or two channel-concatenated sources, optional image-index remap per source)
 # ----------------------------------------------------------------------------------------------

@@ -48,7 +48,7 @@ class MetNetPreprocessor(nn.Module):
         from .. import kernels as K
 
         B, T, C, H, W = x.shape
-        frames = K.metnet_preprocess(x.float(), self.sat_channels, self.crop_size)  # [T*B, S, S, Cp]
+        frames = F.metnet_preprocess(x.float(), self.sat_channels, self.crop_size)  # [T*B, S, S, Cp]
         c = 8 * self.sat_channels + (C - self.sat_channels)
         S = self.crop_size
         return F._FromNHWC.apply(frames, (B, T, c, S, S), B, T, c, S, S, (T * c * S * S, c * S * S, S * S))
@@ -278,7 +278,7 @@ class MetNet(nn.Module):
         enc: DownSampler = self.image_encoder.module
         F_ = Tn * B
         st = encoder_storage_dtype()  # fp32, or bf16 in "bf16a" mode (encoder activations only)
-        frames = K.metnet_preprocess(imgs.float(), self.sat_channels, S, st)  # [T*B, S, S, Cimg_p], computed once
+        frames = F.metnet_preprocess(imgs.float(), self.sat_channels, S, st)  # [T*B, S, S, Cimg_p], computed once
         # conv1: its image part once per frame; ConditionTime's one-hot planes (reference layers/ConditionTime.py:22-33)
         # contribute a per-lead-time, border-aware constant that is added inside the fused first pooling
         c1 = enc.module[0]

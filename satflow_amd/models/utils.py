@@ -24,17 +24,22 @@ def get_conv_layer(conv_type: str = "standard"):
     raise ValueError(f"{conv_type} is not a recognized Conv method")
 
 
+def _perm(v, axes):
+    """Axis permutation for torch tensors and numpy arrays alike (the reference's einops calls accept both, utils.py:23-70)."""
+    return v.permute(*axes) if isinstance(v, torch.Tensor) else v.transpose(*axes)
+
+
 def space_to_depth(frames: torch.Tensor, temporal_block_size: int = 1, spatial_block_size: int = 1) -> torch.Tensor:
     """Channels-last space-to-depth with channel order ``(dt dh dw c)`` (reference ``utils.py:48-70``)."""
     s = spatial_block_size
-    if frames.dim() == 4:
+    if frames.ndim == 4:
         b, h, w, c = frames.shape
-        v = frames.reshape(b, h // s, s, w // s, s, c).permute(0, 1, 3, 2, 4, 5)
+        v = _perm(frames.reshape(b, h // s, s, w // s, s, c), (0, 1, 3, 2, 4, 5))
         return v.reshape(b, h // s, w // s, s * s * c)
-    if frames.dim() == 5:
+    if frames.ndim == 5:
         dt = temporal_block_size
         b, t, h, w, c = frames.shape
-        v = frames.reshape(b, t // dt, dt, h // s, s, w // s, s, c).permute(0, 1, 3, 5, 2, 4, 6, 7)
+        v = _perm(frames.reshape(b, t // dt, dt, h // s, s, w // s, s, c), (0, 1, 3, 5, 2, 4, 6, 7))
         return v.reshape(b, t // dt, h // s, w // s, dt * s * s * c)
     raise ValueError("Frames should be of rank 4 (batch, height, width, channels) or rank 5 (batch, time, height, width, channels)")
 
@@ -42,14 +47,14 @@ def space_to_depth(frames: torch.Tensor, temporal_block_size: int = 1, spatial_b
 def reverse_space_to_depth(frames: torch.Tensor, temporal_block_size: int = 1, spatial_block_size: int = 1) -> torch.Tensor:
     """Inverse of :func:`space_to_depth` (reference ``utils.py:23-45``)."""
     s = spatial_block_size
-    if frames.dim() == 4:
+    if frames.ndim == 4:
         b, h, w, c = frames.shape
-        v = frames.reshape(b, h, w, s, s, c // (s * s)).permute(0, 1, 3, 2, 4, 5)
+        v = _perm(frames.reshape(b, h, w, s, s, c // (s * s)), (0, 1, 3, 2, 4, 5))
         return v.reshape(b, h * s, w * s, c // (s * s))
-    if frames.dim() == 5:
+    if frames.ndim == 5:
         dt = temporal_block_size
         b, t, h, w, c = frames.shape
         co = c // (dt * s * s)
-        v = frames.reshape(b, t, h, w, dt, s, s, co).permute(0, 1, 4, 2, 5, 3, 6, 7)
+        v = _perm(frames.reshape(b, t, h, w, dt, s, s, co), (0, 1, 4, 2, 5, 3, 6, 7))
         return v.reshape(b, t * dt, h * s, w * s, co)
     raise ValueError("Frames should be of rank 4 (batch, height, width, channels) or rank 5 (batch, time, height, width, channels)")

@@ -136,3 +136,73 @@ def test_compute_modes():
             satflow_amd.set_compute_dtype("fp8")
     finally:
         satflow_amd.set_compute_dtype("f32")
+
+
+def test_standalone_layers_match_reference_goldens():
+    """The stand-alone `ConditionTime` / `TimeDistributed` modules (views only, device-agnostic) against the tensors the
+    reference's own modules produced (tests/golden/metnet_layers.npz; layers/ConditionTime.py:22-33, TimeDistributed.py:21-40)."""
+    import numpy as np
+    import torch
+
+    from conftest import GOLDEN
+    from satflow_amd.models.layers import ConditionTime, TimeDistributed
+    from satflow_amd.models.utils import space_to_depth
+
+    G = {k: torch.from_numpy(v) for k, v in np.load(os.path.join(GOLDEN, "metnet_layers.npz")).items()}
+    assert torch.equal(ConditionTime(7)(G["x5"], 2), G["ct5"])
+    assert torch.equal(ConditionTime(5, ch_dim=3, num_dims=4)(G["x4"], 4), G["ct4"])
+    with pytest.raises(AssertionError):
+        ConditionTime(3)(G["x5"], 3)  # `assert i < seq_len` (ConditionTime.py:7)
+    conv = torch.nn.Conv2d(4, 3, 3, padding=1)
+    with torch.no_grad():
+        conv.weight.copy_(G["td_weight"]), conv.bias.copy_(G["td_bias"])
+        assert torch.allclose(TimeDistributed(conv)(G["x5"]), G["td"], rtol=0, atol=1e-6)
+        assert torch.allclose(TimeDistributed(conv, low_mem=True)(G["x5"]), G["td_low"], rtol=0, atol=1e-6)
+    s2d = space_to_depth(G["s4"].numpy(), spatial_block_size=2)  # numpy in, numpy out, as the reference accepts (utils.py:48-50)
+    assert isinstance(s2d, np.ndarray) and np.array_equal(s2d, G["s2d"].numpy())
+    assert torch.equal(space_to_depth(G["s4"], spatial_block_size=2), G["s2d"])
+
+
+def test_warmup_cosine_schedule_closed_form():
+    """LinearWarmupCosineAnnealingLR(warmup_epochs=10, max_epochs=100), stepped per optimizer step (pl_metnet.py:70-77), against
+    the closed form published by pl_bolts: lr = base*e/(W-1) for e < W, else base/2 * (1 + cos(pi (e-W)/(M-W)))."""
+    import math
+
+    import torch
+
+    from satflow_amd.models import LitMetNet
+
+    m = LitMetNet(input_channels=5, sat_channels=4, input_size=8, output_channels=2, hidden_dim=16, forecast_steps=3, lr=1e-3)
+    cfg = m.configure_optimizers()
+    opt, sched = cfg["optimizer"], cfg["lr_scheduler"]["scheduler"]
+    assert isinstance(opt, torch.optim.Adam) and cfg["lr_scheduler"]["interval"] == "step" and cfg["lr_scheduler"]["frequency"] == 1
+    table = {0: 0.0, 1: 1e-3 / 9, 5: 5e-3 / 9, 9: 1e-3, 10: 1e-3, 55: 0.5e-3, 100: 0.0}
+    for e in range(101):
+        lr = opt.param_groups[0]["lr"]
+        want = 1e-3 * e / 9 if e < 10 else 0.5e-3 * (1 + math.cos(math.pi * (e - 10) / 90))
+        assert abs(lr - want) < 1e-12, (e, lr, want)
+        if e in table:
+            assert abs(lr - table[e]) < 1e-9, (e, lr)
+        opt.step()
+        sched.step()
+
+
+def test_combine_data_sources_matches_reference_semantics():
+    """`_combine_data_sources` (pl_metnet.py:90-107): satellite, time-repeated topography (einops 'b c h w -> b c t h w') and the
+    optional NWP list concatenated on dim 1, as float."""
+    import torch
+
+    from satflow_amd.models import LitMetNet
+    from satflow_amd.models.pl_metnet import NWP_DATA, SATELLITE_DATA, TOPOGRAPHIC_DATA
+
+    m = LitMetNet(input_channels=5, sat_channels=4, input_size=8, output_channels=2, hidden_dim=16, forecast_steps=3)
+    sat = torch.randn(2, 3, 4, 6, 6).double()
+    topo = torch.randn(2, 1, 6, 6).double()
+    nwp = [torch.randn(2, 2, 4, 6, 6).double()]
+    out = m._combine_data_sources({SATELLITE_DATA: sat, TOPOGRAPHIC_DATA: topo})
+    assert out.dtype == torch.float32 and out.shape == (2, 4, 4, 6, 6)
+    assert torch.equal(out[:, :3], sat.float())
+    for t in range(4):
+        assert torch.equal(out[:, 3, t], topo[:, 0].float())
+    out2 = m._combine_data_sources({SATELLITE_DATA: sat, TOPOGRAPHIC_DATA: topo, NWP_DATA: nwp})
+    assert out2.shape == (2, 6, 4, 6, 6) and torch.equal(out2[:, 4:], nwp[0].float())
