@@ -1,0 +1,396 @@
+// Weight gradient of the 3x3 same convolution on the bf16 matrix cores for bf16-STORED tensors ("bf16a" mode):
+//
+//   dW[tap][co][ci] = sum over pixels  dout[pixel][co] * in[pixel + tap][ci],   fp32 accumulate
+//
+// GEMM view: M = co, N = ci, K = pixels.  The MFMA wants 8 consecutive K values (pixels) of ONE channel per lane while
+// HBM holds NHWC (channel-contiguous).  Round 1 transposed in registers with dedicated loader waves (conv3x3_wgrad_bf16.hip:
+// 45 % of the MFMA peak, loaders and compute waves never overlapped fully).  Here nobody transposes:
+//   * the NHWC tiles go HBM -> LDS unchanged by LDS-DMA (global_load_lds_dwordx4: no staging registers, no ds_write),
+//     four K tiles deep (a 128 KiB ring), with counted `s_waitcnt vmcnt` and raw `s_barrier`: two tiles stay in flight
+//     across every barrier;
+//   * the MFMA operands are read with `ds_read_b64_tr_b16`: a 16-lane group hands in the addresses of four pixels x
+//     16 channels and every lane receives the four pixels of ITS channel - the transpose is done by the LDS read.  A
+//     horizontal tap shift is just another pixel address: no shifted copies, no v_alignbit, no halo side array.
+// Workgroup = 8 compute waves (2 per SIMD), slab 128 (co) x 64 (ci) x 9 taps: wave w owns co fragment w & 3 and ci half
+// w >> 2, i.e. 9 accumulator tiles (144 VGPRs).  K tile = 4 rows x 16 pixels; per tile a wave reads 4 dout fragments and
+// 18 input fragments (6 halo rows x 3 horizontal shifts, each feeding up to 3 vertical taps) for 36 MFMAs.
+// LDS image of a stage (32 KiB): dout [64 px][256 B] with the four 64-byte channel quarters of a pixel xor-ed with
+// (pixel & 3); input halo [6 x 18 px][128 B] with the two 64-byte halves xor-ed with (x >> 1) & 1 - both make the
+// four pixels of a transposing read fall on disjoint banks (the swizzle is applied to the DMA's SOURCE address).
+// Out-of-image / out-of-range pieces are fetched from a 16-byte zero page instead of being masked off, so every wave
+// issues exactly 4 DMA instructions per tile and the counted waits stay exact.
+// The bias gradient is summed from the dout fragments (VALU, one wave in eight).  Split-K partial slabs in the shared
+// layout; `wgrad_reduce_kernel` (conv3x3_wgrad_f32.hip) finishes.
+#include "wgrad_common.h"
+
+namespace {
+
+using namespace sfwgrad;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int TR = 4, TW = 16;             // K tile: 4 rows x 16 pixels
+constexpr int HR = TR + 2, HW = TW + 2;    // halo tile 6 x 18
+constexpr int A_PIX = 2 * DMA_CO_T;        // 256 bytes per dout pixel
+constexpr int B_PIX = 2 * DMA_CI_T;        // 128 bytes per input pixel
+constexpr int A_BYTES = TR * TW * A_PIX;   // 16384 = 16 DMA blocks of 1 KiB
+constexpr int B_BYTES = 16384;             // 108 px x 128 B = 13824, padded to 16 DMA blocks
+constexpr int STAGE = A_BYTES + B_BYTES;
+constexpr int NS = 4;                      // ring depth (tiles): 3, 4 and 5 measured alike (the DMA's latency is covered)
+constexpr int THREADS = 512;
+
+__device__ __forceinline__ bf16x4_t tr_read(unsigned lds_addr) {
+  return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((__attribute__((address_space(3))) bf16x4_t*)(uintptr_t)lds_addr);
+}
+// LDS-DMA issued from inline asm: hipcc must not know about it - it would drain every pending DMA (`s_waitcnt vmcnt(0)`) in front
+// of each LDS read that might alias, i.e. in front of every fragment read, and the ring would never have a tile in flight
+// (cdna_hip_programming.md 5.7).  M0 (the wave-uniform LDS destination) is written in the same statement and restored.
+__device__ __forceinline__ void glds16(const char* gsrc, unsigned lds_dst) {
+  unsigned keep;
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(gsrc), "s"(lds_dst) : "memory");
+}
+__device__ __forceinline__ bf16x8 cat8(bf16x4_t a, bf16x4_t b) { return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7); }
+
+// LDS-DMA through a buffer descriptor: wave-uniform descriptor + scalar offset (the tile position) + a per-lane byte offset that is
+// CONSTANT for the whole kernel; a lane whose piece lies outside the image gets an out-of-range offset and the hardware
+// range check writes zeros to its LDS slot (tools/ubench/buf_lds_oob.hip) - one v_cndmask per instruction instead of a
+// 64-bit address per lane.  M0 is not used by anything else in this kernel (no compiler-issued LDS-DMA), so it is not saved.
+__device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
+}
+
+// FAST: every 64-channel input tile of the block comes from ONE source (single source, or c0 a multiple of 64): DMA through
+// buffer descriptors with kernel-constant lane offsets.  Otherwise (the ConvLSTM's 16-lane x source in front of h) per-lane
+// 64-bit addresses.
+template <bool FAST>
+__global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
+                                                                     const int xcd_groups) {
+  __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3, wc = wave >> 2;  // co fragment / ci half of this wave
+
+  // block id -> (ks, cot, cit): the (cot, cit) combinations of one K slice are consecutive on one XCD (blocks are dealt
+  // round-robin to the 8 XCDs), so a slice's tiles are shared through that XCD's L2 (pure speed choice).
+  const int combos = gridDim.y * gridDim.z;
+  int ks, cot, cit;
+  {
+    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
+    if (xcd_groups) {
+      const int x = id % 8, j = id / 8;
+      ks = (j / combos) * 8 + x;
+      const int combo = j % combos;
+      cot = combo % gridDim.y; cit = combo / gridDim.y;
+    } else { ks = blockIdx.x; cot = blockIdx.y; cit = blockIdx.z; }
+  }
+  // a slice owns a CONTIGUOUS run of tiles: vertically adjacent tiles re-read two halo rows, which are then L2 hits
+  const int t_begin = ks * per_slice;
+  const int t_end = t_begin + per_slice < p.ntiles ? t_begin + per_slice : p.ntiles;
+  const int my_tiles = t_end > t_begin ? t_end - t_begin : 0;
+
+  // ---- per-lane constants of the DMA pieces this wave issues: dout blocks {wave, wave + 8}, input blocks {wave, wave + 8} ----
+  // dout block a = pixels 4a .. 4a+3 (row a / 4, x = 4 * (a % 4) + lane / 16); piece c = lane % 16 sits in physical quarter
+  // c / 4 and carries logical quarter (c / 4) ^ (pixel & 3)
+  const int a_px = lane >> 4;
+  const int a_ch = cot * DMA_CO_T + ((((lane >> 2) & 3) ^ a_px) * 4 + (lane & 3)) * 8;
+  const bool a_chok = a_ch < p.dc;
+  const long long a_pxb = 2ll * p.ds;  // bytes per dout pixel in HBM
+  // input block b = halo pixels 8b .. 8b+7 (hp = 8b + lane / 8 -> hy = hp / 18, hx = hp % 18); piece c = lane % 8 sits in
+  // physical half c / 4 and carries logical half (c / 4) ^ ((hx >> 1) & 1)
+  int b_hy[2], b_hx[2], b_off[2];
+  bool b_ok[2], b_s1[2];
+#pragma unroll
+  for (int u = 0; u < 2; ++u) {
+    const int hp = 8 * (wave + 8 * u) + (lane >> 3);
+    b_hy[u] = hp / HW; b_hx[u] = hp % HW;
+    const int kc = cit * DMA_CI_T + (((((lane >> 2) & 1) ^ ((b_hx[u] >> 1) & 1)) * 4) + (lane & 3)) * 8;  // concatenated padded K space
+    b_s1[u] = kc >= p.c0;
+    b_ok[u] = hp < HR * HW && (kc < p.c0 ? p.src0 != nullptr : (kc - p.c0 < p.c1 && p.src1 != nullptr));
+    const int s = b_s1[u] ? p.s1 : p.s0, ch = b_s1[u] ? kc - p.c0 : kc;
+    b_off[u] = 2 * ((b_hy[u] * p.W + b_hx[u]) * s + ch);
+  }
+
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  // Tiles are issued strictly in order, one `issue()` per tile: the tile coordinates advance incrementally (no divisions in the loop).
+  int nx_i = 0, nx_stage = 0, nx_tx, nx_ty, nx_n;
+  {
+    int t = t_begin < p.ntiles ? t_begin : 0;
+    nx_tx = t % p.tiles_x; t /= p.tiles_x;
+    nx_ty = t % p.tiles_y;
+    nx_n = t / p.tiles_y;
+  }
+  const bool remap = p.idiv0 > 1 || p.imod0 > 0 || p.idiv1 > 1 || p.imod1 > 0;  // block-uniform
+  const long long a_img = (long long)p.H * p.W * a_pxb, b_img0 = (long long)p.H * p.W * 2 * p.s0, b_img1 = (long long)p.H * p.W * 2 * p.s1;
+  auto issue_slow = [&]() {  // DMA of this slice's next tile into ring stage nx_i % NS (tiles past the end fetch zeros: the counts stay exact)
+    const bool live = nx_i < my_tiles;
+    const int n = nx_n, x0 = nx_tx * TW, y0 = nx_ty * TR;
+    const unsigned stage = lds0 + (unsigned)(nx_stage * STAGE);
+    const char* abase = (const char*)p.dout + n * a_img + (y0 * p.W + x0) * (int)a_pxb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int a = wave + 8 * u, row = a >> 2, x = 4 * (a & 3) + a_px;
+      const bool ok = live && a_chok && y0 + row < p.H && x0 + x < p.W;
+      const char* g = ok ? abase + ((row * p.W + x) * (int)a_pxb + 2 * a_ch) : zero;
+      glds16(g, stage + a * 1024);
+    }
+    int ns0 = n, ns1 = n;
+    if (remap) {
+      ns0 = n / p.idiv0; if (p.imod0) ns0 %= p.imod0;
+      ns1 = n / p.idiv1; if (p.imod1) ns1 %= p.imod1;
+    }
+    const int org = (y0 - 1) * p.W + (x0 - 1);  // halo origin (may lie before the image: only valid lanes dereference)
+    const char* bbase0 = (const char*)p.src0 + ns0 * b_img0 + (long long)org * (2 * p.s0);
+    const char* bbase1 = (const char*)p.src1 + ns1 * b_img1 + (long long)org * (2 * p.s1);
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int gy = y0 - 1 + b_hy[u], gx = x0 - 1 + b_hx[u];
+      const bool ok = live && b_ok[u] && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const char* g = ok ? (b_s1[u] ? bbase1 : bbase0) + b_off[u] : zero;
+      glds16(g, stage + A_BYTES + (wave + 8 * u) * 1024);
+    }
+    ++nx_i;
+    nx_stage = nx_stage + 1 == NS ? 0 : nx_stage + 1;
+    if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; } }
+  };
+
+  // ---- fast path: kernel-constant lane offsets + per-lane validity masks over the 16 tile classes ----
+  // tile class = (ty == 0) | (ty == tiles_y - 1) << 1 | (tx == 0) << 2 | (tx == tiles_x - 1) << 3: the validity of a piece depends
+  // on the tile only through its class (first / last tile row and column: image borders and ragged edges)
+  constexpr unsigned SENT = 0x80000000u;  // >= any descriptor's num_records (the launcher checks image bytes < 2^31)
+  unsigned fa_off[2] = {0, 0}, fb_off[2] = {0, 0}, fa_mask[2] = {0, 0}, fb_mask[2] = {0, 0};
+  const bool from0 = cit * DMA_CI_T < p.c0;  // block-uniform; exact when FAST
+  const float* bsrc = from0 ? p.src0 : p.src1;
+  const int bs = from0 ? p.s0 : p.s1, bidiv = from0 ? p.idiv0 : p.idiv1, bimod = from0 ? p.imod0 : p.imod1;
+  if constexpr (FAST) {
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      const int a = wave + 8 * u, row = a >> 2, x = 4 * (a & 3) + a_px;
+      fa_off[u] = (unsigned)(((row * p.W + x) * p.ds + a_ch) * 2);
+      const int kc = cit * DMA_CI_T + (((((lane >> 2) & 1) ^ ((b_hx[u] >> 1) & 1)) * 4) + (lane & 3)) * 8;
+      const int ch = from0 ? kc : kc - p.c0;
+      const bool chok = 8 * (wave + 8 * u) + (lane >> 3) < HR * HW && bsrc != nullptr && ch < (from0 ? p.c0 : p.c1);
+      fb_off[u] = (unsigned)(((b_hy[u] * p.W + b_hx[u]) * bs + ch) * 2);
+      for (int cls = 0; cls < 16; ++cls) {
+        const int y0 = (cls & 2) ? (p.tiles_y - 1) * TR : ((cls & 1) ? 0 : TR), x0 = (cls & 8) ? (p.tiles_x - 1) * TW : ((cls & 4) ? 0 : TW);
+        if (a_chok && y0 + row < p.H && x0 + x < p.W) fa_mask[u] |= 1u << cls;
+        const int gy = y0 - 1 + b_hy[u], gx = x0 - 1 + b_hx[u];
+        if (chok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) fb_mask[u] |= 1u << cls;
+      }
+    }
+  }
+  const unsigned b_pxb = 2u * (unsigned)bs;
+  const long long b_img = (long long)p.H * p.W * b_pxb;
+  auto issue_fast = [&]() {
+    const bool live = nx_i < my_tiles;
+    const int n = nx_n, px0 = (nx_ty * TR) * p.W + nx_tx * TW;
+    const unsigned cls = (nx_ty == 0 ? 1u : 0u) | (nx_ty == p.tiles_y - 1 ? 2u : 0u) | (nx_tx == 0 ? 4u : 0u) | (nx_tx == p.tiles_x - 1 ? 8u : 0u);
+    const unsigned sel = live ? 1u << cls : 0u;  // dead tiles (past the slice's end) fetch zeros: the DMA counts stay exact
+    const unsigned stage = lds0 + (unsigned)(nx_stage * STAGE);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.dout + n * a_img), 0, (int)a_img, 0x00020000);
+    const unsigned soa = (unsigned)px0 * (unsigned)a_pxb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) bufdma16((fa_mask[u] & sel) ? fa_off[u] : SENT, rsa, soa, stage + (wave + 8 * u) * 1024);
+    int ns = n;
+    if (remap) { ns = n / bidiv; if (bimod) ns %= bimod; }
+    // descriptor starts one image row + one pixel BEFORE the image so that the halo origin has a non-negative offset
+    const long long lead = (long long)(p.W + 1) * b_pxb;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)bsrc + ns * b_img - lead), 0, (int)(b_img + 2 * lead), 0x00020000);
+    const unsigned sob = (unsigned)px0 * b_pxb;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) bufdma16((fb_mask[u] & sel) ? fb_off[u] : SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
+    ++nx_i;
+    nx_stage = nx_stage + 1 == NS ? 0 : nx_stage + 1;
+    if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; } }
+  };
+  auto issue = [&]() {
+    if constexpr (FAST) issue_fast(); else issue_slow();
+  };
+
+  // ---- per-lane LDS read addresses (transposing reads: lane l of a 16-lane group supplies pixel (l >> 2) & 3, 8-byte chunk l & 3) ----
+  const int m = (lane >> 2) & 3, khalf = lane >> 5;
+  const int cbyte = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  const unsigned a_base = lds0 + (8 * khalf + m) * A_PIX + ((wq ^ m) * 64) + cbyte;  // + row * 4096 + r * 1024
+  unsigned b_base[3];                                                               // + hrow * 2304 + r * 512
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+    b_base[kx] = lds0 + A_BYTES + (8 * khalf + m + kx) * B_PIX + ((wc ^ (((m + kx) >> 1) & 1)) * 64) + cbyte;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  const bool want_bias = cit == 0 && wc == 0;  // wave-uniform
+
+  // prologue: NS - 1 tiles in flight, tile 0 visible
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  // fragment reads of ring stage st (base & 0x3ffff: tells the compiler the LDS address is non-negative so that it folds the row /
+  // half offsets into the instructions' immediate offset fields instead of recomputing an address per read)
+  int rd_stage = 0;  // ring stage of the tile whose fragments are requested next
+  auto stage_addr = [&](unsigned& aA, unsigned (&aB)[3]) {
+    const unsigned so = (unsigned)(rd_stage * STAGE);
+    rd_stage = rd_stage + 1 == NS ? 0 : rd_stage + 1;
+    aA = (a_base + so) & 0x3ffffu;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) aB[kx] = (b_base[kx] + so) & 0x3ffffu;
+  };
+  auto load_a = [&](unsigned aA, bf16x8 (&arow)[TR]) {
+#pragma unroll
+    for (int row = 0; row < TR; ++row) arow[row] = cat8(tr_read(aA + row * 4096), tr_read(aA + row * 4096 + 1024));
+  };
+  auto load_b = [&](const unsigned (&aB)[3], int hrow, bf16x8 (&b)[3]) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) b[kx] = cat8(tr_read(aB[kx] + hrow * (HW * B_PIX)), tr_read(aB[kx] + hrow * (HW * B_PIX) + 4 * B_PIX));
+  };
+  auto mfma_row = [&](int hrow, const bf16x8 (&arow)[TR], const bf16x8 (&b)[3]) {
+#pragma unroll
+    for (int ky = 0; ky < 3; ++ky) {
+      const int row = hrow - ky;
+      if (row < 0 || row >= TR) continue;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        acc[ky * 3 + kx] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(arow[row], b[kx], acc[ky * 3 + kx], 0, 0, 0);
+    }
+  };
+
+  // The two waves of a SIMD (w, w + 4) issue the next tile's DMA at different points of the tile so that one's MFMAs cover
+  // the other's issue stall (see conv3x3_bf16.hip).
+  const bool stage_late = wave >= 4;
+  bf16x8 arow_a[TR], arow_b[TR], bq0[3], bq1[3];
+  unsigned aA, aB[3];
+  stage_addr(aA, aB);
+  load_a(aA, arow_a);
+  load_b(aB, 0, bq0);
+
+  // One tile: 36 MFMAs in two halves around the ring's rendezvous.  `cur` holds this tile's dout fragments (read during the
+  // previous tile's second half), `nxt` receives the next tile's; halo row h + 1 is requested before row h's MFMAs.
+  // The rendezvous (counted vmcnt: this wave's pieces of tile i + 1 have landed, one tile stays in flight; barrier: everybody's
+  // have, and everybody is done with tile i - 1, whose stage the DMA of tile i + NS - 1 may now overwrite) sits in the MIDDLE
+  // of the tile: behind it the wave still has half a tile of MFMAs whose operands are in registers or in this tile's stage, and
+  // the next tile's first fragments are requested under them - no wave starts a tile with an empty matrix pipe.
+  auto tile = [&](bf16x8 (&cur)[TR], bf16x8 (&nxt)[TR]) {
+    if (want_bias) {
+#pragma unroll
+      for (int row = 0; row < TR; ++row) {
+        const u32x4 d = __builtin_bit_cast(u32x4, cur[row]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bsum += __builtin_bit_cast(float, d[k] << 16) + __builtin_bit_cast(float, d[k] & 0xffff0000u);
+      }
+    }
+    load_b(aB, 1, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(0, cur, bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(aB, 2, bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(1, cur, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(aB, 3, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(2, cur, bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(aB, 4, bq0);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 3)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!stage_late) issue();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(3, cur, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(aB, 5, bq1);
+    unsigned nA, nB[3];
+    stage_addr(nA, nB);
+    load_a(nA, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(4, cur, bq0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b(nB, 0, bq0);
+    if (stage_late) issue();
+    __builtin_amdgcn_sched_barrier(0);
+    mfma_row(5, cur, bq1);
+    __builtin_amdgcn_sched_barrier(0);
+    aA = nA;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) aB[kx] = nB[kx];
+  };
+  for (int i = 0; i < my_tiles; i += 2) {
+    tile(arow_a, arow_b);
+    if (i + 1 < my_tiles) tile(arow_b, arow_a);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the (dummy) tail may land after the block has retired
+
+  // partial[ks][tap][co][ci]
+  const int r = lane & 31, kh = lane >> 5;
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+    for (int reg = 0; reg < 16; ++reg) {
+      const int co = cot * DMA_CO_T + 32 * wq + frag_row(reg, kh);
+      const int ci = cit * DMA_CI_T + 32 * wc + r;
+      p.partial[(((size_t)ks * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
+    }
+  if (want_bias) {
+    const float tot = bsum + __shfl_xor(bsum, 32);
+    if (kh == 0) p.partial_db[(size_t)ks * p.NpT + cot * DMA_CO_T + 32 * wq + r] = tot;
+  }
+}
+
+}  // namespace
+
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w) {
+  using namespace sfwgrad;
+  Plan pl;
+  pl.tiles_x = (w + TW - 1) / TW;
+  pl.tiles_y = (h + TR - 1) / TR;
+  pl.ntiles = pl.tiles_x * pl.tiles_y * n;
+  pl.cot = (Np + DMA_CO_T - 1) / DMA_CO_T;
+  pl.cit = (Kp + DMA_CI_T - 1) / DMA_CI_T;
+  // one workgroup per CU (128 KiB of LDS): as many K slices as fill the 256 CUs once, in whole groups of 8 (one per XCD)
+  int want = 256 / (pl.cot * pl.cit);
+  want = want / 8 * 8;
+  if (want < 8) want = 8;
+  const int per_min = 6;  // a slice shorter than the ring + pipeline fill is all prologue
+  int ks = want;
+  while (ks > 8 && (pl.ntiles + ks - 1) / ks < per_min) ks -= 8;
+  if (ks > pl.ntiles) ks = pl.ntiles > 0 ? pl.ntiles : 1;
+  pl.KS = ks;
+  pl.ws_floats = (size_t)pl.KS * ((size_t)9 * pl.cot * DMA_CO_T * pl.cit * DMA_CI_T + (size_t)pl.cot * DMA_CO_T) + 64;  // + the zero page
+  return pl;
+}
+
+int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, float* workspace, hipStream_t st) {
+  using namespace sfwgrad;
+  if ((((uintptr_t)p.dout) & 15) || p.ds % 8 || p.dc % 8 || (p.src0 && ((((uintptr_t)p.src0) & 15) || p.s0 % 8 || p.c0 % 8)) ||
+      (p.src1 && ((((uintptr_t)p.src1) & 15) || p.s1 % 8 || p.c1 % 8))) {
+    sf_set_error("wgrad_bf16_dma: bf16 tensors need 16-byte aligned pixels (strides and channel counts multiples of 8)");
+    return 1;
+  }
+  {
+    const long long px = (long long)p.H * p.W + p.W + 1;
+    const long long smax = p.ds > p.s0 ? (p.ds > p.s1 ? p.ds : p.s1) : (p.s0 > p.s1 ? p.s0 : p.s1);
+    if (px * smax * 2 >= (1ll << 31)) { sf_set_error("wgrad_bf16_dma: one image of a tensor must be smaller than 2 GiB"); return 1; }
+  }
+  p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.KS = pl.KS;
+  p.NpT = pl.cot * DMA_CO_T; p.KpT = pl.cit * DMA_CI_T;
+  // workspace: [zero page 64 floats][partial][partial_db]
+  if (hipMemsetAsync(workspace, 0, 64 * sizeof(float), st) != hipSuccess) { sf_set_error("wgrad_bf16_dma: memset failed"); return 2; }
+  p.partial = workspace + 64;
+  p.partial_db = p.partial + (size_t)pl.KS * 9 * p.NpT * p.KpT;
+  const int per_slice = (pl.ntiles + pl.KS - 1) / pl.KS;
+  const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
+  const bool fast = !(p.src0 && p.src1 && p.c1 > 0) || p.c0 % DMA_CI_T == 0;
+  if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
+  else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { sf_set_error("wgrad_bf16_dma: launch failed: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}

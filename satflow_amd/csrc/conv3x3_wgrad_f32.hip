@@ -154,8 +154,10 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
 extern "C" {
 
 size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w) {
-  // the bf16 variant uses taller K tiles, i.e. never more tiles / a larger KS than this plan
-  return make_plan(Np, Kp, n, h, w, KT_H).ws_floats * sizeof(float);
+  // the loader-wave bf16 variant uses taller K tiles, i.e. never more tiles / a larger KS than this plan; the all-bf16-storage
+  // variant has its own plan
+  const size_t a = make_plan(Np, Kp, n, h, w, KT_H).ws_floats, b = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w).ws_floats;
+  return (a > b ? a : b) * sizeof(float);
 }
 
 int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h, int32_t w,
@@ -166,7 +168,9 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   SF_REQUIRE(src0.ptr || src0.c == 0, "bwd_weight: src0 null");
   SF_REQUIRE(src1.ptr || src1.c == 0, "bwd_weight: src1 null with c=%d (pass c=0)", src1.c);
   const int Np = dout.c, Kp = src0.c + src1.c;
-  const Plan pl = make_plan(Np, Kp, n, h, w, dtype == SF_BF16 ? 8 : KT_H);
+  const bool all_bf16 = dtype == SF_BF16 && dout.dtype == SF_BF16 && (!src0.ptr || src0.dtype == SF_BF16) && (!src1.ptr || src1.dtype == SF_BF16) &&
+                        (src0.ptr || src1.ptr);
+  const Plan pl = all_bf16 ? sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w) : make_plan(Np, Kp, n, h, w, dtype == SF_BF16 ? 8 : KT_H);
   SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
              workspace_bytes, pl.ws_floats * sizeof(float));
   WgradParams p{};
@@ -187,7 +191,9 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   p.NpT = pl.cot * CO_T; p.KpT = pl.cit * CI_T;
   p.partial = (float*)workspace;
   p.partial_db = p.partial + (size_t)pl.KS * 9 * p.NpT * p.KpT;
-  if (dtype == SF_BF16) {
+  if (all_bf16) {
+    if (int rc = sf_launch_wgrad_bf16_dma(p, pl, (float*)workspace, (hipStream_t)stream)) return rc;
+  } else if (dtype == SF_BF16) {
     if (int rc = sf_launch_wgrad_bf16(p, pl, (hipStream_t)stream)) return rc;
   } else {
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3(pl.KS, pl.cot, pl.cit), dim3(256), 0, (hipStream_t)stream, p);

@@ -6,6 +6,7 @@ namespace sfwgrad {
 
 constexpr int CO_T = 128, CI_T = 32;   // dW slab per workgroup: 128 (co) x 32 (ci) x 9 taps
 constexpr int KT_W = 16;               // K tile width (pixels)
+constexpr int DMA_CO_T = 128, DMA_CI_T = 64;  // slab of the all-bf16-storage kernel (conv3x3_wgrad_bf16_dma.hip)
 
 struct WgradParams {
   const float* src0; const float* src1; int c0, c1, s0, s1;
@@ -40,5 +41,10 @@ inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
 
 }  // namespace sfwgrad
 
+// all-bf16-storage variant (conv3x3_wgrad_bf16_dma.hip): LDS-DMA tiles + transposing LDS reads; its own plan (4x16 K tiles,
+// 128 x 64 slabs, one workgroup per CU); the launcher places [zero page | partial | partial_db] in the workspace and sets p's
+// plan fields
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w);
+int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, float* workspace, hipStream_t st);
 // bf16-MFMA variant (conv3x3_wgrad_bf16.hip): fills the same partial slabs
 int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);

@@ -176,7 +176,7 @@ def test_cfg3_metnet_train_step_fullsize_f32(device):
         r = rel_l2(p.grad, G[k])
         worst = max(worst, (k, r), key=lambda t: t[1])
     publish({"config": "configs[2] MetNet 12ch 256x256 T=24->12 hid 64, B=2, train step (BN train mode, dropout off)", "mode": "f32",
-             "out_max_abs": float((out.cpu() - ref).abs().max()), "out_rel_l2": rel_l2(out, ref), "worst_grad": worst[0],
+             "out_max_abs": float((out.detach().cpu() - ref).abs().max()), "out_rel_l2": rel_l2(out, ref), "worst_grad": worst[0],
              "worst_grad_rel_l2": worst[1]})
 
 
@@ -212,7 +212,7 @@ def test_cfg3_metnet_train_step_fullsize_bf16a(device):
     yard = {k: rel_l2(P16[k].grad, G[k]) for k in P16 if k not in ZERO_TRUE_GRAD}
     ours = {k: rel_l2(p.grad, G[k]) for k, p in net.named_parameters() if k not in ZERO_TRUE_GRAD}
     rec = {"config": "configs[2] MetNet 12ch 256x256 T=24->12 hid 64, B=2, train step (BN train mode, dropout off)", "mode": "bf16a",
-           "out_max_abs": float((out.cpu() - ref).abs().max()), "out_rel_l2": rel_l2(out, ref),
+           "out_max_abs": float((out.detach().cpu() - ref).abs().max()), "out_rel_l2": rel_l2(out, ref),
            "cpu_autocast_out_rel_l2": rel_l2(ref16.float(), ref), "cpu_autocast_seconds": yard_s,
            "grad_rel_l2": ours, "cpu_autocast_grad_rel_l2": yard}
     publish(rec)

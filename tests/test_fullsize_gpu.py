@@ -73,3 +73,39 @@ def test_conv_linearity_and_adjoint_fullbatch(device):
     # both sides are sums of 6e8 products with heavy cancellation: bound the mismatch by the Cauchy-Schwarz scale
     scale = float(y1.double().norm() * gy.double().norm())
     assert abs(float(lhs - rhs)) <= 1e-6 * scale, (float(lhs), float(rhs), scale)
+
+
+def test_wgrad_bf16_storage_adjoint_fullbatch(device):
+    """The all-bf16-storage weight-gradient kernel (LDS-DMA ring + transposing LDS reads) at the bench's batch (2304 images of
+    32x32, 256 -> 256 channels): <dW, V> == <conv(x; V), gy> for a random direction V, i.e. the weight gradient is the
+    adjoint of the (oracle-checked) forward kernel in its weight argument; db == sum of gy.  bf16-representable operands, so
+    both sides see identical MFMA inputs and differ only by fp32 summation order."""
+    import satflow_amd
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import NULL, T
+    from satflow_amd.functional import ConvEngine
+
+    satflow_amd.set_compute_dtype("bf16a")
+    try:
+        n, C, H, W = 2304, 256, 32, 32
+        g = torch.Generator(device="cpu").manual_seed(7)
+        eng = ConvEngine([C], C)
+        x = torch.randn(n, H, W, C, device=device).bfloat16()
+        gy = torch.randn(n, H, W, C, device=device).bfloat16()
+        V = (torch.randn(C, C, 3, 3, generator=g) * 0.05).bfloat16().float().to(device)
+        dw, db = torch.empty(C, C, 3, 3, device=device), torch.empty(C, device=device)
+        K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw, db, False)
+        packed, _ = K.pack_weights(V, None, eng.fwd_map, False)
+        y = torch.empty(n, H, W, C, device=device)  # fp32 output: the pairing below must not see a bf16 rounding of conv(x; V)
+        K.conv3x3(T(x), NULL, n, H, W, packed, None, eng.fwd_map, T(y))
+        lhs = float((dw.double() * V.double()).sum())
+        rhs = float((y.double() * gy.double()).sum())
+        scale = float(dw.double().norm() * V.double().norm())
+        assert abs(lhs - rhs) <= 1e-5 * scale, (lhs, rhs, scale)
+        assert_close(db, gy.float().sum(dim=(0, 1, 2)), "db", grad=True)
+        # accumulate=True adds into dW
+        dw2 = dw.clone()
+        K.conv3x3_bwd_weight(T(x), NULL, T(gy), n, H, W, eng.wgrad_map, dw2, None, True)
+        assert_close(dw2, 2 * dw, "accumulated dW", grad=True)
+    finally:
+        satflow_amd.set_compute_dtype("f32")

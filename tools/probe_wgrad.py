@@ -8,7 +8,8 @@ from satflow_amd.functional import ConvEngine
 satflow_amd.set_compute_dtype("bf16")
 dev = torch.device("cuda:0")
 st = torch.bfloat16 if os.environ.get("SF_ACT", "f32") == "bf16" else torch.float32
-for (n, cin, cout, H, W) in ((2304, 256, 256, 32, 32), (2304, 160, 256, 32, 32), (192, 96, 160, 64, 64)):
+shapes = ((2304, 256, 256, 32, 32), (2304, 160, 256, 32, 32), (192, 96, 160, 64, 64), (2304, 256, 192, 16, 16))
+for (n, cin, cout, H, W) in shapes[: int(os.environ.get('SF_ONLY', len(shapes)))]:
     eng = ConvEngine([cin], cout)
     x = torch.randn(n, H, W, eng.fwd_map.Kp, device=dev).to(st); gy = torch.randn(n, H, W, eng.coutp, device=dev).to(st)
     dw = torch.empty(cout, cin, 3, 3, device=dev); db = torch.empty(cout, device=dev)
