@@ -47,9 +47,28 @@ def event_time(fn, iters: int, warm: int = 3) -> float:
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def time_cpu(one, what: str, budget_s: float = 25.0) -> dict:
-    """Time `one()` (one CPU sample) on the host cores within a bounded budget (about 10-30 s)."""
-    threads = min(os.cpu_count() or 1, 32)  # more threads than this only adds contention at these conv sizes
+def kernel_source_sha(files=("conv3x3_bf16.hip", "conv_common.h", "sf_common.h")) -> str:
+    """sha256 (16 hex digits) of the dominant kernel's sources: stamps the PMC records under profiles/ so that a stale
+    `roofline.traffic` cannot outlive a kernel change."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for f in files:
+        h.update(open(os.path.join(ROOT, "satflow_amd", "csrc", f), "rb").read())
+    return h.hexdigest()[:16]
+
+
+def cpu_model() -> str:
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                return line.split(":", 1)[1].strip()
+    except OSError:
+        pass
+    return "unknown"
+
+
+def _time_cpu_at(one, threads: int, budget_s: float, max_timed: int = 3):
     torch.set_num_threads(threads)
     t0 = time.perf_counter()
     one()  # warm-up (oneDNN primitive creation)
@@ -57,13 +76,26 @@ def time_cpu(one, what: str, budget_s: float = 25.0) -> dict:
     n, dt = 0, warm
     if warm < budget_s / 2:
         t0 = time.perf_counter()
-        while n < 3 and (time.perf_counter() - t0) + dt < budget_s:
+        while n < max_timed and (time.perf_counter() - t0) + dt < budget_s:
             one()
             n += 1
             dt = (time.perf_counter() - t0) / n
-    return {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port",
-            "sample": f"{what}; {n if n else 1} timed step(s){'' if n else ' (the warm-up itself: budget exhausted)'} "
-                      f"on {threads} threads of {os.cpu_count()} host cores, torch {torch.__version__} CPU, {dt*1e3:.0f} ms/sample"}
+    return dt, n
+
+
+def time_cpu(one, what: str, budget_s: float = 14.0) -> dict:
+    """Time `one()` (one FULL CPU sample: forward + backward + Adam) on the host cores, bounded: with
+    os.cpu_count() threads - the stated baseline - and with 32 threads (at these convolution sizes more threads mostly add
+    contention); `value` is the os.cpu_count() figure, the other one rides along."""
+    cores = os.cpu_count() or 1
+    dt_all, n_all = _time_cpu_at(one, cores, budget_s)
+    res = {"value": 1.0 / dt_all, "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "extrapolated": False,
+           "sample": f"{what}; {n_all if n_all else 1} timed step(s){'' if n_all else ' (the warm-up itself: budget exhausted)'} on "
+                     f"{cores} threads (= os.cpu_count()) of {cpu_model()}, torch {torch.__version__} CPU, {dt_all*1e3:.0f} ms/sample"}
+    if cores > 32:
+        dt32, n32 = _time_cpu_at(one, 32, budget_s)
+        res["threads_32"] = {"value": 1.0 / dt32, "cores": 32, "ms_per_sample": dt32 * 1e3, "timed_steps": n32 if n32 else 1}
+    return res
 
 
 # ----------------------------------------------------------------------------------------------
@@ -85,7 +117,7 @@ class ConvLSTMWorkload:
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)  # per-rank data shard
         self.x = torch.rand(self.B, self.T, self.C, self.H, self.W, generator=g).to(dev)
         self.y = torch.rand(self.B, self.fs, self.out, self.H, self.W, generator=g).to(dev)
-        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr, overlap=not os.environ.get("SF_NO_OVERLAP"))
+        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr, overlap=not os.environ.get("SF_NO_OVERLAP"), buffers=list(self.model.buffers()))
         self.dev = dev
 
     def step(self):
@@ -122,19 +154,25 @@ class ConvLSTMWorkload:
                 "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, 128->256 ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", B),
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
-                "note": "fp32 parity mode: exact-f32 MFMA, bound by the 157.3 TF fp32 matrix pipe (intensity 461 F/B >> ridge 20 F/B)"}
+                "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16); bf16-stored x / h / gates: intensity 922 F/B vs ridge "
+                         "312 F/B -> MFMA-bound" if bf16 and st == torch.bfloat16 else
+                         "bf16 operands / fp32 accumulate, fp32-stored states: intensity 461 F/B vs ridge 312 F/B -> MFMA-bound" if bf16 else
+                         "fp32 parity mode: exact-f32 MFMA, bound by the 157.3 TF fp32 matrix pipe (intensity 461 F/B >> ridge 20 F/B)")}
 
     def cpu_baseline(self):
         from oracle import convlstm as O  # checker/baseline only
 
         params = {k: v.detach().cpu().clone().requires_grad_() for k, v in self.model.model.state_dict().items()}
         x, y = self.x[:1].cpu(), self.y[:1].cpu()
+        opt = torch.optim.Adam(list(params.values()), lr=self.model.lr)
 
         def one():
+            opt.zero_grad()
             loss, _ = O.training_loss(x, y, self.fs, params)
             loss.backward()
+            opt.step()
 
-        return time_cpu(one, "oracle fwd+bwd (no optimizer), B=1 of the same workload, fp32")
+        return time_cpu(one, "oracle fwd + mse + bwd + Adam, B=1 of the same workload, fp32")
 
 
 class MetNetWorkload:
@@ -143,11 +181,11 @@ class MetNetWorkload:
 
     name = "metnet_cfg3"
 
-    def __init__(self, dev, batch: int, rank: int, dropout: float = 0.2):
+    def __init__(self, dev, batch: int, rank: int, dropout: float = 0.2, hidden: int = 64):
         from satflow_amd.models import LitMetNet
         from satflow_amd.optim import FlatAdam
 
-        self.B, self.T, self.C, self.raw, self.hid, self.L, self.out = batch, 24, 12, 256, 64, 12, 12
+        self.B, self.T, self.C, self.raw, self.hid, self.L, self.out = batch, 24, 12, 256, hidden, 12, 12
         torch.manual_seed(1234)
         self.model = LitMetNet(input_channels=12, sat_channels=12, input_size=64, output_channels=self.out, hidden_dim=self.hid,
                                forecast_steps=self.L, num_layers=1, num_att_layers=1, temporal_dropout=dropout).to(dev)
@@ -155,7 +193,7 @@ class MetNetWorkload:
         g = torch.Generator(device="cpu").manual_seed(1234 + rank)
         self.x = torch.randn(self.B, self.T, self.C, self.raw, self.raw, generator=g).to(dev)
         self.y = torch.randn(self.B, self.L, self.out, 16, 16, generator=g).to(dev)
-        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr, overlap=not os.environ.get("SF_NO_OVERLAP"))
+        self.opt = FlatAdam(self.model.parameters(), lr=self.model.lr, overlap=not os.environ.get("SF_NO_OVERLAP"), buffers=list(self.model.buffers()))
         self.dev, self.dropout = dev, dropout
 
     def step(self):
@@ -195,10 +233,14 @@ class MetNetWorkload:
         alg_bytes = 2 * C * H * W * n * esz + 9 * C * C * (2 if bf16 else 4)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", f"r01_metnet_{mode}_pmc_conv256.json")
+        pmc = os.path.join(ROOT, "profiles", f"r02_metnet_{mode}_pmc_conv256.json")
         if n == 2304 and os.path.exists(pmc):  # PMC pass of this very launch shape (tools/prof_pmc.sh), per launch
             rec = json.load(open(pmc))
-            traffic, traffic_src = rec["traffic_bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; profiles/r01_metnet_{mode}_pmc_conv256.json"
+            if rec.get("kernel_src_sha") == kernel_source_sha():  # a record of another kernel version is NOT this kernel's traffic
+                traffic, traffic_src = rec["traffic_bytes"], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; "
+                                                              f"profiles/r02_metnet_{mode}_pmc_conv256.json (kernel sources sha {rec['kernel_src_sha']})")
+            else:
+                traffic_src = f"profiles/r02_metnet_{mode}_pmc_conv256.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": f"conv3x3_{'bf16' if bf16 else 'f32'}_kernel<NF=4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)",
@@ -214,22 +256,69 @@ class MetNetWorkload:
     def cpu_baseline(self):
         from oracle import metnet as M  # checker/baseline only
 
-        sub = 2  # lead times timed on the CPU; per-lead-time work is identical and independent
         p = {k: v.detach().cpu().clone().requires_grad_() for k, v in self.model.model.state_dict().items()
              if v.dtype == torch.float32 and "running" not in k}
-        x, y = self.x[:1].cpu(), self.y[:1, :sub].cpu()
+        x, y = self.x[:1].cpu(), self.y[:1].cpu()
+        opt = torch.optim.Adam(list(p.values()), lr=self.model.lr)
 
-        def one():
-            out = M.metnet_forward(x, p, sat_channels=12, input_size=64, forecast_steps=sub)
+        def one():  # one WHOLE sample: all lead times, forward + loss + backward + Adam (nothing extrapolated)
+            opt.zero_grad()
+            out = M.metnet_forward(x, p, sat_channels=12, input_size=64, forecast_steps=self.L)
             torch.nn.functional.mse_loss(out, y).backward()
+            opt.step()
 
-        # conv1's one-hot columns: the oracle is built for `forecast_steps` planes, so give it a matching slice
-        w0 = "image_encoder.module.module.0.weight"
-        p[w0] = p[w0].detach()[:, : 96 + sub].clone().requires_grad_()
-        res = time_cpu(one, f"oracle fwd+bwd (no optimizer, dropout off), B=1, {sub} of the {self.L} lead times, fp32")
-        res["value"] /= self.L / sub
-        res["sample"] += f"; scaled x{self.L // sub} to all lead times"
-        return res
+        return time_cpu(one, f"oracle fwd + mse + bwd + Adam (dropout off), B=1, all {self.L} lead times, fp32")
+
+    def attention_mfma(self):
+        """north_star: "MFMA utilisation on axial attention".  The layer = one fused q/kv projection GEMM (fp32 MFMA), the
+        attention core (VALU: sequences of length 16 fit a lane's registers, no matrix instruction applies) and the output GEMM."""
+        layer = self.model.model.temporal_agg[0]
+        n, s, hid = self.B * self.L, 16, self.hid
+        x = torch.randn(n, s, s, hid, device=self.dev).requires_grad_()
+
+        def fb():
+            y = layer.run(x)
+            y.backward(y.detach())
+
+        t = event_time(fb, iters=10)
+        rows = n * s * s
+        mfma_flops = 3 * (2 * rows * hid * 6 * hid + 2 * rows * 2 * hid * hid)  # projections fwd + dgrad + wgrad; the core has none
+        core_flops = 3 * 2 * 2 * 2 * n * s * s * s * hid                          # qk^T and pv along both axes, fwd + 2x bwd
+        return {"fwd_bwd_us": t * 1e6, "mfma_flops": mfma_flops, "valu_core_flops": core_flops,
+                "mfma_utilisation": mfma_flops / t / (PEAK_F32_TFLOPS * 1e12),
+                "note": "fraction of the 157.3 TF fp32 MFMA peak over the layer's forward+backward wall time; latency-bound by design "
+                        "(19 MFLOP per layer, SURVEY 8d)"}
+
+
+class StubWorkload:
+    """CPU stand-in with the workloads' interface: exercises this file's launch / timing / reporting plumbing under gloo
+    (tests/test_ddp_cpu.py) - never a measurement."""
+
+    name = "stub"
+
+    def __init__(self, dev, batch: int, rank: int):
+        torch.manual_seed(0)
+        self.B = batch
+        self.net = torch.nn.Linear(8, 4)
+        self.x = torch.randn(batch, 8, generator=torch.Generator().manual_seed(rank))
+        self.opt = torch.optim.SGD(self.net.parameters(), lr=0.1)
+
+    def step(self):
+        self.opt.zero_grad()
+        loss = self.net(self.x).square().mean()
+        loss.backward()
+        if dist.is_initialized():
+            for p in self.net.parameters():
+                dist.all_reduce(p.grad)
+                p.grad /= dist.get_world_size()
+        self.opt.step()
+        return loss
+
+    def config(self, world):
+        return {"workload": "stub (plumbing test only)", "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}"}
+
+    def roofline(self):
+        return {"bound": "hbm", "achieved": 0.0, "peak": PEAK_HBM_GBPS, "unit": "GB/s", "frac": 0.0, "traffic": None}
 
 
 def build_workload(name: str, dev, batch: int, rank: int):
@@ -237,49 +326,24 @@ def build_workload(name: str, dev, batch: int, rank: int):
         return ConvLSTMWorkload(dev, batch, rank)
     if name == "metnet":
         return MetNetWorkload(dev, batch, rank)
+    if name == "stub":
+        return StubWorkload(dev, batch, rank)
     raise SystemExit(f"unknown workload {name}")
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm"])
-    ap.add_argument("--batch", type=int, default=8, help="per-GPU batch (weak scaling)")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f32"],
-                    help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default), the same with the MetNet "
-                         "encoder's activations also STORED as bf16 (bf16a), or exact fp32 (parity mode)")
-    args = ap.parse_args()
-
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
-    import satflow_amd
-
-    satflow_amd.set_compute_dtype(args.dtype)
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=dev)
-
-    wl = build_workload(args.workload, dev, args.batch, rank)
-
+def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
+    """W untimed steps, then exactly K steps between barrier + device sync on both sides; MAX over ranks."""
     def barrier():
         if world > 1:
             dist.barrier()
-        torch.cuda.synchronize()
+        sync()
 
-    for _ in range(args.warmup):
+    for _ in range(warmup):
         wl.step()
     barrier()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    loss = None
+    for _ in range(steps):
         loss = wl.step()
     barrier()
     elapsed = time.perf_counter() - t0
@@ -287,14 +351,79 @@ def main():
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    final_loss = float(loss.item())
+    return elapsed, float(loss.item())
 
+
+def comm_report(wl, world: int, dev) -> dict:
+    """What the gradient exchange costs on this node: ranks RCCL sees, the slices FlatAdam all-reduces and the time of one
+    all-reduce of each (events on the current stream; outside the timed region)."""
+    rep = {"backend": dist.get_backend() if world > 1 else None, "nranks": world}
+    opt = getattr(wl, "opt", None)
+    if world > 1 and hasattr(opt, "flat_g"):
+        ranges = opt._bucket_range if opt.overlap else [[0, opt.numel]]
+        rep["overlap_with_backward"] = bool(opt.overlap)
+        rep["buckets"] = []
+        for lo, hi in ranges:
+            buf = torch.zeros(hi - lo, dtype=torch.float32, device=dev)
+            t = event_time(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM), iters=10)
+            rep["buckets"].append({"bytes": 4 * (hi - lo), "allreduce_us": t * 1e6})
+    return rep
+
+
+
+def main(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=8)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "stub"])
+    ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 8; with --scaling strong: global batch / N)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="weak: fixed per-GPU batch (default, 8/GPU); strong: fixed global batch (--global-batch, BASELINE cfg 4: 64) split over the ranks")
+    ap.add_argument("--global-batch", type=int, default=64)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the extra figures (fp32 parity mode, hidden 32, attention) on rank 0")
+    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f32"],
+                    help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default), the same with the MetNet "
+                         "encoder's activations also STORED as bf16 (bf16a), or exact fp32 (parity mode)")
+    args = ap.parse_args(argv)
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch N > 1 as `python -m torch.distributed.run --nnodes=1 "
+                         f"--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (tools/run_scale.sh)")
+    if args.scaling == "strong":
+        if args.global_batch % world:
+            raise SystemExit(f"--scaling strong: global batch {args.global_batch} is not divisible by {world} ranks")
+        batch = args.global_batch // world
+    else:
+        batch = args.batch if args.batch is not None else 8
+    stub = args.workload == "stub"
+    import satflow_amd
+
+    satflow_amd.set_compute_dtype(args.dtype)
+    if stub:
+        dev, sync, backend = torch.device("cpu"), (lambda: None), "gloo"
+    else:
+        torch.cuda.set_device(local_rank)
+        dev, sync, backend = torch.device("cuda", local_rank), torch.cuda.synchronize, "nccl"
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend, **({} if stub else {"device_id": dev}))
+
+    wl = build_workload(args.workload, dev, batch, rank)
+    elapsed, final_loss = timed_steps(wl, args.steps, args.warmup, world, dev, sync)
+
+    out = None
     if rank == 0:
         samples = args.steps * wl.B * world
         out = {
-            "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else "samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6",
+            "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else
+                      ("samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6" if args.workload == "convlstm" else "stub"),
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16",
             "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
             "config": wl.config(world), "final_loss": final_loss,
@@ -308,14 +437,48 @@ def main():
                      "(backward-only data) stored as bf16; parameters, cell states, the ConvGRU state, state gradients, attention, loss and optimizer state fp32",
         }[args.dtype]
         out["config"]["mode"] = args.dtype
+        out["config"]["parity"] = ("ConvLSTM path pinned to reference-generated goldens; MetNet arithmetic checked against oracle/metnet.py, which is "
+                                   "UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this mode at this size: "
+                                   "profiles/r02_parity_observed.jsonl")
         out["roofline"] = wl.roofline()
-        if not args.no_cpu_baseline and world == 1:
+    if world > 1 or rank == 0:
+        comm = comm_report(wl, world, dev)  # collective: every rank takes part
+        if rank == 0:
+            out["comm"] = comm
+    if rank == 0:
+        if not args.no_cpu_baseline and world == 1 and not stub:
             out["cpu_baseline"] = wl.cpu_baseline()
             out["cpu_baseline"]["gpu_speedup"] = out["value"] / out["cpu_baseline"]["value"]
-        print(json.dumps(out))
+        if not args.no_extra and world == 1 and args.workload == "metnet":
+            out["extra"] = extra_figures(wl, dev, args, batch)
+        print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    return out
+
+
+def extra_figures(wl, dev, args, batch: int) -> dict:
+    """Same JSON line, more of SURVEY 8d: the fp32 parity mode's throughput, the shipped yaml's hidden_dim=32 (metnet.yaml:6) and
+    the axial-attention MFMA figure.  Measured after the timed region, on rank 0 of a 1-GPU run only."""
+    import satflow_amd
+
+    ex = {"axial_attention": wl.attention_mfma()}
+    sync = torch.cuda.synchronize
+    w32 = MetNetWorkload(dev, batch, 0, hidden=32)
+    el, _ = timed_steps(w32, 4, 1, 1, dev, sync)
+    ex[f"hidden32_{args.dtype}_samples_per_s"] = 4 * batch / el
+    del w32
+    if args.dtype != "f32":
+        satflow_amd.set_compute_dtype("f32")
+        try:
+            wf = MetNetWorkload(dev, batch, 0)
+            el, _ = timed_steps(wf, 3, 1, 1, dev, sync)
+            ex["f32_parity_samples_per_s"], ex["f32_parity_ms_per_step"] = 3 * batch / el, el / 3 * 1e3
+            del wf
+        finally:
+            satflow_amd.set_compute_dtype(args.dtype)
+    return ex
 
 
 if __name__ == "__main__":

@@ -205,3 +205,44 @@ def test_flat_adam_is_a_torch_optimizer_with_state():
     opt2.load_state_dict(sd)
     assert opt2.t == 7 and opt2.lr == opt.lr and torch.equal(opt2.flat_m, opt.flat_m) and torch.equal(opt2.flat_v, opt.flat_v)
     del sched
+
+
+def _worker_bench(rank, world, port, out):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), LOCAL_RANK=str(rank), WORLD_SIZE=str(world))
+    import bench
+
+    res = bench.main(["--gpus", str(world), "--steps", "3", "--warmup", "1", "--workload", "stub", "--scaling", "strong", "--global-batch", "64"])
+    out[rank] = None if res is None else {k: res[k] for k in ("n_gpus", "steps", "warmup", "scaling", "unit", "higher_is_better")} | {
+        "per_gpu_batch": res["config"]["per_gpu_batch"], "global_batch": res["config"]["global_batch"], "nranks": res["comm"]["nranks"],
+        "ok": res["value"] > 0 and abs(res["value"] - 3 * 64 / (res["ms_per_step"] * 3e-3)) < 1e-6 * res["value"]}
+
+
+def test_bench_main_launch_plumbing_world2():
+    """bench.py's own main(): env-driven rank/world, process-group setup, warm-up + timed loop between barriers, MAX over ranks,
+    strong-scaling batch split, one JSON record from rank 0 - on gloo with the stub workload, so that the first real N-GPU
+    run cannot die on a flag."""
+    world, port = 2, _free_port()
+    ctx = mp.get_context("spawn")
+    with ctx.Manager() as mgr:
+        out = mgr.dict()
+        procs = [ctx.Process(target=_worker_bench, args=(r, world, port, out)) for r in range(world)]
+        for p in procs:
+            p.start()
+        for p in procs:
+            p.join(180)
+            assert p.exitcode == 0
+        res = dict(out)
+    assert res[1] is None  # only rank 0 reports
+    assert res[0] == {"n_gpus": 2, "steps": 3, "warmup": 1, "scaling": "strong", "unit": "samples/s", "higher_is_better": True,
+                      "per_gpu_batch": 32, "global_batch": 64, "nranks": 2, "ok": True}
+
+
+def test_bench_refuses_world_mismatch(monkeypatch):
+    import bench
+
+    monkeypatch.setenv("WORLD_SIZE", "4")
+    with pytest.raises(SystemExit, match="WORLD_SIZE=4"):
+        bench.main(["--gpus", "8", "--workload", "stub"])
+    monkeypatch.setenv("WORLD_SIZE", "1")
+    with pytest.raises(SystemExit, match="torch.distributed.run"):
+        bench.main(["--gpus", "2", "--workload", "stub"])

@@ -1,0 +1,25 @@
+#!/bin/bash
+# After tools/refresh_profiles.sh (gpurun): copy the judged summaries from gpurun_out/ into profiles/ (tracked).
+set -u
+cd "$(dirname "$0")/.."
+R=${ROUND:-r02}
+for m in bf16a bf16 f32; do for w in metnet convlstm; do
+  d=gpurun_out/${R}_${w}_$m
+  [ -f $d/prof_kernel_stats.csv ] && cp $d/prof_kernel_stats.csv profiles/${R}_${w}_${m}_kernel_stats.csv
+  [ -s $d/bench.json ] && cp $d/bench.json profiles/${R}_${w}_${m}_bench.json
+done; done
+for m in bf16a bf16; do
+  d=gpurun_out/${R}_pmc_metnet_$m
+  for c in FETCH_SIZE WRITE_SIZE; do [ -f $d/pmc_${c}_counter_collection.csv ] && python - $d/pmc_${c}_counter_collection.csv profiles/${R}_metnet_${m}_pmc_$c.csv <<'PY'
+import csv, sys
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv3x3_bf16_kernel" in r["Kernel_Name"]]
+w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Size", "Workgroup_Size"])
+w.writeheader()
+for r in rows: w.writerow({k: r[k] for k in w.fieldnames})
+PY
+  done
+  [ -d $d ] && python tools/parse_pmc.py $d profiles/${R}_metnet_${m}_pmc_conv256.json "conv3x3_bf16_kernel<8, 4, 0, false, true>" > /dev/null
+done
+for f in metnet_bf16a_bench_full convlstm_bf16a_bench_full; do [ -s gpurun_out/${R}_$f.json ] && cp gpurun_out/${R}_$f.json profiles/${R}_$f.json; done
+[ -s gpurun_out/r02_parity_observed.jsonl ] && cp gpurun_out/r02_parity_observed.jsonl profiles/r02_parity_observed.jsonl
+ls profiles | grep $R

@@ -15,5 +15,9 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
 res["read_bytes_corrected"] = res["FETCH_SIZE_KB_avg"] * 1024 * 2
 res["write_bytes"] = res["WRITE_SIZE_KB_avg"] * 1024
 res["traffic_bytes"] = res["read_bytes_corrected"] + res["write_bytes"]
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from bench import kernel_source_sha
+res["kernel_src_sha"] = kernel_source_sha()  # bench.py drops `traffic` when the kernel sources no longer hash to this
 json.dump(res, open(out, "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -1,11 +1,15 @@
+#!/bin/bash
+# ONE gpurun call: kernel-trace stats of every (workload, mode), PMC traffic passes of the dominant kernel, one full bench line.
+# Results under gpurun_out/r02_*; tools/collect_profiles.sh copies the summaries into profiles/.
 set -u
 cd $GRAFT_REPO_ROOT
-for m in bf16a bf16; do
-  bash tools/prof_stats.sh r01_metnet_$m --dtype $m > /dev/null 2>&1
-  bash tools/prof_stats.sh r01_convlstm_$m --workload convlstm --dtype $m > /dev/null 2>&1
+R=${ROUND:-r02}
+for m in bf16a bf16 f32; do
+  bash tools/prof_stats.sh ${R}_metnet_$m --dtype $m --no-cpu-baseline --no-extra > /dev/null 2>&1
+  bash tools/prof_stats.sh ${R}_convlstm_$m --workload convlstm --dtype $m --no-cpu-baseline > /dev/null 2>&1
 done
-bash tools/prof_stats.sh r01_metnet_f32 --dtype f32 > /dev/null 2>&1
-bash tools/prof_stats.sh r01_convlstm_f32 --workload convlstm --dtype f32 > /dev/null 2>&1
-for m in bf16a bf16; do bash tools/prof_pmc.sh pmc_metnet_$m $m > /dev/null 2>&1; done
-for m in bf16a bf16 f32; do for w in metnet convlstm; do cut -c1-260 gpurun_out/r01_${w}_$m/bench.json; done; done
-ls gpurun_out/pmc_metnet_bf16a
+for m in bf16a bf16; do bash tools/prof_pmc.sh ${R}_pmc_metnet_$m $m > /dev/null 2>&1; done
+python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_metnet_bf16a_bench_full.json 2> gpurun_out/${R}_metnet_bf16a_bench_full.err
+python bench.py --workload convlstm --steps 20 --warmup 5 > gpurun_out/${R}_convlstm_bf16a_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
+for m in bf16a bf16 f32; do for w in metnet convlstm; do cut -c1-200 gpurun_out/${R}_${w}_$m/bench.json; done; done
+cut -c1-300 gpurun_out/${R}_metnet_bf16a_bench_full.json

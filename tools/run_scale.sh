@@ -1,0 +1,33 @@
+#!/bin/bash
+# Scaling curve of bench.py on ONE node: N in {1,2,4,8} ranks (one per GPU, RCCL over xGMI), weak (8 samples/GPU, the default)
+# and strong (BASELINE cfg 4: global batch 64 split over the ranks).  One JSON line per run under $OUT (default gpurun_out/scale).
+#   tools/run_scale.sh [steps] [warmup]        e.g. tools/run_scale.sh 20 5
+# Rendezvous on 127.0.0.1 (the container hostname may not resolve); HSA_ENABLE_IPC_MODE_LEGACY=0 is required for RCCL's dmabuf IPC.
+set -u
+cd "$(dirname "$0")/.."
+STEPS=${1:-20}; WARM=${2:-5}
+OUT=${OUT:-gpurun_out/scale}; mkdir -p "$OUT"
+export HSA_ENABLE_IPC_MODE_LEGACY=0
+NGPU=$(python -c 'import torch; print(torch.cuda.device_count())')
+PORT=29500
+for MODE in weak strong; do
+  for N in 1 2 4 8; do
+    [ "$N" -gt "$NGPU" ] && continue
+    PORT=$((PORT + 1))
+    ARGS="--gpus $N --steps $STEPS --warmup $WARM --scaling $MODE --no-cpu-baseline --no-extra"
+    if [ "$N" -eq 1 ]; then
+      python bench.py $ARGS > "$OUT/${MODE}_n$N.json" 2> "$OUT/${MODE}_n$N.err"
+    else
+      python -m torch.distributed.run --nnodes=1 --nproc-per-node "$N" --master-addr 127.0.0.1 --master-port "$PORT" bench.py $ARGS \
+        > "$OUT/${MODE}_n$N.json" 2> "$OUT/${MODE}_n$N.err"
+    fi
+    python - "$OUT/${MODE}_n$N.json" <<'PY'
+import json, sys
+try:
+    d = json.loads([l for l in open(sys.argv[1]) if l.startswith("{")][-1])
+    print(f"{d['scaling']:6s} N={d['n_gpus']} batch/GPU={d['config']['per_gpu_batch']:3d}  {d['value']:9.1f} samples/s  {d['ms_per_step']:8.2f} ms/step  comm={d.get('comm')}")
+except Exception as e:  # noqa: BLE001
+    print("FAILED", sys.argv[1], e)
+PY
+  done
+done
