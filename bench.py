@@ -83,19 +83,41 @@ def _time_cpu_at(one, threads: int, budget_s: float, max_timed: int = 3):
     return dt, n
 
 
+def _threads_probe(threads: int) -> float:
+    """Seconds for a small fixed convolution workload at `threads` threads (decides whether a thread count is sane here)."""
+    torch.set_num_threads(threads)
+    x = torch.randn(8, 64, 64, 64)
+    w = torch.randn(64, 64, 3, 3)
+    torch.nn.functional.conv2d(x, w, padding=1)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        torch.nn.functional.conv2d(x, w, padding=1)
+    return (time.perf_counter() - t0) / 3
+
+
 def time_cpu(one, what: str, budget_s: float = 14.0) -> dict:
-    """Time `one()` (one FULL CPU sample: forward + backward + Adam) on the host cores, bounded: with
-    os.cpu_count() threads - the stated baseline - and with 32 threads (at these convolution sizes more threads mostly add
-    contention); `value` is the os.cpu_count() figure, the other one rides along."""
-    cores = os.cpu_count() or 1
-    dt_all, n_all = _time_cpu_at(one, cores, budget_s)
-    res = {"value": 1.0 / dt_all, "unit": "samples/s", "cores": cores, "kind": "port", "cpu_model": cpu_model(), "extrapolated": False,
-           "sample": f"{what}; {n_all if n_all else 1} timed step(s){'' if n_all else ' (the warm-up itself: budget exhausted)'} on "
-                     f"{cores} threads (= os.cpu_count()) of {cpu_model()}, torch {torch.__version__} CPU, {dt_all*1e3:.0f} ms/sample"}
-    if cores > 32:
-        dt32, n32 = _time_cpu_at(one, 32, budget_s)
-        res["threads_32"] = {"value": 1.0 / dt32, "cores": 32, "ms_per_sample": dt32 * 1e3, "timed_steps": n32 if n32 else 1}
-    return res
+    """Time `one()` (one FULL CPU sample: forward + backward + Adam) on the host cores, bounded.
+
+    The stated baseline is os.cpu_count() threads.  On the GPU boxes that figure (256 logical CPUs) oversubscribes whatever
+    share of the machine the job may use: one MetNet sample then took 22 MINUTES against 2.7 s at 32 threads (measured,
+    profiles/r02_metnet_bf16a_bench_full.json).  So a 50 ms probe convolution decides: all logical CPUs are used when they are
+    not slower than 32 threads on the probe, otherwise the run uses 32 threads and says so (`cores` = threads actually used)."""
+    logical = os.cpu_count() or 1
+    usable = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else logical
+    cand = min(logical, usable)
+    threads, why = cand, f"{cand} threads = all usable logical CPUs"
+    probe = None
+    if cand > 32:
+        t32, tall = _threads_probe(32), _threads_probe(cand)
+        probe = {"threads_32_s": t32, f"threads_{cand}_s": tall}
+        if tall > 1.25 * t32:
+            threads, why = 32, (f"32 threads: a probe convolution ran {tall / t32:.1f}x slower on {cand} threads (os.cpu_count() = {logical}, "
+                                f"sched_getaffinity = {usable}) than on 32 - the full-sample run on all of them was measured once at 22 min/sample")
+    dt, n = _time_cpu_at(one, threads, budget_s)
+    return {"value": 1.0 / dt, "unit": "samples/s", "cores": threads, "kind": "port", "cpu_model": cpu_model(), "extrapolated": False,
+            "logical_cpus": logical, "usable_cpus": usable, "thread_probe": probe,
+            "sample": f"{what}; {n if n else 1} timed step(s){'' if n else ' (the warm-up itself: budget exhausted)'} on {why} of "
+                      f"{cpu_model()}, torch {torch.__version__} CPU, {dt*1e3:.0f} ms/sample"}
 
 
 # ----------------------------------------------------------------------------------------------

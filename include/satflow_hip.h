@@ -268,6 +268,18 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
 int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int32_t w,
                         const void* wpacked, const float* bias_packed, int32_t hidp, sfTensor h_out,
                         sfTensor gates, int32_t dtype, sfStream stream);
+/* The recurrent half of ALL T steps in one launch, hidden state resident on chip (north star: "hidden-state residency across
+ * timesteps"; replaces T calls of sf_convgru_step_fwd, i.e. the loop of upstream ConvGRU.forward behind pl_metnet.py:46-59).
+ * One workgroup owns one map for the whole sequence: fp32 state in registers, its bf16 image (the next step's MFMA operand) in
+ * LDS, recurrent weights streamed from L2 by LDS-DMA.  Maps of at most 16x16 pixels, hidp <= 64, SF_BF16 kernels only.
+ *   gx    : [T][n][h][w][3*hidp] x-part of every step (SF_F32, or SF_BF16: then it is prefetched a K loop ahead)
+ *   h0    : initial state [n][h][w][hidp] fp32 (ptr NULL = zeros)
+ *   hs    : every state h_t, [T][n][h][w][hidp] fp32 (with fp32 gx bit-identical to the per-step calls)
+ *   gates : nullable, [T][n][h][w][4*hidp] = [z | r | n | h2] per step (SF_F32 or SF_BF16) for the backward pass
+ *   wpacked / bias_packed: as for sf_convgru_step_fwd (GRU map, nf == 3). */
+int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h, int32_t w, const void* wpacked,
+                       const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, int32_t dtype,
+                       sfStream stream);
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
  * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
  * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */

@@ -27,6 +27,20 @@ typedef float f32x8 __attribute__((ext_vector_type(8)));
 constexpr int HALO_W = TILE_W + 2;  // 18
 constexpr int PIX_B = 32;           // bytes per pixel / per weight row in LDS (16 bf16)
 
+// LDS-DMA through a buffer descriptor, issued from inline asm: wave-uniform descriptor + scalar byte offset (chunk / tile
+// position) + a per-lane byte offset that is CONSTANT for the whole kernel (an out-of-image piece carries an out-of-range offset:
+// the hardware range check then writes zeros to its LDS slot, tools/ubench/buf_lds_oob.hip).  Hidden from hipcc on purpose: it
+// would otherwise put `s_waitcnt vmcnt(0)` in front of LDS reads that might alias a pending DMA (seen at mid-chunk in this
+// kernel) - the chunk loop waits for its DMA itself, once, at the top of the next chunk.  M0 (the LDS destination) is saved and
+// restored: other code of the same kernel may use compiler-issued LDS-DMA.
+constexpr unsigned DMA_SENT = 0x80000000u;  // >= any descriptor's num_records (the launcher checks tensor bytes < 2^31)
+__device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
+  unsigned keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);  // wave-uniform by construction; keeps it in an SGPR where hipcc cannot prove that
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %3\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, %4 offen lds\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
+}
+
 // DUAL (8 waves, images of at most 16x16 pixels): the 32x16 tile is TWO consecutive images, waves 0-3 on the first and
 // 4-7 on the second, each image with its own halo rows in LDS (2 x 18 rows) - small images keep the 8-wave workgroup's
 // weight reuse and occupancy instead of dropping to the 4-wave 16x16 kernel.
@@ -89,13 +103,40 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   f32x8 inreg[NPIECE];
   int staged_bf = 0;  // storage type of the chunk held in inreg (block-uniform)
 
+  // ---- bf16-stored sources, single-image tiles: everything about a halo piece except the chunk's channel offset is a block
+  // constant - source image (the remap division happens ONCE here, not per piece and chunk), per-lane byte offset and validity.
+  // Descriptor = the source image, started one image row + one pixel early so that the halo origin has a non-negative offset.
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000), rs_in1 = rs_in0, rs_w = rs_in0;
+  unsigned in_off0[NPIECE], in_off1[NPIECE];
+  unsigned so_in0 = 0, so_in1 = 0;
+  if constexpr (!DUAL) {
+    auto desc = [&](const float* src, int stride, int idiv, int imod, unsigned& so) {
+      int ns = n / idiv; if (imod) ns %= imod;
+      const long long pxb = 2ll * stride, lead = (long long)(p.W + 1) * pxb, img = (long long)p.H * p.W * pxb;
+      so = (unsigned)((y0 * p.W + x0) * (int)pxb);
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(src ? (const char*)src + ns * img - lead : nullptr), 0, src ? (int)(img + 2 * lead) : 0, 0x00020000);
+    };
+    rs_in0 = desc(p.bf0 ? p.src0 : nullptr, p.s0, p.idiv0, p.imod0, so_in0);
+    rs_in1 = desc(p.bf1 ? p.src1 : nullptr, p.s1, p.idiv1, p.imod1, so_in1);
+#pragma unroll
+    for (int j = 0; j < NPIECE; ++j) {
+      const int pc = tid + j * THREADS, pix = pc >> 1;
+      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int gy = y0 + iy - 1, gx = x0 + ix - 1;
+      const bool ok = pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      const int half = (pc & 1) ^ (iy & 1);  // the DMA writes lane-linearly: physical half pc & 1 fetches the logical half (bank swizzle)
+      in_off0[j] = ok ? (unsigned)(((iy * p.W + ix) * p.s0 + 8 * half) * 2) : DMA_SENT;
+      in_off1[j] = ok ? (unsigned)(((iy * p.W + ix) * p.s1 + 8 * half) * 2) : DMA_SENT;
+    }
+  }
+  // weights: descriptor over this N block's packed image; the chunk and the 1 KiB piece go into the scalar offset
+  rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wp + (size_t)nb * p.chunks_total * W_B), 0, p.chunks_total * W_B, 0x00020000);
+
   auto issue_weights = [&](int ci, int buf) {
     const int chunk = ci < ch0 ? ci : c0_chunks + (ci - ch0);
-    const char* src = (const char*)p.wp + ((size_t)nb * p.chunks_total + chunk) * W_B + lane * 16;
-    char* dst = lds_w + buf * W_B;
-    for (int i = wave; i < 9 * NF; i += WAVES)
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + i * 1024),
-                                       (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+    const unsigned dst = lds0 + buf * W_B;
+    for (int i = wave; i < 9 * NF; i += WAVES) bufdma16(lane * 16, rs_w, (unsigned)(chunk * W_B + i * 1024), dst + i * 1024);
   };
   auto load_input = [&](int ci) {  // fp32-stored source: registers now, bf16 conversion + ds_write after the chunk's MFMAs
     const float* src; int cbase, stride, idiv, imod;
@@ -131,6 +172,22 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   // the bank swizzle of the register path).  Halo pixels outside the image are never written by the DMA (lanes
   // masked off): their slots are zeroed once per block, below.
   auto dma_input = [&](int ci, int buf) {
+    if constexpr (!DUAL) {
+      const unsigned dst = lds0 + (unsigned)(2 * W_B + buf * IN_B + wave * 1024);
+      // (a uniform branch per source rather than selects: the descriptor must stay in SGPRs)
+      if (ci < ch0) {
+        const unsigned so = so_in0 + (unsigned)(ci * KC * 2);
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j)
+          if (tid + j * THREADS < PIECES) bufdma16(in_off0[j], rs_in0, so, dst + j * WAVES * 1024);  // lanes past the tile are masked off: a zero-filling lane there would write into the other buffer
+      } else {
+        const unsigned so = so_in1 + (unsigned)((ci - ch0) * KC * 2);
+#pragma unroll
+        for (int j = 0; j < NPIECE; ++j)
+          if (tid + j * THREADS < PIECES) bufdma16(in_off1[j], rs_in1, so, dst + j * WAVES * 1024);
+      }
+      return;
+    }
     const float* src; int cbase, stride, idiv, imod;
     if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; idiv = p.idiv0; imod = p.imod0; }
     else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; idiv = p.idiv1; imod = p.imod1; }
@@ -152,7 +209,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     if (staged_bf) dma_input(ci, ci & 1);
     else load_input(ci);
   };
-  if (p.bf0 || p.bf1) {  // zero the out-of-image halo slots of both buffers (the same slots for every chunk of this block)
+  if (DUAL && (p.bf0 || p.bf1)) {  // compiler-issued DMA path (lanes masked off): zero the out-of-image halo slots of both buffers once
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;

@@ -131,9 +131,9 @@ __device__ __forceinline__ void conv_epilogue(f32x16 (&acc)[2][NF], const ConvPa
           const float z = sf_sigmoid(acc[mf][0][reg] + gz[reg]);
           const float rg = sf_sigmoid(acc[mf][1][reg] + gr[reg]);
           const float h2 = acc[mf][2][reg] + b2;
-          const float cand = sf_tanh(gn[reg] + rg * h2);
+          const float cand = sf_tanh(sf_gru_cand_arg(gn[reg], rg, h2));
           if (ok[reg]) {
-            p.h_out[pix[reg] * p.hout_s + hc] = (1.f - z) * cand + z * hp[reg];
+            p.h_out[pix[reg] * p.hout_s + hc] = sf_gru_blend(z, cand, hp[reg]);
             if (p.gates) {
               if (p.gates_bf) {
                 __bf16* gp = reinterpret_cast<__bf16*>(p.gates) + pix[reg] * p.gates_s + hc;

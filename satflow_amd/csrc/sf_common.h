@@ -44,6 +44,13 @@ __device__ __forceinline__ float sf_tanh(float v) {
   return copysignf((1.0f - t) * __builtin_amdgcn_rcpf(1.0f + t), v);
 }
 
+// ConvGRU blend and candidate pre-activation with EXPLICIT fused multiply-adds: the per-step kernel (conv_common.h) and the
+// persistent sequence kernel (convgru_seq.hip) must round identically - left to hipcc's contraction the two epilogues differed by
+// one fp32 ulp here and there, which flips a bf16 rounding of the next step's MFMA operand now and then (3.7e-4 on the states).
+//   h' = (1 - z) * n + z * h  ==  n + z * (h - n)
+__device__ __forceinline__ float sf_gru_blend(float z, float cand, float hp) { return __builtin_fmaf(z, hp - cand, cand); }
+__device__ __forceinline__ float sf_gru_cand_arg(float gn, float rg, float h2) { return __builtin_fmaf(rg, h2, gn); }
+
 // ---- storage-typed 4-channel access (fp32 or bf16 activations) ---------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));
 template <typename T> __device__ __forceinline__ f32x4 ldv4(const T* p);

@@ -6,6 +6,7 @@ arithmetic happens in PyTorch on the hot path except where a comment says so.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -471,16 +472,22 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         hidp, dev = eng.hidp, x.device
         pk = eng.packed(Wx, bx, Wh, bh, src_key)
         keep = any(ctx.needs_input_grad)
-        gx = torch.empty(N, H, W, 3 * hidp, dtype=torch.float32, device=dev)
+        from ._hip import gate_storage_dtype
+        persistent = K.convgru_seq_supported(H, W, hidp) and not os.environ.get("SF_GRU_PER_STEP")
+        # the x-part of all steps in one convolution; with the persistent kernel in "bf16a" mode it is stored as bf16 (what
+        # autocast leaves behind conv_zr / conv_h1) and prefetched by the sequence kernel a whole K loop ahead
+        gx = torch.empty(N, H, W, 3 * hidp, dtype=gate_storage_dtype() if persistent else torch.float32, device=dev)
         K.conv3x3(T(x), NULL, N, H, W, pk["x_fwd"][0], pk["x_fwd"][1], eng.x_fwd, T(gx))
         hs = torch.empty(Tn, n, H, W, hidp, dtype=torch.float32, device=dev)
         # saved gates: backward-only data, bf16 in "bf16a" mode (as the ConvLSTM's)
-        from ._hip import gate_storage_dtype
         gates = torch.empty(Tn, n, H, W, 4 * hidp, dtype=gate_storage_dtype(), device=dev) if keep else None
-        gxs = gx.view(Tn, n, H, W, 3 * hidp)
-        for t in range(Tn):
-            K.convgru_step_fwd(T(gxs[t]), hs[t - 1] if t else None, n, H, W, pk["h_fwd"][0], pk["h_fwd"][1], hidp, hs[t],
-                               gates[t] if keep else None)
+        if persistent:  # all steps in ONE launch, state resident on chip
+            K.convgru_seq_fwd(gx, None, Tn, n, H, W, pk["h_fwd"][0], pk["h_fwd"][1], hidp, hs, gates)
+        else:
+            gxs = gx.view(Tn, n, H, W, 3 * hidp)
+            for t in range(Tn):
+                K.convgru_step_fwd(T(gxs[t]), hs[t - 1] if t else None, n, H, W, pk["h_fwd"][0], pk["h_fwd"][1], hidp, hs[t],
+                                   gates[t] if keep else None)
         ctx.eng, ctx.Tn = eng, Tn
         ctx.pk = pk  # the packed images this forward used (the engine's cache may be rebuilt before the backward runs)
         ctx.set_materialize_grads(False)

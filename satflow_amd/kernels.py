@@ -317,6 +317,18 @@ def convgru_step_fwd(gx: sfTensor, h_prev: Optional[Tensor], n: int, h: int, w: 
                                     hidp, T(h_out), T(gates) if gates is not None else NULL, _hip.compute_dtype(), stream_ptr()), "sf_convgru_step_fwd")
 
 
+def convgru_seq_supported(h: int, w: int, hidp: int) -> bool:
+    """The persistent sequence kernel: SF_BF16 kernels, maps of at most 16x16 pixels (one workgroup per map), hidp <= 64."""
+    return _hip.compute_dtype() == _hip.SF_BF16 and h <= 16 and w <= 16 and 16 <= hidp <= 64
+
+
+def convgru_seq_fwd(gx: Tensor, h0: Optional[Tensor], Tn: int, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor], hidp: int,
+                    hs: Tensor, gates: Optional[Tensor]) -> None:
+    """All Tn recurrent steps in one launch (sf_convgru_seq_fwd): gx ``[Tn*n,h,w,3*hidp]``, hs ``[Tn,n,h,w,hidp]``."""
+    check(lib().sf_convgru_seq_fwd(T(gx), T(h0, hidp), Tn, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
+                                   hidp, T(hs), T(gates) if gates is not None else NULL, _hip.compute_dtype(), stream_ptr()), "sf_convgru_seq_fwd")
+
+
 def convgru_bwd_gates(dh: Sequence[sfTensor], gates: Tensor, h_prev: Optional[Tensor], hidp: int, dgx: Tensor, dgh: Tensor,
                       dh_direct: Optional[Tensor]) -> None:
     dh = list(dh) + [NULL] * (3 - len(dh))

@@ -317,8 +317,8 @@ def test_convlstm_cell_bf16_states(device, bf16a_mode, cin, hid, n, h, w):
 
 @pytest.mark.parametrize("B,T,cin,hid,h,w,layers", [(2, 3, 16, 16, 4, 4, 1), (1, 4, 40, 24, 5, 7, 2), (3, 5, 256, 64, 16, 16, 1)])
 def test_convgru_bf16a_vs_bf16(device, B, T, cin, hid, h, w, layers):
-    """ConvGRU sequence with bf16-STORED saved gates and gate gradients ("bf16a") against fp32-stored ones ("bf16"): the forward
-    pass never reads them, so the states are bit-identical; the gradients differ by the rounding of the saved gates (the
+    """ConvGRU sequence with bf16-STORED x-part pre-activations, saved gates and gate gradients ("bf16a") against fp32-stored ones
+    ("bf16"): states within the bf16 rounding of the x-part; the gradients differ by the rounding of the saved gates (the
     rounding of dgx / dgh themselves is what their consumers' MFMA operands do anyway)."""
     from satflow_amd import functional as F
     from satflow_amd.models.metnet import ConvGRU
@@ -349,8 +349,11 @@ def test_convgru_bf16a_vs_bf16(device, B, T, cin, hid, h, w, layers):
             res[mode] = (seq_nchw.detach().clone(), {"dx": xd.grad.clone(), **{k: p.grad.clone() for k, p in rnn.named_parameters()}})
     finally:
         satflow_amd.set_compute_dtype("f32")
-    assert torch.equal(res["bf16"][0], res["bf16a"][0]), "forward must not depend on the gate storage type"
     rel = lambda a, b: float((a - b).norm() / (b.norm() + 1e-30))
+    # the forward pass never reads the saved gates; with the persistent sequence kernel "bf16a" also stores the x-part of the
+    # pre-activations as bf16 (what autocast leaves behind conv_zr / conv_h1), so the states agree to bf16 rounding of those
+    fwd = rel(res["bf16a"][0], res["bf16"][0])
+    assert fwd < 5e-3, fwd
     worst = max(rel(res["bf16a"][1][k], res["bf16"][1][k]) for k in res["bf16"][1])
-    print(f"bf16a ConvGRU: worst gradient rel L2 vs fp32-stored gates {worst:.2e}")
+    print(f"bf16a ConvGRU: states rel L2 vs fp32-stored x-part {fwd:.2e}; worst gradient rel L2 vs fp32-stored gates {worst:.2e}")
     assert worst < 1e-2

@@ -1,0 +1,90 @@
+"""GPU: the persistent ConvGRU sequence kernel (sf_convgru_seq_fwd: all timesteps in one launch, hidden state resident in
+registers / LDS) against the per-step kernel it replaces (sf_convgru_step_fwd, itself checked against the oracle in
+tests/test_metnet_gpu.py / test_bf16_gpu.py).  Same K order, same bf16 rounding of the state, same epilogue formulas: the
+states and the saved gates must agree BIT FOR BIT, for fp32-stored and (widened) bf16-stored x-parts, with and without an
+initial state, on full 16x16 maps and on ragged ones."""
+import pytest
+import torch
+
+import satflow_amd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16_mode():
+    satflow_amd.set_compute_dtype("bf16")
+    yield
+    satflow_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("Tn,n,H,W,hid", [(5, 3, 16, 16, 64), (4, 2, 16, 16, 32), (3, 2, 12, 10, 24), (3, 1, 5, 7, 16), (24, 4, 16, 16, 64), (1, 1, 16, 16, 64)])
+@pytest.mark.parametrize("gx_dtype", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("with_h0", [False, True])
+def test_persistent_sequence_matches_per_step_kernel(device, bf16_mode, Tn, n, H, W, hid, gx_dtype, with_h0):
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad
+    from satflow_amd.functional import GRUEngine
+
+    g = torch.Generator().manual_seed(Tn * 1000 + H * 10 + hid)
+    hidp = cpad(hid)
+    eng = GRUEngine(16, hid)
+    Wh = (torch.randn(3 * hid, hid, 3, 3, generator=g) * (0.6 / hid**0.5)).to(device)
+    bh = torch.cat((torch.zeros(2 * hid), torch.randn(hid, generator=g) * 0.3)).to(device)
+    packed, bp = K.pack_weights(Wh, bh, eng.h_fwd, False)
+    gx = torch.randn(Tn * n, H, W, 3 * hidp, generator=g).to(device).to(gx_dtype)
+    h0 = (torch.randn(n, H, W, hidp, generator=g) * 0.5).to(device) if with_h0 else None
+    if h0 is not None:
+        h0[..., hid:] = 0
+    assert K.convgru_seq_supported(H, W, hidp)
+    for gates_dtype in (torch.float32, torch.bfloat16):
+        hs = torch.full((Tn, n, H, W, hidp), float("nan"), device=device)
+        gates = torch.full((Tn, n, H, W, 4 * hidp), float("nan"), device=device).to(gates_dtype)
+        K.convgru_seq_fwd(gx, h0, Tn, n, H, W, packed, bp, hidp, hs, gates)
+        # reference: one launch per step on the fp32 widening of the same x-part
+        gxf = gx.float().view(Tn, n, H, W, 3 * hidp)
+        hs_ref = torch.zeros(Tn, n, H, W, hidp, device=device)
+        gates_ref = torch.zeros(Tn, n, H, W, 4 * hidp, device=device).to(gates_dtype)
+        for t in range(Tn):
+            K.convgru_step_fwd(T(gxf[t]), hs_ref[t - 1] if t else h0, n, H, W, packed, bp, hidp, hs_ref[t], gates_ref[t])
+        torch.cuda.synchronize()
+        assert torch.equal(hs[..., :hid], hs_ref[..., :hid]), f"states differ: max {float((hs[..., :hid] - hs_ref[..., :hid]).abs().max()):.3e}"
+        gsel = torch.cat([torch.arange(q * hidp, q * hidp + hid) for q in range(4)]).to(device)
+        assert torch.equal(gates[..., gsel].float(), gates_ref[..., gsel].float()), "saved gates differ"
+        assert float(hs[..., :hid].abs().max()) > 0.05 and torch.isfinite(hs[..., :hid]).all()
+    # without a gates tensor (inference): same states
+    hs2 = torch.empty_like(hs)
+    K.convgru_seq_fwd(gx, h0, Tn, n, H, W, packed, bp, hidp, hs2, None)
+    assert torch.equal(hs2[..., :hid], hs_ref[..., :hid])
+
+
+def test_convgru_module_uses_persistent_kernel_and_matches_per_step(device, monkeypatch):
+    """ConvGRU.run in the bf16 modes: persistent forward == per-step forward (SF_GRU_PER_STEP=1), states and all gradients
+    (the backward pass consumes the same saved tensors either way; in "bf16" mode the x-part is fp32 on both paths)."""
+    from satflow_amd import functional as F
+    from satflow_amd.models.metnet import ConvGRU
+
+    B, T, cin, hid, h, w = 3, 6, 32, 64, 16, 16
+    torch.manual_seed(1)
+    rnn = ConvGRU(cin, hid, (3, 3), 1).to(device).eval()
+    x = torch.randn(B, T, cin, h, w, generator=torch.Generator().manual_seed(2)).to(device)
+    cot = torch.randn(B, hid, h, w, generator=torch.Generator().manual_seed(3)).to(device)
+    res = {}
+    satflow_amd.set_compute_dtype("bf16")
+    try:
+        for mode in ("persistent", "per_step"):
+            if mode == "per_step":
+                monkeypatch.setenv("SF_GRU_PER_STEP", "1")
+            rnn.zero_grad()
+            xd = x.clone().requires_grad_()
+            xs = F._ToNHWC.apply(xd, B, T, cin, h, w, (T * cin * h * w, cin * h * w, h * w))
+            seq, last = rnn.run(xs, T, B)
+            out = F.nhwc_to_nchw(last[-1], hid)
+            (out * cot).sum().backward()
+            res[mode] = (out.detach().clone(), xd.grad.clone(), {k: p.grad.clone() for k, p in rnn.named_parameters()})
+    finally:
+        satflow_amd.set_compute_dtype("f32")
+    assert torch.equal(res["persistent"][0], res["per_step"][0])
+    assert torch.equal(res["persistent"][1], res["per_step"][1])
+    for k in res["per_step"][2]:
+        assert torch.equal(res["persistent"][2][k], res["per_step"][2][k]), k
