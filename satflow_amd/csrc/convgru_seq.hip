@@ -163,7 +163,11 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
       const int it = t * chunks + ci, cur = it & 1;
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weights have landed (and this step's x-part, last step's stores)
       __syncthreads();                                   // ... everybody's; the previous step's state tile writes are visible
-      if (it + 1 < p.T * chunks) issue_weights(ci + 1 < chunks ? ci + 1 : 0, cur ^ 1);
+      // the two waves of a SIMD (w, w + 4) issue the next chunk's DMA at different taps: one's MFMAs cover the other's issue stall
+      const bool stage_late = NBLK == 2 && wave >= 4;
+      const bool more = it + 1 < p.T * chunks;
+      const int nci = ci + 1 < chunks ? ci + 1 : 0;
+      if (more && !stage_late) issue_weights(nci, cur ^ 1);
       const char* inb = lds_h + ci * CHUNK_B + a_lane;
       const char* wb = lds + cur * STAGE_B + b_lane;
       auto load_tap = [&](int tap, bf16x8 (&a)[2], bf16x8 (&b)[3]) {
@@ -184,6 +188,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 #pragma unroll
           for (int g = 0; g < 3; ++g)  // transposed product: D[channel][pixel] - a lane owns one pixel and channel quads
             acc[mf][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][g], fa[tap & 1][mf], acc[mf][g], 0, 0, 0);
+        if (tap == 3 && more && stage_late) issue_weights(nci, cur ^ 1);
       }
     }
     __syncthreads();  // every wave is done reading the state tile of step t - 1
