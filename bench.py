@@ -156,8 +156,10 @@ class ConvLSTMWorkload:
 
     def roofline(self):
         """Dominant kernel: the fused 128->256 ConvLSTM cell step (3 of the 4 cells, 24 of 36 launches)."""
+        return self._cell_roofline(self.model.model.encoder_2_convlstm.engine)
+
+    def _cell_roofline(self, eng):
         from satflow_amd._hip import T
-        eng = self.model.model.encoder_2_convlstm.engine
         B, H, W, hid = self.B, self.H, self.W, self.hid
         import satflow_amd
         from satflow_amd._hip import gate_storage_dtype, state_storage_dtype
@@ -173,7 +175,7 @@ class ConvLSTMWorkload:
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": None,
-                "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, 128->256 ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", B),
+                "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, %d->%d ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", 2 * hid, 4 * hid, B),
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
                 "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16); bf16-stored x / h / gates: intensity 922 F/B vs ridge "
@@ -312,6 +314,85 @@ class MetNetWorkload:
                         "(19 MFLOP per layer, SURVEY 8d)"}
 
 
+class CloudGANWorkload(ConvLSTMWorkload):
+    """CloudGAN with the ConvLSTM generator (configs/model/cloudgan_convlstm.yaml: 12 channels, 32 filters, PatchGAN
+    discriminator, vanilla GAN loss + lambda * L1), 128x128 tiles, T = 12 -> 6.  A step = the generator's optimizer step followed by
+    the discriminator's, each with the other network frozen as Lightning's toggle_optimizer does."""
+
+    name = "cloudgan"
+
+    def __init__(self, dev, batch: int, rank: int):
+        from satflow_amd.models import CloudGAN
+        from satflow_amd.optim import FlatAdam
+
+        self.B, self.T, self.C, self.H, self.W, self.hid, self.fs, self.out = batch, 12, 12, 128, 128, 32, 6, 12
+        torch.manual_seed(1234)
+        self.model = CloudGAN(forecast_steps=self.fs, input_channels=self.C, num_filters=self.hid, generator_model="convlstm", norm="batch",
+                              discriminator_model="basic", loss="vanilla", scheduler="cosine", lambda_l1=1, channels_per_timestep=self.C,
+                              condition_time=True).to(dev).train()
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.x = torch.rand(self.B, self.T, self.C, self.H, self.W, generator=g).to(dev)
+        self.y = torch.rand(self.B, self.fs, self.C, self.H, self.W, generator=g).to(dev)
+        ov = not os.environ.get("SF_NO_OVERLAP")
+        self.opt_g = FlatAdam(self.model.generator.parameters(), lr=self.model.lr, betas=(self.model.b1, self.model.b2), overlap=ov)
+        self.opt_d = FlatAdam(self.model.discriminator.parameters(), lr=self.model.lr, betas=(self.model.b1, self.model.b2), overlap=ov,
+                              buffers=list(self.model.discriminator.buffers()))
+        self.opt = self.opt_g
+        self.dev = dev
+
+    def _toggle(self, train_net, frozen_net):
+        for p in frozen_net.parameters():
+            p.requires_grad_(False)
+        for p in train_net.parameters():
+            p.requires_grad_(True)
+
+    def step(self):
+        m = self.model
+        self._toggle(m.generator, m.discriminator)
+        self.opt_g.zero_grad()
+        g_loss = m.training_step((self.x, self.y), 0, 0)["loss"]
+        g_loss.backward()
+        self.opt_g.step()
+        self._toggle(m.discriminator, m.generator)
+        self.opt_d.zero_grad()
+        d_loss = m.training_step((self.x, self.y), 0, 1)["loss"]
+        d_loss.backward()
+        self.opt_d.step()
+        return g_loss.detach() + d_loss.detach()
+
+    def config(self, world):
+        return {"workload": "CloudGAN: ConvLSTM generator (12 ch, 32 filters) + PatchGAN discriminator, 128x128, T=12 -> 6 "
+                            "(configs/model/cloudgan_convlstm.yaml; SURVEY 8f-2)",
+                "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
+                "step": "generator step (fwd, D(fake), BCE + lambda L1, bwd, adam) + discriminator step (fwd, D(real), D(fake), BCE, bwd, adam)"}
+
+    def roofline(self):
+        r = self._cell_roofline(self.model.generator.encoder_2_convlstm.engine)
+        return r
+
+    def cpu_baseline(self):
+        from oracle import cloudgan as OC  # checker/baseline only
+
+        gen = {k: v.detach().cpu().clone().requires_grad_() for k, v in self.model.generator.state_dict().items()}
+        disc = {k: v.detach().cpu().clone().requires_grad_() for k, v in self.model.discriminator.state_dict().items()
+                if v.dtype == torch.float32 and "running" not in k}
+        x, y = self.x[:1].cpu(), self.y[:1].cpu()
+        og = torch.optim.Adam(list(gen.values()), lr=self.model.lr, betas=(0.5, 0.999))
+        od = torch.optim.Adam(list(disc.values()), lr=self.model.lr, betas=(0.5, 0.999))
+
+        def one():
+            og.zero_grad()
+            OC.generator_step(x, y, gen, disc, self.fs, 1.0)[0].backward()
+            og.step()
+            od.zero_grad()
+            with torch.no_grad():
+                pass
+            OC.discriminator_step(x, y, {k: v.detach() for k, v in gen.items()}, disc, self.fs)[0].backward()
+            od.step()
+
+        return time_cpu(one, "oracle generator step + discriminator step (each fwd + loss + bwd + Adam), B=1 of the same workload, fp32")
+
+
 class StubWorkload:
     """CPU stand-in with the workloads' interface: exercises this file's launch / timing / reporting plumbing under gloo
     (tests/test_ddp_cpu.py) - never a measurement."""
@@ -348,6 +429,8 @@ def build_workload(name: str, dev, batch: int, rank: int):
         return ConvLSTMWorkload(dev, batch, rank)
     if name == "metnet":
         return MetNetWorkload(dev, batch, rank)
+    if name == "cloudgan":
+        return CloudGANWorkload(dev, batch, rank)
     if name == "stub":
         return StubWorkload(dev, batch, rank)
     raise SystemExit(f"unknown workload {name}")
@@ -398,7 +481,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "stub"])
+    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "cloudgan", "stub"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 8; with --scaling strong: global batch / N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: fixed per-GPU batch (default, 8/GPU); strong: fixed global batch (--global-batch, BASELINE cfg 4: 64) split over the ranks")
@@ -443,7 +526,8 @@ def main(argv=None):
         samples = args.steps * wl.B * world
         out = {
             "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else
-                      ("samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6" if args.workload == "convlstm" else "stub"),
+                      ("samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6" if args.workload == "convlstm" else
+                       ("samples/sec + per-step ms, CloudGAN (ConvLSTM generator + PatchGAN) 12ch 128x128 T=12->6" if args.workload == "cloudgan" else "stub")),
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16",

@@ -320,6 +320,36 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
 int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
                 float* y, sfStream stream);
 
+/* =============================================================================================
+ * CloudGAN around the ConvLSTM generator: the PatchGAN discriminator's convolutions and the GAN / L1 losses.
+ * Reference: satflow/models/cloudgan.py:88-92,121-189, satflow/models/gan/discriminators.py:70-223.
+ * ============================================================================================= */
+
+/* nn.Conv2d(cin, cout, (kh, kw), stride, padding=pad) on NHWC fp32 activations (channel counts padded to 8), weights in the
+ * reference's OIHW layout read directly.  leaky_slope != 1 fuses nn.LeakyReLU(slope) (discriminators.py:166-168).  Exact-fp32 MFMA.
+ * Output size: (h + 2*pad - kh) / stride + 1.  Pad lanes of y are written as zeros. */
+int sf_conv2d_fwd(sfTensor x, int32_t n, int32_t h, int32_t w, const float* weight, const float* bias, int32_t cin, int32_t cout,
+                  int32_t kh, int32_t kw, int32_t stride, int32_t pad, float leaky_slope, sfTensor y, int32_t dtype, sfStream stream);
+/* dx of the same convolution (h, w = INPUT size); dy [n][oh][ow][..]. */
+int sf_conv2d_bwd_data(sfTensor dy, int32_t n, int32_t h, int32_t w, const float* weight, int32_t cin, int32_t cout, int32_t kh,
+                       int32_t kw, int32_t stride, int32_t pad, sfTensor dx, int32_t dtype, sfStream stream);
+/* dW [cout][cin][kh][kw] (+)= ..., db [cout] (+)= sum dy (db nullable).  workspace: sf_conv2d_bwd_weight_workspace_bytes(). */
+size_t sf_conv2d_bwd_weight_workspace_bytes(int32_t n, int32_t oh, int32_t ow, int32_t cin, int32_t cout, int32_t kh, int32_t kw);
+int sf_conv2d_bwd_weight(sfTensor x, sfTensor dy, int32_t n, int32_t h, int32_t w, int32_t cin, int32_t cout, int32_t kh, int32_t kw,
+                         int32_t stride, int32_t pad, float* dw, float* db, int32_t accumulate, void* workspace, size_t workspace_bytes,
+                         int32_t dtype, sfStream stream);
+/* y = x > 0 ? x : slope*x over n contiguous floats; sign_ref (nullable) supplies the sign instead of x: the backward pass is
+ * sf_leaky_relu(dy, y_forward, ...) (slope > 0 preserves signs). */
+int sf_leaky_relu(const float* x, const float* sign_ref, int64_t n, float slope, float* y, sfStream stream);
+
+/* nn.L1Loss (mean) and nn.BCEWithLogitsLoss against a constant label (GANLoss "vanilla", discriminators.py:70-136) over the first c
+ * lanes of `rows` NHWC rows split into `groups` equal contiguous groups (timesteps): out[0] = mean over everything, out[1+g] =
+ * mean of group g; grad (nullable, same rows; its pad lanes are zeroed) = d out[0] / d pred.  sums: 1 + groups doubles scratch. */
+int sf_l1_loss(sfTensor pred, sfTensor target, int64_t rows, int32_t groups, int32_t c, sfTensor grad, double* sums, float* out,
+               sfStream stream);
+int sf_bce_logits_loss(sfTensor logits, float label, float label_odd, int64_t rows, int32_t groups, int32_t c, sfTensor grad,
+                       double* sums, float* out, sfStream stream); /* label for even groups, label_odd for odd ones */
+
 #ifdef __cplusplus
 }
 #endif

@@ -83,6 +83,13 @@ PROTOTYPES = {
     "sf_axial_attention_core_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_mse_loss": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sf_dropout2": (C.c_int, [_vp, _i64, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "sf_conv2d_fwd": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, sfTensor, _i32, _vp]),
+    "sf_conv2d_bwd_data": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_conv2d_bwd_weight_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "sf_conv2d_bwd_weight": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp]),
+    "sf_leaky_relu": (C.c_int, [_vp, _vp, _i64, C.c_float, _vp, _vp]),
+    "sf_l1_loss": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
+    "sf_bce_logits_loss": (C.c_int, [sfTensor, C.c_float, C.c_float, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, C.c_float, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),
 }

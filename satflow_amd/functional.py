@@ -636,3 +636,108 @@ def dropout2(x: Tensor, p1: float, p2: float, period: int) -> Tensor:
     if p1 <= 0 and p2 <= 0:
         return x
     return _Dropout2Fn.apply(x.contiguous(), float(p1), float(p2), int(period), *_draw_seeds())
+
+
+# ----------------------------------------------------------------------------------------------
+# CloudGAN side network: general convolution, LeakyReLU, GAN / L1 losses
+# ----------------------------------------------------------------------------------------------
+class _Conv2dFn(torch.autograd.Function):
+    """``nn.Conv2d(k, stride, padding)`` (+ fused ``LeakyReLU(slope)``) on NHWC fp32 ``x [N,H,W,Cp]``; weight in OIHW (sf_conv2d_*)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, pad: int, slope: float):
+        N, H, W, _ = x.shape
+        cout, cin, kh, kw = weight.shape
+        oh, ow = (H + 2 * pad - kh) // stride + 1, (W + 2 * pad - kw) // stride + 1
+        w = weight.contiguous()
+        y = torch.empty(N, oh, ow, cpad(cout), dtype=torch.float32, device=x.device)
+        check(lib().sf_conv2d_fwd(T(x), N, H, W, w.data_ptr(), bias.data_ptr() if bias is not None else None, cin, cout, kh, kw, stride, pad, slope,
+                                  T(y), SF_F32, stream_ptr()), "sf_conv2d_fwd")
+        ctx.meta = (stride, pad, slope, bias is not None)
+        ctx.save_for_backward(x, w, y if slope != 1.0 else x.new_empty(0))
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, w, y = ctx.saved_tensors
+        stride, pad, slope, has_bias = ctx.meta
+        N, H, W, _ = x.shape
+        cout, cin, kh, kw = w.shape
+        gy = gy.contiguous()
+        if slope != 1.0:
+            g2 = torch.empty_like(gy)
+            check(lib().sf_leaky_relu(gy.data_ptr(), y.data_ptr(), gy.numel(), slope, g2.data_ptr(), stream_ptr()), "sf_leaky_relu")
+            gy = g2
+        oh, ow = gy.shape[1], gy.shape[2]
+        dx = None
+        if ctx.needs_input_grad[0]:
+            dx = torch.empty_like(x)
+            check(lib().sf_conv2d_bwd_data(T(gy), N, H, W, w.data_ptr(), cin, cout, kh, kw, stride, pad, T(dx), SF_F32, stream_ptr()), "sf_conv2d_bwd_data")
+        dw = torch.empty_like(w)
+        db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        nbytes = lib().sf_conv2d_bwd_weight_workspace_bytes(N, oh, ow, cin, cout, kh, kw)
+        ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
+        check(lib().sf_conv2d_bwd_weight(T(x), T(gy), N, H, W, cin, cout, kh, kw, stride, pad, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
+                                         ws.data_ptr(), nbytes, SF_F32, stream_ptr()), "sf_conv2d_bwd_weight")
+        return dx, dw, db, None, None, None
+
+
+def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int = 1, padding: int = 0, leaky_slope: float = 1.0) -> Tensor:
+    require_device(x, "x")
+    return _Conv2dFn.apply(x.contiguous(), weight, bias, int(stride), int(padding), float(leaky_slope))
+
+
+class _LeakyFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, slope: float):
+        y = torch.empty_like(x)
+        check(lib().sf_leaky_relu(x.data_ptr(), None, x.numel(), slope, y.data_ptr(), stream_ptr()), "sf_leaky_relu")
+        ctx.slope = slope
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        (y,) = ctx.saved_tensors
+        gy = gy.contiguous()
+        gx = torch.empty_like(gy)
+        check(lib().sf_leaky_relu(gy.data_ptr(), y.data_ptr(), gy.numel(), ctx.slope, gx.data_ptr(), stream_ptr()), "sf_leaky_relu")
+        return gx, None
+
+
+def leaky_relu(x: Tensor, slope: float = 0.2) -> Tensor:
+    return _LeakyFn.apply(x.contiguous(), float(slope))
+
+
+class _PairLossFn(torch.autograd.Function):
+    """(mean loss, per-group means) of L1 (``target`` given) or BCE-with-logits against constant labels, gradient in the same pass."""
+
+    @staticmethod
+    def forward(ctx, pred: Tensor, target: Optional[Tensor], labels: Tuple[float, float], groups: int, c: int):
+        rows = pred.numel() // pred.shape[-1]
+        grad = torch.empty_like(pred) if ctx.needs_input_grad[0] else None
+        sums = torch.empty(1 + groups, dtype=torch.float64, device=pred.device)
+        out = torch.empty(1 + groups, dtype=torch.float32, device=pred.device)
+        g = T(grad) if grad is not None else NULL
+        if target is not None:
+            check(lib().sf_l1_loss(T(pred), T(target), rows, groups, c, g, sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_l1_loss")
+        else:
+            check(lib().sf_bce_logits_loss(T(pred), labels[0], labels[1], rows, groups, c, g, sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_bce_logits_loss")
+        ctx.save_for_backward(grad if grad is not None else pred.new_empty(0))
+        ctx.mark_non_differentiable(out[1:])
+        return out[0], out[1:]
+
+    @staticmethod
+    def backward(ctx, g_loss: Tensor, _g_groups):
+        (grad,) = ctx.saved_tensors
+        return grad * g_loss, None, None, None, None
+
+
+def l1_loss_groups(pred: Tensor, target: Tensor, groups: int, c: int):
+    """``(nn.L1Loss()(pred[..., :c], target[..., :c]), per-group means)`` on NHWC tensors whose leading rows split into ``groups``."""
+    return _PairLossFn.apply(pred.contiguous(), target.contiguous(), (0.0, 0.0), groups, c)
+
+
+def bce_logits_groups(logits: Tensor, label_even: float, label_odd: float, groups: int, c: int = 1):
+    """``nn.BCEWithLogitsLoss()`` of the first ``c`` lanes against a constant label per group parity (GANLoss "vanilla")."""
+    return _PairLossFn.apply(logits.contiguous(), None, (float(label_even), float(label_odd)), groups, c)

@@ -94,6 +94,29 @@ class MSELoss(nn.Module):
         return loss
 
 
+class L1Loss(nn.Module):
+    """``nn.L1Loss()`` (mean) on the fused HIP kernel (``sf_l1_loss``) for same-shape NCHW-side tensors."""
+
+    def forward(self, pred: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+        from ..functional import l1_loss_groups
+
+        p2 = pred.float().contiguous().view(1, -1)
+        t2 = target.float().contiguous().view(1, -1)
+        n = p2.shape[1]
+        pad = (-n) % 8  # the kernels want 16-byte aligned rows
+        if pad:
+            p2, t2 = torch.nn.functional.pad(p2, (0, pad)), torch.nn.functional.pad(t2, (0, pad))
+        loss, _ = l1_loss_groups(p2, t2, 1, n)
+        return loss
+
+
+def get_loss_l1(name: str = "l1") -> nn.Module:
+    """The L1 term of CloudGAN (``get_loss(l1_loss, ...)``, reference ``cloudgan.py:118``): only ``"l1"`` is on the path."""
+    if name in ("l1", "L1"):
+        return L1Loss()
+    raise ValueError(f"l1_loss {name!r} is outside the hot-path scope (only 'l1')")
+
+
 def get_loss(loss: Union[str, nn.Module, Callable] = "mse", **kwargs: Any) -> nn.Module:
     """``nowcasting_utils.models.loss.get_loss``: only ``"mse"`` is on the hot path."""
     if isinstance(loss, nn.Module):

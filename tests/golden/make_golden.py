@@ -187,9 +187,121 @@ def layer_cases():
     print("layers: ok (ConditionTime 5-D/4-D, TimeDistributed fast/low_mem, space_to_depth)")
 
 
+def _shim_cloudgan():
+    """Extra shims for satflow.models.cloudgan: antialiased_cnns / pl_bolts stubs, `from satflow.models import ConvLSTM, R2U_Net`,
+    get_loss("l1") -> nn.L1Loss (nowcasting_utils is not installed; the reference passes `channels=` as a keyword)."""
+
+    def mk(name, **attrs):
+        m = types.ModuleType(name)
+        sys.modules[name] = m
+        for k, v in attrs.items():
+            setattr(m, k, v)
+        return m
+
+    mk("antialiased_cnns")
+    mk("pl_bolts"); mk("pl_bolts.optimizers"); mk("pl_bolts.optimizers.lr_scheduler", LinearWarmupCosineAnnealingLR=object)
+    sys.modules["torchvision"].utils = types.SimpleNamespace()
+    import satflow.models.conv_lstm as cl
+
+    sm = sys.modules["satflow.models"]
+    sm.ConvLSTM = cl.ConvLSTM
+    sm.R2U_Net = type("R2U_Net", (torch.nn.Module,), {})
+    sys.modules["nowcasting_utils.models.loss"].get_loss = lambda name, **kw: torch.nn.L1Loss() if name == "l1" else torch.nn.MSELoss()
+
+
+def cloudgan_cases():
+    """CloudGAN with the ConvLSTM generator (configs/model/cloudgan_convlstm.yaml shape of arguments, small sizes): the PatchGAN
+    discriminator alone, and both optimizer steps of `training_step` with every parameter gradient."""
+    _shim_cloudgan()
+    import satflow.models.cloudgan as cg
+    from satflow.models.gan import NLayerDiscriminator
+    from oracle import cloudgan as OC
+
+    # (1) discriminator alone: logits + gradients for a random cotangent, "hot" weights so that LeakyReLU / BatchNorm matter
+    g = torch.Generator().manual_seed(77)
+    torch.manual_seed(5)
+    D = NLayerDiscriminator(5, ndf=8, n_layers=3, norm_layer=torch.nn.BatchNorm2d)
+    with torch.no_grad():
+        for n, p in D.named_parameters():
+            if p.dim() == 4:
+                p.mul_(1.5)
+            elif n.endswith("weight"):
+                p.copy_(1 + 0.3 * torch.randn(p.shape, generator=g))
+            else:
+                p.copy_(0.2 * torch.randn(p.shape, generator=g))
+    x = torch.randn(3, 5, 40, 36, generator=g).requires_grad_()
+    out = D(x)
+    cot = torch.randn(out.shape, generator=g)
+    (out * cot).sum().backward()
+    rec = dict(x=x, out=out, cot=cot, dx=x.grad)
+    for k, v in D.named_parameters():
+        rec[f"param.{k}"] = v
+        rec[f"grad.{k}"] = v.grad
+    for k, v in D.named_buffers():
+        rec[f"buffer.{k}"] = v
+    P = {k: v.detach() for k, v in D.named_parameters()}
+    assert torch.allclose(OC.patch_discriminator(x.detach(), P), out.detach(), rtol=1e-6, atol=1e-6), "oracle discriminator mismatch"
+    np.savez(f"{HERE}/cloudgan_discriminator.npz", **_np(rec))
+    print(f"discriminator: ok  logits {tuple(out.shape)} in [{out.min():.3f},{out.max():.3f}]")
+
+    # (2) the two optimizer steps
+    for name, (B, T, C, H, W, nf, fs, lam) in {"small": (2, 2, 3, 32, 32, 8, 2, 1.0), "rect": (1, 3, 4, 40, 48, 8, 3, 5.0)}.items():
+        g = torch.Generator().manual_seed(100 + fs)
+        torch.manual_seed(3 + fs)
+        m = cg.CloudGAN(forecast_steps=fs, input_channels=C, num_filters=nf, generator_model="convlstm", norm="batch", discriminator_model="basic",
+                        loss="vanilla", scheduler="cosine", lambda_l1=lam, channels_per_timestep=C, condition_time=True)
+        with torch.no_grad():  # init_net's N(0, 0.02) leaves everything in the linear regime: heat the generator, spread the BN affine
+            for n, p in m.generator.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.25 if p.dim() > 1 else 0.5))
+            for n, p in m.discriminator.named_parameters():
+                if p.dim() == 4:
+                    p.copy_(torch.randn(p.shape, generator=g) * 0.15)
+                elif n.endswith("weight"):
+                    p.copy_(1 + 0.3 * torch.randn(p.shape, generator=g))
+                else:
+                    p.copy_(0.2 * torch.randn(p.shape, generator=g))
+        images = torch.randn(B, T, C, H, W, generator=g)
+        future = torch.rand(B, fs, C, H, W, generator=g)
+        rec = dict(images=images, future=future, forecast_steps=fs, lambda_l1=lam, num_filters=nf)
+        for k, v in m.generator.state_dict().items():
+            rec[f"gen.{k}"] = v.clone()
+        for k, v in m.discriminator.state_dict().items():
+            rec[f"disc.{k}"] = v.clone()
+        gen = {k: v.detach() for k, v in m.generator.named_parameters()}
+        disc = {k: v.detach() for k, v in m.discriminator.named_parameters()}
+        for idx, tag in ((0, "g"), (1, "d")):
+            m.zero_grad()
+            out = m.training_step((images, future), 0, idx)
+            out["loss"].backward()
+            rec[f"{tag}_loss"] = out["loss"]
+            for k, v in m.generator.named_parameters():
+                rec[f"{tag}_grad.gen.{k}"] = v.grad.clone() if v.grad is not None else torch.zeros_like(v)
+            for k, v in m.discriminator.named_parameters():
+                rec[f"{tag}_grad.disc.{k}"] = v.grad.clone() if v.grad is not None else torch.zeros_like(v)
+        for k, v in m.discriminator.state_dict().items():  # running statistics after the two steps (call order matters)
+            if "running" in k or "num_batches" in k:
+                rec[f"disc_after.{k}"] = v.clone()
+        og, _ = OC.generator_step(images, future, gen, disc, fs, lam)
+        od, _ = OC.discriminator_step(images, future, gen, disc, fs)
+        assert torch.allclose(og, rec["g_loss"].detach(), rtol=1e-6, atol=1e-7) and torch.allclose(od, rec["d_loss"].detach(), rtol=1e-6, atol=1e-7), \
+            f"oracle cloudgan mismatch {name}"
+        np.savez(f"{HERE}/cloudgan_{name}.npz", **_np(rec))
+        print(f"cloudgan {name}: ok  g_loss={float(rec['g_loss']):.5f} d_loss={float(rec['d_loss']):.5f}")
+    keys = list(cg.CloudGAN(forecast_steps=2, input_channels=3, num_filters=8, generator_model="convlstm", discriminator_model="basic",
+                            channels_per_timestep=3, condition_time=True).state_dict().keys())
+    with open(f"{HERE}/cloudgan_state_dict_keys.txt", "w") as f:
+        f.write("\n".join(keys) + "\n")
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     _shim_reference()
-    cell_cases()
-    model_cases()
-    layer_cases()
+    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan"]
+    if "cell" in only:
+        cell_cases()
+    if "model" in only:
+        model_cases()
+    if "layer" in only:
+        layer_cases()
+    if "cloudgan" in only:
+        cloudgan_cases()

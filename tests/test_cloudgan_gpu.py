@@ -1,0 +1,122 @@
+"""GPU parity of CloudGAN with the ConvLSTM generator against golden vectors captured from the reference itself
+(tests/golden/make_golden.py::cloudgan_cases imports satflow.models.cloudgan / satflow.models.gan): the PatchGAN discriminator
+alone, then both optimizer steps of `training_step` - losses, EVERY parameter gradient of generator and discriminator, and the
+BatchNorm running statistics after the two steps (their update order follows the reference's per-timestep call order).
+fp32, rtol 1e-4 / atol 1e-5.  Reference: satflow/models/cloudgan.py:121-189, gan/discriminators.py:70-223."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from conftest import GOLDEN, assert_close
+
+pytestmark = pytest.mark.gpu
+
+
+def _load(name):
+    return {k: torch.from_numpy(np.asarray(v)) for k, v in np.load(os.path.join(GOLDEN, name)).items()}
+
+
+def test_patch_discriminator_golden(device):
+    from satflow_amd.models.gan import NLayerDiscriminator
+
+    G = _load("cloudgan_discriminator.npz")
+    D = NLayerDiscriminator(5, ndf=8, n_layers=3, norm_layer=torch.nn.BatchNorm2d)
+    D.load_state_dict({k[len("param."):]: v for k, v in G.items() if k.startswith("param.")}, strict=False)
+    D = D.to(device).train()
+    x = G["x"].to(device).requires_grad_()
+    out = D(x)
+    assert_close(out, G["out"], "patch logits")
+    (out * G["cot"].to(device)).sum().backward()
+    assert_close(x.grad, G["dx"], "dx", grad=True, force_rel=True)
+    for k, p in D.named_parameters():
+        assert_close(p.grad, G[f"grad.{k}"], f"d{k}", grad=True)
+    for k, b in D.named_buffers():  # running statistics after one training-mode call
+        assert_close(b.float(), G[f"buffer.{k}"].float(), k)
+
+
+@pytest.mark.parametrize("case", ["small", "rect"])
+def test_cloudgan_training_steps_golden(device, case):
+    from satflow_amd.models import CloudGAN
+
+    G = _load(f"cloudgan_{case}.npz")
+    B, T, C, H, W = G["images"].shape
+    fs, lam, nf = int(G["forecast_steps"]), float(G["lambda_l1"]), int(G["num_filters"])
+    m = CloudGAN(forecast_steps=fs, input_channels=C, num_filters=nf, generator_model="convlstm", norm="batch", discriminator_model="basic",
+                 loss="vanilla", scheduler="cosine", lambda_l1=lam, channels_per_timestep=C, condition_time=True)
+    m.generator.load_state_dict({k[len("gen."):]: v for k, v in G.items() if k.startswith("gen.")})
+    m.discriminator.load_state_dict({k[len("disc."):]: v for k, v in G.items() if k.startswith("disc.")})
+    m = m.to(device).train()
+    batch = (G["images"].to(device), G["future"].to(device))
+    for idx, tag in ((0, "g"), (1, "d")):  # same order as the golden run: the discriminator's running statistics accumulate
+        m.zero_grad()
+        out = m.training_step(batch, 0, idx)
+        out["loss"].backward()
+        assert_close(out["loss"], G[f"{tag}_loss"], f"{tag}_loss", rtol=1e-5, atol=1e-6)
+        assert f"train/{tag}_loss" in m.logged
+        for k, p in m.generator.named_parameters():
+            ref = G[f"{tag}_grad.gen.{k}"]
+            assert_close(p.grad if p.grad is not None else torch.zeros_like(p), ref, f"{tag} step d(gen.{k})", grad=True)
+        for k, p in m.discriminator.named_parameters():
+            ref = G[f"{tag}_grad.disc.{k}"]
+            assert_close(p.grad if p.grad is not None else torch.zeros_like(p), ref, f"{tag} step d(disc.{k})", grad=True)
+    assert {f"train/frame_{i}_l1_loss" for i in range(fs)} <= set(m.logged) and {f"train/frame_{i}_d_loss" for i in range(fs)} <= set(m.logged)
+    sd = m.discriminator.state_dict()
+    for k, v in G.items():
+        if k.startswith("disc_after."):
+            assert_close(sd[k[len("disc_after."):]].float(), v.float(), k)
+
+
+def test_cloudgan_validation_step_and_eval(device):
+    """validation_step (reference cloudgan.py:271-313) under model.eval(): metric names, finite losses, no statistics update."""
+    from oracle import cloudgan as OC
+    from satflow_amd.models import CloudGAN
+
+    G = _load("cloudgan_small.npz")
+    B, T, C, H, W = G["images"].shape
+    fs = int(G["forecast_steps"])
+    m = CloudGAN(forecast_steps=fs, input_channels=C, num_filters=int(G["num_filters"]), generator_model="convlstm", discriminator_model="basic",
+                 lambda_l1=float(G["lambda_l1"]), channels_per_timestep=C, condition_time=True, scheduler="cosine")
+    m.generator.load_state_dict({k[len("gen."):]: v for k, v in G.items() if k.startswith("gen.")})
+    m.discriminator.load_state_dict({k[len("disc."):]: v for k, v in G.items() if k.startswith("disc.")})
+    m = m.to(device).eval()
+    before = {k: v.clone() for k, v in m.discriminator.state_dict().items() if "running" in k}
+    with torch.no_grad():
+        out = m.validation_step((G["images"].to(device), G["future"].to(device)), 0)
+    assert {"val/d_loss", "val/g_loss", "val/loss"} <= set(m.logged) and {f"val/frame_{i}_l1_loss" for i in range(fs)} <= set(m.logged)
+    assert torch.isfinite(out["val/discriminator_loss"]) and torch.isfinite(out["val/generator_loss"])
+    assert_close(m.logged["val/loss"], out["val/discriminator_loss"] + out["val/generator_loss"], "val/loss", rtol=1e-6, atol=1e-7)
+    for k, v in before.items():
+        assert torch.equal(m.discriminator.state_dict()[k], v)
+    # the L1 part does not depend on the discriminator: check it against the oracle's generator
+    gen = {k[len("gen."):]: v for k, v in G.items() if k.startswith("gen.")}
+    ref = OC.O.convlstm_forward(G["images"], fs, gen)
+    l1 = sum(torch.nn.functional.l1_loss(ref[:, :, i], G["future"][:, i]) for i in range(fs)) / fs * float(G["lambda_l1"])
+    got = sum(m.logged[f"val/frame_{i}_l1_loss"] for i in range(fs)) / fs
+    assert_close(got, l1, "mean val l1", rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w,k,stride,pad,slope", [(2, 5, 8, 20, 18, 4, 2, 1, 0.2), (1, 16, 32, 9, 11, 4, 1, 1, 1.0), (3, 12, 40, 16, 16, 3, 1, 1, 1.0),
+                                                              (2, 8, 1, 7, 6, 4, 1, 1, 1.0), (1, 3, 7, 13, 17, 5, 3, 2, 0.1), (2, 24, 16, 8, 8, 1, 1, 0, 1.0)])
+def test_generic_conv2d_vs_torch(device, n, cin, cout, h, w, k, stride, pad, slope):
+    """sf_conv2d_fwd / bwd_data / bwd_weight (+ fused LeakyReLU) against torch CPU conv2d."""
+    import torch.nn.functional as TF
+
+    from satflow_amd import functional as F
+
+    g = torch.Generator().manual_seed(n * 100 + cin + cout)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, k, k, generator=g) / (k * cin**0.5)
+    b = torch.randn(cout, generator=g)
+    xr, wr, br = x.clone().requires_grad_(), wt.clone().requires_grad_(), b.clone().requires_grad_()
+    ref = TF.leaky_relu(TF.conv2d(xr, wr, br, stride=stride, padding=pad), slope)
+    cot = torch.randn(ref.shape, generator=g)
+    (ref * cot).sum().backward()
+    xd, wd, bd = (t.to(device).requires_grad_() for t in (x, wt, b))
+    y = F.nhwc_to_nchw(F.conv2d(F.nchw_to_nhwc(xd), wd, bd, stride, pad, slope), cout)
+    (y * cot.to(device)).sum().backward()
+    assert_close(y, ref, "conv2d out")
+    assert_close(xd.grad, xr.grad, "conv2d dx", grad=True)
+    assert_close(wd.grad, wr.grad, "conv2d dW", grad=True)
+    assert_close(bd.grad, br.grad, "conv2d db", grad=True)

@@ -206,3 +206,23 @@ def test_combine_data_sources_matches_reference_semantics():
         assert torch.equal(out[:, 3, t], topo[:, 0].float())
     out2 = m._combine_data_sources({SATELLITE_DATA: sat, TOPOGRAPHIC_DATA: topo, NWP_DATA: nwp})
     assert out2.shape == (2, 6, 4, 6, 6) and torch.equal(out2[:, 4:], nwp[0].float())
+
+
+def test_cloudgan_surface_config_and_state_dict_keys():
+    """configs/model/cloudgan_convlstm.yaml loads unchanged into CloudGAN; its state_dict keys are the reference's
+    (pinned file written by tests/golden/make_golden.py from the reference import)."""
+    from satflow_amd.config import instantiate, load_config
+    from satflow_amd.models import CloudGAN
+
+    cfg = load_config(os.path.join(GOLDEN, "configs", "cloudgan_convlstm.yaml"))
+    m = instantiate(cfg)
+    assert isinstance(m, CloudGAN) and m.forecast_steps == 24 and m.lambda_l1 == 1 and m.condition_time
+    assert m.generator.hidden_dim == 32 and m.discriminator.model[0].weight.shape == (32, 12, 4, 4)
+    opts, scheds = m.configure_optimizers()
+    assert len(opts) == 2 and all(isinstance(o, torch.optim.Adam) and o.defaults["betas"] == (0.5, 0.999) for o in opts) and len(scheds) == 2
+    small = CloudGAN(forecast_steps=2, input_channels=3, num_filters=8, generator_model="convlstm", discriminator_model="basic",
+                     channels_per_timestep=3, condition_time=True)
+    want = open(os.path.join(GOLDEN, "cloudgan_state_dict_keys.txt")).read().split()
+    assert list(small.state_dict().keys()) == want
+    with pytest.raises(NotImplementedError):
+        CloudGAN(generator_model="runet")
