@@ -233,22 +233,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);  // by parity of ky
   const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
 
-#ifdef SF_EXP_NOLDS
-  bf16x8 fa[2][2], fb[2][NF];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-#pragma unroll
-    for (int m = 0; m < 2; ++m) fa[i][m] = __builtin_bit_cast(bf16x8, f32x4{1.f + lane, 2.f, 3.f + i, 4.f + m});
-#pragma unroll
-    for (int m = 0; m < NF; ++m) fb[i][m] = __builtin_bit_cast(bf16x8, f32x4{1.5f + lane, 2.5f, 3.f + i, 4.f + m});
-  }
-#endif
   for (int ci = 0; ci < nch; ++ci) {
     const int cur = ci & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weight DMA has landed (LDS-DMA is not covered by the barrier)
-#ifndef SF_EXP_NOBARRIER
     __syncthreads();
-#endif
     // Staging of the NEXT chunk (weight DMA + input DMA / loads) is issued at a different tap by the two waves that
     // share a SIMD (wave w and w + 4 of an 8-wave workgroup): a wave stalls for a few hundred cycles while it issues its
     // ~7 LDS-DMA pieces, and when both partners do that at the same moment the SIMD's matrix pipe idles.  Out of phase,
@@ -256,16 +244,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     // which pairs waves of different SIMDs, gains nothing; spreading the pieces over the taps loses the gain).
     const bool stage_late = WAVES == 8 && wave >= 4;
     auto stage_next = [&]() {
-#ifndef SF_EXP_NOSTAGE
       if (ci + 1 < nch) {
-#ifndef SF_EXP_NOWEIGHTS
         issue_weights(ci + 1, cur ^ 1);
-#endif
-#ifndef SF_EXP_NOINPUT
         stage_input(ci + 1);
-#endif
       }
-#endif
     };
     const char* inb = lds_in + cur * IN_B + a_lane;
     const char* wb = lds_w + cur * W_B + b_lane;
@@ -277,25 +259,17 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
     };
-#ifndef SF_EXP_NOLDS
     bf16x8 fa[2][2], fb[2][NF];
     load_tap(0, fa[0], fb[0]);
-#endif
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
-#ifndef SF_EXP_NOLDS
       if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
-#endif
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
-#ifdef SF_EXP_NOMFMA
-          acc[mf][nf][0] += (float)fa[tap & 1][mf][0] * (float)fb[tap & 1][nf][0];
-#else
           acc[mf][nf] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1][mf], acc[mf][nf], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
-#endif
       // scheduling: one LDS read (the next tap's operands) after each of the first MFMAs of this tap, the remaining
       // MFMAs behind them - a clump of 2+NF reads between two MFMA groups measured 2 % (NF=4) to 15 % (NF=5) slower
       if (tap + 1 < 9) {
@@ -314,9 +288,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-#ifndef SF_EXP_NOSTAGE
     if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
-#endif
   }
 
   // optional per-tile BatchNorm statistics of the stored outputs (linear epilogue): lane sums -> LDS (the operand

@@ -142,9 +142,6 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const unsigned o_const = (unsigned)((o_row * p.W + 8 * o_half) * p.ds + oco) * ESZ_A;
     float bsum8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     auto ld = [](__amdgpu_buffer_rsrc_t rs, unsigned voff, unsigned soff) -> VT {
-#ifdef SF_EXP_WG_NOLOAD
-      return VT{};
-#endif
       if constexpr (BBF) return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b64(rs, voff, soff, 0));
       else return __builtin_bit_cast(VT, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, soff, 0));
     };
@@ -203,13 +200,6 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       }
     };
     auto store_tile = [&](int i, Stage& s) {
-#ifdef SF_EXP_WG_NOSTORE
-#pragma unroll
-      for (int j = 0; j < 8; ++j) { asm volatile("" ::"v"(s.va8[ABF ? j : 0])); }
-#pragma unroll
-      for (int j = 0; j < 10; ++j) { asm volatile("" ::"v"(s.vb[j])); }
-      return;
-#endif
       char* la = lds + (i & 1) * BUF;
       char* lb = la + A_BYTES;
       char* lh = lb + B_BYTES;
@@ -338,9 +328,6 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       // time (256->256: 2.53 -> 2.45 ms; forcing a one-read-per-MFMA interleave with sched_group_barrier on top of this,
       // or a third stage for the shifts, gained nothing more).  The dout window holds 4 rows: 3 in use + the one in flight.
       bf16x8 arow[4];
-#ifdef SF_EXP_WG_NOCOMPUTE
-      if (i >= 0) { __syncthreads(); continue; }
-#endif
       u32x4 mid_n; unsigned left_n, right_n;
       auto load_row = [&](int hrow) {
         if (hrow < KR) arow[hrow & 3] = *reinterpret_cast<const bf16x8*>(la + a_off + hrow * 128);
@@ -368,15 +355,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
           const int row = hrow - ky;
           if (row < 0 || row >= KR) continue;
           const bf16x8 a = arow[row & 3];
-#ifdef SF_EXP_WG_NOMFMA
-          acc[ky * 3 + 0][0] += (float)a[0] * __builtin_bit_cast(float, b0[0]);
-          acc[ky * 3 + 1][0] += (float)a[1] * __builtin_bit_cast(float, mid[1]);
-          acc[ky * 3 + 2][0] += (float)a[2] * __builtin_bit_cast(float, b2[3]);
-#else
           acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, mid), acc[ky * 3 + 1], 0, 0, 0);
           acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0], 0, 0, 0);
           acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2], 0, 0, 0);
-#endif
         }
       }
       __syncthreads();

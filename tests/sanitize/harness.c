@@ -1,0 +1,108 @@
+/* Host-side sanitizer harness (sanitizers row): calls the argument validation of every
+ * sf_* entry point of include/satflow_hip.h with NULL / misaligned / oversize / inconsistent arguments under
+ * -fsanitize=address,undefined (host code only; GPU ASan is not available on this pool).  Every call must be REFUSED (non-zero
+ * return, non-empty sf_last_error_string()) before anything is dereferenced or launched - no GPU is needed or touched.
+ * Build + run: tools/sanitize_host.sh */
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#include "../../include/satflow_hip.h"
+
+static int failures = 0, calls = 0;
+#define REFUSED(expr)                                                                                         \
+  do {                                                                                                        \
+    int rc_ = (expr);                                                                                         \
+    ++calls;                                                                                                  \
+    if (rc_ == 0 || strlen(sf_last_error_string()) == 0) { ++failures; printf("NOT REFUSED: %s (rc=%d)\n", #expr, rc_); } \
+  } while (0)
+
+static sfTensor T(void* p, int c, int stride, int dtype) { sfTensor t = {p, c, stride, 0, 0, dtype}; return t; }
+
+int main(void) {
+  static _Alignas(64) char mem[4096];
+  void* ok = mem;          /* a 64-byte aligned non-null address standing in for a device pointer (never dereferenced) */
+  void* mis = mem + 4;     /* misaligned */
+  const sfTensor N0 = {0, 0, 0, 0, 0, 0};
+  sfTensor a16 = T(ok, 16, 16, SF_F32), m16 = T(mis, 16, 16, SF_F32), odd = T(ok, 12, 12, SF_F32), b16 = T(ok, 16, 16, SF_BF16);
+  sfTensor a64 = T(ok, 64, 64, SF_F32), a48 = T(ok, 48, 48, SF_F32), a192 = T(ok, 192, 192, SF_F32);
+  void* st = 0;
+
+  printf("abi %d\n", sf_abi_version());
+  /* weight repack */
+  REFUSED(sf_conv3x3_pack_weights(ok, 16, 16, ok, 32, ok, 16, 9, 0, ok, 0, 0, SF_F32, st));          /* nf out of range */
+  REFUSED(sf_conv3x3_pack_weights(ok, 16, 16, ok, 32, ok, 16, 1, 0, ok, 0, 0, 7, st));               /* unknown dtype */
+  /* 3x3 convolution */
+  REFUSED(sf_conv3x3_fwd(odd, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F32, st));           /* channels not padded */
+  REFUSED(sf_conv3x3_fwd(b16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F32, st));           /* bf16 storage with the fp32 kernel */
+  REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, m16, SF_BF16, st));          /* misaligned output */
+  REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, 9, a16, SF_F32, st));                       /* unknown epilogue */
+  REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, 5, st));                /* unknown dtype */
+  REFUSED(sf_conv3x3_fwd_stats(a16, N0, 1, 8, 8, ok, 0, 32, 1, a16, ok, SF_F32, st));                /* stats need the bf16 kernels */
+  /* ConvLSTM cell */
+  REFUSED(sf_convlstm_cell_fwd(a16, a64, a64, 1, 8, 8, ok, 0, 48, a64, a64, N0, SF_F32, st));        /* hidp inconsistent with the tensors */
+  REFUSED(sf_convlstm_cell_fwd(odd, a64, a64, 1, 8, 8, ok, 0, 64, a64, a64, N0, SF_F32, st));
+  REFUSED(sf_convlstm_cell_bwd_gates(N0, N0, N0, N0, a64, N0, a64, 64, 60, a64, N0, SF_F32, st));    /* hidp not padded */
+  REFUSED(sf_convlstm_cell_bwd_gates(a64, N0, N0, N0, a64, N0, a64, 64, 64, a64, N0, 3, st));
+  /* weight gradient */
+  REFUSED(sf_conv3x3_bwd_weight(a16, N0, a16, 1, 8, 8, ok, ok, 16, 16, ok, 0, 0, 0, 0, SF_F32, st)); /* no workspace */
+  REFUSED(sf_conv3x3_bwd_weight(odd, N0, a16, 1, 8, 8, ok, ok, 16, 16, ok, 0, 0, ok, 1 << 20, SF_F32, st));
+  REFUSED(sf_conv3x3_bwd_weight(b16, N0, a16, 1, 8, 8, ok, ok, 16, 16, ok, 0, 0, ok, 1 << 30, SF_BF16, st)); /* bf16 inputs, fp32 dout */
+  /* layout */
+  REFUSED(sf_nchw_to_nhwc(ok, 0, 0, 0, 1, 1, 20, 4, 4, a16, SF_F32, st));                            /* more channels than lanes */
+  REFUSED(sf_nhwc_to_nchw(a16, 1, 1, 20, 4, 4, ok, 0, 0, 0, SF_F32, st));
+  /* optimizer */
+  REFUSED(sf_adam_step(mis, ok, ok, ok, 16, 1e-3f, 0.9f, 0.999f, 1e-8f, 1, 1.f, st));                /* misaligned flat buffer */
+  REFUSED(sf_adam_step(ok, ok, ok, ok, 16, 1e-3f, 0.9f, 0.999f, 1e-8f, 0, 1.f, st));                 /* step counts from 1 */
+  /* MetNet encoder */
+  REFUSED(sf_metnet_preprocess_fwd(ok, 1, 1, 12, 12, 250, 256, 64, a192, SF_F32, st));               /* raw size != 4 * crop */
+  REFUSED(sf_metnet_preprocess_fwd(ok, 1, 1, 12, 12, 256, 256, 64, a16, SF_F32, st));                /* too few output lanes */
+  REFUSED(sf_metnet_preprocess_bwd(a16, 1, 1, 12, 12, 256, 256, 64, ok, SF_F32, st));
+  REFUSED(sf_metnet_preprocess_bwd(a192, 1, 1, 12, 12, 256, 256, 64, mis, SF_F32, st));
+  REFUSED(sf_maxpool2_fwd(a16, 1, 7, 8, a16, 0, 0, SF_F32, st));                                     /* odd height */
+  REFUSED(sf_maxpool2_fwd(a16, 5, 8, 8, a16, 2, 3, SF_F32, st));                                     /* n not divisible by the permutation */
+  REFUSED(sf_maxpool2_bwd(a16, a16, 1, 8, 8, a64, 0, 0, SF_F32, st));                                /* channel mismatch */
+  REFUSED(sf_maxpool2_dropout_fwd(a16, 1, 8, 8, a16, 0, 0, 1.5f, 0.f, 256, 1, 2, SF_F32, st));       /* p >= 1 */
+  REFUSED(sf_maxpool2_dropout_bwd(a16, a16, 1, 8, 8, a16, 0, 0, 0.1f, 0.1f, 100, 1, 2, SF_F32, st)); /* period not whole images */
+  REFUSED(sf_batchnorm_train_fwd(odd, 64, 1, 12, ok, ok, 1e-5f, 0.1f, 0, 0, ok, ok, ok, ok, ok, odd, SF_F32, st));
+  REFUSED(sf_batchnorm_train_fwd_stats(a16, 64, 1, 16, ok, ok, 1e-5f, 0.1f, 0, 0, ok, ok, ok, ok, ok, 0, 4, 32, a16, SF_F32, st)); /* null stats */
+  REFUSED(sf_batchnorm_eval_fwd(a16, 64, 32, ok, ok, 1e-5f, ok, ok, ok, ok, a16, SF_F32, st));       /* creal > lanes */
+  REFUSED(sf_batchnorm_eval_bwd(a16, a64, 64, 16, ok, 1e-5f, ok, ok, ok, ok, a16, ok, ok, SF_F32, st));
+  REFUSED(sf_batchnorm_train_bwd(a16, a64, 64, 1, 16, ok, ok, ok, ok, ok, a16, ok, ok, SF_F32, st));
+  REFUSED(sf_leadtime_pool_fwd(a16, 1, 7, 8, ok, 16, 20, 8, 12, ok, a16, SF_F32, st));               /* odd height */
+  REFUSED(sf_leadtime_pool_bwd(a16, a64, 1, 8, 8, ok, 16, 20, 8, 12, ok, a16, ok, SF_F32, st));
+  /* ConvGRU */
+  REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 20, a16, N0, SF_F32, st));                   /* hidp not padded */
+  REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 16, N0, N0, SF_F32, st));                    /* no output */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, a64, N0, SF_F32, st));               /* persistent kernel: bf16 kernels only */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 32, 16, ok, 0, 64, a64, N0, SF_BF16, st));              /* map larger than one workgroup */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 128, a64, N0, SF_BF16, st));             /* hidp > 64 */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, m16, N0, SF_BF16, st));              /* misaligned / wrong-width states */
+  REFUSED(sf_convgru_bwd_gates(N0, N0, N0, a64, N0, 64, 16, a48, a48, N0, SF_F32, st));              /* dh0 missing */
+  /* linear / attention */
+  REFUSED(sf_linear_fwd(a16, 64, ok, 300, 0, a16, SF_F32, st));                                      /* N exceeds the output lanes */
+  REFUSED(sf_linear_fwd(b16, 64, ok, 8, 0, a16, SF_F32, st));                                        /* bf16 storage unsupported */
+  REFUSED(sf_linear_bwd_weight(a16, 8, a16, 64, ok, 0, 0, 0, SF_F32, st));                           /* no workspace */
+  REFUSED(sf_axial_attention_core_fwd(a16, 1, 16, 16, 64, 64, 8, a16, SF_F32, st));                  /* qkv narrower than 6 * hidp */
+  REFUSED(sf_axial_attention_core_bwd(a16, a16, 1, 16, 16, 60, 64, 8, a16, SF_F32, st));             /* hid not divisible by heads */
+  /* losses / dropout */
+  REFUSED(sf_mse_loss(ok, ok, 100, 7, 3, 0, ok, ok, st));                                            /* n not divisible into frames */
+  REFUSED(sf_dropout2(ok, 64, 1.0f, 0.f, 64, 1, 2, ok, st));                                         /* p >= 1 */
+  REFUSED(sf_dropout2(ok, 64, 0.1f, 0.1f, 30, 1, 2, ok, st));                                        /* period not a multiple of 4 */
+  /* CloudGAN side network */
+  REFUSED(sf_conv2d_fwd(odd, 1, 8, 8, ok, 0, 12, 16, 4, 4, 2, 1, 0.2f, a16, SF_F32, st));            /* channels not padded to 8 */
+  REFUSED(sf_conv2d_fwd(a16, 1, 2, 2, ok, 0, 16, 16, 4, 4, 1, 0, 1.f, a16, SF_F32, st));             /* empty output */
+  REFUSED(sf_conv2d_fwd(a16, 1, 8, 8, ok, 0, 16, 16, 4, 4, 2, 1, 1.f, a16, SF_BF16, st));            /* fp32 kernel only */
+  REFUSED(sf_conv2d_bwd_data(a16, 1, 8, 8, 0, 16, 16, 4, 4, 2, 1, a16, SF_F32, st));                 /* null weight */
+  REFUSED(sf_conv2d_bwd_weight(a16, a16, 1, 8, 8, 16, 16, 4, 4, 2, 1, ok, 0, 0, 0, 0, SF_F32, st));  /* no workspace */
+  REFUSED(sf_leaky_relu(mis, 0, 64, 0.2f, ok, st));
+  REFUSED(sf_leaky_relu(ok, 0, 63, 0.2f, ok, st));
+  REFUSED(sf_l1_loss(a16, N0, 64, 1, 16, N0, ok, ok, st));                                           /* no target */
+  REFUSED(sf_l1_loss(a16, a16, 64, 3, 16, N0, ok, ok, st));                                          /* rows not divisible into groups */
+  REFUSED(sf_bce_logits_loss(a16, 1.f, 0.f, 64, 1, 32, N0, ok, ok, st));                             /* more lanes than the stride */
+  /* size queries never fail, must not overflow */
+  printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32),
+         sf_linear_bwd_weight_workspace_bytes(384, 64, 24576), sf_conv2d_bwd_weight_workspace_bytes(48, 64, 64, 12, 32, 4, 4));
+  printf("%d calls, %d not refused\n", calls, failures);
+  return failures ? 1 : 0;
+}

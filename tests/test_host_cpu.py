@@ -226,3 +226,21 @@ def test_cloudgan_surface_config_and_state_dict_keys():
     assert list(small.state_dict().keys()) == want
     with pytest.raises(NotImplementedError):
         CloudGAN(generator_model="runet")
+
+
+def test_sanitizer_harness_covers_every_entry_point():
+    """tests/sanitize/harness.c (run under host ASan + UBSan by tools/sanitize_host.sh; log in profiles/) must exercise the argument
+    validation of EVERY int-returning sf_* entry of the header; SF_RUN_SANITIZER=1 re-runs the sanitizer build here (about a minute)."""
+    import subprocess
+
+    from satflow_amd import _hip
+
+    src = open(os.path.join(ROOT, "tests", "sanitize", "harness.c")).read()
+    entries = [n for n, (res, _) in _hip.PROTOTYPES.items() if n not in ("sf_abi_version", "sf_last_error_string") and not n.endswith(("_bytes", "_elems", "_floats", "_tiles"))]
+    missing = [n for n in entries if f"REFUSED({n}(" not in src]
+    assert not missing, f"entry points without a refusal case in the sanitizer harness: {missing}"
+    log = open(os.path.join(ROOT, "profiles", "r02_host_asan_ubsan.log")).read()
+    assert "0 not refused" in log and "exit code 0" in log and "ERROR: AddressSanitizer" not in log and "runtime error" not in log
+    if os.environ.get("SF_RUN_SANITIZER"):
+        r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), "/tmp/sf_host_sanitize.log"], capture_output=True, text=True, timeout=1200)
+        assert "0 not refused" in r.stdout and "exit code 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
