@@ -107,6 +107,25 @@ int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int
                          const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
                          sfTensor out, float* stats, int32_t dtype, sfStream stream);
 
+/* The DownSampler's BatchNorm2d -> Conv2d pairs (metnet.DownSampler: BatchNorm2d(160) -> Conv2d(160, 256) and twice
+ * BatchNorm2d(256) -> Conv2d(256, 256); call site satflow/models/pl_metnet.py:46-59) with the normalisation FOLDED into the
+ * convolution (training mode, SF_BF16 kernels): conv(a_g * x + b_g) = conv_{W * a_g}(x) + T_g[border class], so the normalised
+ * tensor is never written or read.
+ *   sf_conv3x3_fold_pack : from w [O][I][3][3], bias (nullable) and the BatchNorm's per-group scale / shift [groups][Kp] (as written
+ *       by sf_batchnorm_train_fwd[_stats] with y.ptr == NULL) -> `groups` packed weight images (sf_conv3x3_packed_elems each,
+ *       What = w[n][k][tap] * scale[g][k] rounded to bf16) and bias_tab [groups][9][Np] fp32: the bias plus the shift's contribution
+ *       What * (shift / scale) through the taps that lie inside the image for an output pixel of border class
+ *       3 * (top, interior, bottom) + (left, interior, right) - the same rounded weights as x sees, so that the mean part of x and
+ *       the shift cancel exactly as they do in the unfolded form
+ *   sf_conv3x3_fwd_folded : image i uses weight image i / (n / groups); stats nullable (as sf_conv3x3_fwd_stats).  h, w >= 2.
+ * The matching weight gradient is sf_conv3x3_bwd_weight_folded; the input gradient is the plain one (unscaled W) followed by
+ * sf_batchnorm_train_bwd. */
+int sf_conv3x3_fold_pack(const float* w, int32_t O, int32_t I, const int32_t* nmap, int32_t Np, const int32_t* kmap, int32_t Kp,
+                         int32_t nf, const float* bias, const float* scale, const float* shift, int32_t groups, void* packed,
+                         float* bias_tab, int32_t dtype, sfStream stream);
+int sf_conv3x3_fwd_folded(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_tab, int32_t Np,
+                          int32_t nf, int32_t groups, sfTensor out, float* stats, int32_t dtype, sfStream stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Fused ConvLSTM cell step.  Replaces ConvLSTMCell.forward,
  * satflow/models/layers/ConvLSTM.py:42-57 (cat -> conv -> split i,f,o,g -> sigmoid x3, tanh ->
@@ -150,6 +169,16 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
                           int32_t w, const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I,
                           float* dw, float* db, int32_t accumulate, void* workspace,
                           size_t workspace_bytes, int32_t dtype, sfStream stream);
+/* Weight gradient of a convolution whose input BatchNorm was folded (sf_conv3x3_fwd_folded): `src` is the tensor IN FRONT of the
+ * normalisation (bf16-stored), scale / shift [groups][src.c] the per-group affine map; with in = scale_g * src + shift_g inside the
+ * image (zero padding outside)
+ *   dW = sum_g scale_g[i] * dWraw_g[o][i][tap] + shift_g[i] * V_g[tap][o],   V_g = sum of dout over the group's pixels whose tap
+ * neighbour lies inside the image; db as above.  SF_BF16 kernels, bf16-stored src and dout, h, w >= 2, no image remap. */
+size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups);
+int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap,
+                                 const int32_t* kmap, int32_t O, int32_t I, const float* scale, const float* shift,
+                                 int32_t groups, float* dw, float* db, int32_t accumulate, void* workspace,
+                                 size_t workspace_bytes, int32_t dtype, sfStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout conversion at the module boundary (the reference keeps NCHW-style tensors throughout:
@@ -218,7 +247,8 @@ int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, in
  * time, so statistics are per call), biased variance, running stats updated group after group with
  * `momentum` (unbiased variance; momentum < 0 selects torch's cumulative average of momentum=None with
  * -momentum - 1 = batches tracked before this call).  Scratch: sums [groups][2][C] doubles; mean/rstd/scale/shift
- * [groups][C] floats (mean, rstd are what the backward needs).  creal = real channels of gamma/beta. */
+ * [groups][C] floats (mean, rstd are what the backward needs).  creal = real channels of gamma/beta.
+ * y.ptr == NULL: statistics, scale / shift and the running-stat update only (the apply is folded into the next convolution). */
 int sf_batchnorm_train_fwd(sfTensor x, int64_t pix_per_group, int32_t groups, int32_t creal,
                            const float* gamma, const float* beta, float eps, float momentum,
                            float* running_mean, float* running_var, float* mean, float* rstd,
@@ -243,7 +273,6 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
                            int32_t creal, const float* gamma, const float* mean, const float* rstd,
                            double* sums, float* coef /* scratch [groups][3][C] */, sfTensor dx,
                            float* dgamma, float* dbeta, int32_t dtype, sfStream stream);
-
 /* Lead-time de-duplication of MetNet's first convolution (ConditionTime planes are constant one-hot images and
  * conv1 is linear): with base = conv1_image(frame) + b computed ONCE per frame,
  *   pooled[(l*frames + f)] = maxpool2( base[f] + P_l ),  P_l[y][x][co] = sum of the in-image taps of w1[co][cimg + l]

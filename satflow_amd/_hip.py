@@ -34,6 +34,8 @@ PROTOTYPES = {
     "sf_conv3x3_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_conv3x3_stats_tiles": (_i32, [_i32, _i32]),
     "sf_conv3x3_fwd_stats": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, sfTensor, _vp, _i32, _vp]),
+    "sf_conv3x3_fold_pack": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
+    "sf_conv3x3_fwd_folded": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _vp, _i32, _vp]),
     "sf_convlstm_cell_fwd": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
@@ -46,6 +48,11 @@ PROTOTYPES = {
     "sf_conv3x3_bwd_weight": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp],
+    ),
+    "sf_conv3x3_bwd_weight_folded_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
+    "sf_conv3x3_bwd_weight_folded": (
+        C.c_int,
+        [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp],
     ),
     "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_metnet_preprocess_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),

@@ -94,6 +94,34 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+  // Folded BatchNorm (sf_conv3x3_fwd_folded): the accumulators START at the group's bias of each pixel's border class (the epilogue
+  // then adds no bias) - here, before the K loop, nothing else is live yet.
+  if constexpr (EPI == EPI_LINEAR && !DUAL) {
+    if (p.bias_tab) {
+      const float* tab = p.bias_tab + (size_t)(p.wgroup ? n / p.wgroup : 0) * 9 * p.np + nb * NB;
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+        if constexpr (TR) {  // lane = pixel r of the fragment; register 4g + c = channel 8g + 4kh + c
+          const float* t = tab + (size_t)border_cls(y0 + 4 * wave + 2 * mf + (r >> 4), x0 + (r & 15), p.H, p.W) * p.np + 4 * kh;
+#pragma unroll
+          for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 b = *reinterpret_cast<const f32x4*>(t + nf * 32 + 8 * g);
+#pragma unroll
+              for (int c = 0; c < 4; ++c) acc[mf][nf][4 * g + c] = b[c];
+            }
+        } else {  // lane = channel r; register = pixel frag_row(reg, kh) of the fragment
+#pragma unroll
+          for (int reg = 0; reg < 16; ++reg) {
+            const int rr = frag_row(reg, kh);
+            const float* t = tab + (size_t)border_cls(y0 + 4 * wave + 2 * mf + (rr >> 4), x0 + (rr & 15), p.H, p.W) * p.np + r;
+#pragma unroll
+            for (int nf = 0; nf < NF; ++nf) acc[mf][nf][reg] = t[nf * 32];
+          }
+        }
+    }
+  }
 
   const int ch0 = p.src0 ? p.c0 / KC : 0;
   const int ch1 = p.src1 ? p.c1 / KC : 0;
@@ -131,7 +159,8 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     }
   }
   // weights: descriptor over this N block's packed image; the chunk and the 1 KiB piece go into the scalar offset
-  rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wp + (size_t)nb * p.chunks_total * W_B), 0, p.chunks_total * W_B, 0x00020000);
+  const long long wgrp = (!DUAL && p.wgroup) ? (long long)(n / p.wgroup) * p.wgroup_bytes : 0;  // grouped weights: this image's packed image
+  rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wp + wgrp + (size_t)nb * p.chunks_total * W_B), 0, p.chunks_total * W_B, 0x00020000);
 
   auto issue_weights = [&](int ci, int buf) {
     const int chunk = ci < ch0 ? ci : c0_chunks + (ci - ch0);
@@ -321,12 +350,13 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
 // ---- weight repack (bf16 LDS image) ----------------------------------------------------------
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int I, const int* __restrict__ nmap, int Np,
                                          const int* __restrict__ kmap, int Kp, int NB, int transpose, __bf16* __restrict__ packed,
-                                         const float* __restrict__ bias, float* __restrict__ bias_packed) {
-  const size_t total = (size_t)Np * Kp * 9;
+                                         const float* __restrict__ bias, float* __restrict__ bias_packed, const float* __restrict__ kscale, int groups) {
+  const size_t image = (size_t)Np * Kp * 9, total = image * groups;
   const int chunks = Kp / KC;
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
-    // logical element e -> [nblk][chunk][tap][row][k16]
-    size_t t = e;
+    // logical element e -> [group][nblk][chunk][tap][row][k16]
+    const int grp = (int)(e / image);
+    size_t t = e - grp * image;
     const int k16 = t % KC; t /= KC;
     const int row = t % NB; t /= NB;
     const int tap = t % 9; t /= 9;
@@ -336,6 +366,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int
     const int kk = kmap[chunk * KC + k16];
     float v = 0.f;
     if (nn >= 0 && kk >= 0) v = transpose ? w[((size_t)kk * I + nn) * 9 + (8 - tap)] : w[((size_t)nn * I + kk) * 9 + tap];
+    if (kscale) v *= kscale[(size_t)grp * Kp + chunk * KC + k16];
     // physical position: the two 8-element halves of a row are swapped on rows with bit 3 set
     const int half = (k16 >> 3) ^ ((row >> 3) & 1);
     const size_t base = e - k16;
@@ -413,9 +444,9 @@ int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, 
 }
 
 void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
-                          void* packed, const float* bias, float* bias_packed, hipStream_t st) {
-  const size_t total = (size_t)Np * Kp * 9;
+                          void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale, int groups) {
+  const size_t total = (size_t)Np * Kp * 9 * groups;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, O, I, nmap, Np, kmap, Kp, NB, transpose,
-                     (__bf16*)packed, bias, bias_packed);
+                     (__bf16*)packed, bias, bias_packed, kscale, groups);
 }

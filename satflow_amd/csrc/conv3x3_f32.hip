@@ -166,6 +166,52 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int O, int 
     }
 }
 
+// Folded BatchNorm: the constant part of conv(a*x + b) per border class.  An output pixel in row class rc (0 top, 1 interior,
+// 2 bottom) and column class cc sees the taps whose input pixel lies inside the image; the shift b reaches it only through those.
+// The shift goes through the SAME rounded weights as x does - conv(a*x + b) = conv_{W*a}(x + b/a), What = bf16(W*a) as packed:
+//   table[g][rc*3+cc][n] = bias[n] + sum over valid taps, k  What[g][n][k][tap] * (shift[g][k] / scale[g][k])
+// With exact weights for the shift the two halves would not cancel: sum_px What*x - W*a*mean*N leaves (What - W*a) * mean(x), an
+// offset common to all pixels of a channel (about 2^-9 * mean/std of the output's std: invisible per pixel, but it IS the error of
+// the next BatchNorm's running mean).  scale == 0 (gamma == 0): the channel contributes w * shift exactly.
+// One workgroup per output lane n: its weight row (I x 9 floats, contiguous in OIHW) goes to LDS once, thread (g, tap) forms the
+// per-tap sum over k (fp32, fixed order), thread (g, class) adds the valid taps.
+__global__ __launch_bounds__(256) void fold_bias_table_kernel(const float* __restrict__ w, int I, const int* __restrict__ nmap, int Np,
+                                                             const int* __restrict__ kmap, int Kp, const float* __restrict__ bias,
+                                                             const float* __restrict__ scale, const float* __restrict__ shift, int groups,
+                                                             float* __restrict__ table) {
+  extern __shared__ float sh[];  // [I * 9] weight row | [groups * 9] per-tap sums
+  float* wrow = sh;
+  float* tsum = sh + I * 9;
+  const int n = blockIdx.x, nn = nmap[n];
+  if (nn >= 0)
+    for (int e = threadIdx.x; e < I * 9; e += 256) wrow[e] = w[(size_t)nn * I * 9 + e];
+  __syncthreads();
+  for (int gt = threadIdx.x; gt < groups * 9; gt += 256) {
+    const int g = gt / 9, tap = gt - g * 9;
+    float t = 0.f;
+    if (nn >= 0)
+      for (int k = 0; k < Kp; ++k) {
+        const int kk = kmap[k];
+        if (kk < 0) continue;
+        const float wv = wrow[kk * 9 + tap], a = scale[(size_t)g * Kp + k], b = shift[(size_t)g * Kp + k];
+        t = a != 0.f ? __builtin_fmaf((float)(__bf16)(wv * a), b / a, t) : __builtin_fmaf(wv, b, t);
+      }
+    tsum[gt] = t;
+  }
+  __syncthreads();
+  const float b0 = (bias && nn >= 0) ? bias[nn] : 0.f;
+  for (int gc = threadIdx.x; gc < groups * 9; gc += 256) {
+    const int g = gc / 9, cls = gc - g * 9, rc = cls / 3, cc = cls - rc * 3;
+    float s = b0;
+    for (int ky = 0; ky < 3; ++ky)
+      for (int kx = 0; kx < 3; ++kx) {
+        const bool valid = !(rc == 0 && ky == 0) && !(rc == 2 && ky == 2) && !(cc == 0 && kx == 0) && !(cc == 2 && kx == 2);
+        if (valid) s += tsum[g * 9 + ky * 3 + kx];
+      }
+    table[((size_t)g * 9 + cls) * Np + n] = s;
+  }
+}
+
 template <int EPI>
 int launch_conv(const ConvParams& p, int nf, int nblk, hipStream_t st) {
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
@@ -208,7 +254,7 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
 
 static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
                             const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, float* stats, int32_t dtype,
-                            sfStream stream) {
+                            sfStream stream, int32_t fold_groups = 0) {
   SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_fwd: dtype %d not built", dtype);
   if (check_src(src0, "conv3x3 src0") || check_src(src1, "conv3x3 src1")) return 1;
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && out.c <= Np, "conv3x3: bad Np=%d nf=%d out.c=%d", Np, nf, out.c);
@@ -224,6 +270,10 @@ static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, 
   SF_REQUIRE(dtype == SF_BF16 || !(p.bf0 || p.bf1 || p.out_bf), "conv3x3: bf16-stored tensors need the SF_BF16 kernel");
   SF_REQUIRE(!stats || (dtype == SF_BF16 && epilogue == SF_EPI_LINEAR), "conv3x3: output statistics need the SF_BF16 kernel with the linear epilogue");
   p.stats = stats; p.stats_np = Np;
+  if (fold_groups) {  // bias_packed is the [groups][9][Np] border-class table, wpacked holds one image per group
+    p.bias = nullptr; p.bias_tab = bias_packed; p.np = Np;
+    p.wgroup = n / fold_groups; p.wgroup_bytes = (long long)Np * (src0.c + src1.c) * 9 * 2;
+  }
   if (dtype == SF_BF16) {
     SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
     // the SF_BF16 kernel stores 16-byte channel quads (fp32) / octets (bf16) per pixel
@@ -251,6 +301,32 @@ int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int
                          sfStream stream) {
   SF_REQUIRE(stats != nullptr, "sf_conv3x3_fwd_stats: stats must not be null");
   return conv3x3_fwd_impl(src0, src1, n, h, w, wpacked, bias_packed, Np, nf, SF_EPI_LINEAR, out, stats, dtype, stream);
+}
+
+int sf_conv3x3_fold_pack(const float* w, int32_t O, int32_t I, const int32_t* nmap, int32_t Np, const int32_t* kmap, int32_t Kp,
+                         int32_t nf, const float* bias, const float* scale, const float* shift, int32_t groups, void* packed,
+                         float* bias_tab, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_fold_pack: dtype %d not built (SF_BF16 kernels only)", dtype);
+  SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && Kp % KC == 0 && groups >= 1, "fold_pack: Np=%d nf=%d Kp=%d groups=%d", Np, nf, Kp, groups);
+  SF_REQUIRE(w && scale && shift && packed && bias_tab && ((uintptr_t)bias_tab & 15) == 0, "fold_pack: null / misaligned argument");
+  sf_pack_weights_bf16(w, O, I, nmap, Np, kmap, Kp, 32 * nf, 0, packed, nullptr, nullptr, (hipStream_t)stream, scale, groups);
+  SF_CHECK_LAUNCH("pack_weights_bf16 (grouped)");
+  SF_REQUIRE((size_t)(I + groups) * 9 * sizeof(float) <= 64 * 1024, "fold_pack: I=%d, groups=%d exceed the table kernel's LDS", I, groups);
+  hipLaunchKernelGGL(fold_bias_table_kernel, dim3(Np), dim3(256), (size_t)(I + groups) * 9 * sizeof(float), (hipStream_t)stream, w, I, nmap, Np, kmap,
+                     Kp, bias, scale, shift, groups, bias_tab);
+  SF_CHECK_LAUNCH("fold_bias_table");
+  return 0;
+}
+
+int sf_conv3x3_fwd_folded(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_tab, int32_t Np, int32_t nf,
+                          int32_t groups, sfTensor out, float* stats, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_fwd_folded: dtype %d not built (SF_BF16 kernels only)", dtype);
+  SF_REQUIRE(groups >= 1 && n % groups == 0 && h >= 2 && w >= 2, "fwd_folded: n=%d must split into %d groups of whole images, h, w >= 2", n, groups);
+  SF_REQUIRE(bias_tab && ((uintptr_t)bias_tab & 15) == 0, "fwd_folded: bias_tab null / not 16-byte aligned");
+  // images of at most 16x16 pixels could take the two-images-per-workgroup kernel, which has one weight stream: not with per-group weights
+  SF_REQUIRE(h > 16 || stats || nf < 4 || n < 512, "fwd_folded: this shape dispatches to the two-image tile kernel (no grouped weights)");
+  sfTensor none{nullptr, 0, 0, 0, 0, 0};
+  return conv3x3_fwd_impl(src, none, n, h, w, wpacked, bias_tab, Np, nf, SF_EPI_LINEAR, out, stats, dtype, stream, groups);
 }
 
 int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n, int32_t h, int32_t w,

@@ -60,13 +60,25 @@ __device__ __forceinline__ bf16x8 cat8(bf16x4_t a, bf16x4_t b) { return __builti
 // range check writes zeros to its LDS slot (tools/ubench/buf_lds_oob.hip) - one v_cndmask per instruction instead of a
 // 64-bit address per lane.  M0 is not used by anything else in this kernel (no compiler-issued LDS-DMA), so it is not saved.
 __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
-  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");
+  // (readfirstlane: the values are wave-uniform, but the compiler may hold them in vector registers)
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds" ::"v"(voff), "s"(rs), "s"(__builtin_amdgcn_readfirstlane(lds_dst)),
+               "s"(__builtin_amdgcn_readfirstlane(soff)) : "memory");
+}
+
+// wave-uniform pointer the compiler may have computed on the vector ALU -> scalar registers (inline asm "s" operands are not legalised)
+__device__ __forceinline__ void* uniform_ptr(const void* q) {
+  const uintptr_t v = (uintptr_t)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (void*)(((uintptr_t)hi << 32) | lo);
 }
 
 // FAST: every 64-channel input tile of the block comes from ONE source (single source, or c0 a multiple of 64): DMA through
 // buffer descriptors with kernel-constant lane offsets.  Otherwise (the ConvLSTM's 16-lane x source in front of h) per-lane
 // 64-bit addresses.
-template <bool FAST>
+// GROUPED (folded BatchNorm, sf_conv3x3_bwd_weight_folded): the images come in groups of p.tpg tiles whose raw gradients are
+// scaled differently afterwards, so a slice that crosses a group boundary stores its accumulators there (segment 0, 1, ...
+// of the slice: partial[ks * maxseg + seg]) and starts again from zero.
+template <bool FAST, bool GROUPED = false>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
                                                                      const int xcd_groups) {
   __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
@@ -191,7 +203,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     const unsigned cls = (nx_ty == 0 ? 1u : 0u) | (nx_ty == p.tiles_y - 1 ? 2u : 0u) | (nx_tx == 0 ? 4u : 0u) | (nx_tx == p.tiles_x - 1 ? 8u : 0u);
     const unsigned sel = live ? 1u << cls : 0u;  // dead tiles (past the slice's end) fetch zeros: the DMA counts stay exact
     const unsigned stage = lds0 + (unsigned)(nx_stage * STAGE);
-    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.dout + n * a_img), 0, (int)a_img, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.dout + n * a_img), 0, __builtin_amdgcn_readfirstlane((int)a_img), 0x00020000);
     const unsigned soa = (unsigned)px0 * (unsigned)a_pxb;
 #pragma unroll
     for (int u = 0; u < 2; ++u) bufdma16((fa_mask[u] & sel) ? fa_off[u] : SENT, rsa, soa, stage + (wave + 8 * u) * 1024);
@@ -199,7 +211,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     if (remap) { ns = n / bidiv; if (bimod) ns %= bimod; }
     // descriptor starts one image row + one pixel BEFORE the image so that the halo origin has a non-negative offset
     const long long lead = (long long)(p.W + 1) * b_pxb;
-    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)bsrc + ns * b_img - lead), 0, (int)(b_img + 2 * lead), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)bsrc + ns * b_img - lead), 0, __builtin_amdgcn_readfirstlane((int)(b_img + 2 * lead)), 0x00020000);
     const unsigned sob = (unsigned)px0 * b_pxb;
 #pragma unroll
     for (int u = 0; u < 2; ++u) bufdma16((fb_mask[u] & sel) ? fb_off[u] : SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
@@ -322,31 +334,52 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) aB[kx] = nB[kx];
   };
+  // partial[slot][tap][co][ci], slot = ks (or ks * maxseg + segment)
+  const int r = lane & 31, kh = lane >> 5;
+  auto store_partial = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = cot * DMA_CO_T + 32 * wq + frag_row(reg, kh);
+        const int ci = cit * DMA_CI_T + 32 * wc + r;
+        p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
+      }
+    if (want_bias) {
+      const float tot = bsum + __shfl_xor(bsum, 32);
+      if (kh == 0) p.partial_db[(size_t)slot * p.NpT + cot * DMA_CO_T + 32 * wq + r] = tot;
+    }
+  };
+  int seg = 0, next_flush = 0x7fffffff;
+  if constexpr (GROUPED) next_flush = p.tpg - t_begin % p.tpg;  // tiles until this slice's first group boundary
+  auto group_boundary = [&](int i) __attribute__((always_inline)) {  // block-uniform
+    if constexpr (GROUPED) {
+      if (__builtin_expect(i == next_flush, 0)) {
+        store_partial(ks * p.maxseg + seg);
+        ++seg; next_flush += p.tpg;
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+        bsum = 0.f;
+        // stores and loads retire out of order with each other: with stores pending the counted waits of the ring would no longer
+        // mean "tile landed" - drain everything once (the ring refills within a tile)
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      }
+    }
+  };
   for (int i = 0; i < my_tiles; i += 2) {
+    group_boundary(i);
     tile(arow_a, arow_b);
-    if (i + 1 < my_tiles) tile(arow_b, arow_a);
+    if (i + 1 < my_tiles) { group_boundary(i + 1); tile(arow_b, arow_a); }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // nothing of the (dummy) tail may land after the block has retired
-
-  // partial[ks][tap][co][ci]
-  const int r = lane & 31, kh = lane >> 5;
-#pragma unroll
-  for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-    for (int reg = 0; reg < 16; ++reg) {
-      const int co = cot * DMA_CO_T + 32 * wq + frag_row(reg, kh);
-      const int ci = cit * DMA_CI_T + 32 * wc + r;
-      p.partial[(((size_t)ks * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
-    }
-  if (want_bias) {
-    const float tot = bsum + __shfl_xor(bsum, 32);
-    if (kh == 0) p.partial_db[(size_t)ks * p.NpT + cot * DMA_CO_T + 32 * wq + r] = tot;
-  }
+  store_partial(GROUPED ? ks * p.maxseg + seg : ks);
 }
 
 }  // namespace
 
-sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w) {
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups) {
   using namespace sfwgrad;
   Plan pl;
   pl.tiles_x = (w + TW - 1) / TW;
@@ -363,7 +396,16 @@ sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w) {
   while (ks > 8 && (pl.ntiles + ks - 1) / ks < per_min) ks -= 8;
   if (ks > pl.ntiles) ks = pl.ntiles > 0 ? pl.ntiles : 1;
   pl.KS = ks;
-  pl.ws_floats = (size_t)pl.KS * ((size_t)9 * pl.cot * DMA_CO_T * pl.cit * DMA_CI_T + (size_t)pl.cot * DMA_CO_T) + 64;  // + the zero page
+  pl.tpg = 0; pl.maxseg = 1;
+  if (groups > 0) {  // segments a slice can need: the groups it touches
+    pl.tpg = pl.ntiles / groups;
+    const int per = (pl.ntiles + ks - 1) / ks;
+    for (int k = 0; k < ks && pl.tpg > 0; ++k) {
+      const int b = k * per, e = (b + per < pl.ntiles ? b + per : pl.ntiles) - 1;
+      if (e >= b && e / pl.tpg - b / pl.tpg + 1 > pl.maxseg) pl.maxseg = e / pl.tpg - b / pl.tpg + 1;
+    }
+  }
+  pl.ws_floats = (size_t)pl.KS * pl.maxseg * ((size_t)9 * pl.cot * DMA_CO_T * pl.cit * DMA_CI_T + (size_t)pl.cot * DMA_CO_T) + 64;  // + the zero page
   return pl;
 }
 
@@ -384,11 +426,15 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   // workspace: [zero page 64 floats][partial][partial_db]
   if (hipMemsetAsync(workspace, 0, 64 * sizeof(float), st) != hipSuccess) { sf_set_error("wgrad_bf16_dma: memset failed"); return 2; }
   p.partial = workspace + 64;
-  p.partial_db = p.partial + (size_t)pl.KS * 9 * p.NpT * p.KpT;
+  p.partial_db = p.partial + (size_t)pl.KS * pl.maxseg * 9 * p.NpT * p.KpT;
+  p.tpg = pl.tpg; p.maxseg = pl.maxseg;
   const int per_slice = (pl.ntiles + pl.KS - 1) / pl.KS;
   const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
   const bool fast = !(p.src0 && p.src1 && p.c1 > 0) || p.c0 % DMA_CI_T == 0;
-  if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
+  if (pl.tpg > 0) {
+    if (!fast) { sf_set_error("wgrad_bf16_dma: grouped slices need a single input source"); return 1; }
+    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
+  } else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
   else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("wgrad_bf16_dma: launch failed: %s", hipGetErrorString(e)); return 2; }

@@ -149,9 +149,242 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ partial, const flo
   }
 }
 
+// ---- folded BatchNorm (sf_conv3x3_bwd_weight_folded): dW = sum_g scale_g (.) dWraw_g + shift_g (x) V_g ----
+// V_g[tap][co] = sum of dout over the group's pixels whose tap neighbour lies inside the image = total - excluded border row -
+// excluded border column + their corner.  The border sums are taken here from the bf16 dout (about 12 % of the tensor at 32x32),
+// the group totals come from the main kernel's per-segment bias sums.
+constexpr int BORDER_CATS = 8;  // top row, bottom row, left column, right column, corners TL, TR, BL, BR
+constexpr int BORDER_IMGS = 2;  // images per workgroup (their loads are independent: both in flight)
+__global__ __launch_bounds__(256) void fold_border_sums_kernel(const __bf16* __restrict__ dout, int ds, int Np, int H, int W, int imgs_per_group,
+                                                              int chunks, float* __restrict__ bpart) {
+  // block = (chunk of BORDER_IMGS images, group); thread = (pixel lane, channel octet); bpart[group][chunk][cat][Np]
+  extern __shared__ float red[];  // [pixel lanes][8 cats][Np]
+  typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+  const int oct = Np / 8, plx = 256 / oct;  // Np <= 2048 (launcher)
+  const int o = threadIdx.x % oct, pl = threadIdx.x / oct;
+  const int g = blockIdx.y, chunk = blockIdx.x;
+  const int nb = 2 * W + 2 * (H - 2);  // border pixels of an image
+  float acc[BORDER_CATS][8];
+#pragma unroll
+  for (int c = 0; c < BORDER_CATS; ++c)
+#pragma unroll
+    for (int k = 0; k < 8; ++k) acc[c][k] = 0.f;
+  const int i0 = chunk * BORDER_IMGS;
+  const size_t img_e = (size_t)H * W * ds;
+  const __bf16* base = dout + (size_t)(g * imgs_per_group + i0) * img_e + 8 * o;
+  const bf16x8_t zero = {0, 0, 0, 0, 0, 0, 0, 0};
+  if (pl < plx)
+#pragma unroll 2
+    for (int b = pl; b < nb; b += plx) {
+      int y, x;
+      if (b < W) { y = 0; x = b; }
+      else if (b < 2 * W) { y = H - 1; x = b - W; }
+      else { const int q = b - 2 * W; y = 1 + (q >> 1); x = (q & 1) ? W - 1 : 0; }
+      bf16x8_t v[BORDER_IMGS];
+#pragma unroll
+      for (int im = 0; im < BORDER_IMGS; ++im)
+        v[im] = i0 + im < imgs_per_group ? *reinterpret_cast<const bf16x8_t*>(base + im * img_e + (size_t)(y * W + x) * ds) : zero;
+      const float top = y == 0 ? 1.f : 0.f, bot = y == H - 1 ? 1.f : 0.f, lef = x == 0 ? 1.f : 0.f, rig = x == W - 1 ? 1.f : 0.f;
+      const float m[BORDER_CATS] = {top, bot, lef, rig, top * lef, top * rig, bot * lef, bot * rig};
+#pragma unroll
+      for (int k = 0; k < 8; ++k) {
+        float f = 0.f;
+#pragma unroll
+        for (int im = 0; im < BORDER_IMGS; ++im) f += (float)v[im][k];
+#pragma unroll
+        for (int c = 0; c < BORDER_CATS; ++c) acc[c][k] = __builtin_fmaf(m[c], f, acc[c][k]);
+      }
+    }
+  // fixed-order reduction over the pixel lanes
+  if (pl < plx)
+#pragma unroll
+    for (int c = 0; c < BORDER_CATS; ++c)
+#pragma unroll
+      for (int k = 0; k < 8; ++k) red[((size_t)pl * BORDER_CATS + c) * Np + 8 * o + k] = acc[c][k];
+  __syncthreads();
+  for (int e = threadIdx.x; e < BORDER_CATS * Np; e += 256) {
+    float s = 0.f;
+    for (int q = 0; q < plx; ++q) s += red[(size_t)q * BORDER_CATS * Np + e];
+    bpart[((size_t)g * chunks + chunk) * BORDER_CATS * Np + e] = s;
+  }
+}
+
+// V_g[tap][co] from the group totals (per-segment bias sums of the main kernel) and the border sums; also the slot table of the
+// reduction: slot (ks, seg) of the grouped main kernel belongs to group (ks * per_slice) / tpg + seg, unused slots get -1.
+// block = (32 channels, group), 8 parts x 32 channels: the parts split the slices / chunks, fixed-order combine through LDS.
+__global__ __launch_bounds__(256) void fold_v_kernel(const float* __restrict__ partial_db, int KS, int maxseg, int per_slice, int ntiles, int tpg,
+                                                    int NpT, const float* __restrict__ bpart, int chunks, int Np, int groups,
+                                                    float* __restrict__ V, int* __restrict__ slot_group) {
+  __shared__ float red[8][BORDER_CATS + 1][32];
+  const int lc = threadIdx.x & 31, part = threadIdx.x >> 5;
+  const int co = blockIdx.x * 32 + lc, g = blockIdx.y;
+  if (blockIdx.x == 0 && g == 0)
+    for (int s = threadIdx.x; s < KS * maxseg; s += 256) {
+      const int ks = s / maxseg, seg = s - ks * maxseg, b = ks * per_slice;
+      int gg = -1;
+      if (b < ntiles) {
+        const int e = (b + per_slice < ntiles ? b + per_slice : ntiles) - 1;
+        if (seg <= e / tpg - b / tpg) gg = b / tpg + seg;
+      }
+      slot_group[s] = gg;
+    }
+  float S = 0.f;
+  for (int ks = part; ks < KS; ks += 8) {
+    const int b = ks * per_slice;
+    if (b >= ntiles) break;
+    const int e = (b + per_slice < ntiles ? b + per_slice : ntiles) - 1;
+    const int g0 = b / tpg, g1 = e / tpg;
+    if (g >= g0 && g <= g1) S += partial_db[((size_t)ks * maxseg + (g - g0)) * NpT + co];
+  }
+  red[part][BORDER_CATS][lc] = S;
+#pragma unroll
+  for (int c = 0; c < BORDER_CATS; ++c) {
+    float s = 0.f;
+    if (co < Np)
+      for (int q = part; q < chunks; q += 8) s += bpart[(((size_t)g * chunks + q) * BORDER_CATS + c) * Np + co];
+    red[part][c][lc] = s;
+  }
+  __syncthreads();
+  if (part != 0) return;
+  float B[BORDER_CATS + 1];
+#pragma unroll
+  for (int c = 0; c <= BORDER_CATS; ++c) {
+    float s = 0.f;
+#pragma unroll
+    for (int q = 0; q < 8; ++q) s += red[q][c][lc];
+    B[c] = s;
+  }
+  S = B[BORDER_CATS];
+#pragma unroll
+  for (int ky = 0; ky < 3; ++ky)
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      // tap (ky, kx) reads the input at (y + ky - 1, x + kx - 1): excluded are the top row for ky == 0, the bottom row for ky == 2, ...
+      float v = S;
+      if (ky == 0) v -= B[0];
+      if (ky == 2) v -= B[1];
+      if (kx == 0) v -= B[2];
+      if (kx == 2) v -= B[3];
+      if (ky == 0 && kx == 0) v += B[4];
+      if (ky == 0 && kx == 2) v += B[5];
+      if (ky == 2 && kx == 0) v += B[6];
+      if (ky == 2 && kx == 2) v += B[7];
+      V[((size_t)g * 9 + ky * 3 + kx) * NpT + co] = v;
+    }
+}
+
+__global__ void wgrad_reduce_folded_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db, int slots,
+                                           const int* __restrict__ slot_group, int groups, int NpT, int KpT, int Np, int Kp,
+                                           const int* __restrict__ nmap, const int* __restrict__ kmap, int I,
+                                           const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ V,
+                                           float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+  const size_t slab = (size_t)9 * NpT * KpT;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid < slab) {
+    const int ci = gid % KpT;
+    const int co = (gid / KpT) % NpT;
+    const int tap = gid / ((size_t)KpT * NpT);
+    if (co < Np && ci < Kp) {
+      const int o = nmap[co], i = kmap[ci];
+      if (o >= 0 && i >= 0) {
+        // fixed order: slots ascending over eight chains (the slot table is wave-uniform: scalar loads and branches)
+        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        int s = 0;
+        for (; s + 8 <= slots; s += 8) {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) {
+            const int g = slot_group[s + u];
+            if (g >= 0) s8[u] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)(s + u) * slab + gid], s8[u]);
+          }
+        }
+        for (; s < slots; ++s) {
+          const int g = slot_group[s];
+          if (g >= 0) s8[0] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)s * slab + gid], s8[0]);
+        }
+        float r = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+        float t = 0.f;
+        for (int g = 0; g < groups; ++g) t = __builtin_fmaf(shift[(size_t)g * Kp + ci], V[((size_t)g * 9 + tap) * NpT + co], t);
+        r += t;
+        float* d = dw + ((size_t)o * I + i) * 9 + tap;
+        *d = accumulate ? *d + r : r;
+      }
+    }
+  }
+  if (db && gid < (size_t)NpT) {
+    const int co = (int)gid;
+    if (co < Np && nmap[co] >= 0) {
+      float r = 0.f;
+      for (int s = 0; s < slots; ++s)
+        if (slot_group[s] >= 0) r += partial_db[(size_t)s * NpT + co];
+      float* d = db + nmap[co];
+      *d = accumulate ? *d + r : r;
+    }
+  }
+}
+
+struct FoldLayout { int chunks; size_t bpart_off, v_off, slot_off, total_floats; };
+inline FoldLayout fold_layout(const Plan& pl, int Np, int n, int groups) {
+  FoldLayout f;
+  f.chunks = (n / groups + BORDER_IMGS - 1) / BORDER_IMGS;
+  f.bpart_off = pl.ws_floats;
+  f.v_off = f.bpart_off + (size_t)groups * f.chunks * BORDER_CATS * Np;
+  f.slot_off = f.v_off + (size_t)groups * 9 * pl.cot * DMA_CO_T;
+  f.total_floats = f.slot_off + (size_t)pl.KS * pl.maxseg;
+  return f;
+}
+
 }  // namespace
 
 extern "C" {
+
+size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups) {
+  if (groups < 1 || n % groups) return 0;
+  return fold_layout(sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups), Np, n, groups).total_floats * sizeof(float);
+}
+
+int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
+                                 int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
+                                 int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16 && src.ptr && dout.ptr && src.dtype == SF_BF16 && dout.dtype == SF_BF16,
+             "sf_conv3x3_bwd_weight_folded: bf16-stored tensors and the SF_BF16 kernels only");
+  SF_REQUIRE(groups >= 1 && n % groups == 0 && h >= 2 && w >= 2, "bwd_weight_folded: n=%d must split into %d groups of whole images, h, w >= 2", n, groups);
+  SF_REQUIRE(src.c % SF_CPAD == 0 && dout.c % 8 == 0 && dout.c <= 2048 && src.idiv <= 1 && src.imod <= 0, "bwd_weight_folded: channel padding / no image remap");
+  SF_REQUIRE(scale && shift && dw, "bwd_weight_folded: null argument");
+  const int Np = dout.c, Kp = src.c;
+  const Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups);
+  const FoldLayout fl = fold_layout(pl, Np, n, groups);
+  SF_REQUIRE(workspace && workspace_bytes >= fl.total_floats * sizeof(float), "bwd_weight_folded: workspace too small (%zu < %zu)", workspace_bytes,
+             fl.total_floats * sizeof(float));
+  hipStream_t st = (hipStream_t)stream;
+  WgradParams p{};
+  p.bf = 1; p.bf_dout = 1;
+  p.src0 = (const float*)src.ptr; p.c0 = src.c; p.s0 = src.stride;
+  p.idiv0 = p.idiv1 = 1;
+  p.dout = (const float*)dout.ptr; p.dc = dout.c; p.ds = dout.stride;
+  p.N = n; p.H = h; p.W = w;
+  if (int rc = sf_launch_wgrad_bf16_dma(p, pl, (float*)workspace, st)) return rc;
+  float* bpart = (float*)workspace + fl.bpart_off;
+  float* V = (float*)workspace + fl.v_off;
+  {
+    const int oct = Np / 8, plx = 256 / oct > 0 ? 256 / oct : 1;
+    SF_REQUIRE(oct <= 256, "bwd_weight_folded: Np=%d too wide", Np);
+    const size_t shmem = sizeof(float) * plx * BORDER_CATS * Np;
+    hipLaunchKernelGGL(fold_border_sums_kernel, dim3(fl.chunks, groups), dim3(256), shmem, st, (const __bf16*)dout.ptr, dout.stride, Np, h, w, n / groups,
+                       fl.chunks, bpart);
+    SF_CHECK_LAUNCH("fold_border_sums");
+  }
+  const int per_slice = (pl.ntiles + pl.KS - 1) / pl.KS;
+  int* slot_group = (int*)((float*)workspace + fl.slot_off);
+  hipLaunchKernelGGL(fold_v_kernel, dim3(p.NpT / 32, groups), dim3(256), 0, st, p.partial_db, pl.KS, pl.maxseg, per_slice, pl.ntiles, pl.tpg,
+                     p.NpT, bpart, fl.chunks, Np, groups, V, slot_group);
+  SF_CHECK_LAUNCH("fold_v");
+  const size_t slab = (size_t)9 * p.NpT * p.KpT;
+  hipLaunchKernelGGL(wgrad_reduce_folded_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, p.partial, p.partial_db,
+                     pl.KS * pl.maxseg, slot_group, groups, p.NpT, p.KpT, Np, Kp, nmap, kmap, I, scale, shift, V, dw, db, accumulate);
+  SF_CHECK_LAUNCH("wgrad_reduce_folded");
+  (void)O;
+  return 0;
+}
 
 size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w) {
   // the loader-wave bf16 variant uses taller K tiles, i.e. never more tiles / a larger KS than this plan; the all-bf16-storage

@@ -35,7 +35,17 @@ struct ConvParams {
   int hout_bf;   // lstm epilogue (bf16 kernel): the new hidden state is stored as bf16 (it is only ever read as an MFMA operand)
   // bf16 kernel, linear epilogue: per-tile sum / sum of squares of the stored outputs, [tile][stats_np][2] (or null)
   float* stats; int stats_np;
+  // bf16 kernel, linear epilogue, single-image tiles: GROUPED weights - image n uses the packed image n / wgroup (0 = one image
+  // for all) - and a per-group bias that depends on the pixel's border class (top / interior / bottom x left / interior / right):
+  // the folded BatchNorm in front of this convolution (sf_conv3x3_fwd_folded).  `bias` is null then.
+  int wgroup; long long wgroup_bytes;
+  const float* bias_tab; int np;  // [groups][9][np] or null
 };
+
+// border class of an output pixel (needs H, W >= 2); pixels outside the image (ragged tiles) get some valid class
+__device__ __forceinline__ int border_cls(int py, int px, int H, int W) {
+  return (py == 0 ? 0 : (py >= H - 1 ? 2 : 1)) * 3 + (px == 0 ? 0 : (px >= W - 1 ? 2 : 1));
+}
 
 
 // acc[mf][nf][reg]: wave `wave` owns tile rows 4*wave..4*wave+3; M fragment mf = rows 2*mf, 2*mf+1 (16 px each).
@@ -364,5 +374,6 @@ inline int check_src(const sfTensor& t, const char* name) {
 int sf_conv_bf16_tiles(int h, int w);
 // bf16-MFMA launcher (conv3x3_bf16.hip); epi is one of sfconv::EPI_*
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
+// kscale (nullable): [groups][Kp] per-input-lane factors -> `groups` packed images back to back (folded BatchNorm scale)
 void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
-                          void* packed, const float* bias, float* bias_packed, hipStream_t st);
+                          void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale = nullptr, int groups = 1);

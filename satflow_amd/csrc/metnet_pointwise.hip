@@ -545,7 +545,9 @@ static int bn_train_fwd_impl(sfTensor x, int64_t pix_per_group, int32_t groups, 
                              float eps, float momentum, float* running_mean, float* running_var, float* mean, float* rstd,
                              float* scale, float* shift, double* sums, const float* stats, int32_t tiles_per_group, int32_t stats_np,
                              sfTensor y, hipStream_t st) {
-  SF_REQUIRE(x.c == y.c && ok8(x) && ok8(y) && creal <= x.c && x.dtype == y.dtype, "batchnorm: channels (multiple of 8, 16-byte aligned) / storage type");
+  // y.ptr == null: statistics, scale / shift and the running-stat update only (the apply is folded into the consuming convolution,
+  // sf_conv3x3_fwd_folded)
+  SF_REQUIRE(ok8(x) && creal <= x.c && (!y.ptr || (x.c == y.c && ok8(y) && x.dtype == y.dtype)), "batchnorm: channels (multiple of 8, 16-byte aligned) / storage type");
   if (stats) {
     SF_REQUIRE(tiles_per_group > 0 && stats_np >= x.c, "batchnorm: tiles_per_group=%d stats_np=%d", tiles_per_group, stats_np);
     hipLaunchKernelGGL(bn_sum_tiles_kernel, dim3((x.c + 31) / 32, groups), dim3(256), 0, st, stats, tiles_per_group, stats_np, x.c, sums);
@@ -557,6 +559,7 @@ static int bn_train_fwd_impl(sfTensor x, int64_t pix_per_group, int32_t groups, 
   hipLaunchKernelGGL(bn_finalize_kernel, dim3((x.c + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, (double)pix_per_group, eps,
                      momentum, gamma, beta, mean, rstd, scale, shift, running_mean, running_var);
   SF_CHECK_LAUNCH("bn_finalize");
+  if (!y.ptr) return 0;
   const long long pixels = pix_per_group * groups;
   SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               pixels, (long long)pix_per_group, x.c, (const float*)scale, (const float*)shift, (TA*)y.ptr, y.stride));

@@ -17,10 +17,11 @@ struct WgradParams {
   int NpT, KpT;
   int bf;       // bf16 kernel only: the input sources src0 / src1 are stored as bf16
   int bf_dout;  // bf16 kernel only: dout is stored as bf16 (with fp32 sources: the ConvLSTM's bf16-stored gate gradients)
+  int tpg, maxseg;  // all-bf16 kernel, folded BatchNorm: tiles per group (0: ungrouped), partial slots per slice
 };
 
 
-struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; };
+struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; int tpg = 0, maxseg = 1; };
 
 // kt_h: K-tile height of the kernel variant (4 rows fp32, 8 rows bf16)
 inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
@@ -44,7 +45,8 @@ inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
 // all-bf16-storage variant (conv3x3_wgrad_bf16_dma.hip): LDS-DMA tiles + transposing LDS reads; its own plan (4x16 K tiles,
 // 128 x 64 slabs, one workgroup per CU); the launcher places [zero page | partial | partial_db] in the workspace and sets p's
 // plan fields
-sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w);
+// groups > 0 (folded BatchNorm): n splits into `groups` runs of whole images; a slice stores one partial slab per group it touches
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups = 0);
 int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, float* workspace, hipStream_t st);
 // bf16-MFMA variant (conv3x3_wgrad_bf16.hip): fills the same partial slabs
 int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);

@@ -322,6 +322,97 @@ class _BatchNormTrainFn(torch.autograd.Function):
         return dx, dgamma, dbeta, None, None, None, None, None, None
 
 
+class _BNConvFn(torch.autograd.Function):
+    """``conv3x3(batchnorm_train(x))`` with the normalisation folded into the convolution (bf16-stored activations, SF_BF16 kernels):
+    ``conv(a_g x + b_g) = conv_{W a_g}(x) + T_g[border class]`` - the normalised tensor is never written.  Backward: the plain input
+    gradient (unscaled W) through the BatchNorm backward; the weight gradient from the un-normalised ``x``
+    (``sf_conv3x3_bwd_weight_folded``)."""
+
+    @staticmethod
+    def forward(ctx, eng: ConvEngine, x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
+                groups: int, eps: float, momentum: float, in_stats, weight: Tensor, bias: Optional[Tensor], out_dtype, out_stats: Optional[Tensor]):
+        n, H, W, C = x.shape
+        creal = gamma.shape[0]
+        pixels = n * H * W
+        dev = x.device
+        gm = eng.fwd_map
+        assert gm.Kp == C and x.dtype == torch.bfloat16 and pixels % groups == 0
+        stats = torch.empty(4, groups, C, dtype=torch.float32, device=dev)  # mean, rstd, scale, shift
+        sums = torch.empty(groups, 2, C, dtype=torch.float64, device=dev)
+        rm = running_mean.data_ptr() if running_mean is not None else None
+        rv = running_var.data_ptr() if running_var is not None else None
+        stat_ptrs = (stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr())
+        if in_stats is None:
+            check(lib().sf_batchnorm_train_fwd(T(x), pixels // groups, groups, creal, gamma.data_ptr(), beta.data_ptr(), eps, momentum, rm, rv,
+                                               *stat_ptrs, sums.data_ptr(), NULL, SF_F32, stream_ptr()), "sf_batchnorm_train_fwd")
+        else:
+            assert in_stats.n % groups == 0 and in_stats.np >= C
+            check(lib().sf_batchnorm_train_fwd_stats(T(x), pixels // groups, groups, creal, gamma.data_ptr(), beta.data_ptr(), eps, momentum, rm, rv,
+                                                     *stat_ptrs, sums.data_ptr(), in_stats.data.data_ptr(), in_stats.tiles * (in_stats.n // groups),
+                                                     in_stats.np, NULL, SF_F32, stream_ptr()), "sf_batchnorm_train_fwd_stats")
+        w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
+        packed, tab = K.conv3x3_fold_pack(w4, bias, gm, stats[2], stats[3])
+        y = torch.empty(n, H, W, eng.coutp, dtype=out_dtype or torch.bfloat16, device=dev)
+        K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), out_stats)
+        ctx.eng, ctx.groups, ctx.creal, ctx.has_bias = eng, groups, creal, bias is not None
+        ctx.bias = bias
+        ctx.save_for_backward(x, gamma, stats, weight)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        eng: ConvEngine = ctx.eng
+        x, gamma, stats, weight = ctx.saved_tensors
+        n, H, W, C = x.shape
+        groups = ctx.groups
+        gy = gy.contiguous()
+        if gy.dtype != torch.bfloat16:
+            gy = gy.to(torch.bfloat16)
+        dev = gy.device
+        # d(normalised input) = conv^T(gy, W): plain weights
+        # d(normalised input) = conv^T(gy, W): plain weights
+        gm = eng.bwd_map((True,))
+        dn = torch.empty(n, H, W, C, dtype=x.dtype, device=dev)
+        K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, ctx.bias, "bwd", (True,))[0], None, gm, T(dn))
+        dx = torch.empty_like(x)
+        sums = torch.empty(groups, 2, C, dtype=torch.float64, device=dev)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        coef = torch.empty(groups, 3, C, dtype=torch.float32, device=dev)
+        check(lib().sf_batchnorm_train_bwd(T(x), T(dn), (n * H * W) // groups, groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
+                                           stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
+                                           SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
+        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=dev)
+        db = torch.empty(weight.shape[0], dtype=torch.float32, device=dev) if ctx.has_bias else None
+        K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db)
+        return None, dx, dgamma, dbeta, None, None, None, None, None, None, dw4.reshape(weight.shape), db, None, None
+
+
+def bn_fold_enabled() -> bool:
+    """The BatchNorm -> Conv2d fold runs with bf16-stored activations ("bf16a") unless SF_NO_BN_FOLD is set (A/B switch)."""
+    from ._hip import SF_BF16, compute_dtype
+
+    return compute_dtype() == SF_BF16 and not os.environ.get("SF_NO_BN_FOLD")
+
+
+def batchnorm_conv3x3(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, in_stats: Optional["ConvStats"], eng: ConvEngine, weight: Tensor,
+                      bias: Optional[Tensor], out_dtype=None, want_stats: bool = False):
+    """Training-mode ``conv3x3(bn(x))`` -> ``(y, stats)`` (``stats``: ConvStats of y when ``want_stats``).  Folded (no normalised
+    tensor) when x is bf16-stored and the shape allows, else the two separate ops."""
+    n, H, W, _ = x.shape
+    if not (x.dtype == torch.bfloat16 and bn_fold_enabled() and K.conv3x3_fold_supported(n, H, W, eng.fwd_map, groups, want_stats)):
+        y = batchnorm(x, bn, groups, True, in_stats)
+        return conv3x3(eng, y, weight, bias, out_dtype=out_dtype, want_stats=want_stats)
+    momentum = bn.momentum
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if momentum is None:
+            momentum = -(float(bn.num_batches_tracked) + 1.0)
+        bn.num_batches_tracked += groups
+    st = ConvStats(n, H, W, eng.fwd_map.Np, x.device) if want_stats else None
+    y = _BNConvFn.apply(eng, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups, bn.eps, momentum if momentum is not None else 0.0,
+                        in_stats, weight, bias, out_dtype, st.data if st is not None else None)
+    return y, st
+
+
 class _BatchNormEvalFn(torch.autograd.Function):
     """Eval-mode BatchNorm2d (running statistics are constants): ``y = a*x + b``; backward ``dx = a*dy``, ``dgamma``, ``dbeta``."""
 

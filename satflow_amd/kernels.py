@@ -197,6 +197,44 @@ def conv3x3_bwd_weight(src0: sfTensor, src1: sfTensor, dout: sfTensor, n: int, h
     )
 
 
+def conv3x3_fold_pack(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, scale: Tensor, shift: Tensor) -> Tuple[Tensor, Tensor]:
+    """Per-group packed weights ``W * scale_g`` and the border-class bias table of a folded BatchNorm.  sf_conv3x3_fold_pack."""
+    w = weight.detach().contiguous()
+    groups = scale.shape[0]
+    assert scale.shape == (groups, gm.Kp) and shift.shape == scale.shape and scale.is_contiguous() and shift.is_contiguous()
+    nmap, kmap = gm.tables(w.device)
+    packed = torch.empty(groups * gm.Np * gm.Kp * 9, dtype=torch.bfloat16, device=w.device)
+    tab = torch.empty(groups, 9, gm.Np, dtype=torch.float32, device=w.device)
+    check(lib().sf_conv3x3_fold_pack(w.data_ptr(), w.shape[0], w.shape[1], nmap.data_ptr(), gm.Np, kmap.data_ptr(), gm.Kp, gm.nf,
+                                     bias.detach().contiguous().data_ptr() if bias is not None else None, scale.data_ptr(), shift.data_ptr(),
+                                     groups, packed.data_ptr(), tab.data_ptr(), _hip.SF_BF16, stream_ptr()), "sf_conv3x3_fold_pack")
+    return packed, tab
+
+
+def conv3x3_folded(src: sfTensor, n: int, h: int, w: int, packed: Tensor, tab: Tensor, gm: GemmMap, out: sfTensor,
+                   stats: Optional[Tensor] = None) -> None:
+    check(lib().sf_conv3x3_fwd_folded(src, n, h, w, packed.data_ptr(), tab.data_ptr(), gm.Np, gm.nf, tab.shape[0], out,
+                                      stats.data_ptr() if stats is not None else None, _hip.SF_BF16, stream_ptr()), "sf_conv3x3_fwd_folded")
+
+
+def conv3x3_fold_supported(n: int, h: int, w: int, gm: GemmMap, groups: int, stats: bool) -> bool:
+    """Shapes sf_conv3x3_fwd_folded takes (the two-images-per-workgroup kernel of small images has one weight stream)."""
+    return h >= 2 and w >= 2 and n % groups == 0 and (h > 16 or stats or gm.nf < 4 or n < 512)
+
+
+def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, scale: Tensor, shift: Tensor,
+                              dw: Tensor, db: Optional[Tensor]) -> None:
+    """sf_conv3x3_bwd_weight_folded: dW/db of a convolution behind a folded BatchNorm, from the un-normalised input."""
+    dev = dw.device
+    nmap, kmap = gm.tables(dev)
+    groups = scale.shape[0]
+    nbytes = lib().sf_conv3x3_bwd_weight_folded_workspace_bytes(dout.c, src.c, n, h, w, groups)
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+    check(lib().sf_conv3x3_bwd_weight_folded(src, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), dw.shape[0], dw.shape[1], scale.data_ptr(),
+                                             shift.data_ptr(), groups, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
+                                             ws.data_ptr(), nbytes, _hip.SF_BF16, stream_ptr()), "sf_conv3x3_bwd_weight_folded")
+
+
 def to_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int], cp: Optional[int] = None) -> Tensor:
     """NCHW-side tensor -> time-major NHWC ``[nt*nb, h, w, cp]`` (pad lanes zero).  sf_nchw_to_nhwc."""
     _hip.require_device(src, "input")

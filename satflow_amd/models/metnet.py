@@ -88,6 +88,13 @@ class DownSampler(nn.Module):
         m = self.module
         y = pooled if pooled is not None else F.maxpool2(F.conv3x3(self._eng[0], x, m[0].weight, m[0].bias, out_dtype=x.dtype))
         st = y.dtype
+        if self.training:
+            # BatchNorm -> Conv2d pairs: with bf16-stored activations the normalisation is folded into the convolution
+            # (F.batchnorm_conv3x3; otherwise it runs the two ops below, statistics from the producing convolution's epilogue)
+            y, cs = F.batchnorm_conv3x3(y, m[3], groups, None, self._eng[1], m[4].weight, m[4].bias, out_dtype=st, want_stats=True)
+            y, cs = F.batchnorm_conv3x3(y, m[5], groups, cs, self._eng[2], m[6].weight, m[6].bias, out_dtype=st, want_stats=True)
+            y, _ = F.batchnorm_conv3x3(y, m[7], groups, cs, self._eng[3], m[8].weight, m[8].bias, out_dtype=st)
+            return self._exit(y, perm, dropout, out_dtype)
         y = F.batchnorm(y, m[3], groups, self.training)
         # the two convolutions that feed a BatchNorm also emit its statistics from their epilogue (bf16 kernels, training)
         y, cs = F.conv3x3(self._eng[1], y, m[4].weight, m[4].bias, out_dtype=st, want_stats=self.training)
@@ -95,6 +102,9 @@ class DownSampler(nn.Module):
         y, cs = F.conv3x3(self._eng[2], y, m[6].weight, m[6].bias, out_dtype=st, want_stats=self.training)
         y = F.batchnorm(y, m[7], groups, self.training, cs)
         y = F.conv3x3(self._eng[3], y, m[8].weight, m[8].bias, out_dtype=st)
+        return self._exit(y, perm, dropout, out_dtype)
+
+    def _exit(self, y: Tensor, perm, dropout, out_dtype) -> Tensor:
         if self.capture is not None:
             self.capture["y4"] = y.detach()
         if dropout is not None:  # (p1, p2, timesteps): period = elements of one timestep of the pooled tensor

@@ -39,6 +39,12 @@ int main(void) {
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, 9, a16, SF_F32, st));                       /* unknown epilogue */
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, 5, st));                /* unknown dtype */
   REFUSED(sf_conv3x3_fwd_stats(a16, N0, 1, 8, 8, ok, 0, 32, 1, a16, ok, SF_F32, st));                /* stats need the bf16 kernels */
+  /* folded BatchNorm */
+  REFUSED(sf_conv3x3_fold_pack(ok, 16, 16, ok, 32, ok, 16, 1, 0, ok, ok, 2, ok, ok, SF_F32, st));        /* SF_BF16 kernels only */
+  REFUSED(sf_conv3x3_fold_pack(ok, 16, 16, ok, 32, ok, 16, 1, 0, ok, 0, 2, ok, ok, SF_BF16, st));        /* no shift */
+  REFUSED(sf_conv3x3_fwd_folded(b16, 3, 8, 8, ok, ok, 32, 1, 2, b16, 0, SF_BF16, st));                   /* images do not split into the groups */
+  REFUSED(sf_conv3x3_fwd_folded(b16, 2, 1, 8, ok, ok, 32, 1, 2, b16, 0, SF_BF16, st));                   /* one-row image: no border classes */
+  REFUSED(sf_conv3x3_fwd_folded(b16, 2, 8, 8, ok, mis, 32, 1, 2, b16, 0, SF_BF16, st));                  /* misaligned table */
   /* ConvLSTM cell */
   REFUSED(sf_convlstm_cell_fwd(a16, a64, a64, 1, 8, 8, ok, 0, 48, a64, a64, N0, SF_F32, st));        /* hidp inconsistent with the tensors */
   REFUSED(sf_convlstm_cell_fwd(odd, a64, a64, 1, 8, 8, ok, 0, 64, a64, a64, N0, SF_F32, st));
@@ -97,11 +103,14 @@ int main(void) {
   REFUSED(sf_conv2d_bwd_weight(a16, a16, 1, 8, 8, 16, 16, 4, 4, 2, 1, ok, 0, 0, 0, 0, SF_F32, st));  /* no workspace */
   REFUSED(sf_leaky_relu(mis, 0, 64, 0.2f, ok, st));
   REFUSED(sf_leaky_relu(ok, 0, 63, 0.2f, ok, st));
+  REFUSED(sf_conv3x3_bwd_weight_folded(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
+  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, ok, 16, SF_BF16, st));      /* workspace too small */
+  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 3, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, ok, 1 << 30, SF_BF16, st)); /* ragged groups */
   REFUSED(sf_l1_loss(a16, N0, 64, 1, 16, N0, ok, ok, st));                                           /* no target */
   REFUSED(sf_l1_loss(a16, a16, 64, 3, 16, N0, ok, ok, st));                                          /* rows not divisible into groups */
   REFUSED(sf_bce_logits_loss(a16, 1.f, 0.f, 64, 1, 32, N0, ok, ok, st));                             /* more lanes than the stride */
   /* size queries never fail, must not overflow */
-  printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32),
+  printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32) + sf_conv3x3_bwd_weight_folded_workspace_bytes(256, 256, 2304, 32, 32, 24),
          sf_linear_bwd_weight_workspace_bytes(384, 64, 24576), sf_conv2d_bwd_weight_workspace_bytes(48, 64, 64, 12, 32, 4, 4));
   printf("%d calls, %d not refused\n", calls, failures);
   return failures ? 1 : 0;

@@ -1,0 +1,179 @@
+"""BatchNorm -> Conv2d fold (sf_conv3x3_fold_pack / sf_conv3x3_fwd_folded / sf_conv3x3_bwd_weight_folded; the DownSampler pairs of
+metnet.MetNet, call site satflow/models/pl_metnet.py:46-59).
+
+The kernels are checked against float64 evaluations of EXACTLY the products they form - bf16-stored x and dout, weights
+``bf16(W * scale_g)``, fp32 scale / shift as the BatchNorm kernel wrote them - so the bound is fp32 accumulation noise, not
+bf16 rounding; then the folded DownSampler against the unfolded one (two roundings of the same quantity: bf16 tolerance)."""
+import os
+
+import pytest
+import torch
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _restore_compute_dtype():
+    import satflow_amd
+
+    yield
+    satflow_amd.set_compute_dtype("f32")
+
+
+def _setup(device, n, groups, cin, cout, H, W, seed=0):
+    import satflow_amd
+    from satflow_amd import functional as F
+
+    satflow_amd.set_compute_dtype("bf16")
+    g = torch.Generator().manual_seed(seed)
+    x = (torch.randn(n, H, W, cin, generator=g) * 1.7 + 0.4).to(device).to(torch.bfloat16)
+    bn = torch.nn.BatchNorm2d(cin).to(device)
+    with torch.no_grad():
+        bn.weight.copy_(torch.rand(cin, generator=g) + 0.5)
+        bn.bias.copy_(torch.randn(cin, generator=g) * 0.3)
+    conv = torch.nn.Conv2d(cin, cout, 3, padding=1).to(device)
+    eng = F.ConvEngine([cin], cout)
+    return F, x, bn, conv, eng
+
+
+def _ref_stats(x, bn, groups):
+    """scale / shift per group from the bf16-stored x (biased variance), rounded where bn_finalize_kernel rounds: rstd to fp32,
+    scale = gamma * rstd in fp32 (the packed weights are bf16(W * scale): a different last bit of scale would flip roundings)."""
+    n, H, W, C = x.shape
+    xg = x.double().reshape(groups, -1, C)
+    mean = xg.mean(1)
+    var = xg.var(1, unbiased=False)
+    a = (bn.weight.float() * (1.0 / torch.sqrt(var + bn.eps)).float()).double()
+    return a, bn.bias.double() - mean * a
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W,want_stats", [
+    (6, 3, 32, 64, 20, 20, True),      # ragged 32x16 tiles, statistics epilogue
+    (6, 3, 32, 64, 20, 20, False),     # transposed epilogue
+    (4, 2, 160, 256, 32, 32, True),    # DownSampler conv 2 (NF = 4 stats kernel)
+    (4, 1, 256, 256, 32, 32, False),   # one group
+    (8, 4, 48, 160, 12, 10, True),     # 4-wave kernel, NF = 5
+    (4, 2, 16, 32, 2, 2, False),       # every pixel a corner
+])
+def test_folded_forward_matches_float64_of_its_operands(device, n, groups, cin, cout, H, W, want_stats):
+    F, x, bn, conv, eng = _setup(device, n, groups, cin, cout, H, W)
+    bn.train()
+    y, st = F.batchnorm_conv3x3(x, bn, groups, None, eng, conv.weight, conv.bias, out_dtype=torch.float32, want_stats=want_stats)
+    assert (st is not None) == want_stats
+    a, b = _ref_stats(x, bn, groups)
+    ipg = n // groups
+    for g in range(groups):
+        wg = (conv.weight.float() * a[g].float().view(1, -1, 1, 1)).to(torch.bfloat16).double()  # what fold_pack stores
+        xs = x[g * ipg:(g + 1) * ipg].double().permute(0, 3, 1, 2)
+        ref = torch.nn.functional.conv2d(xs, wg, None, padding=1)
+        shift_img = (b[g] / a[g]).view(1, -1, 1, 1).expand(1, cin, H, W)  # conv(a x + b) = conv_{W a}(x + b / a), same rounded weights
+        ref = ref + torch.nn.functional.conv2d(shift_img, wg, conv.bias.double(), padding=1)
+        got = y[g * ipg:(g + 1) * ipg, ..., :cout].permute(0, 3, 1, 2).double()
+        assert rel_l2(got, ref) < 1e-4, f"group {g}: rel L2 {rel_l2(got, ref):.3e}"
+    if want_stats:  # the emitted statistics describe the stored tensor
+        tiles = st.tiles
+        s = st.data.reshape(n, tiles, st.np, 2).double().sum(1)[:, :cout]
+        assert rel_l2(s[..., 0], y[..., :cout].double().sum((1, 2))) < 1e-5
+        assert rel_l2(s[..., 1], (y[..., :cout].double() ** 2).sum((1, 2))) < 1e-5
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [
+    (6, 3, 32, 64, 20, 20),
+    (12, 3, 160, 256, 32, 32),   # slices cross group boundaries (two segments per slice)
+    (24, 24, 64, 128, 16, 16),   # slices longer than a group (several boundaries per slice)
+    (4, 2, 16, 32, 2, 2),
+])
+def test_folded_weight_gradient_matches_float64_of_its_operands(device, n, groups, cin, cout, H, W):
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T
+
+    F, x, bn, conv, eng = _setup(device, n, groups, cin, cout, H, W, seed=1)
+    g = torch.Generator().manual_seed(5)
+    gy = torch.randn(n, H, W, eng.coutp, generator=g).to(device).to(torch.bfloat16)
+    gy[..., cout:] = 0
+    a, b = _ref_stats(x, bn, groups)
+    scale, shift = a.float().contiguous(), b.float().contiguous()
+    dw = torch.empty(cout, cin, 3, 3, device=device)
+    db = torch.empty(cout, device=device)
+    K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, scale, shift, dw, db)
+    ipg = n // groups
+    w = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=device, requires_grad=True)
+    tot = 0
+    for gi in range(groups):
+        xs = x[gi * ipg:(gi + 1) * ipg].double().permute(0, 3, 1, 2)
+        xin = xs * scale[gi].double().view(1, -1, 1, 1) + shift[gi].double().view(1, -1, 1, 1)
+        out = torch.nn.functional.conv2d(xin, w, None, padding=1)
+        tot = tot + (out * gy[gi * ipg:(gi + 1) * ipg, ..., :cout].double().permute(0, 3, 1, 2)).sum()
+    (ref,) = torch.autograd.grad(tot, w)
+    assert rel_l2(dw, ref) < 2e-5, f"dW rel L2 {rel_l2(dw, ref):.3e}"
+    assert rel_l2(db, gy[..., :cout].double().sum((0, 1, 2))) < 2e-5
+
+
+def test_folded_downsampler_is_as_close_to_fp32_as_unfolded(device, monkeypatch):
+    """Whole DownSampler (three folded pairs), forward + all gradients.  Folded and unfolded are two bf16 roundings of the same
+    quantities; the backward through three BatchNorms amplifies rounding noise to several percent in EITHER form (the bf16a
+    yardstick of test_bf16a_gpu.py), so each is measured against the fp32 kernels: the fold must not be the noisier one."""
+    import satflow_amd
+    from satflow_amd.models.metnet import DownSampler
+
+    torch.manual_seed(3)
+    ds = DownSampler(12, 256).to(device).train()
+    x = torch.randn(12, 32, 32, 16, device=device)
+    x[..., 12:] = 0
+    gout = torch.randn(12, 8, 8, 256, device=device)
+
+    def run(mode, fold):
+        satflow_amd.set_compute_dtype("f32" if mode == "f32" else "bf16")
+        if fold:
+            monkeypatch.delenv("SF_NO_BN_FOLD", raising=False)
+        else:
+            monkeypatch.setenv("SF_NO_BN_FOLD", "1")
+        for p in ds.parameters():
+            p.grad = None
+        for m in ds.modules():
+            if isinstance(m, torch.nn.BatchNorm2d):
+                m.reset_running_stats()
+        xi = (x if mode == "f32" else x.to(torch.bfloat16)).clone().requires_grad_(True)
+        y = ds.run(xi, 3, out_dtype=torch.float32)
+        y.backward(gout)
+        rs = {k: v.clone() for k, v in ds.state_dict().items() if "running" in k}
+        return y.detach(), xi.grad.float(), {k: p.grad.clone() for k, p in ds.named_parameters()}, rs
+
+    try:
+        yr, dxr, gr, rr = run("f32", False)
+        y1, dx1, g1, r1 = run("bf16", True)
+        y0, dx0, g0, r0 = run("bf16", False)
+    finally:
+        satflow_amd.set_compute_dtype("bf16")
+
+    def check(name, folded, unfolded, ref, floor):
+        e1, e0 = rel_l2(folded, ref), rel_l2(unfolded, ref)
+        assert e1 < max(1.5 * e0, floor), f"{name}: folded {e1:.3e} vs unfolded {e0:.3e} from fp32"
+
+    check("y", y1, y0, yr, 5e-3)
+    check("dx", dx1, dx0, dxr, 2e-2)
+    for k in gr:
+        if k.endswith("bias") and ("module.0" in k or "module.4" in k or "module.6" in k):
+            continue  # conv biases in front of a BatchNorm: true gradient zero
+        check(k, g1[k], g0[k], gr[k], 2e-2)
+    for k in rr:
+        check(k, r1[k].double(), r0[k].double(), rr[k].double(), 1e-3)
+
+
+def test_folded_path_is_taken_in_bf16a_mode(device, monkeypatch):
+    """Guard against a silent fallback: the DownSampler's training step must call the folded entry points."""
+    import satflow_amd
+    from satflow_amd import kernels as K
+    from satflow_amd.models.metnet import DownSampler
+
+    satflow_amd.set_compute_dtype("bf16")
+    monkeypatch.delenv("SF_NO_BN_FOLD", raising=False)
+    calls = []
+    orig = K.conv3x3_folded
+    monkeypatch.setattr(K, "conv3x3_folded", lambda *a, **k: (calls.append(1), orig(*a, **k))[1])
+    ds = DownSampler(12, 64).to(device).train()
+    x = torch.randn(4, 16, 16, 16, device=device).to(torch.bfloat16)
+    ds.run(x, 2)
+    assert len(calls) == 3
