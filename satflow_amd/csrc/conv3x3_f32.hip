@@ -173,18 +173,24 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int O, int 
 // With exact weights for the shift the two halves would not cancel: sum_px What*x - W*a*mean*N leaves (What - W*a) * mean(x), an
 // offset common to all pixels of a channel (about 2^-9 * mean/std of the output's std: invisible per pixel, but it IS the error of
 // the next BatchNorm's running mean).  scale == 0 (gamma == 0): the channel contributes w * shift exactly.
-// One workgroup per output lane n: its weight row (I x 9 floats, contiguous in OIHW) goes to LDS once, thread (g, tap) forms the
-// per-tap sum over k (fp32, fixed order), thread (g, class) adds the valid taps.
+// One workgroup per output lane n: its weight row (I x 9 floats, contiguous in OIHW), the scales and the ratios shift / scale go to
+// LDS once; thread (g, tap) forms the per-tap sum over k (fp32, fixed order), thread (g, class) adds the valid taps.
 __global__ __launch_bounds__(256) void fold_bias_table_kernel(const float* __restrict__ w, int I, const int* __restrict__ nmap, int Np,
                                                              const int* __restrict__ kmap, int Kp, const float* __restrict__ bias,
                                                              const float* __restrict__ scale, const float* __restrict__ shift, int groups,
                                                              float* __restrict__ table) {
-  extern __shared__ float sh[];  // [I * 9] weight row | [groups * 9] per-tap sums
+  extern __shared__ float sh[];  // [I * 9] weight row | [groups * Kp] scale | [groups * Kp] shift / scale (or shift) | [groups * 9] tap sums
   float* wrow = sh;
-  float* tsum = sh + I * 9;
+  float* sa = sh + I * 9;
+  float* sc = sa + groups * Kp;
+  float* tsum = sc + groups * Kp;
   const int n = blockIdx.x, nn = nmap[n];
   if (nn >= 0)
     for (int e = threadIdx.x; e < I * 9; e += 256) wrow[e] = w[(size_t)nn * I * 9 + e];
+  for (int e = threadIdx.x; e < groups * Kp; e += 256) {
+    const float a = scale[e], b = shift[e];
+    sa[e] = a; sc[e] = a != 0.f ? b / a : b;
+  }
   __syncthreads();
   for (int gt = threadIdx.x; gt < groups * 9; gt += 256) {
     const int g = gt / 9, tap = gt - g * 9;
@@ -193,8 +199,8 @@ __global__ __launch_bounds__(256) void fold_bias_table_kernel(const float* __res
       for (int k = 0; k < Kp; ++k) {
         const int kk = kmap[k];
         if (kk < 0) continue;
-        const float wv = wrow[kk * 9 + tap], a = scale[(size_t)g * Kp + k], b = shift[(size_t)g * Kp + k];
-        t = a != 0.f ? __builtin_fmaf((float)(__bf16)(wv * a), b / a, t) : __builtin_fmaf(wv, b, t);
+        const float wv = wrow[kk * 9 + tap], a = sa[g * Kp + k];
+        t = __builtin_fmaf(a != 0.f ? (float)(__bf16)(wv * a) : wv, sc[g * Kp + k], t);
       }
     tsum[gt] = t;
   }
@@ -311,8 +317,9 @@ int sf_conv3x3_fold_pack(const float* w, int32_t O, int32_t I, const int32_t* nm
   SF_REQUIRE(w && scale && shift && packed && bias_tab && ((uintptr_t)bias_tab & 15) == 0, "fold_pack: null / misaligned argument");
   sf_pack_weights_bf16(w, O, I, nmap, Np, kmap, Kp, 32 * nf, 0, packed, nullptr, nullptr, (hipStream_t)stream, scale, groups);
   SF_CHECK_LAUNCH("pack_weights_bf16 (grouped)");
-  SF_REQUIRE((size_t)(I + groups) * 9 * sizeof(float) <= 64 * 1024, "fold_pack: I=%d, groups=%d exceed the table kernel's LDS", I, groups);
-  hipLaunchKernelGGL(fold_bias_table_kernel, dim3(Np), dim3(256), (size_t)(I + groups) * 9 * sizeof(float), (hipStream_t)stream, w, I, nmap, Np, kmap,
+  const size_t tab_lds = ((size_t)(I + groups) * 9 + 2 * (size_t)groups * Kp) * sizeof(float);
+  SF_REQUIRE(tab_lds <= 64 * 1024, "fold_pack: I=%d, Kp=%d, groups=%d exceed the table kernel's LDS (%zu bytes)", I, Kp, groups, tab_lds);
+  hipLaunchKernelGGL(fold_bias_table_kernel, dim3(Np), dim3(256), tab_lds, (hipStream_t)stream, w, I, nmap, Np, kmap,
                      Kp, bias, scale, shift, groups, bias_tab);
   SF_CHECK_LAUNCH("fold_bias_table");
   return 0;

@@ -237,12 +237,16 @@ __global__ __launch_bounds__(256) void fold_v_kernel(const float* __restrict__ p
     if (g >= g0 && g <= g1) S += partial_db[((size_t)ks * maxseg + (g - g0)) * NpT + co];
   }
   red[part][BORDER_CATS][lc] = S;
-#pragma unroll
-  for (int c = 0; c < BORDER_CATS; ++c) {
-    float s = 0.f;
+  {
+    float s[BORDER_CATS] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     if (co < Np)
-      for (int q = part; q < chunks; q += 8) s += bpart[(((size_t)g * chunks + q) * BORDER_CATS + c) * Np + co];
-    red[part][c][lc] = s;
+      for (int q = part; q < chunks; q += 8) {
+        const float* bp = bpart + ((size_t)g * chunks + q) * BORDER_CATS * Np + co;
+#pragma unroll
+        for (int c = 0; c < BORDER_CATS; ++c) s[c] += bp[(size_t)c * Np];  // eight independent loads per trip
+      }
+#pragma unroll
+    for (int c = 0; c < BORDER_CATS; ++c) red[part][c][lc] = s[c];
   }
   __syncthreads();
   if (part != 0) return;
@@ -273,52 +277,49 @@ __global__ __launch_bounds__(256) void fold_v_kernel(const float* __restrict__ p
     }
 }
 
-__global__ void wgrad_reduce_folded_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db, int slots,
-                                           const int* __restrict__ slot_group, int groups, int NpT, int KpT, int Np, int Kp,
-                                           const int* __restrict__ nmap, const int* __restrict__ kmap, int I,
-                                           const float* __restrict__ scale, const float* __restrict__ shift, const float* __restrict__ V,
-                                           float* __restrict__ dw, float* __restrict__ db, int accumulate) {
+// block = one (tap, co) row of the slab, threads over ci: slot table, V and the row index are block-uniform (scalar loads)
+__global__ __launch_bounds__(256) void wgrad_reduce_folded_kernel(const float* __restrict__ partial, const float* __restrict__ partial_db, int slots,
+                                                                 const int* __restrict__ slot_group, int groups, int NpT, int KpT, int Np, int Kp,
+                                                                 const int* __restrict__ nmap, const int* __restrict__ kmap, int I,
+                                                                 const float* __restrict__ scale, const float* __restrict__ shift,
+                                                                 const float* __restrict__ V, float* __restrict__ dw, float* __restrict__ db,
+                                                                 int accumulate) {
   const size_t slab = (size_t)9 * NpT * KpT;
-  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid < slab) {
-    const int ci = gid % KpT;
-    const int co = (gid / KpT) % NpT;
-    const int tap = gid / ((size_t)KpT * NpT);
-    if (co < Np && ci < Kp) {
-      const int o = nmap[co], i = kmap[ci];
-      if (o >= 0 && i >= 0) {
-        // fixed order: slots ascending over eight chains (the slot table is wave-uniform: scalar loads and branches)
-        float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
-        int s = 0;
-        for (; s + 8 <= slots; s += 8) {
+  const int row = blockIdx.x;  // tap * NpT + co
+  const int co = row % NpT, tap = row / NpT;
+  const int o = co < Np ? nmap[co] : -1;
+  if (o >= 0)
+    for (int ci = threadIdx.x; ci < Kp; ci += 256) {
+      const int i = kmap[ci];
+      if (i < 0) continue;
+      const size_t gid = (size_t)row * KpT + ci;
+      // fixed order: slots ascending over eight chains
+      float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      int s = 0;
+      for (; s + 8 <= slots; s += 8) {
 #pragma unroll
-          for (int u = 0; u < 8; ++u) {
-            const int g = slot_group[s + u];
-            if (g >= 0) s8[u] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)(s + u) * slab + gid], s8[u]);
-          }
+        for (int u = 0; u < 8; ++u) {
+          const int g = slot_group[s + u];
+          if (g >= 0) s8[u] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)(s + u) * slab + gid], s8[u]);
         }
-        for (; s < slots; ++s) {
-          const int g = slot_group[s];
-          if (g >= 0) s8[0] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)s * slab + gid], s8[0]);
-        }
-        float r = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
-        float t = 0.f;
-        for (int g = 0; g < groups; ++g) t = __builtin_fmaf(shift[(size_t)g * Kp + ci], V[((size_t)g * 9 + tap) * NpT + co], t);
-        r += t;
-        float* d = dw + ((size_t)o * I + i) * 9 + tap;
-        *d = accumulate ? *d + r : r;
       }
-    }
-  }
-  if (db && gid < (size_t)NpT) {
-    const int co = (int)gid;
-    if (co < Np && nmap[co] >= 0) {
-      float r = 0.f;
-      for (int s = 0; s < slots; ++s)
-        if (slot_group[s] >= 0) r += partial_db[(size_t)s * NpT + co];
-      float* d = db + nmap[co];
+      for (; s < slots; ++s) {
+        const int g = slot_group[s];
+        if (g >= 0) s8[0] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)s * slab + gid], s8[0]);
+      }
+      float r = ((s8[0] + s8[1]) + (s8[2] + s8[3])) + ((s8[4] + s8[5]) + (s8[6] + s8[7]));
+      float t = 0.f;
+      for (int g = 0; g < groups; ++g) t = __builtin_fmaf(shift[(size_t)g * Kp + ci], V[((size_t)g * 9 + tap) * NpT + co], t);
+      r += t;
+      float* d = dw + ((size_t)o * I + i) * 9 + tap;
       *d = accumulate ? *d + r : r;
     }
+  if (db && tap == 0 && o >= 0 && threadIdx.x == 0) {
+    float r = 0.f;
+    for (int s = 0; s < slots; ++s)
+      if (slot_group[s] >= 0) r += partial_db[(size_t)s * NpT + co];
+    float* d = db + o;
+    *d = accumulate ? *d + r : r;
   }
 }
 
@@ -378,8 +379,7 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
   hipLaunchKernelGGL(fold_v_kernel, dim3(p.NpT / 32, groups), dim3(256), 0, st, p.partial_db, pl.KS, pl.maxseg, per_slice, pl.ntiles, pl.tpg,
                      p.NpT, bpart, fl.chunks, Np, groups, V, slot_group);
   SF_CHECK_LAUNCH("fold_v");
-  const size_t slab = (size_t)9 * p.NpT * p.KpT;
-  hipLaunchKernelGGL(wgrad_reduce_folded_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, p.partial, p.partial_db,
+  hipLaunchKernelGGL(wgrad_reduce_folded_kernel, dim3(9 * p.NpT), dim3(256), 0, st, p.partial, p.partial_db,
                      pl.KS * pl.maxseg, slot_group, groups, p.NpT, p.KpT, Np, Kp, nmap, kmap, I, scale, shift, V, dw, db, accumulate);
   SF_CHECK_LAUNCH("wgrad_reduce_folded");
   (void)O;

@@ -219,7 +219,8 @@ def conv3x3_folded(src: sfTensor, n: int, h: int, w: int, packed: Tensor, tab: T
 
 def conv3x3_fold_supported(n: int, h: int, w: int, gm: GemmMap, groups: int, stats: bool) -> bool:
     """Shapes sf_conv3x3_fwd_folded takes (the two-images-per-workgroup kernel of small images has one weight stream)."""
-    return h >= 2 and w >= 2 and n % groups == 0 and (h > 16 or stats or gm.nf < 4 or n < 512)
+    table_lds = ((gm.Kp + groups) * 9 + 2 * groups * gm.Kp) * 4  # sf_conv3x3_fold_pack's table kernel stages scale / shift of all groups
+    return h >= 2 and w >= 2 and n % groups == 0 and (h > 16 or stats or gm.nf < 4 or n < 512) and table_lds <= 64 * 1024
 
 
 def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, scale: Tensor, shift: Tensor,
