@@ -173,12 +173,24 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
  * normalisation (bf16-stored), scale / shift [groups][src.c] the per-group affine map; with in = scale_g * src + shift_g inside the
  * image (zero padding outside)
  *   dW = sum_g scale_g[i] * dWraw_g[o][i][tap] + shift_g[i] * V_g[tap][o],   V_g = sum of dout over the group's pixels whose tap
- * neighbour lies inside the image; db as above.  SF_BF16 kernels, bf16-stored src and dout, h, w >= 2, no image remap. */
+ * neighbour lies inside the image; db as above.  SF_BF16 kernels, bf16-stored src and dout, h, w >= 2, no image remap.
+ * bn_sums (nullable; then weight = the convolution's OIHW weights, mean / rstd [groups][src.c] of the BatchNorm): also the two
+ * reductions of that BatchNorm's backward, [groups][2][src.c] doubles = (sum dn, sum dn * xhat) with dn = conv^T(dout, W) the
+ * gradient entering the BatchNorm - formed from V_g and dWraw_g (sum dn = W . V_g, sum dn * x = W . dWraw_g), i.e. without dn:
+ * sf_batchnorm_train_bwd_coef turns them into the coefficients sf_conv3x3_bwd_data_bn applies. */
 size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups);
 int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap,
                                  const int32_t* kmap, int32_t O, int32_t I, const float* scale, const float* shift,
-                                 int32_t groups, float* dw, float* db, int32_t accumulate, void* workspace,
+                                 int32_t groups, float* dw, float* db, int32_t accumulate, const float* weight,
+                                 const float* mean, const float* rstd, double* bn_sums, void* workspace,
                                  size_t workspace_bytes, int32_t dtype, sfStream stream);
+/* Input gradient of the same convolution THROUGH the folded BatchNorm in one launch: dx = A_g * conv^T(dout, W) + B_g * x + K_g
+ * with coef [groups][3][x.c] = (A, B, K) from sf_batchnorm_train_bwd_coef (the affine form of the training-mode BatchNorm
+ * backward) applied in the convolution's epilogue; wpacked = the transposed weight image (sf_conv3x3_pack_weights, transpose 1).
+ * Replaces sf_conv3x3_fwd on dout + sf_batchnorm_train_bwd: the gradient entering the BatchNorm is never written or read.
+ * SF_BF16 kernels; dout, x, dx bf16-stored. */
+int sf_conv3x3_bwd_data_bn(sfTensor dout, int32_t n, int32_t h, int32_t w, const void* wpacked, int32_t Np, int32_t nf,
+                           sfTensor x, const float* coef, int32_t groups, sfTensor dx, int32_t dtype, sfStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Layout conversion at the module boundary (the reference keeps NCHW-style tensors throughout:
@@ -273,6 +285,12 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
                            int32_t creal, const float* gamma, const float* mean, const float* rstd,
                            double* sums, float* coef /* scratch [groups][3][C] */, sfTensor dx,
                            float* dgamma, float* dbeta, int32_t dtype, sfStream stream);
+/* Coefficients (A, B, K) [groups][3][c] of dx = A * dy + B * x + K and dgamma / dbeta from PRECOMPUTED reductions
+ * sums [groups][2][c] doubles = (sum dy, sum dy * xhat): the tail of sf_batchnorm_train_bwd without its two passes over dy. */
+int sf_batchnorm_train_bwd_coef(const double* sums, int64_t pix_per_group, int32_t groups, int32_t c, int32_t creal,
+                                const float* gamma, const float* mean, const float* rstd, float* coef, float* dgamma,
+                                float* dbeta, int32_t dtype, sfStream stream);
+
 /* Lead-time de-duplication of MetNet's first convolution (ConditionTime planes are constant one-hot images and
  * conv1 is linear): with base = conv1_image(frame) + b computed ONCE per frame,
  *   pooled[(l*frames + f)] = maxpool2( base[f] + P_l ),  P_l[y][x][co] = sum of the in-image taps of w1[co][cimg + l]

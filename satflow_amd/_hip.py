@@ -52,8 +52,10 @@ PROTOTYPES = {
     "sf_conv3x3_bwd_weight_folded_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32]),
     "sf_conv3x3_bwd_weight_folded": (
         C.c_int,
-        [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp],
+        [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp],
     ),
+    "sf_conv3x3_bwd_data_bn": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _i32, _i32, sfTensor, _vp, _i32, sfTensor, _i32, _vp]),
+    "sf_batchnorm_train_bwd_coef": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_metnet_preprocess_fwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_metnet_preprocess_bwd": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _i32, _vp]),

@@ -44,7 +44,7 @@ __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t r
 // DUAL (8 waves, images of at most 16x16 pixels): the 32x16 tile is TWO consecutive images, waves 0-3 on the first and
 // 4-7 on the second, each image with its own halo rows in LDS (2 x 18 rows) - small images keep the 8-wave workgroup's
 // weight reuse and occupancy instead of dropping to the 4-wave 16x16 kernel.
-template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false>
+template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false>
 __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
   static_assert(!DUAL || WAVES == 8, "dual-image tiles are an 8-wave layout");
   constexpr int NB = 32 * NF;
@@ -331,7 +331,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       __syncthreads();
     }
   }
-  if constexpr (TR) {
+  if constexpr (TR && BNB) {
+    conv_epilogue_tr_bnb<NF, THREADS>(acc, p, n, nb, y0, x0, wave, r, kh, reinterpret_cast<float*>(lds), tid);
+    return;
+  } else if constexpr (TR) {
     if (!DUAL || n_w < p.N) conv_epilogue_tr<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh);
     return;
   } else {
@@ -399,7 +402,12 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
     const bool tr = p.stats == nullptr;
 #define SF_CONV_CASE(NFV)                                                                                              \
   case NFV:                                                                                                            \
-    if (tr) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);             \
+    if (tr) {                                                                                                          \
+      if constexpr (EPI == EPI_LINEAR && !DUAL) {                                                                      \
+        if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true, true>), grid, block, 0, st, p); \
+        else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);            \
+      } else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);            \
+    }                                                                                                                  \
     else if constexpr (EPI == EPI_LINEAR && !DUAL) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, false>), grid, block, 0, st, p); \
     else { sf_set_error("bf16 conv: statistics need the linear epilogue on single-image tiles"); return 1; }          \
     break;

@@ -336,6 +336,28 @@ int sf_conv3x3_fwd_folded(sfTensor src, int32_t n, int32_t h, int32_t w, const v
   return conv3x3_fwd_impl(src, none, n, h, w, wpacked, bias_tab, Np, nf, SF_EPI_LINEAR, out, stats, dtype, stream, groups);
 }
 
+int sf_conv3x3_bwd_data_bn(sfTensor dout, int32_t n, int32_t h, int32_t w, const void* wpacked, int32_t Np, int32_t nf, sfTensor x,
+                           const float* coef, int32_t groups, sfTensor dx, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_bwd_data_bn: dtype %d not built (SF_BF16 kernels only)", dtype);
+  if (check_src(dout, "conv3x3 bwd_data_bn dout")) return 1;
+  SF_REQUIRE(groups >= 1 && n % groups == 0, "bwd_data_bn: n=%d must split into %d groups of whole images", n, groups);
+  SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && dx.c <= Np, "bwd_data_bn: bad Np=%d nf=%d dx.c=%d", Np, nf, dx.c);
+  SF_REQUIRE(dout.ptr && dout.dtype == SF_BF16 && x.ptr && x.dtype == SF_BF16 && dx.ptr && dx.dtype == SF_BF16 && x.c == dx.c && x.c % 8 == 0 &&
+                 x.stride % 4 == 0 && ((uintptr_t)x.ptr & 7) == 0 && dx.stride % 8 == 0 && ((uintptr_t)dx.ptr & 15) == 0,
+             "bwd_data_bn: bf16-stored dout, x and dx with matching channel lanes (multiples of 8) and aligned pixels");
+  SF_REQUIRE(coef && ((uintptr_t)coef & 15) == 0, "bwd_data_bn: coef null / not 16-byte aligned");
+  // images of at most 16x16 pixels could take the two-images-per-workgroup kernel: one group per tile there is not guaranteed
+  SF_REQUIRE(h > 16 || nf < 4 || n < 512, "bwd_data_bn: this shape dispatches to the two-image tile kernel");
+  ConvParams p{};
+  p.src0 = (const float*)dout.ptr; p.c0 = dout.c; p.s0 = dout.stride; p.bf0 = 1;
+  p.idiv0 = p.idiv1 = 1;
+  p.N = n; p.H = h; p.W = w;
+  p.wp = (const float*)wpacked; p.chunks_total = dout.c / KC;
+  p.out = (float*)dx.ptr; p.out_c = dx.c; p.out_s = dx.stride; p.out_bf = 1;
+  p.bnb_coef = coef; p.bnb_x = x.ptr; p.bnb_xs = x.stride; p.bnb_group = n / groups; p.bnb_c = x.c;
+  return sf_launch_conv_bf16(p, nf, Np / (32 * nf), EPI_LINEAR, (hipStream_t)stream);
+}
+
 int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n, int32_t h, int32_t w,
                          const void* wpacked, const float* bias_packed, int32_t hidp, sfTensor h_out, sfTensor c_out,
                          sfTensor gates, int32_t dtype, sfStream stream) {

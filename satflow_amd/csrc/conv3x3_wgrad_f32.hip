@@ -323,14 +323,88 @@ __global__ __launch_bounds__(256) void wgrad_reduce_folded_kernel(const float* _
   }
 }
 
-struct FoldLayout { int chunks; size_t bpart_off, v_off, slot_off, total_floats; };
+// ---- the BatchNorm backward's two reductions from the weight gradient's own partial results (no pass over the activation gradient) ----
+// With dn = conv^T(dout, W) the gradient entering the folded BatchNorm:
+//   sum_px dn[ci]         = sum_{tap, co} W[co][ci][tap] * V_g[tap][co]
+//   sum_px dn[ci] * x[ci] = sum_{tap, co} W[co][ci][tap] * dWraw_g[co][ci][tap]      (dWraw_g = the group's raw weight gradient)
+// Wt[tap][co][ci]: the weights in the slab layout (zero at pad lanes), so that the products run over coalesced rows.
+__global__ void fold_wt_kernel(const float* __restrict__ w, int I, const int* __restrict__ nmap, const int* __restrict__ kmap, int Np, int Kp,
+                               int NpT, int KpT, float* __restrict__ wt) {
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)9 * NpT * KpT) return;
+  const int ci = gid % KpT, co = (gid / KpT) % NpT, tap = gid / ((size_t)KpT * NpT);
+  float v = 0.f;
+  if (co < Np && ci < Kp) {
+    const int o = nmap[co], i = kmap[ci];
+    if (o >= 0 && i >= 0) v = w[((size_t)o * I + i) * 9 + tap];
+  }
+  wt[gid] = v;
+}
+
+constexpr int S2_ROWPARTS = 8;
+// block = (slot or slots + group, 64-lane ci tile, row part):
+//   T[slot][part][ci]          = sum over the part's rows of Wt[row][ci] * partial[slot][row][ci]
+//   T[slots + group][part][ci] = sum over the part's rows of Wt[row][ci] * V[group][row]
+__global__ __launch_bounds__(256) void fold_bn_s2_kernel(const float* __restrict__ partial, const int* __restrict__ slot_group, int slots,
+                                                        const float* __restrict__ wt, const float* __restrict__ V, int NpT, int KpT,
+                                                        double* __restrict__ T) {
+  __shared__ double red[4][64];
+  const int slot = blockIdx.x, cit = blockIdx.y, part = blockIdx.z;
+  const int lc = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ci = cit * 64 + lc;
+  const int rows = 9 * NpT, per = (rows + S2_ROWPARTS - 1) / S2_ROWPARTS;
+  const int r0 = part * per, r1 = r0 + per < rows ? r0 + per : rows;
+  double acc = 0.0;
+  float a4[4] = {0.f, 0.f, 0.f, 0.f};  // short fp32 chains (16 terms each), combined in double
+  int u = 0;
+  if (slot >= slots) {  // block-uniform: the V part of group slot - slots
+    const float* vg = V + (size_t)(slot - slots) * rows;
+    for (int r = r0 + rl; r < r1; r += 4, ++u) {
+      a4[u & 3] = __builtin_fmaf(wt[(size_t)r * KpT + ci], vg[r], a4[u & 3]);
+      if ((u & 63) == 63) { acc += ((double)a4[0] + (double)a4[1]) + ((double)a4[2] + (double)a4[3]); a4[0] = a4[1] = a4[2] = a4[3] = 0.f; }
+    }
+  } else if (slot_group[slot] >= 0) {
+    const float* ps = partial + (size_t)slot * rows * KpT;
+    for (int r = r0 + rl; r < r1; r += 4, ++u) {
+      a4[u & 3] = __builtin_fmaf(wt[(size_t)r * KpT + ci], ps[(size_t)r * KpT + ci], a4[u & 3]);
+      if ((u & 63) == 63) { acc += ((double)a4[0] + (double)a4[1]) + ((double)a4[2] + (double)a4[3]); a4[0] = a4[1] = a4[2] = a4[3] = 0.f; }
+    }
+  }
+  acc += ((double)a4[0] + (double)a4[1]) + ((double)a4[2] + (double)a4[3]);
+  red[rl][lc] = acc;
+  __syncthreads();
+  if (rl == 0) T[((size_t)slot * S2_ROWPARTS + part) * KpT + ci] = (red[0][lc] + red[1][lc]) + (red[2][lc] + red[3][lc]);
+}
+
+// thread = (group, ci): sums[g][0][ci] = sum dn, sums[g][1][ci] = sum dn * xhat = rstd * (sum dn * x - mean * sum dn)
+__global__ void fold_bn_sums_kernel(const double* __restrict__ T, const int* __restrict__ slot_group, int slots, int groups, int KpT, int C,
+                                    const float* __restrict__ mean, const float* __restrict__ rstd, double* __restrict__ sums) {
+  const int id = blockIdx.x * blockDim.x + threadIdx.x;
+  if (id >= groups * C) return;
+  const int g = id / C, ci = id - g * C;
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int q = 0; q < S2_ROWPARTS; ++q) s1 += T[((size_t)(slots + g) * S2_ROWPARTS + q) * KpT + ci];
+  for (int s = 0; s < slots; ++s)
+    if (slot_group[s] == g) {
+#pragma unroll
+      for (int q = 0; q < S2_ROWPARTS; ++q) s2 += T[((size_t)s * S2_ROWPARTS + q) * KpT + ci];
+    }
+  sums[((size_t)g * 2 + 0) * C + ci] = s1;
+  sums[((size_t)g * 2 + 1) * C + ci] = (double)rstd[(size_t)g * C + ci] * (s2 - (double)mean[(size_t)g * C + ci] * s1);
+}
+
+struct FoldLayout { int chunks; size_t bpart_off, v_off, slot_off, wt_off, t_off, total_floats; };
 inline FoldLayout fold_layout(const Plan& pl, int Np, int n, int groups) {
   FoldLayout f;
   f.chunks = (n / groups + BORDER_IMGS - 1) / BORDER_IMGS;
   f.bpart_off = pl.ws_floats;
   f.v_off = f.bpart_off + (size_t)groups * f.chunks * BORDER_CATS * Np;
   f.slot_off = f.v_off + (size_t)groups * 9 * pl.cot * DMA_CO_T;
-  f.total_floats = f.slot_off + (size_t)pl.KS * pl.maxseg;
+  f.wt_off = (f.slot_off + (size_t)pl.KS * pl.maxseg + 3) / 4 * 4;
+  f.t_off = f.wt_off + (size_t)9 * pl.cot * DMA_CO_T * pl.cit * DMA_CI_T;                       // doubles from here: keep 8-byte alignment
+  f.t_off = (f.t_off + 1) / 2 * 2;
+  f.total_floats = f.t_off + 2 * ((size_t)pl.KS * pl.maxseg + groups) * S2_ROWPARTS * pl.cit * DMA_CI_T;
   return f;
 }
 
@@ -345,12 +419,14 @@ size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int3
 
 int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
                                  int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
-                                 int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+                                 int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
+                                 void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_BF16 && src.ptr && dout.ptr && src.dtype == SF_BF16 && dout.dtype == SF_BF16,
              "sf_conv3x3_bwd_weight_folded: bf16-stored tensors and the SF_BF16 kernels only");
   SF_REQUIRE(groups >= 1 && n % groups == 0 && h >= 2 && w >= 2, "bwd_weight_folded: n=%d must split into %d groups of whole images, h, w >= 2", n, groups);
   SF_REQUIRE(src.c % SF_CPAD == 0 && dout.c % 8 == 0 && dout.c <= 2048 && src.idiv <= 1 && src.imod <= 0, "bwd_weight_folded: channel padding / no image remap");
   SF_REQUIRE(scale && shift && dw, "bwd_weight_folded: null argument");
+  SF_REQUIRE(!bn_sums || (weight && mean && rstd && ((uintptr_t)workspace & 7) == 0), "bwd_weight_folded: bn_sums needs weight, mean, rstd (and an 8-byte aligned workspace)");
   const int Np = dout.c, Kp = src.c;
   const Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups);
   const FoldLayout fl = fold_layout(pl, Np, n, groups);
@@ -382,6 +458,19 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
   hipLaunchKernelGGL(wgrad_reduce_folded_kernel, dim3(9 * p.NpT), dim3(256), 0, st, p.partial, p.partial_db,
                      pl.KS * pl.maxseg, slot_group, groups, p.NpT, p.KpT, Np, Kp, nmap, kmap, I, scale, shift, V, dw, db, accumulate);
   SF_CHECK_LAUNCH("wgrad_reduce_folded");
+  if (bn_sums) {
+    float* wt = (float*)workspace + fl.wt_off;
+    double* T = (double*)((float*)workspace + fl.t_off);
+    const int slots = pl.KS * pl.maxseg;
+    const size_t slab = (size_t)9 * p.NpT * p.KpT;
+    hipLaunchKernelGGL(fold_wt_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, st, weight, I, nmap, kmap, Np, Kp, p.NpT, p.KpT, wt);
+    SF_CHECK_LAUNCH("fold_wt");
+    hipLaunchKernelGGL(fold_bn_s2_kernel, dim3(slots + groups, p.KpT / 64, S2_ROWPARTS), dim3(256), 0, st, p.partial, slot_group, slots, wt, V, p.NpT,
+                       p.KpT, T);
+    SF_CHECK_LAUNCH("fold_bn_s2");
+    hipLaunchKernelGGL(fold_bn_sums_kernel, dim3((groups * Kp + 255) / 256), dim3(256), 0, st, T, slot_group, slots, groups, p.KpT, Kp, mean, rstd, bn_sums);
+    SF_CHECK_LAUNCH("fold_bn_sums");
+  }
   (void)O;
   return 0;
 }

@@ -40,6 +40,10 @@ struct ConvParams {
   // the folded BatchNorm in front of this convolution (sf_conv3x3_fwd_folded).  `bias` is null then.
   int wgroup; long long wgroup_bytes;
   const float* bias_tab; int np;  // [groups][9][np] or null
+  // bf16 kernel, transposed linear epilogue: the BatchNorm backward's affine map applied to the result before it is stored,
+  //   out = A * acc + B * x + K,  coefficients bnb_coef[group][3][bnb_c] (group = image / bnb_group), x = the BatchNorm's input
+  // (bf16, the output's pixels and channel lanes, pixel stride bnb_xs) - sf_conv3x3_bwd_data_bn
+  const float* bnb_coef; const void* bnb_x; int bnb_xs, bnb_group, bnb_c;
 };
 
 // border class of an output pixel (needs H, W >= 2); pixels outside the image (ragged tiles) get some valid class
@@ -351,6 +355,81 @@ __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const Con
 #pragma unroll
         for (int g = 0; g < 4; ++g)
           if (ok && cb + 8 * g < p.out_c) *reinterpret_cast<f32x4*>(of + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      }
+    }
+  }
+}
+
+// Transposed linear epilogue with the BatchNorm backward's affine map (sf_conv3x3_bwd_data_bn): out = A * acc + B * x + K, bf16 out.
+// lds_coef [3][32 * NF]: this N block's (A, B, K), staged here (zeros past out_c).  The x quads of BOTH M fragments are
+// requested before anything else (one memory latency per workgroup instead of one per fragment - the epilogue runs with the
+// matrix pipe idle, 1 workgroup per CU); NF = 5 requests them per M fragment (registers).
+template <int NF, int THREADS>
+__device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0, int wave,
+                                                     int r, int kh, float* lds_coef, int tid) {
+  constexpr int NB = 32 * NF;
+  constexpr int HOIST = NF <= 4 ? 2 : 1;
+  typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+  typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  auto pk = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); };
+  bool ok[2];
+  size_t pix[2];
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
+    ok[mf] = py < p.H && px < p.W;
+    pix[mf] = ok[mf] ? (size_t)(n * p.H + py) * p.W + px : 0;  // 0 for lanes outside: a valid address
+  }
+  int off[NF][4];  // channel quads past out_c (not stored) read quad 0 instead of running past the tensor
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) off[nf][g] = (nb * NB + nf * 32 + 8 * g < p.out_c ? nb * NB + nf * 32 + 8 * g : 0) + 4 * kh;
+  bf16x4_t xq[HOIST][NF][4];
+  auto request = [&](int slot, int mf) __attribute__((always_inline)) {
+    const __bf16* xp = reinterpret_cast<const __bf16*>(p.bnb_x) + pix[mf] * p.bnb_xs;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) xq[slot][nf][g] = *reinterpret_cast<const bf16x4_t*>(xp + off[nf][g]);
+  };
+  if constexpr (HOIST == 2) { request(0, 0); request(1, 1); } else request(0, 0);
+  // this N block's coefficients -> LDS under the x requests (the operand buffers are free once every wave has left the K loop)
+  __syncthreads();
+  {
+    const float* co = p.bnb_coef + (size_t)(n / p.bnb_group) * 3 * p.bnb_c;
+    for (int i = tid; i < 3 * NB; i += THREADS) {
+      const int c = nb * NB + i % NB;
+      lds_coef[i] = c < p.out_c ? co[(size_t)(i / NB) * p.bnb_c + c] : 0.f;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int mf = 0; mf < 2; ++mf) {
+    if constexpr (HOIST == 1) { if (mf == 1) request(0, 1); }
+    const int slot = HOIST == 2 ? mf : 0;
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const int cb = nb * NB + nf * 32;
+      float v[16];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const float* lc = lds_coef + nf * 32 + 8 * g + 4 * kh;
+        const f32x4 A = *reinterpret_cast<const f32x4*>(lc), B = *reinterpret_cast<const f32x4*>(lc + NB), Kc = *reinterpret_cast<const f32x4*>(lc + 2 * NB);
+#pragma unroll
+        for (int c = 0; c < 4; ++c)
+          v[4 * g + c] = __builtin_fmaf(A[c], acc[mf][nf][4 * g + c], __builtin_fmaf(B[c], (float)xq[slot][nf][g][c], Kc[c]));
+      }
+      __bf16* ob = reinterpret_cast<__bf16*>(p.out) + pix[mf] * p.out_s + cb + 8 * kh;
+#pragma unroll
+      for (int g = 0; g < 4; g += 2) {
+        unsigned ax = pk(v[4 * g], v[4 * g + 1]), ay = pk(v[4 * g + 2], v[4 * g + 3]);
+        unsigned bx = pk(v[4 * g + 4], v[4 * g + 5]), by = pk(v[4 * g + 6], v[4 * g + 7]);
+        auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+        auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+        if (ok[mf] && cb + 8 * g < p.out_c) *reinterpret_cast<u32x4_t*>(ob + 8 * g) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
       }
     }
   }

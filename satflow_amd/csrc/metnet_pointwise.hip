@@ -640,6 +640,21 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
   return 0;
 }
 
+int sf_batchnorm_train_bwd_coef(const double* sums, int64_t pix_per_group, int32_t groups, int32_t c, int32_t creal, const float* gamma,
+                                const float* mean, const float* rstd, float* coef, float* dgamma, float* dbeta, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_bwd_coef: dtype %d not built", dtype);
+  SF_REQUIRE(sums && gamma && mean && rstd && coef && dgamma && dbeta && groups >= 1 && creal <= c && c % 8 == 0 && pix_per_group > 0,
+             "batchnorm bwd coef: null argument / groups=%d c=%d creal=%d", groups, c, creal);
+  SF_REQUIRE(((uintptr_t)coef & 15) == 0, "batchnorm bwd coef: coef must be 16-byte aligned");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(bn_bwd_coef_kernel, dim3((groups * c + 255) / 256), dim3(256), 0, st, sums, groups, c, creal, (double)pix_per_group, gamma, mean,
+                     rstd, coef);
+  SF_CHECK_LAUNCH("bn_bwd_coef");
+  hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, groups, c, creal, dgamma, dbeta);
+  SF_CHECK_LAUNCH("bn_param_grad");
+  return 0;
+}
+
 }  // extern "C"
 
 // =============================================================================================

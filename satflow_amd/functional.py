@@ -369,21 +369,31 @@ class _BNConvFn(torch.autograd.Function):
         if gy.dtype != torch.bfloat16:
             gy = gy.to(torch.bfloat16)
         dev = gy.device
-        # d(normalised input) = conv^T(gy, W): plain weights
-        # d(normalised input) = conv^T(gy, W): plain weights
-        gm = eng.bwd_map((True,))
-        dn = torch.empty(n, H, W, C, dtype=x.dtype, device=dev)
-        K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, ctx.bias, "bwd", (True,))[0], None, gm, T(dn))
+        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=dev)
+        db = torch.empty(weight.shape[0], dtype=torch.float32, device=dev) if ctx.has_bias else None
         dx = torch.empty_like(x)
         sums = torch.empty(groups, 2, C, dtype=torch.float64, device=dev)
         dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
         coef = torch.empty(groups, 3, C, dtype=torch.float32, device=dev)
-        check(lib().sf_batchnorm_train_bwd(T(x), T(dn), (n * H * W) // groups, groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
-                                           stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
-                                           SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
-        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=dev)
-        db = torch.empty(weight.shape[0], dtype=torch.float32, device=dev) if ctx.has_bias else None
-        K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db)
+        gm = eng.bwd_map((True,))
+        packed_t = eng.packed(weight, ctx.bias, "bwd", (True,))[0]
+        if os.environ.get("SF_BN_BWD_PASSES"):  # A/B switch: the three-kernel form (input gradient, reduction pass, apply pass)
+            dn = torch.empty(n, H, W, C, dtype=x.dtype, device=dev)
+            K.conv3x3(T(gy), NULL, n, H, W, packed_t, None, gm, T(dn))
+            check(lib().sf_batchnorm_train_bwd(T(x), T(dn), (n * H * W) // groups, groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
+                                               stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
+                                               SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
+            K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db)
+        else:
+            # The weight gradient first: its per-group partial results also give the BatchNorm backward's two reductions
+            # (sum dn = W . V_g, sum dn * x = W . dWraw_g), so d(normalised input) = conv^T(gy, W) is never materialised - the input
+            # gradient convolution applies dx = A dn + B x + K in its epilogue.
+            w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
+            K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db, bn=(w4, stats[0], stats[1], sums))
+            check(lib().sf_batchnorm_train_bwd_coef(sums.data_ptr(), (n * H * W) // groups, groups, C, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
+                                                    stats[1].data_ptr(), coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32, stream_ptr()),
+                  "sf_batchnorm_train_bwd_coef")
+            K.conv3x3_bwd_data_bn(T(gy), n, H, W, packed_t, gm, T(x), coef, T(dx))
         return None, dx, dgamma, dbeta, None, None, None, None, None, None, dw4.reshape(weight.shape), db, None, None
 
 

@@ -224,16 +224,30 @@ def conv3x3_fold_supported(n: int, h: int, w: int, gm: GemmMap, groups: int, sta
 
 
 def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, scale: Tensor, shift: Tensor,
-                              dw: Tensor, db: Optional[Tensor]) -> None:
-    """sf_conv3x3_bwd_weight_folded: dW/db of a convolution behind a folded BatchNorm, from the un-normalised input."""
+                              dw: Tensor, db: Optional[Tensor], bn: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None) -> None:
+    """sf_conv3x3_bwd_weight_folded: dW/db of a convolution behind a folded BatchNorm, from the un-normalised input.
+    ``bn = (weight OIHW, mean, rstd, sums[groups,2,C] float64)``: also fills ``sums`` with the BatchNorm backward's two reductions."""
     dev = dw.device
     nmap, kmap = gm.tables(dev)
     groups = scale.shape[0]
     nbytes = lib().sf_conv3x3_bwd_weight_folded_workspace_bytes(dout.c, src.c, n, h, w, groups)
-    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dev)
+    ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev)
+    wgt = mean = rstd = sums = None
+    if bn is not None:
+        wgt, mean, rstd, sums = bn
+        wgt = wgt.detach().contiguous()
+        assert sums.dtype == torch.float64 and sums.is_contiguous() and mean.is_contiguous() and rstd.is_contiguous()
     check(lib().sf_conv3x3_bwd_weight_folded(src, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), dw.shape[0], dw.shape[1], scale.data_ptr(),
                                              shift.data_ptr(), groups, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
+                                             wgt.data_ptr() if bn is not None else None, mean.data_ptr() if bn is not None else None,
+                                             rstd.data_ptr() if bn is not None else None, sums.data_ptr() if bn is not None else None,
                                              ws.data_ptr(), nbytes, _hip.SF_BF16, stream_ptr()), "sf_conv3x3_bwd_weight_folded")
+
+
+def conv3x3_bwd_data_bn(dout: sfTensor, n: int, h: int, w: int, packed_t: Tensor, gm: GemmMap, x: sfTensor, coef: Tensor, dx: sfTensor) -> None:
+    """sf_conv3x3_bwd_data_bn: ``dx = A * conv^T(dout, W) + B * x + K`` (BatchNorm backward in the convolution's epilogue)."""
+    check(lib().sf_conv3x3_bwd_data_bn(dout, n, h, w, packed_t.data_ptr(), gm.Np, gm.nf, x, coef.data_ptr(), coef.shape[0], dx, _hip.SF_BF16,
+                                       stream_ptr()), "sf_conv3x3_bwd_data_bn")
 
 
 def to_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int], cp: Optional[int] = None) -> Tensor:

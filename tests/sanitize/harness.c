@@ -75,6 +75,8 @@ int main(void) {
   REFUSED(sf_batchnorm_eval_fwd(a16, 64, 32, ok, ok, 1e-5f, ok, ok, ok, ok, a16, SF_F32, st));       /* creal > lanes */
   REFUSED(sf_batchnorm_eval_bwd(a16, a64, 64, 16, ok, 1e-5f, ok, ok, ok, ok, a16, ok, ok, SF_F32, st));
   REFUSED(sf_batchnorm_train_bwd(a16, a64, 64, 1, 16, ok, ok, ok, ok, ok, a16, ok, ok, SF_F32, st));
+  REFUSED(sf_batchnorm_train_bwd_coef(0, 64, 1, 16, 16, ok, ok, ok, ok, ok, ok, SF_F32, st));           /* no sums */
+  REFUSED(sf_batchnorm_train_bwd_coef(ok, 64, 1, 16, 24, ok, ok, ok, ok, ok, ok, SF_F32, st));          /* more real channels than lanes */
   REFUSED(sf_leadtime_pool_fwd(a16, 1, 7, 8, ok, 16, 20, 8, 12, ok, a16, SF_F32, st));               /* odd height */
   REFUSED(sf_leadtime_pool_bwd(a16, a64, 1, 8, 8, ok, 16, 20, 8, 12, ok, a16, ok, SF_F32, st));
   /* ConvGRU */
@@ -103,9 +105,13 @@ int main(void) {
   REFUSED(sf_conv2d_bwd_weight(a16, a16, 1, 8, 8, 16, 16, 4, 4, 2, 1, ok, 0, 0, 0, 0, SF_F32, st));  /* no workspace */
   REFUSED(sf_leaky_relu(mis, 0, 64, 0.2f, ok, st));
   REFUSED(sf_leaky_relu(ok, 0, 63, 0.2f, ok, st));
-  REFUSED(sf_conv3x3_bwd_weight_folded(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
-  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, ok, 16, SF_BF16, st));      /* workspace too small */
-  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 3, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, ok, 1 << 30, SF_BF16, st)); /* ragged groups */
+  REFUSED(sf_conv3x3_bwd_weight_folded(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
+  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 16, SF_BF16, st));      /* workspace too small */
+  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, ok, ok, ok, ok, 1 << 30, SF_BF16, st)); /* bn_sums without the weights */
+  REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 3, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* ragged groups */
+  REFUSED(sf_conv3x3_bwd_data_bn(b16, 2, 8, 8, ok, 32, 1, a16, ok, 2, b16, SF_BF16, st));               /* fp32-stored x */
+  REFUSED(sf_conv3x3_bwd_data_bn(b16, 3, 8, 8, ok, 32, 1, b16, ok, 2, b16, SF_BF16, st));               /* ragged groups */
+  REFUSED(sf_conv3x3_bwd_data_bn(b16, 2, 8, 8, ok, 32, 1, b16, mis, 2, b16, SF_BF16, st));              /* misaligned coefficients */
   REFUSED(sf_l1_loss(a16, N0, 64, 1, 16, N0, ok, ok, st));                                           /* no target */
   REFUSED(sf_l1_loss(a16, a16, 64, 3, 16, N0, ok, ok, st));                                          /* rows not divisible into groups */
   REFUSED(sf_bce_logits_loss(a16, 1.f, 0.f, 64, 1, 32, N0, ok, ok, st));                             /* more lanes than the stride */

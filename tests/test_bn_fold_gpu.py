@@ -177,3 +177,85 @@ def test_folded_path_is_taken_in_bf16a_mode(device, monkeypatch):
     x = torch.randn(4, 16, 16, 16, device=device).to(torch.bfloat16)
     ds.run(x, 2)
     assert len(calls) == 3
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(6, 3, 32, 64, 20, 20), (12, 3, 160, 256, 32, 32), (8, 4, 64, 48, 16, 16)])
+def test_bn_backward_sums_from_weight_gradient_partials(device, n, groups, cin, cout, H, W):
+    """sum dn and sum dn * xhat (dn = conv^T(dout, W)) derived from V_g and the per-group raw weight gradient, against float64 sums
+    over an explicitly formed dn."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T
+
+    F, x, bn, conv, eng = _setup(device, n, groups, cin, cout, H, W, seed=7)
+    g = torch.Generator().manual_seed(8)
+    gy = torch.randn(n, H, W, eng.coutp, generator=g).to(device).to(torch.bfloat16)
+    gy[..., cout:] = 0
+    a, b = _ref_stats(x, bn, groups)
+    xg = x.double().reshape(groups, -1, cin)
+    mean, var = xg.mean(1), xg.var(1, unbiased=False)
+    rstd = 1.0 / torch.sqrt(var + bn.eps)
+    dw = torch.empty(cout, cin, 3, 3, device=device)
+    sums = torch.empty(groups, 2, cin, dtype=torch.float64, device=device)
+    K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, a.float().contiguous(), b.float().contiguous(), dw, None,
+                                bn=(conv.weight, mean.float().contiguous(), rstd.float().contiguous(), sums))
+    dn = torch.nn.functional.conv_transpose2d(gy[..., :cout].double().permute(0, 3, 1, 2), conv.weight.double(), padding=1)  # [n, cin, H, W]
+    dng = dn.permute(0, 2, 3, 1).reshape(groups, -1, cin)
+    xhat = (xg - mean.float().double()[:, None]) * rstd.float().double()[:, None]
+    assert rel_l2(sums[:, 0], dng.sum(1)) < 1e-4
+    assert rel_l2(sums[:, 1], (dng * xhat).sum(1)) < 1e-4
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(6, 3, 32, 64, 20, 20), (4, 2, 160, 256, 32, 32), (8, 4, 48, 96, 12, 10)])
+def test_input_gradient_with_batchnorm_backward_epilogue(device, n, groups, cin, cout, H, W):
+    """sf_conv3x3_bwd_data_bn: dx = A * conv^T(dout, W) + B * x + K per (group, channel), float64 of the same operands."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T
+
+    F, x, bn, conv, eng = _setup(device, n, groups, cin, cout, H, W, seed=9)
+    g = torch.Generator().manual_seed(10)
+    gy = torch.randn(n, H, W, eng.coutp, generator=g).to(device).to(torch.bfloat16)
+    gy[..., cout:] = 0
+    coef = torch.randn(groups, 3, cin, generator=g).to(device).contiguous()
+    dx = torch.empty_like(x)
+    packed_t = eng.packed(conv.weight, conv.bias, "bwd", (True,))[0]
+    K.conv3x3_bwd_data_bn(T(gy), n, H, W, packed_t, eng.bwd_map((True,)), T(x), coef, T(dx))
+    wb = conv.weight.to(torch.bfloat16).double()
+    dn = torch.nn.functional.conv_transpose2d(gy[..., :cout].double().permute(0, 3, 1, 2), wb, padding=1).permute(0, 2, 3, 1)
+    ipg = n // groups
+    cg = coef.double().repeat_interleave(ipg, 0)  # [n, 3, cin]
+    ref = cg[:, 0, None, None, :] * dn + cg[:, 1, None, None, :] * x.double() + cg[:, 2, None, None, :]
+    assert rel_l2(dx.double(), ref) < 3e-3  # bf16 storage of the result
+    assert rel_l2(dx.double(), ref.float().to(torch.bfloat16).double()) < 3e-4  # against the rounded reference: a few last-bit flips
+
+
+def test_fused_batchnorm_backward_matches_the_three_kernel_form(device, monkeypatch):
+    import satflow_amd
+    from satflow_amd.models.metnet import DownSampler
+
+    satflow_amd.set_compute_dtype("bf16")
+    monkeypatch.delenv("SF_NO_BN_FOLD", raising=False)
+    torch.manual_seed(4)
+    ds = DownSampler(12, 256).to(device).train()
+    x = torch.randn(12, 32, 32, 16, device=device).to(torch.bfloat16)
+    gout = torch.randn(12, 8, 8, 256, device=device)
+
+    def run(passes):
+        if passes:
+            monkeypatch.setenv("SF_BN_BWD_PASSES", "1")
+        else:
+            monkeypatch.delenv("SF_BN_BWD_PASSES", raising=False)
+        for p in ds.parameters():
+            p.grad = None
+        xi = x.clone().requires_grad_(True)
+        ds.run(xi, 3, out_dtype=torch.float32).backward(gout)
+        return xi.grad.float(), {k: p.grad.clone() for k, p in ds.named_parameters()}
+
+    dx1, g1 = run(False)
+    dx0, g0 = run(True)
+    # the three-kernel form rounds the gradient entering each BatchNorm to bf16 before reducing it, the fused form does not:
+    # differences are that rounding, amplified by the two BatchNorms behind it
+    assert rel_l2(dx1, dx0) < 3e-2
+    for k in g0:
+        if k.endswith("bias") and ("module.0" in k or "module.4" in k or "module.6" in k):
+            continue
+        assert rel_l2(g1[k], g0[k]) < 3e-2, f"{k}: {rel_l2(g1[k], g0[k]):.3e}"
