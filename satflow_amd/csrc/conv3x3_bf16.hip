@@ -56,6 +56,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   constexpr int PIECES = HALO_H * HALO_W * 2;                 // 16-byte bf16 pieces of the halo tile
   constexpr int NPIECE = (PIECES + THREADS - 1) / THREADS;
   __shared__ __attribute__((aligned(1024))) char lds[2 * W_B + 2 * IN_B];
+  __shared__ __attribute__((aligned(16))) float lds_coef[BNB ? 3 * NB : 4];  // BatchNorm-backward epilogue: (A, B, K) of this N block
   char* lds_w = lds;
   char* lds_in = lds + 2 * W_B;
 
@@ -86,6 +87,14 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     ni = n + sel; gy = y0 + (iy - 18 * sel) - 1; gx = x0 + ix - 1;
     return ni < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
   };
+
+  if constexpr (BNB) {  // staged now, read in the epilogue: the K loop's barriers order the two, the epilogue pays nothing for it
+    const float* co = p.bnb_coef + (size_t)(n / p.bnb_group) * 3 * p.bnb_c;
+    for (int i = tid; i < 3 * NB; i += THREADS) {
+      const int c = nb * NB + i % NB;
+      lds_coef[i] = c < p.out_c ? co[(size_t)(i / NB) * p.bnb_c + c] : 0.f;
+    }
+  }
 
   f32x16 acc[2][NF];
 #pragma unroll
@@ -332,7 +341,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     }
   }
   if constexpr (TR && BNB) {
-    conv_epilogue_tr_bnb<NF, THREADS>(acc, p, n, nb, y0, x0, wave, r, kh, reinterpret_cast<float*>(lds), tid);
+    conv_epilogue_tr_bnb<NF>(acc, p, n, nb, y0, x0, wave, r, kh, lds_coef);
     return;
   } else if constexpr (TR) {
     if (!DUAL || n_w < p.N) conv_epilogue_tr<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh);

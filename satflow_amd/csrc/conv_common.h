@@ -361,12 +361,12 @@ __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const Con
 }
 
 // Transposed linear epilogue with the BatchNorm backward's affine map (sf_conv3x3_bwd_data_bn): out = A * acc + B * x + K, bf16 out.
-// lds_coef [3][32 * NF]: this N block's (A, B, K), staged here (zeros past out_c).  The x quads of BOTH M fragments are
+// lds_coef [3][32 * NF]: this N block's (A, B, K), staged by the kernel BEFORE its K loop (zeros past out_c).  The x quads of BOTH M fragments are
 // requested before anything else (one memory latency per workgroup instead of one per fragment - the epilogue runs with the
 // matrix pipe idle, 1 workgroup per CU); NF = 5 requests them per M fragment (registers).
-template <int NF, int THREADS>
+template <int NF>
 __device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0, int wave,
-                                                     int r, int kh, float* lds_coef, int tid) {
+                                                     int r, int kh, const float* lds_coef) {
   constexpr int NB = 32 * NF;
   constexpr int HOIST = NF <= 4 ? 2 : 1;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
@@ -396,16 +396,6 @@ __device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const
       for (int g = 0; g < 4; ++g) xq[slot][nf][g] = *reinterpret_cast<const bf16x4_t*>(xp + off[nf][g]);
   };
   if constexpr (HOIST == 2) { request(0, 0); request(1, 1); } else request(0, 0);
-  // this N block's coefficients -> LDS under the x requests (the operand buffers are free once every wave has left the K loop)
-  __syncthreads();
-  {
-    const float* co = p.bnb_coef + (size_t)(n / p.bnb_group) * 3 * p.bnb_c;
-    for (int i = tid; i < 3 * NB; i += THREADS) {
-      const int c = nb * NB + i % NB;
-      lds_coef[i] = c < p.out_c ? co[(size_t)(i / NB) * p.bnb_c + c] : 0.f;
-    }
-  }
-  __syncthreads();
 #pragma unroll
   for (int mf = 0; mf < 2; ++mf) {
     if constexpr (HOIST == 1) { if (mf == 1) request(0, 1); }
