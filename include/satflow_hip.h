@@ -327,6 +327,15 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
 int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h, int32_t w, const void* wpacked,
                        const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, int32_t dtype,
                        sfStream stream);
+/* The backward time loop of the same sequence in ONE launch (one workgroup per image, maps of at most 16x16, hidp 32 or 64,
+ * SF_BF16 kernels, bf16-stored gates): for t = T-1 .. 0 the gate backward (as sf_convgru_bwd_gates) and the recurrent
+ * input-gradient convolution conv^T(dgh_t, Wh) (as sf_conv3x3_fwd with the transposed image wpacked_t: N = hidp, K = 3*hidp),
+ * the carried gradient staying in registers.  g_seq [T][n][h][w][hidp] / g_last [n][h][w][hidp]: gradients wrt all states / the
+ * last state (fp32, either may be NULL); gates, hs as written by sf_convgru_seq_fwd; out: dgx = [az|ar|an], dgh = [az|ar|dh2]
+ * [T][n][h][w][3*hidp] bf16-stored - bit-identical to the per-step entry points. */
+int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor hs, int32_t T, int32_t n, int32_t h,
+                       int32_t w, const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, int32_t dtype,
+                       sfStream stream);
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
  * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
  * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */

@@ -81,6 +81,7 @@ PROTOTYPES = {
     "sf_batchnorm_train_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),
     "sf_convgru_step_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_convgru_seq_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
+    "sf_convgru_seq_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_convgru_bwd_gates": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],

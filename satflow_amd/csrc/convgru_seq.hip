@@ -252,6 +252,208 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
 
+
+// =============================================================================================
+// Persistent BACKWARD of the same time loop (sf_convgru_seq_bwd): for t = T-1 .. 0
+//   dh_t   = [g_seq_t] + [g_last at t = T-1] + dd_{t+1} + conv3x3^T(dgh_{t+1}, Wh)
+//   (az, ar, an, d2, dd) = gate backward(dh_t; saved z, r, n, h2 of step t; h_{t-1})          (sf_gru_bwd)
+//   dgx_t = [az | ar | an],  dgh_t = [az | ar | d2]                                          -> HBM (bf16), read by the batched convolutions
+// One workgroup owns one image.  The carried gradient (dd and the convolution result) never leaves registers: the lane that
+// receives an element of conv^T(dgh_{t+1}) from the MFMA is the lane that runs the gate backward of that element.  dgh_{t+1} as the
+// convolution's operand lives in LDS as bf16 [K chunk][pixel][16 channels] (no halo: taps that fall outside the image read a
+// zero pixel kept behind every chunk); the transposed-flipped recurrent weights (sf_conv3x3_pack_weights, transpose 1, N = hidp,
+// K = 3 * hidp) stream from L2 through a two-stage ring by LDS-DMA.  The saved gates and h_{t-1} of the NEXT step to process are
+// requested before the K loop and arrive under it.
+// 8 waves: wave = (4-row band, M fragment): one 32-pixel fragment x all hidp channels per wave; K order (chunks ascending, taps
+// ascending) and products are those of the per-step convolution, the gate arithmetic is sf_gru_bwd: dgx / dgh are bit-identical
+// to the per-step kernels (sf_convgru_bwd_gates + sf_conv3x3_fwd), tests/test_convgru_seq_gpu.py.
+struct GruSeqBwdParams {
+  const float* g_seq; int gs_s;        // [T][n][H][W][hidp] fp32 or null
+  const float* g_last; int gl_s;       // [n][H][W][hidp] fp32 or null
+  const __bf16* gates; int gates_s;    // saved z | r | n | h2, [T][n][H][W][4*hidp] bf16
+  const float* hs; int hs_s;           // states [T][n][H][W][hidp] fp32 (h_{t-1} = hs[t-1], zeros at t = 0)
+  __bf16* dgx; int dgx_s;              // [T][n][H][W][3*hidp] bf16
+  __bf16* dgh; int dgh_s;
+  const void* wp;                      // packed transposed weights [chunks = 3*hidp/16][9][hidp][16] bf16
+  int T, n, H, W, hidp;
+};
+
+constexpr int BP_CHUNK_B = (256 + 1) * PIX_B;  // 256 pixels + one zero pixel per K chunk
+
+template <int NFR>  // 32-channel fragments of the hidden state (hidp = 32 * NFR)
+__global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwdParams p) {
+  constexpr int HID = 32 * NFR, CHUNKS = 3 * HID / 16;
+  constexpr int WB = 9 * HID * PIX_B;          // weights of one chunk
+  constexpr int PIECES = WB / 1024;            // 9 * NFR
+  constexpr int THREADS = 512, WAVES = 8;
+  __shared__ __attribute__((aligned(1024))) char lds[2 * WB + CHUNKS * BP_CHUNK_B];
+  char* lds_t = lds + 2 * WB;
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wl = wave & 3, mf = wave >> 2;
+  const int r = lane & 31, kh = lane >> 5;
+  const int img = blockIdx.x;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+
+  for (int i = tid; i < CHUNKS * BP_CHUNK_B / 16; i += THREADS) *reinterpret_cast<f32x4*>(lds_t + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)p.wp, 0, CHUNKS * WB, 0x00020000);
+  auto issue_weights = [&](int ci, int buf) {
+    for (int i = wave; i < PIECES; i += WAVES) bufdma16(lane * 16, rs_w, (unsigned)(ci * WB + i * 1024), lds0 + (unsigned)(buf * WB + i * 1024));
+  };
+
+  // this lane's pixel and its channel quads nf * 32 + 8g + 4kh (the transposed product's accumulator layout)
+  const int py = 4 * wl + 2 * mf + (r >> 4), px = r & 15;
+  const bool ok = py < p.H && px < p.W;
+  const long long img_px = (long long)p.H * p.W;
+  const long long pix_i = (long long)img * img_px + (ok ? py * p.W + px : 0);  // + t * n * img_px; clamped: loads are unconditional
+  const long long step_px = (long long)p.n * img_px;
+  const int cq = 4 * kh;
+
+  // A-operand read offsets per tap (within a chunk): the source pixel of tap (ky, kx), or the chunk's zero pixel
+  int a_off[9];
+#pragma unroll
+  for (int tap = 0; tap < 9; ++tap) {
+    const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
+    const bool in = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+    a_off[tap] = in ? (sy * 16 + sx) * PIX_B + 16 * (kh ^ (sy & 1)) : 256 * PIX_B + 16 * kh;
+  }
+  const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
+
+  __syncthreads();  // zero fill complete
+  issue_weights(0, 0);
+
+  // gradient wrt h_t carried into the gate backward (this lane's 16 * NFR elements)
+  f32x4 dh[NFR][4];
+  {
+    const long long pl = (long long)img * img_px + (ok ? py * p.W + px : 0);
+    const long long pt = (long long)(p.T - 1) * step_px + pix_i;
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int ch = nf * 32 + 8 * g + cq;
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};
+        if (p.g_seq) v = *reinterpret_cast<const f32x4*>(p.g_seq + pt * p.gs_s + ch);
+        if (p.g_last) v += *reinterpret_cast<const f32x4*>(p.g_last + pl * p.gl_s + ch);
+        dh[nf][g] = v;
+      }
+  }
+  // saved gates and previous state of the step about to be processed
+  bf16x4 gv[4][NFR][4];
+  f32x4 hp[NFR][4];
+  auto request = [&](int t) __attribute__((always_inline)) {
+    const long long pt = (long long)t * step_px + pix_i;
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+#pragma unroll
+      for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) gv[q][nf][g] = *reinterpret_cast<const bf16x4*>(p.gates + pt * p.gates_s + q * p.hidp + nf * 32 + 8 * g + cq);
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        hp[nf][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+        if (t > 0) hp[nf][g] = *reinterpret_cast<const f32x4*>(p.hs + (pt - step_px) * p.hs_s + nf * 32 + 8 * g + cq);
+      }
+  };
+  request(p.T - 1);
+
+  for (int t = p.T - 1; t >= 0; --t) {
+    // ---- gate backward of step t ----
+    const long long pt = (long long)t * step_px + pix_i;
+    f32x4 dd[NFR][4];
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf) {
+      f32x4 az[4], ar[4], an[4], d2[4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const f32x4 z = __builtin_convertvector(gv[0][nf][g], f32x4), rr = __builtin_convertvector(gv[1][nf][g], f32x4),
+                    nn = __builtin_convertvector(gv[2][nf][g], f32x4), h2 = __builtin_convertvector(gv[3][nf][g], f32x4);
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          const sfGruBwd o = sf_gru_bwd(dh[nf][g][c], z[c], rr[c], nn[c], h2[c], hp[nf][g][c]);
+          az[g][c] = o.az; ar[g][c] = o.ar; an[g][c] = o.an; d2[g][c] = o.d2; dd[nf][g][c] = o.dd;
+        }
+      }
+      // octets after the half-wave swap: this lane then holds channels nf*32 + 8*(g + kh) .. +7 for g = 0, 2
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // q: 0 az, 1 ar, 2 an (dgx only), 3 d2 (dgh only)
+        const f32x4* v = q == 0 ? az : q == 1 ? ar : q == 2 ? an : d2;
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const unsigned ax = pk(v[g][0], v[g][1]), ay = pk(v[g][2], v[g][3]);
+          const unsigned bx = pk(v[g + 1][0], v[g + 1][1]), by = pk(v[g + 1][2], v[g + 1][3]);
+          const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          const u32x4_t oct = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+          const int ch = nf * 32 + 8 * (g + kh);
+          if (ok) {
+            if (q != 3) *reinterpret_cast<u32x4_t*>(p.dgx + pt * p.dgx_s + q * p.hidp + ch) = oct;
+            if (q != 2) {
+              const int qh = q == 3 ? 2 : q;  // dgh = [az | ar | d2]
+              *reinterpret_cast<u32x4_t*>(p.dgh + pt * p.dgh_s + qh * p.hidp + ch) = oct;
+              if (t > 0) {  // the next convolution's operand
+                const int k = qh * HID + ch;
+                *reinterpret_cast<u32x4_t*>(lds_t + (k >> 4) * BP_CHUNK_B + (py * 16 + px) * PIX_B + 16 * (((ch >> 3) & 1) ^ (py & 1))) = oct;
+              }
+            }
+          }
+        }
+      }
+    }
+    if (t == 0) break;
+    request(t - 1);  // arrives under the K loop
+
+    // ---- carry = conv3x3^T(dgh_t, Wh): D[channel][pixel], K = 3 * hidp ----
+    f32x16 acc[NFR];
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+      for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+    for (int ci = 0; ci < CHUNKS; ++ci) {
+      const int it = (p.T - 1 - t) * CHUNKS + ci, cur = it & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weights have landed
+      __syncthreads();                                   // ... everybody's; the tile writes of this step are visible
+      const bool more = !(t == 1 && ci + 1 == CHUNKS);
+      const bool stage_late = wave >= 4;
+      const int nci = ci + 1 < CHUNKS ? ci + 1 : 0;
+      if (more && !stage_late) issue_weights(nci, cur ^ 1);
+      const char* inb = lds_t + ci * BP_CHUNK_B;
+      const char* wb = lds + cur * WB + b_lane;
+      bf16x8 fa[2], fb[2][NFR];
+      auto load_tap = [&](int tap, bf16x8& a, bf16x8 (&b)[NFR]) __attribute__((always_inline)) {
+        a = *reinterpret_cast<const bf16x8*>(inb + a_off[tap]);
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * HID + nf * 32) * PIX_B);
+      };
+      load_tap(0, fa[0], fb[0]);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1], acc[nf], 0, 0, 0);
+        if (tap == 3 && more && stage_late) issue_weights(nci, cur ^ 1);
+      }
+    }
+    __syncthreads();  // every wave is done reading the tile of step t
+
+    // dh_{t-1} = [g_seq_{t-1}] + dd_t + carry   (summation order of the per-step path: (g_seq + direct) + carry)
+#pragma unroll
+    for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        f32x4 base = dd[nf][g];
+        if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + (pt - step_px) * p.gs_s + nf * 32 + 8 * g + cq) + dd[nf][g];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) dh[nf][g][c] = base[c] + acc[nf][4 * g + c];
+      }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
 }  // namespace
 
 extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h, int32_t w, const void* wpacked,
@@ -281,5 +483,34 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   else { if (p.gx_bf) SF_GRU_SEQ(2, true); else SF_GRU_SEQ(2, false); }
 #undef SF_GRU_SEQ
   SF_CHECK_LAUNCH("convgru_seq_fwd");
+  return 0;
+}
+
+extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor hs, int32_t T, int32_t n, int32_t h, int32_t w,
+                                  const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16, "sf_convgru_seq_bwd: the persistent sequence kernel is built for the SF_BF16 kernels (got dtype %d)", dtype);
+  SF_REQUIRE(h >= 1 && w >= 1 && h <= 16 && w <= 16, "sf_convgru_seq_bwd: one workgroup owns a whole map: H, W <= 16 (got %dx%d)", h, w);
+  SF_REQUIRE(hidp == 32 || hidp == 64, "sf_convgru_seq_bwd: hidp=%d (32 or 64)", hidp);
+  SF_REQUIRE(gates.ptr && gates.dtype == SF_BF16 && gates.c == 4 * hidp && ((uintptr_t)gates.ptr & 7) == 0 && gates.stride % 4 == 0,
+             "sf_convgru_seq_bwd: gates [..,4*hidp] bf16-stored, 8-byte aligned channel quads");
+  SF_REQUIRE(hs.ptr && hs.dtype == SF_F32 && hs.c == hidp && ((uintptr_t)hs.ptr & 15) == 0 && hs.stride % 4 == 0, "sf_convgru_seq_bwd: hs [..,hidp] fp32, 16-byte aligned pixels");
+  auto grad_ok = [&](const sfTensor& t) { return !t.ptr || (t.dtype == SF_F32 && t.c == hidp && ((uintptr_t)t.ptr & 15) == 0 && t.stride % 4 == 0); };
+  SF_REQUIRE(grad_ok(g_seq) && grad_ok(g_last), "sf_convgru_seq_bwd: g_seq / g_last [..,hidp] fp32, 16-byte aligned pixels (or null)");
+  auto out_ok = [&](const sfTensor& t) { return t.ptr && t.dtype == SF_BF16 && t.c == 3 * hidp && ((uintptr_t)t.ptr & 15) == 0 && t.stride % 8 == 0; };
+  SF_REQUIRE(out_ok(dgx) && out_ok(dgh) && wpacked_t, "sf_convgru_seq_bwd: dgx / dgh [..,3*hidp] bf16-stored, 16-byte aligned pixels; weights non-null");
+  if (T <= 0 || n <= 0) return 0;
+  GruSeqBwdParams p{};
+  p.g_seq = (const float*)g_seq.ptr; p.gs_s = g_seq.stride;
+  p.g_last = (const float*)g_last.ptr; p.gl_s = g_last.stride;
+  p.gates = (const __bf16*)gates.ptr; p.gates_s = gates.stride;
+  p.hs = (const float*)hs.ptr; p.hs_s = hs.stride;
+  p.dgx = (__bf16*)dgx.ptr; p.dgx_s = dgx.stride;
+  p.dgh = (__bf16*)dgh.ptr; p.dgh_s = dgh.stride;
+  p.wp = wpacked_t;
+  p.T = T; p.n = n; p.H = h; p.W = w; p.hidp = hidp;
+  hipStream_t st = (hipStream_t)stream;
+  if (hidp == 64) hipLaunchKernelGGL((convgru_seq_bwd_kernel<2>), dim3(n), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((convgru_seq_bwd_kernel<1>), dim3(n), dim3(512), 0, st, p);
+  SF_CHECK_LAUNCH("convgru_seq_bwd");
   return 0;
 }

@@ -41,13 +41,8 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p
     f32x4 az, ar, an, d2, dd;
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const float dn = dh[j] * (1.f - z[j]);
-      const float dz = dh[j] * (hp[j] - n[j]);
-      an[j] = dn * (1.f - n[j] * n[j]);
-      ar[j] = an[j] * h2[j] * r[j] * (1.f - r[j]);
-      d2[j] = an[j] * r[j];
-      az[j] = dz * z[j] * (1.f - z[j]);
-      dd[j] = dh[j] * z[j];
+      const sfGruBwd o = sf_gru_bwd(dh[j], z[j], r[j], n[j], h2[j], hp[j]);
+      az[j] = o.az; ar[j] = o.ar; an[j] = o.an; d2[j] = o.d2; dd[j] = o.dd;
     }
     TD* a = reinterpret_cast<TD*>(p.dgx) + pix * p.s_dgx + c;
     stv4(a, az); stv4(a + p.hidp, ar); stv4(a + 2 * p.hidp, an);

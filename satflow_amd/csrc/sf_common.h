@@ -50,6 +50,23 @@ __device__ __forceinline__ float sf_tanh(float v) {
 //   h' = (1 - z) * n + z * h  ==  n + z * (h - n)
 __device__ __forceinline__ float sf_gru_blend(float z, float cand, float hp) { return __builtin_fmaf(z, hp - cand, cand); }
 __device__ __forceinline__ float sf_gru_cand_arg(float gn, float rg, float h2) { return __builtin_fmaf(rg, h2, gn); }
+// Gate backward of one element, shared by gru_bwd_gates_kernel and the persistent backward kernel (convgru_seq.hip) with a fixed
+// operation order (no contraction): the two must produce the same bf16 MFMA operands for the recurrent input-gradient convolution.
+//   in: dh' and the saved z, r, n (candidate), h2, previous state hp
+//   out: az, ar (pre-activation gradients of z, r), an (of the candidate's argument), d2 = d(h2), dd = dh' * z (direct path to hp)
+struct sfGruBwd { float az, ar, an, d2, dd; };
+__device__ __forceinline__ sfGruBwd sf_gru_bwd(float dh, float z, float r, float n, float h2, float hp) {
+#pragma clang fp contract(off)
+  sfGruBwd o;
+  const float dn = dh * (1.f - z);
+  const float dz = dh * (hp - n);
+  o.an = dn * (1.f - n * n);
+  o.ar = o.an * h2 * r * (1.f - r);
+  o.d2 = o.an * r;
+  o.az = dz * z * (1.f - z);
+  o.dd = dh * z;
+  return o;
+}
 
 // ---- storage-typed 4-channel access (fp32 or bf16 activations) ---------------------------------
 typedef __bf16 bf16x4 __attribute__((ext_vector_type(4)));

@@ -611,11 +611,17 @@ class _ConvGRUSeqFn(torch.autograd.Function):
         gdt = gates.dtype
         dgx = torch.empty(Tn, n, H, W, 3 * hidp, dtype=gdt, device=dev)
         dgh = torch.empty(Tn, n, H, W, 3 * hidp, dtype=gdt, device=dev)
-        direct = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)  # dh * z of the step above
-        carry = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)   # conv^T(dgh) of the step above
+        if K.convgru_seq_bwd_supported(H, W, hidp, gates) and not os.environ.get("SF_GRU_PER_STEP"):
+            # the whole time loop in ONE launch, carried gradient in registers (bit-identical dgx / dgh)
+            K.convgru_seq_bwd(g_seq, g_last, gates, hs, Tn, n, H, W, pk["h_bwd"], hidp, dgx, dgh)
+            steps = ()
+        else:
+            steps = range(Tn - 1, -1, -1)
+            direct = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)  # dh * z of the step above
+            carry = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)   # conv^T(dgh) of the step above
         zeros = None
         have_carry = False
-        for t in range(Tn - 1, -1, -1):
+        for t in steps:
             src: List[sfTensor] = []
             if g_seq is not None:
                 src.append(T(g_seq[t]))

@@ -382,6 +382,18 @@ def convgru_seq_fwd(gx: Tensor, h0: Optional[Tensor], Tn: int, n: int, h: int, w
                                    hidp, T(hs), T(gates) if gates is not None else NULL, _hip.compute_dtype(), stream_ptr()), "sf_convgru_seq_fwd")
 
 
+def convgru_seq_bwd_supported(h: int, w: int, hidp: int, gates: Tensor) -> bool:
+    """The persistent backward kernel: as the forward one, hidp 32 or 64, bf16-stored gates ("bf16a" mode)."""
+    return convgru_seq_supported(h, w, hidp) and hidp in (32, 64) and gates.dtype == torch.bfloat16
+
+
+def convgru_seq_bwd(g_seq: Optional[Tensor], g_last: Optional[Tensor], gates: Tensor, hs: Tensor, Tn: int, n: int, h: int, w: int,
+                    packed_t: Tensor, hidp: int, dgx: Tensor, dgh: Tensor) -> None:
+    """The whole backward time loop in one launch (sf_convgru_seq_bwd)."""
+    check(lib().sf_convgru_seq_bwd(T(g_seq, hidp), T(g_last, hidp), T(gates), T(hs), Tn, n, h, w, packed_t.data_ptr(), hidp, T(dgx), T(dgh),
+                                   _hip.SF_BF16, stream_ptr()), "sf_convgru_seq_bwd")
+
+
 def convgru_bwd_gates(dh: Sequence[sfTensor], gates: Tensor, h_prev: Optional[Tensor], hidp: int, dgx: Tensor, dgh: Tensor,
                       dh_direct: Optional[Tensor]) -> None:
     dh = list(dh) + [NULL] * (3 - len(dh))

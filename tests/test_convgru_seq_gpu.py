@@ -88,3 +88,52 @@ def test_convgru_module_uses_persistent_kernel_and_matches_per_step(device, monk
     assert torch.equal(res["persistent"][1], res["per_step"][1])
     for k in res["per_step"][2]:
         assert torch.equal(res["persistent"][2][k], res["per_step"][2][k]), k
+
+
+@pytest.mark.parametrize("Tn,n,H,W,hid", [(5, 3, 16, 16, 64), (4, 2, 16, 16, 32), (3, 2, 12, 10, 64), (3, 1, 5, 7, 32), (24, 4, 16, 16, 64), (1, 2, 16, 16, 64)])
+@pytest.mark.parametrize("use_seq,use_last", [(False, True), (True, False), (True, True)])
+def test_persistent_backward_matches_per_step_kernels(device, bf16_mode, Tn, n, H, W, hid, use_seq, use_last):
+    """sf_convgru_seq_bwd (the whole backward time loop in one launch) against sf_convgru_bwd_gates + sf_conv3x3_fwd per step: the
+    bf16-stored dgx / dgh must agree bit for bit (same gate arithmetic, same K order, same summation order of the carried gradient)."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import NULL, T, cpad
+    from satflow_amd.functional import GRUEngine
+
+    g = torch.Generator().manual_seed(Tn * 1000 + H * 10 + hid + 7)
+    hidp = cpad(hid)
+    eng = GRUEngine(16, hid)
+    Wh = (torch.randn(3 * hid, hid, 3, 3, generator=g) * (0.6 / hid**0.5)).to(device)
+    packed_t = K.pack_weights(Wh, None, eng.h_bwd, True)[0]
+    gates = torch.rand(Tn, n, H, W, 4 * hidp, generator=g)
+    gates[..., 2 * hidp:] = gates[..., 2 * hidp:] * 2 - 1  # candidate in (-1, 1), h2 any sign
+    gates = gates.to(device).to(torch.bfloat16)
+    hs = (torch.randn(Tn, n, H, W, hidp, generator=g) * 0.5).to(device)
+    g_seq = torch.randn(Tn, n, H, W, hidp, generator=g).to(device) if use_seq else None
+    g_last = torch.randn(n, H, W, hidp, generator=g).to(device) if use_last else None
+    assert K.convgru_seq_bwd_supported(H, W, hidp, gates)
+    dgx = torch.full((Tn, n, H, W, 3 * hidp), float("nan"), device=device).to(torch.bfloat16)
+    dgh = torch.full((Tn, n, H, W, 3 * hidp), float("nan"), device=device).to(torch.bfloat16)
+    K.convgru_seq_bwd(g_seq, g_last, gates, hs, Tn, n, H, W, packed_t, hidp, dgx, dgh)
+    # reference: the per-step kernels
+    rgx, rgh = torch.zeros_like(dgx), torch.zeros_like(dgh)
+    direct = torch.empty(n, H, W, hidp, device=device)
+    carry = torch.empty(n, H, W, hidp, device=device)
+    have = False
+    for t in range(Tn - 1, -1, -1):
+        src = []
+        if g_seq is not None:
+            src.append(T(g_seq[t]))
+        if t == Tn - 1 and g_last is not None:
+            src.append(T(g_last))
+        if have:
+            src += [T(direct), T(carry)]
+        K.convgru_bwd_gates(src, gates[t], hs[t - 1] if t else None, hidp, rgx[t], rgh[t], direct if t else None)
+        if t:
+            K.conv3x3(T(rgh[t]), NULL, n, H, W, packed_t, None, eng.h_bwd, T(carry))
+            have = True
+    torch.cuda.synchronize()
+    assert torch.isfinite(dgx.float()).all() and torch.isfinite(dgh.float()).all()
+    for name, a, b in (("dgx", dgx, rgx), ("dgh", dgh, rgh)):
+        for t in range(Tn - 1, -1, -1):  # report the first step (from the end) that differs
+            assert torch.equal(a[t], b[t]), f"{name}[{t}] differs: max {float((a[t].float() - b[t].float()).abs().max()):.3e}"
+    assert float(dgx.float().abs().max()) > 1e-3
