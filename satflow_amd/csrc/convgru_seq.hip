@@ -286,8 +286,9 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
   constexpr int WB = 9 * HID * PIX_B;          // weights of one chunk
   constexpr int PIECES = WB / 1024;            // 9 * NFR
   constexpr int THREADS = 512, WAVES = 8;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * WB + CHUNKS * BP_CHUNK_B];
-  char* lds_t = lds + 2 * WB;
+  constexpr int RING = 3;                      // weight stages: a chunk's DMA is issued two chunks (~1.5 us) ahead of its use
+  __shared__ __attribute__((aligned(1024))) char lds[RING * WB + CHUNKS * BP_CHUNK_B];
+  char* lds_t = lds + RING * WB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -322,7 +323,10 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
   const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
 
   __syncthreads();  // zero fill complete
-  issue_weights(0, 0);
+  const int total_chunks = (p.T - 1) * CHUNKS;  // K chunks of the whole sequence (T - 1 convolutions)
+  if (total_chunks > 0) issue_weights(0, 0);
+  if (total_chunks > 1) issue_weights(1 % CHUNKS, 1);
+  const bool many = wave < PIECES - WAVES * (PIECES / WAVES);  // this wave issues one more DMA piece per chunk than the others (uniform)
 
   // gradient wrt h_t carried into the gate backward (this lane's 16 * NFR elements)
   f32x4 dh[NFR][4];
@@ -414,13 +418,19 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
     for (int ci = 0; ci < CHUNKS; ++ci) {
-      const int it = (p.T - 1 - t) * CHUNKS + ci, cur = it & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weights have landed
-      __syncthreads();                                   // ... everybody's; the tile writes of this step are visible
-      const bool more = !(t == 1 && ci + 1 == CHUNKS);
+      const int it = (p.T - 1 - t) * CHUNKS + ci, cur = it % RING;
+      // chunk `it` has landed; chunk it + 1 (this wave's pieces of it: the youngest DMA) may stay in flight.  Counted wait: loads
+      // return in order, so "at most the younger chunk's pieces outstanding" implies this chunk is complete (pending stores or
+      // the gate prefetch can only make the wait longer, never shorter).
+      if (it + 1 < total_chunks) {
+        if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / WAVES + 1) : "memory");
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / WAVES) : "memory");
+      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // ... everybody's; the tile writes of this step are visible; stage (it + 2) % RING (chunk it - 1) is free
+      const bool more = it + 2 < total_chunks;
       const bool stage_late = wave >= 4;
-      const int nci = ci + 1 < CHUNKS ? ci + 1 : 0;
-      if (more && !stage_late) issue_weights(nci, cur ^ 1);
+      const int nci = (ci + 2) % CHUNKS, nbuf = (it + 2) % RING;
+      if (more && !stage_late) issue_weights(nci, nbuf);
       const char* inb = lds_t + ci * BP_CHUNK_B;
       const char* wb = lds + cur * WB + b_lane;
       bf16x8 fa[2], fb[2][NFR];
@@ -435,7 +445,7 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
         if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1], acc[nf], 0, 0, 0);
-        if (tap == 3 && more && stage_late) issue_weights(nci, cur ^ 1);
+        if (tap == 3 && more && stage_late) issue_weights(nci, nbuf);
       }
     }
     __syncthreads();  // every wave is done reading the tile of step t
