@@ -280,19 +280,22 @@ struct GruSeqBwdParams {
 
 constexpr int BP_CHUNK_B = (256 + 1) * PIX_B;  // 256 pixels + one zero pixel per K chunk
 
-template <int NFR>  // 32-channel fragments of the hidden state (hidp = 32 * NFR)
-__global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwdParams p) {
+// NFR: 32-channel fragments of the hidden state (hidp = 32 * NFR); MFW: M fragments (32 pixels) per wave - 8 / MFW waves.
+// MFW = 2 (4 waves, one per SIMD, 512 registers each): a tap costs 2 + NFR fragment reads for 2 * NFR MFMAs instead of 1 + NFR for
+// NFR; the element-to-lane map stays that of the MFMA result.  The launcher uses MFW = 1 (see there).
+template <int NFR, int MFW>
+__global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(const GruSeqBwdParams p) {
   constexpr int HID = 32 * NFR, CHUNKS = 3 * HID / 16;
   constexpr int WB = 9 * HID * PIX_B;          // weights of one chunk
   constexpr int PIECES = WB / 1024;            // 9 * NFR
-  constexpr int THREADS = 512, WAVES = 8;
-  constexpr int RING = 3;                      // weight stages: a chunk's DMA is issued two chunks (~1.5 us) ahead of its use
+  constexpr int WAVES = 8 / MFW, THREADS = 64 * WAVES;
+  constexpr int RING = 3;                      // weight stages: a chunk's DMA is issued two chunks ahead of its use
   __shared__ __attribute__((aligned(1024))) char lds[RING * WB + CHUNKS * BP_CHUNK_B];
   char* lds_t = lds + RING * WB;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wl = wave & 3, mf = wave >> 2;
+  const int wl = wave & 3, mf0 = MFW == 2 ? 0 : wave >> 2;  // this wave's M fragments: mf0 .. mf0 + MFW - 1 of the 4-row band wl
   const int r = lane & 31, kh = lane >> 5;
   const int img = blockIdx.x;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
@@ -304,21 +307,25 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
     for (int i = wave; i < PIECES; i += WAVES) bufdma16(lane * 16, rs_w, (unsigned)(ci * WB + i * 1024), lds0 + (unsigned)(buf * WB + i * 1024));
   };
 
-  // this lane's pixel and its channel quads nf * 32 + 8g + 4kh (the transposed product's accumulator layout)
-  const int py = 4 * wl + 2 * mf + (r >> 4), px = r & 15;
-  const bool ok = py < p.H && px < p.W;
+  // this lane's pixels (one per M fragment) and its channel quads nf * 32 + 8g + 4kh (the transposed product's accumulator layout)
   const long long img_px = (long long)p.H * p.W;
-  const long long pix_i = (long long)img * img_px + (ok ? py * p.W + px : 0);  // + t * n * img_px; clamped: loads are unconditional
   const long long step_px = (long long)p.n * img_px;
   const int cq = 4 * kh;
-
-  // A-operand read offsets per tap (within a chunk): the source pixel of tap (ky, kx), or the chunk's zero pixel
-  int a_off[9];
+  int py[MFW], px[MFW];
+  bool ok[MFW];
+  long long pix_i[MFW];  // + t * n * img_px; clamped: loads are unconditional
+  int a_off[MFW][9];     // A-operand read offsets per tap (within a chunk): the source pixel of tap (ky, kx), or the chunk's zero pixel
 #pragma unroll
-  for (int tap = 0; tap < 9; ++tap) {
-    const int sy = py + tap / 3 - 1, sx = px + tap % 3 - 1;
-    const bool in = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
-    a_off[tap] = in ? (sy * 16 + sx) * PIX_B + 16 * (kh ^ (sy & 1)) : 256 * PIX_B + 16 * kh;
+  for (int m = 0; m < MFW; ++m) {
+    py[m] = 4 * wl + 2 * (mf0 + m) + (r >> 4); px[m] = r & 15;
+    ok[m] = py[m] < p.H && px[m] < p.W;
+    pix_i[m] = (long long)img * img_px + (ok[m] ? py[m] * p.W + px[m] : 0);
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap) {
+      const int sy = py[m] + tap / 3 - 1, sx = px[m] + tap % 3 - 1;
+      const bool in = sy >= 0 && sy < p.H && sx >= 0 && sx < p.W;
+      a_off[m][tap] = in ? (sy * 16 + sx) * PIX_B + 16 * (kh ^ (sy & 1)) : 256 * PIX_B + 16 * kh;
+    }
   }
   const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
 
@@ -328,11 +335,11 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
   if (total_chunks > 1) issue_weights(1 % CHUNKS, 1);
   const bool many = wave < PIECES - WAVES * (PIECES / WAVES);  // this wave issues one more DMA piece per chunk than the others (uniform)
 
-  // gradient wrt h_t carried into the gate backward (this lane's 16 * NFR elements)
-  f32x4 dh[NFR][4];
-  {
-    const long long pl = (long long)img * img_px + (ok ? py * p.W + px : 0);
-    const long long pt = (long long)(p.T - 1) * step_px + pix_i;
+  // gradient wrt h_t carried into the gate backward (this lane's 16 * NFR elements per M fragment)
+  f32x4 dh[MFW][NFR][4];
+#pragma unroll
+  for (int m = 0; m < MFW; ++m) {
+    const long long pt = (long long)(p.T - 1) * step_px + pix_i[m];
 #pragma unroll
     for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
@@ -340,68 +347,75 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
         const int ch = nf * 32 + 8 * g + cq;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (p.g_seq) v = *reinterpret_cast<const f32x4*>(p.g_seq + pt * p.gs_s + ch);
-        if (p.g_last) v += *reinterpret_cast<const f32x4*>(p.g_last + pl * p.gl_s + ch);
-        dh[nf][g] = v;
+        if (p.g_last) v += *reinterpret_cast<const f32x4*>(p.g_last + pix_i[m] * p.gl_s + ch);
+        dh[m][nf][g] = v;
       }
   }
   // saved gates and previous state of the step about to be processed
-  bf16x4 gv[4][NFR][4];
-  f32x4 hp[NFR][4];
+  bf16x4 gv[MFW][4][NFR][4];
+  f32x4 hp[MFW][NFR][4];
   auto request = [&](int t) __attribute__((always_inline)) {
-    const long long pt = (long long)t * step_px + pix_i;
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
+    for (int m = 0; m < MFW; ++m) {
+      const long long pt = (long long)t * step_px + pix_i[m];
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            gv[m][q][nf][g] = *reinterpret_cast<const bf16x4*>(p.gates + pt * p.gates_s + q * p.hidp + nf * 32 + 8 * g + cq);
 #pragma unroll
       for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-        for (int g = 0; g < 4; ++g) gv[q][nf][g] = *reinterpret_cast<const bf16x4*>(p.gates + pt * p.gates_s + q * p.hidp + nf * 32 + 8 * g + cq);
-#pragma unroll
-    for (int nf = 0; nf < NFR; ++nf)
-#pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        hp[nf][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-        if (t > 0) hp[nf][g] = *reinterpret_cast<const f32x4*>(p.hs + (pt - step_px) * p.hs_s + nf * 32 + 8 * g + cq);
-      }
+        for (int g = 0; g < 4; ++g) {
+          hp[m][nf][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+          if (t > 0) hp[m][nf][g] = *reinterpret_cast<const f32x4*>(p.hs + (pt - step_px) * p.hs_s + nf * 32 + 8 * g + cq);
+        }
+    }
   };
   request(p.T - 1);
 
   for (int t = p.T - 1; t >= 0; --t) {
     // ---- gate backward of step t ----
-    const long long pt = (long long)t * step_px + pix_i;
-    f32x4 dd[NFR][4];
+    f32x4 dd[MFW][NFR][4];
 #pragma unroll
-    for (int nf = 0; nf < NFR; ++nf) {
-      f32x4 az[4], ar[4], an[4], d2[4];
+    for (int m = 0; m < MFW; ++m) {
+      const long long pt = (long long)t * step_px + pix_i[m];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 z = __builtin_convertvector(gv[0][nf][g], f32x4), rr = __builtin_convertvector(gv[1][nf][g], f32x4),
-                    nn = __builtin_convertvector(gv[2][nf][g], f32x4), h2 = __builtin_convertvector(gv[3][nf][g], f32x4);
+      for (int nf = 0; nf < NFR; ++nf) {
+        f32x4 az[4], ar[4], an[4], d2[4];
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          const sfGruBwd o = sf_gru_bwd(dh[nf][g][c], z[c], rr[c], nn[c], h2[c], hp[nf][g][c]);
-          az[g][c] = o.az; ar[g][c] = o.ar; an[g][c] = o.an; d2[g][c] = o.d2; dd[nf][g][c] = o.dd;
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 z = __builtin_convertvector(gv[m][0][nf][g], f32x4), rr = __builtin_convertvector(gv[m][1][nf][g], f32x4),
+                      nn = __builtin_convertvector(gv[m][2][nf][g], f32x4), h2 = __builtin_convertvector(gv[m][3][nf][g], f32x4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const sfGruBwd o = sf_gru_bwd(dh[m][nf][g][c], z[c], rr[c], nn[c], h2[c], hp[m][nf][g][c]);
+            az[g][c] = o.az; ar[g][c] = o.ar; an[g][c] = o.an; d2[g][c] = o.d2; dd[m][nf][g][c] = o.dd;
+          }
         }
-      }
-      // octets after the half-wave swap: this lane then holds channels nf*32 + 8*(g + kh) .. +7 for g = 0, 2
+        // octets after the half-wave swap: this lane then holds channels nf*32 + 8*(g + kh) .. +7 for g = 0, 2
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {  // q: 0 az, 1 ar, 2 an (dgx only), 3 d2 (dgh only)
-        const f32x4* v = q == 0 ? az : q == 1 ? ar : q == 2 ? an : d2;
+        for (int q = 0; q < 4; ++q) {  // q: 0 az, 1 ar, 2 an (dgx only), 3 d2 (dgh only)
+          const f32x4* v = q == 0 ? az : q == 1 ? ar : q == 2 ? an : d2;
 #pragma unroll
-        for (int g = 0; g < 4; g += 2) {
-          const unsigned ax = pk(v[g][0], v[g][1]), ay = pk(v[g][2], v[g][3]);
-          const unsigned bx = pk(v[g + 1][0], v[g + 1][1]), by = pk(v[g + 1][2], v[g + 1][3]);
-          const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
-          const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-          const u32x4_t oct = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
-          const int ch = nf * 32 + 8 * (g + kh);
-          if (ok) {
-            if (q != 3) *reinterpret_cast<u32x4_t*>(p.dgx + pt * p.dgx_s + q * p.hidp + ch) = oct;
-            if (q != 2) {
-              const int qh = q == 3 ? 2 : q;  // dgh = [az | ar | d2]
-              *reinterpret_cast<u32x4_t*>(p.dgh + pt * p.dgh_s + qh * p.hidp + ch) = oct;
-              if (t > 0) {  // the next convolution's operand
-                const int k = qh * HID + ch;
-                *reinterpret_cast<u32x4_t*>(lds_t + (k >> 4) * BP_CHUNK_B + (py * 16 + px) * PIX_B + 16 * (((ch >> 3) & 1) ^ (py & 1))) = oct;
+          for (int g = 0; g < 4; g += 2) {
+            const unsigned ax = pk(v[g][0], v[g][1]), ay = pk(v[g][2], v[g][3]);
+            const unsigned bx = pk(v[g + 1][0], v[g + 1][1]), by = pk(v[g + 1][2], v[g + 1][3]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            const u32x4_t oct = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+            const int ch = nf * 32 + 8 * (g + kh);
+            if (ok[m]) {
+              if (q != 3) *reinterpret_cast<u32x4_t*>(p.dgx + pt * p.dgx_s + q * p.hidp + ch) = oct;
+              if (q != 2) {
+                const int qh = q == 3 ? 2 : q;  // dgh = [az | ar | d2]
+                *reinterpret_cast<u32x4_t*>(p.dgh + pt * p.dgh_s + qh * p.hidp + ch) = oct;
+                if (t > 0) {  // the next convolution's operand
+                  const int k = qh * HID + ch;
+                  *reinterpret_cast<u32x4_t*>(lds_t + (k >> 4) * BP_CHUNK_B + (py[m] * 16 + px[m]) * PIX_B + 16 * (((ch >> 3) & 1) ^ (py[m] & 1))) = oct;
+                }
               }
             }
           }
@@ -412,11 +426,13 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
     request(t - 1);  // arrives under the K loop
 
     // ---- carry = conv3x3^T(dgh_t, Wh): D[channel][pixel], K = 3 * hidp ----
-    f32x16 acc[NFR];
+    f32x16 acc[MFW][NFR];
 #pragma unroll
-    for (int nf = 0; nf < NFR; ++nf)
+    for (int m = 0; m < MFW; ++m)
 #pragma unroll
-      for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+      for (int nf = 0; nf < NFR; ++nf)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[m][nf][i] = 0.f;
     for (int ci = 0; ci < CHUNKS; ++ci) {
       const int it = (p.T - 1 - t) * CHUNKS + ci, cur = it % RING;
       // chunk `it` has landed; chunk it + 1 (this wave's pieces of it: the youngest DMA) may stay in flight.  Counted wait: loads
@@ -428,14 +444,15 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // ... everybody's; the tile writes of this step are visible; stage (it + 2) % RING (chunk it - 1) is free
       const bool more = it + 2 < total_chunks;
-      const bool stage_late = wave >= 4;
+      const bool stage_late = MFW == 1 && wave >= 4;  // two waves per SIMD: they issue at different taps
       const int nci = (ci + 2) % CHUNKS, nbuf = (it + 2) % RING;
       if (more && !stage_late) issue_weights(nci, nbuf);
       const char* inb = lds_t + ci * BP_CHUNK_B;
       const char* wb = lds + cur * WB + b_lane;
-      bf16x8 fa[2], fb[2][NFR];
-      auto load_tap = [&](int tap, bf16x8& a, bf16x8 (&b)[NFR]) __attribute__((always_inline)) {
-        a = *reinterpret_cast<const bf16x8*>(inb + a_off[tap]);
+      bf16x8 fa[2][MFW], fb[2][NFR];
+      auto load_tap = [&](int tap, bf16x8 (&a)[MFW], bf16x8 (&b)[NFR]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int m = 0; m < MFW; ++m) a[m] = *reinterpret_cast<const bf16x8*>(inb + a_off[m][tap]);
 #pragma unroll
         for (int nf = 0; nf < NFR; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * HID + nf * 32) * PIX_B);
       };
@@ -444,7 +461,10 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
       for (int tap = 0; tap < 9; ++tap) {
         if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1], acc[nf], 0, 0, 0);
+        for (int m = 0; m < MFW; ++m)
+#pragma unroll
+          for (int nf = 0; nf < NFR; ++nf)
+            acc[m][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1][m], acc[m][nf], 0, 0, 0);
         if (tap == 3 && more && stage_late) issue_weights(nci, nbuf);
       }
     }
@@ -452,14 +472,18 @@ __global__ __launch_bounds__(512, 2) void convgru_seq_bwd_kernel(const GruSeqBwd
 
     // dh_{t-1} = [g_seq_{t-1}] + dd_t + carry   (summation order of the per-step path: (g_seq + direct) + carry)
 #pragma unroll
-    for (int nf = 0; nf < NFR; ++nf)
+    for (int m = 0; m < MFW; ++m) {
+      const long long ptm = (long long)(t - 1) * step_px + pix_i[m];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        f32x4 base = dd[nf][g];
-        if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + (pt - step_px) * p.gs_s + nf * 32 + 8 * g + cq) + dd[nf][g];
+      for (int nf = 0; nf < NFR; ++nf)
 #pragma unroll
-        for (int c = 0; c < 4; ++c) dh[nf][g][c] = base[c] + acc[nf][4 * g + c];
-      }
+        for (int g = 0; g < 4; ++g) {
+          f32x4 base = dd[m][nf][g];
+          if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + ptm * p.gs_s + nf * 32 + 8 * g + cq) + dd[m][nf][g];
+#pragma unroll
+          for (int c = 0; c < 4; ++c) dh[m][nf][g][c] = base[c] + acc[m][nf][4 * g + c];
+        }
+    }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 }
@@ -519,8 +543,10 @@ extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gate
   p.wp = wpacked_t;
   p.T = T; p.n = n; p.H = h; p.W = w; p.hidp = hidp;
   hipStream_t st = (hipStream_t)stream;
-  if (hidp == 64) hipLaunchKernelGGL((convgru_seq_bwd_kernel<2>), dim3(n), dim3(512), 0, st, p);
-  else hipLaunchKernelGGL((convgru_seq_bwd_kernel<1>), dim3(n), dim3(512), 0, st, p);
+  // (4 waves with two M fragments each - fewer fragment reads per MFMA - measured SLOWER, 695 vs 580 us: one wave per SIMD has
+  // nobody to cover its LDS waits and its gate arithmetic)
+  if (hidp == 64) hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1>), dim3(n), dim3(512), 0, st, p);
+  else hipLaunchKernelGGL((convgru_seq_bwd_kernel<1, 1>), dim3(n), dim3(512), 0, st, p);
   SF_CHECK_LAUNCH("convgru_seq_bwd");
   return 0;
 }
