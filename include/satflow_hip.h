@@ -302,6 +302,14 @@ size_t sf_leadtime_pool_workspace_floats(int32_t L, int32_t C);
 int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O,
                          int32_t I, int32_t cimg, int32_t L, float* workspace, sfTensor out,
                          int32_t dtype, sfStream stream);
+/* sf_leadtime_pool_fwd that also emits the statistics the BatchNorm behind it needs (the DownSampler's BatchNorm2d(160) follows
+ * its first MaxPool2d): stats[(l * sf_leadtime_pool_stats_tiles() + block)][C][2] fp32 = per workgroup sum / sum of squares of the
+ * STORED outputs of lead time l - the layout sf_batchnorm_train_fwd_stats reads with tiles_per_group = sf_leadtime_pool_stats_tiles()
+ * and groups = L.  L <= 12. */
+int32_t sf_leadtime_pool_stats_tiles(void);
+int sf_leadtime_pool_fwd_stats(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I,
+                               int32_t cimg, int32_t L, float* workspace, sfTensor out, float* stats, int32_t dtype,
+                               sfStream stream);
 int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h, int32_t w,
                          const float* w1, int32_t O, int32_t I, int32_t cimg, int32_t L,
                          float* workspace, sfTensor dbase, float* dw1, int32_t dtype, sfStream stream);

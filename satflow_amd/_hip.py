@@ -67,6 +67,8 @@ PROTOTYPES = {
                                           C.c_uint64, _i32, _vp]),
     "sf_leadtime_pool_workspace_floats": (_sz, [_i32, _i32]),
     "sf_leadtime_pool_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, sfTensor, _i32, _vp]),
+    "sf_leadtime_pool_stats_tiles": (_i32, []),
+    "sf_leadtime_pool_fwd_stats": (C.c_int, [sfTensor, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, sfTensor, _vp, _i32, _vp]),
     "sf_leadtime_pool_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, sfTensor, _vp, _i32, _vp]),
     "sf_batchnorm_train_fwd": (
         C.c_int,

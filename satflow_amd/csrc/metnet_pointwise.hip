@@ -728,6 +728,70 @@ __global__ __launch_bounds__(1024) void leadbias_pool_fwd_kernel(const TA* __res
   }
 }
 
+// The same pooling that also emits what the BatchNorm behind it needs: per workgroup and lead time the sum and the sum of squares of
+// the STORED outputs, stats[(l * gridDim.x + block)][C][2] - the layout sf_batchnorm_train_fwd_stats reads (group l owns gridDim.x
+// "tiles").  A thread owns ONE channel quad for the whole kernel (its sums stay in registers, L <= LEAD_REG) and walks pooling
+// windows; the window lanes of a workgroup are combined through LDS in lane order (deterministic).
+constexpr int LEAD_REG_FWD = 12;
+template <typename TA>
+__global__ __launch_bounds__(512) void leadbias_pool_fwd_stats_kernel(const TA* __restrict__ base, int bs, long long F, int H, int W, int C, int L,
+                                                                     const float* __restrict__ ptab_g, TA* __restrict__ out, int os,
+                                                                     float* __restrict__ stats) {
+  extern __shared__ float P[];  // [L][9][C] table | [L][C][2] sums
+  const int nP = L * 9 * C;
+  float* S = P + nP;
+  for (int i = threadIdx.x; i < nP; i += blockDim.x) P[i] = ptab_g[i];
+  for (int i = threadIdx.x; i < L * C * 2; i += blockDim.x) S[i] = 0.f;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2, q = C / 4;
+  const int lanes = blockDim.x / q;
+  const int cq = threadIdx.x % q, wl = threadIdx.x / q;
+  const int c = cq * 4;
+  const long long windows = F * Ho * Wo;
+  f32x4 s1[LEAD_REG_FWD], s2[LEAD_REG_FWD];
+#pragma unroll
+  for (int l = 0; l < LEAD_REG_FWD; ++l) { s1[l] = f32x4{0.f, 0.f, 0.f, 0.f}; s2[l] = s1[l]; }
+  if (wl < lanes)
+    for (long long op = (long long)blockIdx.x * lanes + wl; op < windows; op += (long long)gridDim.x * lanes) {
+      const int xo = op % Wo, yo = (op / Wo) % Ho;
+      const long long f = op / ((long long)Wo * Ho);
+      const TA* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
+      const f32x4 v0 = ldv4(p), v1 = ldv4(p + bs), v2 = ldv4(p + (long long)W * bs), v3 = ldv4(p + (long long)W * bs + bs);
+      const int k0 = border_class(2 * yo, 2 * xo, H, W), k1 = border_class(2 * yo, 2 * xo + 1, H, W);
+      const int k2 = border_class(2 * yo + 1, 2 * xo, H, W), k3 = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+#pragma unroll
+      for (int l = 0; l < LEAD_REG_FWD; ++l) {
+        if (l < L) {  // block-uniform
+          const float* pt = P + (size_t)l * 9 * C + c;
+          const f32x4 a0 = v0 + ld4(pt + k0 * C), a1 = v1 + ld4(pt + k1 * C), a2 = v2 + ld4(pt + k2 * C), a3 = v3 + ld4(pt + k3 * C);
+          f32x4 m;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] = fmaxf(fmaxf(a0[j], a1[j]), fmaxf(a2[j], a3[j]));
+          TA* o = out + (((l * F + f) * Ho + yo) * Wo + xo) * os + c;
+          stv4(o, m);
+          const f32x4 r = rnd4<TA>(m);  // the stored values
+          s1[l] += r; s2[l] += r * r;
+        }
+      }
+    }
+  // window lanes in order: lane w adds its sums in round w
+  for (int w = 0; w < lanes; ++w) {
+    if (wl == w) {
+#pragma unroll
+      for (int l = 0; l < LEAD_REG_FWD; ++l)
+        if (l < L) {
+#pragma unroll
+          for (int j = 0; j < 4; ++j) { S[((size_t)l * C + c + j) * 2] += s1[l][j]; S[((size_t)l * C + c + j) * 2 + 1] += s2[l][j]; }
+        }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < L * C * 2; i += blockDim.x) {
+    const int l = i / (C * 2), rest = i - l * C * 2;
+    stats[((size_t)l * gridDim.x + blockIdx.x) * C * 2 + rest] = S[i];
+  }
+}
+
 // dbase[f] = sum_l unpool(dpooled[l*F+f]);  class sums for the one-hot weight columns by a 2-stage reduce.
 // Two kernels:
 //  * the MAIN kernel (persistent grid) writes dbase for every window.  A thread owns ONE channel quad for the whole
@@ -1005,6 +1069,32 @@ int sf_leadtime_pool_fwd(sfTensor base, int64_t frames, int32_t h, int32_t w, co
                                                    base.stride, (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride));
   }
   SF_CHECK_LAUNCH("leadbias_pool_fwd");
+  return 0;
+}
+
+int32_t sf_leadtime_pool_stats_tiles(void) { return LEADBIAS_BLOCKS; }
+
+int sf_leadtime_pool_fwd_stats(sfTensor base, int64_t frames, int32_t h, int32_t w, const float* w1, int32_t O, int32_t I, int32_t cimg,
+                               int32_t L, float* workspace, sfTensor out, float* stats, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_leadtime_pool_fwd_stats: dtype %d not built", dtype);
+  SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && h >= 2 && w >= 2 && base.c == out.c && ok4(base) && ok4(out) && base.dtype == out.dtype && O <= base.c && cimg + L <= I,
+             "leadtime_pool: shapes (h=%d w=%d C=%d O=%d I=%d cimg=%d L=%d)", h, w, base.c, O, I, cimg, L);
+  SF_REQUIRE(stats != nullptr && L <= LEAD_REG_FWD && base.c / 4 <= 512, "leadtime_pool_fwd_stats: stats null, L=%d > %d or too many channels", L, LEAD_REG_FWD);
+  hipStream_t st = (hipStream_t)stream;
+  const int C = base.c, nt = L * 9 * C;
+  const size_t lds = ((size_t)nt + (size_t)L * C * 2) * sizeof(float);
+  SF_REQUIRE(lds <= 160 * 1024, "leadtime_pool_fwd_stats: L*11*C floats exceed LDS");
+  hipLaunchKernelGGL(leadbias_table_kernel, dim3((nt + 255) / 256), dim3(256), 0, st, w1, O, I, cimg, L, C, workspace);
+  SF_CHECK_LAUNCH("leadbias_table");
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_stats_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_stats_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
+  }
+  SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_stats_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(512), lds, st, (const TA*)base.ptr,
+                                                 base.stride, (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride, stats));
+  SF_CHECK_LAUNCH("leadbias_pool_fwd_stats");
   return 0;
 }
 

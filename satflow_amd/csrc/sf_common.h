@@ -75,6 +75,10 @@ template <> __device__ __forceinline__ f32x4 ldv4<float>(const float* p) { retur
 template <> __device__ __forceinline__ f32x4 ldv4<__bf16>(const __bf16* p) {
   return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(p), f32x4);
 }
+// the value a storage type keeps of v (what stv4 writes, widened again)
+template <typename T> __device__ __forceinline__ f32x4 rnd4(f32x4 v);
+template <> __device__ __forceinline__ f32x4 rnd4<float>(f32x4 v) { return v; }
+template <> __device__ __forceinline__ f32x4 rnd4<__bf16>(f32x4 v) { return __builtin_convertvector(__builtin_convertvector(v, bf16x4), f32x4); }
 template <typename T> __device__ __forceinline__ void stv4(T* p, f32x4 v);
 template <> __device__ __forceinline__ void stv4<float>(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
 template <> __device__ __forceinline__ void stv4<__bf16>(__bf16* p, f32x4 v) { *reinterpret_cast<bf16x4*>(p) = __builtin_convertvector(v, bf16x4); }

@@ -247,13 +247,17 @@ class _LeadTimePoolFn(torch.autograd.Function):
     """``pooled[l*F + f] = maxpool2(base[f] + P_l(w1))`` for all lead times l (see ``sf_leadtime_pool_fwd``)."""
 
     @staticmethod
-    def forward(ctx, base: Tensor, w1: Tensor, cimg: int, L: int):
+    def forward(ctx, base: Tensor, w1: Tensor, cimg: int, L: int, stats: Optional[Tensor] = None):
         Fr, H, W, C = base.shape
         w1 = w1.contiguous()
         ws = torch.empty(lib().sf_leadtime_pool_workspace_floats(L, C), dtype=torch.float32, device=base.device)
         out = torch.empty(L * Fr, H // 2, W // 2, C, dtype=base.dtype, device=base.device)
-        check(lib().sf_leadtime_pool_fwd(T(base), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(out), SF_F32,
-                                         stream_ptr()), "sf_leadtime_pool_fwd")
+        if stats is not None:  # also the per-workgroup sums the BatchNorm behind the pooling needs
+            check(lib().sf_leadtime_pool_fwd_stats(T(base), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(out),
+                                                   stats.data_ptr(), SF_F32, stream_ptr()), "sf_leadtime_pool_fwd_stats")
+        else:
+            check(lib().sf_leadtime_pool_fwd(T(base), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(out), SF_F32,
+                                             stream_ptr()), "sf_leadtime_pool_fwd")
         ctx.meta = (cimg, L)
         ctx.save_for_backward(base, w1)
         return out
@@ -269,11 +273,27 @@ class _LeadTimePoolFn(torch.autograd.Function):
         dw1 = torch.zeros_like(w1)  # only the one-hot columns cimg..cimg+L-1 are written
         check(lib().sf_leadtime_pool_bwd(T(base), T(g), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(dbase),
                                          dw1.data_ptr(), SF_F32, stream_ptr()), "sf_leadtime_pool_bwd")
-        return dbase, dw1, None, None
+        return dbase, dw1, None, None, None
 
 
-def leadtime_pool(base: Tensor, w1: Tensor, cimg: int, L: int) -> Tensor:
-    return _LeadTimePoolFn.apply(base, w1, cimg, L)
+class PoolStats:
+    """Per-workgroup output statistics of the lead-time pooling (``sf_leadtime_pool_fwd_stats``) in the record layout of
+    ``ConvStats``: group (lead time) l owns records ``[l * tiles, (l + 1) * tiles)``."""
+
+    def __init__(self, L: int, C: int, device) -> None:
+        self.tiles = int(lib().sf_leadtime_pool_stats_tiles())
+        self.np, self.n = C, L
+        self.data = torch.empty(L * self.tiles, C, 2, dtype=torch.float32, device=device)
+
+
+def leadtime_pool(base: Tensor, w1: Tensor, cimg: int, L: int, want_stats: bool = False):
+    """``want_stats``: returns ``(pooled, PoolStats)`` for the BatchNorm behind the pooling (L <= 12 and an LDS-sized border table,
+    else ``(pooled, None)``)."""
+    if not want_stats:
+        return _LeadTimePoolFn.apply(base, w1, cimg, L)
+    C = base.shape[-1]
+    st = PoolStats(L, C, base.device) if L <= 12 and L * 11 * C * 4 <= 160 * 1024 else None
+    return _LeadTimePoolFn.apply(base, w1, cimg, L, st.data if st is not None else None), st
 
 
 class _BatchNormTrainFn(torch.autograd.Function):

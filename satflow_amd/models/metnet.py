@@ -79,8 +79,10 @@ class DownSampler(nn.Module):
         self.capture = None  # tests set a dict: receives the tensor in front of the last pooling ("y4")
         self._eng = [ConvEngine([in_channels], 160), ConvEngine([160], oc), ConvEngine([oc], oc), ConvEngine([oc], oc)]
 
-    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None, dropout=None, out_dtype=torch.float32) -> Tensor:
-        """NHWC pipeline from the first pooling's output (``pooled``) or from the input ``x``; ``groups`` BatchNorm batches.
+    def run(self, x: Tensor, groups: int, pooled: Optional[Tensor] = None, perm=None, dropout=None, out_dtype=torch.float32,
+            pooled_stats=None) -> Tensor:
+        """NHWC pipeline from the first pooling's output (``pooled``, optionally with its per-group statistics ``pooled_stats`` from
+        ``F.leadtime_pool(..., want_stats=True)``) or from the input ``x``; ``groups`` BatchNorm batches.
 
         The activations keep the storage type they arrive in (fp32, or bf16 in "bf16a" mode); the last pooling returns
         ``out_dtype`` (fp32 at the module surface; MetNet keeps the encoder's storage type - its only consumers are the
@@ -91,7 +93,9 @@ class DownSampler(nn.Module):
         if self.training:
             # BatchNorm -> Conv2d pairs: with bf16-stored activations the normalisation is folded into the convolution
             # (F.batchnorm_conv3x3; otherwise it runs the two ops below, statistics from the producing convolution's epilogue)
-            y, cs = F.batchnorm_conv3x3(y, m[3], groups, None, self._eng[1], m[4].weight, m[4].bias, out_dtype=st, want_stats=True)
+            if pooled_stats is not None and pooled_stats.n != groups:
+                raise RuntimeError("pooled_stats were taken for a different number of BatchNorm groups")
+            y, cs = F.batchnorm_conv3x3(y, m[3], groups, pooled_stats, self._eng[1], m[4].weight, m[4].bias, out_dtype=st, want_stats=True)
             y, cs = F.batchnorm_conv3x3(y, m[5], groups, cs, self._eng[2], m[6].weight, m[6].bias, out_dtype=st, want_stats=True)
             y, _ = F.batchnorm_conv3x3(y, m[7], groups, cs, self._eng[3], m[8].weight, m[8].bias, out_dtype=st)
             return self._exit(y, perm, dropout, out_dtype)
@@ -296,13 +300,14 @@ class MetNet(nn.Module):
         base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias, out_dtype=st)  # [T*B, S, S, 160]
         if enc.capture is not None:
             enc.capture["base"] = base.detach()
-        p1 = F.leadtime_pool(base, c1.weight, cimg, L)  # [L*T*B, S/2, S/2, 160], image (l*F + f)
+        # [L*T*B, S/2, S/2, 160], image (l*F + f); in training mode with the per-lead-time sums its BatchNorm needs
+        p1, p1_stats = F.leadtime_pool(base, c1.weight, cimg, L, want_stats=True) if self.training else (F.leadtime_pool(base, c1.weight, cimg, L), None)
         # rest of the DownSampler with per-lead-time BatchNorm batches; the last pooling also re-orders
         # images from [lead][time][batch] to [time][lead][batch] for the recurrent part
         rnn = self.temporal_enc.rnn
         # nn.Dropout(temporal_dropout) and the ConvGRU's sequence-consistent input dropout ride on the encoder's last pooling
         drop = (self.drop.p, rnn.input_p, Tn) if self.training else None
-        feat = enc.run(None, L, pooled=p1, perm=(L, Tn), dropout=drop, out_dtype=st)  # [T*L*B, S/4, S/4, 256]
+        feat = enc.run(None, L, pooled=p1, perm=(L, Tn), dropout=drop, out_dtype=st, pooled_stats=p1_stats)  # [T*L*B, S/4, S/4, 256]
         _, last = rnn.run(feat, Tn, L * B, input_dropout_done=True)
         a = last[-1]  # [L*B, s, s, hidp]
         for layer in self.temporal_agg:

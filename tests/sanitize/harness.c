@@ -78,6 +78,8 @@ int main(void) {
   REFUSED(sf_batchnorm_train_bwd_coef(0, 64, 1, 16, 16, ok, ok, ok, ok, ok, ok, SF_F32, st));           /* no sums */
   REFUSED(sf_batchnorm_train_bwd_coef(ok, 64, 1, 16, 24, ok, ok, ok, ok, ok, ok, SF_F32, st));          /* more real channels than lanes */
   REFUSED(sf_leadtime_pool_fwd(a16, 1, 7, 8, ok, 16, 20, 8, 12, ok, a16, SF_F32, st));               /* odd height */
+  REFUSED(sf_leadtime_pool_fwd_stats(a16, 4, 8, 8, ok, 16, 20, 4, 4, ok, a16, 0, SF_F32, st));          /* no stats */
+  REFUSED(sf_leadtime_pool_fwd_stats(a16, 4, 8, 8, ok, 16, 40, 4, 13, ok, a16, ok, SF_F32, st));        /* more lead times than the kernel keeps in registers */
   REFUSED(sf_leadtime_pool_bwd(a16, a64, 1, 8, 8, ok, 16, 20, 8, 12, ok, a16, ok, SF_F32, st));
   /* ConvGRU */
   REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 20, a16, N0, SF_F32, st));                   /* hidp not padded */

@@ -259,3 +259,21 @@ def test_fused_batchnorm_backward_matches_the_three_kernel_form(device, monkeypa
         if k.endswith("bias") and ("module.0" in k or "module.4" in k or "module.6" in k):
             continue
         assert rel_l2(g1[k], g0[k]) < 3e-2, f"{k}: {rel_l2(g1[k], g0[k]):.3e}"
+
+
+@pytest.mark.parametrize("Fr,H,W,C,L,dtype", [(6, 16, 16, 160, 12, torch.bfloat16), (5, 12, 20, 32, 3, torch.float32), (2, 2, 2, 16, 1, torch.bfloat16)])
+def test_leadtime_pool_statistics(device, Fr, H, W, C, L, dtype):
+    """sf_leadtime_pool_fwd_stats: same pooled tensor as sf_leadtime_pool_fwd, plus per-lead-time sum / sum of squares of the stored values."""
+    from satflow_amd import functional as F
+
+    g = torch.Generator().manual_seed(11)
+    cimg = 20
+    base = torch.randn(Fr, H, W, C, generator=g).to(device).to(dtype)
+    w1 = (torch.randn(C, cimg + L, 3, 3, generator=g) * 0.3).to(device)
+    ref = F.leadtime_pool(base, w1, cimg, L)
+    out, st = F.leadtime_pool(base, w1, cimg, L, want_stats=True)
+    assert st is not None and torch.equal(out, ref)
+    s = st.data.reshape(L, st.tiles, C, 2).double().sum(1)
+    o = out.double().reshape(L, -1, C)
+    assert rel_l2(s[..., 0], o.sum(1)) < 1e-5
+    assert rel_l2(s[..., 1], (o * o).sum(1)) < 1e-5
