@@ -297,10 +297,19 @@ __global__ __launch_bounds__(256) void wgrad_reduce_folded_kernel(const float* _
       float s8[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       int s = 0;
       for (; s + 8 <= slots; s += 8) {
+        // all eight slab reads requested before the first use: unconditional loads (an unused slot's slab is allocated, its garbage is
+        // discarded by a select, never multiplied) - a load under `if (g >= 0)` is emitted as load -> wait -> use, one at a time
+        float pv[8], sc[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
           const int g = slot_group[s + u];
-          if (g >= 0) s8[u] = __builtin_fmaf(scale[(size_t)g * Kp + ci], partial[(size_t)(s + u) * slab + gid], s8[u]);
+          pv[u] = partial[(size_t)(s + u) * slab + gid];
+          sc[u] = scale[(size_t)(g >= 0 ? g : 0) * Kp + ci];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          const int g = slot_group[s + u];
+          s8[u] = __builtin_fmaf(g >= 0 ? sc[u] : 0.f, g >= 0 ? pv[u] : 0.f, s8[u]);
         }
       }
       for (; s < slots; ++s) {
@@ -365,10 +374,17 @@ __global__ __launch_bounds__(256) void fold_bn_s2_kernel(const float* __restrict
     }
   } else if (slot_group[slot] >= 0) {
     const float* ps = partial + (size_t)slot * rows * KpT;
-    for (int r = r0 + rl; r < r1; r += 4, ++u) {
-      a4[u & 3] = __builtin_fmaf(wt[(size_t)r * KpT + ci], ps[(size_t)r * KpT + ci], a4[u & 3]);
-      if ((u & 63) == 63) { acc += ((double)a4[0] + (double)a4[1]) + ((double)a4[2] + (double)a4[3]); a4[0] = a4[1] = a4[2] = a4[3] = 0.f; }
+    int r = r0 + rl;
+    for (; r + 28 < r1; r += 32) {  // eight rows' loads in flight
+      float wv[8], pv[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) { wv[k] = wt[(size_t)(r + 4 * k) * KpT + ci]; pv[k] = ps[(size_t)(r + 4 * k) * KpT + ci]; }
+#pragma unroll
+      for (int k = 0; k < 8; ++k) a4[k & 3] = __builtin_fmaf(wv[k], pv[k], a4[k & 3]);
+      u += 8;
+      if ((u & 63) == 0) { acc += ((double)a4[0] + (double)a4[1]) + ((double)a4[2] + (double)a4[3]); a4[0] = a4[1] = a4[2] = a4[3] = 0.f; }
     }
+    for (; r < r1; r += 4, ++u) a4[u & 3] = __builtin_fmaf(wt[(size_t)r * KpT + ci], ps[(size_t)r * KpT + ci], a4[u & 3]);
   }
   acc += ((double)a4[0] + (double)a4[1]) + ((double)a4[2] + (double)a4[3]);
   red[rl][lc] = acc;
