@@ -804,7 +804,7 @@ __global__ __launch_bounds__(512) void leadbias_pool_fwd_stats_kernel(const TA* 
 // emitted as load + vmcnt(0) one by one, hence the clamped unconditional form) and read the border table from LDS
 // when it fits next to the sums.
 constexpr int LEAD_REG = 12;
-constexpr int LEADBIAS_BLOCKS = 512, LEADBIAS_BORDER_BLOCKS = 128;
+constexpr int LEADBIAS_BLOCKS = 512, LEADBIAS_BORDER_BLOCKS = 256;  // border: 4 x 56 edge workgroups + 32 corner workgroups, one per CU (138 KB of LDS each at L = 12)
 
 __device__ __forceinline__ int argmax4(float a0, float a1, float a2, float a3) {
   int am = 0; float m = a0;  // first maximum in row-major window order, as max_pool2d
@@ -882,7 +882,7 @@ __global__ __launch_bounds__(512) void leadbias_pool_bwd_kernel(const TA* __rest
 // positions on the image border share one class, the two inner ones are class 4, so two register sums per lead time
 // suffice and the loop is atomics-free like the main kernel's) and the last LEADBIAS_CORNER_BLOCKS blocks for the corner
 // windows (4 classes; LDS atomics) - or for every border window when the image is too small to have plain edges.
-constexpr int LEADBIAS_CORNER_BLOCKS = 8;
+constexpr int LEADBIAS_CORNER_BLOCKS = 32;  // (8 were the tail of the kernel: 290 us of per-window serial loads)
 template <typename TA, bool PLDS>
 __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
                                                              long long F, int H, int W, int C, int L, const float* __restrict__ ptab_g,
@@ -961,10 +961,18 @@ __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restri
       else { r -= 2 * Wo; const int per_row = Wo > 1 ? 2 : 1; yo = 1 + r / per_row; xo = (r % per_row) ? Wo - 1 : 0; }
       f32x4 v[4]; int k[4];
       window(f, yo, xo, v, k);
+      f32x4 gl[LEAD_REG];  // the first LEAD_REG lead times' gradients requested together (clamped index: unconditional loads)
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l) gl[l] = ldv4(dout + ((((l < L ? l : 0) * F + f) * Ho + yo) * Wo + xo) * dos + c);
       for (int l = 0; l < L; ++l) {
         const float* pt = ptab + (size_t)l * 9 * C + c;
         const f32x4 a0 = v[0] + ld4(pt + k[0] * C), a1 = v[1] + ld4(pt + k[1] * C), a2 = v[2] + ld4(pt + k[2] * C), a3 = v[3] + ld4(pt + k[3] * C);
-        const f32x4 g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
+        f32x4 g;
+        if (l < LEAD_REG) {
+          g = gl[0];
+#pragma unroll
+          for (int u = 1; u < LEAD_REG; ++u) g = l == u ? gl[u] : g;
+        } else g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
         float* Sl = S + (size_t)l * 9 * C + c;
 #pragma unroll
         for (int j = 0; j < 4; ++j) atomicAdd(Sl + k[argmax4(a0[j], a1[j], a2[j], a3[j])] * C + j, g[j]);
