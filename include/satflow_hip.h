@@ -291,6 +291,27 @@ int sf_batchnorm_train_bwd_coef(const double* sums, int64_t pix_per_group, int32
                                 const float* gamma, const float* mean, const float* rstd, float* coef, float* dgamma,
                                 float* dbeta, int32_t dtype, sfStream stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * ST-LSTM cell with memory decoupling (PredRNN v2), SURVEY 8f-4: SpatioTemporalLSTMCell.forward,
+ * satflow/models/layers/SpatioTemporalLSTMCell_memory_decoupling.py:110-138 (layer_norm=False).  Its 3x3 convolutions
+ * (conv_x, conv_h, conv_m, conv_o) are sf_conv3x3_fwd, its 1x1 conv_last is sf_linear_fwd; these are the two pointwise stages.
+ * All tensors NHWC fp32 with gate-major blocks of hidp padded hidden channels.
+ *   gates (:114-132): gx [..,7*hidp] = conv_x(x): i f g i' f' g' o;  gh [..,4*hidp] = conv_h(h): i f g o;  gm [..,3*hidp] = conv_m(m):
+ *     i' f' g'  ->  c' = sig(f_x+f_h+forget_bias) c + delta_c, delta_c = sig(i_x+i_h) tanh(g_x+g_h); m', delta_m likewise from the primed
+ *     gates and gm; pre_o = o_x + o_h; mem = [c' | m'] (the input of conv_o / conv_last); gates (nullable) = i f g i' f' g' for backward
+ *   out (:135-136): h' = sig(pre_o + conv_o) * tanh(last); saved (nullable) = [o | tanh(last)] for backward
+ * The backward entries take NULL for absent incoming gradients. */
+int sf_stlstm_gates_fwd(sfTensor gx, sfTensor gh, sfTensor gm, sfTensor c, sfTensor m, int64_t pixels, int32_t hidp,
+                        float forget_bias, sfTensor c_new, sfTensor m_new, sfTensor mem, sfTensor delta_c, sfTensor delta_m,
+                        sfTensor pre_o, sfTensor gates, int32_t dtype, sfStream stream);
+int sf_stlstm_gates_bwd(sfTensor d_c_new, sfTensor d_m_new, sfTensor d_mem, sfTensor d_delta_c, sfTensor d_delta_m,
+                        sfTensor d_pre_o, sfTensor gates, sfTensor c, sfTensor m, int64_t pixels, int32_t hidp, sfTensor dgx,
+                        sfTensor dgh, sfTensor dgm, sfTensor dc, sfTensor dm, int32_t dtype, sfStream stream);
+int sf_stlstm_out_fwd(sfTensor pre_o, sfTensor conv_o, sfTensor last, int64_t pixels, int32_t hidp, sfTensor h_new,
+                      sfTensor saved, int32_t dtype, sfStream stream);
+int sf_stlstm_out_bwd(sfTensor dh, sfTensor saved, int64_t pixels, int32_t hidp, sfTensor d_a, sfTensor d_last, int32_t dtype,
+                      sfStream stream);
+
 /* Lead-time de-duplication of MetNet's first convolution (ConditionTime planes are constant one-hot images and
  * conv1 is linear): with base = conv1_image(frame) + b computed ONCE per frame,
  *   pooled[(l*frames + f)] = maxpool2( base[f] + P_l ),  P_l[y][x][co] = sum of the in-image taps of w1[co][cimg + l]

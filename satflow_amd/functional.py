@@ -868,3 +868,77 @@ def l1_loss_groups(pred: Tensor, target: Tensor, groups: int, c: int):
 def bce_logits_groups(logits: Tensor, label_even: float, label_odd: float, groups: int, c: int = 1):
     """``nn.BCEWithLogitsLoss()`` of the first ``c`` lanes against a constant label per group parity (GANLoss "vanilla")."""
     return _PairLossFn.apply(logits.contiguous(), None, (float(label_even), float(label_odd)), groups, c)
+
+
+# ----------------------------------------------------------------------------------------------
+# ST-LSTM cell with memory decoupling (SURVEY 8f-4): the two pointwise stages
+# ----------------------------------------------------------------------------------------------
+class _STLSTMGatesFn(torch.autograd.Function):
+    """(gx, gh, gm, c, m) -> (c', m', mem = [c' | m'], delta_c, delta_m, pre_o); ``sf_stlstm_gates_fwd/bwd``."""
+
+    @staticmethod
+    def forward(ctx, gx: Tensor, gh: Tensor, gm: Tensor, c: Tensor, m: Tensor, hidp: int, forget_bias: float):
+        gx, gh, gm, c, m = (t.contiguous() for t in (gx, gh, gm, c, m))
+        shp, dev = c.shape[:-1], c.device
+        pixels = c.numel() // hidp
+        new = lambda lanes: torch.empty(*shp, lanes, dtype=torch.float32, device=dev)
+        c_new, m_new, mem, dc, dm, po = new(hidp), new(hidp), new(2 * hidp), new(hidp), new(hidp), new(hidp)
+        keep = any(ctx.needs_input_grad)
+        gates = new(6 * hidp) if keep else None
+        check(lib().sf_stlstm_gates_fwd(T(gx), T(gh), T(gm), T(c), T(m), pixels, hidp, forget_bias, T(c_new), T(m_new), T(mem), T(dc), T(dm), T(po),
+                                        T(gates) if keep else NULL, SF_F32, stream_ptr()), "sf_stlstm_gates_fwd")
+        ctx.hidp = hidp
+        if keep:
+            ctx.save_for_backward(gates, c, m)
+        ctx.set_materialize_grads(False)
+        return c_new, m_new, mem, dc, dm, po
+
+    @staticmethod
+    def backward(ctx, d_cn, d_mn, d_mem, d_dc, d_dm, d_po):
+        gates, c, m = ctx.saved_tensors
+        hidp = ctx.hidp
+        shp, dev = c.shape[:-1], c.device
+        pixels = c.numel() // hidp
+        new = lambda lanes: torch.empty(*shp, lanes, dtype=torch.float32, device=dev)
+        dgx, dgh, dgm, dc, dm = new(7 * hidp), new(4 * hidp), new(3 * hidp), new(hidp), new(hidp)
+        g = [T(t.contiguous()) if t is not None else NULL for t in (d_cn, d_mn, d_mem, d_dc, d_dm, d_po)]
+        check(lib().sf_stlstm_gates_bwd(*g, T(gates), T(c), T(m), pixels, hidp, T(dgx), T(dgh), T(dgm), T(dc), T(dm), SF_F32, stream_ptr()),
+              "sf_stlstm_gates_bwd")
+        return dgx, dgh, dgm, dc, dm, None, None
+
+
+class _STLSTMOutFn(torch.autograd.Function):
+    """``h' = sigmoid(pre_o + conv_o) * tanh(last)``; ``sf_stlstm_out_fwd/bwd``."""
+
+    @staticmethod
+    def forward(ctx, pre_o: Tensor, conv_o: Tensor, last: Tensor, hidp: int):
+        pre_o, conv_o, last = pre_o.contiguous(), conv_o.contiguous(), last.contiguous()
+        pixels = pre_o.numel() // hidp
+        h_new = torch.empty_like(pre_o)
+        keep = any(ctx.needs_input_grad)
+        saved = torch.empty(*pre_o.shape[:-1], 2 * hidp, dtype=torch.float32, device=pre_o.device) if keep else None
+        check(lib().sf_stlstm_out_fwd(T(pre_o), T(conv_o), T(last), pixels, hidp, T(h_new), T(saved) if keep else NULL, SF_F32, stream_ptr()),
+              "sf_stlstm_out_fwd")
+        ctx.meta = (hidp, conv_o.shape[-1], last.shape[-1])
+        if keep:
+            ctx.save_for_backward(saved)
+        return h_new
+
+    @staticmethod
+    def backward(ctx, dh: Tensor):
+        (saved,) = ctx.saved_tensors
+        hidp, co_lanes, last_lanes = ctx.meta
+        dh = dh.contiguous()
+        pixels = dh.numel() // hidp
+        d_a, d_last = torch.empty_like(dh), torch.empty_like(dh)
+        check(lib().sf_stlstm_out_bwd(T(dh), T(saved), pixels, hidp, T(d_a), T(d_last), SF_F32, stream_ptr()), "sf_stlstm_out_bwd")
+        pad = lambda t, lanes: t if lanes == hidp else torch.nn.functional.pad(t, (0, lanes - hidp))
+        return d_a, pad(d_a, co_lanes), pad(d_last, last_lanes), None
+
+
+def stlstm_gates(gx: Tensor, gh: Tensor, gm: Tensor, c: Tensor, m: Tensor, hidp: int, forget_bias: float = 1.0):
+    return _STLSTMGatesFn.apply(gx, gh, gm, c, m, hidp, forget_bias)
+
+
+def stlstm_out(pre_o: Tensor, conv_o: Tensor, last: Tensor, hidp: int) -> Tensor:
+    return _STLSTMOutFn.apply(pre_o, conv_o, last, hidp)

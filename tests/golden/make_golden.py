@@ -293,10 +293,51 @@ def cloudgan_cases():
         f.write("\n".join(keys) + "\n")
 
 
+def stlstm_cases():
+    """ST-LSTM cell with memory decoupling: reference import -> inputs, weights, the five outputs and every gradient
+    for a random cotangent on all five outputs."""
+    from satflow.models.layers.SpatioTemporalLSTMCell_memory_decoupling import SpatioTemporalLSTMCell
+    from oracle import stlstm as OS
+
+    for name, (cin, nh, width, B, scale) in {"a": (8, 16, 12, 2, 1.0), "b": (12, 32, 16, 1, 1.0), "odd": (5, 16, 9, 2, 1.0), "hot": (8, 32, 10, 2, 4.0)}.items():
+        gen = torch.Generator().manual_seed(zlib_seed("stlstm" + name))
+        cell = SpatioTemporalLSTMCell(cin, nh, width, 3, 1, False)
+        with torch.no_grad():
+            for p_ in cell.parameters():
+                p_.copy_((torch.rand(p_.shape, generator=gen) * 2 - 1) * scale * (1.0 / (p_.shape[1] * p_.shape[2] * p_.shape[3]) ** 0.5))
+        ins = {k: torch.randn(B, c_, width, width, generator=gen).requires_grad_() for k, c_ in (("x", cin), ("h", nh), ("c", nh), ("m", nh))}
+        outs = cell(ins["x"], ins["h"], ins["c"], ins["m"])
+        names = ("h_new", "c_new", "m_new", "delta_c", "delta_m")
+        cots = {f"cot_{k}": torch.randn(o.shape, generator=gen) for k, o in zip(names, outs)}
+        loss = sum((o * cots[f"cot_{k}"]).sum() for k, o in zip(names, outs))
+        params = dict(cell.named_parameters())
+        grads = torch.autograd.grad(loss, list(ins.values()) + list(params.values()))
+        rec = {k: v.detach() for k, v in ins.items()}
+        rec.update({k: o.detach() for k, o in zip(names, outs)})
+        rec.update(cots)
+        rec.update({f"w.{k}": v.detach() for k, v in params.items()})
+        rec.update({f"d_{k}": g for k, g in zip(list(ins.keys()) + [f"w.{k}" for k in params], grads)})
+        # the restatement must reproduce the reference module
+        oo = OS.stlstm_cell(ins["x"], ins["h"], ins["c"], ins["m"], params["conv_x.0.weight"], params["conv_h.0.weight"], params["conv_m.0.weight"],
+                            params["conv_o.0.weight"], params["conv_last.weight"])
+        for k, a, b in zip(names, oo, outs):
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), f"oracle stlstm mismatch {name}.{k}"
+        np.savez(f"{HERE}/stlstm_{name}.npz", **_np(rec))
+        print(f"stlstm {name}: ok  |h'|max={float(outs[0].abs().max()):.4f}")
+    with open(f"{HERE}/stlstm_state_dict_keys.txt", "w") as f:
+        f.write("\n".join(SpatioTemporalLSTMCell(4, 8, 8, 3, 1, False).state_dict().keys()) + "\n")
+
+
+def zlib_seed(s):
+    import zlib
+
+    return zlib.crc32(s.encode()) & 0x7FFFFFFF
+
+
 if __name__ == "__main__":
     torch.set_num_threads(8)
     _shim_reference()
-    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan"]
+    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan", "stlstm"]
     if "cell" in only:
         cell_cases()
     if "model" in only:
@@ -305,3 +346,5 @@ if __name__ == "__main__":
         layer_cases()
     if "cloudgan" in only:
         cloudgan_cases()
+    if "stlstm" in only:
+        stlstm_cases()

@@ -120,6 +120,12 @@ int main(void) {
   REFUSED(sf_l1_loss(a16, N0, 64, 1, 16, N0, ok, ok, st));                                           /* no target */
   REFUSED(sf_l1_loss(a16, a16, 64, 3, 16, N0, ok, ok, st));                                          /* rows not divisible into groups */
   REFUSED(sf_bce_logits_loss(a16, 1.f, 0.f, 64, 1, 32, N0, ok, ok, st));                             /* more lanes than the stride */
+  /* ST-LSTM pointwise stages */
+  REFUSED(sf_stlstm_gates_fwd(a192, a64, a48, a16, a16, 64, 16, 1.f, a16, a16, a16, a16, a16, a16, N0, SF_F32, st));  /* mem narrower than 2*hidp */
+  REFUSED(sf_stlstm_gates_fwd(a192, a64, a48, a16, a16, 64, 16, 1.f, a16, a16, a64, a16, a16, a16, N0, SF_BF16, st)); /* dtype not built */
+  REFUSED(sf_stlstm_gates_bwd(N0, N0, N0, N0, N0, N0, N0, a16, a16, 64, 16, a192, a64, a48, a16, a16, SF_F32, st));   /* no saved gates */
+  REFUSED(sf_stlstm_out_fwd(a16, a16, a16, 64, 12, a16, N0, SF_F32, st));                                             /* hidp not padded */
+  REFUSED(sf_stlstm_out_bwd(a16, a16, 64, 16, a16, a16, SF_F32, st));                                                 /* saved narrower than 2*hidp */
   /* size queries never fail, must not overflow */
   printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32) + sf_conv3x3_bwd_weight_folded_workspace_bytes(256, 256, 2304, 32, 32, 24),
          sf_linear_bwd_weight_workspace_bytes(384, 64, 24576), sf_conv2d_bwd_weight_workspace_bytes(48, 64, 64, 12, 32, 4, 4));
