@@ -393,6 +393,86 @@ class CloudGANWorkload(ConvLSTMWorkload):
         return time_cpu(one, "oracle generator step + discriminator step (each fwd + loss + bwd + Adam), B=1 of the same workload, fp32")
 
 
+class STLSTMWorkload:
+    """the ST-LSTM cell with memory decoupling (PredRNN v2, reference layers/SpatioTemporalLSTMCell_memory_decoupling.py),
+    unrolled over T = 6 frames of 12 channels at 64x64 with 64 hidden channels; a step = forward over the sequence + MSE on the last
+    hidden state's first 12 channels + the decoupling terms' mean + backward + Adam."""
+
+    name = "stlstm"
+
+    def __init__(self, dev, batch: int, rank: int):
+        from satflow_amd.models.layers import SpatioTemporalLSTMCell
+        from satflow_amd.optim import FlatAdam
+
+        self.B, self.T, self.C, self.H, self.W, self.hid = batch, 6, 12, 64, 64, 64
+        torch.manual_seed(1234)
+        self.cell = SpatioTemporalLSTMCell(self.C, self.hid, self.W, 3, 1, False).to(dev)
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.x = torch.rand(self.T, self.B, self.H, self.W, 16, generator=g).to(dev)
+        self.x[..., self.C:] = 0
+        self.y = torch.rand(self.B, self.H, self.W, self.hid, generator=g).to(dev)
+        self.opt = FlatAdam(self.cell.parameters(), lr=1e-3, overlap=not os.environ.get("SF_NO_OVERLAP"))
+        self.dev = dev
+
+    def _loss(self, cell_run, x, y, zeros):
+        h = c = m = zeros
+        dec = 0.0
+        for t in range(self.T):
+            h, c, m, dc, dm = cell_run(x[t], h, c, m)
+            dec = dec + (dc * dm).mean()
+        return ((h - y) ** 2).mean() + 0.01 * dec
+
+    def step(self):
+        self.opt.zero_grad()
+        z = torch.zeros(self.B, self.H, self.W, self.hid, device=self.dev)
+        loss = self._loss(self.cell.run, self.x, self.y, z)
+        loss.backward()
+        self.opt.step()
+        return loss.detach()
+
+    def config(self, world):
+        return {"workload": "ST-LSTM cell with memory decoupling (PredRNN v2; SURVEY 8f-4), 12 -> 64 hidden channels, 64x64, T=6 unrolled",
+                "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
+                "step": "fwd over T cells + mse + decoupling term + bwd + adam"}
+
+    def roofline(self):
+        from satflow_amd import kernels as K
+        from satflow_amd._hip import NULL, T
+        import satflow_amd
+
+        eng, n, H, W, hid = self.cell._eng_h, self.B, self.H, self.W, self.hid
+        w = self.cell.conv_h[0].weight
+        packed, bp = eng.packed(w, None, "fwd")
+        hx = torch.randn(n, H, W, hid, device=self.dev)
+        out = torch.empty(n, H, W, eng.coutp, device=self.dev)
+        t = event_time(lambda: K.conv3x3(T(hx), NULL, n, H, W, packed, bp, eng.fwd_map, T(out)), iters=20)
+        flops = 2 * 9 * hid * 4 * hid * H * W * n
+        bf16 = satflow_amd.compute_dtype_name() in ("bf16", "bf16a")
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        alg_bytes = (hid + 4 * hid) * 4 * H * W * n + 9 * hid * 4 * hid * 4
+        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak, "traffic": None,
+                "kernel": "conv3x3 (sf_conv3x3_fwd, conv_h: %d -> %d ch, %dx%d, B=%d)" % (hid, 4 * hid, H, W, n), "launch_us": t * 1e6,
+                "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes, "hbm_gbps_algorithmic": alg_bytes / t / 1e9,
+                "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS}
+
+    def cpu_baseline(self):
+        from oracle import stlstm as OS  # checker/baseline only
+
+        ws = [p.detach().cpu().clone().requires_grad_() for p in (self.cell.conv_x[0].weight, self.cell.conv_h[0].weight, self.cell.conv_m[0].weight,
+                                                                   self.cell.conv_o[0].weight, self.cell.conv_last.weight)]
+        x = self.x[:, :1, ..., :self.C].permute(0, 1, 4, 2, 3).contiguous().cpu()
+        y = self.y[:1].permute(0, 3, 1, 2).contiguous().cpu()
+        opt = torch.optim.Adam(ws, lr=1e-3)
+        z = torch.zeros(1, self.hid, self.H, self.W)
+
+        def one():
+            opt.zero_grad()
+            self._loss(lambda xt, h, c, m: OS.stlstm_cell(xt, h, c, m, *ws), x, y, z).backward()
+            opt.step()
+
+        return time_cpu(one, "oracle fwd over T cells + loss + bwd + Adam, B=1 of the same workload, fp32")
+
+
 class StubWorkload:
     """CPU stand-in with the workloads' interface: exercises this file's launch / timing / reporting plumbing under gloo
     (tests/test_ddp_cpu.py) - never a measurement."""
@@ -431,6 +511,8 @@ def build_workload(name: str, dev, batch: int, rank: int):
         return MetNetWorkload(dev, batch, rank)
     if name == "cloudgan":
         return CloudGANWorkload(dev, batch, rank)
+    if name == "stlstm":
+        return STLSTMWorkload(dev, batch, rank)
     if name == "stub":
         return StubWorkload(dev, batch, rank)
     raise SystemExit(f"unknown workload {name}")
@@ -481,7 +563,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "cloudgan", "stub"])
+    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "cloudgan", "stlstm", "stub"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 8; with --scaling strong: global batch / N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: fixed per-GPU batch (default, 8/GPU); strong: fixed global batch (--global-batch, BASELINE cfg 4: 64) split over the ranks")
@@ -527,7 +609,8 @@ def main(argv=None):
         out = {
             "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else
                       ("samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6" if args.workload == "convlstm" else
-                       ("samples/sec + per-step ms, CloudGAN (ConvLSTM generator + PatchGAN) 12ch 128x128 T=12->6" if args.workload == "cloudgan" else "stub")),
+                       ("samples/sec + per-step ms, CloudGAN (ConvLSTM generator + PatchGAN) 12ch 128x128 T=12->6" if args.workload == "cloudgan" else
+                        ("samples/sec + per-step ms, ST-LSTM cell (memory decoupling) 12ch 64x64 T=6" if args.workload == "stlstm" else "stub"))),
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16",
@@ -543,9 +626,9 @@ def main(argv=None):
                      "(backward-only data) stored as bf16; parameters, cell states, the ConvGRU state, state gradients, attention, loss and optimizer state fp32",
         }[args.dtype]
         out["config"]["mode"] = args.dtype
-        out["config"]["parity"] = ("ConvLSTM path pinned to reference-generated goldens; MetNet arithmetic checked against oracle/metnet.py, which is "
-                                   "UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this mode at this size: "
-                                   "profiles/r02_parity_observed.jsonl")
+        out["config"]["parity"] = ("ConvLSTM, CloudGAN and ST-LSTM paths pinned to reference-generated goldens; MetNet arithmetic checked against "
+                                   "oracle/metnet.py, which is UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this "
+                                   "mode at this size: profiles/r02_parity_observed.jsonl")
         out["roofline"] = wl.roofline()
     if world > 1 or rank == 0:
         comm = comm_report(wl, world, dev)  # collective: every rank takes part

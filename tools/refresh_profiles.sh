@@ -11,5 +11,8 @@ done
 for m in bf16a bf16; do bash tools/prof_pmc.sh ${R}_pmc_metnet_$m $m > /dev/null 2>&1; done
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_metnet_bf16a_bench_full.json 2> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload convlstm --steps 20 --warmup 5 > gpurun_out/${R}_convlstm_bf16a_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
+python bench.py --workload cloudgan --steps 10 --warmup 3 --no-extra > gpurun_out/${R}_cloudgan_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
+python bench.py --workload stlstm --steps 10 --warmup 3 --no-extra > gpurun_out/${R}_stlstm_bf16a_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
+python bench.py --workload stlstm --dtype f32 --steps 10 --warmup 3 --no-extra --no-cpu-baseline > gpurun_out/${R}_stlstm_f32_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 for m in bf16a bf16 f32; do for w in metnet convlstm; do cut -c1-200 gpurun_out/${R}_${w}_$m/bench.json; done; done
 cut -c1-300 gpurun_out/${R}_metnet_bf16a_bench_full.json
