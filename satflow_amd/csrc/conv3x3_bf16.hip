@@ -15,6 +15,8 @@
 //     (v_cvt_pk_bf16_f32, RNE) and written after them into the other input buffer (halves swapped on
 //     odd halo rows - conflict-free for the 2-rows-per-fragment access pattern).
 // One barrier per chunk; 18*NF MFMAs (32 cycles each) per wave between barriers.
+#include <cstdlib>
+
 #include "conv_common.h"
 
 namespace {
@@ -450,6 +452,9 @@ int sf_conv_bf16_tiles(int h, int w) {
 }
 
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st) {
+  // large single-source bf16-stored launches: one persistent workgroup per CU (SF_NO_PERSIST_CONV=1: A/B switch)
+  static const bool no_persist = getenv("SF_NO_PERSIST_CONV") != nullptr;
+  if (!no_persist && sf_conv_bf16_persist_ok(p, epi, nf)) return sf_launch_conv_bf16_persist(p, nf, nblk, st);
   switch (epi) {
     case EPI_LINEAR: return launch_e<EPI_LINEAR>(p, nf, nblk, st);
     case EPI_SIGMOID: return launch_e<EPI_SIGMOID>(p, nf, nblk, st);

@@ -364,11 +364,10 @@ __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const Con
 // lds_coef [3][32 * NF]: this N block's (A, B, K), staged by the kernel BEFORE its K loop (zeros past out_c).  The x quads of BOTH M fragments are
 // requested before anything else (one memory latency per workgroup instead of one per fragment - the epilogue runs with the
 // matrix pipe idle, 1 workgroup per CU); NF = 5 requests them per M fragment (registers).
-template <int NF>
+template <int NF, int HOIST = (NF <= 4 ? 2 : 1)>
 __device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const ConvParams& p, int n, int nb, int y0, int x0, int wave,
                                                      int r, int kh, const float* lds_coef) {
   constexpr int NB = 32 * NF;
-  constexpr int HOIST = NF <= 4 ? 2 : 1;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
   typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
@@ -443,6 +442,9 @@ inline int check_src(const sfTensor& t, const char* name) {
 int sf_conv_bf16_tiles(int h, int w);
 // bf16-MFMA launcher (conv3x3_bf16.hip); epi is one of sfconv::EPI_*
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
+// persistent variant for the large single-source bf16-stored launches (conv3x3_bf16_persist.hip); bit-identical results
+bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf);
+int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p, int nf, int nblk, hipStream_t st);
 // kscale (nullable): [groups][Kp] per-input-lane factors -> `groups` packed images back to back (folded BatchNorm scale)
 void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
                           void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale = nullptr, int groups = 1);

@@ -56,6 +56,9 @@ def _ref_stats(x, bn, groups):
     (4, 1, 256, 256, 32, 32, False),   # one group
     (8, 4, 48, 160, 12, 10, True),     # 4-wave kernel, NF = 5
     (4, 2, 16, 32, 2, 2, False),       # every pixel a corner
+    (520, 4, 32, 64, 32, 32, True),    # 1040 tiles: the persistent kernel (one workgroup per CU walks several items), statistics epilogue
+    (516, 4, 32, 160, 40, 24, False),  # large launch with NF = 5: stays on the one-item kernel
+    (528, 4, 48, 128, 36, 20, False),  # persistent kernel, transposed epilogue, ragged tiles
 ])
 def test_folded_forward_matches_float64_of_its_operands(device, n, groups, cin, cout, H, W, want_stats):
     F, x, bn, conv, eng = _setup(device, n, groups, cin, cout, H, W)

@@ -1,0 +1,52 @@
+"""GPU: the persistent bf16 convolution kernel (conv3x3_bf16_persist.hip: one workgroup per CU walks several (tile, N block) items,
+the next item's first K chunk requested during the current item's last) against the one-item-per-workgroup kernel it replaces for
+large launches.  Same arithmetic, same K order, same epilogues: a launch over N images (persistent: >= 1024 tiles) must equal, BIT FOR
+BIT, two launches over the halves (below the threshold: one-item kernel); the per-tile BatchNorm statistics to fp32 noise (LDS atomics)."""
+import pytest
+import torch
+
+import satflow_amd
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture()
+def bf16_mode():
+    satflow_amd.set_compute_dtype("bf16")
+    yield
+    satflow_amd.set_compute_dtype("f32")
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W", [(520, 32, 64, 32, 32), (400, 160, 256, 40, 24), (600, 16, 96, 17, 33), (2040, 256, 128, 32, 16)])
+@pytest.mark.parametrize("stats", [False, True])
+def test_persistent_kernel_matches_one_item_kernel(device, bf16_mode, n, cin, cout, H, W, stats):
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import NULL, T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(n + cin)
+    eng = ConvEngine([cin], cout)
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+    packed, bp = K.pack_weights(w, b, eng.fwd_map, False)
+    x = torch.randn(n, H, W, cpad(cin), generator=g).to(device).to(torch.bfloat16)
+    tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
+    assert tiles * n >= 1024 and tiles * (n // 2) < 1024  # whole launch persistent, halves not
+
+    def run(xs):
+        m = xs.shape[0]
+        y = torch.full((m, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
+        st = torch.full((m * tiles, eng.fwd_map.Np, 2), float("nan"), device=device) if stats else None
+        K.conv3x3(T(xs), NULL, m, H, W, packed, bp, eng.fwd_map, T(y), stats=st)
+        return y, st
+
+    y, st = run(x)
+    h = n // 2
+    ya, sa = run(x[:h].contiguous())
+    yb, sb = run(x[h:].contiguous())
+    torch.cuda.synchronize()
+    assert torch.isfinite(y[..., :cout].float()).all()
+    assert torch.equal(y[:h, ..., :cout], ya[..., :cout]) and torch.equal(y[h:, ..., :cout], yb[..., :cout])
+    if stats:  # per-tile sums: the lanes add into LDS with atomics (order varies run to run, in either kernel): fp32 noise only
+        ref = torch.cat((sa, sb))[:, :cout]
+        assert torch.allclose(st[:, :cout], ref, rtol=1e-5, atol=1e-4 * float(ref.abs().max()))
