@@ -47,7 +47,7 @@ def event_time(fn, iters: int, warm: int = 3) -> float:
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def kernel_source_sha(files=("conv3x3_bf16.hip", "conv_common.h", "sf_common.h")) -> str:
+def kernel_source_sha(files=("conv3x3_bf16.hip", "conv3x3_bf16_persist.hip", "conv_common.h", "sf_common.h")) -> str:
     """sha256 (16 hex digits) of the dominant kernel's sources: stamps the PMC records under profiles/ so that a stale
     `roofline.traffic` cannot outlive a kernel change."""
     import hashlib
@@ -267,7 +267,8 @@ class MetNetWorkload:
                 traffic_src = f"profiles/r02_metnet_{mode}_pmc_conv256.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": f"conv3x3_{'bf16' if bf16 else 'f32'}_kernel<NF=4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)",
+                "kernel": (f"conv3x3_bf16_persist_kernel<NF=4,TR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images; one persistent workgroup per CU)" if act16 else
+                           f"conv3x3_{'bf16' if bf16 else 'f32'}_kernel<NF=4,LINEAR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images)"),
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
                 "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), bf16 activations in HBM: intensity 1150 F/B vs "

@@ -12,13 +12,15 @@ for m in bf16a bf16; do
   d=gpurun_out/${R}_pmc_metnet_$m
   for c in FETCH_SIZE WRITE_SIZE; do [ -f $d/pmc_${c}_counter_collection.csv ] && python - $d/pmc_${c}_counter_collection.csv profiles/${R}_metnet_${m}_pmc_$c.csv <<'PY'
 import csv, sys
-rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv3x3_bf16_kernel" in r["Kernel_Name"]]
+rows = [r for r in csv.DictReader(open(sys.argv[1])) if "conv3x3_bf16_" in r["Kernel_Name"]]
 w = csv.DictWriter(open(sys.argv[2], "w"), fieldnames=["Kernel_Name", "Counter_Name", "Counter_Value", "Grid_Size", "Workgroup_Size"])
 w.writeheader()
 for r in rows: w.writerow({k: r[k] for k in w.fieldnames})
 PY
   done
-  [ -d $d ] && python tools/parse_pmc.py $d profiles/${R}_metnet_${m}_pmc_conv256.json "conv3x3_bf16_kernel<8, 4, 0, false, true, false>" > /dev/null
+  # the probe's launch: bf16-stored activations take the persistent kernel, fp32-stored ones the one-item kernel
+  if [ $m = bf16a ]; then KF="conv3x3_bf16_persist_kernel<4, 0>"; else KF="conv3x3_bf16_kernel<8, 4, 0, false, true, false>"; fi
+  [ -d $d ] && python tools/parse_pmc.py $d profiles/${R}_metnet_${m}_pmc_conv256.json "$KF" > /dev/null
 done
 [ -s gpurun_out/${R}_cloudgan_bench.json ] && cp gpurun_out/${R}_cloudgan_bench.json profiles/${R}_cloudgan_f32_bench.json
 for f in stlstm_bf16a_bench stlstm_f32_bench; do [ -s gpurun_out/${R}_$f.json ] && cp gpurun_out/${R}_$f.json profiles/${R}_$f.json; done
