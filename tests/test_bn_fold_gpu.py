@@ -280,3 +280,14 @@ def test_leadtime_pool_statistics(device, Fr, H, W, C, L, dtype):
     o = out.double().reshape(L, -1, C)
     assert rel_l2(s[..., 0], o.sum(1)) < 1e-5
     assert rel_l2(s[..., 1], (o * o).sum(1)) < 1e-5
+
+
+def test_leadtime_pool_statistics_fall_back_beyond_the_register_budget(device):
+    """More than 12 lead times: no statistics records (the BatchNorm then reduces the pooled tensor itself), same pooled tensor."""
+    from satflow_amd import functional as F
+
+    g = torch.Generator().manual_seed(12)
+    base = torch.randn(2, 8, 8, 32, generator=g).to(device)
+    w1 = (torch.randn(32, 4 + 13, 3, 3, generator=g) * 0.3).to(device)
+    out, st = F.leadtime_pool(base, w1, 4, 13, want_stats=True)
+    assert st is None and torch.equal(out, F.leadtime_pool(base, w1, 4, 13))
