@@ -253,6 +253,14 @@ int sf_maxpool2_dropout_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTens
 int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l,
                             int32_t perm_t, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
                             int32_t dtype, sfStream stream);
+/* The same pooling (p1 = p2 = 0: without the dropouts) that RECORDS which window element every channel took - route
+ * [n][h/2][w/2][c/8] uint16, 2 bits per channel, first maximum in row-major window order as max_pool2d - so that the backward
+ * pass neither keeps nor re-reads the input tensor (the DownSampler's last pooling: 1.2 GB at the benchmark size). */
+int sf_maxpool2_route_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, float p1,
+                          float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* route, int32_t dtype, sfStream stream);
+int sf_maxpool2_route_bwd(const void* route, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l,
+                          int32_t perm_t, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype,
+                          sfStream stream);
 
 /* nn.BatchNorm2d of the DownSampler.  Training mode: `groups` independent batches of
  * pix_per_group pixels each (one per lead time: the reference calls the encoder once per lead

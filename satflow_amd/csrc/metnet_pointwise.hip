@@ -159,7 +159,8 @@ __device__ __forceinline__ f32x8_t drop_scales8(const sfDrop& dr, unsigned long 
 
 template <typename TI, typename TO, bool DROP>
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__ in, int is, long long N, int H, int W, int C,
-                                                          TO* __restrict__ out, int os, const OuterPerm pm, const sfDrop dr, long long npt) {
+                                                          TO* __restrict__ out, int os, const OuterPerm pm, const sfDrop dr, long long npt,
+                                                          unsigned short* __restrict__ route) {
   const int Ho = H / 2, Wo = W / 2, q = C / 8;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -170,6 +171,18 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__
     const TI* p = in + ((n * H + 2 * yo) * W + 2 * xo) * is + c;
     f32x8_t m = ldv8(p);
     const f32x8_t v1 = ldv8(p + is), v2 = ldv8(p + (long long)W * is), v3 = ldv8(p + (long long)W * is + is);
+    if (route) {  // which window element each channel took (2 bits per channel: first maximum in row-major order), [input window idx]
+      unsigned rt = 0;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        int am = 0; float mm = m[j];
+        if (v1[j] > mm) { mm = v1[j]; am = 1; }
+        if (v2[j] > mm) { mm = v2[j]; am = 2; }
+        if (v3[j] > mm) { mm = v3[j]; am = 3; }
+        rt |= (unsigned)am << (2 * j);
+      }
+      route[idx] = (unsigned short)rt;
+    }
 #pragma unroll
     for (int j = 0; j < 8; ++j) m[j] = fmaxf(fmaxf(m[j], v1[j]), fmaxf(v2[j], v3[j]));
     const long long no = perm_image(n, pm);
@@ -184,7 +197,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__
 template <typename TI, typename TO, bool DROP>  // TI: input and its gradient, TO: pooled output's gradient
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__ in, int is, const TO* __restrict__ dout, int dos,
                                                           long long N, int H, int W, int C, TI* __restrict__ din, int dis,
-                                                          const OuterPerm pm, const sfDrop dr, long long npt) {
+                                                          const OuterPerm pm, const sfDrop dr, long long npt, const unsigned short* __restrict__ route) {
   const int Ho = H / 2, Wo = W / 2, q = C / 8;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -193,8 +206,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
     const int xo = op % Wo, yo = (op / Wo) % Ho;
     const long long n = op / ((long long)Wo * Ho);
     const long long base = (n * H + 2 * yo) * W + 2 * xo;
-    const TI* p = in + base * is + c;
-    const f32x8_t v0 = ldv8(p), v1 = ldv8(p + is), v2 = ldv8(p + (long long)W * is), v3 = ldv8(p + (long long)W * is + is);
+    f32x8_t v0 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}, v1 = v0, v2 = v0, v3 = v0;
+    unsigned rt = 0;
+    if (route) rt = route[idx];  // the forward pass recorded the routing: the input is not read again
+    else {
+      const TI* p = in + base * is + c;
+      v0 = ldv8(p); v1 = ldv8(p + is); v2 = ldv8(p + (long long)W * is); v3 = ldv8(p + (long long)W * is + is);
+    }
     const long long no = perm_image(n, pm);
     f32x8_t g = ldv8(dout + ((no * Ho + yo) * Wo + xo) * dos + c);
     if constexpr (DROP) {
@@ -209,6 +227,7 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
       if (v1[j] > m) { m = v1[j]; am = 1; }
       if (v2[j] > m) { m = v2[j]; am = 2; }
       if (v3[j] > m) { m = v3[j]; am = 3; }
+      if (route) am = (rt >> (2 * j)) & 3;
       g0[j] = am == 0 ? g[j] : 0.f; g1[j] = am == 1 ? g[j] : 0.f; g2[j] = am == 2 ? g[j] : 0.f; g3[j] = am == 3 ? g[j] : 0.f;
     }
     TI* d = din + base * dis + c;
@@ -444,8 +463,10 @@ int sf_metnet_preprocess_bwd(sfTensor dout, int32_t B, int32_t T, int32_t C, int
 }
 
 static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
-                          const sfDrop* drop, int64_t period, hipStream_t st) {
+                          const sfDrop* drop, int64_t period, hipStream_t st, void* route = nullptr) {
   sfTensor& out = dout_or_out;
+  if (bwd && route && !in.ptr) { in = din; in.ptr = din.ptr; }  // routing recorded: the input tensor is only described (never read)
+  SF_REQUIRE(!route || ((uintptr_t)route & 1) == 0, "maxpool2: route must be 2-byte aligned");
   SF_REQUIRE(h % 2 == 0 && w % 2 == 0 && in.c == out.c && ok8(in) && ok8(out) && (!bwd || (in.c == din.c && ok8(din))),
              "maxpool2: needs even H,W and matching channels (multiple of 8, 16-byte aligned pixels)");
   SF_REQUIRE(in.dtype == out.dtype || (in.dtype == SF_BF16 && out.dtype == SF_F32), "maxpool2: unsupported storage pair %d -> %d", in.dtype, out.dtype);
@@ -469,9 +490,9 @@ static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n
 #define SF_MP(TI_, TO_, DROP_)                                                                                                                   \
   do {                                                                                                                                            \
     if (bwd) hipLaunchKernelGGL((maxpool_bwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (const TO_*)out.ptr,   \
-                                out.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm, dr, npt);                                    \
+                                out.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm, dr, npt, (const unsigned short*)route); \
     else hipLaunchKernelGGL((maxpool_fwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (long long)n, h, w, in.c,   \
-                            (TO_*)out.ptr, out.stride, pm, dr, npt);                                                                              \
+                            (TO_*)out.ptr, out.stride, pm, dr, npt, (unsigned short*)route);                                                     \
   } while (0)
 #define SF_MP_T(DROP_)                                         \
   do {                                                         \
@@ -517,6 +538,27 @@ int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, in
   if (int rc = check_drop(p1, p2)) return rc;
   const sfDrop d = sf_make_drop(p1, p2, seed1, seed2);
   return maxpool_launch(true, in, dout, n, h, w, din, perm_l, perm_t, &d, period, (hipStream_t)stream);
+}
+
+int sf_maxpool2_route_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, float p1, float p2,
+                          int64_t period, uint64_t seed1, uint64_t seed2, void* route, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_route_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(route != nullptr, "sf_maxpool2_route_fwd: route must not be null");
+  if (p1 == 0.f && p2 == 0.f) return maxpool_launch(false, in, out, n, h, w, sfTensor{}, perm_l, perm_t, nullptr, 0, (hipStream_t)stream, route);
+  if (int rc = check_drop(p1, p2)) return rc;
+  const sfDrop d = sf_make_drop(p1, p2, seed1, seed2);
+  return maxpool_launch(false, in, out, n, h, w, sfTensor{}, perm_l, perm_t, &d, period, (hipStream_t)stream, route);
+}
+
+int sf_maxpool2_route_bwd(const void* route, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t, float p1,
+                          float p2, int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_route_bwd: dtype %d not built", dtype);
+  SF_REQUIRE(route != nullptr && din.ptr != nullptr, "sf_maxpool2_route_bwd: route / din must not be null");
+  sfTensor none{};
+  if (p1 == 0.f && p2 == 0.f) return maxpool_launch(true, none, dout, n, h, w, din, perm_l, perm_t, nullptr, 0, (hipStream_t)stream, (void*)route);
+  if (int rc = check_drop(p1, p2)) return rc;
+  const sfDrop d = sf_make_drop(p1, p2, seed1, seed2);
+  return maxpool_launch(true, none, dout, n, h, w, din, perm_l, perm_t, &d, period, (hipStream_t)stream, (void*)route);
 }
 
 static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, const float* mean,

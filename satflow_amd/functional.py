@@ -217,16 +217,28 @@ def conv3x3_broadcast(eng: ConvEngine, x0: Tensor, x1: Tensor, weight: Tensor, b
 # max pooling / batch norm
 # ----------------------------------------------------------------------------------------------
 class _MaxPoolFn(torch.autograd.Function):
+    """2x2 max-pooling; when a gradient will be needed the forward pass records the routing (2 bits per element) instead of keeping
+    the input alive: the backward pass reads the routing, not the input (``sf_maxpool2_route_fwd/bwd``; SF_POOL_RECOMPUTE=1: the
+    argmax-recomputing kernels)."""
+
     @staticmethod
     def forward(ctx, x: Tensor, perm: Optional[Tuple[int, int]], out_dtype=None, drop=None):
         ctx.perm, ctx.drop = perm, drop
+        if ctx.needs_input_grad[0] and x.shape[-1] % 8 == 0 and not os.environ.get("SF_POOL_RECOMPUTE"):
+            y, route = K.maxpool2_route_fwd(x, perm, out_dtype, drop)
+            ctx.meta = (tuple(x.shape), x.dtype)
+            ctx.save_for_backward(route)
+            return y
+        ctx.meta = None
         ctx.save_for_backward(x)
         return K.maxpool2_fwd(x, perm, out_dtype, drop)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
-        (x,) = ctx.saved_tensors
-        return K.maxpool2_bwd(x, gy.contiguous(), ctx.perm, ctx.drop), None, None, None
+        (t,) = ctx.saved_tensors
+        if ctx.meta is not None:
+            return K.maxpool2_route_bwd(t, gy.contiguous(), ctx.meta[0], ctx.meta[1], ctx.perm, ctx.drop), None, None, None
+        return K.maxpool2_bwd(t, gy.contiguous(), ctx.perm, ctx.drop), None, None, None
 
 
 def _draw_seeds() -> Tuple[int, int]:

@@ -314,6 +314,27 @@ def maxpool2_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=No
     return y
 
 
+def maxpool2_route_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dtype=None, drop=None) -> Tuple[Tensor, Tensor]:
+    """The pooling that also records the routing (2 bits per channel, uint16 per channel octet) for ``maxpool2_route_bwd``:
+    the backward pass then needs neither x nor a second read of it.  sf_maxpool2_route_fwd."""
+    n, h, w, c = x.shape
+    y = torch.empty(n, h // 2, w // 2, c, dtype=out_dtype or x.dtype, device=x.device)
+    route = torch.empty(n, h // 2, w // 2, c // 8, dtype=torch.int16, device=x.device)
+    pl, pt = perm or (0, 0)
+    d = drop if drop is not None else (0.0, 0.0, 0, 0, 0)
+    check(lib().sf_maxpool2_route_fwd(T(x), n, h, w, T(y), pl, pt, *d, route.data_ptr(), SF_F32, stream_ptr()), "sf_maxpool2_route_fwd")
+    return y, route
+
+
+def maxpool2_route_bwd(route: Tensor, gy: Tensor, shape, dtype, perm: Optional[Tuple[int, int]] = None, drop=None) -> Tensor:
+    n, h, w, c = shape
+    gx = torch.empty(shape, dtype=dtype, device=gy.device)
+    pl, pt = perm or (0, 0)
+    d = drop if drop is not None else (0.0, 0.0, 0, 0, 0)
+    check(lib().sf_maxpool2_route_bwd(route.data_ptr(), T(gy), n, h, w, T(gx), pl, pt, *d, SF_F32, stream_ptr()), "sf_maxpool2_route_bwd")
+    return gx
+
+
 def maxpool2_bwd(x: Tensor, gy: Tensor, perm: Optional[Tuple[int, int]] = None, drop=None) -> Tensor:
     n, h, w, c = x.shape
     gx = torch.empty_like(x)

@@ -70,6 +70,9 @@ int main(void) {
   REFUSED(sf_maxpool2_bwd(a16, a16, 1, 8, 8, a64, 0, 0, SF_F32, st));                                /* channel mismatch */
   REFUSED(sf_maxpool2_dropout_fwd(a16, 1, 8, 8, a16, 0, 0, 1.5f, 0.f, 256, 1, 2, SF_F32, st));       /* p >= 1 */
   REFUSED(sf_maxpool2_dropout_bwd(a16, a16, 1, 8, 8, a16, 0, 0, 0.1f, 0.1f, 100, 1, 2, SF_F32, st)); /* period not whole images */
+  REFUSED(sf_maxpool2_route_fwd(a16, 1, 8, 8, a16, 0, 0, 0.f, 0.f, 0, 0, 0, 0, SF_F32, st));         /* no routing buffer */
+  REFUSED(sf_maxpool2_route_fwd(a16, 1, 8, 8, a16, 0, 0, 0.f, 0.f, 0, 0, 0, (char*)ok + 1, SF_F32, st)); /* misaligned routing buffer */
+  REFUSED(sf_maxpool2_route_bwd(ok, a16, 1, 8, 8, N0, 0, 0, 0.f, 0.f, 0, 0, 0, SF_F32, st));         /* no din */
   REFUSED(sf_batchnorm_train_fwd(odd, 64, 1, 12, ok, ok, 1e-5f, 0.1f, 0, 0, ok, ok, ok, ok, ok, odd, SF_F32, st));
   REFUSED(sf_batchnorm_train_fwd_stats(a16, 64, 1, 16, ok, ok, 1e-5f, 0.1f, 0, 0, ok, ok, ok, ok, ok, 0, 4, 32, a16, SF_F32, st)); /* null stats */
   REFUSED(sf_batchnorm_eval_fwd(a16, 64, 32, ok, ok, 1e-5f, ok, ok, ok, ok, a16, SF_F32, st));       /* creal > lanes */

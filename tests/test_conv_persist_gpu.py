@@ -50,3 +50,34 @@ def test_persistent_kernel_matches_one_item_kernel(device, bf16_mode, n, cin, co
     if stats:  # per-tile sums: the lanes add into LDS with atomics (order varies run to run, in either kernel): fp32 noise only
         ref = torch.cat((sa, sb))[:, :cout]
         assert torch.allclose(st[:, :cout], ref, rtol=1e-5, atol=1e-4 * float(ref.abs().max()))
+
+
+@pytest.mark.parametrize("dtype,out_dtype", [(torch.bfloat16, torch.bfloat16), (torch.bfloat16, torch.float32), (torch.float32, torch.float32)])
+@pytest.mark.parametrize("perm,drop", [(None, None), ((3, 2), None), ((3, 2), (0.2, 0.1, 6 * 4 * 3 * 32))])  # period: 6 pooled images per timestep
+def test_maxpool_with_recorded_routing_matches_recomputed_argmax(device, monkeypatch, dtype, out_dtype, perm, drop):
+    """sf_maxpool2_route_fwd/bwd (the forward pass records which window element every channel took; the backward pass reads that
+    instead of the input) against the argmax-recomputing kernels: same pooled tensor, same gradient, bit for bit - including ties
+    (first maximum in row-major window order), the image permutation and the fused dropouts."""
+    from satflow_amd import functional as F
+
+    g = torch.Generator().manual_seed(21)
+    n, h, w, c = 12, 8, 6, 32
+    x = torch.randint(-3, 4, (n, h, w, c), generator=g).float()  # small integers: many exact ties
+    x = x.to(device).to(dtype)
+    gy = torch.randn(n, h // 2, w // 2, c, generator=g).to(device).to(out_dtype)
+
+    def run(recompute):
+        if recompute:
+            monkeypatch.setenv("SF_POOL_RECOMPUTE", "1")
+        else:
+            monkeypatch.delenv("SF_POOL_RECOMPUTE", raising=False)
+        torch.manual_seed(5)  # the dropout seeds come from the torch RNG
+        xi = x.clone().requires_grad_(True)
+        y = F.maxpool2(xi, perm, out_dtype=out_dtype, dropout=drop)
+        y.backward(gy)
+        return y.detach(), xi.grad
+
+    y1, g1 = run(False)
+    y0, g0 = run(True)
+    assert torch.equal(y1, y0) and torch.equal(g1, g0)
+    assert float(g1.float().abs().sum()) > 0
