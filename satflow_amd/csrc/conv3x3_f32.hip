@@ -343,7 +343,7 @@ int sf_conv3x3_bwd_data_bn(sfTensor dout, int32_t n, int32_t h, int32_t w, const
   SF_REQUIRE(groups >= 1 && n % groups == 0, "bwd_data_bn: n=%d must split into %d groups of whole images", n, groups);
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && dx.c <= Np, "bwd_data_bn: bad Np=%d nf=%d dx.c=%d", Np, nf, dx.c);
   SF_REQUIRE(dout.ptr && dout.dtype == SF_BF16 && x.ptr && x.dtype == SF_BF16 && dx.ptr && dx.dtype == SF_BF16 && x.c == dx.c && x.c % 8 == 0 &&
-                 x.stride % 4 == 0 && ((uintptr_t)x.ptr & 7) == 0 && dx.stride % 8 == 0 && ((uintptr_t)dx.ptr & 15) == 0,
+                 x.stride % 8 == 0 && ((uintptr_t)x.ptr & 15) == 0 && dx.stride % 8 == 0 && ((uintptr_t)dx.ptr & 15) == 0,
              "bwd_data_bn: bf16-stored dout, x and dx with matching channel lanes (multiples of 8) and aligned pixels");
   SF_REQUIRE(coef && ((uintptr_t)coef & 15) == 0, "bwd_data_bn: coef null / not 16-byte aligned");
   // images of at most 16x16 pixels could take the two-images-per-workgroup kernel: one group per tile there is not guaranteed

@@ -370,7 +370,6 @@ __device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const
   constexpr int NB = 32 * NF;
   typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
   typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
-  typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
   typedef float f32x2_t __attribute__((ext_vector_type(2)));
   auto pk = [](float a, float b) -> unsigned { return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t)); };
   bool ok[2];
@@ -381,18 +380,22 @@ __device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const
     ok[mf] = py < p.H && px < p.W;
     pix[mf] = ok[mf] ? (size_t)(n * p.H + py) * p.W + px : 0;  // 0 for lanes outside: a valid address
   }
-  int off[NF][4];  // channel quads past out_c (not stored) read quad 0 instead of running past the tensor
+  // x is read the way the result is written: as 16-byte channel OCTETS - lane (r, kh) fetches octets g + kh (g = 0, 2) of its pixel,
+  // the two half-waves then trade the quads they hold for each other (`v_permlane32_swap`, the store path in reverse).  Half the load
+  // instructions of 8-byte quads per lane, and every request is a full 32-byte sector pair (the epilogue's x read was bound by the
+  // number of sector requests, not by latency).  Octets past out_c (never stored) read octet 0 instead of running past the tensor.
+  int off[NF][2];
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-    for (int g = 0; g < 4; ++g) off[nf][g] = (nb * NB + nf * 32 + 8 * g < p.out_c ? nb * NB + nf * 32 + 8 * g : 0) + 4 * kh;
-  bf16x4_t xq[HOIST][NF][4];
+    for (int j = 0; j < 2; ++j) off[nf][j] = nb * NB + nf * 32 + 16 * j < p.out_c ? nb * NB + nf * 32 + 16 * j + 8 * kh : 0;
+  u32x4_t xo[HOIST][NF][2];
   auto request = [&](int slot, int mf) __attribute__((always_inline)) {
     const __bf16* xp = reinterpret_cast<const __bf16*>(p.bnb_x) + pix[mf] * p.bnb_xs;
 #pragma unroll
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) xq[slot][nf][g] = *reinterpret_cast<const bf16x4_t*>(xp + off[nf][g]);
+      for (int j = 0; j < 2; ++j) xo[slot][nf][j] = *reinterpret_cast<const u32x4_t*>(xp + off[nf][j]);
   };
   if constexpr (HOIST == 2) { request(0, 0); request(1, 1); } else request(0, 0);
 #pragma unroll
@@ -404,12 +407,23 @@ __device__ __forceinline__ void conv_epilogue_tr_bnb(f32x16 (&acc)[2][NF], const
       const int cb = nb * NB + nf * 32;
       float v[16];
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const float* lc = lds_coef + nf * 32 + 8 * g + 4 * kh;
-        const f32x4 A = *reinterpret_cast<const f32x4*>(lc), B = *reinterpret_cast<const f32x4*>(lc + NB), Kc = *reinterpret_cast<const f32x4*>(lc + 2 * NB);
+      for (int j = 0; j < 2; ++j) {
+        // octet (dwords d0..d3) -> this lane's quads 2j and 2j + 1: (d0, d1) of the lower half-wave and (d2, d3) of the upper one stay,
+        // the other two pairs cross over
+        const u32x4_t o = xo[slot][nf][j];
+        const auto s0 = __builtin_amdgcn_permlane32_swap(o[0], o[2], false, false);
+        const auto s1 = __builtin_amdgcn_permlane32_swap(o[1], o[3], false, false);
 #pragma unroll
-        for (int c = 0; c < 4; ++c)
-          v[4 * g + c] = __builtin_fmaf(A[c], acc[mf][nf][4 * g + c], __builtin_fmaf(B[c], (float)xq[slot][nf][g][c], Kc[c]));
+        for (int gg = 0; gg < 2; ++gg) {
+          const int g = 2 * j + gg;
+          const unsigned w0 = s0[gg], w1 = s1[gg];
+          const float xv[4] = {__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                               __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+          const float* lc = lds_coef + nf * 32 + 8 * g + 4 * kh;
+          const f32x4 A = *reinterpret_cast<const f32x4*>(lc), B = *reinterpret_cast<const f32x4*>(lc + NB), Kc = *reinterpret_cast<const f32x4*>(lc + 2 * NB);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[4 * g + c] = __builtin_fmaf(A[c], acc[mf][nf][4 * g + c], __builtin_fmaf(B[c], xv[c], Kc[c]));
+        }
       }
       __bf16* ob = reinterpret_cast<__bf16*>(p.out) + pix[mf] * p.out_s + cb + 8 * kh;
 #pragma unroll
