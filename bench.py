@@ -528,13 +528,21 @@ def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
 
     for _ in range(warmup):
         wl.step()
+    use_events = dev.type == "cuda"
+    if use_events:  # HIP events on the step's stream beside the wall clock (BASELINE.md section 3 / SURVEY 8d)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     barrier()
     t0 = time.perf_counter()
+    if use_events:
+        ev0.record()
     loss = None
     for _ in range(steps):
         loss = wl.step()
+    if use_events:
+        ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    timed_steps.last_event_ms = ev0.elapsed_time(ev1) if use_events else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -603,6 +611,7 @@ def main(argv=None):
 
     wl = build_workload(args.workload, dev, batch, rank)
     elapsed, final_loss = timed_steps(wl, args.steps, args.warmup, world, dev, sync)
+    event_ms = getattr(timed_steps, "last_event_ms", None)
 
     out = None
     if rank == 0:
@@ -617,6 +626,8 @@ def main(argv=None):
             "dtype": "f32" if args.dtype == "f32" else "bf16",
             "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
             "config": wl.config(world), "final_loss": final_loss,
+            # the same K steps between two HIP events on the launch stream (this rank); `ms_per_step` is the wall clock incl. the barriers
+            "ms_per_step_hip_events": (event_ms / args.steps) if event_ms is not None else None,
         }
         out["config"]["arithmetic"] = {
             "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",

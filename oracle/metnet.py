@@ -130,23 +130,27 @@ def downsampler(x: Tensor, p: Params, prefix: str, bn_stats: Dict[str, Tuple[Ten
     return max_pool2(conv(8, t), routing[1])
 
 
-def convgru_cell(x: Tensor, h: Tensor, p: Params, prefix: str) -> Tensor:
+def convgru_cell(x: Tensor, h: Tensor, p: Params, prefix: str, operand=None) -> Tensor:
     """``ConvGRUCell``: ``z,r = split(sigmoid(conv_zr([x;h])))``; ``n = tanh(conv_h1(x) + r*conv_h2(h))``;
-    ``h' = (1-z)*n + z*h``."""
+    ``h' = (1-z)*n + z*h``.
+
+    ``operand`` (tests of the bf16 kernels): a rounding applied to every convolution OPERAND (inputs and weights) and to nothing
+    else - what a bf16-operand / fp32-accumulate convolution sees; the blend keeps the unrounded state."""
+    op = operand if operand is not None else (lambda t: t)
     hid = h.shape[1]
     pad = p[f"{prefix}.conv_zr.weight"].shape[-1] // 2
     zr = torch.sigmoid(
-        F.conv2d(torch.cat((x, h), 1), p[f"{prefix}.conv_zr.weight"], p[f"{prefix}.conv_zr.bias"], padding=pad)
+        F.conv2d(op(torch.cat((x, h), 1)), op(p[f"{prefix}.conv_zr.weight"]), p[f"{prefix}.conv_zr.bias"], padding=pad)
     )
     z, r = zr[:, :hid], zr[:, hid:]
     n = torch.tanh(
-        F.conv2d(x, p[f"{prefix}.conv_h1.weight"], p[f"{prefix}.conv_h1.bias"], padding=pad)
-        + r * F.conv2d(h, p[f"{prefix}.conv_h2.weight"], p[f"{prefix}.conv_h2.bias"], padding=pad)
+        F.conv2d(op(x), op(p[f"{prefix}.conv_h1.weight"]), p[f"{prefix}.conv_h1.bias"], padding=pad)
+        + r * F.conv2d(op(h), op(p[f"{prefix}.conv_h2.weight"]), p[f"{prefix}.conv_h2.bias"], padding=pad)
     )
     return (1 - z) * n + z * h
 
 
-def convgru(x: Tensor, p: Params, prefix: str, num_layers: int) -> Tuple[Tensor, List[Tensor]]:
+def convgru(x: Tensor, p: Params, prefix: str, num_layers: int, operand=None) -> Tuple[Tensor, List[Tensor]]:
     """Multi-layer ConvGRU over ``x[B,T,C,H,W]`` with zero initial state (dropout off).
 
     Returns ``(layer_output[B,T,hid,H,W] of the last layer, [last h of every layer])``.
@@ -160,7 +164,7 @@ def convgru(x: Tensor, p: Params, prefix: str, num_layers: int) -> Tuple[Tensor,
         h = x.new_zeros(B, hid, H, W)
         outs = []
         for t in range(T):
-            h = convgru_cell(seq[t], h, p, cell)
+            h = convgru_cell(seq[t], h, p, cell, operand)
             outs.append(h)
         seq = outs
         last.append(h)

@@ -172,7 +172,7 @@ __global__ void pack_weights_f32_kernel(const float* __restrict__ w, int O, int 
 //   table[g][rc*3+cc][n] = bias[n] + sum over valid taps, k  What[g][n][k][tap] * (shift[g][k] / scale[g][k])
 // With exact weights for the shift the two halves would not cancel: sum_px What*x - W*a*mean*N leaves (What - W*a) * mean(x), an
 // offset common to all pixels of a channel (about 2^-9 * mean/std of the output's std: invisible per pixel, but it IS the error of
-// the next BatchNorm's running mean).  scale == 0 (gamma == 0): the channel contributes w * shift exactly.
+// the next BatchNorm's running mean).  scale == 0 or tiny (gamma ~ 0, shift / scale not finite): the channel contributes w * shift exactly.
 // One workgroup per output lane n: its weight row (I x 9 floats, contiguous in OIHW), the scales and the ratios shift / scale go to
 // LDS once; thread (g, tap) forms the per-tap sum over k (fp32, fixed order), thread (g, class) adds the valid taps.
 __global__ __launch_bounds__(256) void fold_bias_table_kernel(const float* __restrict__ w, int I, const int* __restrict__ nmap, int Np,
@@ -189,7 +189,11 @@ __global__ __launch_bounds__(256) void fold_bias_table_kernel(const float* __res
     for (int e = threadIdx.x; e < I * 9; e += 256) wrow[e] = w[(size_t)nn * I * 9 + e];
   for (int e = threadIdx.x; e < groups * Kp; e += 256) {
     const float a = scale[e], b = shift[e];
-    sa[e] = a; sc[e] = a != 0.f ? b / a : b;
+    // a pruned / decayed BatchNorm channel (|gamma * rstd| tiny but nonzero): b / a would overflow while bf16(w * a) flushes to
+    // zero - inf * 0 = NaN in every output pixel of the group.  Such a channel takes the exact w * shift branch like scale == 0.
+    const float ratio = b / a;
+    const bool tiny = !(fabsf(a) >= 1e-18f) || !(fabsf(ratio) <= 3.0e38f);
+    sa[e] = tiny ? 0.f : a; sc[e] = tiny ? b : ratio;
   }
   __syncthreads();
   for (int gt = threadIdx.x; gt < groups * 9; gt += 256) {

@@ -17,7 +17,7 @@ struct GConvParams {
   const float* x; int xs;          // input  [N][H][W][xs], cin real channels (lanes >= cin are never read as non-zero weights)
   const float* w;                  // [cout][cin][kh][kw]
   const float* bias;               // [cout] or null
-  float* y; int ys;                // output [N][OH][OW][ys]
+  float* y; int ys; int yc;        // output [N][OH][OW][ys]; yc = channel lanes the caller owns in a pixel (<= ys: a strided view keeps its neighbours)
   int N, H, W, OH, OW, cin, cout, kh, kw, stride, pad;
   float slope;                     // fused LeakyReLU negative slope (1 = identity)
 };
@@ -59,7 +59,7 @@ __global__ __launch_bounds__(256) void gconv_fwd_kernel(const GConvParams p) {
       }
     }
   // D[row = pixel][col = channel]: lane holds channel `co`, rows frag_row(reg, h)
-  if (co < p.ys) {
+  if (co < p.yc) {
     const float bv = (p.bias && co < p.cout) ? p.bias[co] : 0.f;
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
@@ -107,7 +107,7 @@ __global__ __launch_bounds__(256) void gconv_bwd_data_kernel(const GConvParams p
         }
       }
     }
-  if (ci < p.ys) {
+  if (ci < p.yc) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const long long q = ((long long)blockIdx.x * 4 + wave) * 32 + frag_row(r, h);
@@ -212,7 +212,7 @@ int sf_conv2d_fwd(sfTensor x, int32_t n, int32_t h, int32_t w, const float* weig
   SF_REQUIRE(kh >= 1 && kw >= 1 && stride >= 1 && pad >= 0 && cin >= 1 && cout >= 1 && x.c >= (cin + 7) / 8 * 8 && y.c >= cout, "sf_conv2d_fwd: geometry");
   const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
   SF_REQUIRE(oh >= 1 && ow >= 1, "sf_conv2d_fwd: empty output (%dx%d)", oh, ow);
-  GConvParams p{(const float*)x.ptr, x.stride, weight, bias, (float*)y.ptr, y.stride, n, h, w, oh, ow, cin, cout, kh, kw, stride, pad, leaky_slope};
+  GConvParams p{(const float*)x.ptr, x.stride, weight, bias, (float*)y.ptr, y.stride, y.c, n, h, w, oh, ow, cin, cout, kh, kw, stride, pad, leaky_slope};
   const long long npix = (long long)n * oh * ow;
   if (npix == 0) return 0;
   hipLaunchKernelGGL(gconv_fwd_kernel, dim3((unsigned)((npix + 127) / 128), (y.c + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);
@@ -225,7 +225,7 @@ int sf_conv2d_bwd_data(sfTensor dy, int32_t n, int32_t h, int32_t w, const float
   SF_REQUIRE(dtype == SF_F32, "sf_conv2d_bwd_data: exact-fp32 kernel only (dtype %d)", dtype);
   SF_REQUIRE(okt(dy) && okt(dx) && weight && dy.c >= (cout + 7) / 8 * 8 && dx.c >= cin, "sf_conv2d_bwd_data: tensors");
   const int oh = (h + 2 * pad - kh) / stride + 1, ow = (w + 2 * pad - kw) / stride + 1;
-  GConvParams p{(const float*)dy.ptr, dy.stride, weight, nullptr, (float*)dx.ptr, dx.stride, n, h, w, oh, ow, cin, cout, kh, kw, stride, pad, 1.f};
+  GConvParams p{(const float*)dy.ptr, dy.stride, weight, nullptr, (float*)dx.ptr, dx.stride, dx.c, n, h, w, oh, ow, cin, cout, kh, kw, stride, pad, 1.f};
   const long long npix = (long long)n * h * w;
   if (npix == 0) return 0;
   hipLaunchKernelGGL(gconv_bwd_data_kernel, dim3((unsigned)((npix + 127) / 128), (dx.c + 31) / 32), dim3(256), 0, (hipStream_t)stream, p);

@@ -732,8 +732,9 @@ class _MSEFn(torch.autograd.Function):
         check(lib().sf_mse_loss(pred.data_ptr(), target.data_ptr(), n, inner, frames, grad.data_ptr() if grad is not None else None,
                                 sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_mse_loss")
         ctx.save_for_backward(grad if grad is not None else pred.new_empty(0))
-        ctx.mark_non_differentiable(out[1:])
-        return out[0], out[1:]
+        loss, per = out[0], out[1:]
+        ctx.mark_non_differentiable(per)  # the very tensor object that is returned (a second out[1:] would be another view)
+        return loss, per
 
     @staticmethod
     def backward(ctx, g_loss: Tensor, _g_frames):
@@ -863,8 +864,9 @@ class _PairLossFn(torch.autograd.Function):
         else:
             check(lib().sf_bce_logits_loss(T(pred), labels[0], labels[1], rows, groups, c, g, sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_bce_logits_loss")
         ctx.save_for_backward(grad if grad is not None else pred.new_empty(0))
-        ctx.mark_non_differentiable(out[1:])
-        return out[0], out[1:]
+        loss, per = out[0], out[1:]
+        ctx.mark_non_differentiable(per)
+        return loss, per
 
     @staticmethod
     def backward(ctx, g_loss: Tensor, _g_groups):

@@ -277,8 +277,6 @@ class MetNet(nn.Module):
         self.head = nn.Conv2d(hidden_dim, output_channels, kernel_size=(1, 1))
         # conv1 restricted to the image lanes (the one-hot lead-time lanes are folded into the first pooling)
         self._conv1 = ConvEngine([self.image_channels], 160)
-        c1 = encoder.module[0]
-        self._conv1.key_tensors = (c1.weight, c1.bias)  # forward() hands it a fresh slice of c1.weight every call
 
     def forward(self, imgs: Tensor, lead_time: int = 0) -> Tensor:
         """``imgs[B,T,C,4*input_size,4*input_size] -> [B, forecast_steps, output_channels, input_size//4, input_size//4]``."""
@@ -297,6 +295,9 @@ class MetNet(nn.Module):
         # contribute a per-lead-time, border-aware constant that is added inside the fused first pooling
         c1 = enc.module[0]
         cimg = self.image_channels
+        # the convolution is handed a fresh slice of c1.weight every call: its packed-weight cache keys on the LIVE parameters
+        # (looked up now, not captured at construction - they may have been replaced by load_state_dict(assign=True) / re-assignment)
+        self._conv1.key_tensors = (c1.weight, c1.bias)
         base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias, out_dtype=st)  # [T*B, S, S, 160]
         if enc.capture is not None:
             enc.capture["base"] = base.detach()

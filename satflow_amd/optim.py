@@ -41,7 +41,6 @@ class FlatAdam(torch.optim.Optimizer):
         assert self.params, "no parameters"
         dev = self.params[0].device
         super().__init__(self.params, dict(lr=lr, betas=betas, eps=eps))
-        self.betas, self.eps = betas, eps
         self.offsets, total = [], 0
         for p in self.params:
             assert p.dtype == torch.float32 and p.device == dev
@@ -94,12 +93,33 @@ class FlatAdam(torch.optim.Optimizer):
             self._count = [self._bucket_of.count(k) for k in range(len(self._bucket_range))]
             self._pending = list(self._count)
             self._hooks = [p.register_post_accumulate_grad_hook(self._make_hook(self._bucket_of[i])) for i, p in enumerate(self.params)]
+        elif self.exchange:
+            # one all-reduce after the backward pass: a backward that lands AFTER the exchange (explicit allreduce_grads(), then
+            # another backward, then step()) would add rank-local gradients to the reduced sum - refuse it like the overlap path
+            self._hooks = [p.register_post_accumulate_grad_hook(self._guard_hook) for p in self.params]
 
     def disable_overlap(self) -> None:
         """Back to one all-reduce after the backward pass (removes the autograd hooks)."""
         for h in getattr(self, "_hooks", []):
             h.remove()
         self._hooks, self._work, self.overlap = [], {}, False
+
+    # hyper-parameters live in param_groups[0] (what torch schedulers and Lightning edit); step() reads them from there
+    @property
+    def betas(self):
+        return self.param_groups[0]["betas"]
+
+    @betas.setter
+    def betas(self, value) -> None:
+        self.param_groups[0]["betas"] = tuple(value)
+
+    @property
+    def eps(self) -> float:
+        return self.param_groups[0]["eps"]
+
+    @eps.setter
+    def eps(self, value: float) -> None:
+        self.param_groups[0]["eps"] = float(value)
 
     @property
     def lr(self) -> float:
@@ -118,6 +138,12 @@ class FlatAdam(torch.optim.Optimizer):
             yield
         finally:
             self._sync = old
+
+    def _guard_hook(self, _param) -> None:
+        if self._reduced:
+            raise RuntimeError("FlatAdam: a backward pass reached the gradient buffer after this step's all-reduce; the local gradients "
+                               "would be added to the already reduced sum.  Call step() / zero_grad() first, or accumulate inside "
+                               "`optimizer.no_sync()` before the exchanging backward.")
 
     def _make_hook(self, k: int):
         def hook(_param) -> None:
@@ -167,8 +193,12 @@ class FlatAdam(torch.optim.Optimizer):
 
     # ---- checkpoint / resume: Adam moments, step count and lr travel with the optimizer state ----
     def state_dict(self) -> dict:
-        return {"flat_m": self.flat_m.clone(), "flat_v": self.flat_v.clone(), "t": self.t, "lr": self.lr, "betas": tuple(self.betas),
-                "eps": self.eps, "numel": self.numel}
+        # not torch.optim's {"state", "param_groups"} layout (the moments are two flat buffers, not per-parameter entries);
+        # "param_groups" carries the hyper-parameters in torch's form for tooling that reads lr / betas from it
+        g = self.param_groups[0]
+        return {"flat_m": self.flat_m.clone(), "flat_v": self.flat_v.clone(), "t": self.t, "lr": g["lr"], "betas": tuple(g["betas"]),
+                "eps": g["eps"], "numel": self.numel,
+                "param_groups": [{k: v for k, v in g.items() if k != "params"} | {"params": list(range(len(self.params)))}]}
 
     def load_state_dict(self, state: dict) -> None:
         if int(state["numel"]) != self.numel:

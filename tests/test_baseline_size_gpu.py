@@ -182,7 +182,7 @@ def test_cfg3_metnet_train_step_fullsize_f32(device):
 
 def test_cfg3_metnet_train_step_fullsize_bf16a(device):
     """The benchmarked mode at the benchmarked size (B=2 of the 8) against the fp32 oracle; observed errors published.
-    Bounds: the small-size calibration of tests/test_bf16a_gpu.py (CPU-autocast yardstick x2, floor 3e-2 / 5e-2)."""
+    Bounds: 1.25x (output) / 1.5x (gradients) the CPU-autocast yardstick, floors 1e-2 / 2e-2."""
     net = _cfg3_model()
     P = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype == torch.float32 and "running" not in k}
     x, cot = _cfg3_inputs()
@@ -217,9 +217,11 @@ def test_cfg3_metnet_train_step_fullsize_bf16a(device):
            "grad_rel_l2": ours, "cpu_autocast_grad_rel_l2": yard}
     publish(rec)
     assert out.dtype == torch.float32 and torch.isfinite(out).all()
-    assert rec["out_rel_l2"] < max(2 * rec["cpu_autocast_out_rel_l2"], 3e-2), rec
+    # observed (profiles/r02_parity_observed.jsonl): the large encoder gradients sit at 0.96-1.09x the yardstick, the worst small one
+    # (a 3 % bias gradient) at 1.27x, the output at 0.4x - the bound leaves that spread and nothing like a factor of two
+    assert rec["out_rel_l2"] < max(1.25 * rec["cpu_autocast_out_rel_l2"], 1e-2), rec
     for k in ours:
-        assert ours[k] < max(2 * yard[k], 5e-2), (k, ours[k], yard[k])
+        assert ours[k] < max(1.5 * yard[k], 2e-2), (k, ours[k], yard[k])
 
 
 # ------------------------------------------------------------------------------------------------------------------

@@ -82,6 +82,30 @@ def test_folded_forward_matches_float64_of_its_operands(device, n, groups, cin, 
         assert rel_l2(s[..., 1], (y[..., :cout].double() ** 2).sum((1, 2))) < 1e-5
 
 
+def test_folded_forward_with_vanishing_gamma(device):
+    """A pruned / decayed BatchNorm channel: gamma * rstd tiny but nonzero.  shift / scale overflows while bf16(w * scale) flushes to
+    zero - the table must take the exact w * shift branch (inf * 0 would put NaN into every pixel of the group) and agree with the
+    unfolded BatchNorm -> convolution."""
+    n, groups, cin, cout, H, W = 4, 2, 32, 64, 12, 12
+    F, x, bn, conv, eng = _setup(device, n, groups, cin, cout, H, W)
+    with torch.no_grad():
+        bn.weight[3] = 1e-30
+        bn.weight[7] = 0.0
+        bn.weight[11] = -1e-38
+        bn.bias[3], bn.bias[7], bn.bias[11] = 0.7, -0.4, 1.3
+    bn.train()
+    y, _ = F.batchnorm_conv3x3(x, bn, groups, None, eng, conv.weight, conv.bias, out_dtype=torch.float32, want_stats=False)
+    assert torch.isfinite(y).all()
+    a, b = _ref_stats(x, bn, groups)
+    ipg = n // groups
+    for g in range(groups):
+        xs = x[g * ipg:(g + 1) * ipg].double().permute(0, 3, 1, 2)
+        xn = xs * a[g].view(1, -1, 1, 1) + b[g].view(1, -1, 1, 1)
+        ref = torch.nn.functional.conv2d(xn, conv.weight.double(), conv.bias.double(), padding=1)
+        got = y[g * ipg:(g + 1) * ipg, ..., :cout].permute(0, 3, 1, 2).double()
+        assert rel_l2(got, ref) < 2e-2, f"group {g}: rel L2 {rel_l2(got, ref):.3e}"  # bf16 operands vs float64
+
+
 @pytest.mark.parametrize("n,groups,cin,cout,H,W", [
     (6, 3, 32, 64, 20, 20),
     (12, 3, 160, 256, 32, 32),   # slices cross group boundaries (two segments per slice)

@@ -137,3 +137,72 @@ def test_persistent_backward_matches_per_step_kernels(device, bf16_mode, Tn, n, 
         for t in range(Tn - 1, -1, -1):  # report the first step (from the end) that differs
             assert torch.equal(a[t], b[t]), f"{name}[{t}] differs: max {float((a[t].float() - b[t].float()).abs().max()):.3e}"
     assert float(dgx.float().abs().max()) > 1e-3
+
+
+class _RoundOperand(torch.autograd.Function):
+    """bf16 rounding of a convolution operand with a straight-through gradient that is ALSO rounded to bf16 where the kernels round
+    it: the cotangent of a convolution input is formed from bf16(dout) x bf16(W), which the oracle's conv backward reproduces by
+    itself once its operands are rounded - so the pass-through here is the identity."""
+
+    @staticmethod
+    def forward(ctx, t):
+        return t.bfloat16().float()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+@pytest.mark.parametrize("mode", ["bf16", "bf16a"])
+@pytest.mark.parametrize("B,T,cin,hid,h,w", [(3, 6, 32, 64, 16, 16), (2, 5, 16, 32, 12, 10)])
+def test_persistent_sequence_kernels_against_oracle(device, mode, B, T, cin, hid, h, w):
+    """DIRECT oracle check of sf_convgru_seq_fwd / sf_convgru_seq_bwd (not via the per-step kernels): the ConvGRU module in the
+    bf16 modes against oracle.metnet.convgru whose convolution operands (inputs, states, weights) are rounded to bf16 - everything
+    else fp32 on both sides.  "bf16": persistent forward, per-step backward; "bf16a": both persistent, x-part / gates / gate
+    gradients stored as bf16 (an extra 2^-9 relative rounding per stored value, hence the looser bounds)."""
+    from conftest import rel_l2
+    from oracle import metnet as M
+    from satflow_amd import functional as F
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import cpad
+    from satflow_amd.models.metnet import ConvGRU
+
+    torch.manual_seed(11)
+    rnn = ConvGRU(cin, hid, (3, 3), 1).eval()
+    with torch.no_grad():  # hot weights: gates leave the linear regime, the carried state matters
+        for p_ in rnn.parameters():
+            if p_.dim() > 1:
+                p_.mul_(3.0)
+            else:
+                p_.copy_(torch.randn(p_.shape) * 0.3)
+    P = {f"rnn.{k}": v.detach().clone().requires_grad_() for k, v in rnn.state_dict().items()}
+    x = torch.randn(B, T, cin, h, w, generator=torch.Generator().manual_seed(2))
+    cot_seq = torch.randn(B, T, hid, h, w, generator=torch.Generator().manual_seed(3))
+    cot_last = torch.randn(B, hid, h, w, generator=torch.Generator().manual_seed(4))
+    xr = x.clone().requires_grad_()
+    ref_seq, ref_last = M.convgru(xr, P, "rnn", 1, operand=_RoundOperand.apply)
+    ((ref_seq * cot_seq).sum() + (ref_last[-1] * cot_last).sum()).backward()
+
+    rnn = rnn.to(device)
+    satflow_amd.set_compute_dtype(mode)
+    try:
+        assert K.convgru_seq_supported(h, w, cpad(hid))
+        xd = x.to(device).requires_grad_()
+        xs = F._ToNHWC.apply(xd, B, T, cin, h, w, (T * cin * h * w, cin * h * w, h * w))
+        seq, last = rnn.run(xs, T, B)
+        out_seq = F._FromNHWC.apply(seq, (B, T, hid, h, w), B, T, hid, h, w, (T * hid * h * w, hid * h * w, h * w))
+        out_last = F.nhwc_to_nchw(last[-1], hid)
+        ((out_seq * cot_seq.to(device)).sum() + (out_last * cot_last.to(device)).sum()).backward()
+    finally:
+        satflow_amd.set_compute_dtype("f32")
+    tight = mode == "bf16"
+    e_seq, e_last = rel_l2(out_seq, ref_seq), rel_l2(out_last, ref_last[-1])
+    print(f"   {mode}: states rel L2 {e_seq:.2e}, last {e_last:.2e}")
+    assert e_seq < (2e-4 if tight else 4e-3) and e_last < (2e-4 if tight else 4e-3), (e_seq, e_last)
+    e_dx = rel_l2(xd.grad, xr.grad)
+    print(f"   {mode}: dx rel L2 {e_dx:.2e}")
+    assert e_dx < (6e-3 if tight else 1.5e-2), e_dx
+    for k, p_ in rnn.named_parameters():
+        e = rel_l2(p_.grad, P[f"rnn.{k}"].grad)
+        print(f"   {mode}: d{k} rel L2 {e:.2e}")
+        assert e < (6e-3 if tight else 1.5e-2), (k, e)
