@@ -443,6 +443,77 @@ int sf_l1_loss(sfTensor pred, sfTensor target, int64_t rows, int32_t groups, int
 int sf_bce_logits_loss(sfTensor logits, float label, float label_odd, int64_t rows, int32_t groups, int32_t c, sfTensor grad,
                        double* sums, float* out, sfStream stream); /* label for even groups, label_odd for odd ones */
 
+/* ---------------------------------------------------------------------------------------------
+ * In-tree DGMR / DVD-GAN style networks: satflow/models/layers/{Normalization,GResBlock,Discriminator,Generator}.py.
+ * Their convolutions run on sf_conv3x3_* (3x3; a Conv3d(3,3,3) as one 3x3 convolution over the channel stack of its three
+ * temporal taps), sf_conv2d_* (5x5) and sf_linear_* (1x1); the entries below are everything else.  fp32, NHWC, 16-byte pixels.
+ * ------------------------------------------------------------------------------------------- */
+/* SpectralNorm._update_u_v (Normalization.py:19-31): `power_iterations` rounds of v = l2n(W^T u), u = l2n(W v) on the
+ * [height][width] view of w_bar (u [height], v [width] are UPDATED IN PLACE - the module's persistent state), then
+ * sigma = u . (W v) and w_out = w_bar / sigma.  workspace: width + height floats. */
+int sf_spectral_norm_fwd(const float* w_bar, int32_t height, int32_t width, float* u, float* v, int32_t power_iterations,
+                         float* w_out, float* sigma, float* workspace, sfStream stream);
+/* Its backward (u, v constants as in the reference, which iterates on .data): dw_bar = g / sigma - (<g, w_bar> / sigma^2) u v^T.
+ * u, v, sigma as left by the forward call.  workspace: 512 floats. */
+int sf_spectral_norm_bwd(const float* g, const float* w_bar, const float* u, const float* v, const float* sigma, int32_t height,
+                         int32_t width, float* dw_bar, float* workspace, sfStream stream);
+/* y [n_out][oh][ow] = scale * (sum over the 2x2 window, and over tpool consecutive frames) of x + addend (nullable).
+ * Frames are time-major: image o = k * nb + b reads images (tpool * k + f) * nb + b.  F.avg_pool2d(x, 2) = (tpool 1, scale 1/4),
+ * F.avg_pool3d(x, 2) = (tpool 2, scale 1/8) (GResBlock.py:81-82,89-90; Discriminator.py:214-215,267-268,382-383,438-439);
+ * with scale 1 the backward pass of the nearest up-sampling.  `addend` fuses the residual sum (GResBlock.py:94). */
+int sf_pool2(sfTensor x, int64_t n_out, int32_t oh, int32_t ow, int32_t tpool, int32_t nb, float scale, sfTensor addend, sfTensor y,
+             sfStream stream);
+/* y [n_in * texp][2h][2w] = scale * x (nearest neighbour; texp 2 also repeats every frame twice): F.interpolate(scale_factor=2)
+ * (GResBlock.py:69-70,86-87) with scale 1; the backward pass of the average poolings with scale 1/4, 1/8. */
+int sf_expand2(sfTensor x, int64_t n_in, int32_t h, int32_t w, int32_t texp, int32_t nb, float scale, sfTensor y, sfStream stream);
+/* The three temporal taps of nn.Conv3d(k=3, padding=1) (Discriminator.py:345-356,405-410) as channels:
+ * y[t][p][dt * C + c] = x[t + dt - 1][p][c] (zero outside the clip), time-major dense x [T][pixels_per_frame][C]; and its adjoint. */
+int sf_time_stack3_fwd(sfTensor x, int32_t T, int64_t pixels_per_frame, sfTensor y, sfStream stream);
+int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTensor gx, sfStream stream);
+/* ConditionalNorm (Normalization.py:76-85) behind its statistics, fused with what follows it in GResBlock.forward (:63-70,75-78):
+ * y = act(gamma[img][c] * (x - mean[c]) * rstd[c] + beta[img][c]), embed [n][2 * creal] = gamma | beta (the Linear's output),
+ * relu: F.relu, up: nearest x2 up-sampling of the result (y [n][2h][2w]).  mean / rstd: sf_batchnorm_train_fwd without affine. */
+int sf_film_act_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, const float* mean, const float* rstd, const float* embed,
+                    int32_t creal, int32_t relu, int32_t up, sfTensor y, sfStream stream);
+/* Backward: dxhat = d(normalised x) (then through sf_batchnorm_train_bwd), dembed [n][2 * creal] = d(gamma | beta).
+ * workspace: sf_film_act_bwd_workspace_floats() floats. */
+size_t sf_film_act_bwd_workspace_floats(int64_t n, int32_t h, int32_t w, int32_t c, int32_t creal);
+int sf_film_act_bwd(sfTensor gy, sfTensor x, int64_t n, int32_t h, int32_t w, const float* mean, const float* rstd,
+                    const float* embed, int32_t creal, int32_t relu, int32_t up, sfTensor dxhat, float* dembed, float* workspace,
+                    sfStream stream);
+/* out[img][c] = sum over the image's pixels of relu(x) (Discriminator.py:286-293,452-459) and its backward. */
+int sf_relu_sum_pixels_fwd(sfTensor x, int64_t n, int64_t pixels, float* out, sfStream stream);
+int sf_relu_sum_pixels_bwd(const float* g, sfTensor x, int64_t n, int64_t pixels, sfTensor gx, sfStream stream);
+/* y = a * o + x over n floats, a = *gamma_dev (a device scalar: SelfAttention.gamma, Discriminator.py:125, Attention.py:108) or
+ * `alpha` when gamma_dev is NULL; x nullable.  sf_dot: out[0] = <a, b> (gamma's gradient); workspace 512 floats. */
+int sf_axpy(const float* o, const float* x, const float* gamma_dev, float alpha, int64_t n, float* y, sfStream stream);
+int sf_dot(const float* a, const float* b, int64_t n, float* out, float* workspace, sfStream stream);
+/* out = tanh(x) (Generator.py:126); with y_for_backward: out = x * (1 - y^2). */
+int sf_tanh(const float* x, const float* y_for_backward, int64_t n, float* out, sfStream stream);
+/* Gate arithmetic of the generator's ConvGRU (the module reference Generator.py:5 imports; restated in oracle/dgmr.py):
+ *   gates: zr = [sig(gx_z + gh_z) | sig(gx_r + gh_r)], rh = r * h     (gx, gh: [.., 2*hidp], gh / h nullable = zeros)
+ *   out:   cand = tanh(gx_o + gh_o), h_new = h (1 - z) + cand z
+ * and their backward passes (dpre: gradient wrt the z | r pre-activations; da: wrt the candidate's pre-activation). */
+int sf_dvdgru_gates_fwd(sfTensor gx, sfTensor gh, sfTensor h, int64_t pixels, int32_t hidp, sfTensor zr, sfTensor rh, sfStream stream);
+int sf_dvdgru_gates_bwd(sfTensor dz, sfTensor drh, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor dpre, sfTensor dh,
+                        sfStream stream);
+int sf_dvdgru_out_fwd(sfTensor gx, sfTensor gh, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor cand, sfTensor h_new,
+                      sfStream stream);
+int sf_dvdgru_out_bwd(sfTensor dh_new, sfTensor cand, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor da, sfTensor dz,
+                      sfTensor dh, sfStream stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * torch.bmm / softmax(dim=-1) of the in-tree attention layers (Discriminator.py:104-126; Attention.py:23-223) on exact-fp32 MFMA:
+ * C[b][m][n] = alpha * sum_k A[b][m][k] B[b][k][n] + beta * C[b][m][n], every operand an arbitrary strided view (element strides),
+ * because the reference multiplies `.view()` / `.permute()` windows of its tensors.  Softmax over contiguous rows of length L
+ * (y may alias x; dx may alias g): dx = y * (g - <g, y>).
+ * ------------------------------------------------------------------------------------------- */
+int sf_bmm_f32(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
+               int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta,
+               sfStream stream);
+int sf_softmax_rows_fwd(const float* x, int64_t rows, int32_t L, float* y, sfStream stream);
+int sf_softmax_rows_bwd(const float* g, const float* y, int64_t rows, int32_t L, float* dx, sfStream stream);
+
 #ifdef __cplusplus
 }
 #endif

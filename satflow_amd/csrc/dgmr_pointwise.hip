@@ -1,0 +1,640 @@
+// HBM-bound stages of the in-tree DGMR / DVD-GAN style networks: everything of
+//   satflow/models/layers/Normalization.py (SpectralNorm :10-62, ConditionalNorm :65-85),
+//   satflow/models/layers/GResBlock.py:55-99, satflow/models/layers/Discriminator.py:200-314 / :368-478,
+//   satflow/models/layers/Generator.py:75-131
+// that is not a convolution (those run on the MFMA kernels: sf_conv3x3_*, sf_conv2d_*, sf_linear_*):
+//   spectral normalisation (power iteration, sigma, W / sigma and its backward), 2x2 (x2 frames) sum pooling and nearest expansion
+//   with a scale (avg_pool2d / avg_pool3d / F.interpolate and their backward passes), the three temporal taps of a Conv3d as a
+//   channel stack, conditional BatchNorm -> ReLU -> up-sampling in one pass, ReLU + sum over pixels (discriminator head),
+//   gamma * attention + x, tanh, and the gate arithmetic of the generator's ConvGRU.
+// All activations NHWC fp32 with 16-byte channel quads.
+#include "sf_common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+#define kZero4 (f32x4{0.f, 0.f, 0.f, 0.f})
+
+inline int grid_of(long long work, int cap = 16384) {
+  long long b = (work + 255) / 256;
+  return (int)(b < 1 ? 1 : (b > cap ? cap : b));
+}
+inline bool okd(const sfTensor& t, int lanes) {  // dense fp32 tensor of `lanes` channels, 16-byte aligned pixels
+  return t.ptr && t.dtype == SF_F32 && ((uintptr_t)t.ptr & 15) == 0 && t.c == lanes && t.stride == lanes && lanes % 4 == 0;
+}
+inline bool oks(const sfTensor& t, int lanes) {  // strided view: at least `lanes` channels
+  return t.ptr && t.dtype == SF_F32 && ((uintptr_t)t.ptr & 15) == 0 && t.c >= lanes && t.stride >= t.c && t.stride % 4 == 0 && lanes % 4 == 0;
+}
+
+__device__ __forceinline__ float block_sum(float v, float* red) {  // 256 threads; result in every thread
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_down(v, o);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  const float s = (red[0] + red[1]) + (red[2] + red[3]);
+  __syncthreads();
+  return s;
+}
+
+// ---- spectral normalisation (Normalization.py:19-31) ------------------------------------------------------------------
+// vraw[j] = sum_i W[i][j] u[i]
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, int h, int w, const float* __restrict__ u, float* __restrict__ vraw) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= w) return;
+  float s = 0.f;
+  for (int i = 0; i < h; ++i) s = __builtin_fmaf(W[(size_t)i * w + j], u[i], s);
+  vraw[j] = s;
+}
+// v = vraw / (|vraw| + eps) (block 0 stores it);  uraw[i] = sum_j W[i][j] v[j]   - one workgroup per row
+__global__ __launch_bounds__(256) void sn_w_v_kernel(const float* __restrict__ W, int h, int w, const float* __restrict__ vraw, float* __restrict__ v,
+                                                     float* __restrict__ uraw) {
+  __shared__ float red[4];
+  float q = 0.f;
+  for (int j = threadIdx.x; j < w; j += 256) q = __builtin_fmaf(vraw[j], vraw[j], q);
+  const float den = sqrtf(block_sum(q, red)) + 1e-12f;
+  const int i = blockIdx.x;
+  float s = 0.f;
+  for (int j = threadIdx.x; j < w; j += 256) {
+    const float vj = vraw[j] / den;
+    if (i == 0) v[j] = vj;
+    s = __builtin_fmaf(W[(size_t)i * w + j], vj, s);
+  }
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) uraw[i] = s;
+}
+// u = uraw / (|uraw| + eps) (in place into the caller's u; only between power iterations)
+__global__ __launch_bounds__(256) void sn_norm_u_kernel(const float* __restrict__ uraw, int h, float* __restrict__ u) {
+  __shared__ float red[4];
+  float q = 0.f;
+  for (int i = threadIdx.x; i < h; i += 256) q = __builtin_fmaf(uraw[i], uraw[i], q);
+  const float den = sqrtf(block_sum(q, red)) + 1e-12f;
+  for (int i = threadIdx.x; i < h; i += 256) u[i] = uraw[i] / den;
+}
+// u = uraw / (|uraw| + eps), sigma = u . uraw ( = u . (W v) ), Wout = W / sigma
+__global__ __launch_bounds__(256) void sn_finish_kernel(const float* __restrict__ W, int h, int w, const float* __restrict__ uraw, float* __restrict__ u,
+                                                        float* __restrict__ sigma_out, float* __restrict__ Wout) {
+  __shared__ float red[4];
+  float q = 0.f;
+  for (int i = threadIdx.x; i < h; i += 256) q = __builtin_fmaf(uraw[i], uraw[i], q);
+  const float den = sqrtf(block_sum(q, red)) + 1e-12f;
+  float d = 0.f;
+  for (int i = threadIdx.x; i < h; i += 256) {
+    const float ui = uraw[i] / den;
+    if (blockIdx.x == 0) u[i] = ui;
+    d = __builtin_fmaf(ui, uraw[i], d);
+  }
+  const float sigma = block_sum(d, red);
+  if (blockIdx.x == 0 && threadIdx.x == 0) *sigma_out = sigma;
+  const long long n = (long long)h * w;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) Wout[e] = W[e] / sigma;
+}
+__global__ __launch_bounds__(256) void dot_partial_kernel(const float* __restrict__ a, const float* __restrict__ b, long long n, float* __restrict__ partial) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) s = __builtin_fmaf(a[e], b[e], s);
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) partial[blockIdx.x] = s;
+}
+// dWbar = g / sigma - (<g, Wbar> / sigma^2) u v^T
+__global__ __launch_bounds__(256) void sn_bwd_kernel(const float* __restrict__ g, const float* __restrict__ u, const float* __restrict__ v,
+                                                     const float* __restrict__ sigma, const float* __restrict__ partial, int nparts, int h, int w,
+                                                     float* __restrict__ dW) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+  const float dot = block_sum(s, red);
+  const float sg = *sigma;
+  const float c = dot / (sg * sg);
+  const long long n = (long long)h * w;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < n; e += (long long)gridDim.x * 256) {
+    const int i = (int)(e / w), j = (int)(e - (long long)i * w);
+    dW[e] = g[e] / sg - c * u[i] * v[j];
+  }
+}
+
+// ---- 2x2 (x tp frames) sum pooling / nearest expansion ---------------------------------------------------------------
+// y[o][yy][xx] = scale * sum over the 2x2 window (and tp frames) of x + addend;  image o = k * nb + b reads frames tp*k .. tp*k + tp-1
+__global__ __launch_bounds__(256) void pool2_kernel(const float* __restrict__ x, int xs, long long n_out, int oh, int ow, int tp, int nb, float scale,
+                                                    const float* __restrict__ add, int as, float* __restrict__ y, int ys, int q) {
+  const long long total = n_out * oh * ow * q;
+  const int h = oh * 2, w = ow * 2;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int xx = (int)(r % ow); r /= ow;
+    const int yy = (int)(r % oh); const long long o = r / oh;
+    const long long k = o / nb, b = o - k * nb;
+    f32x4 s = kZero4;
+    for (int f = 0; f < tp; ++f) {
+      const float* base = x + ((((k * tp + f) * nb + b) * h + 2 * yy) * (long long)w + 2 * xx) * xs + c;
+      s += (ld4(base) + ld4(base + xs)) + (ld4(base + (long long)w * xs) + ld4(base + (long long)w * xs + xs));
+    }
+    s *= scale;
+    const long long pix = (o * oh + yy) * ow + xx;
+    if (add) s += ld4(add + pix * as + c);
+    st4(y + pix * ys + c, s);
+  }
+}
+// y[image][2 yy + a][2 xx + b] = scale * x[image'][yy][xx], every output element once
+__global__ __launch_bounds__(256) void expand2_kernel(const float* __restrict__ x, int xs, long long n_in, int h, int w, int tp, int nb, float scale,
+                                                      float* __restrict__ y, int ys, int q) {
+  const int oh = 2 * h, ow = 2 * w;
+  const long long total = n_in * tp * oh * ow * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int ox = (int)(r % ow); r /= ow;
+    const int oy = (int)(r % oh); const long long o = r / oh;  // output image = (k * tp + f) * nb + b
+    const long long kf = o / nb, b = o - kf * nb, k = kf / tp;
+    const f32x4 v = ld4(x + (((k * nb + b) * h + (oy >> 1)) * (long long)w + (ox >> 1)) * xs + c) * scale;
+    st4(y + ((o * oh + oy) * ow + ox) * ys + c, v);
+  }
+}
+
+// ---- Conv3d temporal taps as a channel stack -------------------------------------------------------------------------
+// y[t][b][p][dt * C + c] = x[t + dt - 1][b][p][c] (zero outside 0 <= t + dt - 1 < T);  per = nb * pixels per image
+__global__ __launch_bounds__(256) void tstack3_fwd_kernel(const float* __restrict__ x, int T, long long per, int q, float* __restrict__ y) {
+  const long long total = (long long)T * per * 3 * q;
+  const int C = q * 4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int dt = (int)(r % 3); r /= 3;
+    const long long p = r % per; const int t = (int)(r / per);
+    const int ts = t + dt - 1;
+    const f32x4 v = (ts >= 0 && ts < T) ? ld4(x + ((long long)ts * per + p) * C + c) : kZero4;
+    st4(y + ((long long)t * per + p) * 3 * C + dt * C + c, v);
+  }
+}
+// gx[t][..][c] = gy[t + 1][..][c] + gy[t][..][C + c] + gy[t - 1][..][2 C + c]
+__global__ __launch_bounds__(256) void tstack3_bwd_kernel(const float* __restrict__ gy, int T, long long per, int q, float* __restrict__ gx) {
+  const long long total = (long long)T * per * q;
+  const int C = q * 4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    const long long r = idx / q;
+    const long long p = r % per; const int t = (int)(r / per);
+    f32x4 s = ld4(gy + ((long long)t * per + p) * 3 * C + C + c);
+    if (t + 1 < T) s += ld4(gy + ((long long)(t + 1) * per + p) * 3 * C + c);
+    if (t >= 1) s += ld4(gy + ((long long)(t - 1) * per + p) * 3 * C + 2 * C + c);
+    st4(gx + r * C + c, s);
+  }
+}
+
+// ---- conditional BatchNorm (+ ReLU, + nearest x2) --------------------------------------------------------------------
+// y = act(gamma[n][c] * (x - mean[c]) * rstd[c] + beta[n][c]), stored once or to the 2x2 block of the up-sampled map
+__global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ x, long long n, int h, int w, int q, const float* __restrict__ mean,
+                                                       const float* __restrict__ rstd, const float* __restrict__ embed, int creal, int relu, int up,
+                                                       float* __restrict__ y) {
+  const long long total = n * h * w * q;
+  const int C = q * 4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int xx = (int)(r % w); r /= w;
+    const int yy = (int)(r % h); const long long img = r / h;
+    const f32x4 v = ld4(x + idx * 4);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cj = c + j;
+      float z = 0.f;
+      if (cj < creal) {
+        const float xh = (v[j] - mean[cj]) * rstd[cj];
+        z = embed[img * 2 * creal + cj] * xh + embed[img * 2 * creal + creal + cj];
+        if (relu) z = fmaxf(z, 0.f);
+      }
+      o[j] = z;
+    }
+    if (!up) st4(y + idx * 4, o);
+    else {
+      float* d = y + (((img * 2 * h + 2 * yy) * (long long)(2 * w)) + 2 * xx) * C + c;
+      st4(d, o); st4(d + C, o); st4(d + (long long)2 * w * C, o); st4(d + (long long)2 * w * C + C, o);
+    }
+  }
+}
+// dz = mask * (gy, summed over the 2x2 block when up);  dxhat = dz * gamma;  per (image, channel): dgamma = sum dz * xhat, dbeta = sum dz
+// grid (slices, n, ceil(q / 16)); thread = (pixel lane 0..15, channel quad 0..15)
+__global__ __launch_bounds__(256) void film_bwd_kernel(const float* __restrict__ gy, const float* __restrict__ x, int h, int w, int q,
+                                                       const float* __restrict__ mean, const float* __restrict__ rstd, const float* __restrict__ embed,
+                                                       int creal, int relu, int up, float* __restrict__ dxhat, float* __restrict__ partial) {
+  __shared__ float red[2][16][16][4];
+  const int C = q * 4;
+  const int ql = threadIdx.x & 15, pl = threadIdx.x >> 4;
+  const int qq = blockIdx.z * 16 + ql;
+  const long long img = blockIdx.y;
+  const int slices = gridDim.x, sl = blockIdx.x;
+  const long long pixels = (long long)h * w;
+  const long long per = (pixels + slices - 1) / slices, p0 = sl * per, p1 = p0 + per < pixels ? p0 + per : pixels;
+  f32x4 ag = kZero4, ab = kZero4;
+  if (qq < q) {
+    const int c = qq * 4;
+    float gm[4], bt[4], mu[4], rs[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int cj = c + j;
+      const bool live = cj < creal;
+      gm[j] = live ? embed[img * 2 * creal + cj] : 0.f; bt[j] = live ? embed[img * 2 * creal + creal + cj] : 0.f;
+      mu[j] = live ? mean[cj] : 0.f; rs[j] = live ? rstd[cj] : 0.f;
+    }
+    for (long long p = p0 + pl; p < p1; p += 16) {
+      const long long e = (img * pixels + p) * C + c;
+      const f32x4 v = ld4(x + e);
+      f32x4 g;
+      if (!up) g = ld4(gy + e);
+      else {
+        const int yy = (int)(p / w), xx = (int)(p - (long long)yy * w);
+        const float* s = gy + (((img * 2 * h + 2 * yy) * (long long)(2 * w)) + 2 * xx) * C + c;
+        g = (ld4(s) + ld4(s + C)) + (ld4(s + (long long)2 * w * C) + ld4(s + (long long)2 * w * C + C));
+      }
+      f32x4 d;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float xh = (v[j] - mu[j]) * rs[j];
+        const float z = gm[j] * xh + bt[j];
+        const float dz = (c + j < creal && (!relu || z > 0.f)) ? g[j] : 0.f;
+        ag[j] = __builtin_fmaf(dz, xh, ag[j]); ab[j] += dz;
+        d[j] = dz * gm[j];
+      }
+      st4(dxhat + e, d);
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) { red[0][pl][ql][j] = ag[j]; red[1][pl][ql][j] = ab[j]; }
+  __syncthreads();
+  if (threadIdx.x < 128) {  // (which, quad, j): sum the 16 pixel lanes
+    const int which = threadIdx.x >> 6, ql2 = (threadIdx.x >> 2) & 15, j = threadIdx.x & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[which][k][ql2][j];
+    const int cj = (blockIdx.z * 16 + ql2) * 4 + j;
+    if (cj < creal) partial[((long long)sl * gridDim.y + img) * 2 * creal + which * creal + cj] = s;
+  }
+}
+__global__ void sum_slices_kernel(const float* __restrict__ partial, int slices, long long n, float* __restrict__ out) {
+  const long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (e >= n) return;
+  float s = 0.f;
+  for (int k = 0; k < slices; ++k) s += partial[(long long)k * n + e];
+  out[e] = s;
+}
+
+// ---- ReLU + sum over the pixels of an image (discriminator head, Discriminator.py:286-293) -----------------------------
+// grid (n, ceil(q / 16)); thread = (pixel lane, channel quad)
+__global__ __launch_bounds__(256) void relu_sum_fwd_kernel(const float* __restrict__ x, long long pixels, int q, float* __restrict__ out) {
+  __shared__ float red[16][16][4];
+  const int C = q * 4, ql = threadIdx.x & 15, pl = threadIdx.x >> 4, qq = blockIdx.y * 16 + ql;
+  const long long img = blockIdx.x;
+  f32x4 a = kZero4;
+  if (qq < q)
+    for (long long p = pl; p < pixels; p += 16) {
+      const f32x4 v = ld4(x + (img * pixels + p) * C + qq * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) a[j] += fmaxf(v[j], 0.f);
+    }
+#pragma unroll
+  for (int j = 0; j < 4; ++j) red[pl][ql][j] = a[j];
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int ql2 = threadIdx.x >> 2, j = threadIdx.x & 3;
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 16; ++k) s += red[k][ql2][j];
+    const int cj = (blockIdx.y * 16 + ql2) * 4 + j;
+    if (cj < C) out[img * C + cj] = s;
+  }
+}
+__global__ __launch_bounds__(256) void relu_sum_bwd_kernel(const float* __restrict__ g, const float* __restrict__ x, long long n, long long pixels, int q,
+                                                           float* __restrict__ gx) {
+  const long long total = n * pixels * q;
+  const int C = q * 4;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    const long long img = idx / q / pixels;
+    const f32x4 v = ld4(x + idx * 4), gv = ld4(g + img * C + c);
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = v[j] > 0.f ? gv[j] : 0.f;
+    st4(gx + idx * 4, o);
+  }
+}
+
+// ---- y = gamma * o + x (SelfAttention residual, Discriminator.py:125) and plain sums ----------------------------------
+__global__ __launch_bounds__(256) void axpy_kernel(const float* __restrict__ o, const float* __restrict__ x, const float* __restrict__ gamma, float alpha,
+                                                   long long n4, float* __restrict__ y) {
+  const float g = gamma ? *gamma : alpha;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
+    f32x4 v = ld4(o + idx * 4) * g;
+    if (x) v += ld4(x + idx * 4);
+    st4(y + idx * 4, v);
+  }
+}
+__global__ __launch_bounds__(256) void sum_final_kernel(const float* __restrict__ partial, int nparts, float* __restrict__ out) {
+  __shared__ float red[4];
+  float s = 0.f;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += partial[i];
+  s = block_sum(s, red);
+  if (threadIdx.x == 0) *out = s;
+}
+
+// ---- tanh -------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tanh_kernel(const float* __restrict__ x, const float* __restrict__ yref, long long n4, float* __restrict__ out) {
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < n4; idx += (long long)gridDim.x * 256) {
+    const f32x4 v = ld4(x + idx * 4);
+    f32x4 o;
+    if (!yref) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = sf_tanh(v[j]);
+    } else {  // backward: x = dy, yref = y
+      const f32x4 yv = ld4(yref + idx * 4);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = v[j] * (1.f - yv[j] * yv[j]);
+    }
+    st4(out + idx * 4, o);
+  }
+}
+
+// ---- gate arithmetic of the generator's ConvGRU -----------------------------------------------------------------------
+// gates: z = sig(gx_z + gh_z), r = sig(gx_r + gh_r), rh = r * h      (gx, gh: [.., 2*H] = z | r pre-activation parts)
+__global__ __launch_bounds__(256) void dvdgru_gates_fwd_kernel(const float* __restrict__ gx, int sx, const float* __restrict__ gh, int sh,
+                                                               const float* __restrict__ h, int hs, long long pixels, int H, float* __restrict__ zr,
+                                                               float* __restrict__ rh) {
+  const int q = H >> 2;
+  const long long total = pixels * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx / q;
+    const int c = (int)(idx - pix * q) * 4;
+    f32x4 az = ld4(gx + pix * sx + c), ar = ld4(gx + pix * sx + H + c);
+    if (gh) { az += ld4(gh + pix * sh + c); ar += ld4(gh + pix * sh + H + c); }
+    const f32x4 hv = h ? ld4(h + pix * hs + c) : kZero4;
+    f32x4 z, r, o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { z[j] = sf_sigmoid(az[j]); r[j] = sf_sigmoid(ar[j]); o[j] = r[j] * hv[j]; }
+    st4(zr + pix * 2 * H + c, z); st4(zr + pix * 2 * H + H + c, r);
+    st4(rh + pix * H + c, o);
+  }
+}
+// in: dz (gradient wrt the gate z, nullable), drh (wrt r*h, nullable), saved zr, h  ->  dpre [.., 2H] (z | r pre-activations), dh (+= nothing: written)
+__global__ __launch_bounds__(256) void dvdgru_gates_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ drh, const float* __restrict__ zr,
+                                                               const float* __restrict__ h, int hs, long long pixels, int H, float* __restrict__ dpre,
+                                                               float* __restrict__ dh) {
+  const int q = H >> 2;
+  const long long total = pixels * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx / q;
+    const int c = (int)(idx - pix * q) * 4;
+    const f32x4 z = ld4(zr + pix * 2 * H + c), r = ld4(zr + pix * 2 * H + H + c);
+    const f32x4 gz = dz ? ld4(dz + pix * H + c) : kZero4, gr = drh ? ld4(drh + pix * H + c) : kZero4;
+    const f32x4 hv = h ? ld4(h + pix * hs + c) : kZero4;
+    f32x4 pz, pr, o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      pz[j] = gz[j] * z[j] * (1.f - z[j]);
+      pr[j] = gr[j] * hv[j] * r[j] * (1.f - r[j]);
+      o[j] = gr[j] * r[j];
+    }
+    st4(dpre + pix * 2 * H + c, pz); st4(dpre + pix * 2 * H + H + c, pr);
+    if (dh) st4(dh + pix * H + c, o);
+  }
+}
+// out: n = tanh(gx_o + gh_o), h' = h (1 - z) + n z
+__global__ __launch_bounds__(256) void dvdgru_out_fwd_kernel(const float* __restrict__ gx, int sx, const float* __restrict__ gh, int sh,
+                                                             const float* __restrict__ zr, const float* __restrict__ h, int hs, long long pixels, int H,
+                                                             float* __restrict__ cand, float* __restrict__ hn) {
+  const int q = H >> 2;
+  const long long total = pixels * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx / q;
+    const int c = (int)(idx - pix * q) * 4;
+    f32x4 a = ld4(gx + pix * sx + c);
+    if (gh) a += ld4(gh + pix * sh + c);
+    const f32x4 z = ld4(zr + pix * 2 * H + c);
+    const f32x4 hv = h ? ld4(h + pix * hs + c) : kZero4;
+    f32x4 n, o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { n[j] = sf_tanh(a[j]); o[j] = hv[j] * (1.f - z[j]) + n[j] * z[j]; }
+    if (cand) st4(cand + pix * H + c, n);
+    st4(hn + pix * H + c, o);
+  }
+}
+// in: dh', saved cand, zr, h  ->  da (wrt the candidate's pre-activation), dz (wrt the gate z), dh (direct path dh' (1 - z))
+__global__ __launch_bounds__(256) void dvdgru_out_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ cand, const float* __restrict__ zr,
+                                                             const float* __restrict__ h, int hs, long long pixels, int H, float* __restrict__ da,
+                                                             float* __restrict__ dz, float* __restrict__ dh) {
+  const int q = H >> 2;
+  const long long total = pixels * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx / q;
+    const int c = (int)(idx - pix * q) * 4;
+    const f32x4 g = ld4(dhn + pix * H + c), n = ld4(cand + pix * H + c), z = ld4(zr + pix * 2 * H + c);
+    const f32x4 hv = h ? ld4(h + pix * hs + c) : kZero4;
+    f32x4 a, gz, gh;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      a[j] = g[j] * z[j] * (1.f - n[j] * n[j]);
+      gz[j] = g[j] * (n[j] - hv[j]);
+      gh[j] = g[j] * (1.f - z[j]);
+    }
+    st4(da + pix * H + c, a); st4(dz + pix * H + c, gz);
+    if (dh) st4(dh + pix * H + c, gh);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int sf_spectral_norm_fwd(const float* w_bar, int32_t height, int32_t width, float* u, float* v, int32_t power_iterations, float* w_out, float* sigma,
+                         float* workspace, sfStream stream) {
+  SF_REQUIRE(w_bar && u && v && w_out && sigma && workspace && height >= 1 && width >= 1 && power_iterations >= 1,
+             "sf_spectral_norm_fwd: null pointer or empty matrix (%d x %d, %d iterations)", height, width, power_iterations);
+  hipStream_t st = (hipStream_t)stream;
+  float* vraw = workspace;
+  float* uraw = workspace + width;
+  for (int it = 0; it < power_iterations; ++it) {
+    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((width + 255) / 256), dim3(256), 0, st, w_bar, height, width, (const float*)u, vraw);
+    hipLaunchKernelGGL(sn_w_v_kernel, dim3(height), dim3(256), 0, st, w_bar, height, width, (const float*)vraw, v, uraw);
+    if (it + 1 < power_iterations) hipLaunchKernelGGL(sn_norm_u_kernel, dim3(1), dim3(256), 0, st, (const float*)uraw, height, u);
+  }
+  hipLaunchKernelGGL(sn_finish_kernel, dim3(grid_of((long long)height * width, 1024)), dim3(256), 0, st, w_bar, height, width, (const float*)uraw, u, sigma, w_out);
+  SF_CHECK_LAUNCH("spectral_norm_fwd");
+  return 0;
+}
+
+int sf_spectral_norm_bwd(const float* g, const float* w_bar, const float* u, const float* v, const float* sigma, int32_t height, int32_t width,
+                         float* dw_bar, float* workspace, sfStream stream) {
+  SF_REQUIRE(g && w_bar && u && v && sigma && dw_bar && workspace && height >= 1 && width >= 1, "sf_spectral_norm_bwd: null pointer or empty matrix");
+  hipStream_t st = (hipStream_t)stream;
+  const long long n = (long long)height * width;
+  const int parts = grid_of(n, 512);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(parts), dim3(256), 0, st, g, w_bar, n, workspace);
+  hipLaunchKernelGGL(sn_bwd_kernel, dim3(grid_of(n, 1024)), dim3(256), 0, st, g, u, v, sigma, (const float*)workspace, parts, height, width, dw_bar);
+  SF_CHECK_LAUNCH("spectral_norm_bwd");
+  return 0;
+}
+
+int sf_pool2(sfTensor x, int64_t n_out, int32_t oh, int32_t ow, int32_t tpool, int32_t nb, float scale, sfTensor addend, sfTensor y, sfStream stream) {
+  SF_REQUIRE(tpool == 1 || tpool == 2, "sf_pool2: tpool %d (1 or 2)", tpool);
+  SF_REQUIRE(oks(x, y.c) && oks(y, y.c) && (!addend.ptr || oks(addend, y.c)) && oh >= 1 && ow >= 1 && nb >= 1 && n_out % nb == 0,
+             "sf_pool2: fp32 NHWC tensors with 16-byte pixels, n_out a multiple of nb");
+  if (n_out <= 0) return 0;
+  const int q = y.c / 4;
+  hipLaunchKernelGGL(pool2_kernel, dim3(grid_of(n_out * oh * ow * q)), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, x.stride, (long long)n_out, oh, ow,
+                     tpool, nb, scale, (const float*)addend.ptr, addend.stride, (float*)y.ptr, y.stride, q);
+  SF_CHECK_LAUNCH("pool2");
+  return 0;
+}
+
+int sf_expand2(sfTensor x, int64_t n_in, int32_t h, int32_t w, int32_t texp, int32_t nb, float scale, sfTensor y, sfStream stream) {
+  SF_REQUIRE(texp == 1 || texp == 2, "sf_expand2: texp %d (1 or 2)", texp);
+  SF_REQUIRE(oks(x, y.c) && oks(y, y.c) && h >= 1 && w >= 1 && nb >= 1 && n_in % nb == 0, "sf_expand2: fp32 NHWC tensors with 16-byte pixels, n_in a multiple of nb");
+  if (n_in <= 0) return 0;
+  const int q = y.c / 4;
+  hipLaunchKernelGGL(expand2_kernel, dim3(grid_of(n_in * texp * 4 * h * w * q)), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, x.stride, (long long)n_in, h, w,
+                     texp, nb, scale, (float*)y.ptr, y.stride, q);
+  SF_CHECK_LAUNCH("expand2");
+  return 0;
+}
+
+int sf_time_stack3_fwd(sfTensor x, int32_t T, int64_t pixels_per_frame, sfTensor y, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(y, 3 * x.c) && T >= 1, "sf_time_stack3_fwd: dense fp32 x [T][per][C], y [T][per][3C]");
+  if (pixels_per_frame <= 0) return 0;
+  hipLaunchKernelGGL(tstack3_fwd_kernel, dim3(grid_of((long long)T * pixels_per_frame * 3 * (x.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, T,
+                     (long long)pixels_per_frame, x.c / 4, (float*)y.ptr);
+  SF_CHECK_LAUNCH("time_stack3_fwd");
+  return 0;
+}
+
+int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTensor gx, sfStream stream) {
+  SF_REQUIRE(gx.ptr && okd(gx, gx.c) && okd(gy, 3 * gx.c) && T >= 1, "sf_time_stack3_bwd: dense fp32 gy [T][per][3C], gx [T][per][C]");
+  if (pixels_per_frame <= 0) return 0;
+  hipLaunchKernelGGL(tstack3_bwd_kernel, dim3(grid_of((long long)T * pixels_per_frame * (gx.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gy.ptr, T,
+                     (long long)pixels_per_frame, gx.c / 4, (float*)gx.ptr);
+  SF_CHECK_LAUNCH("time_stack3_bwd");
+  return 0;
+}
+
+int sf_film_act_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, const float* mean, const float* rstd, const float* embed, int32_t creal, int32_t relu,
+                    int32_t up, sfTensor y, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(y, x.c) && mean && rstd && embed && creal >= 1 && creal <= x.c && h >= 1 && w >= 1,
+             "sf_film_act_fwd: dense fp32 x / y, statistics and embedding [n][2*creal]");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(film_fwd_kernel, dim3(grid_of(n * h * w * (x.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)n, h, w, x.c / 4, mean,
+                     rstd, embed, creal, relu, up, (float*)y.ptr);
+  SF_CHECK_LAUNCH("film_act_fwd");
+  return 0;
+}
+
+static int film_slices(long long n, int h, int w, int q) {
+  long long blocks = n * ((q + 15) / 16);
+  long long s = (1024 + blocks - 1) / blocks;
+  const long long maxs = ((long long)h * w + 255) / 256;
+  if (s > maxs) s = maxs;
+  if (s < 1) s = 1;
+  if (s > 256) s = 256;
+  return (int)s;
+}
+size_t sf_film_act_bwd_workspace_floats(int64_t n, int32_t h, int32_t w, int32_t c, int32_t creal) {
+  return (size_t)film_slices(n, h, w, c / 4) * n * 2 * creal;
+}
+int sf_film_act_bwd(sfTensor gy, sfTensor x, int64_t n, int32_t h, int32_t w, const float* mean, const float* rstd, const float* embed, int32_t creal,
+                    int32_t relu, int32_t up, sfTensor dxhat, float* dembed, float* workspace, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(gy, x.c) && okd(dxhat, x.c) && mean && rstd && embed && dembed && workspace && creal >= 1 && creal <= x.c,
+             "sf_film_act_bwd: dense fp32 tensors, statistics, embedding and workspace");
+  if (n <= 0) return 0;
+  const int q = x.c / 4, slices = film_slices(n, h, w, q);
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(film_bwd_kernel, dim3(slices, (unsigned)n, (q + 15) / 16), dim3(256), 0, st, (const float*)gy.ptr, (const float*)x.ptr, h, w, q, mean, rstd, embed,
+                     creal, relu, up, (float*)dxhat.ptr, workspace);
+  const long long ne = n * 2 * creal;
+  hipLaunchKernelGGL(sum_slices_kernel, dim3((unsigned)((ne + 255) / 256)), dim3(256), 0, st, (const float*)workspace, slices, ne, dembed);
+  SF_CHECK_LAUNCH("film_act_bwd");
+  return 0;
+}
+
+int sf_relu_sum_pixels_fwd(sfTensor x, int64_t n, int64_t pixels, float* out, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && out, "sf_relu_sum_pixels_fwd: dense fp32 x, out [n][C]");
+  if (n <= 0) return 0;
+  const int q = x.c / 4;
+  hipLaunchKernelGGL(relu_sum_fwd_kernel, dim3((unsigned)n, (q + 15) / 16), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)pixels, q, out);
+  SF_CHECK_LAUNCH("relu_sum_pixels_fwd");
+  return 0;
+}
+
+int sf_relu_sum_pixels_bwd(const float* g, sfTensor x, int64_t n, int64_t pixels, sfTensor gx, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(gx, x.c) && g, "sf_relu_sum_pixels_bwd: dense fp32 tensors");
+  if (n <= 0 || pixels <= 0) return 0;
+  hipLaunchKernelGGL(relu_sum_bwd_kernel, dim3(grid_of(n * pixels * (x.c / 4))), dim3(256), 0, (hipStream_t)stream, g, (const float*)x.ptr, (long long)n,
+                     (long long)pixels, x.c / 4, (float*)gx.ptr);
+  SF_CHECK_LAUNCH("relu_sum_pixels_bwd");
+  return 0;
+}
+
+int sf_axpy(const float* o, const float* x, const float* gamma_dev, float alpha, int64_t n, float* y, sfStream stream) {
+  SF_REQUIRE(o && y && n % 4 == 0 && (((uintptr_t)o | (uintptr_t)y | (uintptr_t)x) & 15) == 0, "sf_axpy: 16-byte aligned fp32 arrays, n %% 4 == 0");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(axpy_kernel, dim3(grid_of(n / 4)), dim3(256), 0, (hipStream_t)stream, o, x, gamma_dev, alpha, (long long)(n / 4), y);
+  SF_CHECK_LAUNCH("axpy");
+  return 0;
+}
+
+int sf_dot(const float* a, const float* b, int64_t n, float* out, float* workspace, sfStream stream) {
+  SF_REQUIRE(a && b && out && workspace && n >= 0, "sf_dot: null pointer");
+  hipStream_t st = (hipStream_t)stream;
+  const int parts = grid_of(n, 512);
+  hipLaunchKernelGGL(dot_partial_kernel, dim3(parts), dim3(256), 0, st, a, b, (long long)n, workspace);
+  hipLaunchKernelGGL(sum_final_kernel, dim3(1), dim3(256), 0, st, (const float*)workspace, parts, out);
+  SF_CHECK_LAUNCH("dot");
+  return 0;
+}
+
+int sf_tanh(const float* x, const float* y_for_backward, int64_t n, float* out, sfStream stream) {
+  SF_REQUIRE(x && out && n % 4 == 0 && (((uintptr_t)x | (uintptr_t)out | (uintptr_t)y_for_backward) & 15) == 0, "sf_tanh: 16-byte aligned fp32 arrays, n %% 4 == 0");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(tanh_kernel, dim3(grid_of(n / 4)), dim3(256), 0, (hipStream_t)stream, x, y_for_backward, (long long)(n / 4), out);
+  SF_CHECK_LAUNCH("tanh");
+  return 0;
+}
+
+int sf_dvdgru_gates_fwd(sfTensor gx, sfTensor gh, sfTensor h, int64_t pixels, int32_t hidp, sfTensor zr, sfTensor rh, sfStream stream) {
+  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && oks(gx, 2 * hidp) && (!gh.ptr || oks(gh, 2 * hidp)) && (!h.ptr || oks(h, hidp)) && okd(zr, 2 * hidp) && okd(rh, hidp),
+             "sf_dvdgru_gates_fwd: gx / gh [.., 2*hidp], h [.., hidp], dense zr / rh (fp32, 16-byte pixels)");
+  if (pixels <= 0) return 0;
+  hipLaunchKernelGGL(dvdgru_gates_fwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gx.ptr, gx.stride,
+                     (const float*)gh.ptr, gh.stride, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)zr.ptr, (float*)rh.ptr);
+  SF_CHECK_LAUNCH("dvdgru_gates_fwd");
+  return 0;
+}
+
+int sf_dvdgru_gates_bwd(sfTensor dz, sfTensor drh, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor dpre, sfTensor dh, sfStream stream) {
+  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && (!dz.ptr || okd(dz, hidp)) && (!drh.ptr || okd(drh, hidp)) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) &&
+                 okd(dpre, 2 * hidp) && (!dh.ptr || okd(dh, hidp)), "sf_dvdgru_gates_bwd: dense fp32 tensors");
+  if (pixels <= 0) return 0;
+  hipLaunchKernelGGL(dvdgru_gates_bwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)dz.ptr, (const float*)drh.ptr,
+                     (const float*)zr.ptr, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)dpre.ptr, (float*)dh.ptr);
+  SF_CHECK_LAUNCH("dvdgru_gates_bwd");
+  return 0;
+}
+
+int sf_dvdgru_out_fwd(sfTensor gx, sfTensor gh, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor cand, sfTensor h_new, sfStream stream) {
+  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && oks(gx, hidp) && (!gh.ptr || oks(gh, hidp)) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) &&
+                 (!cand.ptr || okd(cand, hidp)) && okd(h_new, hidp), "sf_dvdgru_out_fwd: gx / gh [.., hidp], dense zr, cand, h_new (fp32)");
+  if (pixels <= 0) return 0;
+  hipLaunchKernelGGL(dvdgru_out_fwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gx.ptr, gx.stride,
+                     (const float*)gh.ptr, gh.stride, (const float*)zr.ptr, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)cand.ptr, (float*)h_new.ptr);
+  SF_CHECK_LAUNCH("dvdgru_out_fwd");
+  return 0;
+}
+
+int sf_dvdgru_out_bwd(sfTensor dh_new, sfTensor cand, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor da, sfTensor dz, sfTensor dh,
+                      sfStream stream) {
+  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && okd(dh_new, hidp) && okd(cand, hidp) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) && okd(da, hidp) && okd(dz, hidp) &&
+                 (!dh.ptr || okd(dh, hidp)), "sf_dvdgru_out_bwd: dense fp32 tensors");
+  if (pixels <= 0) return 0;
+  hipLaunchKernelGGL(dvdgru_out_bwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)dh_new.ptr, (const float*)cand.ptr,
+                     (const float*)zr.ptr, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)da.ptr, (float*)dz.ptr, (float*)dh.ptr);
+  SF_CHECK_LAUNCH("dvdgru_out_bwd");
+  return 0;
+}
+
+}  // extern "C"

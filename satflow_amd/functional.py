@@ -527,7 +527,7 @@ class _LinearFn(torch.autograd.Function):
             Wt = torch.zeros(Kp, gy.shape[-1], dtype=torch.float32, device=W.device)
             Wt[:, :N] = W.t()
             dx = K.linear_fwd(gy, Wt, None, Kp)
-        dW, db = K.linear_bwd_weight(gy, x, N, ctx.has_bias)
+        dW, db = K.linear_bwd_weight_any(gy, x, N, ctx.has_bias)
         return dx, dW, db, None
 
 

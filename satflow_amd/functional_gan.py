@@ -1,0 +1,471 @@
+"""Autograd-aware ops of the in-tree DGMR / DVD-GAN style networks and attention layers over the C ABI.
+
+As in ``functional.py`` every ``torch.autograd.Function`` is plumbing: it allocates outputs, hands raw pointers to
+libsatflow_hip.so on the current stream and wires the matching backward kernels.  Activations are NHWC fp32 ``[N,H,W,Cp]``
+(``Cp`` = channels padded to 16) unless a docstring says otherwise.
+"""
+from __future__ import annotations
+
+from typing import Optional, Tuple
+
+import torch
+
+from . import functional as F
+from . import kernels as K
+from ._hip import NULL, SF_F32, T, check, cpad, lib, require_device, stream_ptr
+
+Tensor = torch.Tensor
+
+
+def _ws(n: int, dev) -> Tensor:
+    return torch.empty(max(int(n), 1), dtype=torch.float32, device=dev)
+
+
+# ----------------------------------------------------------------------------------------------
+# spectral normalisation (reference layers/Normalization.py:10-62)
+# ----------------------------------------------------------------------------------------------
+class _SpectralNormFn(torch.autograd.Function):
+    """``w_bar -> w_bar / sigma`` with the power iteration advancing ``u`` / ``v`` IN PLACE (the reference assigns ``u.data`` /
+    ``v.data`` in every forward call, ``Normalization.py:25-27``).  ``u`` / ``v`` are constants of the differentiation."""
+
+    @staticmethod
+    def forward(ctx, w_bar: Tensor, u: Tensor, v: Tensor, power_iterations: int):
+        wb = w_bar.contiguous()
+        height = wb.shape[0]
+        width = wb.numel() // height
+        assert u.numel() == height and v.numel() == width and u.is_contiguous() and v.is_contiguous()
+        w = torch.empty_like(wb)
+        sigma = torch.empty(1, dtype=torch.float32, device=wb.device)
+        ws = _ws(height + width, wb.device)
+        check(lib().sf_spectral_norm_fwd(wb.data_ptr(), height, width, u.data_ptr(), v.data_ptr(), int(power_iterations), w.data_ptr(), sigma.data_ptr(),
+                                         ws.data_ptr(), stream_ptr()), "sf_spectral_norm_fwd")
+        # the vectors this call ended with (a later call advances the module's own copies before the backward pass runs)
+        ctx.save_for_backward(wb, u.detach().clone(), v.detach().clone(), sigma)
+        return w
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        wb, u, v, sigma = ctx.saved_tensors
+        g = g.contiguous()
+        height = wb.shape[0]
+        dw = torch.empty_like(wb)
+        ws = _ws(512, wb.device)
+        check(lib().sf_spectral_norm_bwd(g.data_ptr(), wb.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), height, wb.numel() // height, dw.data_ptr(),
+                                         ws.data_ptr(), stream_ptr()), "sf_spectral_norm_bwd")
+        return dw, None, None, None
+
+
+def spectral_norm_weight(w_bar: Tensor, u: Tensor, v: Tensor, power_iterations: int = 1) -> Tensor:
+    require_device(w_bar, "weight_bar")
+    return _SpectralNormFn.apply(w_bar, u, v, power_iterations)
+
+
+# ----------------------------------------------------------------------------------------------
+# pooling / up-sampling / temporal taps
+# ----------------------------------------------------------------------------------------------
+class _Pool2Fn(torch.autograd.Function):
+    """``scale * sum`` over 2x2 windows (and ``tpool`` frames, time-major with ``nb`` images per frame) ``+ addend``."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, tpool: int, nb: int, scale: float, addend: Optional[Tensor]):
+        n, h, w, c = x.shape
+        assert h % 2 == 0 and w % 2 == 0 and n % (tpool * nb) == 0, (x.shape, tpool, nb)
+        y = torch.empty(n // tpool, h // 2, w // 2, c, dtype=torch.float32, device=x.device)
+        check(lib().sf_pool2(T(x), n // tpool, h // 2, w // 2, tpool, nb, scale, T(addend) if addend is not None else NULL, T(y), stream_ptr()), "sf_pool2")
+        ctx.meta = (tpool, nb, scale, tuple(x.shape))
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        tpool, nb, scale, shape = ctx.meta
+        g = g.contiguous()
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty(shape, dtype=torch.float32, device=g.device)
+            check(lib().sf_expand2(T(g), g.shape[0], g.shape[1], g.shape[2], tpool, nb, scale, T(gx), stream_ptr()), "sf_expand2")
+        return gx, None, None, None, (g if ctx.needs_input_grad[4] else None)
+
+
+class _Expand2Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, scale: float):
+        n, h, w, c = x.shape
+        y = torch.empty(n, 2 * h, 2 * w, c, dtype=torch.float32, device=x.device)
+        check(lib().sf_expand2(T(x), n, h, w, 1, 1, scale, T(y), stream_ptr()), "sf_expand2")
+        ctx.scale = scale
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.contiguous()
+        n, h2, w2, c = g.shape
+        gx = torch.empty(n, h2 // 2, w2 // 2, c, dtype=torch.float32, device=g.device)
+        check(lib().sf_pool2(T(g), n, h2 // 2, w2 // 2, 1, 1, ctx.scale, NULL, T(gx), stream_ptr()), "sf_pool2")
+        return gx, None
+
+
+def avg_pool2(x: Tensor, addend: Optional[Tensor] = None) -> Tensor:
+    """``F.avg_pool2d(x, 2) (+ addend)``."""
+    return _Pool2Fn.apply(x.contiguous(), 1, 1, 0.25, addend.contiguous() if addend is not None else None)
+
+
+def avg_pool3(x: Tensor, nb: int, addend: Optional[Tensor] = None) -> Tensor:
+    """``F.avg_pool3d(x, 2) (+ addend)`` on time-major frames ``[T*nb,H,W,C] -> [T/2*nb,H/2,W/2,C]``."""
+    return _Pool2Fn.apply(x.contiguous(), 2, nb, 0.125, addend.contiguous() if addend is not None else None)
+
+
+def upsample2(x: Tensor) -> Tensor:
+    """``F.interpolate(x, scale_factor=2)`` (nearest)."""
+    return _Expand2Fn.apply(x.contiguous(), 1.0)
+
+
+class _TimeStack3Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, Tn: int):
+        n, h, w, c = x.shape
+        assert n % Tn == 0
+        y = torch.empty(n, h, w, 3 * c, dtype=torch.float32, device=x.device)
+        check(lib().sf_time_stack3_fwd(T(x), Tn, (n // Tn) * h * w, T(y), stream_ptr()), "sf_time_stack3_fwd")
+        ctx.Tn = Tn
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.contiguous()
+        n, h, w, c3 = g.shape
+        gx = torch.empty(n, h, w, c3 // 3, dtype=torch.float32, device=g.device)
+        check(lib().sf_time_stack3_bwd(T(g), ctx.Tn, (n // ctx.Tn) * h * w, T(gx), stream_ptr()), "sf_time_stack3_bwd")
+        return gx, None
+
+
+def time_stack3(x: Tensor, Tn: int) -> Tensor:
+    """Time-major ``[T*nb,H,W,C] -> [T*nb,H,W,3C]``: lanes ``dt*C + c`` hold frame ``t + dt - 1`` (zeros outside the clip)."""
+    return _TimeStack3Fn.apply(x.contiguous(), Tn)
+
+
+# ----------------------------------------------------------------------------------------------
+# convolutions whose weight is a fresh tensor every call (spectral norm): nothing is cached across calls
+# ----------------------------------------------------------------------------------------------
+class FreshConvEngine(F.ConvEngine):
+    """Index maps of a 3x3 convolution whose weight changes with every forward call (``W / sigma`` with an advancing sigma): the
+    packed images are built per call and travel with the autograd node - two forward passes of the same layer before a backward
+    (discriminator on real and on generated frames) must not see each other's weights."""
+
+    def packed(self, weight: Tensor, bias: Optional[Tensor], kind, need: Tuple[bool, ...] = ()):
+        w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
+        if kind == "fwd":
+            return K.pack_weights(w4, bias, self.fwd_map, transpose=False)
+        return K.pack_weights(w4, None, self.bwd_map(need), transpose=True)
+
+
+def conv_nhwc(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: Optional[F.ConvEngine] = None) -> Tensor:
+    """``nn.Conv2d(k, padding=k//2)`` on NHWC ``x``: 1x1 -> ``sf_linear_*``, 3x3 -> the MFMA kernels (``eng``), else ``sf_conv2d_*``."""
+    k = weight.shape[-1]
+    if k == 1:
+        return F.linear(x, weight.reshape(weight.shape[0], weight.shape[1]), bias)
+    if k == 3:
+        assert eng is not None
+        return F.conv3x3(eng, x, weight, bias)
+    return F.conv2d(x, weight, bias, 1, k // 2)
+
+
+# ----------------------------------------------------------------------------------------------
+# conditional BatchNorm (+ ReLU, + nearest up-sampling)  (reference layers/Normalization.py:65-85, GResBlock.py:63-78)
+# ----------------------------------------------------------------------------------------------
+class _CondNormFn(torch.autograd.Function):
+    """``act(gamma_n * batchnorm(x) + beta_n)`` (training-mode statistics over all images, no affine) with ``embed [N, 2*C]`` =
+    ``gamma | beta`` per image; optionally ReLU and 2x nearest up-sampling of the result in the same pass."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, embed: Tensor, creal: int, running_mean: Optional[Tensor], running_var: Optional[Tensor], momentum: float, eps: float,
+                training: bool, relu: bool, up: bool):
+        n, h, w, C = x.shape
+        dev = x.device
+        embed = embed.contiguous()
+        assert embed.shape == (n, 2 * creal)
+        if training:
+            stats = torch.empty(4, C, dtype=torch.float32, device=dev)
+            sums = torch.empty(2, C, dtype=torch.float64, device=dev)
+            ones, zeros = torch.ones(creal, dtype=torch.float32, device=dev), torch.zeros(creal, dtype=torch.float32, device=dev)
+            check(lib().sf_batchnorm_train_fwd(T(x), n * h * w, 1, creal, ones.data_ptr(), zeros.data_ptr(), eps, momentum,
+                                               running_mean.data_ptr() if running_mean is not None else None,
+                                               running_var.data_ptr() if running_var is not None else None,
+                                               stats[0].data_ptr(), stats[1].data_ptr(), stats[2].data_ptr(), stats[3].data_ptr(), sums.data_ptr(), NULL, SF_F32,
+                                               stream_ptr()), "sf_batchnorm_train_fwd")
+            mean, rstd = stats[0], stats[1]
+        else:  # running statistics are constants (tiny per-channel torch ops)
+            mean = torch.zeros(C, dtype=torch.float32, device=dev)
+            rstd = torch.zeros(C, dtype=torch.float32, device=dev)
+            mean[:creal] = running_mean
+            rstd[:creal] = torch.rsqrt(running_var + eps)
+        y = torch.empty(n, 2 * h if up else h, 2 * w if up else w, C, dtype=torch.float32, device=dev)
+        check(lib().sf_film_act_fwd(T(x), n, h, w, mean.data_ptr(), rstd.data_ptr(), embed.data_ptr(), creal, int(relu), int(up), T(y), stream_ptr()), "sf_film_act_fwd")
+        ctx.meta = (creal, training, relu, up)
+        ctx.save_for_backward(x, embed, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, embed, mean, rstd = ctx.saved_tensors
+        creal, training, relu, up = ctx.meta
+        n, h, w, C = x.shape
+        dev = x.device
+        gy = gy.contiguous()
+        dxhat = torch.empty_like(x)
+        dembed = torch.empty_like(embed)
+        ws = _ws(lib().sf_film_act_bwd_workspace_floats(n, h, w, C, creal), dev)
+        check(lib().sf_film_act_bwd(T(gy), T(x), n, h, w, mean.data_ptr(), rstd.data_ptr(), embed.data_ptr(), creal, int(relu), int(up), T(dxhat), dembed.data_ptr(),
+                                    ws.data_ptr(), stream_ptr()), "sf_film_act_bwd")
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if training:  # through the batch statistics: the BatchNorm backward with a unit affine map
+                dx = torch.empty_like(x)
+                sums = torch.empty(2, C, dtype=torch.float64, device=dev)
+                coef = torch.empty(3, C, dtype=torch.float32, device=dev)
+                ones = torch.ones(creal, dtype=torch.float32, device=dev)
+                dummy = torch.empty(2, creal, dtype=torch.float32, device=dev)
+                check(lib().sf_batchnorm_train_bwd(T(x), T(dxhat), n * h * w, 1, creal, ones.data_ptr(), mean.data_ptr(), rstd.data_ptr(), sums.data_ptr(),
+                                                   coef.data_ptr(), T(dx), dummy[0].data_ptr(), dummy[1].data_ptr(), SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
+            else:
+                dx = dxhat * rstd  # frozen statistics: d xhat / dx = rstd (pointwise torch op; evaluation-mode fine-tuning only)
+        return dx, dembed, None, None, None, None, None, None, None, None
+
+
+def conditional_norm(x: Tensor, embed: Tensor, creal: int, bn: torch.nn.BatchNorm2d, training: bool, relu: bool = False, up: bool = False) -> Tensor:
+    momentum = bn.momentum
+    if training and bn.track_running_stats and bn.num_batches_tracked is not None:
+        if momentum is None:
+            momentum = -(float(bn.num_batches_tracked) + 1.0)
+        bn.num_batches_tracked += 1
+    use_batch = training or bn.running_mean is None
+    return _CondNormFn.apply(x.contiguous(), embed, creal, bn.running_mean, bn.running_var, float(momentum if momentum is not None else 0.0), bn.eps, use_batch,
+                             relu, up)
+
+
+# ----------------------------------------------------------------------------------------------
+# small pointwise pieces
+# ----------------------------------------------------------------------------------------------
+def relu(x: Tensor) -> Tensor:
+    return F.leaky_relu(x, 0.0)
+
+
+class _ReluSumFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        n, C = x.shape[0], x.shape[-1]
+        pixels = x.numel() // (n * C)
+        out = torch.empty(n, C, dtype=torch.float32, device=x.device)
+        check(lib().sf_relu_sum_pixels_fwd(T(x), n, pixels, out.data_ptr(), stream_ptr()), "sf_relu_sum_pixels_fwd")
+        ctx.save_for_backward(x)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (x,) = ctx.saved_tensors
+        n, C = x.shape[0], x.shape[-1]
+        g = g.contiguous()
+        gx = torch.empty_like(x)
+        check(lib().sf_relu_sum_pixels_bwd(g.data_ptr(), T(x), n, x.numel() // (n * C), T(gx), stream_ptr()), "sf_relu_sum_pixels_bwd")
+        return gx
+
+
+def relu_sum_pixels(x: Tensor) -> Tensor:
+    """``F.relu(x).view(N, C, -1).sum(2)`` on NHWC ``x`` -> ``[N, Cp]``."""
+    return _ReluSumFn.apply(x.contiguous())
+
+
+class _GammaResidualFn(torch.autograd.Function):
+    """``gamma * o + x`` with ``gamma`` a one-element parameter."""
+
+    @staticmethod
+    def forward(ctx, o: Tensor, x: Tensor, gamma: Tensor):
+        y = torch.empty_like(o)
+        check(lib().sf_axpy(o.data_ptr(), x.data_ptr(), gamma.data_ptr(), 0.0, o.numel(), y.data_ptr(), stream_ptr()), "sf_axpy")
+        ctx.save_for_backward(o, gamma)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        o, gamma = ctx.saved_tensors
+        g = g.contiguous()
+        go = torch.empty_like(g)
+        check(lib().sf_axpy(g.data_ptr(), None, gamma.data_ptr(), 0.0, g.numel(), go.data_ptr(), stream_ptr()), "sf_axpy")
+        dgamma = torch.empty_like(gamma)
+        ws = _ws(512, g.device)
+        check(lib().sf_dot(g.data_ptr(), o.data_ptr(), g.numel(), dgamma.data_ptr(), ws.data_ptr(), stream_ptr()), "sf_dot")
+        return go, g, dgamma
+
+
+def gamma_residual(o: Tensor, x: Tensor, gamma: Tensor) -> Tensor:
+    assert o.shape == x.shape and gamma.numel() == 1
+    return _GammaResidualFn.apply(o.contiguous(), x.contiguous(), gamma)
+
+
+class _AddFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, a: Tensor, b: Tensor):
+        y = torch.empty_like(a)
+        check(lib().sf_axpy(a.data_ptr(), b.data_ptr(), None, 1.0, a.numel(), y.data_ptr(), stream_ptr()), "sf_axpy")
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        return g, g
+
+
+def add(a: Tensor, b: Tensor) -> Tensor:
+    assert a.shape == b.shape
+    return _AddFn.apply(a.contiguous(), b.contiguous())
+
+
+class _TanhFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        y = torch.empty_like(x)
+        check(lib().sf_tanh(x.data_ptr(), None, x.numel(), y.data_ptr(), stream_ptr()), "sf_tanh")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        gx = torch.empty_like(g)
+        check(lib().sf_tanh(g.data_ptr(), y.data_ptr(), g.numel(), gx.data_ptr(), stream_ptr()), "sf_tanh")
+        return gx
+
+
+def tanh(x: Tensor) -> Tensor:
+    return _TanhFn.apply(x.contiguous())
+
+
+# ----------------------------------------------------------------------------------------------
+# gate arithmetic of the generator's ConvGRU
+# ----------------------------------------------------------------------------------------------
+class _DvdGruGatesFn(torch.autograd.Function):
+    """``(gx_zr, gh_zr, h) -> (z, rh)``: ``z = sig(.)`` is returned as the first ``hidp`` lanes of ``zr`` (kept whole for the out stage)."""
+
+    @staticmethod
+    def forward(ctx, gx: Tensor, gh: Optional[Tensor], h: Optional[Tensor], hidp: int):
+        shp, dev = gx.shape[:-1], gx.device
+        pixels = gx.numel() // gx.shape[-1]
+        zr = torch.empty(*shp, 2 * hidp, dtype=torch.float32, device=dev)
+        rh = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
+        check(lib().sf_dvdgru_gates_fwd(T(gx), T(gh) if gh is not None else NULL, T(h) if h is not None else NULL, pixels, hidp, T(zr), T(rh), stream_ptr()),
+              "sf_dvdgru_gates_fwd")
+        ctx.hidp, ctx.has = hidp, (gh is not None, h is not None)
+        ctx.save_for_backward(zr, h if h is not None else gx.new_empty(0))
+        ctx.set_materialize_grads(False)
+        return zr, rh
+
+    @staticmethod
+    def backward(ctx, dzr: Optional[Tensor], drh: Optional[Tensor]):
+        # dzr: only the z half can carry a gradient (the out stage reads z from zr); it arrives as a dense [.., 2*hidp] tensor
+        zr, h = ctx.saved_tensors
+        hidp = ctx.hidp
+        has_gh, has_h = ctx.has
+        pixels = zr.numel() // (2 * hidp)
+        dz = dzr[..., :hidp].contiguous() if dzr is not None else None
+        drh = drh.contiguous() if drh is not None else None
+        dpre = torch.empty_like(zr)
+        dh = torch.empty(*zr.shape[:-1], hidp, dtype=torch.float32, device=zr.device) if has_h else None
+        check(lib().sf_dvdgru_gates_bwd(T(dz) if dz is not None else NULL, T(drh) if drh is not None else NULL, T(zr), T(h) if has_h else NULL, pixels, hidp, T(dpre),
+                                        T(dh) if dh is not None else NULL, stream_ptr()), "sf_dvdgru_gates_bwd")
+        return dpre, (dpre if has_gh else None), dh, None
+
+
+class _DvdGruOutFn(torch.autograd.Function):
+    """``(gx_o, gh_o, zr, h) -> h' = h (1 - z) + tanh(gx_o + gh_o) z``."""
+
+    @staticmethod
+    def forward(ctx, gx: Tensor, gh: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int):
+        shp, dev = gx.shape[:-1], gx.device
+        pixels = gx.numel() // gx.shape[-1]
+        cand = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
+        hn = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
+        check(lib().sf_dvdgru_out_fwd(T(gx), T(gh) if gh is not None else NULL, T(zr), T(h) if h is not None else NULL, pixels, hidp, T(cand), T(hn), stream_ptr()),
+              "sf_dvdgru_out_fwd")
+        ctx.hidp, ctx.has, ctx.lanes = hidp, (gh is not None, h is not None), gx.shape[-1]
+        ctx.save_for_backward(cand, zr, h if h is not None else gx.new_empty(0))
+        return hn
+
+    @staticmethod
+    def backward(ctx, dhn: Tensor):
+        cand, zr, h = ctx.saved_tensors
+        hidp = ctx.hidp
+        has_gh, has_h = ctx.has
+        pixels = cand.numel() // hidp
+        dhn = dhn.contiguous()
+        da = torch.empty_like(cand)
+        dz = torch.empty_like(cand)
+        dh = torch.empty_like(cand) if has_h else None
+        check(lib().sf_dvdgru_out_bwd(T(dhn), T(cand), T(zr), T(h) if has_h else NULL, pixels, hidp, T(da), T(dz), T(dh) if dh is not None else NULL, stream_ptr()),
+              "sf_dvdgru_out_bwd")
+        dzr = torch.cat((dz, torch.zeros_like(dz)), -1)  # the r half of zr does not reach h' through this stage
+        return da, (da if has_gh else None), dzr, dh, None
+
+
+def dvdgru_gates(gx_zr: Tensor, gh_zr: Optional[Tensor], h: Optional[Tensor], hidp: int) -> Tuple[Tensor, Tensor]:
+    return _DvdGruGatesFn.apply(gx_zr.contiguous(), gh_zr.contiguous() if gh_zr is not None else None, h.contiguous() if h is not None else None, hidp)
+
+
+def dvdgru_out(gx_o: Tensor, gh_o: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int) -> Tensor:
+    return _DvdGruOutFn.apply(gx_o.contiguous(), gh_o.contiguous() if gh_o is not None else None, zr, h.contiguous() if h is not None else None, hidp)
+
+
+# ----------------------------------------------------------------------------------------------
+# torch.bmm / softmax on strided views
+# ----------------------------------------------------------------------------------------------
+_bmm_raw = K.bmm_raw
+
+
+class _BmmFn(torch.autograd.Function):
+    """``torch.bmm(A, B)`` for arbitrary strided 3-D views; the gradients are the same kernel on transposed views."""
+
+    @staticmethod
+    def forward(ctx, A: Tensor, B: Tensor):
+        out = torch.empty(A.shape[0], A.shape[1], B.shape[2], dtype=torch.float32, device=A.device)
+        _bmm_raw(A, B, out)
+        ctx.save_for_backward(A, B)
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        A, B = ctx.saved_tensors
+        dA = dB = None
+        if ctx.needs_input_grad[0]:
+            dA = torch.empty(A.shape, dtype=torch.float32, device=A.device)
+            _bmm_raw(g, B.transpose(1, 2), dA)
+        if ctx.needs_input_grad[1]:
+            dB = torch.empty(B.shape, dtype=torch.float32, device=B.device)
+            _bmm_raw(A.transpose(1, 2), g, dB)
+        return dA, dB
+
+
+def bmm(A: Tensor, B: Tensor) -> Tensor:
+    require_device(A, "A")
+    return _BmmFn.apply(A, B)
+
+
+class _SoftmaxFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        L = x.shape[-1]
+        y = torch.empty_like(x)
+        check(lib().sf_softmax_rows_fwd(x.data_ptr(), x.numel() // L, L, y.data_ptr(), stream_ptr()), "sf_softmax_rows_fwd")
+        ctx.save_for_backward(y)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (y,) = ctx.saved_tensors
+        g = g.contiguous()
+        L = y.shape[-1]
+        dx = torch.empty_like(y)
+        check(lib().sf_softmax_rows_bwd(g.data_ptr(), y.data_ptr(), y.numel() // L, L, dx.data_ptr(), stream_ptr()), "sf_softmax_rows_bwd")
+        return dx
+
+
+def softmax_last(x: Tensor) -> Tensor:
+    """``softmax(x, dim=-1)`` of a contiguous fp32 tensor."""
+    return _SoftmaxFn.apply(x.contiguous())

@@ -368,6 +368,48 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[T
     return dW, db
 
 
+def bmm_raw(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: float = 0.0) -> None:
+    """``out[b] = alpha * A[b] @ B[b] + beta * out[b]`` for 3-D fp32 views with arbitrary strides.  sf_bmm_f32."""
+    assert A.dim() == B.dim() == out.dim() == 3 and A.dtype == B.dtype == out.dtype == torch.float32
+    bsz, M, Kd = A.shape
+    N = B.shape[2]
+    assert B.shape[0] == bsz and B.shape[1] == Kd and out.shape == (bsz, M, N), (A.shape, B.shape, out.shape)
+    sa, sb, sc = A.stride(), B.stride(), out.stride()
+    check(lib().sf_bmm_f32(A.data_ptr(), sa[0], sa[1], sa[2], B.data_ptr(), sb[0], sb[1], sb[2], out.data_ptr(), sc[0], sc[1], sc[2], bsz, M, N, Kd,
+                           alpha, beta, stream_ptr()), "sf_bmm_f32")
+
+
+def linear_bwd_weight_any(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[Tensor, Optional[Tensor]]:
+    """``linear_bwd_weight`` for any K: the split-K MFMA kernel up to K = 256, beyond that (the 1x1 convolutions of the DGMR
+    discriminators, up to 2048 channels) the strided batched product over row slices plus a product with a ones vector that sums
+    the slices (both sf_bmm_f32)."""
+    Kd = x.shape[-1]
+    if Kd <= 256:
+        return linear_bwd_weight(dy, x, N, want_bias)
+    rows = x.numel() // Kd
+    lanes = dy.shape[-1]
+    S = 1
+    for cand in (64, 32, 16, 8, 4, 2):
+        if rows % cand == 0 and rows // cand >= 64:
+            S = cand
+            break
+    per = rows // S
+    dy3, x3 = dy.reshape(S, per, lanes), x.reshape(S, per, Kd)
+    part = torch.empty(S, N, Kd, dtype=torch.float32, device=x.device)
+    bmm_raw(dy3[..., :N].transpose(1, 2), x3, part)
+    ones = torch.ones(1, 1, max(S, per), dtype=torch.float32, device=x.device)
+    dW = torch.empty(1, 1, N * Kd, dtype=torch.float32, device=x.device)
+    bmm_raw(ones[..., :S], part.view(1, S, N * Kd), dW)
+    db = None
+    if want_bias:
+        pb = torch.empty(S, 1, N, dtype=torch.float32, device=x.device)
+        bmm_raw(ones[..., :per].expand(S, 1, per), dy3[..., :N], pb)
+        db = torch.empty(1, 1, N, dtype=torch.float32, device=x.device)
+        bmm_raw(ones[..., :S], pb.view(1, S, N), db)
+        db = db.view(N)
+    return dW.view(N, Kd), db
+
+
 def attention_core_fwd(qkv: Tensor, hid: int, heads: int) -> Tensor:
     n, h, w, c6 = qkv.shape
     hidp = c6 // 6

@@ -328,6 +328,157 @@ def stlstm_cases():
         f.write("\n".join(SpatioTemporalLSTMCell(4, 8, 8, 3, 1, False).state_dict().keys()) + "\n")
 
 
+def _randomise(module, gen, wscale=1.0, bscale=0.3):
+    """Spread every parameter (biases away from zero, gammas away from 0 / 1) without touching spectral-norm u / v vectors."""
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if n.endswith("_u") or n.endswith("_v"):
+                continue
+            if n.endswith("gamma"):
+                p.fill_(0.6)
+            elif n.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=gen) * bscale)
+            elif wscale != 1.0:
+                p.mul_(wscale)
+
+
+def _record_module(rec, module, tag, with_grads):
+    for k, v in module.state_dict().items():
+        rec[f"{tag}.{k}"] = v.detach().clone()
+    if with_grads:
+        for k, v in module.named_parameters():
+            if v.requires_grad:
+                rec[f"grad.{k}"] = (v.grad if v.grad is not None else torch.zeros_like(v)).detach().clone()
+
+
+def dgmr_cases():
+    """The in-tree DGMR / DVD-GAN pieces that import here: Normalization (SpectralNorm, ConditionalNorm), GResBlock,
+    Discriminator (Spatial / Temporal).  Every case stores the state BEFORE the call (`before.*`, incl. the spectral-norm vectors),
+    inputs, outputs, a random cotangent, every gradient, and the state AFTER the call (`after.*`: advanced u / v, running statistics)."""
+    from satflow.models.layers.Normalization import ConditionalNorm, SpectralNorm
+    from satflow.models.layers.GResBlock import GResBlock
+    from satflow.models.layers.Discriminator import SpatialDiscriminator, TemporalDiscriminator
+    from oracle import dgmr as OD
+
+    def P_of(module):
+        return {k: v.detach().clone().requires_grad_(v.dtype.is_floating_point and not (k.endswith("_u") or k.endswith("_v")) and "running" not in k)
+                for k, v in module.state_dict().items()}
+
+    # (1) SpectralNorm around a convolution, a linear map and an embedding; two consecutive calls (the vectors advance)
+    gen = torch.Generator().manual_seed(zlib_seed("dgmr-sn"))
+    torch.manual_seed(21)
+    rec = {}
+    for tag, inner, x in (("conv", torch.nn.Conv2d(5, 7, 3, padding=1), torch.randn(2, 5, 9, 8, generator=gen)),
+                          ("lin", torch.nn.Linear(12, 1), torch.randn(6, 12, generator=gen)),
+                          ("emb", torch.nn.Embedding(4, 10), torch.tensor([0, 3, 1, 1, 2]))):
+        m = SpectralNorm(inner)
+        _randomise(m, gen, wscale=2.5)
+        _record_module(rec, m, f"{tag}.before", False)
+        P = P_of(m)
+        xin = x.clone().requires_grad_() if x.dtype.is_floating_point else x
+        out1 = m(xin)
+        cot = torch.randn(out1.shape, generator=gen)
+        (out1 * cot).sum().backward()
+        _record_module(rec, m, f"{tag}.after1", False)
+        rec.update({f"{tag}.x": x, f"{tag}.out1": out1.detach(), f"{tag}.cot": cot})
+        if x.dtype.is_floating_point:
+            rec[f"{tag}.dx"] = xin.grad.clone()
+        for k, v in m.named_parameters():
+            if v.requires_grad:
+                rec[f"{tag}.grad.{k}"] = v.grad.clone()
+        out2 = m(x)
+        rec[f"{tag}.out2"] = out2.detach()
+        _record_module(rec, m, f"{tag}.after2", False)
+        ns = {}
+        w = OD.spectral_weight(P, "module.", ns)
+        ref = {"conv": lambda: torch.nn.functional.conv2d(x, w, P["module.bias"], padding=1), "lin": lambda: torch.nn.functional.linear(x, w, P["module.bias"]),
+               "emb": lambda: torch.nn.functional.embedding(x, w)}[tag]()
+        assert torch.allclose(ref, out1.detach(), rtol=1e-6, atol=1e-7), f"oracle spectral norm mismatch {tag}"
+        assert torch.allclose(ns["module.weight_u"], rec[f"{tag}.after1.module.weight_u"], rtol=1e-6, atol=1e-7)
+    np.savez(f"{HERE}/dgmr_spectral_norm.npz", **_np(rec))
+    print("dgmr spectral norm: ok (conv / linear / embedding, two calls each)")
+
+    # (2) ConditionalNorm
+    gen = torch.Generator().manual_seed(zlib_seed("dgmr-cbn"))
+    torch.manual_seed(22)
+    cn = ConditionalNorm(6, 5)
+    _randomise(cn, gen)
+    with torch.no_grad():
+        cn.embed.weight[6:].copy_(torch.randn(6, 5, generator=gen) * 0.3)  # the shift half is zero-initialised
+    rec = {}
+    _record_module(rec, cn, "before", False)
+    P = P_of(cn)
+    x = (torch.randn(4, 6, 7, 5, generator=gen) * 1.5 + 0.3).requires_grad_()
+    cond = torch.randn(4, 5, generator=gen).requires_grad_()
+    out = cn(x, cond)
+    cot = torch.randn(out.shape, generator=gen)
+    (out * cot).sum().backward()
+    rec.update(dict(x=x.detach(), cond=cond.detach(), out=out.detach(), cot=cot, dx=x.grad, dcond=cond.grad))
+    _record_module(rec, cn, "after", True)
+    assert torch.allclose(OD.conditional_norm(x.detach(), cond.detach(), P, ""), out.detach(), rtol=1e-6, atol=1e-6)
+    np.savez(f"{HERE}/dgmr_conditional_norm.npz", **_np(rec))
+    print("dgmr conditional norm: ok")
+
+    # (3) GResBlock: up-sampling (the generator's), resolution-preserving, down-sampling (no norm)
+    for name, (cin, cout, kw, BT, W, H) in {"up": (6, 10, dict(n_class=5), 4, 6, 5), "same": (8, 8, dict(n_class=5, upsample_factor=1), 4, 7, 6),
+                                             "down": (6, 12, dict(bn=False, downsample_factor=2), 3, 8, 10)}.items():
+        gen = torch.Generator().manual_seed(zlib_seed("dgmr-gres" + name))
+        torch.manual_seed(23)
+        blk = GResBlock(cin, cout, **kw)
+        _randomise(blk, gen, wscale=2.0)
+        if hasattr(blk, "CBNorm1"):
+            with torch.no_grad():
+                for cb in (blk.CBNorm1, blk.CBNorm2):
+                    c_ = cb.in_channel
+                    cb.embed.weight[c_:].copy_(torch.randn(c_, 5, generator=gen) * 0.3)
+        rec = dict(upsample_factor=blk.upsample_factor, downsample_factor=blk.downsample_factor, bn=int(blk.bn))
+        _record_module(rec, blk, "before", False)
+        P = P_of(blk)
+        x = torch.randn(BT, cin, W, H, generator=gen).requires_grad_()
+        cond = torch.randn(BT, 5, generator=gen).requires_grad_()
+        out = blk(x, cond)
+        cot = torch.randn(out.shape, generator=gen)
+        (out * cot).sum().backward()
+        rec.update(dict(x=x.detach(), cond=cond.detach(), out=out.detach(), cot=cot, dx=x.grad))
+        if cond.grad is not None:
+            rec["dcond"] = cond.grad
+        _record_module(rec, blk, "after", True)
+        ref = OD.gresblock(x.detach(), cond.detach(), P, "", None, bn=kw.get("bn", True), upsample_factor=kw.get("upsample_factor", 2),
+                           downsample_factor=kw.get("downsample_factor", 1))
+        assert torch.allclose(ref, out.detach(), rtol=1e-5, atol=1e-6), f"oracle gresblock mismatch {name}"
+        np.savez(f"{HERE}/dgmr_gresblock_{name}.npz", **_np(rec))
+        print(f"dgmr gresblock {name}: ok  out {tuple(out.shape)} |out|max={float(out.abs().max()):.3f}")
+
+    # (4) the two discriminators
+    for name, cls, shape in (("spatial", SpatialDiscriminator, (2, 2, 3, 32, 32)), ("temporal", TemporalDiscriminator, (2, 3, 4, 32, 32))):
+        gen = torch.Generator().manual_seed(zlib_seed("dgmr-disc" + name))
+        torch.manual_seed(24)
+        D = cls(chn=4, n_class=3)
+        _randomise(D, gen, wscale=1.5)
+        rec = {}
+        _record_module(rec, D, "before", False)
+        P = P_of(D)
+        x = torch.randn(*shape, generator=gen).requires_grad_()
+        cls_id = torch.tensor([2, 0])
+        out = D(x, cls_id)
+        cot = torch.randn(out.shape, generator=gen)
+        (out * cot).sum().backward()
+        rec.update(dict(x=x.detach(), class_id=cls_id, out=out.detach(), cot=cot, dx=x.grad))
+        _record_module(rec, D, "after", True)
+        ns = {}
+        ref = (OD.spatial_discriminator if name == "spatial" else OD.temporal_discriminator)(x.detach(), cls_id, P, ns)
+        assert torch.allclose(ref, out.detach(), rtol=1e-5, atol=1e-5), f"oracle {name} discriminator mismatch: {float((ref - out.detach()).abs().max())}"
+        for k, v in ns.items():
+            assert torch.allclose(v, rec[f"after.{k}"], rtol=1e-6, atol=1e-7), k
+        np.savez(f"{HERE}/dgmr_{name}_discriminator.npz", **_np(rec))
+        with open(f"{HERE}/dgmr_{name}_discriminator_keys.txt", "w") as f:
+            f.write("\n".join(D.state_dict().keys()) + "\n")
+        print(f"dgmr {name} discriminator: ok  scores {out.detach().numpy().round(4)}")
+    with open(f"{HERE}/dgmr_gresblock_keys.txt", "w") as f:
+        f.write("\n".join(GResBlock(4, 8, n_class=5).state_dict().keys()) + "\n")
+
+
+
 def zlib_seed(s):
     import zlib
 
@@ -337,7 +488,7 @@ def zlib_seed(s):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     _shim_reference()
-    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan", "stlstm"]
+    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan", "stlstm", "dgmr"]
     if "cell" in only:
         cell_cases()
     if "model" in only:
@@ -348,3 +499,5 @@ if __name__ == "__main__":
         cloudgan_cases()
     if "stlstm" in only:
         stlstm_cases()
+    if "dgmr" in only:
+        dgmr_cases()
