@@ -16,6 +16,7 @@ Rank 0 prints ONE JSON line.  Besides the contract fields it carries
 from __future__ import annotations
 
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -474,6 +475,149 @@ class STLSTMWorkload:
         return time_cpu(one, "oracle fwd over T cells + loss + bwd + Adam, B=1 of the same workload, fp32")
 
 
+class DGMRWorkload:
+    """BASELINE configs[4] at one GPU: a DGMR / DVD-GAN style GAN step on 12-channel 256x256 frames built from the
+    reference's in-tree pieces - ``layers/Generator.py`` (ConvGRU + GResBlock stack, latent 16x16 -> 256x256), ``layers/Discriminator.py``
+    (SpatialDiscriminator on every frame, TemporalDiscriminator on the 2x down-sampled clip, the DVD-GAN arrangement the file's comments
+    describe).  The reference ships no training module for them (``configs/model/nowcasting_gan.yaml`` points at a class that is not in
+    the tree), so the step is the standard hinge-loss pair: the generator runs ONCE per step; the discriminators are updated on
+    (real, generated.detach()), then the generator through the updated discriminators.  bf16 MFMA operands for every 3x3 / 3x3x3
+    convolution ("fp16" in BASELINE: this path's 16-bit operand type), fp32 everything else."""
+
+    name = "dgmr"
+
+    def __init__(self, dev, batch: int, rank: int, ch: int = None, chn: int = None, frames: int = None):
+        from satflow_amd.models.layers.Discriminator import SpatialDiscriminator, TemporalDiscriminator
+        from satflow_amd.models.layers.Generator import Generator
+        from satflow_amd.optim import FlatAdam
+
+        self.B, self.C, self.H = batch, 12, 256
+        self.T = frames or int(os.environ.get("SF_DGMR_FRAMES", "8"))
+        self.ch = ch or int(os.environ.get("SF_DGMR_CH", "16"))
+        self.chn = chn or int(os.environ.get("SF_DGMR_CHN", "16"))
+        self.in_dim, self.n_class = 120, 4
+        torch.manual_seed(1234)
+        self.G = Generator(in_dim=self.in_dim, latent_dim=self.H // 16, n_class=self.n_class, ch=self.ch, n_frames=self.T, out_channels=self.C).to(dev).train()
+        self.Ds = SpatialDiscriminator(chn=self.chn, n_class=self.n_class, in_channels=self.C).to(dev).train()
+        self.Dt = TemporalDiscriminator(chn=self.chn, n_class=self.n_class, in_channels=self.C).to(dev).train()
+        g = torch.Generator(device="cpu").manual_seed(1234 + rank)
+        self.real = (torch.rand(self.B, self.T, self.C, self.H, self.H, generator=g) * 2 - 1).to(dev)   # [B,T,C,H,W] in the tanh range
+        self.cls = torch.randint(0, self.n_class, (self.B,), generator=g).to(dev)
+        self.noise_gen = torch.Generator(device=dev).manual_seed(99 + rank)
+        ov = not os.environ.get("SF_NO_OVERLAP")
+        self.opt_g = FlatAdam(self.G.parameters(), lr=5e-5, betas=(0.0, 0.999), overlap=ov, buffers=list(self.G.buffers()))
+        self.opt_d = FlatAdam(list(self.Ds.parameters()) + list(self.Dt.parameters()), lr=2e-4, betas=(0.0, 0.999), overlap=ov)
+        self.opt = self.opt_g
+        self.dev = dev
+        for net in (self.G, self.Ds, self.Dt):  # spectral-norm vectors are non-trainable parameters: never toggled
+            for p in net.parameters():
+                p._sf_frozen_forever = not p.requires_grad
+
+    def _scores(self, frames_tm):
+        """time-major NHWC frames ``[T*B,H,W,Cp]`` -> (spatial scores of every frame, temporal scores of the 2x down-sampled clip)."""
+        from satflow_amd import functional_gan as FG
+
+        return self.Ds.run(frames_tm, self.cls, self.T, time_major=True), self.Dt.run(FG.avg_pool2(frames_tm), self.cls, self.T, self.B)
+
+    @staticmethod
+    def _train(nets, on: bool):
+        for net in nets:
+            for p in net.parameters():
+                if not p._sf_frozen_forever:
+                    p.requires_grad_(on)
+
+    def step(self):
+        from satflow_amd import functional as F
+
+        B, T, C, H = self.B, self.T, self.C, self.H
+        z = torch.randn(B, self.in_dim, generator=self.noise_gen, device=self.dev)
+        fake = self.G.run(z, self.cls)                                                   # time-major NHWC, with the generator's graph
+        real = F._ToNHWC.apply(self.real, B, T, C, H, H, (T * C * H * H, C * H * H, H * H))
+        # discriminator update on (real, generated.detach()): hinge loss
+        self.opt_d.zero_grad()
+        rs, rt = self._scores(real)
+        fs, ft = self._scores(fake.detach())
+        d_loss = torch.relu(1 - rs).mean() + torch.relu(1 + fs).mean() + torch.relu(1 - rt).mean() + torch.relu(1 + ft).mean()
+        d_loss.backward()
+        self.opt_d.step()
+        # generator update through the updated (and, for this pass, frozen) discriminators
+        self.opt_g.zero_grad()
+        self._train((self.Ds, self.Dt), False)
+        gs, gt = self._scores(fake)
+        g_loss = -gs.mean() - gt.mean()
+        g_loss.backward()
+        self._train((self.Ds, self.Dt), True)
+        self.opt_g.step()
+        return d_loss.detach() + g_loss.detach()
+
+    def config(self, world):
+        return {"workload": f"DGMR-style GAN step (BASELINE configs[4] at {world} GPU(s)): generator (ConvGRU + GResBlock, ch {self.ch}, latent 16x16 -> "
+                            f"12 ch 256x256, {self.T} frames) + spatial and temporal discriminators (chn {self.chn}); reference layers/Generator.py, "
+                            "layers/Discriminator.py, layers/GResBlock.py, layers/Normalization.py",
+                "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
+                "step": "G forward once; D update: hinge loss on (real, generated.detach()), backward, Adam; G update: -D(generated) through the updated "
+                        "discriminators, backward, Adam"}
+
+    def roofline(self):
+        """The spatial discriminator's widest full-resolution convolution (pre_conv.2: 2chn -> 2chn, 3x3, 256x256 frames), timed live."""
+        from satflow_amd import functional as F
+
+        sn = self.Ds.pre_conv[2]
+        cin = cout = 2 * self.chn
+        n = self.B * self.T
+        from satflow_amd._hip import cpad
+
+        x = torch.randn(n, self.H, self.H, cpad(cin), device=self.dev)
+        w = torch.randn(cout, cin, 3, 3, device=self.dev) * 0.05
+        eng = F.ConvEngine([cin], cout)
+        with torch.no_grad():
+            t = event_time(lambda: F.conv3x3(eng, x, w, None), iters=10)
+        flops = 2.0 * 9 * cin * cout * self.H * self.H * n
+        bf16 = satflow_amd_mode() != "f32"
+        peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak, "traffic": None,
+                "kernel": f"sf_conv3x3_fwd {cin}->{cout} @256x256 x {n} frames", "us_per_launch": t * 1e6,
+                "algorithmic_hbm_GBps": (n * self.H * self.H * (cpad(cin) + cpad(cout)) * 4) / t / 1e9}
+
+    def cpu_baseline(self):
+        from oracle import dgmr as OD  # checker / baseline only
+
+        T, C, H = self.T, self.C, self.H
+        PG = {k: v.detach().cpu().clone().requires_grad_(v.dtype.is_floating_point and not k.endswith(("_u", "_v")) and "running" not in k)
+              for k, v in self.G.state_dict().items()}
+        PS = {k: v.detach().cpu().clone().requires_grad_(not k.endswith(("_u", "_v"))) for k, v in self.Ds.state_dict().items()}
+        PT = {k: v.detach().cpu().clone().requires_grad_(not k.endswith(("_u", "_v"))) for k, v in self.Dt.state_dict().items()}
+        og = torch.optim.Adam([v for v in PG.values() if v.requires_grad], lr=5e-5, betas=(0.0, 0.999))
+        od = torch.optim.Adam([v for v in list(PS.values()) + list(PT.values()) if v.requires_grad], lr=2e-4, betas=(0.0, 0.999))
+        real, cls = self.real[:1].cpu(), self.cls[:1].cpu()
+        pool = torch.nn.functional.avg_pool2d
+
+        def scores(fr):  # fr [1,T,C,H,W]
+            tm = pool(fr.reshape(T, C, H, H), 2).view(1, T, C, H // 2, H // 2).permute(0, 2, 1, 3, 4)
+            return OD.spatial_discriminator(fr, cls, PS), OD.temporal_discriminator(tm, cls, PT)
+
+        def one():
+            z = torch.randn(1, self.in_dim)
+            fake = OD.generator(z, cls, PG, None, ch=self.ch, latent_dim=H // 16, n_frames=T)
+            od.zero_grad()
+            rs, rt = scores(real)
+            fs, ft = scores(fake.detach())
+            (torch.relu(1 - rs).mean() + torch.relu(1 + fs).mean() + torch.relu(1 - rt).mean() + torch.relu(1 + ft).mean()).backward()
+            od.step()
+            og.zero_grad()
+            gs, gt = scores(fake)
+            (-gs.mean() - gt.mean()).backward()
+            og.step()
+
+        return time_cpu(one, "oracle DGMR-style step (G forward, D update, G update, Adam), B=1 of the same workload, fp32", budget_s=25.0)
+
+
+def satflow_amd_mode() -> str:
+    from satflow_amd._hip import compute_dtype_name
+
+    return compute_dtype_name()
+
+
 class StubWorkload:
     """CPU stand-in with the workloads' interface: exercises this file's launch / timing / reporting plumbing under gloo
     (tests/test_ddp_cpu.py) - never a measurement."""
@@ -514,6 +658,8 @@ def build_workload(name: str, dev, batch: int, rank: int):
         return CloudGANWorkload(dev, batch, rank)
     if name == "stlstm":
         return STLSTMWorkload(dev, batch, rank)
+    if name == "dgmr":
+        return DGMRWorkload(dev, batch, rank)
     if name == "stub":
         return StubWorkload(dev, batch, rank)
     raise SystemExit(f"unknown workload {name}")
@@ -572,7 +718,7 @@ def main(argv=None):
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=8)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "cloudgan", "stlstm", "stub"])
+    ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "cloudgan", "stlstm", "dgmr", "stub"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 8; with --scaling strong: global batch / N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="weak: fixed per-GPU batch (default, 8/GPU); strong: fixed global batch (--global-batch, BASELINE cfg 4: 64) split over the ranks")
@@ -595,7 +741,7 @@ def main(argv=None):
             raise SystemExit(f"--scaling strong: global batch {args.global_batch} is not divisible by {world} ranks")
         batch = args.global_batch // world
     else:
-        batch = args.batch if args.batch is not None else 8
+        batch = args.batch if args.batch is not None else (2 if args.workload == "dgmr" else 8)
     stub = args.workload == "stub"
     import satflow_amd
 
@@ -620,7 +766,8 @@ def main(argv=None):
             "metric": "samples/sec + per-step ms, MetNet 12ch 256x256 T=24->12 at 1/2/4/8 GPUs" if args.workload == "metnet" else
                       ("samples/sec + per-step ms, ConvLSTM 12ch 128x128 T=12->6" if args.workload == "convlstm" else
                        ("samples/sec + per-step ms, CloudGAN (ConvLSTM generator + PatchGAN) 12ch 128x128 T=12->6" if args.workload == "cloudgan" else
-                        ("samples/sec + per-step ms, ST-LSTM cell (memory decoupling) 12ch 64x64 T=6" if args.workload == "stlstm" else "stub"))),
+                        ("samples/sec + per-step ms, ST-LSTM cell (memory decoupling) 12ch 64x64 T=6" if args.workload == "stlstm" else
+                         ("samples/sec + per-step ms, DGMR-style GAN generator+discriminator step 12ch 256x256" if args.workload == "dgmr" else "stub")))),
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
             "dtype": "f32" if args.dtype == "f32" else "bf16",

@@ -450,7 +450,8 @@ int sf_bce_logits_loss(sfTensor logits, float label, float label_odd, int64_t ro
  * ------------------------------------------------------------------------------------------- */
 /* SpectralNorm._update_u_v (Normalization.py:19-31): `power_iterations` rounds of v = l2n(W^T u), u = l2n(W v) on the
  * [height][width] view of w_bar (u [height], v [width] are UPDATED IN PLACE - the module's persistent state), then
- * sigma = u . (W v) and w_out = w_bar / sigma.  workspace: width + height floats. */
+ * sigma = u . (W v) and w_out = w_bar / sigma.  workspace: sf_spectral_norm_workspace_floats() floats. */
+size_t sf_spectral_norm_workspace_floats(int32_t height, int32_t width);
 int sf_spectral_norm_fwd(const float* w_bar, int32_t height, int32_t width, float* u, float* v, int32_t power_iterations,
                          float* w_out, float* sigma, float* workspace, sfStream stream);
 /* Its backward (u, v constants as in the reference, which iterates on .data): dw_bar = g / sigma - (<g, w_bar> / sigma^2) u v^T.
@@ -470,6 +471,14 @@ int sf_expand2(sfTensor x, int64_t n_in, int32_t h, int32_t w, int32_t texp, int
  * y[t][p][dt * C + c] = x[t + dt - 1][p][c] (zero outside the clip), time-major dense x [T][pixels_per_frame][C]; and its adjoint. */
 int sf_time_stack3_fwd(sfTensor x, int32_t T, int64_t pixels_per_frame, sfTensor y, sfStream stream);
 int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTensor gx, sfStream stream);
+/* A 5x5 'same' convolution (the generator's ConvGRU, Generator.py:29-68 kernel_sizes 5) as ONE 3x3 convolution on the MFMA kernels:
+ * ys [n][h+4][w+4][4C], ys[q][s*C + c] = x[q - 2 + d_s][c] (zero outside the image), d_s = (2 (s>>1) - 1, 2 (s&1) - 1): the input on a
+ * domain padded by 2, shifted four ways and stacked as channels; the 5x5 kernel is covered by four 3x3 tiles at offsets {0,2}^2
+ * (shared middle row / column zeroed in the second tile) and the result is the interior of conv3x3(ys, tiles).  _bwd: the adjoint.
+ * sf_border: pad == 0 crops a border of `border` pixels (x [n][h+2b][w+2b] -> y [n][h][w]), pad != 0 adds a zero border. */
+int sf_pad_shift_stack4_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream);
+int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream);
+int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32_t pad, sfTensor y, sfStream stream);
 /* ConditionalNorm (Normalization.py:76-85) behind its statistics, fused with what follows it in GResBlock.forward (:63-70,75-78):
  * y = act(gamma[img][c] * (x - mean[c]) * rstd[c] + beta[img][c]), embed [n][2 * creal] = gamma | beta (the Linear's output),
  * relu: F.relu, up: nearest x2 up-sampling of the result (y [n][2h][2w]).  mean / rstd: sf_batchnorm_train_fwd without affine. */

@@ -111,12 +111,16 @@ PROTOTYPES = {
     "sf_l1_loss": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_bce_logits_loss": (C.c_int, [sfTensor, C.c_float, C.c_float, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, C.c_float, _vp]),
+    "sf_spectral_norm_workspace_floats": (_sz, [_i32, _i32]),
     "sf_spectral_norm_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),
     "sf_spectral_norm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i32, _vp, _vp, _vp]),
     "sf_pool2": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, C.c_float, sfTensor, sfTensor, _vp]),
     "sf_expand2": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, C.c_float, sfTensor, _vp]),
     "sf_time_stack3_fwd": (C.c_int, [sfTensor, _i32, _i64, sfTensor, _vp]),
     "sf_time_stack3_bwd": (C.c_int, [sfTensor, _i32, _i64, sfTensor, _vp]),
+    "sf_pad_shift_stack4_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
+    "sf_pad_shift_stack4_bwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
+    "sf_border": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, sfTensor, _vp]),
     "sf_film_act_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, sfTensor, _vp]),
     "sf_film_act_bwd_workspace_floats": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sf_film_act_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, sfTensor, _vp, _vp, _vp]),

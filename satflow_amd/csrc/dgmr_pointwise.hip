@@ -38,11 +38,20 @@ __device__ __forceinline__ float block_sum(float v, float* red) {  // 256 thread
 
 // ---- spectral normalisation (Normalization.py:19-31) ------------------------------------------------------------------
 // vraw[j] = sum_i W[i][j] u[i]
-__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, int h, int w, const float* __restrict__ u, float* __restrict__ vraw) {
+// grid (column blocks, row slices): slice r sums its rows into part[r][j]; sn_sum_slices_kernel adds the slices in a fixed order
+__global__ __launch_bounds__(256) void sn_wt_u_kernel(const float* __restrict__ W, int h, int w, const float* __restrict__ u, float* __restrict__ part) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  if (j >= w) return;
+  const int per = (h + gridDim.y - 1) / gridDim.y, i0 = blockIdx.y * per, i1 = i0 + per < h ? i0 + per : h;
+  float s = 0.f;
+  for (int i = i0; i < i1; ++i) s = __builtin_fmaf(W[(size_t)i * w + j], u[i], s);
+  part[(size_t)blockIdx.y * w + j] = s;
+}
+__global__ __launch_bounds__(256) void sn_sum_slices_kernel(const float* __restrict__ part, int slices, int w, float* __restrict__ vraw) {
   const int j = blockIdx.x * 256 + threadIdx.x;
   if (j >= w) return;
   float s = 0.f;
-  for (int i = 0; i < h; ++i) s = __builtin_fmaf(W[(size_t)i * w + j], u[i], s);
+  for (int r = 0; r < slices; ++r) s += part[(size_t)r * w + j];
   vraw[j] = s;
 }
 // v = vraw / (|vraw| + eps) (block 0 stores it);  uraw[i] = sum_j W[i][j] v[j]   - one workgroup per row
@@ -178,6 +187,70 @@ __global__ __launch_bounds__(256) void tstack3_bwd_kernel(const float* __restric
     if (t + 1 < T) s += ld4(gy + ((long long)(t + 1) * per + p) * 3 * C + c);
     if (t >= 1) s += ld4(gy + ((long long)(t - 1) * per + p) * 3 * C + 2 * C + c);
     st4(gx + r * C + c, s);
+  }
+}
+
+
+// ---- a 5x5 'same' convolution as ONE 3x3 convolution ------------------------------------------------------------------
+// The 5x5 kernel is covered by four 3x3 tiles at offsets {0, 2}^2 (the shared middle row / column zeroed in the second tile), each
+// reading the input shifted by (2 ty - 1, 2 tx - 1).  On a domain padded by 2 on every side no tap of an interior output touches
+// the 3x3 kernel's own zero padding, so the shifted copies can be stacked as channels of ONE tensor:
+//   ys[n][q][s * C + c] = x[n][q - 2 + d_s][c]  (zero outside the image),  q in [0, H + 4) x [0, W + 4),  d_s = (2 ty - 1, 2 tx - 1)
+// and the 5x5 result is the interior of conv3x3(ys, W3).  pad_shift4_bwd is the adjoint; crop / zero-pad kernels cut the border.
+__global__ __launch_bounds__(256) void pad_shift4_fwd_kernel(const float* __restrict__ x, long long n, int h, int w, int q, float* __restrict__ y) {
+  const int H4 = h + 4, W4 = w + 4, C = q * 4;
+  const long long total = n * H4 * W4 * 4 * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int s = (int)(r % 4); r /= 4;
+    const int xx = (int)(r % W4); r /= W4;
+    const int yy = (int)(r % H4); const long long img = r / H4;
+    const int sy = yy - 2 + 2 * (s >> 1) - 1, sx = xx - 2 + 2 * (s & 1) - 1;
+    const f32x4 v = (sy >= 0 && sy < h && sx >= 0 && sx < w) ? ld4(x + ((img * h + sy) * (long long)w + sx) * C + c) : kZero4;
+    st4(y + ((img * H4 + yy) * (long long)W4 + xx) * 4 * C + s * C + c, v);
+  }
+}
+__global__ __launch_bounds__(256) void pad_shift4_bwd_kernel(const float* __restrict__ gy, long long n, int h, int w, int q, float* __restrict__ gx) {
+  const int H4 = h + 4, W4 = w + 4, C = q * 4;
+  const long long total = n * h * w * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int sx = (int)(r % w); r /= w;
+    const int sy = (int)(r % h); const long long img = r / h;
+    f32x4 a = kZero4;
+#pragma unroll
+    for (int s = 0; s < 4; ++s) {  // the padded position that read this pixel through shift s (always inside the padded domain)
+      const int yy = sy + 2 - (2 * (s >> 1) - 1), xx = sx + 2 - (2 * (s & 1) - 1);
+      a += ld4(gy + ((img * H4 + yy) * (long long)W4 + xx) * 4 * C + s * C + c);
+    }
+    st4(gx + idx * 4, a);
+  }
+}
+// y[n][yy][xx] = x[n][yy + b][xx + b] (crop) or, with pad != 0, y = x inside and 0 on a border of width b (the adjoint)
+__global__ __launch_bounds__(256) void border_kernel(const float* __restrict__ x, long long n, int h, int w, int b, int q, int pad, float* __restrict__ y) {
+  const int C = q * 4;
+  if (!pad) {  // x [h + 2b][w + 2b] -> y [h][w]
+    const long long total = n * h * w * q;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+      const int c = (int)(idx % q) * 4;
+      long long r = idx / q;
+      const int xx = (int)(r % w); r /= w;
+      const int yy = (int)(r % h); const long long img = r / h;
+      st4(y + idx * 4, ld4(x + ((img * (h + 2 * b) + yy + b) * (long long)(w + 2 * b) + xx + b) * C + c));
+    }
+  } else {     // x [h][w] -> y [h + 2b][w + 2b]
+    const int H2 = h + 2 * b, W2 = w + 2 * b;
+    const long long total = n * H2 * W2 * q;
+    for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+      const int c = (int)(idx % q) * 4;
+      long long r = idx / q;
+      const int xx = (int)(r % W2) - b; r /= W2;
+      const int yy = (int)(r % H2) - b; const long long img = r / H2;
+      const f32x4 v = (yy >= 0 && yy < h && xx >= 0 && xx < w) ? ld4(x + ((img * h + yy) * (long long)w + xx) * C + c) : kZero4;
+      st4(y + idx * 4, v);
+    }
   }
 }
 
@@ -444,6 +517,9 @@ __global__ __launch_bounds__(256) void dvdgru_out_bwd_kernel(const float* __rest
 
 extern "C" {
 
+static int sn_slices(int height) { const int s = height / 16; return s < 1 ? 1 : (s > 32 ? 32 : s); }
+size_t sf_spectral_norm_workspace_floats(int32_t height, int32_t width) { return (size_t)width + height + (size_t)sn_slices(height) * width; }
+
 int sf_spectral_norm_fwd(const float* w_bar, int32_t height, int32_t width, float* u, float* v, int32_t power_iterations, float* w_out, float* sigma,
                          float* workspace, sfStream stream) {
   SF_REQUIRE(w_bar && u && v && w_out && sigma && workspace && height >= 1 && width >= 1 && power_iterations >= 1,
@@ -451,8 +527,14 @@ int sf_spectral_norm_fwd(const float* w_bar, int32_t height, int32_t width, floa
   hipStream_t st = (hipStream_t)stream;
   float* vraw = workspace;
   float* uraw = workspace + width;
+  float* part = uraw + height;
+  const int slices = sn_slices(height);
   for (int it = 0; it < power_iterations; ++it) {
-    hipLaunchKernelGGL(sn_wt_u_kernel, dim3((width + 255) / 256), dim3(256), 0, st, w_bar, height, width, (const float*)u, vraw);
+    if (slices == 1) hipLaunchKernelGGL(sn_wt_u_kernel, dim3((width + 255) / 256, 1), dim3(256), 0, st, w_bar, height, width, (const float*)u, vraw);
+    else {
+      hipLaunchKernelGGL(sn_wt_u_kernel, dim3((width + 255) / 256, slices), dim3(256), 0, st, w_bar, height, width, (const float*)u, part);
+      hipLaunchKernelGGL(sn_sum_slices_kernel, dim3((width + 255) / 256), dim3(256), 0, st, (const float*)part, slices, width, vraw);
+    }
     hipLaunchKernelGGL(sn_w_v_kernel, dim3(height), dim3(256), 0, st, w_bar, height, width, (const float*)vraw, v, uraw);
     if (it + 1 < power_iterations) hipLaunchKernelGGL(sn_norm_u_kernel, dim3(1), dim3(256), 0, st, (const float*)uraw, height, u);
   }
@@ -511,6 +593,33 @@ int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTenso
   hipLaunchKernelGGL(tstack3_bwd_kernel, dim3(grid_of((long long)T * pixels_per_frame * (gx.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gy.ptr, T,
                      (long long)pixels_per_frame, gx.c / 4, (float*)gx.ptr);
   SF_CHECK_LAUNCH("time_stack3_bwd");
+  return 0;
+}
+
+int sf_pad_shift_stack4_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(y, 4 * x.c) && h >= 1 && w >= 1, "sf_pad_shift_stack4_fwd: dense fp32 x [n][h][w][C], y [n][h+4][w+4][4C]");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pad_shift4_fwd_kernel, dim3(grid_of(n * (h + 4) * (w + 4) * x.c)), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)n, h, w,
+                     x.c / 4, (float*)y.ptr);
+  SF_CHECK_LAUNCH("pad_shift_stack4_fwd");
+  return 0;
+}
+
+int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream) {
+  SF_REQUIRE(gx.ptr && okd(gx, gx.c) && okd(gy, 4 * gx.c) && h >= 1 && w >= 1, "sf_pad_shift_stack4_bwd: dense fp32 gy [n][h+4][w+4][4C], gx [n][h][w][C]");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pad_shift4_bwd_kernel, dim3(grid_of(n * h * w * (gx.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gy.ptr, (long long)n, h, w,
+                     gx.c / 4, (float*)gx.ptr);
+  SF_CHECK_LAUNCH("pad_shift_stack4_bwd");
+  return 0;
+}
+
+int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32_t pad, sfTensor y, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(y, x.c) && h >= 1 && w >= 1 && border >= 1, "sf_border: dense fp32 tensors of equal channel count, border >= 1");
+  if (n <= 0) return 0;
+  const long long work = pad ? n * (h + 2 * border) * (w + 2 * border) * (x.c / 4) : n * h * w * (x.c / 4);
+  hipLaunchKernelGGL(border_kernel, dim3(grid_of(work)), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)n, h, w, border, x.c / 4, pad, (float*)y.ptr);
+  SF_CHECK_LAUNCH("border");
   return 0;
 }
 

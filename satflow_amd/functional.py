@@ -175,6 +175,8 @@ class _ConvFn(torch.autograd.Function):
                 d0 = dcat
             else:
                 d1 = dcat
+        if not (ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])):
+            return None, d0, d1, None, None, None, None, None, None, None, None  # frozen parameters (a GAN's other network): no weight gradient
         dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=gy.device)
         db = torch.empty(weight.shape[0], dtype=torch.float32, device=gy.device) if has_bias else None
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
@@ -527,6 +529,8 @@ class _LinearFn(torch.autograd.Function):
             Wt = torch.zeros(Kp, gy.shape[-1], dtype=torch.float32, device=W.device)
             Wt[:, :N] = W.t()
             dx = K.linear_fwd(gy, Wt, None, Kp)
+        if not (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])):
+            return dx, None, None, None
         dW, db = K.linear_bwd_weight_any(gy, x, N, ctx.has_bias)
         return dx, dW, db, None
 

@@ -36,7 +36,7 @@ class _SpectralNormFn(torch.autograd.Function):
         assert u.numel() == height and v.numel() == width and u.is_contiguous() and v.is_contiguous()
         w = torch.empty_like(wb)
         sigma = torch.empty(1, dtype=torch.float32, device=wb.device)
-        ws = _ws(height + width, wb.device)
+        ws = _ws(lib().sf_spectral_norm_workspace_floats(height, width), wb.device)
         check(lib().sf_spectral_norm_fwd(wb.data_ptr(), height, width, u.data_ptr(), v.data_ptr(), int(power_iterations), w.data_ptr(), sigma.data_ptr(),
                                          ws.data_ptr(), stream_ptr()), "sf_spectral_norm_fwd")
         # the vectors this call ended with (a later call advances the module's own copies before the backward pass runs)
@@ -167,6 +167,76 @@ def conv_nhwc(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: Optional[F
         assert eng is not None
         return F.conv3x3(eng, x, weight, bias)
     return F.conv2d(x, weight, bias, 1, k // 2)
+
+
+class _PadShift4Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        n, h, w, c = x.shape
+        y = torch.empty(n, h + 4, w + 4, 4 * c, dtype=torch.float32, device=x.device)
+        check(lib().sf_pad_shift_stack4_fwd(T(x), n, h, w, T(y), stream_ptr()), "sf_pad_shift_stack4_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib().sf_pad_shift_stack4_bwd(T(g.contiguous()), n, h, w, T(gx), stream_ptr()), "sf_pad_shift_stack4_bwd")
+        return gx
+
+
+class _CropFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x: Tensor, border: int):
+        n, hp, wp, c = x.shape
+        h, w = hp - 2 * border, wp - 2 * border
+        y = torch.empty(n, h, w, c, dtype=torch.float32, device=x.device)
+        check(lib().sf_border(T(x), n, h, w, border, 0, T(y), stream_ptr()), "sf_border")
+        ctx.border = border
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.contiguous()
+        n, h, w, c = g.shape
+        b = ctx.border
+        gx = torch.empty(n, h + 2 * b, w + 2 * b, c, dtype=torch.float32, device=g.device)
+        check(lib().sf_border(T(g), n, h, w, b, 1, T(gx), stream_ptr()), "sf_border")
+        return gx, None
+
+
+_TILE_MASKS = {}
+
+
+def _tile_masks(dev):
+    if dev not in _TILE_MASKS:
+        row = torch.ones(3, 3, device=dev)
+        row[0, :] = 0
+        col = torch.ones(3, 3, device=dev)
+        col[:, 0] = 0
+        _TILE_MASKS[dev] = (row, col)
+    return _TILE_MASKS[dev]
+
+
+def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.ConvEngine") -> Tensor:
+    """``nn.Conv2d(k=5, padding=2)`` on the 3x3 MFMA kernels (``sf_pad_shift_stack4_fwd``: the input on a domain padded by 2, shifted
+    four ways, stacked as channels; the 5x5 kernel as four 3x3 tiles, tiny autograd-tracked weight slices; the interior of the result).
+    ``eng``: a ConvEngine for ``[4 * x lanes] -> cout``."""
+    O, I = weight.shape[0], weight.shape[1]
+    cp = x.shape[-1]
+    row, col = _tile_masks(weight.device)
+    tiles = []
+    for ty in (0, 1):
+        for tx in (0, 1):
+            t = weight[:, :, 2 * ty:2 * ty + 3, 2 * tx:2 * tx + 3]
+            if ty:
+                t = t * row   # the middle row of the 5x5 kernel belongs to the upper tile
+            if tx:
+                t = t * col
+            tiles.append(torch.nn.functional.pad(t, (0, 0, 0, 0, 0, cp - I)) if cp != I else t)
+    w3 = torch.cat(tiles, 1).contiguous()   # [O, 4*cp, 3, 3]
+    return _CropFn.apply(F.conv3x3(eng, _PadShift4Fn.apply(x.contiguous()), w3, bias), 2)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -8,10 +8,12 @@ from (parity UNPINNED, oracle/dgmr.py): ``ConvGRU(input_size, hidden_sizes, kern
 Execution on the HIP kernels: every gate convolution is split into its x-part and its h-part (a convolution over a concatenation is
 the sum of the convolutions of the parts), so nothing is concatenated; over a SEQUENCE (``run_sequence``) the x-parts of a layer
 run for all frames in one launch and only the h-parts + the two fused gate stages (``sf_dvdgru_*``) are sequential.
-3x3 kernels run on the MFMA convolution, 5x5 on ``sf_conv2d_*``.
+3x3 kernels run on the MFMA convolution, and so do 5x5 kernels: as ONE 3x3 convolution over four shifted copies of the padded input
+(``functional_gan.conv5x5_as_3x3``); other sizes on the direct ``sf_conv2d_*``.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional
 
 import torch
@@ -55,12 +57,14 @@ class ConvGRUCell(nn.Module):
         )
 
     def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
-        if self.kernel_size == 3:
-            key = (tag, w.shape[1], w.shape[0])
+        k = self.kernel_size
+        if k in (3, 5) and not (k == 5 and os.environ.get("SF_CONV5_DIRECT")):
+            cin = w.shape[1] if k == 3 else 4 * x.shape[-1]   # 5x5: four shifted copies of the (padded) input lanes
+            key = (tag, cin, w.shape[0])
             if key not in self._eng:
-                self._eng[key] = FG.FreshConvEngine([w.shape[1]], w.shape[0])
-            return F.conv3x3(self._eng[key], x, w, b)
-        return FG.conv_nhwc(x, w, b)
+                self._eng[key] = FG.FreshConvEngine([cin], w.shape[0])
+            return F.conv3x3(self._eng[key], x, w, b) if k == 3 else FG.conv5x5_as_3x3(x, w, b, self._eng[key])
+        return FG.conv_nhwc(x, w, b)   # any other size (and SF_CONV5_DIRECT=1, the A/B switch): the direct fp32 convolution
 
     def x_parts(self, x: Tensor, W: dict):
         """x-parts of the three gates for any number of frames at once: ``(gx_zr [.., 2*hidp], gx_o [.., hidp])`` incl. the biases."""

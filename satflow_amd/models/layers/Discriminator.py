@@ -119,7 +119,7 @@ class GBlock(nn.Module):
         return F.nhwc_to_nchw(self.run(F.nchw_to_nhwc(input.float()), condition), self.out_channel)
 
 
-def _head(owner, feat: Tensor, class_id: Tensor, frames_per_sample: int, order: Tensor = None) -> Tensor:
+def _head(owner, feat: Tensor, class_id: Tensor, frames_per_sample: int, order: Tensor = None, time_major: bool = False) -> Tensor:
     """Shared tail (reference ``:286-314`` / ``:452-478``): ReLU, sum over the pixels, spectral-normed linear score plus the
     projection onto the spectral-normed class embedding.  ``feat`` NHWC ``[N,h,w,Cp]`` -> ``[N]`` scores (rows permuted by ``order``)."""
     c = owner.linear.module.in_features
@@ -129,7 +129,7 @@ def _head(owner, feat: Tensor, class_id: Tensor, frames_per_sample: int, order: 
     n = pooled.shape[0]
     w_lin = owner.linear.compute_weight()                                    # [1, C]
     out_linear = F.linear(pooled, w_lin, owner.linear.module.bias)[:, 0]
-    ids = class_id.view(-1, 1).repeat(1, frames_per_sample).view(-1)
+    ids = class_id.repeat(frames_per_sample) if time_major else class_id.view(-1, 1).repeat(1, frames_per_sample).view(-1)
     emb = owner.embed.compute_weight()[ids]                                  # [N, C] row gather
     prod = FG.bmm(pooled[:, :c].unsqueeze(1), emb.unsqueeze(2)).view(n)      # per-row dot products on the matrix cores
     return out_linear + prod
@@ -158,8 +158,8 @@ class SpatialDiscriminator(nn.Module):
         self.embed.weight.data.uniform_(-0.1, 0.1)
         self.embed = SpectralNorm(self.embed)
 
-    def run(self, frames: Tensor, class_id: Tensor, T_frames: int) -> Tensor:
-        """NHWC frames ``[B*T,H,W,Cp]`` in the reference's (b, t) order -> scores ``[B*T]``."""
+    def run(self, frames: Tensor, class_id: Tensor, T_frames: int, time_major: bool = False) -> Tensor:
+        """NHWC frames ``[B*T,H,W,Cp]`` in the reference's (b, t) order (``time_major``: image t*B + b) -> scores in the same order."""
         out = self.pre_conv[0].run(frames)
         out = FG.relu(out)
         out = self.pre_conv[2].run(out)
@@ -168,7 +168,7 @@ class SpatialDiscriminator(nn.Module):
         out = self.attn.run(out)
         for blk in self.conv2:
             out = blk.run(out)
-        return _head(self, out, class_id, T_frames)
+        return _head(self, out, class_id, T_frames, time_major=time_major)
 
     def forward(self, x, class_id):
         """``x [B,T,C,W,H]`` -> one score per frame ``[B*T]`` (reference ``:263-314``)."""

@@ -140,7 +140,7 @@ class FlatAdam(torch.optim.Optimizer):
             self._sync = old
 
     def _guard_hook(self, _param) -> None:
-        if self._reduced:
+        if self._reduced and self._sync:
             raise RuntimeError("FlatAdam: a backward pass reached the gradient buffer after this step's all-reduce; the local gradients "
                                "would be added to the already reduced sum.  Call step() / zero_grad() first, or accumulate inside "
                                "`optimizer.no_sync()` before the exchanging backward.")
