@@ -129,6 +129,37 @@ int main(void) {
   REFUSED(sf_stlstm_gates_bwd(N0, N0, N0, N0, N0, N0, N0, a16, a16, 64, 16, a192, a64, a48, a16, a16, SF_F32, st));   /* no saved gates */
   REFUSED(sf_stlstm_out_fwd(a16, a16, a16, 64, 12, a16, N0, SF_F32, st));                                             /* hidp not padded */
   REFUSED(sf_stlstm_out_bwd(a16, a16, 64, 16, a16, a16, SF_F32, st));                                                 /* saved narrower than 2*hidp */
+  /* DGMR / attention stages */
+  REFUSED(sf_spectral_norm_fwd(ok, 8, 8, ok, ok, 0, ok, ok, ok, st));                                    /* zero power iterations */
+  REFUSED(sf_spectral_norm_fwd(ok, 8, 8, 0, ok, 1, ok, ok, ok, st));                                     /* no u */
+  REFUSED(sf_spectral_norm_bwd(ok, ok, ok, ok, 0, 8, 8, ok, ok, st));                                    /* no sigma */
+  REFUSED(sf_pool2(a16, 4, 4, 4, 3, 1, 0.25f, N0, a16, st));                                             /* temporal window 3 */
+  REFUSED(sf_pool2(a16, 5, 4, 4, 2, 2, 0.125f, N0, a16, st));                                            /* images do not split into frames */
+  REFUSED(sf_pool2(b16, 4, 4, 4, 1, 1, 0.25f, N0, a16, st));                                             /* bf16 storage */
+  REFUSED(sf_expand2(a16, 4, 4, 4, 1, 1, 1.f, m16, st));                                                 /* misaligned output */
+  REFUSED(sf_time_stack3_fwd(a16, 4, 64, a16, st));                                                      /* output must have 3x the lanes */
+  REFUSED(sf_time_stack3_bwd(a16, 4, 64, a16, st));
+  REFUSED(sf_pad_shift_stack4_fwd(a16, 1, 8, 8, a48, st));                                               /* output must have 4x the lanes */
+  REFUSED(sf_pad_shift_stack4_bwd(a48, 1, 8, 8, a16, st));
+  REFUSED(sf_border(a16, 1, 8, 8, 0, 0, a16, st));                                                       /* empty border */
+  REFUSED(sf_border(a16, 1, 8, 8, 2, 1, a64, st));                                                       /* channel mismatch */
+  REFUSED(sf_film_act_fwd(a16, 2, 8, 8, ok, ok, 0, 12, 1, 0, a16, st));                                  /* no embedding */
+  REFUSED(sf_film_act_fwd(a16, 2, 8, 8, ok, ok, ok, 20, 1, 0, a16, st));                                 /* more real channels than lanes */
+  REFUSED(sf_film_act_bwd(a16, a16, 2, 8, 8, ok, ok, ok, 12, 1, 0, a16, ok, 0, st));                     /* no workspace */
+  REFUSED(sf_relu_sum_pixels_fwd(a16, 2, 64, 0, st));                                                    /* no output */
+  REFUSED(sf_relu_sum_pixels_bwd(ok, a16, 2, 64, a64, st));                                              /* channel mismatch */
+  REFUSED(sf_axpy(ok, ok, 0, 1.f, 6, ok, st));                                                           /* length not a multiple of 4 */
+  REFUSED(sf_axpy(mis, 0, 0, 1.f, 8, ok, st));                                                           /* misaligned */
+  REFUSED(sf_dot(ok, ok, 8, ok, 0, st));                                                                 /* no workspace */
+  REFUSED(sf_tanh(ok, 0, 10, ok, st));                                                                   /* length not a multiple of 4 */
+  REFUSED(sf_dvdgru_gates_fwd(a16, N0, N0, 64, 16, a16, a16, st));                                       /* gx narrower than 2*hidp */
+  REFUSED(sf_dvdgru_gates_bwd(N0, N0, a16, N0, 64, 16, a16, N0, st));                                    /* zr narrower than 2*hidp */
+  REFUSED(sf_dvdgru_out_fwd(a16, N0, a16, N0, 64, 16, N0, a16, st));                                     /* zr narrower than 2*hidp */
+  REFUSED(sf_dvdgru_out_bwd(a16, a16, a16, N0, 64, 16, a16, a16, N0, st));
+  REFUSED(sf_bmm_f32(ok, 0, 8, 1, 0, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                   /* no B */
+  REFUSED(sf_bmm_f32(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                  /* empty inner dimension */
+  REFUSED(sf_softmax_rows_fwd(ok, 4, 0, ok, st));                                                        /* empty rows */
+  REFUSED(sf_softmax_rows_bwd(ok, 0, 4, 8, ok, st));                                                     /* no softmax output */
   /* size queries never fail, must not overflow */
   printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32) + sf_conv3x3_bwd_weight_folded_workspace_bytes(256, 256, 2304, 32, 32, 24),
          sf_linear_bwd_weight_workspace_bytes(384, 64, 24576), sf_conv2d_bwd_weight_workspace_bytes(48, 64, 64, 12, 32, 4, 4));
