@@ -72,6 +72,8 @@ PROTOTYPES = {
     "sf_leadtime_pool_workspace_floats": (_sz, [_i32, _i32]),
     "sf_stlstm_gates_fwd": (C.c_int, [sfTensor] * 5 + [_i64, _i32, C.c_float] + [sfTensor] * 7 + [_i32, _vp]),
     "sf_stlstm_gates_bwd": (C.c_int, [sfTensor] * 9 + [_i64, _i32] + [sfTensor] * 5 + [_i32, _vp]),
+    "sf_layernorm_chw_fwd": (C.c_int, [sfTensor, _i64, _i64, _i32, _i32, _i32, _vp, _vp, C.c_float, _vp, sfTensor, _vp]),
+    "sf_layernorm_chw_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i64, _i32, _i32, _i32, _vp, C.c_float, _vp, _vp, sfTensor, _vp, _vp, _vp]),
     "sf_stlstm_out_fwd": (C.c_int, [sfTensor] * 3 + [_i64, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_stlstm_out_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_leadtime_pool_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _vp, sfTensor, _i32, _vp]),

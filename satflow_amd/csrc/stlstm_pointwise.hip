@@ -135,6 +135,120 @@ __global__ __launch_bounds__(256) void stlstm_out_bwd_kernel(const float* __rest
   }
 }
 
+
+// ---- nn.LayerNorm([C', W, W]) behind the cell's convolutions (layer_norm=True, reference :20-62) ---------------------------
+// Activations: NHWC with GATE-MAJOR PADDED lanes: lane l = g * hidp + j is channel g * hid + j of the reference (j < hid), pad lanes
+// are zero and take no part.  Statistics per sample over all real channels and pixels; the affine parameters keep the reference's
+// [C'][pixels] (CHW) layout.  Per sample the sums are taken by LN_SLICES workgroups in double precision; the consumers add the slices.
+#define LN_SLICES 32
+struct LnGeom { int gates, hid, hidp; long long pixels; };
+__device__ __forceinline__ int ln_channel(const LnGeom& g, int lane) {  // real channel of a lane or -1
+  const int gt = lane / g.hidp, j = lane - gt * g.hidp;
+  return j < g.hid ? gt * g.hid + j : -1;
+}
+// partial[n][slice][2] = (sum a, sum b): mode 0: a = x, b = x^2; mode 1 (backward): a = dy*gamma, b = dy*gamma*xhat
+__global__ __launch_bounds__(256) void ln_sums_kernel(const float* __restrict__ x, const float* __restrict__ dy, const float* __restrict__ gamma,
+                                                      const double* __restrict__ fwd_partial, float eps, LnGeom g, double* __restrict__ partial) {
+  __shared__ double red[2][4];
+  const int lanes = g.gates * g.hidp;
+  const long long n = blockIdx.y, per = (g.pixels + LN_SLICES - 1) / LN_SLICES, p0 = (long long)blockIdx.x * per, p1 = p0 + per < g.pixels ? p0 + per : g.pixels;
+  const double cnt = (double)g.pixels * g.gates * g.hid;
+  float mean = 0.f, rstd = 0.f;
+  if (dy) {
+    double s0 = 0, s1 = 0;
+    for (int k = 0; k < LN_SLICES; ++k) { s0 += fwd_partial[(n * LN_SLICES + k) * 2]; s1 += fwd_partial[(n * LN_SLICES + k) * 2 + 1]; }
+    const double mu = s0 / cnt, var = s1 / cnt - mu * mu;
+    mean = (float)mu; rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  }
+  double a = 0, b = 0;
+  const long long work = (p1 > p0 ? p1 - p0 : 0) * lanes;
+  for (long long e = threadIdx.x; e < work; e += 256) {
+    const long long p = p0 + e / lanes;
+    const int lane = (int)(e % lanes), c = ln_channel(g, lane);
+    if (c < 0) continue;
+    const float v = x[(n * g.pixels + p) * lanes + lane];
+    if (!dy) { a += v; b += (double)v * v; }
+    else {
+      const float d = dy[(n * g.pixels + p) * lanes + lane] * gamma[(long long)c * g.pixels + p];
+      a += d; b += (double)d * ((v - mean) * rstd);
+    }
+  }
+  for (int o = 32; o > 0; o >>= 1) { a += __shfl_down(a, o); b += __shfl_down(b, o); }
+  if ((threadIdx.x & 63) == 0) { red[0][threadIdx.x >> 6] = a; red[1][threadIdx.x >> 6] = b; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    partial[(n * LN_SLICES + blockIdx.x) * 2] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+    partial[(n * LN_SLICES + blockIdx.x) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+  }
+}
+__device__ __forceinline__ void ln_stats(const double* partial, long long n, double cnt, float eps, float& mean, float& rstd) {
+  double s0 = 0, s1 = 0;
+  for (int k = 0; k < LN_SLICES; ++k) { s0 += partial[(n * LN_SLICES + k) * 2]; s1 += partial[(n * LN_SLICES + k) * 2 + 1]; }
+  const double mu = s0 / cnt, var = s1 / cnt - mu * mu;
+  mean = (float)mu; rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+}
+// y = (x - mean_n) * rstd_n * gamma[c][p] + beta[c][p]  (pad lanes: 0)
+__global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, float eps, LnGeom g, long long n_samples, float* __restrict__ y) {
+  const int lanes = g.gates * g.hidp;
+  const double cnt = (double)g.pixels * g.gates * g.hid;
+  const long long total = n_samples * g.pixels * lanes;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int lane = (int)(e % lanes), c = ln_channel(g, lane);
+    const long long pp = e / lanes, p = pp % g.pixels, n = pp / g.pixels;
+    float o = 0.f;
+    if (c >= 0) {
+      float mean, rstd;
+      ln_stats(partial, n, cnt, eps, mean, rstd);
+      o = (x[e] - mean) * rstd * gamma[(long long)c * g.pixels + p] + beta[(long long)c * g.pixels + p];
+    }
+    y[e] = o;
+  }
+}
+// dx = rstd_n * (dxhat - mean_n(dxhat) - xhat * mean_n(dxhat * xhat)), dxhat = dy * gamma
+__global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy, const double* __restrict__ fpart,
+                                                           const double* __restrict__ bpart, const float* __restrict__ gamma, float eps, LnGeom g,
+                                                           long long n_samples, float* __restrict__ dx) {
+  const int lanes = g.gates * g.hidp;
+  const double cnt = (double)g.pixels * g.gates * g.hid;
+  const long long total = n_samples * g.pixels * lanes;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int lane = (int)(e % lanes), c = ln_channel(g, lane);
+    const long long pp = e / lanes, p = pp % g.pixels, n = pp / g.pixels;
+    float o = 0.f;
+    if (c >= 0) {
+      float mean, rstd;
+      ln_stats(fpart, n, cnt, eps, mean, rstd);
+      double s0 = 0, s1 = 0;
+      for (int k = 0; k < LN_SLICES; ++k) { s0 += bpart[(n * LN_SLICES + k) * 2]; s1 += bpart[(n * LN_SLICES + k) * 2 + 1]; }
+      const float m0 = (float)(s0 / cnt), m1 = (float)(s1 / cnt);
+      const float xh = (x[e] - mean) * rstd;
+      o = rstd * (dy[e] * gamma[(long long)c * g.pixels + p] - m0 - xh * m1);
+    }
+    dx[e] = o;
+  }
+}
+// dgamma[c][p] = sum_n dy * xhat, dbeta[c][p] = sum_n dy: one thread per (pixel, lane), coalesced over lanes
+__global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ dy, const double* __restrict__ fpart, float eps,
+                                                            LnGeom g, long long n_samples, float* __restrict__ dgamma, float* __restrict__ dbeta) {
+  const int lanes = g.gates * g.hidp;
+  const double cnt = (double)g.pixels * g.gates * g.hid;
+  const long long total = g.pixels * lanes;
+  for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
+    const int lane = (int)(e % lanes), c = ln_channel(g, lane);
+    if (c < 0) continue;
+    const long long p = e / lanes;
+    float sg = 0.f, sb = 0.f;
+    for (long long n = 0; n < n_samples; ++n) {
+      float mean, rstd;
+      ln_stats(fpart, n, cnt, eps, mean, rstd);
+      const float d = dy[n * total + e];
+      sg = __builtin_fmaf(d, (x[n * total + e] - mean) * rstd, sg); sb += d;
+    }
+    dgamma[(long long)c * g.pixels + p] = sg; dbeta[(long long)c * g.pixels + p] = sb;
+  }
+}
+
 bool okf(const sfTensor& t, int c) {  // fp32, 16-byte aligned pixels, at least c lanes
   return t.ptr && t.dtype == SF_F32 && (((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.c >= c;
 }
@@ -187,6 +301,39 @@ int sf_stlstm_gates_bwd(sfTensor d_c_new, sfTensor d_m_new, sfTensor d_mem, sfTe
   p.pixels = pixels; p.hidp = hidp;
   hipLaunchKernelGGL(stlstm_gates_bwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("stlstm_gates_bwd");
+  return 0;
+}
+
+static bool ln_ok(const sfTensor& t, int lanes) { return t.ptr && t.dtype == SF_F32 && t.c == lanes && t.stride == lanes; }
+
+int sf_layernorm_chw_fwd(sfTensor x, int64_t n, int64_t pixels, int32_t gates, int32_t hid, int32_t hidp, const float* gamma, const float* beta, float eps,
+                         double* partial, sfTensor y, sfStream stream) {
+  SF_REQUIRE(gates >= 1 && hid >= 1 && hidp >= hid && ln_ok(x, gates * hidp) && ln_ok(y, gates * hidp) && gamma && beta && partial,
+             "sf_layernorm_chw_fwd: dense fp32 x / y of gates * hidp lanes, affine parameters, partial sums buffer");
+  if (n <= 0 || pixels <= 0) return 0;
+  const LnGeom g{gates, hid, hidp, (long long)pixels};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ln_sums_kernel, dim3(LN_SLICES, (unsigned)n), dim3(256), 0, st, (const float*)x.ptr, (const float*)nullptr, (const float*)nullptr,
+                     (const double*)nullptr, eps, g, partial);
+  hipLaunchKernelGGL(ln_apply_kernel, dim3(grid_of(n * pixels * gates * hidp)), dim3(256), 0, st, (const float*)x.ptr, (const double*)partial, gamma, beta, eps, g,
+                     (long long)n, (float*)y.ptr);
+  SF_CHECK_LAUNCH("layernorm_chw_fwd");
+  return 0;
+}
+
+int sf_layernorm_chw_bwd(sfTensor x, sfTensor dy, int64_t n, int64_t pixels, int32_t gates, int32_t hid, int32_t hidp, const float* gamma, float eps,
+                         const double* partial, double* bwd_partial, sfTensor dx, float* dgamma, float* dbeta, sfStream stream) {
+  SF_REQUIRE(gates >= 1 && hid >= 1 && hidp >= hid && ln_ok(x, gates * hidp) && ln_ok(dy, gates * hidp) && ln_ok(dx, gates * hidp) && gamma && partial && bwd_partial &&
+                 dgamma && dbeta, "sf_layernorm_chw_bwd: dense fp32 tensors of gates * hidp lanes, gamma, the forward's partial sums, scratch, parameter gradients");
+  if (n <= 0 || pixels <= 0) return 0;
+  const LnGeom g{gates, hid, hidp, (long long)pixels};
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(ln_sums_kernel, dim3(LN_SLICES, (unsigned)n), dim3(256), 0, st, (const float*)x.ptr, (const float*)dy.ptr, gamma, partial, eps, g, bwd_partial);
+  hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(grid_of(n * pixels * gates * hidp)), dim3(256), 0, st, (const float*)x.ptr, (const float*)dy.ptr, partial,
+                     (const double*)bwd_partial, gamma, eps, g, (long long)n, (float*)dx.ptr);
+  hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(grid_of(pixels * gates * hidp)), dim3(256), 0, st, (const float*)x.ptr, (const float*)dy.ptr, partial, eps, g,
+                     (long long)n, dgamma, dbeta);
+  SF_CHECK_LAUNCH("layernorm_chw_bwd");
   return 0;
 }
 

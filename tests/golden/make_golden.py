@@ -295,16 +295,24 @@ def cloudgan_cases():
 
 def stlstm_cases():
     """ST-LSTM cell with memory decoupling: reference import -> inputs, weights, the five outputs and every gradient
-    for a random cotangent on all five outputs."""
+    for a random cotangent on all five outputs.  "ln*": layer_norm=True (the LayerNorm affine parameters spread away from 1 / 0);
+    "*12": a hidden width that is not a multiple of the kernels' channel padding."""
     from satflow.models.layers.SpatioTemporalLSTMCell_memory_decoupling import SpatioTemporalLSTMCell
     from oracle import stlstm as OS
 
-    for name, (cin, nh, width, B, scale) in {"a": (8, 16, 12, 2, 1.0), "b": (12, 32, 16, 1, 1.0), "odd": (5, 16, 9, 2, 1.0), "hot": (8, 32, 10, 2, 4.0)}.items():
+    specs = {"a": (8, 16, 12, 2, 1.0, False), "b": (12, 32, 16, 1, 1.0, False), "odd": (5, 16, 9, 2, 1.0, False), "hot": (8, 32, 10, 2, 4.0, False),
+             "ln": (8, 16, 12, 2, 2.0, True), "ln12": (5, 12, 9, 3, 2.0, True), "h12": (7, 12, 10, 2, 3.0, False)}
+    for name, (cin, nh, width, B, scale, lnorm) in specs.items():
         gen = torch.Generator().manual_seed(zlib_seed("stlstm" + name))
-        cell = SpatioTemporalLSTMCell(cin, nh, width, 3, 1, False)
+        cell = SpatioTemporalLSTMCell(cin, nh, width, 3, 1, lnorm)
         with torch.no_grad():
-            for p_ in cell.parameters():
-                p_.copy_((torch.rand(p_.shape, generator=gen) * 2 - 1) * scale * (1.0 / (p_.shape[1] * p_.shape[2] * p_.shape[3]) ** 0.5))
+            for k_, p_ in cell.named_parameters():
+                if p_.dim() == 4:
+                    p_.copy_((torch.rand(p_.shape, generator=gen) * 2 - 1) * scale * (1.0 / (p_.shape[1] * p_.shape[2] * p_.shape[3]) ** 0.5))
+                elif k_.endswith("weight"):  # LayerNorm gamma
+                    p_.copy_(1 + 0.3 * torch.randn(p_.shape, generator=gen))
+                else:
+                    p_.copy_(0.2 * torch.randn(p_.shape, generator=gen))
         ins = {k: torch.randn(B, c_, width, width, generator=gen).requires_grad_() for k, c_ in (("x", cin), ("h", nh), ("c", nh), ("m", nh))}
         outs = cell(ins["x"], ins["h"], ins["c"], ins["m"])
         names = ("h_new", "c_new", "m_new", "delta_c", "delta_m")
@@ -317,15 +325,19 @@ def stlstm_cases():
         rec.update(cots)
         rec.update({f"w.{k}": v.detach() for k, v in params.items()})
         rec.update({f"d_{k}": g for k, g in zip(list(ins.keys()) + [f"w.{k}" for k in params], grads)})
+        rec["layer_norm"] = int(lnorm)
         # the restatement must reproduce the reference module
+        ln = {t: (params[f"conv_{t}.1.weight"], params[f"conv_{t}.1.bias"]) for t in "xhmo"} if lnorm else None
         oo = OS.stlstm_cell(ins["x"], ins["h"], ins["c"], ins["m"], params["conv_x.0.weight"], params["conv_h.0.weight"], params["conv_m.0.weight"],
-                            params["conv_o.0.weight"], params["conv_last.weight"])
+                            params["conv_o.0.weight"], params["conv_last.weight"], ln)
         for k, a, b in zip(names, oo, outs):
-            assert torch.allclose(a, b, rtol=1e-6, atol=1e-7), f"oracle stlstm mismatch {name}.{k}"
+            assert torch.allclose(a, b, rtol=1e-6, atol=1e-6), f"oracle stlstm mismatch {name}.{k}"
         np.savez(f"{HERE}/stlstm_{name}.npz", **_np(rec))
         print(f"stlstm {name}: ok  |h'|max={float(outs[0].abs().max()):.4f}")
     with open(f"{HERE}/stlstm_state_dict_keys.txt", "w") as f:
         f.write("\n".join(SpatioTemporalLSTMCell(4, 8, 8, 3, 1, False).state_dict().keys()) + "\n")
+    with open(f"{HERE}/stlstm_ln_state_dict_keys.txt", "w") as f:
+        f.write("\n".join(SpatioTemporalLSTMCell(4, 8, 8, 3, 1, True).state_dict().keys()) + "\n")
 
 
 def _randomise(module, gen, wscale=1.0, bscale=0.3):
