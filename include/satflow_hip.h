@@ -489,6 +489,13 @@ int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTenso
 int sf_pad_shift_stack4_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream);
 int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream);
 int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32_t pad, sfTensor y, sfStream stream);
+/* nn.MaxPool3d of the in-tree attention layers (satflow/models/layers/Attention.py:50: kernel (2,1,1) stride (pf,1,1); :127: kernel 2
+ * stride pf) over dense NHWC tokens x [batch][d0][d1][d2][C] -> y [batch][o0][o1][o2][C], o = (d - k) / s + 1; stride >= window.
+ * Backward: the gradient goes to the first maximum of each window in scan order (torch's tie rule), recomputed from x. */
+int sf_maxpool3d_fwd(sfTensor x, int64_t batch, int32_t d0, int32_t d1, int32_t d2, int32_t k0, int32_t k1, int32_t k2, int32_t s0,
+                     int32_t s1, int32_t s2, sfTensor y, sfStream stream);
+int sf_maxpool3d_bwd(sfTensor x, sfTensor gy, int64_t batch, int32_t d0, int32_t d1, int32_t d2, int32_t k0, int32_t k1, int32_t k2,
+                     int32_t s0, int32_t s1, int32_t s2, sfTensor gx, sfStream stream);
 /* ConditionalNorm (Normalization.py:76-85) behind its statistics, fused with what follows it in GResBlock.forward (:63-70,75-78):
  * y = act(gamma[img][c] * (x - mean[c]) * rstd[c] + beta[img][c]), embed [n][2 * creal] = gamma | beta (the Linear's output),
  * relu: F.relu, up: nearest x2 up-sampling of the result (y [n][2h][2w]).  mean / rstd: sf_batchnorm_train_fwd without affine. */

@@ -123,6 +123,8 @@ PROTOTYPES = {
     "sf_pad_shift_stack4_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
     "sf_pad_shift_stack4_bwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
     "sf_border": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, sfTensor, _vp]),
+    "sf_maxpool3d_fwd": (C.c_int, [sfTensor, _i64] + [_i32] * 9 + [sfTensor, _vp]),
+    "sf_maxpool3d_bwd": (C.c_int, [sfTensor, sfTensor, _i64] + [_i32] * 9 + [sfTensor, _vp]),
     "sf_film_act_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, sfTensor, _vp]),
     "sf_film_act_bwd_workspace_floats": (_sz, [_i64, _i32, _i32, _i32, _i32]),
     "sf_film_act_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _i32, _i32, _i32, sfTensor, _vp, _vp, _vp]),

@@ -254,6 +254,64 @@ __global__ __launch_bounds__(256) void border_kernel(const float* __restrict__ x
   }
 }
 
+
+// ---- nn.MaxPool3d over NHWC tokens [B][D0][D1][D2][C] (Attention.py:50,127: kernel 2 or (2,1,1), stride pooling_factor) --------
+struct Pool3 { int d0, d1, d2, o0, o1, o2, k0, k1, k2, s0, s1, s2; };
+__global__ __launch_bounds__(256) void maxpool3_fwd_kernel(const float* __restrict__ x, long long B, Pool3 g, int q, float* __restrict__ y) {
+  const int C = q * 4;
+  const long long total = B * g.o0 * g.o1 * g.o2 * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int c2 = (int)(r % g.o2); r /= g.o2;
+    const int c1 = (int)(r % g.o1); r /= g.o1;
+    const int c0 = (int)(r % g.o0); const long long b = r / g.o0;
+    f32x4 m = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+    for (int a0 = 0; a0 < g.k0; ++a0)
+      for (int a1 = 0; a1 < g.k1; ++a1)
+        for (int a2 = 0; a2 < g.k2; ++a2) {
+          const f32x4 v = ld4(x + ((((b * g.d0 + c0 * g.s0 + a0) * g.d1 + c1 * g.s1 + a1) * (long long)g.d2) + c2 * g.s2 + a2) * C + c);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) m[j] = v[j] > m[j] ? v[j] : m[j];
+        }
+    st4(y + idx * 4, m);
+  }
+}
+// gradient to the FIRST maximum of every window in scan order (as torch); windows may overlap only when stride < kernel, which the
+// callers never use (stride >= kernel is required), so every input element belongs to at most one window: no atomics
+__global__ __launch_bounds__(256) void maxpool3_bwd_kernel(const float* __restrict__ x, const float* __restrict__ gy, long long B, Pool3 g, int q,
+                                                           float* __restrict__ gx) {
+  const int C = q * 4;
+  const long long total = B * g.d0 * g.d1 * g.d2 * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int i2 = (int)(r % g.d2); r /= g.d2;
+    const int i1 = (int)(r % g.d1); r /= g.d1;
+    const int i0 = (int)(r % g.d0); const long long b = r / g.d0;
+    const int c0 = i0 / g.s0, c1 = i1 / g.s1, c2 = i2 / g.s2;
+    const int a0 = i0 - c0 * g.s0, a1 = i1 - c1 * g.s1, a2 = i2 - c2 * g.s2;
+    f32x4 o = kZero4;
+    if (c0 < g.o0 && c1 < g.o1 && c2 < g.o2 && a0 < g.k0 && a1 < g.k1 && a2 < g.k2) {
+      const f32x4 mine = ld4(x + idx * 4);
+      bool first[4] = {true, true, true, true};
+      for (int b0 = 0; b0 < g.k0; ++b0)
+        for (int b1 = 0; b1 < g.k1; ++b1)
+          for (int b2 = 0; b2 < g.k2; ++b2) {
+            if (b0 == a0 && b1 == a1 && b2 == a2) continue;
+            const f32x4 v = ld4(x + ((((b * g.d0 + c0 * g.s0 + b0) * g.d1 + c1 * g.s1 + b1) * (long long)g.d2) + c2 * g.s2 + b2) * C + c);
+            const bool before = (b0 * g.k1 + b1) * g.k2 + b2 < (a0 * g.k1 + a1) * g.k2 + a2;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) first[j] = first[j] && (before ? v[j] < mine[j] : v[j] <= mine[j]);
+          }
+      const f32x4 gv = ld4(gy + ((((b * g.o0 + c0) * g.o1 + c1) * (long long)g.o2) + c2) * C + c);
+#pragma unroll
+      for (int j = 0; j < 4; ++j) o[j] = first[j] ? gv[j] : 0.f;
+    }
+    st4(gx + idx * 4, o);
+  }
+}
+
 // ---- conditional BatchNorm (+ ReLU, + nearest x2) --------------------------------------------------------------------
 // y = act(gamma[n][c] * (x - mean[c]) * rstd[c] + beta[n][c]), stored once or to the 2x2 block of the up-sampled map
 __global__ __launch_bounds__(256) void film_fwd_kernel(const float* __restrict__ x, long long n, int h, int w, int q, const float* __restrict__ mean,
@@ -620,6 +678,34 @@ int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32
   const long long work = pad ? n * (h + 2 * border) * (w + 2 * border) * (x.c / 4) : n * h * w * (x.c / 4);
   hipLaunchKernelGGL(border_kernel, dim3(grid_of(work)), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)n, h, w, border, x.c / 4, pad, (float*)y.ptr);
   SF_CHECK_LAUNCH("border");
+  return 0;
+}
+
+static int pool3_geom(int32_t d0, int32_t d1, int32_t d2, int32_t k0, int32_t k1, int32_t k2, int32_t s0, int32_t s1, int32_t s2, Pool3* g) {
+  if (d0 < 1 || d1 < 1 || d2 < 1 || k0 < 1 || k1 < 1 || k2 < 1 || s0 < k0 || s1 < k1 || s2 < k2 || k0 > d0 || k1 > d1 || k2 > d2) return 1;
+  *g = Pool3{d0, d1, d2, (d0 - k0) / s0 + 1, (d1 - k1) / s1 + 1, (d2 - k2) / s2 + 1, k0, k1, k2, s0, s1, s2};
+  return 0;
+}
+int sf_maxpool3d_fwd(sfTensor x, int64_t batch, int32_t d0, int32_t d1, int32_t d2, int32_t k0, int32_t k1, int32_t k2, int32_t s0, int32_t s1, int32_t s2,
+                     sfTensor y, sfStream stream) {
+  Pool3 g;
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(y, x.c) && pool3_geom(d0, d1, d2, k0, k1, k2, s0, s1, s2, &g) == 0,
+             "sf_maxpool3d_fwd: dense fp32 tokens, window <= extent, stride >= window");
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(maxpool3_fwd_kernel, dim3(grid_of(batch * g.o0 * g.o1 * g.o2 * (x.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)batch, g,
+                     x.c / 4, (float*)y.ptr);
+  SF_CHECK_LAUNCH("maxpool3d_fwd");
+  return 0;
+}
+int sf_maxpool3d_bwd(sfTensor x, sfTensor gy, int64_t batch, int32_t d0, int32_t d1, int32_t d2, int32_t k0, int32_t k1, int32_t k2, int32_t s0, int32_t s1,
+                     int32_t s2, sfTensor gx, sfStream stream) {
+  Pool3 g;
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(gy, x.c) && okd(gx, x.c) && pool3_geom(d0, d1, d2, k0, k1, k2, s0, s1, s2, &g) == 0,
+             "sf_maxpool3d_bwd: dense fp32 tokens, window <= extent, stride >= window");
+  if (batch <= 0) return 0;
+  hipLaunchKernelGGL(maxpool3_bwd_kernel, dim3(grid_of(batch * d0 * d1 * d2 * (x.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (const float*)gy.ptr,
+                     (long long)batch, g, x.c / 4, (float*)gx.ptr);
+  SF_CHECK_LAUNCH("maxpool3d_bwd");
   return 0;
 }
 

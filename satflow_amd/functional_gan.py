@@ -539,3 +539,30 @@ class _SoftmaxFn(torch.autograd.Function):
 def softmax_last(x: Tensor) -> Tensor:
     """``softmax(x, dim=-1)`` of a contiguous fp32 tensor."""
     return _SoftmaxFn.apply(x.contiguous())
+
+
+class _MaxPool3Fn(torch.autograd.Function):
+    """``nn.MaxPool3d(kernel, stride)`` over NHWC tokens ``[B, D0, D1, D2, C]`` (``sf_maxpool3d_*``)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, kernel: Tuple[int, int, int], stride: Tuple[int, int, int]):
+        B, d0, d1, d2, C = x.shape
+        o = [(d - k) // s_ + 1 for d, k, s_ in zip((d0, d1, d2), kernel, stride)]
+        y = torch.empty(B, *o, C, dtype=torch.float32, device=x.device)
+        check(lib().sf_maxpool3d_fwd(T(x), B, d0, d1, d2, *kernel, *stride, T(y), stream_ptr()), "sf_maxpool3d_fwd")
+        ctx.meta = (kernel, stride)
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        (x,) = ctx.saved_tensors
+        kernel, stride = ctx.meta
+        B, d0, d1, d2, C = x.shape
+        gx = torch.empty_like(x)
+        check(lib().sf_maxpool3d_bwd(T(x), T(g.contiguous()), B, d0, d1, d2, *kernel, *stride, T(gx), stream_ptr()), "sf_maxpool3d_bwd")
+        return gx, None, None
+
+
+def max_pool3(x: Tensor, kernel: Tuple[int, int, int], stride: Tuple[int, int, int]) -> Tensor:
+    return _MaxPool3Fn.apply(x.contiguous(), tuple(kernel), tuple(stride))

@@ -491,6 +491,57 @@ def dgmr_cases():
 
 
 
+def attention_cases():
+    """The in-tree attention layers (satflow/models/layers/Attention.py): SelfAttention2d, the 3-D SelfAttention with
+    max-pooled keys / values, SeparableAttn (T, W, H cells).  gamma is moved off its zero initialisation so that the attention
+    branch is visible; outputs, a random cotangent, the input gradient and every parameter gradient are stored."""
+    from satflow.models.layers.Attention import SelfAttention, SelfAttention2d, SeparableAttn
+    from oracle import attention as OA
+
+    def heat(m, gen, scale):
+        with torch.no_grad():
+            for k, p in m.named_parameters():
+                if k.endswith("gamma"):
+                    p.fill_(0.7)
+                elif k.endswith("bias"):
+                    p.copy_(torch.randn(p.shape, generator=gen) * 0.3)
+                else:
+                    p.mul_(scale)
+
+    cases = {
+        "2d": (lambda: SelfAttention2d(16, return_attn=True), (2, 16, 6, 5)),
+        "2d_wide": (lambda: SelfAttention2d(24, output_dims=5), (1, 24, 9, 8)),
+        "3d": (lambda: SelfAttention(8), (2, 8, 4, 6, 4)),
+        "separable": (lambda: SeparableAttn(8), (2, 8, 4, 6, 8)),
+    }
+    for name, (make, shape) in cases.items():
+        gen = torch.Generator().manual_seed(zlib_seed("attn" + name))
+        torch.manual_seed(31)
+        m = make()
+        # (three chained cells with flat-view products over thousands of terms: x3 weights put the fp32 reference itself 1.5e-4 from
+        # a float64 evaluation on some gradients - the separable case is heated less)
+        heat(m, gen, 1.0 if name == "separable" else 3.0)
+        x = torch.randn(*shape, generator=gen).requires_grad_()
+        res = m(x)
+        out = res[0] if isinstance(res, tuple) else res
+        cot = torch.randn(out.shape, generator=gen)
+        (out * cot).sum().backward()
+        rec = dict(x=x.detach(), out=out.detach(), cot=cot, dx=x.grad)
+        if isinstance(res, tuple):
+            rec["attn"] = res[1].detach()
+        for k, p in m.named_parameters():
+            rec[f"param.{k}"] = p.detach().clone()
+            rec[f"grad.{k}"] = p.grad.clone()
+        P = {k: p.detach() for k, p in m.named_parameters()}
+        ref = {"2d": lambda: OA.self_attention_2d(x.detach(), P)[0], "2d_wide": lambda: OA.self_attention_2d(x.detach(), P)[0],
+               "3d": lambda: OA.self_attention_3d(x.detach(), P), "separable": lambda: OA.separable_attn(x.detach(), P)}[name]()
+        assert torch.allclose(ref, out.detach(), rtol=1e-4, atol=1e-5), f"oracle attention mismatch {name}: {float((ref - out.detach()).abs().max())}"
+        np.savez(f"{HERE}/attention_{name}.npz", **_np(rec))
+        print(f"attention {name}: ok  out {tuple(out.shape)}  |out - x|max={float((out.detach() - x.detach()).abs().max()):.3f}")
+    with open(f"{HERE}/attention_separable_keys.txt", "w") as f:
+        f.write("\n".join(SeparableAttn(8).state_dict().keys()) + "\n")
+
+
 def zlib_seed(s):
     import zlib
 
@@ -500,7 +551,7 @@ def zlib_seed(s):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     _shim_reference()
-    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan", "stlstm", "dgmr"]
+    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan", "stlstm", "dgmr", "attention"]
     if "cell" in only:
         cell_cases()
     if "model" in only:
@@ -513,3 +564,5 @@ if __name__ == "__main__":
         stlstm_cases()
     if "dgmr" in only:
         dgmr_cases()
+    if "attention" in only:
+        attention_cases()

@@ -163,6 +163,8 @@ int main(void) {
   REFUSED(sf_layernorm_chw_fwd(a64, 2, 64, 4, 12, 16, ok, ok, 1e-5f, 0, a64, st));                       /* no partial-sum buffer */
   REFUSED(sf_layernorm_chw_fwd(a48, 2, 64, 4, 12, 16, ok, ok, 1e-5f, ok, a48, st));                      /* lanes != gates * hidp */
   REFUSED(sf_layernorm_chw_bwd(a64, a64, 2, 64, 4, 20, 16, ok, 1e-5f, ok, ok, a64, ok, ok, st));         /* hid > hidp */
+  REFUSED(sf_maxpool3d_fwd(a16, 1, 4, 4, 4, 2, 2, 2, 1, 2, 2, a16, st));                                   /* stride below the window */
+  REFUSED(sf_maxpool3d_bwd(a16, a16, 1, 4, 4, 4, 8, 1, 1, 8, 1, 1, a16, st));                              /* window beyond the extent */
   /* size queries never fail, must not overflow */
   printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32) + sf_conv3x3_bwd_weight_folded_workspace_bytes(256, 256, 2304, 32, 32, 24),
          sf_linear_bwd_weight_workspace_bytes(384, 64, 24576), sf_conv2d_bwd_weight_workspace_bytes(48, 64, 64, 12, 32, 4, 4));
