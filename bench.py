@@ -709,6 +709,25 @@ def comm_report(wl, world: int, dev) -> dict:
             buf = torch.zeros(hi - lo, dtype=torch.float32, device=dev)
             t = event_time(lambda: dist.all_reduce(buf, op=dist.ReduceOp.SUM), iters=10)
             rep["buckets"].append({"bytes": 4 * (hi - lo), "allreduce_us": t * 1e6})
+        # what the exchange costs a step, measured in this process after the timed region (every rank runs the same sequence):
+        # steps as timed (overlapped), with ONE all-reduce after the backward pass, and with the exchange switched off
+        def few(k=3):
+            torch.cuda.synchronize(); dist.barrier()
+            t0 = time.perf_counter()
+            for _ in range(k):
+                wl.step()
+            torch.cuda.synchronize(); dist.barrier()
+            return (time.perf_counter() - t0) / k * 1e3
+        opts = [o for o in (getattr(wl, "opt_g", None), getattr(wl, "opt_d", None), opt) if hasattr(o, "flat_g")]
+        opts = list({id(o): o for o in opts}.values())
+        rep["ms_per_step_overlapped"] = few()
+        for o in opts:
+            o.disable_overlap()
+        rep["ms_per_step_single_allreduce"] = few()
+        for o in opts:
+            o.exchange = False
+        rep["ms_per_step_no_exchange"] = few()   # (the replicas drift apart from here on: last measurement of the run)
+        rep["exposed_comm_ms"] = rep["ms_per_step_overlapped"] - rep["ms_per_step_no_exchange"]
     return rep
 
 

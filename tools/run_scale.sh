@@ -13,6 +13,15 @@ PORT=29500
 for MODE in weak strong; do
   for N in 1 2 4 8; do
     [ "$N" -gt "$NGPU" ] && continue
+    if [ "$MODE" = strong ]; then  # per-GPU batch 64 / N: skip a leg that cannot fit (about 2.7 GiB of HBM per MetNet sample in the benchmarked mode)
+      FIT=$(python - "$N" <<'PY'
+import sys, torch
+free, _ = torch.cuda.mem_get_info(0)
+print(int(free / 2**30 > 2.7 * 64 / int(sys.argv[1]) + 8))
+PY
+)
+      if [ "$FIT" != 1 ]; then echo "strong N=$N: per-GPU batch $((64 / N)) does not fit this GPU's free memory - leg skipped"; continue; fi
+    fi
     PORT=$((PORT + 1))
     ARGS="--gpus $N --steps $STEPS --warmup $WARM --scaling $MODE --no-cpu-baseline --no-extra"
     if [ "$N" -eq 1 ]; then
