@@ -493,8 +493,8 @@ class DGMRWorkload:
 
         self.B, self.C, self.H = batch, 12, 256
         self.T = frames or int(os.environ.get("SF_DGMR_FRAMES", "8"))
-        self.ch = ch or int(os.environ.get("SF_DGMR_CH", "16"))
-        self.chn = chn or int(os.environ.get("SF_DGMR_CHN", "16"))
+        self.ch = ch or int(os.environ.get("SF_DGMR_CH", "32"))
+        self.chn = chn or int(os.environ.get("SF_DGMR_CHN", "64"))
         self.in_dim, self.n_class = 120, 4
         torch.manual_seed(1234)
         self.G = Generator(in_dim=self.in_dim, latent_dim=self.H // 16, n_class=self.n_class, ch=self.ch, n_frames=self.T, out_channels=self.C).to(dev).train()
@@ -509,6 +509,8 @@ class DGMRWorkload:
         self.opt_d = FlatAdam(list(self.Ds.parameters()) + list(self.Dt.parameters()), lr=2e-4, betas=(0.0, 0.999), overlap=ov)
         self.opt = self.opt_g
         self.dev = dev
+        self.z = torch.zeros(self.B, self.in_dim, device=dev)
+        self.graphed, self.graph_note = False, "eager"
         for net in (self.G, self.Ds, self.Dt):  # spectral-norm vectors are non-trainable parameters: never toggled
             for p in net.parameters():
                 p._sf_frozen_forever = not p.requires_grad
@@ -526,29 +528,68 @@ class DGMRWorkload:
                 if not p._sf_frozen_forever:
                     p.requires_grad_(on)
 
-    def step(self):
+    # ---- the two halves of a step (everything except the two Adam updates and the noise draw) ----
+    def _d_half(self):
+        """G forward (kept for the second half), D update's forward + hinge loss + backward."""
         from satflow_amd import functional as F
 
         B, T, C, H = self.B, self.T, self.C, self.H
-        z = torch.randn(B, self.in_dim, generator=self.noise_gen, device=self.dev)
-        fake = self.G.run(z, self.cls)                                                   # time-major NHWC, with the generator's graph
+        self._fake = self.G.run(self.z, self.cls)                                        # time-major NHWC, with the generator's graph
         real = F._ToNHWC.apply(self.real, B, T, C, H, H, (T * C * H * H, C * H * H, H * H))
-        # discriminator update on (real, generated.detach()): hinge loss
         self.opt_d.zero_grad()
         rs, rt = self._scores(real)
-        fs, ft = self._scores(fake.detach())
-        d_loss = torch.relu(1 - rs).mean() + torch.relu(1 + fs).mean() + torch.relu(1 - rt).mean() + torch.relu(1 + ft).mean()
-        d_loss.backward()
-        self.opt_d.step()
-        # generator update through the updated (and, for this pass, frozen) discriminators
+        fs, ft = self._scores(self._fake.detach())
+        self._d_loss = torch.relu(1 - rs).mean() + torch.relu(1 + fs).mean() + torch.relu(1 - rt).mean() + torch.relu(1 + ft).mean()
+        self._d_loss.backward()
+
+    def _g_half(self):
+        """G update through the updated (and, for this pass, frozen) discriminators: forward of D on the kept frames, backward into G."""
         self.opt_g.zero_grad()
         self._train((self.Ds, self.Dt), False)
-        gs, gt = self._scores(fake)
-        g_loss = -gs.mean() - gt.mean()
-        g_loss.backward()
+        gs, gt = self._scores(self._fake)
+        self._g_loss = -gs.mean() - gt.mean()
+        self._g_loss.backward()
         self._train((self.Ds, self.Dt), True)
+
+    def capture(self):
+        """hipGraph capture of the two halves (the step is ~8000 small launches and host-bound in eager mode; the two Adam updates
+        stay eager: their step count is a host-side kernel argument).  Nothing on this path caches derived weights across steps
+        (spectral-normed and regrouped weights are re-packed every call), so a replay is arithmetically the eager step."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._eager_step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self._d_half()
+        self.opt_d.step()
+        self.g2 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g2, pool=self.g1.pool()):
+            self._g_half()
         self.opt_g.step()
-        return d_loss.detach() + g_loss.detach()
+        torch.cuda.synchronize()
+        self.graphed = True
+
+    def _eager_step(self):
+        self.z.copy_(torch.randn(self.B, self.in_dim, generator=self.noise_gen, device=self.dev))
+        self._d_half()
+        self.opt_d.step()
+        self._g_half()
+        self.opt_g.step()
+        return self._d_loss.detach() + self._g_loss.detach()
+
+    def step(self):
+        if not self.graphed:
+            return self._eager_step()
+        self.z.copy_(torch.randn(self.B, self.in_dim, generator=self.noise_gen, device=self.dev))
+        self.g1.replay()
+        self.opt_d.step()
+        self.g2.replay()
+        self.opt_g.step()
+        return self._d_loss.detach() + self._g_loss.detach()
 
     def config(self, world):
         return {"workload": f"DGMR-style GAN step (BASELINE configs[4] at {world} GPU(s)): generator (ConvGRU + GResBlock, ch {self.ch}, latent 16x16 -> "
@@ -556,7 +597,7 @@ class DGMRWorkload:
                             "layers/Discriminator.py, layers/GResBlock.py, layers/Normalization.py",
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
                 "step": "G forward once; D update: hinge loss on (real, generated.detach()), backward, Adam; G update: -D(generated) through the updated "
-                        "discriminators, backward, Adam"}
+                        "discriminators, backward, Adam", "launch": self.graph_note}
 
     def roofline(self):
         """The spatial discriminator's widest full-resolution convolution (pre_conv.2: 2chn -> 2chn, 3x3, 256x256 frames), timed live."""
@@ -775,6 +816,12 @@ def main(argv=None):
         dist.init_process_group(backend, **({} if stub else {"device_id": dev}))
 
     wl = build_workload(args.workload, dev, batch, rank)
+    if args.workload == "dgmr" and world == 1 and not os.environ.get("SF_NO_GRAPH"):
+        try:
+            wl.capture()
+            wl.graph_note = "hipGraph replay of the two half-steps (torch.cuda.CUDAGraph), Adam updates eager"
+        except Exception as e:  # noqa: BLE001 - the eager step is the fallback, and the line says so
+            wl.graphed, wl.graph_note = False, f"eager (capture failed: {type(e).__name__}: {str(e)[:200]})"
     elapsed, final_loss = timed_steps(wl, args.steps, args.warmup, world, dev, sync)
     event_ms = getattr(timed_steps, "last_event_ms", None)
 

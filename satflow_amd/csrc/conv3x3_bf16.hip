@@ -46,8 +46,14 @@ __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t r
 // DUAL (8 waves, images of at most 16x16 pixels): the 32x16 tile is TWO consecutive images, waves 0-3 on the first and
 // 4-7 on the second, each image with its own halo rows in LDS (2 x 18 rows) - small images keep the 8-wave workgroup's
 // weight reuse and occupancy instead of dropping to the 4-wave 16x16 kernel.
-template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false>
-__global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
+// WS (4 waves): ONE weight buffer instead of two - 58 KB of LDS, so TWO workgroups share a CU (one wave of each per SIMD).  A
+// workgroup then waits for its next chunk's weights after every chunk (the DMA is issued behind an end-of-chunk barrier), but the
+// partner workgroup's MFMAs, prologue and epilogue run in those gaps: for the fused LSTM cell, whose epilogue moves 5 state / gate
+// tensors per tile, that overlap is worth more than the double buffer (ConvLSTM cell).
+template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false, bool WS = false>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
+  static_assert(!WS || (WAVES == 4 && !DUAL), "the single-weight-buffer variant is a 4-wave layout");
+  constexpr int WBUFS = WS ? 1 : 2;
   static_assert(!DUAL || WAVES == 8, "dual-image tiles are an 8-wave layout");
   constexpr int NB = 32 * NF;
   constexpr int THREADS = WAVES * 64;
@@ -57,10 +63,10 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   constexpr int W_B = 9 * NB * PIX_B;
   constexpr int PIECES = HALO_H * HALO_W * 2;                 // 16-byte bf16 pieces of the halo tile
   constexpr int NPIECE = (PIECES + THREADS - 1) / THREADS;
-  __shared__ __attribute__((aligned(1024))) char lds[2 * W_B + 2 * IN_B];
+  __shared__ __attribute__((aligned(1024))) char lds[WBUFS * W_B + 2 * IN_B];
   __shared__ __attribute__((aligned(16))) float lds_coef[BNB ? 3 * NB : 4];  // BatchNorm-backward epilogue: (A, B, K) of this N block
   char* lds_w = lds;
-  char* lds_in = lds + 2 * W_B;
+  char* lds_in = lds + WBUFS * W_B;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -213,7 +219,7 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
   // masked off): their slots are zeroed once per block, below.
   auto dma_input = [&](int ci, int buf) {
     if constexpr (!DUAL) {
-      const unsigned dst = lds0 + (unsigned)(2 * W_B + buf * IN_B + wave * 1024);
+      const unsigned dst = lds0 + (unsigned)(WBUFS * W_B + buf * IN_B + wave * 1024);
       // (a uniform branch per source rather than selects: the descriptor must stay in SGPRs)
       if (ci < ch0) {
         const unsigned so = so_in0 + (unsigned)(ci * KC * 2);
@@ -285,12 +291,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
     const bool stage_late = WAVES == 8 && wave >= 4;
     auto stage_next = [&]() {
       if (ci + 1 < nch) {
-        issue_weights(ci + 1, cur ^ 1);
+        if constexpr (!WS) issue_weights(ci + 1, cur ^ 1);
         stage_input(ci + 1);
       }
     };
     const char* inb = lds_in + cur * IN_B + a_lane;
-    const char* wb = lds_w + cur * W_B + b_lane;
+    const char* wb = lds_w + (WS ? 0 : cur) * W_B + b_lane;
     auto load_tap = [&](int tap, bf16x8 (&a)[2], bf16x8 (&b)[NF]) {
       const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
@@ -329,6 +335,12 @@ __global__ __launch_bounds__(WAVES * 64, WAVES == 8 ? 2 : 1) void conv3x3_bf16_k
       }
     }
     if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
+    if constexpr (WS) {
+      if (ci + 1 < nch) {
+        __syncthreads();              // every wave has read its last weight fragment of this chunk
+        issue_weights(ci + 1, 0);     // lands while the partner workgroup on this CU computes
+      }
+    }
   }
 
   // optional per-tile BatchNorm statistics of the stored outputs (linear epilogue): lane sums -> LDS (the operand
@@ -402,6 +414,11 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
   dim3 grid(DUAL ? (p.N + 1) / 2 : p.tiles_x * p.tiles_y * p.N, nblk), block(WAVES * 64);
   if constexpr (EPI == EPI_LSTM) {
     if (nf != 4) { sf_set_error("bf16 conv: LSTM epilogue needs nf=4"); return 1; }
+    if constexpr (WAVES == 4 && !DUAL) {
+      static const bool ws = getenv("SF_LSTM_WS") != nullptr;  // experiment switch (with SF_LSTM_W4=1): single weight buffer, two workgroups per CU
+      if (ws) hipLaunchKernelGGL((conv3x3_bf16_kernel<4, 4, EPI, false, true, false, true>), grid, block, 0, st, p);
+      else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL, true>), grid, block, 0, st, p);
+    } else
     hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL, true>), grid, block, 0, st, p);
   } else if constexpr (EPI == EPI_GRU) {
     if (nf != 3) { sf_set_error("bf16 conv: GRU epilogue needs nf=3"); return 1; }
@@ -439,6 +456,10 @@ int launch_e(const ConvParams& p, int nf, int nblk, hipStream_t st) {
   // where that kernel fits only one workgroup per CU (NF >= 4: 94 KB LDS) and there are enough images to fill the chip
   // with 8-wave workgroups holding two images each (measured 192->256 @16x16 x 2304: 811 -> 574 us; NF = 3 and the
   // 96-image ConvGRU steps are faster on the 4-wave kernel)
+  if constexpr (EPI == EPI_LSTM) {  // SF_LSTM_W4=1: the fused cell on 16x16 tiles, two workgroups per CU (experiment switch)
+    static const bool w4 = getenv("SF_LSTM_W4") != nullptr;
+    if (w4) return launch_w<4, EPI>(p, nf, nblk, st);
+  }
   if (p.H > 16) return launch_w<8, EPI>(p, nf, nblk, st);
   if (p.W <= 16 && !p.stats && nf >= 4 && p.N >= 512) return launch_w<8, EPI, true>(p, nf, nblk, st);
   return launch_w<4, EPI>(p, nf, nblk, st);

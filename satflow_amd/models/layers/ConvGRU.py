@@ -62,7 +62,10 @@ class ConvGRUCell(nn.Module):
             cin = w.shape[1] if k == 3 else 4 * x.shape[-1]   # 5x5: four shifted copies of the (padded) input lanes
             key = (tag, cin, w.shape[0])
             if key not in self._eng:
-                self._eng[key] = FG.FreshConvEngine([cin], w.shape[0])
+                self._eng[key] = F.ConvEngine([cin], w.shape[0])
+            # the regrouped weights are fresh tensors every call but functions of the cell's parameters only: the packed images are
+            # cached on THOSE (identity + version + optimizer generation) - one pack per step, not one per frame
+            self._eng[key].key_tensors = tuple(self.parameters())
             return F.conv3x3(self._eng[key], x, w, b) if k == 3 else FG.conv5x5_as_3x3(x, w, b, self._eng[key])
         return FG.conv_nhwc(x, w, b)   # any other size (and SF_CONV5_DIRECT=1, the A/B switch): the direct fp32 convolution
 
