@@ -372,8 +372,14 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
  *   gates : nullable, [T][n][h][w][4*hidp] = [z | r | n | h2] per step (SF_F32 or SF_BF16) for the backward pass
  *   wpacked / bias_packed: as for sf_convgru_step_fwd (GRU map, nf == 3). */
 int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h, int32_t w, const void* wpacked,
-                       const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, int32_t dtype,
-                       sfStream stream);
+                       const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, void* workspace,
+                       size_t workspace_bytes, int32_t dtype, sfStream stream);
+/* workspace (nullable): with sf_convgru_seq_fwd_workspace_bytes(n, h, hidp) bytes (0 = not applicable) the launch may split every
+ * map over TWO workgroups of 8 rows each (maps of more than 8 rows, hidp 48..64, 2n <= number of CUs - MetNet's 96 maps then use
+ * 192 of the 256 CUs): after every step a workgroup hands the bf16 image of its boundary row to its partner inside the launch
+ * ({epoch, value} granules, one write-through store each; the workspace is zeroed by the call).  Same arithmetic, same results.
+ * Word [workspace_bytes / 8 - 2] is non-zero afterwards if a receiver gave up waiting (results invalid; it never hangs). */
+size_t sf_convgru_seq_fwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
 /* The backward time loop of the same sequence in ONE launch (one workgroup per image, maps of at most 16x16, hidp 32 or 64,
  * SF_BF16 kernels, bf16-stored gates): for t = T-1 .. 0 the gate backward (as sf_convgru_bwd_gates) and the recurrent
  * input-gradient convolution conv^T(dgh_t, Wh) (as sf_conv3x3_fwd with the transposed image wpacked_t: N = hidp, K = 3*hidp),

@@ -92,7 +92,8 @@ PROTOTYPES = {
     "sf_batchnorm_eval_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _vp, C.c_float, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),
     "sf_batchnorm_train_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _vp, _vp, _vp, _vp, _vp, sfTensor, _vp, _vp, _i32, _vp]),
     "sf_convgru_step_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
-    "sf_convgru_seq_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
+    "sf_convgru_seq_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _vp, _sz, _i32, _vp]),
+    "sf_convgru_seq_fwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "sf_convgru_seq_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_convgru_bwd_gates": (
         C.c_int,

@@ -14,6 +14,7 @@
 //   * per step the only HBM traffic is gx_t in, h_t (and the saved gates, for the backward pass) out.
 // Arithmetic is that of the per-step kernel (same K order, same bf16 rounding of h, same epilogue formulas): with fp32-stored
 // gx the states are bit-identical to 24 launches of sf_convgru_step_fwd.
+#include <cstdlib>
 #include <type_traits>
 
 #include "conv_common.h"
@@ -41,7 +42,16 @@ struct GruSeqParams {
   void* gates; int gates_s, gates_bf;     // saved z | r | n | h2, [T][n][H][W][4*hidp], or null
   const void* wp; const float* bias;      // packed weights [nblk][chunks][9][96][16] bf16; bias [nblk*96] or null
   int T, n, H, W, hidp, chunks;
+  unsigned long long* mbox;               // SPLIT kernel: boundary-row mailbox (see convgru_seq_fwd_kernel), zeroed before the launch
 };
+
+// SPLIT: boundary-row hand-off between the two workgroups of an image.  One row of the bf16 state = chunks x 16 pixels x 2 octets x
+// 4 dwords; every dword travels as an 8-byte {tag = epoch, value} granule written by ONE write-through store - the data is the flag
+// (cdna_hip_programming.md Guideline 16, form R2): no fence, no separate flag.  Slots alternate with the epoch's parity: a sender
+// can be at most one state ahead of its receiver.
+constexpr int MB_ROW = 4 * 16 * 2 * 4;                       // granules of one boundary row (4 chunks max)
+__host__ __device__ constexpr long long mbox_slot(long long img, int half, int parity) { return ((img * 2 + half) * 2 + parity) * MB_ROW; }
+constexpr unsigned MB_SPIN_LIMIT = 1u << 21;                 // polls before a receiver gives up (then: error word set, results invalid)
 
 // LDS-DMA hidden from hipcc (see conv3x3_bf16.hip): wave-uniform descriptor + scalar offset + constant per-lane offset.
 __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
@@ -56,8 +66,15 @@ __device__ __forceinline__ unsigned pk(float a, float b) {
 }
 
 // NBLK: 32-channel N blocks of the hidden state (1: hidp <= 32, 2: hidp <= 64); 4 waves per N block, wave = (4-row band, N block).
-template <int NBLK, bool GXBF>
+// SPLIT (NBLK = 2): TWO workgroups per image, each owning 8 rows (192 workgroups instead of 96 on the 256 CUs for MetNet); a wave
+// then has ONE M fragment (32 pixels), wave = (4-row band, M fragment of the band, N block): still 8 waves, two per SIMD.  After
+// every step a workgroup hands the bf16 image of its boundary row to its partner through the mailbox and reads the partner's
+// into its halo row; everything else (K order, roundings, epilogue formulas, the lane that owns an element) is unchanged, so the
+// states stay bit-identical to the per-step kernel.
+template <int NBLK, bool GXBF, bool SPLIT = false>
 __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const GruSeqParams p) {
+  static_assert(!SPLIT || NBLK == 2, "the split kernel is the 8-wave layout");
+  constexpr int MFW = SPLIT ? 1 : 2;   // M fragments per wave
   constexpr int WAVES = 4 * NBLK, THREADS = 64 * WAVES;
   constexpr int STAGE_B = NBLK * W_B;
   constexpr int MAXCH = 2 * NBLK;
@@ -66,9 +83,12 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wl = wave & 3, nbk = wave >> 2;
+  const int nbk = wave >> 2;
   const int r = lane & 31, kh = lane >> 5;
-  const int img = blockIdx.x;
+  const int img = SPLIT ? blockIdx.x >> 1 : blockIdx.x;
+  const int half = SPLIT ? blockIdx.x & 1 : 0;
+  // first tile row of this wave's fragments: 4-row band wl of the map (SPLIT: band (wave & 3) >> 1 of this half, fragment wave & 1)
+  const int wrow = SPLIT ? 8 * half + 4 * ((wave & 3) >> 1) + 2 * (wave & 1) : 4 * (wave & 3);
   const int chunks = p.chunks;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
@@ -86,15 +106,19 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 
   // ---- this lane's two pixels (one per M fragment) and its 16 hidden channels: quads at hb + 8g, g = 0..3 ----
   const int hb = nbk * 32 + 4 * kh;
-  int py[2], px[2]; bool ok[2];
+  int py[MFW], px[MFW]; bool ok[MFW];
 #pragma unroll
-  for (int mf = 0; mf < 2; ++mf) { py[mf] = 4 * wl + 2 * mf + (r >> 4); px[mf] = r & 15; ok[mf] = py[mf] < p.H && px[mf] < p.W; }
+  for (int mf = 0; mf < MFW; ++mf) { py[mf] = wrow + 2 * mf + (r >> 4); px[mf] = r & 15; ok[mf] = py[mf] < p.H && px[mf] < p.W; }
   const long long img_px = (long long)p.H * p.W;
+  // SPLIT: the row this workgroup sends (its last / first row) and the halo row it receives (the partner's first / last row)
+  const int send_row = half == 0 ? 7 : 8, recv_row = half == 0 ? 8 : 7;
+  const bool has_partner = SPLIT && p.H > 8;
+  unsigned mb_failed = 0;
 
   // state registers
-  f32x4 hst[2][4];
+  f32x4 hst[MFW][4];
 #pragma unroll
-  for (int mf = 0; mf < 2; ++mf)
+  for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       hst[mf][g] = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -102,9 +126,9 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
         hst[mf][g] = *reinterpret_cast<const f32x4*>(p.h0 + ((long long)img * img_px + py[mf] * p.W + px[mf]) * p.h0_s + hb + 8 * g);
     }
   // bf16 image of a state into the LDS tile: after the half-wave swap a lane holds the channel octets hb8 + 16*(g/2) .. +7
-  auto write_state_tile = [&]() {
+  auto write_state_tile = [&](unsigned epoch) {
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
       for (int g = 0; g < 4; g += 2) {
         const unsigned ax = pk(hst[mf][g][0], hst[mf][g][1]), ay = pk(hst[mf][g][2], hst[mf][g][3]);
@@ -116,15 +140,58 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
           const int iy = py[mf] + 1, ix = px[mf] + 1;
           char* dst = lds_h + (ch >> 4) * CHUNK_B + (iy * HALO + ix) * PIX_B + 16 * (((ch >> 3) & 1) ^ (iy & 1));
           *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+          if constexpr (SPLIT) {
+            if (has_partner && py[mf] == send_row) {  // the partner's halo row: four {epoch, dword} granules, write-through
+              unsigned long long* g8 = p.mbox + mbox_slot(img, half, epoch & 1) + (ch >> 4) * 128 + px[mf] * 8 + ((ch >> 3) & 1) * 4;
+              const unsigned long long tag = (unsigned long long)epoch << 32;
+              __hip_atomic_store(g8 + 0, tag | sx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(g8 + 1, tag | sy[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(g8 + 2, tag | sx[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(g8 + 3, tag | sy[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
         }
       }
   };
+  // SPLIT: wave 0 sweeps the partner's granules of `epoch` (8 per lane) until every tag matches, then writes them into the halo row
+  auto receive_row = [&](unsigned epoch) {
+    if constexpr (SPLIT) {
+      if (has_partner && wave == 0) {
+        const unsigned long long* src = p.mbox + mbox_slot(img, half ^ 1, epoch & 1);
+        unsigned v[8];
+        bool need[8];
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int gi = lane + 64 * k;                       // granule = (chunk, pixel, octet, dword)
+          need[k] = (gi >> 7) < chunks && ((gi >> 3) & 15) < p.W;
+        }
+        for (unsigned spins = 0;; ++spins) {
+          bool all = true;
+#pragma unroll
+          for (int k = 0; k < 8; ++k) {
+            const unsigned long long x = __hip_atomic_load(src + lane + 64 * k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[k] = (unsigned)x;
+            all = all && (!need[k] || (unsigned)(x >> 32) == epoch);
+          }
+          if (__all(all)) break;
+          if (spins >= MB_SPIN_LIMIT) { mb_failed = 1; break; }   // wave-uniform (spins is): never hang the GPU
+          __builtin_amdgcn_s_sleep(2);
+        }
+        const int iy = recv_row + 1;
+#pragma unroll
+        for (int k = 0; k < 8; ++k) {
+          const int gi = lane + 64 * k, ck = gi >> 7, pxl = (gi >> 3) & 15, oh = (gi >> 2) & 1, dw = gi & 3;
+          if (need[k]) *reinterpret_cast<unsigned*>(lds_h + ck * CHUNK_B + (iy * HALO + pxl + 1) * PIX_B + 16 * (oh ^ (iy & 1)) + 4 * dw) = v[k];
+        }
+      }
+    }
+  };
   __syncthreads();  // the zero fill is complete
-  if (p.h0) write_state_tile();
+  if (p.h0) { write_state_tile(1u); receive_row(1u); }
 
   // per-lane LDS offsets of the fragment reads (as in conv3x3_bf16.hip)
   const int rowpar = (r >> 4) & 1;
-  const int a_lane = ((4 * wl + (r >> 4)) * HALO + (r & 15)) * PIX_B;
+  const int a_lane = ((wrow + (r >> 4)) * HALO + (r & 15)) * PIX_B;
   const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);
   const int b_lane = nbk * W_B + r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
 
@@ -132,9 +199,9 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 
   using GXV = typename std::conditional<GXBF, bf16x4, f32x4>::type;
   for (int t = 0; t < p.T; ++t) {
-    f32x16 acc[2][3];
+    f32x16 acc[MFW][3];
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf)
+    for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
       for (int g = 0; g < 3; ++g)
 #pragma unroll
@@ -142,7 +209,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 
     // this step's x-part: bf16-stored, it is requested now and consumed by the epilogue a whole K loop later (48 registers);
     // fp32-stored, it would take 96 registers over the K loop and is fetched by the epilogue instead
-    GXV gxv[2][3][4];
+    GXV gxv[MFW][3][4];
     const long long pix_t = ((long long)t * p.n + img) * img_px;
     auto load_gx = [&](int mf) {
     {
@@ -157,7 +224,12 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
         }
     }
     };
-    if constexpr (GXBF) { load_gx(0); load_gx(1); }
+    if constexpr (GXBF) {
+#pragma unroll
+      for (int mf = 0; mf < MFW; ++mf) load_gx(mf);
+    }
+    // SPLIT: the partner's boundary row of the state this step reads (epoch t + 1: the state after step t - 1)
+    if (t > 0) receive_row((unsigned)t + 1u);
 
     for (int ci = 0; ci < chunks; ++ci) {
       const int it = t * chunks + ci, cur = it & 1;
@@ -170,21 +242,21 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
       if (more && !stage_late) issue_weights(nci, cur ^ 1);
       const char* inb = lds_h + ci * CHUNK_B + a_lane;
       const char* wb = lds + cur * STAGE_B + b_lane;
-      auto load_tap = [&](int tap, bf16x8 (&a)[2], bf16x8 (&b)[3]) {
+      auto load_tap = [&](int tap, bf16x8 (&a)[MFW], bf16x8 (&b)[3]) {
         const int ky = tap / 3, kx = tap % 3;
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+        for (int mf = 0; mf < MFW; ++mf)
           a[mf] = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
 #pragma unroll
         for (int g = 0; g < 3; ++g) b[g] = *reinterpret_cast<const bf16x8*>(wb + (tap * NBG + g * 32) * PIX_B);
       };
-      bf16x8 fa[2][2], fb[2][3];
+      bf16x8 fa[2][MFW], fb[2][3];
       load_tap(0, fa[0], fb[0]);
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
         if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
 #pragma unroll
-        for (int mf = 0; mf < 2; ++mf)
+        for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
           for (int g = 0; g < 3; ++g)  // transposed product: D[channel][pixel] - a lane owns one pixel and channel quads
             acc[mf][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][g], fa[tap & 1][mf], acc[mf][g], 0, 0, 0);
@@ -198,7 +270,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 #pragma unroll
     for (int g = 0; g < 4; ++g) b2[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbk * NBG + 64 + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-    for (int mf = 0; mf < 2; ++mf) {
+    for (int mf = 0; mf < MFW; ++mf) {
       if constexpr (!GXBF) load_gx(mf);
       const long long pix = pix_t + (ok[mf] ? py[mf] * p.W + px[mf] : 0);
       f32x4 zz[4], rr[4], nn[4], hh2[4];
@@ -216,6 +288,9 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
           hst[mf][g][c] = sf_gru_blend(z, cand, hst[mf][g][c]);
         }
       }
+      // SPLIT (one M fragment per wave): the new state's bf16 image - and with it the boundary row for the partner workgroup - leaves
+      // BEFORE this step's outputs are stored: the hand-off's latency then runs under the stores
+      if constexpr (SPLIT) write_state_tile((unsigned)t + 2u);
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         if (ok[mf] && hb + 8 * g < p.hidp) *reinterpret_cast<f32x4*>(p.hs + pix * p.hs_s + hb + 8 * g) = hst[mf][g];
@@ -247,9 +322,12 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
         }
       }
     }
-    write_state_tile();
+    if constexpr (!SPLIT) write_state_tile((unsigned)t + 2u);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (SPLIT) {
+    if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox + mbox_slot(p.n, 0, 0)), 1u);  // error word behind the slots
+  }
 }
 
 
@@ -490,8 +568,15 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 
 }  // namespace
 
+// mailbox of the two-workgroups-per-image kernel: 2 directions x 2 parities x one boundary row of granules per image + an error word
+extern "C" size_t sf_convgru_seq_fwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp) {
+  if (n <= 0 || h <= 8 || hidp <= 32) return 0;
+  return (size_t)(mbox_slot(n, 0, 0) + 2) * sizeof(unsigned long long);
+}
+
 extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h, int32_t w, const void* wpacked,
-                                  const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, int32_t dtype, sfStream stream) {
+                                  const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, void* workspace, size_t workspace_bytes,
+                                  int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_BF16, "sf_convgru_seq_fwd: the persistent sequence kernel is built for the SF_BF16 kernels (got dtype %d)", dtype);
   SF_REQUIRE(h >= 1 && w >= 1 && h <= 16 && w <= 16, "sf_convgru_seq_fwd: one workgroup owns a whole map: H, W <= 16 (got %dx%d)", h, w);
   SF_REQUIRE(hidp % SF_CPAD == 0 && hidp >= 16 && hidp <= 64, "sf_convgru_seq_fwd: hidp=%d (16..64)", hidp);
@@ -512,6 +597,25 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   p.T = T; p.n = n; p.H = h; p.W = w; p.hidp = hidp; p.chunks = hidp / 16;
   const int nblk = (hidp + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
+  // two workgroups per image (8 rows each, boundary rows through the mailbox) when the map has more than 8 rows, both N blocks
+  // are in use and EVERY workgroup of the launch is resident at once (a receiver spins on its partner: 2n <= number of CUs)
+  static const bool no_split = getenv("SF_GRU_NO_SPLIT") != nullptr;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+  }
+  const size_t need = sf_convgru_seq_fwd_workspace_bytes(n, h, hidp);
+  const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
+  if (have_ws && hipMemsetAsync(workspace, 0, need, st) != hipSuccess) { sf_set_error("sf_convgru_seq_fwd: mailbox memset failed"); return 2; }
+  if (!no_split && nblk == 2 && h > 8 && 2 * n <= cus && have_ws) {
+    p.mbox = (unsigned long long*)workspace;
+    if (p.gx_bf) hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, true, true>), dim3(2 * n), dim3(512), 0, st, p);
+    else hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, false, true>), dim3(2 * n), dim3(512), 0, st, p);
+    SF_CHECK_LAUNCH("convgru_seq_fwd (split)");
+    return 0;
+  }
 #define SF_GRU_SEQ(NB_, BF_) hipLaunchKernelGGL((convgru_seq_fwd_kernel<NB_, BF_>), dim3(n), dim3(256 * NB_), 0, st, p)
   if (nblk == 1) { if (p.gx_bf) SF_GRU_SEQ(1, true); else SF_GRU_SEQ(1, false); }
   else { if (p.gx_bf) SF_GRU_SEQ(2, true); else SF_GRU_SEQ(2, false); }

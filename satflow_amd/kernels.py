@@ -439,10 +439,16 @@ def convgru_seq_supported(h: int, w: int, hidp: int) -> bool:
 
 
 def convgru_seq_fwd(gx: Tensor, h0: Optional[Tensor], Tn: int, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor], hidp: int,
-                    hs: Tensor, gates: Optional[Tensor]) -> None:
-    """All Tn recurrent steps in one launch (sf_convgru_seq_fwd): gx ``[Tn*n,h,w,3*hidp]``, hs ``[Tn,n,h,w,hidp]``."""
+                    hs: Tensor, gates: Optional[Tensor]) -> Optional[Tensor]:
+    """All Tn recurrent steps in one launch (sf_convgru_seq_fwd): gx ``[Tn*n,h,w,3*hidp]``, hs ``[Tn,n,h,w,hidp]``.
+    With a workspace the library may split every map over two workgroups (boundary rows exchanged inside the launch); ``check_split``
+    (tests) reads the workspace's error word back."""
+    nbytes = int(lib().sf_convgru_seq_fwd_workspace_bytes(n, h, hidp))
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=gx.device) if nbytes else None
     check(lib().sf_convgru_seq_fwd(T(gx), T(h0, hidp), Tn, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
-                                   hidp, T(hs), T(gates) if gates is not None else NULL, _hip.compute_dtype(), stream_ptr()), "sf_convgru_seq_fwd")
+                                   hidp, T(hs), T(gates) if gates is not None else NULL, ws.data_ptr() if ws is not None else None, nbytes,
+                                   _hip.compute_dtype(), stream_ptr()), "sf_convgru_seq_fwd")
+    return ws
 
 
 def convgru_seq_bwd_supported(h: int, w: int, hidp: int, gates: Tensor) -> bool:

@@ -87,13 +87,13 @@ int main(void) {
   /* ConvGRU */
   REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 20, a16, N0, SF_F32, st));                   /* hidp not padded */
   REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 16, N0, N0, SF_F32, st));                    /* no output */
-  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, a64, N0, SF_F32, st));               /* persistent kernel: bf16 kernels only */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, a64, N0, 0, 0, SF_F32, st));         /* persistent kernel: bf16 kernels only */
   REFUSED(sf_convgru_seq_bwd(N0, a64, T(ok, 256, 256, SF_BF16), a64, 4, 2, 32, 16, ok, 64, T(ok, 192, 192, SF_BF16), T(ok, 192, 192, SF_BF16), SF_BF16, st)); /* map taller than 16 */
   REFUSED(sf_convgru_seq_bwd(N0, a64, T(ok, 256, 256, SF_F32), a64, 4, 2, 16, 16, ok, 64, T(ok, 192, 192, SF_BF16), T(ok, 192, 192, SF_BF16), SF_BF16, st));  /* fp32-stored gates */
   REFUSED(sf_convgru_seq_bwd(N0, a48, T(ok, 192, 192, SF_BF16), a48, 4, 2, 16, 16, ok, 48, T(ok, 144, 144, SF_BF16), T(ok, 144, 144, SF_BF16), SF_BF16, st)); /* hidp 48 */
-  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 32, 16, ok, 0, 64, a64, N0, SF_BF16, st));              /* map larger than one workgroup */
-  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 128, a64, N0, SF_BF16, st));             /* hidp > 64 */
-  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, m16, N0, SF_BF16, st));              /* misaligned / wrong-width states */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 32, 16, ok, 0, 64, a64, N0, 0, 0, SF_BF16, st));        /* map larger than one workgroup */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 128, a64, N0, 0, 0, SF_BF16, st));       /* hidp > 64 */
+  REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, m16, N0, 0, 0, SF_BF16, st));        /* misaligned / wrong-width states */
   REFUSED(sf_convgru_bwd_gates(N0, N0, N0, a64, N0, 64, 16, a48, a48, N0, SF_F32, st));              /* dh0 missing */
   /* linear / attention */
   REFUSED(sf_linear_fwd(a16, 64, ok, 300, 0, a16, SF_F32, st));                                      /* N exceeds the output lanes */

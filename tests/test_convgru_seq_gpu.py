@@ -18,7 +18,8 @@ def bf16_mode():
     satflow_amd.set_compute_dtype("f32")
 
 
-@pytest.mark.parametrize("Tn,n,H,W,hid", [(5, 3, 16, 16, 64), (4, 2, 16, 16, 32), (3, 2, 12, 10, 24), (3, 1, 5, 7, 16), (24, 4, 16, 16, 64), (1, 1, 16, 16, 64)])
+@pytest.mark.parametrize("Tn,n,H,W,hid", [(5, 3, 16, 16, 64), (4, 2, 16, 16, 32), (3, 2, 12, 10, 24), (3, 1, 5, 7, 16), (24, 4, 16, 16, 64), (1, 1, 16, 16, 64),
+                                          (24, 96, 16, 16, 64), (6, 5, 11, 13, 48), (7, 128, 9, 16, 64), (3, 130, 16, 16, 64)])  # split over two workgroups: MetNet's size, ragged, 256 workgroups; one-workgroup kernel beyond the CU count
 @pytest.mark.parametrize("gx_dtype", [torch.float32, torch.bfloat16])
 @pytest.mark.parametrize("with_h0", [False, True])
 def test_persistent_sequence_matches_per_step_kernel(device, bf16_mode, Tn, n, H, W, hid, gx_dtype, with_h0):
@@ -40,7 +41,10 @@ def test_persistent_sequence_matches_per_step_kernel(device, bf16_mode, Tn, n, H
     for gates_dtype in (torch.float32, torch.bfloat16):
         hs = torch.full((Tn, n, H, W, hidp), float("nan"), device=device)
         gates = torch.full((Tn, n, H, W, 4 * hidp), float("nan"), device=device).to(gates_dtype)
-        K.convgru_seq_fwd(gx, h0, Tn, n, H, W, packed, bp, hidp, hs, gates)
+        ws = K.convgru_seq_fwd(gx, h0, Tn, n, H, W, packed, bp, hidp, hs, gates)
+        if ws is not None:  # the two-workgroups-per-map kernel ran (H > 8, hidp > 32): no receiver gave up on its partner's boundary row
+            torch.cuda.synchronize()
+            assert int(ws[-2]) == 0, "split kernel: a boundary-row hand-off timed out"
         # reference: one launch per step on the fp32 widening of the same x-part
         gxf = gx.float().view(Tn, n, H, W, 3 * hidp)
         hs_ref = torch.zeros(Tn, n, H, W, hidp, device=device)
