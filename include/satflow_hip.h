@@ -386,9 +386,12 @@ size_t sf_convgru_seq_fwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
  * the carried gradient staying in registers.  g_seq [T][n][h][w][hidp] / g_last [n][h][w][hidp]: gradients wrt all states / the
  * last state (fp32, either may be NULL); gates, hs as written by sf_convgru_seq_fwd; out: dgx = [az|ar|an], dgh = [az|ar|dh2]
  * [T][n][h][w][3*hidp] bf16-stored - bit-identical to the per-step entry points. */
-int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor hs, int32_t T, int32_t n, int32_t h,
-                       int32_t w, const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, int32_t dtype,
-                       sfStream stream);
+int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor hs, int32_t T, int32_t n, int32_t h, int32_t w,
+                       const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, void* workspace, size_t workspace_bytes,
+                       int32_t dtype, sfStream stream);
+/* workspace (nullable, sf_convgru_seq_bwd_workspace_bytes(n, h, hidp) bytes, 0 = not applicable): as for sf_convgru_seq_fwd - two
+ * workgroups per map of more than 8 rows (hidp 64, 2n <= number of CUs), the boundary row of dgh handed over inside the launch. */
+size_t sf_convgru_seq_bwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
  * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
  * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */
@@ -458,6 +461,10 @@ int sf_l1_loss(sfTensor pred, sfTensor target, int64_t rows, int32_t groups, int
                sfStream stream);
 int sf_bce_logits_loss(sfTensor logits, float label, float label_odd, int64_t rows, int32_t groups, int32_t c, sfTensor grad,
                        double* sums, float* out, sfStream stream); /* label for even groups, label_odd for odd ones */
+/* The three objectives of GANLoss (gan/discriminators.py:70-136) in the same form: mode 1 "vanilla" (= sf_bce_logits_loss), 2 "lsgan"
+ * (nn.MSELoss against the label), 3 "wgangp" (-mean for a real target, label > 0.5; +mean for a generated one). */
+int sf_gan_loss(int32_t mode, sfTensor pred, float label, float label_odd, int64_t rows, int32_t groups, int32_t c, sfTensor grad,
+                double* sums, float* out, sfStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * In-tree DGMR / DVD-GAN style networks: satflow/models/layers/{Normalization,GResBlock,Discriminator,Generator}.py.

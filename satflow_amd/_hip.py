@@ -94,7 +94,8 @@ PROTOTYPES = {
     "sf_convgru_step_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
     "sf_convgru_seq_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, _vp, _sz, _i32, _vp]),
     "sf_convgru_seq_fwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "sf_convgru_seq_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _i32, sfTensor, sfTensor, _i32, _vp]),
+    "sf_convgru_seq_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _i32, sfTensor, sfTensor, _vp, _sz, _i32, _vp]),
+    "sf_convgru_seq_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "sf_convgru_bwd_gates": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
@@ -113,6 +114,7 @@ PROTOTYPES = {
     "sf_leaky_relu": (C.c_int, [_vp, _vp, _i64, C.c_float, _vp, _vp]),
     "sf_l1_loss": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_bce_logits_loss": (C.c_int, [sfTensor, C.c_float, C.c_float, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
+    "sf_gan_loss": (C.c_int, [_i32, sfTensor, C.c_float, C.c_float, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_adam_step": (C.c_int, [_vp, _vp, _vp, _vp, _i64, C.c_float, C.c_float, C.c_float, C.c_float, _i32, C.c_float, _vp]),
     "sf_spectral_norm_workspace_floats": (_sz, [_i32, _i32]),
     "sf_spectral_norm_fwd": (C.c_int, [_vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp]),

@@ -354,15 +354,24 @@ struct GruSeqBwdParams {
   __bf16* dgh; int dgh_s;
   const void* wp;                      // packed transposed weights [chunks = 3*hidp/16][9][hidp][16] bf16
   int T, n, H, W, hidp;
+  unsigned long long* mbox;            // SPLIT kernel: boundary-row mailbox, zeroed before the launch
 };
+constexpr int MBB_ROW = 12 * 16 * 2 * 4;  // granules of one boundary row of dgh (3 * 64 channels = 12 K chunks)
+__host__ __device__ constexpr long long mbox_bwd_slot(long long img, int half, int parity) { return ((img * 2 + half) * 2 + parity) * MBB_ROW; }
 
 constexpr int BP_CHUNK_B = (256 + 1) * PIX_B;  // 256 pixels + one zero pixel per K chunk
 
 // NFR: 32-channel fragments of the hidden state (hidp = 32 * NFR); MFW: M fragments (32 pixels) per wave - 8 / MFW waves.
 // MFW = 2 (4 waves, one per SIMD, 512 registers each): a tap costs 2 + NFR fragment reads for 2 * NFR MFMAs instead of 1 + NFR for
 // NFR; the element-to-lane map stays that of the MFMA result.  The launcher uses MFW = 1 (see there).
-template <int NFR, int MFW>
+// SPLIT (NFR = 2, MFW = 1): two workgroups per image, 8 rows each; wave = (4-row band, M fragment of the band, channel fragment): a
+// wave owns ONE 32-pixel fragment x ONE 32-channel fragment (NFW = 1), still 8 waves.  After the gate backward of a step the bf16
+// dgh values of the workgroup's boundary row go to the partner through the mailbox (12 K chunks x 16 pixels x 2 octets x 4 dwords
+// = 1536 granules) and the partner's row lands in the tile before the K loop; everything else is unchanged (bit-identical results).
+template <int NFR, int MFW, bool SPLIT = false>
 __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(const GruSeqBwdParams p) {
+  static_assert(!SPLIT || (NFR == 2 && MFW == 1), "the split kernel is the hidp = 64, one-fragment-per-wave layout");
+  constexpr int NFW = SPLIT ? 1 : NFR;  // channel fragments per wave
   constexpr int HID = 32 * NFR, CHUNKS = 3 * HID / 16;
   constexpr int WB = 9 * HID * PIX_B;          // weights of one chunk
   constexpr int PIECES = WB / 1024;            // 9 * NFR
@@ -373,9 +382,15 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wl = wave & 3, mf0 = MFW == 2 ? 0 : wave >> 2;  // this wave's M fragments: mf0 .. mf0 + MFW - 1 of the 4-row band wl
   const int r = lane & 31, kh = lane >> 5;
-  const int img = blockIdx.x;
+  const int img = SPLIT ? blockIdx.x >> 1 : blockIdx.x;
+  const int half = SPLIT ? blockIdx.x & 1 : 0;
+  // first row of this wave's M fragment(s): band wl = wave & 3, fragments mf0 .. of it (SPLIT: band (wave & 3) >> 1 of this half, fragment wave & 1)
+  const int wrow = SPLIT ? 8 * half + 4 * ((wave & 3) >> 1) + 2 * (wave & 1) : 4 * (wave & 3) + 2 * (MFW == 2 ? 0 : wave >> 2);
+  const int nf0 = SPLIT ? wave >> 2 : 0;  // first channel fragment of this wave
+  const int send_row = half == 0 ? 7 : 8, recv_row = half == 0 ? 8 : 7;
+  const bool has_partner = SPLIT && p.H > 8;
+  unsigned mb_failed = 0;
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
 
   for (int i = tid; i < CHUNKS * BP_CHUNK_B / 16; i += THREADS) *reinterpret_cast<f32x4*>(lds_t + i * 16) = f32x4{0.f, 0.f, 0.f, 0.f};
@@ -395,7 +410,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
   int a_off[MFW][9];     // A-operand read offsets per tap (within a chunk): the source pixel of tap (ky, kx), or the chunk's zero pixel
 #pragma unroll
   for (int m = 0; m < MFW; ++m) {
-    py[m] = 4 * wl + 2 * (mf0 + m) + (r >> 4); px[m] = r & 15;
+    py[m] = wrow + 2 * m + (r >> 4); px[m] = r & 15;
     ok[m] = py[m] < p.H && px[m] < p.W;
     pix_i[m] = (long long)img * img_px + (ok[m] ? py[m] * p.W + px[m] : 0);
 #pragma unroll
@@ -414,15 +429,15 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
   const bool many = wave < PIECES - WAVES * (PIECES / WAVES);  // this wave issues one more DMA piece per chunk than the others (uniform)
 
   // gradient wrt h_t carried into the gate backward (this lane's 16 * NFR elements per M fragment)
-  f32x4 dh[MFW][NFR][4];
+  f32x4 dh[MFW][NFW][4];
 #pragma unroll
   for (int m = 0; m < MFW; ++m) {
     const long long pt = (long long)(p.T - 1) * step_px + pix_i[m];
 #pragma unroll
-    for (int nf = 0; nf < NFR; ++nf)
+    for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int ch = nf * 32 + 8 * g + cq;
+        const int ch = (nf0 + nf) * 32 + 8 * g + cq;
         f32x4 v = {0.f, 0.f, 0.f, 0.f};
         if (p.g_seq) v = *reinterpret_cast<const f32x4*>(p.g_seq + pt * p.gs_s + ch);
         if (p.g_last) v += *reinterpret_cast<const f32x4*>(p.g_last + pix_i[m] * p.gl_s + ch);
@@ -430,8 +445,8 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
       }
   }
   // saved gates and previous state of the step about to be processed
-  bf16x4 gv[MFW][4][NFR][4];
-  f32x4 hp[MFW][NFR][4];
+  bf16x4 gv[MFW][4][NFW][4];
+  f32x4 hp[MFW][NFW][4];
   auto request = [&](int t) __attribute__((always_inline)) {
 #pragma unroll
     for (int m = 0; m < MFW; ++m) {
@@ -439,16 +454,16 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 #pragma unroll
       for (int q = 0; q < 4; ++q)
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf)
+        for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            gv[m][q][nf][g] = *reinterpret_cast<const bf16x4*>(p.gates + pt * p.gates_s + q * p.hidp + nf * 32 + 8 * g + cq);
+            gv[m][q][nf][g] = *reinterpret_cast<const bf16x4*>(p.gates + pt * p.gates_s + q * p.hidp + (nf0 + nf) * 32 + 8 * g + cq);
 #pragma unroll
-      for (int nf = 0; nf < NFR; ++nf)
+      for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           hp[m][nf][g] = f32x4{0.f, 0.f, 0.f, 0.f};
-          if (t > 0) hp[m][nf][g] = *reinterpret_cast<const f32x4*>(p.hs + (pt - step_px) * p.hs_s + nf * 32 + 8 * g + cq);
+          if (t > 0) hp[m][nf][g] = *reinterpret_cast<const f32x4*>(p.hs + (pt - step_px) * p.hs_s + (nf0 + nf) * 32 + 8 * g + cq);
         }
     }
   };
@@ -456,12 +471,12 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 
   for (int t = p.T - 1; t >= 0; --t) {
     // ---- gate backward of step t ----
-    f32x4 dd[MFW][NFR][4];
+    f32x4 dd[MFW][NFW][4];
 #pragma unroll
     for (int m = 0; m < MFW; ++m) {
       const long long pt = (long long)t * step_px + pix_i[m];
 #pragma unroll
-      for (int nf = 0; nf < NFR; ++nf) {
+      for (int nf = 0; nf < NFW; ++nf) {
         f32x4 az[4], ar[4], an[4], d2[4];
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
@@ -484,7 +499,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
             const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
             const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
             const u32x4_t oct = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
-            const int ch = nf * 32 + 8 * (g + kh);
+            const int ch = (nf0 + nf) * 32 + 8 * (g + kh);
             if (ok[m]) {
               if (q != 3) *reinterpret_cast<u32x4_t*>(p.dgx + pt * p.dgx_s + q * p.hidp + ch) = oct;
               if (q != 2) {
@@ -493,6 +508,17 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
                 if (t > 0) {  // the next convolution's operand
                   const int k = qh * HID + ch;
                   *reinterpret_cast<u32x4_t*>(lds_t + (k >> 4) * BP_CHUNK_B + (py[m] * 16 + px[m]) * PIX_B + 16 * (((ch >> 3) & 1) ^ (py[m] & 1))) = oct;
+                  if constexpr (SPLIT) {
+                    if (has_partner && py[m] == send_row) {  // ... and the partner's, for its rows next to this one
+                      const unsigned epoch = (unsigned)(p.T - t);
+                      unsigned long long* g8 = p.mbox + mbox_bwd_slot(img, half, epoch & 1) + (k >> 4) * 128 + px[m] * 8 + ((ch >> 3) & 1) * 4;
+                      const unsigned long long tag = (unsigned long long)epoch << 32;
+                      __hip_atomic_store(g8 + 0, tag | oct[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      __hip_atomic_store(g8 + 1, tag | oct[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      __hip_atomic_store(g8 + 2, tag | oct[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                      __hip_atomic_store(g8 + 3, tag | oct[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    }
+                  }
                 }
               }
             }
@@ -502,13 +528,39 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
     }
     if (t == 0) break;
     request(t - 1);  // arrives under the K loop
+    if constexpr (SPLIT) {
+      if (has_partner && wave == 0) {  // the partner's boundary row of dgh_t: 1536 granules, 24 per lane, swept until every tag matches
+        const unsigned epoch = (unsigned)(p.T - t);
+        const unsigned long long* src = p.mbox + mbox_bwd_slot(img, half ^ 1, epoch & 1);
+        constexpr int PER = MBB_ROW / 64;
+        unsigned v[PER];
+        for (unsigned spins = 0;; ++spins) {
+          bool all = true;
+#pragma unroll
+          for (int kk = 0; kk < PER; ++kk) {
+            const int gi = lane + 64 * kk;
+            const unsigned long long x = __hip_atomic_load(src + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v[kk] = (unsigned)x;
+            all = all && (((gi >> 3) & 15) >= p.W || (unsigned)(x >> 32) == epoch);
+          }
+          if (__all(all)) break;
+          if (spins >= MB_SPIN_LIMIT) { mb_failed = 1; break; }
+          __builtin_amdgcn_s_sleep(2);
+        }
+#pragma unroll
+        for (int kk = 0; kk < PER; ++kk) {
+          const int gi = lane + 64 * kk, ck = gi >> 7, pxl = (gi >> 3) & 15, oh = (gi >> 2) & 1, dw = gi & 3;
+          if (pxl < p.W) *reinterpret_cast<unsigned*>(lds_t + ck * BP_CHUNK_B + (recv_row * 16 + pxl) * PIX_B + 16 * (oh ^ (recv_row & 1)) + 4 * dw) = v[kk];
+        }
+      }
+    }
 
     // ---- carry = conv3x3^T(dgh_t, Wh): D[channel][pixel], K = 3 * hidp ----
-    f32x16 acc[MFW][NFR];
+    f32x16 acc[MFW][NFW];
 #pragma unroll
     for (int m = 0; m < MFW; ++m)
 #pragma unroll
-      for (int nf = 0; nf < NFR; ++nf)
+      for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][nf][i] = 0.f;
     for (int ci = 0; ci < CHUNKS; ++ci) {
@@ -527,12 +579,12 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
       if (more && !stage_late) issue_weights(nci, nbuf);
       const char* inb = lds_t + ci * BP_CHUNK_B;
       const char* wb = lds + cur * WB + b_lane;
-      bf16x8 fa[2][MFW], fb[2][NFR];
-      auto load_tap = [&](int tap, bf16x8 (&a)[MFW], bf16x8 (&b)[NFR]) __attribute__((always_inline)) {
+      bf16x8 fa[2][MFW], fb[2][NFW];
+      auto load_tap = [&](int tap, bf16x8 (&a)[MFW], bf16x8 (&b)[NFW]) __attribute__((always_inline)) {
 #pragma unroll
         for (int m = 0; m < MFW; ++m) a[m] = *reinterpret_cast<const bf16x8*>(inb + a_off[m][tap]);
 #pragma unroll
-        for (int nf = 0; nf < NFR; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * HID + nf * 32) * PIX_B);
+        for (int nf = 0; nf < NFW; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * HID + (nf0 + nf) * 32) * PIX_B);
       };
       load_tap(0, fa[0], fb[0]);
 #pragma unroll
@@ -541,7 +593,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 #pragma unroll
         for (int m = 0; m < MFW; ++m)
 #pragma unroll
-          for (int nf = 0; nf < NFR; ++nf)
+          for (int nf = 0; nf < NFW; ++nf)
             acc[m][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1][m], acc[m][nf], 0, 0, 0);
         if (tap == 3 && more && stage_late) issue_weights(nci, nbuf);
       }
@@ -553,17 +605,20 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
     for (int m = 0; m < MFW; ++m) {
       const long long ptm = (long long)(t - 1) * step_px + pix_i[m];
 #pragma unroll
-      for (int nf = 0; nf < NFR; ++nf)
+      for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 base = dd[m][nf][g];
-          if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + ptm * p.gs_s + nf * 32 + 8 * g + cq) + dd[m][nf][g];
+          if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + ptm * p.gs_s + (nf0 + nf) * 32 + 8 * g + cq) + dd[m][nf][g];
 #pragma unroll
           for (int c = 0; c < 4; ++c) dh[m][nf][g][c] = base[c] + acc[m][nf][4 * g + c];
         }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if constexpr (SPLIT) {
+    if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox + mbox_bwd_slot(p.n, 0, 0)), 1u);
+  }
 }
 
 }  // namespace
@@ -624,8 +679,14 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   return 0;
 }
 
+extern "C" size_t sf_convgru_seq_bwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp) {
+  if (n <= 0 || h <= 8 || hidp != 64) return 0;
+  return (size_t)(mbox_bwd_slot(n, 0, 0) + 2) * sizeof(unsigned long long);
+}
+
 extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor hs, int32_t T, int32_t n, int32_t h, int32_t w,
-                                  const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, int32_t dtype, sfStream stream) {
+                                  const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, void* workspace, size_t workspace_bytes,
+                                  int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_BF16, "sf_convgru_seq_bwd: the persistent sequence kernel is built for the SF_BF16 kernels (got dtype %d)", dtype);
   SF_REQUIRE(h >= 1 && w >= 1 && h <= 16 && w <= 16, "sf_convgru_seq_bwd: one workgroup owns a whole map: H, W <= 16 (got %dx%d)", h, w);
   SF_REQUIRE(hidp == 32 || hidp == 64, "sf_convgru_seq_bwd: hidp=%d (32 or 64)", hidp);
@@ -649,6 +710,22 @@ extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gate
   hipStream_t st = (hipStream_t)stream;
   // (4 waves with two M fragments each - fewer fragment reads per MFMA - measured SLOWER, 695 vs 580 us: one wave per SIMD has
   // nobody to cover its LDS waits and its gate arithmetic)
+  static const bool no_split = getenv("SF_GRU_NO_SPLIT") != nullptr;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    cus = (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0) ? prop.multiProcessorCount : 1;
+  }
+  const size_t need = sf_convgru_seq_bwd_workspace_bytes(n, h, hidp);
+  const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
+  if (have_ws && hipMemsetAsync(workspace, 0, need, st) != hipSuccess) { sf_set_error("sf_convgru_seq_bwd: mailbox memset failed"); return 2; }
+  if (!no_split && hidp == 64 && h > 8 && 2 * n <= cus && have_ws) {  // two workgroups per map (see sf_convgru_seq_fwd)
+    p.mbox = (unsigned long long*)workspace;
+    hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1, true>), dim3(2 * n), dim3(512), 0, st, p);
+    SF_CHECK_LAUNCH("convgru_seq_bwd (split)");
+    return 0;
+  }
   if (hidp == 64) hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1>), dim3(n), dim3(512), 0, st, p);
   else hipLaunchKernelGGL((convgru_seq_bwd_kernel<1, 1>), dim3(n), dim3(512), 0, st, p);
   SF_CHECK_LAUNCH("convgru_seq_bwd");

@@ -9,7 +9,9 @@
 namespace {
 
 // MODE 0: L1 against `target` (same layout);  MODE 1: BCE-with-logits against a constant label (`label` for even groups,
-// `label_odd` for odd ones: the discriminator step interleaves real and generated frames, cloudgan.py:163-172)
+// `label_odd` for odd ones: the discriminator step interleaves real and generated frames, cloudgan.py:163-172);
+// MODE 2: GANLoss("lsgan") = nn.MSELoss against the constant label;  MODE 3: GANLoss("wgangp") = -mean(x) for a real target
+// (label > 0.5), +mean(x) for a generated one (gan/discriminators.py:94-136)
 template <int MODE>
 __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict__ pred, int ps, const float* __restrict__ target, int ts, float label, float label_odd,
                                                         long long rows_per_group, int c, float gscale, float* __restrict__ grad, int gs,
@@ -27,11 +29,19 @@ __global__ __launch_bounds__(256) void pair_loss_kernel(const float* __restrict_
       const float df = x - target[row * ts + lane];
       l = fabsf(df);
       d = df > 0.f ? 1.f : (df < 0.f ? -1.f : 0.f);
-    } else {
+    } else if (MODE == 1) {
       // max(x, 0) - x * t + log(1 + exp(-|x|));  d/dx = sigmoid(x) - t
       const float t = (g & 1) ? label_odd : label;
       l = fmaxf(x, 0.f) - x * t + log1pf(expf(-fabsf(x)));
       d = 1.f / (1.f + expf(-x)) - t;
+    } else if (MODE == 2) {
+      const float df = x - ((g & 1) ? label_odd : label);
+      l = df * df;
+      d = 2.f * df;
+    } else {
+      const float sgn = (((g & 1) ? label_odd : label) > 0.5f) ? -1.f : 1.f;
+      l = sgn * x;
+      d = sgn;
     }
     acc += (double)l;
     if (grad) grad[row * gs + lane] = d * gscale;
@@ -64,7 +74,8 @@ int launch(int mode, sfTensor pred, sfTensor target, float label, float label_od
            hipStream_t st) {
   SF_REQUIRE(pred.ptr && pred.dtype == SF_F32 && sums && out && groups >= 1 && groups <= 1024 && rows % groups == 0 && c >= 1 && c <= pred.stride,
              "gan loss: pred fp32, rows %% groups == 0, c <= stride");
-  SF_REQUIRE(mode == 1 || (target.ptr && target.dtype == SF_F32 && c <= target.stride), "l1 loss: target");
+  SF_REQUIRE(mode >= 0 && mode <= 3, "gan loss: mode %d (0 l1, 1 vanilla, 2 lsgan, 3 wgangp)", mode);
+  SF_REQUIRE(mode != 0 || (target.ptr && target.dtype == SF_F32 && c <= target.stride), "l1 loss: target");
   SF_REQUIRE(!grad.ptr || (grad.dtype == SF_F32 && c <= grad.stride && grad.c <= grad.stride), "gan loss: grad layout");
   if (hipMemsetAsync(sums, 0, sizeof(double) * (1 + groups), st) != hipSuccess) { sf_set_error("gan loss: memset failed"); return 2; }
   if (rows == 0) {  // an empty batch: torch's mean over nothing is NaN; never leave `out` uninitialised
@@ -76,12 +87,15 @@ int launch(int mode, sfTensor pred, sfTensor target, float label, float label_od
   const float gscale = (float)(1.0 / (count * groups));  // d(mean over ALL elements)
   int bx = (int)((total + 255) / 256); if (bx > 512) bx = 512; if (bx < 1) bx = 1;
   dim3 grid(bx, groups), block(256);
+#define SF_PAIR(M_) hipLaunchKernelGGL((pair_loss_kernel<M_>), grid, block, 0, st, (const float*)pred.ptr, pred.stride, (const float*)nullptr, 0, label, label_odd, rpg, c, \
+                                      gscale, (float*)grad.ptr, grad.stride, grad.c, sums)
   if (mode == 0)
     hipLaunchKernelGGL((pair_loss_kernel<0>), grid, block, 0, st, (const float*)pred.ptr, pred.stride, (const float*)target.ptr, target.stride, 0.f, 0.f, rpg, c,
                        gscale, (float*)grad.ptr, grad.stride, grad.c, sums);
-  else
-    hipLaunchKernelGGL((pair_loss_kernel<1>), grid, block, 0, st, (const float*)pred.ptr, pred.stride, (const float*)nullptr, 0, label, label_odd, rpg, c, gscale,
-                       (float*)grad.ptr, grad.stride, grad.c, sums);
+  else if (mode == 1) SF_PAIR(1);
+  else if (mode == 2) SF_PAIR(2);
+  else SF_PAIR(3);
+#undef SF_PAIR
   SF_CHECK_LAUNCH("gan loss");
   hipLaunchKernelGGL(pair_loss_finalize_kernel, dim3(1), dim3(1024), 0, st, sums, count, groups, out);
   SF_CHECK_LAUNCH("gan loss finalize");
@@ -99,6 +113,13 @@ int sf_l1_loss(sfTensor pred, sfTensor target, int64_t rows, int32_t groups, int
 int sf_bce_logits_loss(sfTensor logits, float label, float label_odd, int64_t rows, int32_t groups, int32_t c, sfTensor grad, double* sums, float* out, sfStream stream) {
   sfTensor none{};
   return launch(1, logits, none, label, label_odd, rows, groups, c, grad, sums, out, (hipStream_t)stream);
+}
+
+int sf_gan_loss(int32_t mode, sfTensor pred, float label, float label_odd, int64_t rows, int32_t groups, int32_t c, sfTensor grad, double* sums, float* out,
+                sfStream stream) {
+  sfTensor none{};
+  SF_REQUIRE(mode >= 1 && mode <= 3, "sf_gan_loss: mode %d (1 vanilla, 2 lsgan, 3 wgangp)", mode);
+  return launch(mode, pred, none, label, label_odd, rows, groups, c, grad, sums, out, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -866,7 +866,8 @@ class _PairLossFn(torch.autograd.Function):
         if target is not None:
             check(lib().sf_l1_loss(T(pred), T(target), rows, groups, c, g, sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_l1_loss")
         else:
-            check(lib().sf_bce_logits_loss(T(pred), labels[0], labels[1], rows, groups, c, g, sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_bce_logits_loss")
+            mode = int(labels[2]) if len(labels) > 2 else 1
+            check(lib().sf_gan_loss(mode, T(pred), labels[0], labels[1], rows, groups, c, g, sums.data_ptr(), out.data_ptr(), stream_ptr()), "sf_gan_loss")
         ctx.save_for_backward(grad if grad is not None else pred.new_empty(0))
         loss, per = out[0], out[1:]
         ctx.mark_non_differentiable(per)
@@ -883,9 +884,13 @@ def l1_loss_groups(pred: Tensor, target: Tensor, groups: int, c: int):
     return _PairLossFn.apply(pred.contiguous(), target.contiguous(), (0.0, 0.0), groups, c)
 
 
-def bce_logits_groups(logits: Tensor, label_even: float, label_odd: float, groups: int, c: int = 1):
-    """``nn.BCEWithLogitsLoss()`` of the first ``c`` lanes against a constant label per group parity (GANLoss "vanilla")."""
-    return _PairLossFn.apply(logits.contiguous(), None, (float(label_even), float(label_odd)), groups, c)
+GAN_MODES = {"vanilla": 1, "lsgan": 2, "wgangp": 3}
+
+
+def bce_logits_groups(logits: Tensor, label_even: float, label_odd: float, groups: int, c: int = 1, mode: str = "vanilla"):
+    """GANLoss of the first ``c`` lanes against a constant label per group parity: ``vanilla`` = ``nn.BCEWithLogitsLoss()``, ``lsgan`` =
+    ``nn.MSELoss()``, ``wgangp`` = ``-mean`` (real label) / ``+mean`` (reference gan/discriminators.py:70-136; ``sf_gan_loss``)."""
+    return _PairLossFn.apply(logits.contiguous(), None, (float(label_even), float(label_odd), GAN_MODES[mode]), groups, c)
 
 
 # ----------------------------------------------------------------------------------------------

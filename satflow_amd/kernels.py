@@ -457,10 +457,14 @@ def convgru_seq_bwd_supported(h: int, w: int, hidp: int, gates: Tensor) -> bool:
 
 
 def convgru_seq_bwd(g_seq: Optional[Tensor], g_last: Optional[Tensor], gates: Tensor, hs: Tensor, Tn: int, n: int, h: int, w: int,
-                    packed_t: Tensor, hidp: int, dgx: Tensor, dgh: Tensor) -> None:
-    """The whole backward time loop in one launch (sf_convgru_seq_bwd)."""
+                    packed_t: Tensor, hidp: int, dgx: Tensor, dgh: Tensor) -> Optional[Tensor]:
+    """The whole backward time loop in one launch (sf_convgru_seq_bwd); returns the split kernel's workspace (its error word is read by
+    the tests) or None."""
+    nbytes = int(lib().sf_convgru_seq_bwd_workspace_bytes(n, h, hidp))
+    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=gates.device) if nbytes else None
     check(lib().sf_convgru_seq_bwd(T(g_seq, hidp), T(g_last, hidp), T(gates), T(hs), Tn, n, h, w, packed_t.data_ptr(), hidp, T(dgx), T(dgh),
-                                   _hip.SF_BF16, stream_ptr()), "sf_convgru_seq_bwd")
+                                   ws.data_ptr() if ws is not None else None, nbytes, _hip.SF_BF16, stream_ptr()), "sf_convgru_seq_bwd")
+    return ws
 
 
 def convgru_bwd_gates(dh: Sequence[sfTensor], gates: Tensor, h_prev: Optional[Tensor], hidp: int, dgx: Tensor, dgh: Tensor,

@@ -40,7 +40,10 @@ def get_norm_layer(norm_type: str = "instance"):
 
 def _is_affine_map(m: nn.Module) -> bool:
     name = type(m).__name__
-    return getattr(m, "weight", None) is not None and ("Conv" in name or "Linear" in name)
+    w = getattr(m, "weight", None)
+    if isinstance(w, nn.parameter.UninitializedParameter):  # a LazyLinear before its first batch: it initialises itself when it materialises
+        return False
+    return w is not None and ("Conv" in name or "Linear" in name)
 
 
 def init_weights(net: nn.Module, init_type: str = "normal", init_gain: float = 0.02) -> None:
@@ -62,3 +65,13 @@ def init_weights(net: nn.Module, init_type: str = "normal", init_gain: float = 0
 def init_net(net: nn.Module, init_type: str = "normal", init_gain: float = 0.02) -> nn.Module:
     init_weights(net, init_type, init_gain=init_gain)
     return net
+
+
+def cal_gradient_penalty(netD, real_data, fake_data, device, type="mixed", constant=1.0, lambda_gp=10.0):
+    """Reference ``gan/common.py:87-133`` (WGAN-GP penalty; defined there but called by no model).  ``lambda_gp <= 0`` returns ``(0.0, None)``
+    as the reference does.  The penalty itself differentiates THROUGH a gradient (``create_graph=True``): the HIP discriminators'
+    autograd nodes implement first derivatives only, so it raises instead of silently computing something else."""
+    if lambda_gp > 0.0:
+        raise NotImplementedError("cal_gradient_penalty: second-order gradients through the HIP discriminator kernels are not implemented "
+                                  "(no reference model calls it; GANLoss('wgangp') itself is available)")
+    return 0.0, None

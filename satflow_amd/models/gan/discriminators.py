@@ -26,9 +26,10 @@ def define_discriminator(input_nc, ndf, netD, n_layers_D=3, norm="batch", init_t
         net = NLayerDiscriminator(input_nc, ndf, n_layers=3, norm_layer=norm_layer, conv_type=conv_type)
     elif netD == "n_layers":
         net = NLayerDiscriminator(input_nc, ndf, n_layers_D, norm_layer=norm_layer, conv_type=conv_type)
-    elif netD in ("pixel", "enhanced"):
-        raise NotImplementedError(f"discriminator {netD!r}: the HIP path implements the PatchGAN the shipped CloudGAN-ConvLSTM config uses "
-                                  "(discriminator_model: 'basic', configs/model/cloudgan_convlstm.yaml:13)")
+    elif netD == "pixel":
+        net = PixelDiscriminator(input_nc, ndf, norm_layer=norm_layer, conv_type=conv_type)
+    elif netD == "enhanced":
+        net = CloudGANDiscriminator(input_channels=input_nc, num_filters=ndf, num_stages=3, conv_type=conv_type)
     else:
         raise NotImplementedError("Discriminator model name [%s] is not recognized" % netD)
     return init_net(net, init_type, init_gain)
@@ -42,9 +43,7 @@ class GANLoss(nn.Module):
         self.register_buffer("real_label", torch.tensor(target_real_label))
         self.register_buffer("fake_label", torch.tensor(target_fake_label))
         self.gan_mode = gan_mode
-        if gan_mode != "vanilla":
-            if gan_mode in ("lsgan", "wgangp"):
-                raise NotImplementedError(f"gan mode {gan_mode}: the HIP path implements 'vanilla' (loss: 'vanilla', cloudgan_convlstm.yaml:15)")
+        if gan_mode not in F.GAN_MODES:
             raise NotImplementedError("gan mode %s not implemented" % gan_mode)
 
     def labels(self, target_is_real: bool) -> float:
@@ -52,13 +51,160 @@ class GANLoss(nn.Module):
 
     def __call__(self, prediction, target_is_real):
         """``prediction [N,1,h,w]`` (NCHW, as the reference's discriminator returns it) -> scalar loss."""
+        if prediction.dim() == 2:  # [N, 1] scores (CloudGANDiscriminator): one pixel per sample
+            prediction = prediction.reshape(prediction.shape[0], prediction.shape[1], 1, 1)
         logits = F.nchw_to_nhwc(prediction)
-        loss, _ = F.bce_logits_groups(logits, self.labels(target_is_real), self.labels(target_is_real), 1, prediction.shape[1])
+        loss, _ = F.bce_logits_groups(logits, self.labels(target_is_real), self.labels(target_is_real), 1, prediction.shape[1], self.gan_mode)
         return loss
 
     def grouped(self, logits_nhwc, real_even: bool, real_odd: bool, groups: int):
         """Loss over ``groups`` concatenated discriminator calls on NHWC logits: (mean over all calls, per-call means)."""
-        return F.bce_logits_groups(logits_nhwc, self.labels(real_even), self.labels(real_odd), groups, 1)
+        return F.bce_logits_groups(logits_nhwc, self.labels(real_even), self.labels(real_odd), groups, 1, self.gan_mode)
+
+
+def instance_norm(x: torch.Tensor, m: nn.InstanceNorm2d) -> torch.Tensor:
+    """``nn.InstanceNorm2d`` without affine parameters or running statistics (what ``get_norm_layer("instance")`` builds, reference
+    ``gan/common.py:19-22``) on NHWC ``x``: per (image, channel) statistics = the training-mode BatchNorm kernels with one group per
+    image and a unit affine map."""
+    if m.affine or m.track_running_stats:
+        raise NotImplementedError("InstanceNorm2d with affine parameters / running statistics (the reference factory builds neither)")
+    n, c = x.shape[0], m.num_features
+    key = (c, str(x.device))
+    if key not in _UNIT_AFFINE:
+        _UNIT_AFFINE[key] = (torch.ones(c, device=x.device), torch.zeros(c, device=x.device))
+    ones, zeros = _UNIT_AFFINE[key]
+    return F._BatchNormTrainFn.apply(x, ones, zeros, None, None, n, m.eps, 0.0, None)
+
+
+_UNIT_AFFINE = {}
+
+
+def _run_sequence(mods, x_nhwc: torch.Tensor, groups: int, training: bool) -> torch.Tensor:
+    """Shared executor of the discriminators' ``nn.Sequential``s: Conv2d (+ fused LeakyReLU), BatchNorm2d / InstanceNorm2d / Identity."""
+    y, i = x_nhwc, 0
+    while i < len(mods):
+        m = mods[i]
+        if isinstance(m, nn.Conv2d):
+            fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)  # conv -> LeakyReLU without a norm in between
+            slope = mods[i + 1].negative_slope if fuse else 1.0
+            if m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0):
+                y = F.linear(y, m.weight.view(m.out_channels, m.in_channels), m.bias)
+                if fuse:
+                    y = F.leaky_relu(y, slope)
+            else:
+                y = F.conv2d(y, m.weight, m.bias, m.stride[0], m.padding[0], slope)
+            i += 2 if fuse else 1
+        elif isinstance(m, nn.BatchNorm2d):
+            y = F.batchnorm(y, m, groups if training else 1, training)
+            i += 1
+        elif isinstance(m, nn.InstanceNorm2d):
+            y = instance_norm(y, m)
+            i += 1
+        elif isinstance(m, nn.LeakyReLU):
+            y = F.leaky_relu(y, m.negative_slope)
+            i += 1
+        elif isinstance(m, nn.Identity):
+            i += 1
+        else:
+            raise NotImplementedError(type(m).__name__)
+    return y
+
+
+class PixelDiscriminator(nn.Module):
+    """Defines a 1x1 PatchGAN discriminator (pixelGAN), reference ``gan/discriminators.py:228-262``: three 1x1 convolutions
+    (``sf_linear_*``) with a norm layer and LeakyReLU(0.2) in between."""
+
+    def __init__(self, input_nc, ndf=64, norm_layer=nn.BatchNorm2d, conv_type: str = "standard"):
+        super().__init__()
+        if type(norm_layer) == functools.partial:
+            use_bias = norm_layer.func == nn.InstanceNorm2d
+        else:
+            use_bias = norm_layer == nn.InstanceNorm2d
+        if conv_type != "standard":
+            raise NotImplementedError("the HIP discriminators implement conv_type='standard'")
+        conv2d = get_conv_layer(conv_type)
+        self.net = nn.Sequential(
+            conv2d(input_nc, ndf, kernel_size=1, stride=1, padding=0), nn.LeakyReLU(0.2, True),
+            conv2d(ndf, ndf * 2, kernel_size=1, stride=1, padding=0, bias=use_bias), norm_layer(ndf * 2), nn.LeakyReLU(0.2, True),
+            conv2d(ndf * 2, 1, kernel_size=1, stride=1, padding=0, bias=use_bias),
+        )
+
+    def run(self, x_nhwc: torch.Tensor, groups: int = 1) -> torch.Tensor:
+        return _run_sequence(list(self.net), x_nhwc, groups, self.training)
+
+    def forward(self, input):
+        require_device(input, "input")
+        return F.nhwc_to_nchw(self.run(F.nchw_to_nhwc(input.float()), 1), 1)
+
+
+class CloudGANBlock(nn.Module):
+    """Reference ``gan/discriminators.py:265-283``: 3x3 convolution WITHOUT padding, ReLU, 2x2 max-pooling (floor)."""
+
+    def __init__(self, input_channels, conv_type: str = "standard"):
+        super().__init__()
+        if conv_type != "standard":
+            raise NotImplementedError("the HIP discriminators implement conv_type='standard' (the antialiased variant needs antialiased_cnns.BlurPool)")
+        conv2d = get_conv_layer(conv_type)
+        self.conv = conv2d(input_channels, input_channels * 2, kernel_size=(3, 3))
+        self.relu = torch.nn.ReLU()
+        self.pool = torch.nn.MaxPool2d(kernel_size=(2, 2), stride=2)
+        self.blurpool = torch.nn.Identity()
+        self._eng = F.ConvEngine([input_channels], input_channels * 2)
+
+    def run(self, x: torch.Tensor) -> torch.Tensor:
+        from ... import functional_gan as FG
+
+        # the unpadded convolution = the interior of the 'same' convolution (MFMA kernel) - one border pixel cut off
+        y = FG._CropFn.apply(F.conv3x3(self._eng, x, self.conv.weight, self.conv.bias), 1)
+        y = F.leaky_relu(y, 0.0)
+        n, h, w, c = y.shape
+        return FG.max_pool3(y.view(n, 1, h, w, c), (1, 2, 2), (1, 2, 2)).view(n, h // 2, w // 2, c)
+
+    def forward(self, x):
+        require_device(x, "x")
+        return F.nhwc_to_nchw(self.run(F.nchw_to_nhwc(x.float())), self.conv.out_channels)
+
+
+class CloudGANDiscriminator(nn.Module):
+    """Reference ``gan/discriminators.py:286-312`` (``discriminator_model="enhanced"``, CloudGAN's constructor default): 1x1 convolution,
+    ``num_stages`` CloudGANBlocks, flatten, one linear score per sample.  ``fc`` is the reference's ``LazyLinear``: it takes its input
+    width from the first batch; its weight keeps the reference's (C, H, W) flattening order in the ``state_dict`` and is re-ordered to
+    the kernels' (H, W, C) on the fly."""
+
+    def __init__(self, input_channels: int = 12, num_filters: int = 64, num_stages: int = 3, conv_type: str = "standard"):
+        super().__init__()
+        conv2d = get_conv_layer(conv_type)
+        self.conv_1 = conv2d(input_channels, num_filters, kernel_size=1, stride=1, padding=0)
+        stages = []
+        for _ in range(num_stages):
+            stages.append(CloudGANBlock(num_filters, conv_type))
+            num_filters = num_filters * 2
+        self.stages = torch.nn.Sequential(*stages)
+        self.flatten = torch.nn.Flatten()
+        self.fc = torch.nn.LazyLinear(1)  # Real/Fake
+        self._out_channels = num_filters
+
+    def run(self, x_nhwc: torch.Tensor, groups: int = 1) -> torch.Tensor:
+        """NHWC ``[N,H,W,Cp] -> [N,1,1,16]`` scores in lane 0 (``groups`` is irrelevant: no batch statistics)."""
+        y = F.linear(x_nhwc, self.conv_1.weight.view(self.conv_1.out_channels, self.conv_1.in_channels), self.conv_1.bias)
+        for blk in self.stages:
+            y = blk.run(y)
+        n, h, w, cp = y.shape
+        c = self._out_channels
+        if isinstance(self.fc.weight, nn.parameter.UninitializedParameter):  # LazyLinear: materialise as torch would on its first call
+            with torch.no_grad():
+                self.fc.initialize_parameters(torch.empty(1, c * h * w, device=y.device))
+                self.fc.in_features = c * h * w
+                self.fc.reset_parameters()
+            self.fc.__class__ = self.fc.cls_to_become
+        if self.fc.in_features != c * h * w:
+            raise RuntimeError(f"CloudGANDiscriminator: fc was built for {self.fc.in_features} features, this input gives {c * h * w}")
+        wk = torch.nn.functional.pad(self.fc.weight.view(1, c, h, w).permute(0, 2, 3, 1), (0, cp - c)).reshape(1, h * w * cp)
+        return F.linear(y.reshape(n, h * w * cp), wk, self.fc.bias).view(n, 1, 1, -1)
+
+    def forward(self, x):
+        require_device(x, "x")
+        return self.run(F.nchw_to_nhwc(x.float()))[:, 0, 0, :1]
 
 
 class NLayerDiscriminator(nn.Module):
@@ -88,23 +234,7 @@ class NLayerDiscriminator(nn.Module):
 
     def run(self, x_nhwc: torch.Tensor, groups: int = 1) -> torch.Tensor:
         """NHWC ``[N,H,W,Cp] -> [N,h,w,16]`` patch logits in lane 0; N = ``groups`` reference calls concatenated."""
-        mods = list(self.model)
-        y, i = x_nhwc, 0
-        while i < len(mods):
-            m = mods[i]
-            if isinstance(m, nn.Conv2d):
-                fuse = i + 1 < len(mods) and isinstance(mods[i + 1], nn.LeakyReLU)  # conv -> LeakyReLU without a norm in between
-                y = F.conv2d(y, m.weight, m.bias, m.stride[0], m.padding[0], mods[i + 1].negative_slope if fuse else 1.0)
-                i += 2 if fuse else 1
-            elif isinstance(m, nn.BatchNorm2d):
-                y = F.batchnorm(y, m, groups if self.training else 1, self.training)
-                i += 1
-            elif isinstance(m, nn.LeakyReLU):
-                y = F.leaky_relu(y, m.negative_slope)
-                i += 1
-            else:
-                raise NotImplementedError(type(m).__name__)
-        return y
+        return _run_sequence(list(self.model), x_nhwc, groups, self.training)
 
     def forward(self, input):
         """Standard forward on NCHW input (one reference call)."""

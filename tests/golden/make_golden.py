@@ -287,6 +287,48 @@ def cloudgan_cases():
             f"oracle cloudgan mismatch {name}"
         np.savez(f"{HERE}/cloudgan_{name}.npz", **_np(rec))
         print(f"cloudgan {name}: ok  g_loss={float(rec['g_loss']):.5f} d_loss={float(rec['d_loss']):.5f}")
+    # (3) the rest of the discriminator / objective surface: CloudGANDiscriminator ("enhanced", the constructor default),
+    # PixelDiscriminator, the PatchGAN with InstanceNorm2d, GANLoss "lsgan" / "wgangp"
+    import functools
+    from satflow.models.gan.discriminators import CloudGANDiscriminator, GANLoss, PixelDiscriminator
+
+    rec = {}
+    builds = {
+        "enhanced": (lambda: CloudGANDiscriminator(input_channels=5, num_filters=8, num_stages=3), (3, 5, 30, 34)),
+        "pixel": (lambda: PixelDiscriminator(5, ndf=8, norm_layer=torch.nn.BatchNorm2d), (3, 5, 9, 11)),
+        "instance": (lambda: NLayerDiscriminator(5, ndf=8, n_layers=2, norm_layer=functools.partial(torch.nn.InstanceNorm2d, affine=False, track_running_stats=False)),
+                     (2, 5, 24, 20)),
+    }
+    for tag, (make, shape) in builds.items():
+        g = torch.Generator().manual_seed(zlib_seed("cloudgan-more" + tag))
+        torch.manual_seed(13)
+        D = make()
+        x = torch.randn(*shape, generator=g).requires_grad_()
+        out = D(x)  # (materialises the LazyLinear of the enhanced discriminator)
+        with torch.no_grad():
+            for n, p in D.named_parameters():
+                p.copy_(torch.randn(p.shape, generator=g) * (0.3 if p.dim() > 1 else 0.2))
+        x.grad = None
+        out = D(x)
+        cot = torch.randn(out.shape, generator=g)
+        (out * cot).sum().backward()
+        rec.update({f"{tag}.x": x.detach(), f"{tag}.out": out.detach(), f"{tag}.cot": cot, f"{tag}.dx": x.grad})
+        for k, v in D.named_parameters():
+            rec[f"{tag}.param.{k}"] = v.detach().clone()
+            rec[f"{tag}.grad.{k}"] = v.grad.clone()
+        print(f"discriminator {tag}: ok  out {tuple(out.shape)}")
+    g = torch.Generator().manual_seed(zlib_seed("ganloss"))
+    pred = torch.randn(4, 1, 6, 5, generator=g)
+    rec["loss.pred"] = pred
+    for mode in ("vanilla", "lsgan", "wgangp"):
+        crit = GANLoss(mode)
+        for real in (True, False):
+            pr = pred.clone().requires_grad_()
+            l = crit(pr, real)
+            l.backward()
+            rec[f"loss.{mode}.{int(real)}"] = l.detach()
+            rec[f"loss.{mode}.{int(real)}.grad"] = pr.grad
+    np.savez(f"{HERE}/cloudgan_more.npz", **_np(rec))
     keys = list(cg.CloudGAN(forecast_steps=2, input_channels=3, num_filters=8, generator_model="convlstm", discriminator_model="basic",
                             channels_per_timestep=3, condition_time=True).state_dict().keys())
     with open(f"{HERE}/cloudgan_state_dict_keys.txt", "w") as f:

@@ -88,9 +88,9 @@ int main(void) {
   REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 20, a16, N0, SF_F32, st));                   /* hidp not padded */
   REFUSED(sf_convgru_step_fwd(a48, a16, 1, 8, 8, ok, 0, 16, N0, N0, SF_F32, st));                    /* no output */
   REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, a64, N0, 0, 0, SF_F32, st));         /* persistent kernel: bf16 kernels only */
-  REFUSED(sf_convgru_seq_bwd(N0, a64, T(ok, 256, 256, SF_BF16), a64, 4, 2, 32, 16, ok, 64, T(ok, 192, 192, SF_BF16), T(ok, 192, 192, SF_BF16), SF_BF16, st)); /* map taller than 16 */
-  REFUSED(sf_convgru_seq_bwd(N0, a64, T(ok, 256, 256, SF_F32), a64, 4, 2, 16, 16, ok, 64, T(ok, 192, 192, SF_BF16), T(ok, 192, 192, SF_BF16), SF_BF16, st));  /* fp32-stored gates */
-  REFUSED(sf_convgru_seq_bwd(N0, a48, T(ok, 192, 192, SF_BF16), a48, 4, 2, 16, 16, ok, 48, T(ok, 144, 144, SF_BF16), T(ok, 144, 144, SF_BF16), SF_BF16, st)); /* hidp 48 */
+  REFUSED(sf_convgru_seq_bwd(N0, a64, T(ok, 256, 256, SF_BF16), a64, 4, 2, 32, 16, ok, 64, T(ok, 192, 192, SF_BF16), T(ok, 192, 192, SF_BF16), 0, 0, SF_BF16, st)); /* map taller than 16 */
+  REFUSED(sf_convgru_seq_bwd(N0, a64, T(ok, 256, 256, SF_F32), a64, 4, 2, 16, 16, ok, 64, T(ok, 192, 192, SF_BF16), T(ok, 192, 192, SF_BF16), 0, 0, SF_BF16, st));  /* fp32-stored gates */
+  REFUSED(sf_convgru_seq_bwd(N0, a48, T(ok, 192, 192, SF_BF16), a48, 4, 2, 16, 16, ok, 48, T(ok, 144, 144, SF_BF16), T(ok, 144, 144, SF_BF16), 0, 0, SF_BF16, st)); /* hidp 48 */
   REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 32, 16, ok, 0, 64, a64, N0, 0, 0, SF_BF16, st));        /* map larger than one workgroup */
   REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 128, a64, N0, 0, 0, SF_BF16, st));       /* hidp > 64 */
   REFUSED(sf_convgru_seq_fwd(a192, N0, 4, 2, 16, 16, ok, 0, 64, m16, N0, 0, 0, SF_BF16, st));        /* misaligned / wrong-width states */
@@ -165,6 +165,7 @@ int main(void) {
   REFUSED(sf_layernorm_chw_bwd(a64, a64, 2, 64, 4, 20, 16, ok, 1e-5f, ok, ok, a64, ok, ok, st));         /* hid > hidp */
   REFUSED(sf_maxpool3d_fwd(a16, 1, 4, 4, 4, 2, 2, 2, 1, 2, 2, a16, st));                                   /* stride below the window */
   REFUSED(sf_maxpool3d_bwd(a16, a16, 1, 4, 4, 4, 8, 1, 1, 8, 1, 1, a16, st));                              /* window beyond the extent */
+  REFUSED(sf_gan_loss(4, a16, 1.f, 0.f, 64, 1, 1, N0, ok, ok, st));                                        /* unknown objective */
   /* size queries never fail, must not overflow */
   printf("packed %zu ws %zu %zu %zu\n", sf_conv3x3_packed_elems(256, 256), sf_conv3x3_bwd_weight_workspace_bytes(256, 256, 2304, 32, 32) + sf_conv3x3_bwd_weight_folded_workspace_bytes(256, 256, 2304, 32, 32, 24),
          sf_linear_bwd_weight_workspace_bytes(384, 64, 24576), sf_conv2d_bwd_weight_workspace_bytes(48, 64, 64, 12, 32, 4, 4));

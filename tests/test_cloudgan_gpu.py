@@ -120,3 +120,73 @@ def test_generic_conv2d_vs_torch(device, n, cin, cout, h, w, k, stride, pad, slo
     assert_close(xd.grad, xr.grad, "conv2d dx", grad=True)
     assert_close(wd.grad, wr.grad, "conv2d dW", grad=True)
     assert_close(bd.grad, br.grad, "conv2d db", grad=True)
+
+
+# ---- the rest of the discriminator / objective surface (goldens: make_golden.py cloudgan, part 3) ---------------------------------
+def _more(device):
+    z = np.load(os.path.join(GOLDEN, "cloudgan_more.npz"))
+    return {k: torch.from_numpy(np.asarray(z[k])).to(device) for k in z.files}
+
+
+@pytest.mark.parametrize("tag", ["enhanced", "pixel", "instance"])
+def test_discriminator_variants_match_reference(device, tag):
+    """CloudGANDiscriminator ("enhanced": the reference constructor's default), PixelDiscriminator and the PatchGAN with InstanceNorm2d
+    (reference gan/discriminators.py:139-312, gan/common.py:19-22): scores, input gradient, every parameter gradient."""
+    import functools
+
+    from satflow_amd.models.gan import CloudGANDiscriminator, NLayerDiscriminator, PixelDiscriminator
+
+    g = _more(device)
+    D = {"enhanced": lambda: CloudGANDiscriminator(input_channels=5, num_filters=8, num_stages=3),
+         "pixel": lambda: PixelDiscriminator(5, ndf=8, norm_layer=torch.nn.BatchNorm2d),
+         "instance": lambda: NLayerDiscriminator(5, ndf=8, n_layers=2, norm_layer=functools.partial(torch.nn.InstanceNorm2d, affine=False, track_running_stats=False))}[tag]()
+    D = D.to(device).train()
+    x = g[f"{tag}.x"].clone().requires_grad_()
+    if tag == "enhanced":
+        with torch.no_grad():
+            D(x.detach())  # materialises the LazyLinear, as the reference's first call does
+    D.load_state_dict({k[len(tag) + 7:]: v for k, v in g.items() if k.startswith(f"{tag}.param.")}, strict=False)
+    out = D(x)
+    assert_close(out, g[f"{tag}.out"], f"{tag}: scores")
+    (out * g[f"{tag}.cot"]).sum().backward()
+    assert_close(x.grad, g[f"{tag}.dx"], f"{tag}: dx", grad=True)
+    for k, p in D.named_parameters():
+        want = g[f"{tag}.grad.{k}"]
+        if float(want.abs().max()) < 1e-4 and k.endswith("bias"):  # a bias in front of a normalisation layer: exact zero gradient
+            assert float(p.grad.abs().max()) < 1e-3, k
+        else:
+            assert_close(p.grad, want, f"{tag}: d{k}", grad=True)
+
+
+@pytest.mark.parametrize("mode", ["vanilla", "lsgan", "wgangp"])
+def test_gan_loss_modes_match_reference(device, mode):
+    from satflow_amd.models.gan import GANLoss
+
+    g = _more(device)
+    crit = GANLoss(mode).to(device)
+    for real in (True, False):
+        pr = g["loss.pred"].clone().requires_grad_()
+        loss = crit(pr, real)
+        assert_close(loss, g[f"loss.{mode}.{int(real)}"], f"{mode} real={real}")
+        loss.backward()
+        assert_close(pr.grad, g[f"loss.{mode}.{int(real)}.grad"], f"{mode} real={real}: gradient", grad=True)
+
+
+def test_cloudgan_default_discriminator_and_objectives_run(device):
+    """The reference constructor's defaults that used to raise: discriminator_model="enhanced", loss "lsgan" / "wgangp", norm="instance"
+    (with the PatchGAN).  One generator and one discriminator step each: finite losses, gradients on the trained network only."""
+    from satflow_amd.models import CloudGAN
+
+    for kw in (dict(discriminator_model="enhanced", loss="lsgan"), dict(discriminator_model="enhanced", loss="wgangp"),
+               dict(discriminator_model="basic", loss="vanilla", norm="instance"), dict(discriminator_model="pixel", loss="lsgan")):
+        torch.manual_seed(3)
+        m = CloudGAN(forecast_steps=2, input_channels=3, num_filters=8, generator_model="convlstm", channels_per_timestep=3, condition_time=True, **kw).to(device)
+        x = torch.randn(2, 3, 3, 32, 32, device=device)
+        y = torch.rand(2, 2, 3, 32, 32, device=device)
+        for idx in (0, 1):
+            m.zero_grad()
+            loss = m.training_step((x, y), 0, idx)["loss"]
+            assert torch.isfinite(loss), (kw, idx)
+            loss.backward()
+            net = m.generator if idx == 0 else m.discriminator
+            assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters()), (kw, idx)

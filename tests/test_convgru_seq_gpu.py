@@ -94,7 +94,8 @@ def test_convgru_module_uses_persistent_kernel_and_matches_per_step(device, monk
         assert torch.equal(res["persistent"][2][k], res["per_step"][2][k]), k
 
 
-@pytest.mark.parametrize("Tn,n,H,W,hid", [(5, 3, 16, 16, 64), (4, 2, 16, 16, 32), (3, 2, 12, 10, 64), (3, 1, 5, 7, 32), (24, 4, 16, 16, 64), (1, 2, 16, 16, 64)])
+@pytest.mark.parametrize("Tn,n,H,W,hid", [(5, 3, 16, 16, 64), (4, 2, 16, 16, 32), (3, 2, 12, 10, 64), (3, 1, 5, 7, 32), (24, 4, 16, 16, 64), (1, 2, 16, 16, 64),
+                                          (24, 96, 16, 16, 64), (6, 128, 9, 13, 64), (3, 130, 16, 16, 64)])  # MetNet's size / ragged on 256 workgroups (split); beyond the CU count (one workgroup per map)
 @pytest.mark.parametrize("use_seq,use_last", [(False, True), (True, False), (True, True)])
 def test_persistent_backward_matches_per_step_kernels(device, bf16_mode, Tn, n, H, W, hid, use_seq, use_last):
     """sf_convgru_seq_bwd (the whole backward time loop in one launch) against sf_convgru_bwd_gates + sf_conv3x3_fwd per step: the
@@ -117,7 +118,10 @@ def test_persistent_backward_matches_per_step_kernels(device, bf16_mode, Tn, n, 
     assert K.convgru_seq_bwd_supported(H, W, hidp, gates)
     dgx = torch.full((Tn, n, H, W, 3 * hidp), float("nan"), device=device).to(torch.bfloat16)
     dgh = torch.full((Tn, n, H, W, 3 * hidp), float("nan"), device=device).to(torch.bfloat16)
-    K.convgru_seq_bwd(g_seq, g_last, gates, hs, Tn, n, H, W, packed_t, hidp, dgx, dgh)
+    ws = K.convgru_seq_bwd(g_seq, g_last, gates, hs, Tn, n, H, W, packed_t, hidp, dgx, dgh)
+    if ws is not None:  # the two-workgroups-per-map kernel ran: no receiver gave up on its partner's boundary row
+        torch.cuda.synchronize()
+        assert int(ws[-2]) == 0, "split kernel: a boundary-row hand-off timed out"
     # reference: the per-step kernels
     rgx, rgh = torch.zeros_like(dgx), torch.zeros_like(dgh)
     direct = torch.empty(n, H, W, hidp, device=device)
