@@ -316,6 +316,42 @@ class MetNetWorkload:
                         "(19 MFLOP per layer, SURVEY 8d)"}
 
 
+def convgru_seq_figures(dev, Tn: int, n: int, hid: int) -> dict:
+    """The north star's recurrent kernel on its own: the persistent ConvGRU sequence kernels (sf_convgru_seq_fwd / _bwd) at the
+    workload's recurrent shape (Tn steps, n maps of 16x16, hidden `hid`), timed with HIP events; achieved MFMA rate and ALGORITHMIC HBM
+    rate (forward: gx in, states and saved gates out; backward: gates, states and state gradients in, dgx / dgh out)."""
+    from satflow_amd import kernels as K
+    from satflow_amd.functional import GRUEngine
+
+    H = W = 16
+    eng = GRUEngine(256, hid)
+    Wh = torch.randn(3 * hid, hid, 3, 3, device=dev) * 0.05
+    bh = torch.randn(3 * hid, device=dev) * 0.1
+    packed, bp = K.pack_weights(Wh, bh, eng.h_fwd, False)
+    packed_t = K.pack_weights(Wh, None, eng.h_bwd, True)[0]
+    gx = torch.randn(Tn * n, H, W, 3 * hid, device=dev).bfloat16()
+    hs = torch.empty(Tn, n, H, W, hid, device=dev)
+    gates = torch.empty(Tn, n, H, W, 4 * hid, device=dev, dtype=torch.bfloat16)
+    t_f = event_time(lambda: K.convgru_seq_fwd(gx, None, Tn, n, H, W, packed, bp, hid, hs, gates), iters=10)
+    g_seq = torch.randn(Tn, n, H, W, hid, device=dev)
+    dgx = torch.empty(Tn, n, H, W, 3 * hid, device=dev, dtype=torch.bfloat16)
+    dgh = torch.empty_like(dgx)
+    out = {"shape": f"T={Tn}, {n} maps of 16x16, hidden {hid}", "fwd_us": t_f * 1e6}
+    px = Tn * n * H * W
+    flops_f = 2.0 * 9 * hid * 3 * hid * px
+    bytes_f = px * (3 * hid * 2 + hid * 4 + 4 * hid * 2)
+    out.update({"fwd_mfma_TFLOPs": flops_f / t_f / 1e12, "fwd_mfma_frac": flops_f / t_f / 1e12 / PEAK_BF16_TFLOPS,
+                "fwd_algorithmic_hbm_GBps": bytes_f / t_f / 1e9, "fwd_hbm_frac": bytes_f / t_f / 1e9 / PEAK_HBM_GBPS})
+    if K.convgru_seq_bwd_supported(H, W, hid, gates):
+        t_b = event_time(lambda: K.convgru_seq_bwd(g_seq, None, gates, hs, Tn, n, H, W, packed_t, hid, dgx, dgh), iters=10)
+        bytes_b = px * (4 * hid * 2 + hid * 4 + hid * 4 + 2 * 3 * hid * 2)
+        out.update({"bwd_us": t_b * 1e6, "bwd_mfma_TFLOPs": flops_f / t_b / 1e12, "bwd_mfma_frac": flops_f / t_b / 1e12 / PEAK_BF16_TFLOPS,
+                    "bwd_algorithmic_hbm_GBps": bytes_b / t_b / 1e9, "bwd_hbm_frac": bytes_b / t_b / 1e9 / PEAK_HBM_GBPS})
+    out["note"] = ("two workgroups per map (8 rows each, boundary rows exchanged inside the launch): 2n workgroups on the chip's CUs; one chain of "
+                   "Tn dependent steps per workgroup - latency-bound by design (a step is 57 MFLOP per map)")
+    return out
+
+
 class CloudGANWorkload(ConvLSTMWorkload):
     """CloudGAN with the ConvLSTM generator (configs/model/cloudgan_convlstm.yaml: 12 channels, 32 filters, PatchGAN
     discriminator, vanilla GAN loss + lambda * L1), 128x128 tiles, T = 12 -> 6.  A step = the generator's optimizer step followed by
@@ -877,7 +913,7 @@ def extra_figures(wl, dev, args, batch: int) -> dict:
     the axial-attention MFMA figure.  Measured after the timed region, on rank 0 of a 1-GPU run only."""
     import satflow_amd
 
-    ex = {"axial_attention": wl.attention_mfma()}
+    ex = {"axial_attention": wl.attention_mfma(), "convgru_sequence_kernels": convgru_seq_figures(dev, wl.T if hasattr(wl, "T") else 24, wl.B * wl.L, wl.hid)}
     sync = torch.cuda.synchronize
     w32 = MetNetWorkload(dev, batch, 0, hidden=32)
     el, _ = timed_steps(w32, 4, 1, 1, dev, sync)
