@@ -258,14 +258,14 @@ class MetNetWorkload:
         alg_bytes = 2 * C * H * W * n * esz + 9 * C * C * (2 if bf16 else 4)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", f"r02_metnet_{mode}_pmc_conv256.json")
+        pmc = os.path.join(ROOT, "profiles", f"r03_metnet_{mode}_pmc_conv256.json")
         if n == 2304 and os.path.exists(pmc):  # PMC pass of this very launch shape (tools/prof_pmc.sh), per launch
             rec = json.load(open(pmc))
             if rec.get("kernel_src_sha") == kernel_source_sha():  # a record of another kernel version is NOT this kernel's traffic
                 traffic, traffic_src = rec["traffic_bytes"], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; "
-                                                              f"profiles/r02_metnet_{mode}_pmc_conv256.json (kernel sources sha {rec['kernel_src_sha']})")
+                                                              f"profiles/r03_metnet_{mode}_pmc_conv256.json (kernel sources sha {rec['kernel_src_sha']})")
             else:
-                traffic_src = f"profiles/r02_metnet_{mode}_pmc_conv256.json is stale (kernel sources changed): dropped"
+                traffic_src = f"profiles/r03_metnet_{mode}_pmc_conv256.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": (f"conv3x3_bf16_persist_kernel<NF=4,TR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images; one persistent workgroup per CU)" if act16 else
@@ -889,7 +889,7 @@ def main(argv=None):
         out["config"]["mode"] = args.dtype
         out["config"]["parity"] = ("ConvLSTM, CloudGAN and ST-LSTM paths pinned to reference-generated goldens; MetNet arithmetic checked against "
                                    "oracle/metnet.py, which is UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this "
-                                   "mode at this size: profiles/r02_parity_observed.jsonl")
+                                   "mode at this size: profiles/r03_parity_observed.jsonl")
         out["roofline"] = wl.roofline()
     if world > 1 or rank == 0:
         comm = comm_report(wl, world, dev)  # collective: every rank takes part

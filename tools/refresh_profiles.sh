@@ -1,9 +1,9 @@
 #!/bin/bash
 # ONE gpurun call: kernel-trace stats of every (workload, mode), PMC traffic passes of the dominant kernel, one full bench line.
-# Results under gpurun_out/r02_*; tools/collect_profiles.sh copies the summaries into profiles/.
+# Results under gpurun_out/r03_*; tools/collect_profiles.sh copies the summaries into profiles/.
 set -u
 cd $GRAFT_REPO_ROOT
-R=${ROUND:-r02}
+R=${ROUND:-r03}
 for m in bf16a bf16 f32; do
   bash tools/prof_stats.sh ${R}_metnet_$m --dtype $m --no-cpu-baseline --no-extra > /dev/null 2>&1
   bash tools/prof_stats.sh ${R}_convlstm_$m --workload convlstm --dtype $m --no-cpu-baseline > /dev/null 2>&1
@@ -14,5 +14,7 @@ python bench.py --workload convlstm --steps 20 --warmup 5 > gpurun_out/${R}_conv
 python bench.py --workload cloudgan --steps 10 --warmup 3 --no-extra > gpurun_out/${R}_cloudgan_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload stlstm --steps 10 --warmup 3 --no-extra > gpurun_out/${R}_stlstm_bf16a_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload stlstm --dtype f32 --steps 10 --warmup 3 --no-extra --no-cpu-baseline > gpurun_out/${R}_stlstm_f32_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
+SF_NO_GRAPH=1 bash tools/prof_stats.sh ${R}_dgmr_bf16 --workload dgmr --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
+timeout 900 python bench.py --workload dgmr --dtype bf16 --steps 5 --warmup 2 > gpurun_out/${R}_dgmr_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 for m in bf16a bf16 f32; do for w in metnet convlstm; do cut -c1-200 gpurun_out/${R}_${w}_$m/bench.json; done; done
 cut -c1-300 gpurun_out/${R}_metnet_bf16a_bench_full.json
