@@ -117,10 +117,11 @@ class ConditionalNorm(nn.Module):
 
     def run(self, x: Tensor, class_id: Tensor, relu: bool = False, up: bool = False, embed_rows=None) -> Tensor:
         """NHWC ``x``; ``relu`` / ``up``: the ReLU and nearest 2x up-sampling GResBlock applies next, in the same pass.
-        ``embed_rows`` (index tensor): image i uses condition row ``embed_rows[i]`` (the generator repeats its conditions)."""
+        ``embed_rows`` (0/1 matrix ``[N, conditions]``): image i uses the condition row its row selects (the generator repeats its
+        conditions; a product instead of an index gather: the gather's backward is a scatter-add whose atomics' order varies from run to run)."""
         e = self.embedding(class_id)
-        if embed_rows is not None:
-            e = e[embed_rows]
+        if embed_rows is not None:  # a 0/1 selection matrix [N, conditions]: rows of e gathered by a product - deterministic in both directions
+            e = FG.bmm(embed_rows.unsqueeze(0), e.unsqueeze(0))[0]
         return FG.conditional_norm(x, e, self.in_channel, self.bn, self.training, relu, up)
 
     def forward(self, x, class_id):
