@@ -212,6 +212,7 @@ def metnet_forward(
     num_att_layers: int = 1,
     bn_stats: Dict[str, Tuple[Tensor, Tensor]] | None = None,
     pool_routing: Dict[Tuple[str, int], Tensor] | None = None,
+    feature_scale: Dict[int, Tensor] | None = None,
 ) -> Tensor:
     """``MetNet.forward(imgs[B,T,C,H,W]) -> [B, forecast_steps, out, input_size//4, input_size//4]``.
 
@@ -221,7 +222,9 @@ def metnet_forward(
     Per lead time ``i`` (upstream recomputes everything per lead time, SURVEY
     3.2): preprocess -> ConditionTime(i) -> TimeDistributed(DownSampler) ->
     ConvGRU (last state of last layer) -> axial attention layers -> 1x1 head;
-    stacked on dim 1.  Dropouts are identity (``temporal_dropout=0`` / eval).
+    stacked on dim 1.  Dropouts are identity (``temporal_dropout=0`` / eval) unless ``feature_scale`` (tests only) gives, per lead
+    time, the keep-scale ``[B,T,256,s,s]`` of ``nn.Dropout(temporal_dropout)`` times the ConvGRU's sequence-consistent input dropout:
+    the masks are then REPLAYED (they come from the kernels' counter-based generator), not drawn.
     """
     outs = []
     base = preprocess(imgs, sat_channels, input_size)
@@ -229,6 +232,8 @@ def metnet_forward(
         t = condition_time(base, i, forecast_steps)
         rt = (None, None) if pool_routing is None else (pool_routing.get(("p1", i)), pool_routing.get(("p2", i)))
         t = time_distributed(lambda f: downsampler(f, p, "image_encoder.module.module", bn_stats, rt), t)
+        if feature_scale is not None:
+            t = t * feature_scale[i]
         _, last = convgru(t, p, "temporal_enc.rnn", num_layers)
         a = last[-1]
         for layer in range(num_att_layers):

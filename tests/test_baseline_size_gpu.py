@@ -180,6 +180,61 @@ def test_cfg3_metnet_train_step_fullsize_f32(device):
              "worst_grad_rel_l2": worst[1]})
 
 
+def test_cfg3_metnet_train_step_fullsize_f32_with_dropout(device):
+    """configs[2] at B=2 with the benchmarked temporal_dropout = 0.2 (and the ConvGRU's input dropout), fp32 mode: the two fused dropouts'
+    counter-based masks are REPLAYED on the oracle side (same seeds through sf_dropout2 on a tensor of ones), so outputs and every
+    parameter gradient are compared exactly as in the dropout-free test - the masks of the timed configuration at full size."""
+    from satflow_amd import functional as F
+    from satflow_amd.models import MetNet
+
+    torch.manual_seed(1234)
+    net = MetNet(**CFG3, temporal_dropout=0.2)
+    g = torch.Generator().manual_seed(99)
+    with torch.no_grad():
+        for name, p in net.named_parameters():
+            if "module.module" in name and p.dim() == 1 and name.endswith("weight"):
+                p.copy_(1 + 0.2 * torch.randn(p.shape, generator=g))
+            elif name.endswith("bias"):
+                p.copy_(0.1 * torch.randn(p.shape, generator=g))
+    P = {k: v.detach().clone() for k, v in net.state_dict().items() if v.dtype == torch.float32 and "running" not in k}
+    x, cot = _cfg3_inputs()
+    B, Tn, L, s, C = 2, 24, 12, 16, 256
+    net = net.to(device).train()
+    net.image_encoder.module.capture = {}
+    torch.manual_seed(4242)                      # the forward pass draws the two dropout seeds from the host generator ...
+    out = net(x.to(device))
+    (out * cot.to(device)).sum().backward()
+    torch.manual_seed(4242)                      # ... replay the draw
+    seed1, seed2 = F._draw_seeds()
+    p1, p2 = net.drop.p, net.temporal_enc.rnn.input_p
+    assert p1 == 0.2 and p2 > 0
+    ones = torch.ones(Tn * L * B, s, s, C, device=device)                  # the pooled tensor's layout: [time][lead][batch]
+    scale = F._Dropout2Fn.apply(ones, p1, p2, L * B * s * s * C, seed1, seed2)
+    keep = float((scale != 0).float().mean())
+    assert abs(keep - (1 - p1) * (1 - p2)) < 0.01, keep
+    sc = scale.view(Tn, L, B, s, s, C).permute(1, 2, 0, 5, 3, 4).contiguous().cpu()   # [lead][B][T][C][s][s]
+    routing = gpu_pool_routing(net, B, Tn)
+    net.image_encoder.module.capture = None
+    from oracle import metnet as M
+
+    _threads()
+    Pr = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
+    ref = M.metnet_forward(x, Pr, sat_channels=12, input_size=64, forecast_steps=12, pool_routing=routing, feature_scale={l: sc[l] for l in range(L)})
+    (ref * cot).sum().backward()
+    assert_close(out, ref.detach(), "cfg3 out (dropout 0.2 replayed)")
+    worst = ("", 0.0)
+    for k, p in net.named_parameters():
+        gk = Pr[k].grad
+        if k in ZERO_TRUE_GRAD:
+            scale_k = max(1.0, float(Pr[k.replace(".bias", ".weight")].grad.abs().max()))
+            assert float(p.grad.abs().max()) <= 1e-4 * scale_k, k
+            continue
+        assert_close(p.grad, gk, f"cfg3+dropout d{k}", grad=True)
+        worst = max(worst, (k, rel_l2(p.grad, gk)), key=lambda t: t[1])
+    publish({"config": "configs[2] MetNet 12ch 256x256 T=24->12 hid 64, B=2, train step, temporal_dropout 0.2 + ConvGRU input dropout (masks replayed)",
+             "mode": "f32", "out_rel_l2": rel_l2(out, ref.detach()), "worst_grad": worst[0], "worst_grad_rel_l2": worst[1], "keep_fraction": keep})
+
+
 def test_cfg3_metnet_train_step_fullsize_bf16a(device):
     """The benchmarked mode at the benchmarked size (B=2 of the 8) against the fp32 oracle; observed errors published.
     Bounds: 1.25x (output) / 1.5x (gradients) the CPU-autocast yardstick, floors 1e-2 / 2e-2."""
