@@ -532,7 +532,9 @@ int sf_tanh(const float* x, const float* y_for_backward, int64_t n, float* out, 
 /* Gate arithmetic of the generator's ConvGRU (the module reference Generator.py:5 imports; restated in oracle/dgmr.py):
  *   gates: zr = [sig(gx_z + gh_z) | sig(gx_r + gh_r)], rh = r * h     (gx, gh: [.., 2*hidp], gh / h nullable = zeros)
  *   out:   cand = tanh(gx_o + gh_o), h_new = h (1 - z) + cand z
- * and their backward passes (dpre: gradient wrt the z | r pre-activations; da: wrt the candidate's pre-activation). */
+ * and their backward passes (dpre: gradient wrt the z | r pre-activations; da: wrt the candidate's pre-activation).  The gradient of z travels
+ * between the two backward passes either as [.., hidp] or as the gradient of the whole z | r tensor [.., 2*hidp]: sf_dvdgru_out_bwd zeroes the r half
+ * of such a dz, sf_dvdgru_gates_bwd reads the first hidp lanes of a row-strided dz. */
 int sf_dvdgru_gates_fwd(sfTensor gx, sfTensor gh, sfTensor h, int64_t pixels, int32_t hidp, sfTensor zr, sfTensor rh, sfStream stream);
 int sf_dvdgru_gates_bwd(sfTensor dz, sfTensor drh, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor dpre, sfTensor dh,
                         sfStream stream);

@@ -506,7 +506,7 @@ __global__ __launch_bounds__(256) void dvdgru_gates_fwd_kernel(const float* __re
   }
 }
 // in: dz (gradient wrt the gate z, nullable), drh (wrt r*h, nullable), saved zr, h  ->  dpre [.., 2H] (z | r pre-activations), dh (+= nothing: written)
-__global__ __launch_bounds__(256) void dvdgru_gates_bwd_kernel(const float* __restrict__ dz, const float* __restrict__ drh, const float* __restrict__ zr,
+__global__ __launch_bounds__(256) void dvdgru_gates_bwd_kernel(const float* __restrict__ dz, int dzs, const float* __restrict__ drh, const float* __restrict__ zr,
                                                                const float* __restrict__ h, int hs, long long pixels, int H, float* __restrict__ dpre,
                                                                float* __restrict__ dh) {
   const int q = H >> 2;
@@ -515,7 +515,7 @@ __global__ __launch_bounds__(256) void dvdgru_gates_bwd_kernel(const float* __re
     const long long pix = idx / q;
     const int c = (int)(idx - pix * q) * 4;
     const f32x4 z = ld4(zr + pix * 2 * H + c), r = ld4(zr + pix * 2 * H + H + c);
-    const f32x4 gz = dz ? ld4(dz + pix * H + c) : kZero4, gr = drh ? ld4(drh + pix * H + c) : kZero4;
+    const f32x4 gz = dz ? ld4(dz + pix * dzs + c) : kZero4, gr = drh ? ld4(drh + pix * H + c) : kZero4;
     const f32x4 hv = h ? ld4(h + pix * hs + c) : kZero4;
     f32x4 pz, pr, o;
 #pragma unroll
@@ -551,7 +551,7 @@ __global__ __launch_bounds__(256) void dvdgru_out_fwd_kernel(const float* __rest
 // in: dh', saved cand, zr, h  ->  da (wrt the candidate's pre-activation), dz (wrt the gate z), dh (direct path dh' (1 - z))
 __global__ __launch_bounds__(256) void dvdgru_out_bwd_kernel(const float* __restrict__ dhn, const float* __restrict__ cand, const float* __restrict__ zr,
                                                              const float* __restrict__ h, int hs, long long pixels, int H, float* __restrict__ da,
-                                                             float* __restrict__ dz, float* __restrict__ dh) {
+                                                             float* __restrict__ dz, int dzs, float* __restrict__ dh) {
   const int q = H >> 2;
   const long long total = pixels * q;
   for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
@@ -566,7 +566,8 @@ __global__ __launch_bounds__(256) void dvdgru_out_bwd_kernel(const float* __rest
       gz[j] = g[j] * (n[j] - hv[j]);
       gh[j] = g[j] * (1.f - z[j]);
     }
-    st4(da + pix * H + c, a); st4(dz + pix * H + c, gz);
+    st4(da + pix * H + c, a); st4(dz + pix * dzs + c, gz);
+    if (dzs >= 2 * H) st4(dz + pix * dzs + H + c, kZero4);   // dz as the gradient of the whole z | r tensor: the r half does not reach h' here
     if (dh) st4(dh + pix * H + c, gh);
   }
 }
@@ -802,10 +803,10 @@ int sf_dvdgru_gates_fwd(sfTensor gx, sfTensor gh, sfTensor h, int64_t pixels, in
 }
 
 int sf_dvdgru_gates_bwd(sfTensor dz, sfTensor drh, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor dpre, sfTensor dh, sfStream stream) {
-  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && (!dz.ptr || okd(dz, hidp)) && (!drh.ptr || okd(drh, hidp)) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) &&
-                 okd(dpre, 2 * hidp) && (!dh.ptr || okd(dh, hidp)), "sf_dvdgru_gates_bwd: dense fp32 tensors");
+  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && (!dz.ptr || oks(dz, hidp)) && (!drh.ptr || okd(drh, hidp)) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) &&
+                 okd(dpre, 2 * hidp) && (!dh.ptr || okd(dh, hidp)), "sf_dvdgru_gates_bwd: fp32 tensors, dense except dz / h (row-strided)");
   if (pixels <= 0) return 0;
-  hipLaunchKernelGGL(dvdgru_gates_bwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)dz.ptr, (const float*)drh.ptr,
+  hipLaunchKernelGGL(dvdgru_gates_bwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)dz.ptr, dz.stride, (const float*)drh.ptr,
                      (const float*)zr.ptr, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)dpre.ptr, (float*)dh.ptr);
   SF_CHECK_LAUNCH("dvdgru_gates_bwd");
   return 0;
@@ -823,11 +824,11 @@ int sf_dvdgru_out_fwd(sfTensor gx, sfTensor gh, sfTensor zr, sfTensor h, int64_t
 
 int sf_dvdgru_out_bwd(sfTensor dh_new, sfTensor cand, sfTensor zr, sfTensor h, int64_t pixels, int32_t hidp, sfTensor da, sfTensor dz, sfTensor dh,
                       sfStream stream) {
-  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && okd(dh_new, hidp) && okd(cand, hidp) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) && okd(da, hidp) && okd(dz, hidp) &&
-                 (!dh.ptr || okd(dh, hidp)), "sf_dvdgru_out_bwd: dense fp32 tensors");
+  SF_REQUIRE(hidp > 0 && hidp % 4 == 0 && okd(dh_new, hidp) && okd(cand, hidp) && okd(zr, 2 * hidp) && (!h.ptr || oks(h, hidp)) && okd(da, hidp) && (okd(dz, hidp) || okd(dz, 2 * hidp)) &&
+                 (!dh.ptr || okd(dh, hidp)), "sf_dvdgru_out_bwd: dense fp32 tensors (dz: hidp lanes, or 2*hidp = the gradient of z | r with a zero r half)");
   if (pixels <= 0) return 0;
   hipLaunchKernelGGL(dvdgru_out_bwd_kernel, dim3(grid_of(pixels * (hidp / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)dh_new.ptr, (const float*)cand.ptr,
-                     (const float*)zr.ptr, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)da.ptr, (float*)dz.ptr, (float*)dh.ptr);
+                     (const float*)zr.ptr, (const float*)h.ptr, h.stride, (long long)pixels, hidp, (float*)da.ptr, (float*)dz.ptr, dz.stride, (float*)dh.ptr);
   SF_CHECK_LAUNCH("dvdgru_out_bwd");
   return 0;
 }

@@ -206,36 +206,42 @@ class _CropFn(torch.autograd.Function):
         return gx, None
 
 
-_TILE_MASKS = {}
+_REGROUP5 = {}
 
 
-def _tile_masks(dev):
-    if dev not in _TILE_MASKS:
-        row = torch.ones(3, 3, device=dev)
-        row[0, :] = 0
-        col = torch.ones(3, 3, device=dev)
-        col[:, 0] = 0
-        _TILE_MASKS[dev] = (row, col)
-    return _TILE_MASKS[dev]
+def _regroup5_index(dev):
+    """Gather index / mask of the 5x5 -> four 3x3 tiles regrouping: tile (ty, tx) holds taps (2 ty + ky, 2 tx + kx); the middle row / column of the
+    5x5 kernel is covered twice and belongs to the upper / left tile."""
+    if dev not in _REGROUP5:
+        idx, mask = [], []
+        for ty in (0, 1):
+            for tx in (0, 1):
+                for ky in range(3):
+                    for kx in range(3):
+                        idx.append((2 * ty + ky) * 5 + 2 * tx + kx)
+                        mask.append(0.0 if (ty and ky == 0) or (tx and kx == 0) else 1.0)
+        _REGROUP5[dev] = (torch.tensor(idx, device=dev), torch.tensor(mask, device=dev))
+    return _REGROUP5[dev]
+
+
+def regroup5x5(weight: Tensor, lanes: int) -> Tensor:
+    """``[O, I, 5, 5]`` -> ``[O, 4 * lanes, 3, 3]``: the weight of the ONE 3x3 convolution over four shifted copies (``lanes`` channels each, ``I <= lanes``)
+    that equals the 5x5 convolution.  Autograd-tracked torch ops on a parameter-sized tensor; a function of the weight only, so a recurrent cell
+    builds it once per sequence, not once per frame."""
+    O, I = weight.shape[0], weight.shape[1]
+    idx, mask = _regroup5_index(weight.device)
+    g = (weight.reshape(O, I, 25).index_select(2, idx) * mask).view(O, I, 4, 9).transpose(1, 2)   # [O, tile, I, 9]
+    if lanes != I:
+        g = torch.nn.functional.pad(g, (0, 0, 0, lanes - I))
+    return g.reshape(O, 4 * lanes, 3, 3)
 
 
 def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.ConvEngine") -> Tensor:
     """``nn.Conv2d(k=5, padding=2)`` on the 3x3 MFMA kernels (``sf_pad_shift_stack4_fwd``: the input on a domain padded by 2, shifted
-    four ways, stacked as channels; the 5x5 kernel as four 3x3 tiles, tiny autograd-tracked weight slices; the interior of the result).
-    ``eng``: a ConvEngine for ``[4 * x lanes] -> cout``."""
-    O, I = weight.shape[0], weight.shape[1]
-    cp = x.shape[-1]
-    row, col = _tile_masks(weight.device)
-    tiles = []
-    for ty in (0, 1):
-        for tx in (0, 1):
-            t = weight[:, :, 2 * ty:2 * ty + 3, 2 * tx:2 * tx + 3]
-            if ty:
-                t = t * row   # the middle row of the 5x5 kernel belongs to the upper tile
-            if tx:
-                t = t * col
-            tiles.append(torch.nn.functional.pad(t, (0, 0, 0, 0, 0, cp - I)) if cp != I else t)
-    w3 = torch.cat(tiles, 1).contiguous()   # [O, 4*cp, 3, 3]
+    four ways, stacked as channels; the 5x5 kernel as four 3x3 tiles; the interior of the result).  ``weight``: the 5x5 weight, or what
+    ``regroup5x5(weight, x lanes)`` made of it.  ``eng``: a ConvEngine for ``[4 * x lanes] -> cout``."""
+    w3 = regroup5x5(weight, x.shape[-1]) if weight.shape[-1] == 5 else weight
+    assert w3.shape[1] == 4 * x.shape[-1] and w3.shape[-1] == 3, (w3.shape, x.shape)
     return _CropFn.apply(F.conv3x3(eng, _PadShift4Fn.apply(x.contiguous()), w3, bias), 2)
 
 
@@ -435,7 +441,7 @@ class _DvdGruGatesFn(torch.autograd.Function):
         hidp = ctx.hidp
         has_gh, has_h = ctx.has
         pixels = zr.numel() // (2 * hidp)
-        dz = dzr[..., :hidp].contiguous() if dzr is not None else None
+        dz = dzr.contiguous() if dzr is not None else None   # read through its row stride: no slice copy
         drh = drh.contiguous() if drh is not None else None
         dpre = torch.empty_like(zr)
         dh = torch.empty(*zr.shape[:-1], hidp, dtype=torch.float32, device=zr.device) if has_h else None
@@ -467,11 +473,10 @@ class _DvdGruOutFn(torch.autograd.Function):
         pixels = cand.numel() // hidp
         dhn = dhn.contiguous()
         da = torch.empty_like(cand)
-        dz = torch.empty_like(cand)
+        dzr = torch.empty_like(zr)   # the kernel zeroes the r half: it does not reach h' through this stage
         dh = torch.empty_like(cand) if has_h else None
-        check(lib().sf_dvdgru_out_bwd(T(dhn), T(cand), T(zr), T(h) if has_h else NULL, pixels, hidp, T(da), T(dz), T(dh) if dh is not None else NULL, stream_ptr()),
+        check(lib().sf_dvdgru_out_bwd(T(dhn), T(cand), T(zr), T(h) if has_h else NULL, pixels, hidp, T(da), T(dzr), T(dh) if dh is not None else NULL, stream_ptr()),
               "sf_dvdgru_out_bwd")
-        dzr = torch.cat((dz, torch.zeros_like(dz)), -1)  # the r half of zr does not reach h' through this stage
         return da, (da if has_gh else None), dzr, dh, None
 
 

@@ -46,20 +46,31 @@ class ConvGRUCell(nn.Module):
     def _rows(self, w: Tensor) -> Tensor:
         return TF.pad(w, (0, 0, 0, 0, 0, 0, 0, self._hp - self.hidden_size)) if self._hp != self.hidden_size else w
 
-    def weights(self):
+    def _as_tiles(self) -> bool:
+        return self.kernel_size == 5 and not os.environ.get("SF_CONV5_DIRECT")
+
+    def weights(self, x_lanes: Optional[int] = None):
+        """The six derived weights of a call / a sequence.  5x5 kernels are regrouped HERE into the weight of the 3x3 convolution over four shifted
+        copies (``x_lanes``: channel lanes of the cell's input tensor) - once per sequence, not once per frame."""
         ci, hp, hid = self.input_size, self._hp, self.hidden_size
         wz, wr, wo = self._rows(self.update_gate.weight), self._rows(self.reset_gate.weight), self._rows(self.out_gate.weight)
         pb = (lambda b: TF.pad(b, (0, hp - hid))) if hp != hid else (lambda b: b)
-        return dict(
-            zr_x=torch.cat((wz[:, :ci], wr[:, :ci]), 0).contiguous(), zr_h=torch.cat((wz[:, ci:], wr[:, ci:]), 0).contiguous(),
-            o_x=wo[:, :ci].contiguous(), o_h=wo[:, ci:].contiguous(),
-            b_zr=torch.cat((pb(self.update_gate.bias), pb(self.reset_gate.bias)), 0), b_o=pb(self.out_gate.bias),
-        )
+        wzr = torch.cat((wz, wr), 0)
+        W = dict(zr_x=wzr[:, :ci], zr_h=wzr[:, ci:], o_x=wo[:, :ci], o_h=wo[:, ci:],
+                 b_zr=torch.cat((pb(self.update_gate.bias), pb(self.reset_gate.bias)), 0), b_o=pb(self.out_gate.bias))
+        if self._as_tiles():
+            xl = cpad(ci) if x_lanes is None else x_lanes
+            for k, lanes in (("zr_x", xl), ("o_x", xl), ("zr_h", hp), ("o_h", hp)):
+                W[k] = FG.regroup5x5(W[k], lanes)
+        else:
+            for k in ("zr_x", "zr_h", "o_x", "o_h"):
+                W[k] = W[k].contiguous()
+        return W
 
     def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
         k = self.kernel_size
-        if k in (3, 5) and not (k == 5 and os.environ.get("SF_CONV5_DIRECT")):
-            cin = w.shape[1] if k == 3 else 4 * x.shape[-1]   # 5x5: four shifted copies of the (padded) input lanes
+        if k == 3 or self._as_tiles():
+            cin = w.shape[1]   # 5x5: already regrouped over four shifted copies of the (padded) input lanes
             key = (tag, cin, w.shape[0])
             if key not in self._eng:
                 self._eng[key] = F.ConvEngine([cin], w.shape[0])
@@ -84,7 +95,7 @@ class ConvGRUCell(nn.Module):
         return FG.dvdgru_out(gx_o, gh_o, zr, h, hp)
 
     def run(self, x: Tensor, h: Optional[Tensor]) -> Tensor:
-        W = self.weights()
+        W = self.weights(x.shape[-1])
         return self.step(*self.x_parts(x, W), h, W)
 
     def forward(self, input_, prev_state=None):
@@ -124,7 +135,7 @@ class ConvGRU(nn.Module):
         layer's states, time-major ``[T*n,H,W,hidp]``.  Layer by layer: a layer's x-parts for all frames in one launch."""
         seq, const = x, constant_input
         for cell in self.cells:
-            W = cell.weights()
+            W = cell.weights(seq.shape[-1])
             gx_zr, gx_o = cell.x_parts(seq, W)
             n = gx_zr.shape[0] if const else gx_zr.shape[0] // T_frames
             # per-frame views through unbind (its backward is ONE stack, not a zero-filled full-size tensor per slice)
