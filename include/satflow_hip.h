@@ -552,6 +552,11 @@ int sf_dvdgru_out_bwd(sfTensor dh_new, sfTensor cand, sfTensor zr, sfTensor h, i
 int sf_bmm_f32(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
                int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta,
                sfStream stream);
+/* The same product with the operands rounded to bf16 (RNE) as they are staged, fp32 accumulate: what torch.bmm computes under torch.autocast, i.e. the
+ * attention products of Discriminator.py:104-126 / Attention.py in the reference's 16-bit training mode (configs precision: 16).  fp32 data in memory. */
+int sf_bmm_bf16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
+                int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta,
+                sfStream stream);
 int sf_softmax_rows_fwd(const float* x, int64_t rows, int32_t L, float* y, sfStream stream);
 int sf_softmax_rows_bwd(const float* g, const float* y, int64_t rows, int32_t L, float* dx, sfStream stream);
 

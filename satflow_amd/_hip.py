@@ -141,6 +141,7 @@ PROTOTYPES = {
     "sf_dvdgru_out_fwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, _vp]),
     "sf_dvdgru_out_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _vp]),
     "sf_bmm_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
+    "sf_bmm_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sf_softmax_rows_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "sf_softmax_rows_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),

@@ -76,6 +76,137 @@ __global__ __launch_bounds__(256) void bmm_f32_kernel(const BmmParams p) {
   }
 }
 
+// ---- the same product with bf16 MFMA operands (fp32 data in memory, fp32 accumulate) -----------------------------------------
+// What torch.bmm computes under torch.autocast: used for the attention products in the bf16 compute modes.  The 16x higher MFMA rate
+// needs operand reuse the direct-from-global kernel above does not have: a workgroup owns a 128 x 128 tile of C, stages 128 x 32 blocks of A and
+// B through LDS as bf16 (rounded once, RNE; [row][k] with rows padded to 80 bytes: the MFMA operand of a lane is one ds_read_b128), 2 x 2 waves
+// with 2 x 2 fragments of 32 x 32 each.  The global loads of block k+1 are in flight while block k is multiplied; one barrier per block (two LDS
+// buffers).  MODE 0: the operand is k-contiguous (16-byte loads along k), MODE 1: any strides (lanes walk the row index - coalesced when that is
+// the contiguous one).
+constexpr int BK = 32, BT = 128, LROW = 40;   // k-block, tile edge, LDS row pitch in bf16 elements
+
+template <int MODE>
+__device__ __forceinline__ void bmm_load_block(const float* __restrict__ base, long long srow, long long sk, int rows_total, int row0, int k0, int K, float (&v)[16]) {
+  const int t = threadIdx.x;
+  if (MODE == 0) {
+    const int row = row0 + (t >> 1);
+    const float* ptr = base + (long long)(row < rows_total ? row : rows_total - 1) * srow + k0 + (t & 1) * 16;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const bool ok = k0 + (t & 1) * 16 + 4 * j < K;   // K % 4 == 0 in this mode: a quad is inside or outside
+      const f32x4 q = *reinterpret_cast<const f32x4*>(ok ? ptr + 4 * j : base);
+#pragma unroll
+      for (int c = 0; c < 4; ++c) v[4 * j + c] = ok ? q[c] : 0.f;
+    }
+  } else {
+    const int kq = k0 + (t >> 6) * 8;
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      const int row = row0 + (t & 63) + 64 * rr;
+      const float* ptr = base + (long long)(row < rows_total ? row : rows_total - 1) * srow;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const bool ok = kq + j < K;
+        const float x = ptr[(long long)(ok ? kq + j : 0) * sk];
+        v[8 * rr + j] = ok ? x : 0.f;
+      }
+    }
+  }
+}
+template <int MODE>
+__device__ __forceinline__ void bmm_store_block(__bf16* __restrict__ tile, const float (&v)[16]) {
+  const int t = threadIdx.x;
+  if (MODE == 0) {
+    __bf16* d = tile + (t >> 1) * LROW + (t & 1) * 16;
+#pragma unroll
+    for (int hlf = 0; hlf < 2; ++hlf) {
+      f32x8_t f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) f[c] = v[8 * hlf + c];
+      *reinterpret_cast<bf16x8_t*>(d + 8 * hlf) = __builtin_convertvector(f, bf16x8_t);
+    }
+  } else {
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+      f32x8_t f;
+#pragma unroll
+      for (int c = 0; c < 8; ++c) f[c] = v[8 * rr + c];
+      *reinterpret_cast<bf16x8_t*>(tile + ((t & 63) + 64 * rr) * LROW + (t >> 6) * 8) = __builtin_convertvector(f, bf16x8_t);
+    }
+  }
+}
+
+template <int AMODE, int BMODE>
+__global__ __launch_bounds__(256) void bmm_bf16_kernel(const BmmParams p) {
+  __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][BT * LROW];   // [buffer][A | B][row][k]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int i = lane & 31, h = lane >> 5;
+  const int b = blockIdx.x / p.mtiles, mt = blockIdx.x - b * p.mtiles;
+  const int m0 = mt * BT, n0 = blockIdx.y * BT;
+  const int wm = (wave >> 1) * 64, wn = (wave & 1) * 64;
+  const float* Ab = p.A + (long long)b * p.sAb;
+  const float* Bb = p.B + (long long)b * p.sBb;
+  f32x16 acc[2][2];
+#pragma unroll
+  for (int x = 0; x < 2; ++x)
+#pragma unroll
+    for (int y = 0; y < 2; ++y)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[x][y][r] = 0.f;
+  float va[16], vb[16];
+  bmm_load_block<AMODE>(Ab, p.sAm, p.sAk, p.M, m0, 0, p.K, va);
+  bmm_load_block<BMODE>(Bb, p.sBn, p.sBk, p.N, n0, 0, p.K, vb);
+  bmm_store_block<AMODE>(lds[0][0], va);
+  bmm_store_block<BMODE>(lds[0][1], vb);
+  __syncthreads();
+  const int nblk = (p.K + BK - 1) / BK;
+  for (int kb = 0; kb < nblk; ++kb) {
+    const int cur = kb & 1;
+    const bool more = kb + 1 < nblk;
+    if (more) {
+      bmm_load_block<AMODE>(Ab, p.sAm, p.sAk, p.M, m0, (kb + 1) * BK, p.K, va);
+      bmm_load_block<BMODE>(Bb, p.sBn, p.sBk, p.N, n0, (kb + 1) * BK, p.K, vb);
+    }
+    const __bf16* ta = lds[cur][0];
+    const __bf16* tb = lds[cur][1];
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[2], fb[2];
+#pragma unroll
+      for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const bf16x8_t*>(ta + (wm + 32 * x + i) * LROW + ks * 16 + 8 * h);
+#pragma unroll
+      for (int y = 0; y < 2; ++y) fb[y] = *reinterpret_cast<const bf16x8_t*>(tb + (wn + 32 * y + i) * LROW + ks * 16 + 8 * h);
+#pragma unroll
+      for (int x = 0; x < 2; ++x)
+#pragma unroll
+        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[y], acc[x][y], 0, 0, 0);
+    }
+    if (more) {
+      bmm_store_block<AMODE>(lds[cur ^ 1][0], va);
+      bmm_store_block<BMODE>(lds[cur ^ 1][1], vb);
+    }
+    __syncthreads();
+  }
+  // D[m][n]: the lane holds column n = .. + i, rows frag_row(r, h) (as in bmm_f32_kernel)
+#pragma unroll
+  for (int y = 0; y < 2; ++y) {
+    const int n = n0 + wn + 32 * y + i;
+    if (n >= p.N) continue;
+    float* Cp = p.C + (long long)b * p.sCb + (long long)n * p.sCn;
+#pragma unroll
+    for (int x = 0; x < 2; ++x)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int mm = m0 + wm + 32 * x + frag_row(r, h);
+        if (mm < p.M) {
+          float* d = Cp + (long long)mm * p.sCm;
+          const float v = p.alpha * acc[x][y][r];
+          *d = p.beta != 0.f ? v + p.beta * *d : v;
+        }
+      }
+  }
+}
+
 // ---- softmax over contiguous rows ------------------------------------------------------------------------------------
 __device__ __forceinline__ float block_max(float v, float* red) {
   for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_down(v, o));
@@ -177,6 +308,24 @@ int sf_bmm_f32(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const floa
   else if (bvec) hipLaunchKernelGGL((bmm_f32_kernel<false, true>), grid, block, 0, st, p);
   else hipLaunchKernelGGL((bmm_f32_kernel<false, false>), grid, block, 0, st, p);
   SF_CHECK_LAUNCH("bmm_f32");
+  return 0;
+}
+
+int sf_bmm_bf16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C, int64_t sCb, int64_t sCm,
+                int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta, sfStream stream) {
+  SF_REQUIRE(A && B && C && batch >= 0 && M >= 0 && N >= 0 && K >= 1, "sf_bmm_bf16: null operand or bad extents (%d x %d x %d, batch %d)", M, N, K, batch);
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  BmmParams p{A, B, C, sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn, batch, M, N, K, (M + BT - 1) / BT, alpha, beta};
+  SF_REQUIRE((long long)batch * p.mtiles < 2147483647LL && (N + BT - 1) / BT <= 65535, "sf_bmm_bf16: grid too large");
+  const bool avec = sAk == 1 && ((uintptr_t)A & 15) == 0 && sAb % 4 == 0 && sAm % 4 == 0 && K % 4 == 0;
+  const bool bvec = sBk == 1 && ((uintptr_t)B & 15) == 0 && sBb % 4 == 0 && sBn % 4 == 0 && K % 4 == 0;
+  dim3 grid((unsigned)(batch * p.mtiles), (N + BT - 1) / BT), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (avec && bvec) hipLaunchKernelGGL((bmm_bf16_kernel<0, 0>), grid, block, 0, st, p);
+  else if (avec) hipLaunchKernelGGL((bmm_bf16_kernel<0, 1>), grid, block, 0, st, p);
+  else if (bvec) hipLaunchKernelGGL((bmm_bf16_kernel<1, 0>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((bmm_bf16_kernel<1, 1>), grid, block, 0, st, p);
+  SF_CHECK_LAUNCH("bmm_bf16");
   return 0;
 }
 

@@ -77,6 +77,43 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
   }
 }
 
+// Few rows (a latent vector through a fully connected layer: 2 x 240 -> 65536; an attention projection on a 4x4 map): the 128-row MFMA tile above
+// is nearly empty and its W loads are one 16-byte piece per lane from 32 different rows.  Here a WAVE owns one output column n and a block of up to 8
+// rows: W[n][:] is read once, coalesced (the whole layer is then one pass over W at HBM speed), the x rows come from L1/L2, the 64 partial dot products
+// are combined with xor-shuffles (fixed order: deterministic).
+__global__ __launch_bounds__(256) void linear_fwd_fewrows_kernel(const float* __restrict__ x, int xs, int rows, int K, const float* __restrict__ W, int N,
+                                                                 const float* __restrict__ bias, float* __restrict__ y, int ys, int yc) {
+  const int lane = threadIdx.x & 63;
+  const int rblocks = (rows + 7) / 8;
+  const long long tasks = (long long)yc * rblocks;
+  for (long long task = (long long)blockIdx.x * 4 + (threadIdx.x >> 6); task < tasks; task += (long long)gridDim.x * 4) {
+    const int n = (int)(task / rblocks), r0 = (int)(task - (long long)n * rblocks) * 8;
+    float acc[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) acc[r] = 0.f;
+    if (n < N) {
+      const float* wr = W + (long long)n * K;
+      for (int k = lane * 4; k < K; k += 256) {
+        const f32x4 w = ld4(wr + k);
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int rr = r0 + r < rows ? r0 + r : rows - 1;   // clamped: unconditional loads
+          const f32x4 a = ld4(x + (long long)rr * xs + k);
+          acc[r] += w[0] * a[0] + w[1] * a[1] + w[2] * a[2] + w[3] * a[3];
+        }
+      }
+#pragma unroll
+      for (int r = 0; r < 8; ++r)
+#pragma unroll
+        for (int m = 32; m >= 1; m >>= 1) acc[r] += __shfl_xor(acc[r], m);
+    }
+    const float b = (bias && n < N) ? bias[n] : 0.f;
+#pragma unroll
+    for (int r = 0; r < 8; ++r)
+      if (lane == r && r0 + r < rows) y[(long long)(r0 + r) * ys + n] = acc[r] + b;   // pad lanes n >= N: zeros, as the MFMA kernel writes them
+  }
+}
+
 // dW partial: grid (KS, ceil(N/128)); wave w owns n rows 32w..32w+31 of the block's 128, all K/32 column fragments.
 template <int KF>
 __global__ __launch_bounds__(256) void linear_wgrad_kernel(const float* __restrict__ dy, int dys, int N, const float* __restrict__ x,
@@ -199,10 +236,20 @@ int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const flo
   SF_REQUIRE(N >= 1 && y.c >= 1, "linear: N=%d y.c=%d", N, y.c);
   if (rows == 0) return 0;
   const int lanes = y.c > N ? y.c : N;
+  hipStream_t st = (hipStream_t)stream;
+  if (rows <= 64) {   // GEMV-shaped: one wave per (output column, block of 8 rows)
+    const long long tasks = (long long)y.c * ((rows + 7) / 8);
+    const long long blocks = (tasks + 3) / 4;
+    hipLaunchKernelGGL(linear_fwd_fewrows_kernel, dim3((unsigned)(blocks < 16384 ? blocks : 16384)), dim3(256), 0, st, (const float*)x.ptr, x.stride, (int)rows,
+                       x.c, W, N, bias, (float*)y.ptr, y.stride, y.c);
+    SF_CHECK_LAUNCH("linear_fwd_fewrows");
+    return 0;
+  }
   int nf = (lanes + 31) / 32;
   if (nf > 4) nf = 4;
+  // a square-ish map (1024 rows x 1024 columns) is 64 tiles of 128 x 128: narrower column blocks until the 256 CUs have a workgroup each
+  while (nf > 1 && nf != 3 && ((rows + 127) / 128) * ((lanes + 32 * nf - 1) / (32 * nf)) < 256) nf >>= 1;
   dim3 grid((unsigned)((rows + 127) / 128), (lanes + 32 * nf - 1) / (32 * nf));
-  hipStream_t st = (hipStream_t)stream;
 #define SF_LIN(NFV)                                                                                                         \
   hipLaunchKernelGGL((linear_fwd_kernel<NFV>), grid, dim3(256), 0, st, (const float*)x.ptr, x.stride, (long long)rows, x.c, W, N, \
                      bias, (float*)y.ptr, y.stride, y.c)

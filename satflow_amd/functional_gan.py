@@ -495,13 +495,15 @@ _bmm_raw = K.bmm_raw
 
 
 class _BmmFn(torch.autograd.Function):
-    """``torch.bmm(A, B)`` for arbitrary strided 3-D views; the gradients are the same kernel on transposed views."""
+    """``torch.bmm(A, B)`` for arbitrary strided 3-D views; the gradients are the same kernel on transposed views.  ``lowp``: an attention
+    product - bf16 MFMA operands in the bf16 compute modes (forward and both gradients), as under the reference's autocast."""
 
     @staticmethod
-    def forward(ctx, A: Tensor, B: Tensor):
+    def forward(ctx, A: Tensor, B: Tensor, lowp: bool):
         out = torch.empty(A.shape[0], A.shape[1], B.shape[2], dtype=torch.float32, device=A.device)
-        _bmm_raw(A, B, out)
+        _bmm_raw(A, B, out, lowp=lowp)
         ctx.save_for_backward(A, B)
+        ctx.lowp = lowp
         return out
 
     @staticmethod
@@ -510,16 +512,17 @@ class _BmmFn(torch.autograd.Function):
         dA = dB = None
         if ctx.needs_input_grad[0]:
             dA = torch.empty(A.shape, dtype=torch.float32, device=A.device)
-            _bmm_raw(g, B.transpose(1, 2), dA)
+            _bmm_raw(g, B.transpose(1, 2), dA, lowp=ctx.lowp)
         if ctx.needs_input_grad[1]:
             dB = torch.empty(B.shape, dtype=torch.float32, device=B.device)
-            _bmm_raw(A.transpose(1, 2), g, dB)
-        return dA, dB
+            _bmm_raw(A.transpose(1, 2), g, dB, lowp=ctx.lowp)
+        return dA, dB, None
 
 
-def bmm(A: Tensor, B: Tensor) -> Tensor:
+def bmm(A: Tensor, B: Tensor, lowp: bool = False) -> Tensor:
+    """``lowp=False``: exact fp32 in every compute mode (selection matrices, dot products of embeddings)."""
     require_device(A, "A")
-    return _BmmFn.apply(A, B)
+    return _BmmFn.apply(A, B, lowp)
 
 
 class _SoftmaxFn(torch.autograd.Function):

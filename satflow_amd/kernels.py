@@ -368,15 +368,17 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[T
     return dW, db
 
 
-def bmm_raw(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: float = 0.0) -> None:
-    """``out[b] = alpha * A[b] @ B[b] + beta * out[b]`` for 3-D fp32 views with arbitrary strides.  sf_bmm_f32."""
+def bmm_raw(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: float = 0.0, lowp: bool = False) -> None:
+    """``out[b] = alpha * A[b] @ B[b] + beta * out[b]`` for 3-D fp32 views with arbitrary strides.  sf_bmm_f32 (exact fp32 MFMA), or - ``lowp`` in a
+    bf16 compute mode - sf_bmm_bf16 (operands rounded to bf16 as torch.bmm's are under autocast)."""
     assert A.dim() == B.dim() == out.dim() == 3 and A.dtype == B.dtype == out.dtype == torch.float32
     bsz, M, Kd = A.shape
     N = B.shape[2]
     assert B.shape[0] == bsz and B.shape[1] == Kd and out.shape == (bsz, M, N), (A.shape, B.shape, out.shape)
     sa, sb, sc = A.stride(), B.stride(), out.stride()
-    check(lib().sf_bmm_f32(A.data_ptr(), sa[0], sa[1], sa[2], B.data_ptr(), sb[0], sb[1], sb[2], out.data_ptr(), sc[0], sc[1], sc[2], bsz, M, N, Kd,
-                           alpha, beta, stream_ptr()), "sf_bmm_f32")
+    fn, name = (lib().sf_bmm_bf16, "sf_bmm_bf16") if (lowp and _hip.compute_dtype() == _hip.SF_BF16) else (lib().sf_bmm_f32, "sf_bmm_f32")
+    check(fn(A.data_ptr(), sa[0], sa[1], sa[2], B.data_ptr(), sb[0], sb[1], sb[2], out.data_ptr(), sc[0], sc[1], sc[2], bsz, M, N, Kd,
+             alpha, beta, stream_ptr()), name)
 
 
 def linear_bwd_weight_any(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[Tensor, Optional[Tensor]]:

@@ -91,8 +91,8 @@ class SeparableAttnCell(nn.Module):
         v = _untokens(FG.max_pool3(_project(tok, self.value_conv, out_lanes=cpad(C)), (2, 1, 1), (pf, 1, 1)), C)
         # the reference's flat views (Attention.py:86-98)
         query, key, value = q.view(B, A, -1), k.view(B, -1, A // pf), v.view(B, -1, A // pf)
-        score = FG.softmax_last(FG.bmm(query, key))                      # [B, A, A // pf]
-        o = FG.bmm(value, score.transpose(2, 1))                         # [B, C*r1*r2, A]
+        score = FG.softmax_last(FG.bmm(query, key, lowp=True))                      # [B, A, A // pf]
+        o = FG.bmm(value, score.transpose(2, 1), lowp=True)                         # [B, C*r1*r2, A]
         if self.attn_id == "T":
             o = o.view(B, C, W, H, Tn).permute(0, 1, 4, 2, 3)
         elif self.attn_id == "W":
@@ -138,8 +138,8 @@ class SelfAttention(nn.Module):
         nk = k.shape[1] * k.shape[2] * k.shape[3]
         if nk != N // self.pooling_factor:
             raise RuntimeError(f"shape '[{B}, -1, {N // self.pooling_factor}]' is invalid for the pooled keys ({nk} positions)")  # the reference's .view fails
-        score = FG.softmax_last(FG.bmm(q, k.view(B, nk, -1).transpose(1, 2)))   # [B, N, N / pf^3]
-        out = FG.bmm(score, v.view(B, nk, cp)).view(B, Tn, W, H, cp)
+        score = FG.softmax_last(FG.bmm(q, k.view(B, nk, -1).transpose(1, 2), lowp=True))   # [B, N, N / pf^3]
+        out = FG.bmm(score, v.view(B, nk, cp), lowp=True).view(B, Tn, W, H, cp)
         return _untokens(FG.gamma_residual(out, tok, self.gamma), C)
 
 
@@ -168,7 +168,7 @@ class SelfAttention2d(nn.Module):
         q = _project(tok, self.query).view(B, n, -1)
         k = _project(tok, self.key).view(B, n, -1)
         v = _project(tok, self.value, out_lanes=cp).view(B, n, cp)
-        attn = FG.softmax_last(FG.bmm(k, q.transpose(1, 2)))             # attn[i, j] = key_i . query_j, softmax over j
-        out = FG.bmm(attn.transpose(1, 2), v).view(B, H, W, cp)          # out[j] = sum_i attn[i, j] value_i
+        attn = FG.softmax_last(FG.bmm(k, q.transpose(1, 2), lowp=True))             # attn[i, j] = key_i . query_j, softmax over j
+        out = FG.bmm(attn.transpose(1, 2), v, lowp=True).view(B, H, W, cp)          # out[j] = sum_i attn[i, j] value_i
         res = F.nhwc_to_nchw(FG.gamma_residual(out, tok, self.gamma), C)
         return (res, attn) if self.return_attn else res

@@ -158,6 +158,9 @@ int main(void) {
   REFUSED(sf_dvdgru_out_bwd(a16, a16, a16, N0, 64, 16, a16, a16, N0, st));
   REFUSED(sf_bmm_f32(ok, 0, 8, 1, 0, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                   /* no B */
   REFUSED(sf_bmm_f32(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                  /* empty inner dimension */
+  REFUSED(sf_bmm_bf16(ok, 0, 8, 1, 0, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                  /* no B */
+  REFUSED(sf_bmm_bf16(ok, 0, 8, 1, ok, 0, 8, 1, 0, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                  /* no C */
+  REFUSED(sf_bmm_bf16(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                 /* empty inner dimension */
   REFUSED(sf_softmax_rows_fwd(ok, 4, 0, ok, st));                                                        /* empty rows */
   REFUSED(sf_softmax_rows_bwd(ok, 0, 4, 8, ok, st));                                                     /* no softmax output */
   REFUSED(sf_layernorm_chw_fwd(a64, 2, 64, 4, 12, 16, ok, ok, 1e-5f, 0, a64, st));                       /* no partial-sum buffer */

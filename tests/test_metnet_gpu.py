@@ -94,7 +94,8 @@ def test_batchnorm_train(device, groups, n, h, w, c):
         assert_close(ye, bn_ref(x), "bn eval")
 
 
-@pytest.mark.parametrize("rows,K,N", [(300, 16, 12), (1000, 64, 384), (77, 128, 64), (4096, 32, 96)])
+@pytest.mark.parametrize("rows,K,N", [(300, 16, 12), (1000, 64, 384), (77, 128, 64), (4096, 32, 96),
+                                      (2, 240, 4100), (1, 16, 5), (13, 272, 70), (64, 1024, 1024), (1024, 512, 1024)])  # few rows: the wave-per-column kernel
 def test_linear(device, rows, K, N):
     from satflow_amd import functional as F
 
