@@ -121,6 +121,44 @@ class ConvEngine:
         return self._packed[k]
 
 
+class WeightGradBatch:
+    """Weight gradient of ONE convolution weight applied several times (a recurrent cell's state convolution over the frames of a sequence),
+    computed once over all applications instead of once per application: every application's backward pass hands in its (input, output
+    gradient) pair and returns no weight gradient, the one that completes the set runs the weight-gradient kernel over the concatenation.
+    Per-frame launches on a few small images are bound by WRITING the gradient (75 MB for a 2048 -> 1024 kernel), and autograd then adds the
+    per-frame results pairwise.  If a backward pass ends with applications missing (an output that did not reach the loss) it raises
+    instead of dropping the gradient."""
+
+    def __init__(self) -> None:
+        self.uses = 0
+        self.xs: List[Tensor] = []
+        self.gys: List[Tensor] = []
+        self._armed = False
+
+    def register(self) -> None:
+        self.uses += 1
+
+    def add(self, x: Tensor, gy: Tensor) -> bool:
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        self.xs.append(x)
+        self.gys.append(gy)
+        return len(self.xs) == self.uses
+
+    def take(self) -> Tuple[Tensor, Tensor]:
+        x, g = torch.cat(self.xs, 0), torch.cat(self.gys, 0)
+        self.xs, self.gys = [], []
+        return x, g
+
+    def _end_of_backward(self) -> None:
+        left, self._armed = len(self.xs), False
+        self.xs, self.gys = [], []
+        if left:
+            raise RuntimeError(f"WeightGradBatch: the backward pass ended with {left} of {self.uses} applications reported - an application's "
+                               "output did not reach the loss; its weight gradient cannot be batched")
+
+
 class _ConvFn(torch.autograd.Function):
     """``y = act(conv3x3(cat(x0, x1)) + b)``: x_i ``[N_i,H,W,C_ip]`` -> ``[n,H,W,Coutp]``.
 
@@ -131,8 +169,13 @@ class _ConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: ConvEngine, x0: Tensor, x1: Optional[Tensor], weight: Tensor, bias: Optional[Tensor], n: int,
-                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool, out_dtype=None, stats: Optional[Tensor] = None):
+                remap0: Tuple[int, int], remap1: Tuple[int, int], sigmoid: bool, out_dtype=None, stats: Optional[Tensor] = None,
+                wbatch: Optional[WeightGradBatch] = None):
         H, W = x0.shape[1], x0.shape[2]
+        ctx.wbatch = wbatch
+        if wbatch is not None:
+            assert x1 is None and remap0 == (0, 0) and not sigmoid, "a batched weight gradient takes plain single-source applications"
+            wbatch.register()
         packed, bp = eng.packed(weight, bias, "fwd")
         y = torch.empty(n, H, W, eng.coutp, dtype=out_dtype or torch.float32, device=x0.device)
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
@@ -176,13 +219,18 @@ class _ConvFn(torch.autograd.Function):
             else:
                 d1 = dcat
         if not (ctx.needs_input_grad[3] or (has_bias and ctx.needs_input_grad[4])):
-            return None, d0, d1, None, None, None, None, None, None, None, None  # frozen parameters (a GAN's other network): no weight gradient
+            return None, d0, d1, None, None, None, None, None, None, None, None, None  # frozen parameters (a GAN's other network): no weight gradient
+        if ctx.wbatch is not None:
+            if not ctx.wbatch.add(x0, gy):
+                return None, d0, d1, None, None, None, None, None, None, None, None, None   # a later application's backward completes the set
+            x0, gy = ctx.wbatch.take()
+            n = x0.shape[0]
         dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=gy.device)
         db = torch.empty(weight.shape[0], dtype=torch.float32, device=gy.device) if has_bias else None
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
         K.conv3x3_bwd_weight(s0, s1, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
-        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None, None, None
+        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None, None, None, None
 
 
 class ConvStats:
@@ -195,12 +243,12 @@ class ConvStats:
 
 
 def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False, out_dtype=None,
-            want_stats: Optional[bool] = None):
+            want_stats: Optional[bool] = None, wbatch: Optional[WeightGradBatch] = None):
     """``out_dtype=torch.bfloat16`` stores the result as bf16 (SF_BF16 kernels only; "bf16a" encoder mode).
     ``want_stats`` not None: returns ``(y, stats)`` with ``stats`` a ``ConvStats`` for ``batchnorm(..., stats=)`` when it is
     true and the bf16 kernels run, else None."""
     if want_stats is None:
-        return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype)
+        return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype, None, wbatch)
     from ._hip import SF_BF16, compute_dtype
 
     st = None

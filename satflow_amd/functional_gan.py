@@ -236,13 +236,13 @@ def regroup5x5(weight: Tensor, lanes: int) -> Tensor:
     return g.reshape(O, 4 * lanes, 3, 3)
 
 
-def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.ConvEngine") -> Tensor:
+def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.ConvEngine", wbatch: Optional["F.WeightGradBatch"] = None) -> Tensor:
     """``nn.Conv2d(k=5, padding=2)`` on the 3x3 MFMA kernels (``sf_pad_shift_stack4_fwd``: the input on a domain padded by 2, shifted
     four ways, stacked as channels; the 5x5 kernel as four 3x3 tiles; the interior of the result).  ``weight``: the 5x5 weight, or what
     ``regroup5x5(weight, x lanes)`` made of it.  ``eng``: a ConvEngine for ``[4 * x lanes] -> cout``."""
     w3 = regroup5x5(weight, x.shape[-1]) if weight.shape[-1] == 5 else weight
     assert w3.shape[1] == 4 * x.shape[-1] and w3.shape[-1] == 3, (w3.shape, x.shape)
-    return _CropFn.apply(F.conv3x3(eng, _PadShift4Fn.apply(x.contiguous()), w3, bias), 2)
+    return _CropFn.apply(F.conv3x3(eng, _PadShift4Fn.apply(x.contiguous()), w3, bias, wbatch=wbatch), 2)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -67,7 +67,7 @@ class ConvGRUCell(nn.Module):
                 W[k] = W[k].contiguous()
         return W
 
-    def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor]) -> Tensor:
+    def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor], wbatch=None) -> Tensor:
         k = self.kernel_size
         if k == 3 or self._as_tiles():
             cin = w.shape[1]   # 5x5: already regrouped over four shifted copies of the (padded) input lanes
@@ -77,7 +77,7 @@ class ConvGRUCell(nn.Module):
             # the regrouped weights are fresh tensors every call but functions of the cell's parameters only: the packed images are
             # cached on THOSE (identity + version + optimizer generation) - one pack per step, not one per frame
             self._eng[key].key_tensors = tuple(self.parameters())
-            return F.conv3x3(self._eng[key], x, w, b) if k == 3 else FG.conv5x5_as_3x3(x, w, b, self._eng[key])
+            return F.conv3x3(self._eng[key], x, w, b, wbatch=wbatch) if k == 3 else FG.conv5x5_as_3x3(x, w, b, self._eng[key], wbatch)
         return FG.conv_nhwc(x, w, b)   # any other size (and SF_CONV5_DIRECT=1, the A/B switch): the direct fp32 convolution
 
     def x_parts(self, x: Tensor, W: dict):
@@ -89,9 +89,9 @@ class ConvGRUCell(nn.Module):
         if h is None:  # zero state: the h-parts vanish
             zr, _ = FG.dvdgru_gates(gx_zr, None, None, hp)
             return FG.dvdgru_out(gx_o, None, zr, None, hp)
-        gh_zr = self._conv("zr_h", h, W["zr_h"], None)
+        gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"))
         zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp)
-        gh_o = self._conv("o_h", rh, W["o_h"], None)
+        gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"))
         return FG.dvdgru_out(gx_o, gh_o, zr, h, hp)
 
     def run(self, x: Tensor, h: Optional[Tensor]) -> Tensor:
@@ -136,6 +136,9 @@ class ConvGRU(nn.Module):
         seq, const = x, constant_input
         for cell in self.cells:
             W = cell.weights(seq.shape[-1])
+            if cell.kernel_size in (3, 5) and not os.environ.get("SF_GRU_WGRAD_PER_FRAME"):
+                # the state convolutions' weight gradients: once per sequence over all frames, not once per frame (functional.WeightGradBatch)
+                W["batch_zr_h"], W["batch_o_h"] = F.WeightGradBatch(), F.WeightGradBatch()
             gx_zr, gx_o = cell.x_parts(seq, W)
             n = gx_zr.shape[0] if const else gx_zr.shape[0] // T_frames
             # per-frame views through unbind (its backward is ONE stack, not a zero-filled full-size tensor per slice)

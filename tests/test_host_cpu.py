@@ -244,3 +244,51 @@ def test_sanitizer_harness_covers_every_entry_point():
     if os.environ.get("SF_RUN_SANITIZER"):
         r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), "/tmp/sf_host_sanitize.log"], capture_output=True, text=True, timeout=1200)
         assert "0 not refused" in r.stdout and "exit code 0" in r.stdout, r.stdout[-2000:] + r.stderr[-2000:]
+
+
+def test_weight_grad_batch_protocol():
+    """functional.WeightGradBatch (the once-per-sequence weight gradient of a recurrent cell's state convolution): the application whose
+    backward completes the set emits the gradient of ALL applications, a second backward through a retained graph works again, and a
+    backward pass that ends with applications missing raises instead of dropping the gradient.  Host logic only - a stand-in autograd
+    function with the protocol of ``_ConvFn`` (register in forward; add / take in backward)."""
+    from satflow_amd.functional import WeightGradBatch
+
+    class Scale(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x, w, batch):
+            ctx.batch = batch
+            batch.register()
+            ctx.save_for_backward(x, w)
+            return x * w
+
+        @staticmethod
+        def backward(ctx, g):
+            x, w = ctx.saved_tensors
+            if not ctx.batch.add(x, g):
+                return g * w, None, None
+            xs, gs = ctx.batch.take()
+            return g * w, (xs * gs).sum().reshape(1), None
+
+    w = torch.tensor([1.5], requires_grad=True)
+    h0 = torch.arange(3.0)
+    batch, x, outs = WeightGradBatch(), h0, []
+    for _ in range(4):
+        x = Scale.apply(x, w, batch)
+        outs.append(x)
+    loss = sum(o.sum() for o in outs)
+    loss.backward(retain_graph=True)
+    wr, xr, lr = torch.tensor([1.5], requires_grad=True), h0, 0
+    for _ in range(4):
+        xr = xr * wr
+        lr = lr + xr.sum()
+    lr.backward()
+    assert torch.allclose(w.grad, wr.grad)
+    w.grad = None
+    loss.backward()
+    assert torch.allclose(w.grad, wr.grad)
+    batch, x, outs = WeightGradBatch(), h0, []
+    for _ in range(3):
+        x = Scale.apply(x, w, batch)
+        outs.append(x)
+    with pytest.raises(RuntimeError, match="WeightGradBatch"):
+        outs[1].sum().backward()
