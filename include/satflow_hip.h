@@ -98,6 +98,15 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
 int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w,
                    const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
                    int32_t epilogue, sfTensor out, int32_t dtype, sfStream stream);
+/* The same convolution (SF_BF16 kernels, linear epilogue, one source, nf = 4) for FEW SMALL IMAGES WITH MANY INPUT CHANNELS - the state convolutions
+ * of the DGMR generator's ConvGRU (reference layers/Generator.py:91-117 calling the ConvGRU cell frame by frame: 2 images of 16x16 .. 64x64 pixels,
+ * up to 2048 -> 1024 channels), the deepest discriminator blocks (layers/Discriminator.py:169-226 at 8x8 / 4x4).  sf_conv3x3_fwd would run them on a few
+ * dozen workgroups, each streaming megabytes of weights through its LDS; here the input channels are cut into slices (grid z), every slice writes its
+ * fp32 partial sums to `workspace`, a second kernel adds the slices in a fixed order (deterministic) and the bias.
+ * sf_conv3x3_fwd_splitk_workspace_bytes returns 0 for shapes that are not worth splitting (Kp = source channel lanes): call sf_conv3x3_fwd then. */
+size_t sf_conv3x3_fwd_splitk_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t Kp, int32_t dtype);
+int sf_conv3x3_fwd_splitk(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
+                          sfTensor out, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream);
 /* The same convolution (SF_BF16 kernels, linear epilogue) that also emits what the BatchNorm2d behind it in the DownSampler
  * needs: per pixel tile, the sum and the sum of squares of every output channel's STORED values,
  * stats[(image * sf_conv3x3_stats_tiles(h, w) + tile)][Np][2] fp32 - consumed by sf_batchnorm_train_fwd_stats, which then

@@ -32,6 +32,8 @@ PROTOTYPES = {
     "sf_conv3x3_packed_elems": (_sz, [_i32, _i32]),
     "sf_conv3x3_pack_weights": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "sf_conv3x3_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _i32, _vp]),
+    "sf_conv3x3_fwd_splitk_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "sf_conv3x3_fwd_splitk": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, sfTensor, _vp, _sz, _i32, _vp]),
     "sf_conv3x3_stats_tiles": (_i32, [_i32, _i32]),
     "sf_conv3x3_fwd_stats": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, sfTensor, _vp, _i32, _vp]),
     "sf_conv3x3_fold_pack": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),

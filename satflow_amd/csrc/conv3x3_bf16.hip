@@ -50,9 +50,22 @@ __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t r
 // workgroup then waits for its next chunk's weights after every chunk (the DMA is issued behind an end-of-chunk barrier), but the
 // partner workgroup's MFMAs, prologue and epilogue run in those gaps: for the fused LSTM cell, whose epilogue moves 5 state / gate
 // tensors per tile, that overlap is worth more than the double buffer (ConvLSTM cell).
-template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false, bool WS = false>
-__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p) {
+// SPLITK: grid z = slice of the input channels (ConvParams::split_c): the same kernel on a shifted source / weight / output pointer.
+template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false, bool WS = false, bool SPLITK = false>
+__global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p_in) {
   static_assert(!WS || (WAVES == 4 && !DUAL), "the single-weight-buffer variant is a 4-wave layout");
+  static_assert(!SPLITK || (EPI == EPI_LINEAR && !DUAL && TR && !BNB && !WS), "split-K: plain linear launches only");
+  ConvParams p_split;
+  if constexpr (SPLITK) {
+    const int z = blockIdx.z;
+    p_split = p_in;
+    const int cbeg = z * p_in.split_c;
+    p_split.src0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p_in.src0) + (size_t)cbeg * (p_in.bf0 ? 2 : 4));
+    p_split.c0 = p_in.c0 - cbeg < p_in.split_c ? p_in.c0 - cbeg : p_in.split_c;
+    p_split.wp = reinterpret_cast<const char*>(p_in.wp) + (size_t)(cbeg / KC) * (9 * 32 * NF * PIX_B);
+    p_split.out = p_in.out + (size_t)z * p_in.split_out;
+  }
+  const ConvParams& p = SPLITK ? p_split : p_in;
   constexpr int WBUFS = WS ? 1 : 2;
   static_assert(!DUAL || WAVES == 8, "dual-image tiles are an 8-wave layout");
   constexpr int NB = 32 * NF;
@@ -426,6 +439,16 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
     // pixel-per-lane form (22.8 vs 24.9 us per step)
     hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 3, EPI, DUAL, false>), grid, block, 0, st, p);
   } else {
+    if constexpr (EPI == EPI_LINEAR && !DUAL) {
+      if (p.split_c > 0) {   // split-K (sf_conv3x3_fwd_splitk planned it): grid z = channel slices
+        if (nf != 4 || p.stats || p.bnb_coef || p.bias_tab || p.src1) { sf_set_error("bf16 conv: split-K takes plain nf=4 single-source launches"); return 1; }
+        grid.z = (p.c0 + p.split_c - 1) / p.split_c;
+        hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, false, true, false, false, true>), grid, block, 0, st, p);
+        hipError_t es = hipGetLastError();
+        if (es != hipSuccess) { sf_set_error("conv3x3_bf16 (split-K): launch failed: %s", hipGetErrorString(es)); return 2; }
+        return 0;
+      }
+    }
     // without BatchNorm statistics the product is computed transposed (pixel-per-lane epilogue with 16-byte stores)
     const bool tr = p.stats == nullptr;
 #define SF_CONV_CASE(NFV)                                                                                              \
@@ -475,7 +498,7 @@ int sf_conv_bf16_tiles(int h, int w) {
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st) {
   // large single-source bf16-stored launches: one persistent workgroup per CU (SF_NO_PERSIST_CONV=1: A/B switch)
   static const bool no_persist = getenv("SF_NO_PERSIST_CONV") != nullptr;
-  if (!no_persist && sf_conv_bf16_persist_ok(p, epi, nf)) return sf_launch_conv_bf16_persist(p, nf, nblk, st);
+  if (!no_persist && !p.split_c && sf_conv_bf16_persist_ok(p, epi, nf)) return sf_launch_conv_bf16_persist(p, nf, nblk, st);
   switch (epi) {
     case EPI_LINEAR: return launch_e<EPI_LINEAR>(p, nf, nblk, st);
     case EPI_SIGMOID: return launch_e<EPI_SIGMOID>(p, nf, nblk, st);

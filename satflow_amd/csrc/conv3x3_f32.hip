@@ -237,6 +237,46 @@ int launch_conv(const ConvParams& p, int nf, int nblk, hipStream_t st) {
   return 0;
 }
 
+// split-K (sf_conv3x3_fwd_splitk): out[pix][c] = bias[c] + sum_z part[z][pix][c], channel quads, fp32 or bf16 output
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, long long slab, int splits, int np, long long pixels,
+                                                            const float* __restrict__ bias, void* __restrict__ out, int out_c, int out_s, int out_bf) {
+  const int q = out_c >> 2;
+  const long long total = pixels * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const long long pix = idx / q;
+    const int c = (int)(idx - pix * q) * 4;
+    f32x4 a = bias ? *reinterpret_cast<const f32x4*>(bias + c) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* src = part + pix * np + c;
+    for (int z = 0; z < splits; ++z) a += *reinterpret_cast<const f32x4*>(src + z * slab);
+    if (out_bf) {
+      bf16x4 b = {(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3]};
+      *reinterpret_cast<bf16x4*>(reinterpret_cast<__bf16*>(out) + pix * out_s + c) = b;
+    } else {
+      *reinterpret_cast<f32x4*>(reinterpret_cast<float*>(out) + pix * out_s + c) = a;
+    }
+  }
+}
+
+// How many channel slices a plain bf16 launch should be cut into (1 = do not split).  Few small images with many input channels - a recurrent
+// cell's state convolution on 2 x 20 x 20 pixels with 2048 -> 1024 channels is 32 workgroups each streaming 4.7 MB of weights through its LDS.
+int splitk_plan(int n, int h, int w, int Np, int nf, int Kp, int* split_c) {
+  static const bool off = getenv("SF_NO_SPLITK") != nullptr;
+  *split_c = 0;
+  if (off || nf != 4 || Kp % KC != 0 || h < 1 || w < 1 || n < 1) return 1;
+  const int th = h > 16 ? 32 : 16;
+  if (h <= 16 && w <= 16 && n >= 512) return 1;   // the two-images-per-workgroup kernel takes these
+  const long long wgs = (long long)((w + 15) / 16) * ((h + th - 1) / th) * n * (Np / 128);
+  const int chunks = Kp / KC;
+  if (wgs > 128 || chunks < 8) return 1;
+  int s = (int)(256 / wgs);
+  if (s > 8) s = 8;
+  if (s > chunks / 4) s = chunks / 4;
+  if (s < 2) return 1;
+  const int per = (chunks + s - 1) / s;
+  *split_c = per * KC;
+  return (chunks + per - 1) / per;
+}
+
 }  // namespace
 
 extern "C" {
@@ -302,6 +342,44 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
                    const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, int32_t dtype,
                    sfStream stream) {
   return conv3x3_fwd_impl(src0, src1, n, h, w, wpacked, bias_packed, Np, nf, epilogue, out, nullptr, dtype, stream);
+}
+
+size_t sf_conv3x3_fwd_splitk_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t Kp, int32_t dtype) {
+  int split_c;
+  if (dtype != SF_BF16) return 0;
+  const int s = splitk_plan(n, h, w, Np, nf, Kp, &split_c);
+  return s > 1 ? (size_t)s * n * h * w * Np * sizeof(float) : 0;
+}
+
+int sf_conv3x3_fwd_splitk(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
+                          sfTensor out, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_fwd_splitk: the SF_BF16 kernels only (dtype %d)", dtype);
+  if (check_src(src, "conv3x3 split-K src")) return 1;
+  SF_REQUIRE(src.ptr && src.idiv <= 1 && src.imod <= 0, "sf_conv3x3_fwd_splitk: one plain source (no image remap)");
+  SF_REQUIRE(nf == 4 && Np % 128 == 0 && out.c <= Np && out.ptr && ((uintptr_t)out.ptr & 15) == 0 && out.c % 8 == 0 && out.stride % 8 == 0,
+             "sf_conv3x3_fwd_splitk: nf=4 launches with 16-byte aligned outputs (Np=%d nf=%d out.c=%d)", Np, nf, out.c);
+  int split_c;
+  const int splits = splitk_plan(n, h, w, Np, nf, src.c, &split_c);
+  SF_REQUIRE(splits > 1, "sf_conv3x3_fwd_splitk: this shape is not split (sf_conv3x3_fwd_splitk_workspace_bytes returned 0)");
+  const size_t slab = (size_t)n * h * w * Np;
+  SF_REQUIRE(workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= slab * splits * sizeof(float), "sf_conv3x3_fwd_splitk: workspace too small");
+  SF_REQUIRE(!bias_packed || ((uintptr_t)bias_packed & 15) == 0, "conv3x3: bias_packed must be 16-byte aligned");
+  ConvParams p{};
+  p.src0 = (const float*)src.ptr; p.c0 = src.c; p.s0 = src.stride;
+  p.idiv0 = 1; p.idiv1 = 1;
+  p.N = n; p.H = h; p.W = w; p.tiles_x = (w + TILE - 1) / TILE; p.tiles_y = (h + TILE - 1) / TILE;
+  p.wp = wpacked; p.bias = nullptr; p.chunks_total = src.c / KC;
+  p.out = (float*)workspace; p.out_c = Np; p.out_s = Np; p.out_bf = 0;
+  p.bf0 = src.dtype == SF_BF16;
+  p.stats_np = Np;
+  p.split_c = split_c; p.split_out = (long long)slab;
+  if (int rc = sf_launch_conv_bf16(p, nf, Np / 128, EPI_LINEAR, (hipStream_t)stream)) return rc;
+  const long long pixels = (long long)n * h * w;
+  const long long quads = pixels * (out.c / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,
+                     (const float*)workspace, (long long)slab, splits, Np, pixels, bias_packed, out.ptr, out.c, out.stride, (int)(out.dtype == SF_BF16));
+  SF_CHECK_LAUNCH("conv3x3 split-K reduce");
+  return 0;
 }
 
 int32_t sf_conv3x3_stats_tiles(int32_t h, int32_t w) { return sf_conv_bf16_tiles(h, w); }

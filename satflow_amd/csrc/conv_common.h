@@ -44,6 +44,9 @@ struct ConvParams {
   //   out = A * acc + B * x + K,  coefficients bnb_coef[group][3][bnb_c] (group = image / bnb_group), x = the BatchNorm's input
   // (bf16, the output's pixels and channel lanes, pixel stride bnb_xs) - sf_conv3x3_bwd_data_bn
   const float* bnb_coef; const void* bnb_x; int bnb_xs, bnb_group, bnb_c;
+  // bf16 kernel, split-K launches (sf_conv3x3_fwd_splitk; few small images with many input channels): workgroup z handles input channels
+  // [z * split_c, (z + 1) * split_c) of src0 and stores its raw fp32 partial sums to out + z * split_out (no bias); 0 = not split
+  int split_c; long long split_out;
 };
 
 // border class of an output pixel (needs H, W >= 2); pixels outside the image (ragged tiles) get some valid class

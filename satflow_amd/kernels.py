@@ -153,6 +153,14 @@ def conv3x3(src0: sfTensor, src1: sfTensor, n: int, h: int, w: int, packed: Tens
             "sf_conv3x3_fwd_stats",
         )
         return
+    if epilogue == SF_EPI_LINEAR and src1.ptr is None and not src0.idiv:
+        # few small images with many input channels (a recurrent cell's state convolution): input channels sliced over workgroups
+        nbytes = lib().sf_conv3x3_fwd_splitk_workspace_bytes(n, h, w, gm.Np, gm.nf, src0.c, _hip.compute_dtype())
+        if nbytes:
+            ws = torch.empty(nbytes // 4, dtype=torch.float32, device=packed.device)
+            check(lib().sf_conv3x3_fwd_splitk(src0, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None, gm.Np, gm.nf,
+                                              out, ws.data_ptr(), nbytes, _hip.compute_dtype(), stream_ptr()), "sf_conv3x3_fwd_splitk")
+            return
     check(
         lib().sf_conv3x3_fwd(src0, src1, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
                              gm.Np, gm.nf, epilogue, out, _hip.compute_dtype(), stream_ptr()),

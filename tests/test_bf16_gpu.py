@@ -25,9 +25,17 @@ def _r(t):
     return t.bfloat16().float()
 
 
-@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 40, 33), (256, 256, 2, 32, 32), (48, 96, 1, 64, 20)])
+SPLITK_SHAPES = [(256, 256, 2, 20, 20), (512, 128, 1, 16, 16), (272, 256, 2, 36, 24), (1024, 512, 2, 8, 8)]   # few small images, many channels: sf_conv3x3_fwd_splitk
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 40, 33), (256, 256, 2, 32, 32), (48, 96, 1, 64, 20)] + SPLITK_SHAPES)
 def test_conv3x3_bf16(device, bf16_mode, cin, cout, n, h, w):
     from satflow_amd.functional import ConvEngine, conv3x3, nchw_to_nhwc, nhwc_to_nchw
+
+    if (cin, cout, n, h, w) in SPLITK_SHAPES:   # make sure these cases DO run the channel-sliced kernel (forward and input gradient)
+        from satflow_amd._hip import SF_BF16, cpad, lib
+        eng = ConvEngine([cin], cout)
+        assert lib().sf_conv3x3_fwd_splitk_workspace_bytes(n, h, w, eng.fwd_map.Np, eng.fwd_map.nf, cpad(cin), SF_BF16) > 0
 
     g = torch.Generator().manual_seed(cin + cout)
     x = torch.randn(n, cin, h, w, generator=g)

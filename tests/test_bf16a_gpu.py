@@ -53,7 +53,8 @@ def _nchw(t, c):
     return nhwc_to_nchw(t.detach().float().contiguous(), c).cpu()
 
 
-@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 40, 33), (256, 256, 2, 32, 32), (160, 256, 3, 24, 40)])
+@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 40, 33), (256, 256, 2, 32, 32), (160, 256, 3, 24, 40),
+                                            (256, 256, 2, 20, 20), (512, 128, 1, 16, 16)])   # the last two: channel-sliced launches (sf_conv3x3_fwd_splitk), bf16 in and out
 def test_conv3x3_bf16_storage(device, bf16a_mode, cin, cout, n, h, w):
     from satflow_amd.functional import ConvEngine, conv3x3
 
