@@ -42,8 +42,8 @@ int main(void) {
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 4, a16, ok, 1 << 20, SF_F32, st));         /* split-K: SF_BF16 kernels only */
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 2, a16, ok, 1 << 20, SF_BF16, st));        /* split-K: nf = 4 only */
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 4, a16, ok, 1 << 20, SF_BF16, st));        /* a 16-channel source is not split */
-  REFUSED(sf_conv3x3_fwd_splitk(T(buf, 256, 256, SF_F32), 1, 8, 8, ok, 0, 128, 4, a16, 0, 0, SF_BF16, st)); /* no workspace */
-  REFUSED(sf_conv3x3_fwd_splitk(T(buf, 256, 256, SF_F32), 1, 8, 8, ok, 0, 128, 4, a16, ok, 16, SF_BF16, st)); /* workspace too small */
+  REFUSED(sf_conv3x3_fwd_splitk(T(ok, 256, 256, SF_F32), 1, 8, 8, ok, 0, 128, 4, a16, 0, 0, SF_BF16, st)); /* no workspace */
+  REFUSED(sf_conv3x3_fwd_splitk(T(ok, 256, 256, SF_F32), 1, 8, 8, ok, 0, 128, 4, a16, ok, 16, SF_BF16, st)); /* workspace too small */
   /* folded BatchNorm */
   REFUSED(sf_conv3x3_fold_pack(ok, 16, 16, ok, 32, ok, 16, 1, 0, ok, ok, 2, ok, ok, SF_F32, st));        /* SF_BF16 kernels only */
   REFUSED(sf_conv3x3_fold_pack(ok, 16, 16, ok, 32, ok, 16, 1, 0, ok, 0, 2, ok, ok, SF_BF16, st));        /* no shift */
