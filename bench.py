@@ -522,12 +522,12 @@ class DGMRWorkload:
 
     name = "dgmr"
 
-    def __init__(self, dev, batch: int, rank: int, ch: int = None, chn: int = None, frames: int = None):
+    def __init__(self, dev, batch: int, rank: int, ch: int = None, chn: int = None, frames: int = None, size: int = 256):
         from satflow_amd.models.layers.Discriminator import SpatialDiscriminator, TemporalDiscriminator
         from satflow_amd.models.layers.Generator import Generator
         from satflow_amd.optim import FlatAdam
 
-        self.B, self.C, self.H = batch, 12, 256
+        self.B, self.C, self.H = batch, 12, size   # size: frame edge (256 = BASELINE configs[4]; tests use a small one)
         self.T = frames or int(os.environ.get("SF_DGMR_FRAMES", "8"))
         self.ch = ch or int(os.environ.get("SF_DGMR_CH", "32"))
         self.chn = chn or int(os.environ.get("SF_DGMR_CHN", "64"))

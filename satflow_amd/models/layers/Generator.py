@@ -55,8 +55,8 @@ class Generator(nn.Module):
         y = F.nchw_to_nhwc(y.reshape(B, c0, ld, ld))                           # the reference's .view(-1, 8*ch, ld, ld)
         # image (t, b) of the time-major batch is image j = b*T + t of the reference's batch and takes condition row j % B
         t_idx, b_idx = torch.arange(Tn, device=x.device).view(Tn, 1), torch.arange(B, device=x.device).view(1, B)
-        rows = torch.zeros(Tn * B, B, device=x.device)
-        rows[torch.arange(Tn * B, device=x.device), ((b_idx * Tn + t_idx) % B).reshape(-1)] = 1.0   # selection matrix (a constant)
+        # selection matrix (a constant), built by comparison: an indexed assignment cannot be captured into a hipGraph
+        rows = (((b_idx * Tn + t_idx) % B).reshape(-1, 1) == torch.arange(B, device=x.device).view(1, B)).float()
         for k_, layer in enumerate(self.conv):
             if isinstance(layer, ConvGRU):
                 y = layer.run_sequence(y, Tn, constant_input=(k_ == 0))
