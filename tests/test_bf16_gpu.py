@@ -196,7 +196,14 @@ def test_conv_epilogue_statistics_feed_batchnorm(device, storage, cin, cout, n, 
         y1, st = conv3x3(eng, x, wt, b, out_dtype=storage, want_stats=True)
         assert st is not None and st.data.shape == (n * st.tiles, eng.fwd_map.Np, 2)
         y2 = conv3x3(eng, x, wt, b, out_dtype=storage)
-        assert torch.equal(y1, y2)
+        from satflow_amd._hip import SF_BF16, cpad, lib
+        if lib().sf_conv3x3_fwd_splitk_workspace_bytes(n, h, w, eng.fwd_map.Np, eng.fwd_map.nf, cpad(cin), SF_BF16):
+            # few images: the plain launch sums its input channels in slices (sf_conv3x3_fwd_splitk) - same products, another fp32 order
+            d = (y1.float() - y2.float()).abs()
+            assert float((d > 2.0**-7 * y2.float().abs() + 1e-5).float().mean()) == 0.0
+            y2 = y1
+        else:
+            assert torch.equal(y1, y2)
         o1, o2 = batchnorm(y1, bn1, groups, True, st), batchnorm(y2, bn2, groups, True)
         # statistics: fp32 per-tile sums of the same stored values, then fp64 - vs fp32 per-row sums, then fp64
         assert_close(bn1.running_mean, bn2.running_mean, "running_mean from epilogue statistics", rtol=1e-5, atol=1e-6)
