@@ -318,6 +318,56 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
     };
+    if constexpr (NF == 5) {
+      // NF = 5 (160 accumulators): the weight fragments are SINGLE-buffered - fragment nf of the next tap is read into the same registers right
+      // behind the two MFMAs that consumed it (operands are read at issue), eight MFMAs ahead of its next use; only the two pixel fragments
+      // are double-buffered.  20 registers less than two full operand sets: the kernel spilled 36 registers INSIDE the tap loop (1.6 GB of
+      // scratch reloads per launch of the 256 -> 160 input gradient: 3.74 GB read against 2.1 GB of operands); the 16 that are still spilled
+      // are DMA offsets reloaded once per chunk in the staging blocks.  256 -> 160 @32x32 x 2304: 1.56 -> 1.44 ms.  (Single-buffering the pixel
+      // fragments too: same spills, 2 % slower.  Dropping the never-taken fp32 staging path from the BatchNorm-backward variant: the
+      // compiler then spills 128 accumulator registers around the epilogue instead, 1.93 ms.)
+      bf16x8 fa[2][2], fb1[NF];
+      auto load_a = [&](int tap, bf16x8 (&a)[2]) {
+        const int ky = tap / 3, kx = tap % 3;
+#pragma unroll
+        for (int mf = 0; mf < 2; ++mf)
+          a[mf] = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO_W + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
+      };
+      auto load_b = [&](int tap, int nf) { return *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B); };
+      load_a(0, fa[0]);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) fb1[nf] = load_b(0, nf);
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap + 1 < 9) load_a(tap + 1, fa[(tap + 1) & 1]);
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+            acc[mf][nf] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[nf], fa[tap & 1][mf], acc[mf][nf], 0, 0, 0)
+                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb1[nf], acc[mf][nf], 0, 0, 0);
+          if (tap + 1 < 9) fb1[nf] = load_b(tap + 1, nf);
+        }
+        if (tap + 1 < 9) {   // 2 MFMAs, then reads and MFMAs alternate: every read sits behind the MFMAs that free its registers
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+#pragma unroll
+          for (int k = 0; k < 4; ++k) {
+            __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap == 0 || tap == 5) {
+          if (stage_late == (tap == 5)) stage_next();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+    } else {
     bf16x8 fa[2][2], fb[2][NF];
     load_tap(0, fa[0], fb[0]);
 #pragma unroll
@@ -346,6 +396,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
         if (stage_late == (tap == 5)) stage_next();
         __builtin_amdgcn_sched_barrier(0);
       }
+    }
     }
     if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
     if constexpr (WS) {
