@@ -511,6 +511,12 @@ int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTenso
 int sf_pad_shift_stack4_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream);
 int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream);
 int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32_t pad, sfTensor y, sfStream stream);
+/* A 4x4 stride-2 Conv2d with padding 1 - the down-sampling layers of the PatchGAN discriminator (satflow/models/gan/discriminators.py:166-186,
+ * called by CloudGAN, satflow/models/cloudgan.py) - as ONE 3x3 convolution: x padded by 1 with its 2x2 pixel blocks folded into channels,
+ * y[n][Y][X][(2 dy + dx) C + c] = x[n][2Y + dy - 1][2X + dx - 1][c] for Y < h/2 + 1, X < w/2 + 1 (h, w even); the 4x4 kernel becomes the taps
+ * (1..2, 1..2) of a 3x3 kernel over 4C channels and the result is the first h/2 x w/2 outputs.  _bwd is the adjoint (a gather). */
+int sf_pad_s2d_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream);
+int sf_pad_s2d_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream);
 /* nn.MaxPool3d of the in-tree attention layers (satflow/models/layers/Attention.py:50: kernel (2,1,1) stride (pf,1,1); :127: kernel 2
  * stride pf) over dense NHWC tokens x [batch][d0][d1][d2][C] -> y [batch][o0][o1][o2][C], o = (d - k) / s + 1; stride >= window.
  * Backward: the gradient goes to the first maximum of each window in scan order (torch's tie rule), recomputed from x. */

@@ -228,6 +228,37 @@ __global__ __launch_bounds__(256) void pad_shift4_bwd_kernel(const float* __rest
     st4(gx + idx * 4, a);
   }
 }
+// 4x4 stride-2 convolution with padding 1 (the PatchGAN discriminator's down-sampling layers, gan/discriminators.py:166-197) on the 3x3 kernels:
+// pad by 1 and fold 2x2 pixel blocks into channels,
+//   ys[n][Y][X][(2 dy + dx) * C + c] = x[n][2 Y + dy - 1][2 X + dx - 1][c]  (zero outside the image),  Y in [0, h/2 + 1), X in [0, w/2 + 1)
+// then out[Y][X] = sum_{a,b in {0,1}} W'[a][b] . ys[Y + a][X + b] with W'[a][b][(dy, dx, c)] = W[c][2a + dy][2b + dx]: a 2x2 convolution, i.e. the
+// 3x3 "same" convolution whose taps (1 + a, 1 + b) hold W' and whose other five taps are zero; the first h/2 x w/2 outputs are the result.
+__global__ __launch_bounds__(256) void pad_s2d_fwd_kernel(const float* __restrict__ x, long long n, int h, int w, int q, float* __restrict__ y) {
+  const int H2 = h / 2 + 1, W2 = w / 2 + 1, C = q * 4;
+  const long long total = n * H2 * W2 * 4 * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int s = (int)(r % 4); r /= 4;
+    const int X = (int)(r % W2); r /= W2;
+    const int Y = (int)(r % H2); const long long img = r / H2;
+    const int sy = 2 * Y + (s >> 1) - 1, sx = 2 * X + (s & 1) - 1;
+    const f32x4 v = (sy >= 0 && sy < h && sx >= 0 && sx < w) ? ld4(x + ((img * h + sy) * (long long)w + sx) * C + c) : kZero4;
+    st4(y + ((img * H2 + Y) * (long long)W2 + X) * 4 * C + s * C + c, v);
+  }
+}
+__global__ __launch_bounds__(256) void pad_s2d_bwd_kernel(const float* __restrict__ gy, long long n, int h, int w, int q, float* __restrict__ gx) {
+  const int H2 = h / 2 + 1, W2 = w / 2 + 1, C = q * 4;
+  const long long total = n * h * w * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int sx = (int)(r % w); r /= w;
+    const int sy = (int)(r % h); const long long img = r / h;
+    const int Y = (sy + 1) >> 1, X = (sx + 1) >> 1, s = ((sy + 1) & 1) * 2 + ((sx + 1) & 1);   // every pixel sits in exactly one block
+    st4(gx + idx * 4, ld4(gy + ((img * H2 + Y) * (long long)W2 + X) * 4 * C + s * C + c));
+  }
+}
 // y[n][yy][xx] = x[n][yy + b][xx + b] (crop) or, with pad != 0, y = x inside and 0 on a border of width b (the adjoint)
 __global__ __launch_bounds__(256) void border_kernel(const float* __restrict__ x, long long n, int h, int w, int b, int q, int pad, float* __restrict__ y) {
   const int C = q * 4;
@@ -670,6 +701,26 @@ int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTens
   hipLaunchKernelGGL(pad_shift4_bwd_kernel, dim3(grid_of(n * h * w * (gx.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gy.ptr, (long long)n, h, w,
                      gx.c / 4, (float*)gx.ptr);
   SF_CHECK_LAUNCH("pad_shift_stack4_bwd");
+  return 0;
+}
+
+int sf_pad_s2d_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream) {
+  SF_REQUIRE(x.ptr && okd(x, x.c) && okd(y, 4 * x.c) && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0,
+             "sf_pad_s2d_fwd: dense fp32 x [n][h][w][C] with even h, w; y [n][h/2+1][w/2+1][4C]");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pad_s2d_fwd_kernel, dim3(grid_of(n * (h / 2 + 1) * (w / 2 + 1) * x.c)), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)n, h, w,
+                     x.c / 4, (float*)y.ptr);
+  SF_CHECK_LAUNCH("pad_s2d_fwd");
+  return 0;
+}
+
+int sf_pad_s2d_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream) {
+  SF_REQUIRE(gx.ptr && okd(gx, gx.c) && okd(gy, 4 * gx.c) && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0,
+             "sf_pad_s2d_bwd: dense fp32 gy [n][h/2+1][w/2+1][4C], gx [n][h][w][C] with even h, w");
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(pad_s2d_bwd_kernel, dim3(grid_of(n * h * w * (gx.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gy.ptr, (long long)n, h, w,
+                     gx.c / 4, (float*)gx.ptr);
+  SF_CHECK_LAUNCH("pad_s2d_bwd");
   return 0;
 }
 

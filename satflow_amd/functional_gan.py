@@ -246,6 +246,52 @@ def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.Co
 
 
 # ----------------------------------------------------------------------------------------------
+# 4x4 convolutions (PatchGAN, reference gan/discriminators.py:139-223) on the 3x3 MFMA kernels
+# ----------------------------------------------------------------------------------------------
+class _PadS2dFn(torch.autograd.Function):
+    """``[n,h,w,C] -> [n,h/2+1,w/2+1,4C]``: pad by 1, fold 2x2 pixel blocks into channels (``sf_pad_s2d_fwd``)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor):
+        n, h, w, c = x.shape
+        y = torch.empty(n, h // 2 + 1, w // 2 + 1, 4 * c, dtype=torch.float32, device=x.device)
+        check(lib().sf_pad_s2d_fwd(T(x), n, h, w, T(y), stream_ptr()), "sf_pad_s2d_fwd")
+        ctx.shape = tuple(x.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        n, h, w, c = ctx.shape
+        gx = torch.empty(ctx.shape, dtype=torch.float32, device=g.device)
+        check(lib().sf_pad_s2d_bwd(T(g.contiguous()), n, h, w, T(gx), stream_ptr()), "sf_pad_s2d_bwd")
+        return gx
+
+
+def regroup4x4s2(weight: Tensor, lanes: int) -> Tensor:
+    """``[O, I, 4, 4]`` (stride 2, padding 1) -> ``[O, 4 * lanes, 3, 3]``: the weight of the 3x3 convolution over ``_PadS2dFn``'s tensor that equals the
+    strided convolution - tap ``(1 + a, 1 + b)`` holds ``W[:, c, 2a + dy, 2b + dx]`` for channel ``(2 dy + dx) * lanes + c``, the other five taps are
+    zero.  Autograd-tracked torch ops on a parameter-sized tensor."""
+    O, I = weight.shape[0], weight.shape[1]
+    g = weight.reshape(O, I, 2, 2, 2, 2).permute(0, 3, 5, 1, 2, 4)          # [O, dy, dx, I, a, b]
+    if lanes != I:
+        g = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, lanes - I))
+    return torch.nn.functional.pad(g.reshape(O, 4 * lanes, 2, 2), (1, 0, 1, 0))
+
+
+def conv4x4_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, eng: "F.ConvEngine") -> Tensor:
+    """``nn.Conv2d(k=4, stride=1|2, padding=1)`` on the 3x3 MFMA kernels.  Stride 2 (even h, w): one 3x3 convolution over the padded input with its
+    2x2 pixel blocks folded into channels (``regroup4x4s2``).  Stride 1: the 4x4 kernel is a 5x5 kernel with a zero first row and column, i.e.
+    ``conv5x5_as_3x3``; its last output row and column do not exist in the reference's result.  ``eng``: a ConvEngine for ``[4 * x lanes] -> cout``."""
+    n, h, w, cp = x.shape
+    if stride == 2:
+        y = F.conv3x3(eng, _PadS2dFn.apply(x.contiguous()), regroup4x4s2(weight, cp), bias)
+        return y[:, : h // 2, : w // 2].contiguous()
+    assert stride == 1
+    w5 = torch.nn.functional.pad(weight, (1, 0, 1, 0))                       # offsets -2..2 with a zero at -2
+    return conv5x5_as_3x3(x, w5, bias, eng)[:, : h - 1, : w - 1].contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
 # conditional BatchNorm (+ ReLU, + nearest up-sampling)  (reference layers/Normalization.py:65-85, GResBlock.py:63-78)
 # ----------------------------------------------------------------------------------------------
 class _CondNormFn(torch.autograd.Function):

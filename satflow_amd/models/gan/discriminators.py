@@ -9,11 +9,13 @@ per call (``groups``), in call order.
 from __future__ import annotations
 
 import functools
+import os
 
 import torch
 from torch import nn
 
 from ... import functional as F
+from ... import functional_gan as FG
 from ..._hip import require_device
 from ..utils import get_conv_layer
 from .common import get_norm_layer, init_net
@@ -79,6 +81,15 @@ def instance_norm(x: torch.Tensor, m: nn.InstanceNorm2d) -> torch.Tensor:
 _UNIT_AFFINE = {}
 
 
+def _on_mfma(m: nn.Conv2d, x: torch.Tensor) -> bool:
+    """4x4 kernels with padding 1 and stride 1 or 2 (even maps) run as 3x3 convolutions; SF_CONV4_DIRECT=1: the direct fp32 kernel (A/B switch)."""
+    if os.environ.get("SF_CONV4_DIRECT") or m.kernel_size != (4, 4) or m.padding != (1, 1) or m.dilation != (1, 1) or m.groups != 1:
+        return False
+    if m.stride == (2, 2):
+        return x.shape[1] % 2 == 0 and x.shape[2] % 2 == 0 and x.shape[1] >= 2 and x.shape[2] >= 2
+    return m.stride == (1, 1) and x.shape[1] >= 2 and x.shape[2] >= 2
+
+
 def _run_sequence(mods, x_nhwc: torch.Tensor, groups: int, training: bool) -> torch.Tensor:
     """Shared executor of the discriminators' ``nn.Sequential``s: Conv2d (+ fused LeakyReLU), BatchNorm2d / InstanceNorm2d / Identity."""
     y, i = x_nhwc, 0
@@ -89,6 +100,17 @@ def _run_sequence(mods, x_nhwc: torch.Tensor, groups: int, training: bool) -> to
             slope = mods[i + 1].negative_slope if fuse else 1.0
             if m.kernel_size == (1, 1) and m.stride == (1, 1) and m.padding == (0, 0):
                 y = F.linear(y, m.weight.view(m.out_channels, m.in_channels), m.bias)
+                if fuse:
+                    y = F.leaky_relu(y, slope)
+            elif _on_mfma(m, y):
+                # 4x4 kernels (PatchGAN) as 3x3 convolutions on the matrix cores (functional_gan.conv4x4_as_3x3); the packed weights are cached
+                # on the layer's own parameters
+                cin = 4 * y.shape[-1]
+                eng = m.__dict__.setdefault("_sf_eng", {})
+                if cin not in eng:
+                    eng[cin] = F.ConvEngine([cin], m.out_channels)
+                eng[cin].key_tensors = (m.weight,) if m.bias is None else (m.weight, m.bias)
+                y = FG.conv4x4_as_3x3(y, m.weight, m.bias, m.stride[0], eng[cin])
                 if fuse:
                     y = F.leaky_relu(y, slope)
             else:

@@ -146,6 +146,10 @@ int main(void) {
   REFUSED(sf_time_stack3_bwd(a16, 4, 64, a16, st));
   REFUSED(sf_pad_shift_stack4_fwd(a16, 1, 8, 8, a48, st));                                               /* output must have 4x the lanes */
   REFUSED(sf_pad_shift_stack4_bwd(a48, 1, 8, 8, a16, st));
+  REFUSED(sf_pad_s2d_fwd(a16, 1, 8, 8, a48, st));                                                      /* y must carry 4C lanes */
+  REFUSED(sf_pad_s2d_fwd(a16, 1, 7, 8, a64, st));                                                      /* odd height */
+  REFUSED(sf_pad_s2d_bwd(a48, 1, 8, 8, a16, st));                                                      /* gy must carry 4C lanes */
+  REFUSED(sf_pad_s2d_bwd(a64, 1, 8, 9, a16, st));                                                      /* odd width */
   REFUSED(sf_border(a16, 1, 8, 8, 0, 0, a16, st));                                                       /* empty border */
   REFUSED(sf_border(a16, 1, 8, 8, 2, 1, a64, st));                                                       /* channel mismatch */
   REFUSED(sf_film_act_fwd(a16, 2, 8, 8, ok, ok, 0, 12, 1, 0, a16, st));                                  /* no embedding */

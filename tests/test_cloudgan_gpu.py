@@ -190,3 +190,47 @@ def test_cloudgan_default_discriminator_and_objectives_run(device):
             loss.backward()
             net = m.generator if idx == 0 else m.discriminator
             assert all(p.grad is not None and torch.isfinite(p.grad).all() for p in net.parameters()), (kw, idx)
+
+
+@pytest.mark.parametrize("mode", ["f32", "bf16"])
+@pytest.mark.parametrize("cin,cout,n,h,w,stride", [(12, 64, 2, 32, 32, 2), (64, 128, 3, 16, 24, 2), (5, 7, 1, 6, 10, 2), (128, 256, 2, 16, 16, 1), (256, 1, 2, 15, 15, 1), (20, 33, 1, 7, 9, 1)])
+def test_conv4x4_on_the_3x3_kernels(device, mode, cin, cout, n, h, w, stride):
+    """PatchGAN's ``Conv2d(k=4, stride 1|2, padding=1)`` as ONE 3x3 MFMA convolution (``functional_gan.conv4x4_as_3x3``: 2x2 pixel blocks folded into
+    channels / zero-extended 5x5 kernel) against ``torch.nn.functional.conv2d``: output, input gradient, weight and bias gradients.  fp32 mode at the
+    parity gate; bf16 mode against the same convolution of the bf16-rounded operands."""
+    import torch.nn.functional as TF
+
+    import satflow_amd
+    from satflow_amd import functional as F
+    from satflow_amd import functional_gan as FG
+    from satflow_amd._hip import cpad
+
+    g = torch.Generator().manual_seed(cin * 3 + cout + stride)
+    x = torch.randn(n, cin, h, w, generator=g)
+    wt = torch.randn(cout, cin, 4, 4, generator=g) / (4 * cin**0.5)
+    b = torch.randn(cout, generator=g)
+    rnd = (lambda t: t.bfloat16().float()) if mode == "bf16" else (lambda t: t)
+    xr, wr, br = rnd(x).clone().requires_grad_(), rnd(wt).clone().requires_grad_(), b.clone().requires_grad_()
+    ref = TF.conv2d(xr, wr, br, stride=stride, padding=1)
+    cot = torch.randn(ref.shape, generator=g)
+    satflow_amd.set_compute_dtype(mode)
+    try:
+        xd = x.to(device).requires_grad_()
+        wd, bd = wt.to(device).requires_grad_(), b.to(device).requires_grad_()
+        xn = F.nchw_to_nhwc(xd)
+        eng = F.ConvEngine([4 * cpad(cin)], cout)
+        y = F.nhwc_to_nchw(FG.conv4x4_as_3x3(xn, wd, bd, stride, eng), cout)
+        assert y.shape == ref.shape
+        assert_close(y, ref.detach(), f"conv4x4 stride {stride} ({mode})")
+        (y * cot.to(device)).sum().backward()
+        if mode == "bf16":   # the kernels round the cotangent to bf16 for both gradient products; the bias gradient sums it unrounded
+            dxr, dwr = torch.autograd.grad(TF.conv2d(xr, wr, None, stride=stride, padding=1), (xr, wr), rnd(cot))
+            dbr = cot.sum(dim=(0, 2, 3))
+        else:
+            (ref * cot).sum().backward()
+            dxr, dwr, dbr = xr.grad, wr.grad, br.grad
+        assert_close(xd.grad, dxr, "dx", grad=True)
+        assert_close(wd.grad, dwr, "dW", grad=True)
+        assert_close(bd.grad, dbr, "db", grad=True)
+    finally:
+        satflow_amd.set_compute_dtype("f32")
