@@ -11,7 +11,7 @@ done
 for m in bf16a bf16; do bash tools/prof_pmc.sh ${R}_pmc_metnet_$m $m > /dev/null 2>&1; done
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_metnet_bf16a_bench_full.json 2> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload convlstm --steps 20 --warmup 5 > gpurun_out/${R}_convlstm_bf16a_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
-python bench.py --workload cloudgan --steps 10 --warmup 3 --no-extra > gpurun_out/${R}_cloudgan_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
+python bench.py --workload cloudgan --steps 40 --warmup 20 --no-extra > gpurun_out/${R}_cloudgan_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload stlstm --steps 10 --warmup 3 --no-extra > gpurun_out/${R}_stlstm_bf16a_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload stlstm --dtype f32 --steps 10 --warmup 3 --no-extra --no-cpu-baseline > gpurun_out/${R}_stlstm_f32_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 SF_NO_GRAPH=1 bash tools/prof_stats.sh ${R}_dgmr_bf16 --workload dgmr --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
