@@ -17,6 +17,7 @@ from __future__ import annotations
 
 import argparse
 import contextlib
+import gc
 import json
 import os
 import sys
@@ -751,6 +752,11 @@ def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
 
     for _ in range(warmup):
         wl.step()
+    # Python's cyclic garbage collector pauses the launching thread for ~90 ms once every dozen steps (a generation-2 pass over the autograd
+    # objects: tools/probe_steps.py) - a host hiccup that says nothing about the path and, on N ranks, stalls every rank at the next
+    # collective.  Collected now, paused for the K timed steps (what large training loops do: collect at chosen steps), re-enabled after.
+    gc.collect()
+    gc.disable()
     use_events = dev.type == "cuda"
     if use_events:  # HIP events on the step's stream beside the wall clock (BASELINE.md section 3 / SURVEY 8d)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -765,6 +771,7 @@ def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
         ev1.record()
     barrier()
     elapsed = time.perf_counter() - t0
+    gc.enable()
     timed_steps.last_event_ms = ev0.elapsed_time(ev1) if use_events else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
@@ -812,8 +819,8 @@ def comm_report(wl, world: int, dev) -> dict:
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=8)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=30)     # a MetNet step is 24 ms: the defaults time one second of training after
+    ap.add_argument("--warmup", type=int, default=10)    # a quarter second of warm-up (lazy initialisation, allocator, clocks)
     ap.add_argument("--workload", default=os.environ.get("SF_WORKLOAD", "metnet"), choices=["metnet", "convlstm", "cloudgan", "stlstm", "dgmr", "stub"])
     ap.add_argument("--batch", type=int, default=None, help="per-GPU batch (default 8; with --scaling strong: global batch / N)")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
