@@ -6,6 +6,7 @@ arithmetic happens in PyTorch on the hot path except where a comment says so.
 """
 from __future__ import annotations
 
+import contextlib
 import os
 from typing import List, Optional, Sequence, Tuple
 
@@ -242,12 +243,32 @@ class ConvStats:
         self.data = torch.empty(n * self.tiles, np_, 2, dtype=torch.float32, device=device)
 
 
+_WBATCH_SCOPE: List[Optional[dict]] = [None]
+
+
+@contextlib.contextmanager
+def batched_weight_grads():
+    """Scope for the FORWARD pass of a cell unrolled over time: every plain ``conv3x3`` application of the same ``ConvEngine`` (= the same layer)
+    inside it shares one ``WeightGradBatch``, so the backward pass computes each layer's weight gradient once over all time steps instead of
+    once per step (T launches writing the whole gradient each, then T - 1 adds by autograd).  The weight handed to the applications must be
+    the same function of the same parameters every time (a cell's layer: yes).  Every application's output must reach the loss
+    (``WeightGradBatch`` raises at the end of a backward pass otherwise)."""
+    prev, _WBATCH_SCOPE[0] = _WBATCH_SCOPE[0], {}
+    try:
+        yield
+    finally:
+        _WBATCH_SCOPE[0] = prev
+
+
 def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], sigmoid: bool = False, out_dtype=None,
             want_stats: Optional[bool] = None, wbatch: Optional[WeightGradBatch] = None):
     """``out_dtype=torch.bfloat16`` stores the result as bf16 (SF_BF16 kernels only; "bf16a" encoder mode).
     ``want_stats`` not None: returns ``(y, stats)`` with ``stats`` a ``ConvStats`` for ``batchnorm(..., stats=)`` when it is
     true and the bf16 kernels run, else None."""
     if want_stats is None:
+        scope = _WBATCH_SCOPE[0]
+        if wbatch is None and scope is not None and not sigmoid and torch.is_grad_enabled() and weight.requires_grad:
+            wbatch = scope.setdefault(id(eng), WeightGradBatch())
         return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype, None, wbatch)
     from ._hip import SF_BF16, compute_dtype
 
