@@ -767,13 +767,15 @@ def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
     if use_events:
         ev0.record()
     loss = None
-    for _ in range(steps):
-        loss = wl.step()
-    if use_events:
-        ev1.record()
-    barrier()
-    elapsed = time.perf_counter() - t0
-    gc.enable()
+    try:
+        for _ in range(steps):
+            loss = wl.step()
+        if use_events:
+            ev1.record()
+        barrier()
+        elapsed = time.perf_counter() - t0
+    finally:
+        gc.enable()
     timed_steps.last_event_ms = ev0.elapsed_time(ev1) if use_events else None
     if world > 1:
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
