@@ -511,6 +511,11 @@ int sf_time_stack3_bwd(sfTensor gy, int32_t T, int64_t pixels_per_frame, sfTenso
 int sf_pad_shift_stack4_fwd(sfTensor x, int64_t n, int32_t h, int32_t w, sfTensor y, sfStream stream);
 int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTensor gx, sfStream stream);
 int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32_t pad, sfTensor y, sfStream stream);
+/* The weight side of the 5x5-as-3x3 route (sf_pad_shift_stack4_*; the generator's ConvGRU, Generator.py:29-68): [O][I][5][5] (rows `row_pitch` elements apart: a
+ * column slice of a wider Conv2d weight is taken in place) -> [O][4 * lanes][3][3], tile (ty, tx) = taps (2 ty + ky, 2 tx + kx), duplicates of the middle
+ * row / column masked, lanes >= I zero-padded; _bwd gathers the gradient of the 5x5 weight (dense [O][I][5][5]) back out of the 3x3 form. */
+int sf_regroup5x5_fwd(const float* w5, int64_t row_pitch, int32_t O, int32_t I, int32_t lanes, float* w3, sfStream stream);
+int sf_regroup5x5_bwd(const float* g3, int32_t O, int32_t I, int32_t lanes, float* g5, sfStream stream);
 /* A 4x4 stride-2 Conv2d with padding 1 - the down-sampling layers of the PatchGAN discriminator (satflow/models/gan/discriminators.py:166-186,
  * called by CloudGAN, satflow/models/cloudgan.py) - as ONE 3x3 convolution: x padded by 1 with its 2x2 pixel blocks folded into channels,
  * y[n][Y][X][(2 dy + dx) C + c] = x[n][2Y + dy - 1][2X + dx - 1][c] for Y < h/2 + 1, X < w/2 + 1 (h, w even); the 4x4 kernel becomes the taps

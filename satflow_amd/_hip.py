@@ -127,6 +127,8 @@ PROTOTYPES = {
     "sf_time_stack3_bwd": (C.c_int, [sfTensor, _i32, _i64, sfTensor, _vp]),
     "sf_pad_shift_stack4_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
     "sf_pad_shift_stack4_bwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
+    "sf_regroup5x5_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
+    "sf_regroup5x5_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
     "sf_pad_s2d_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
     "sf_pad_s2d_bwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
     "sf_border": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, _i32, sfTensor, _vp]),

@@ -228,6 +228,31 @@ __global__ __launch_bounds__(256) void pad_shift4_bwd_kernel(const float* __rest
     st4(gx + idx * 4, a);
   }
 }
+// Weight of the ONE 3x3 convolution that equals a 5x5 convolution over the four shifted copies (pad_shift4 above): tile (ty, tx) = copy 2 ty + tx holds
+// the 5x5 taps (2 ty + ky, 2 tx + kx); the middle row / column of the 5x5 kernel is covered twice and belongs to the upper / left tile.
+//   w3[o][(2 ty + tx) * lanes + i][ky][kx] = w5[o][i][2 ty + ky][2 tx + kx]   (0 for i >= I and for the masked duplicates)
+// w5 may be a column slice of a wider weight: row pitch `so` elements.  The backward pass is the inverse gather (every 5x5 tap has one owner).
+__global__ __launch_bounds__(256) void regroup5_fwd_kernel(const float* __restrict__ w5, long long so, int O, int I, int lanes, float* __restrict__ w3) {
+  const long long total = (long long)O * 4 * lanes * 9;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int k = (int)(idx % 9); long long r = idx / 9;
+    const int i = (int)(r % lanes); r /= lanes;
+    const int t = (int)(r % 4); const long long o = r / 4;
+    const int ty = t >> 1, tx = t & 1, ky = k / 3, kx = k - 3 * ky;
+    const bool live = i < I && !(ty && ky == 0) && !(tx && kx == 0);
+    w3[idx] = live ? w5[o * so + (long long)i * 25 + (2 * ty + ky) * 5 + 2 * tx + kx] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void regroup5_bwd_kernel(const float* __restrict__ g3, int O, int I, int lanes, float* __restrict__ g5) {
+  const long long total = (long long)O * I * 25;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int x = (int)(idx % 5); long long r = idx / 5;
+    const int y = (int)(r % 5); r /= 5;
+    const int i = (int)(r % I); const long long o = r / I;
+    const int ty = y > 2 ? 1 : 0, tx = x > 2 ? 1 : 0;   // rows / columns 0..2 belong to the upper / left tile
+    g5[idx] = g3[((o * 4 + 2 * ty + tx) * lanes + i) * 9 + (y - 2 * ty) * 3 + (x - 2 * tx)];
+  }
+}
 // 4x4 stride-2 convolution with padding 1 (the PatchGAN discriminator's down-sampling layers, gan/discriminators.py:166-197) on the 3x3 kernels:
 // pad by 1 and fold 2x2 pixel blocks into channels,
 //   ys[n][Y][X][(2 dy + dx) * C + c] = x[n][2 Y + dy - 1][2 X + dx - 1][c]  (zero outside the image),  Y in [0, h/2 + 1), X in [0, w/2 + 1)
@@ -701,6 +726,19 @@ int sf_pad_shift_stack4_bwd(sfTensor gy, int64_t n, int32_t h, int32_t w, sfTens
   hipLaunchKernelGGL(pad_shift4_bwd_kernel, dim3(grid_of(n * h * w * (gx.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)gy.ptr, (long long)n, h, w,
                      gx.c / 4, (float*)gx.ptr);
   SF_CHECK_LAUNCH("pad_shift_stack4_bwd");
+  return 0;
+}
+
+int sf_regroup5x5_fwd(const float* w5, int64_t row_pitch, int32_t O, int32_t I, int32_t lanes, float* w3, sfStream stream) {
+  SF_REQUIRE(w5 && w3 && O >= 1 && I >= 1 && lanes >= I && row_pitch >= (int64_t)I * 25, "sf_regroup5x5_fwd: null pointer, lanes (%d) < I (%d) or row pitch too small", lanes, I);
+  hipLaunchKernelGGL(regroup5_fwd_kernel, dim3(grid_of((long long)O * 4 * lanes * 9)), dim3(256), 0, (hipStream_t)stream, w5, (long long)row_pitch, O, I, lanes, w3);
+  SF_CHECK_LAUNCH("regroup5x5_fwd");
+  return 0;
+}
+int sf_regroup5x5_bwd(const float* g3, int32_t O, int32_t I, int32_t lanes, float* g5, sfStream stream) {
+  SF_REQUIRE(g3 && g5 && O >= 1 && I >= 1 && lanes >= I, "sf_regroup5x5_bwd: null pointer or lanes (%d) < I (%d)", lanes, I);
+  hipLaunchKernelGGL(regroup5_bwd_kernel, dim3(grid_of((long long)O * I * 25)), dim3(256), 0, (hipStream_t)stream, g3, O, I, lanes, g5);
+  SF_CHECK_LAUNCH("regroup5x5_bwd");
   return 0;
 }
 

@@ -206,34 +206,31 @@ class _CropFn(torch.autograd.Function):
         return gx, None
 
 
-_REGROUP5 = {}
+class _Regroup5Fn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight: Tensor, lanes: int):
+        O, I = weight.shape[0], weight.shape[1]
+        if not (weight.stride(3) == 1 and weight.stride(2) == 5 and weight.stride(1) == 25):   # anything but a column slice of a dense weight
+            weight = weight.contiguous()
+        w3 = torch.empty(O, 4 * lanes, 3, 3, dtype=torch.float32, device=weight.device)
+        check(lib().sf_regroup5x5_fwd(weight.data_ptr(), weight.stride(0), O, I, lanes, w3.data_ptr(), stream_ptr()), "sf_regroup5x5_fwd")
+        ctx.meta = (O, I, lanes)
+        return w3
 
-
-def _regroup5_index(dev):
-    """Gather index / mask of the 5x5 -> four 3x3 tiles regrouping: tile (ty, tx) holds taps (2 ty + ky, 2 tx + kx); the middle row / column of the
-    5x5 kernel is covered twice and belongs to the upper / left tile."""
-    if dev not in _REGROUP5:
-        idx, mask = [], []
-        for ty in (0, 1):
-            for tx in (0, 1):
-                for ky in range(3):
-                    for kx in range(3):
-                        idx.append((2 * ty + ky) * 5 + 2 * tx + kx)
-                        mask.append(0.0 if (ty and ky == 0) or (tx and kx == 0) else 1.0)
-        _REGROUP5[dev] = (torch.tensor(idx, device=dev), torch.tensor(mask, device=dev))
-    return _REGROUP5[dev]
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        O, I, lanes = ctx.meta
+        g5 = torch.empty(O, I, 5, 5, dtype=torch.float32, device=g.device)
+        check(lib().sf_regroup5x5_bwd(g.contiguous().data_ptr(), O, I, lanes, g5.data_ptr(), stream_ptr()), "sf_regroup5x5_bwd")
+        return g5, None
 
 
 def regroup5x5(weight: Tensor, lanes: int) -> Tensor:
     """``[O, I, 5, 5]`` -> ``[O, 4 * lanes, 3, 3]``: the weight of the ONE 3x3 convolution over four shifted copies (``lanes`` channels each, ``I <= lanes``)
-    that equals the 5x5 convolution.  Autograd-tracked torch ops on a parameter-sized tensor; a function of the weight only, so a recurrent cell
-    builds it once per sequence, not once per frame."""
-    O, I = weight.shape[0], weight.shape[1]
-    idx, mask = _regroup5_index(weight.device)
-    g = (weight.reshape(O, I, 25).index_select(2, idx) * mask).view(O, I, 4, 9).transpose(1, 2)   # [O, tile, I, 9]
-    if lanes != I:
-        g = torch.nn.functional.pad(g, (0, 0, 0, lanes - I))
-    return g.reshape(O, 4 * lanes, 3, 3)
+    that equals the 5x5 convolution (``sf_regroup5x5_*``: one gather each way; a column slice of a wider weight is read in place).  A function of the
+    weight only, so a recurrent cell builds it once per sequence, not once per frame."""
+    require_device(weight, "weight")
+    return _Regroup5Fn.apply(weight.float(), lanes)
 
 
 def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.ConvEngine", wbatch: Optional["F.WeightGradBatch"] = None) -> Tensor:

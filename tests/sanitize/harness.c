@@ -146,6 +146,9 @@ int main(void) {
   REFUSED(sf_time_stack3_bwd(a16, 4, 64, a16, st));
   REFUSED(sf_pad_shift_stack4_fwd(a16, 1, 8, 8, a48, st));                                               /* output must have 4x the lanes */
   REFUSED(sf_pad_shift_stack4_bwd(a48, 1, 8, 8, a16, st));
+  REFUSED(sf_regroup5x5_fwd(ok, 100, 4, 8, 4, ok, st));                                                /* lanes < I */
+  REFUSED(sf_regroup5x5_fwd(ok, 10, 4, 8, 16, ok, st));                                                /* row pitch smaller than a row */
+  REFUSED(sf_regroup5x5_bwd(0, 4, 8, 16, ok, st));                                                     /* no gradient */
   REFUSED(sf_pad_s2d_fwd(a16, 1, 8, 8, a48, st));                                                      /* y must carry 4C lanes */
   REFUSED(sf_pad_s2d_fwd(a16, 1, 7, 8, a64, st));                                                      /* odd height */
   REFUSED(sf_pad_s2d_bwd(a48, 1, 8, 8, a16, st));                                                      /* gy must carry 4C lanes */
