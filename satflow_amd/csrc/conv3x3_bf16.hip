@@ -124,6 +124,23 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     for (int nf = 0; nf < NF; ++nf)
 #pragma unroll
       for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+  // Fused LSTM cell: the accumulators START at the gate biases (lane = pixel, register 4g + c of fragment q = channel 8g + 4kh + c of gate q): the
+  // loads run under the first chunk's staging and the epilogue begins with the cell-state loads instead of sixteen bias loads.
+  if constexpr (EPI == EPI_LSTM) {
+    static_assert(TR, "the LSTM epilogue is the transposed one");
+    if (p.bias) {
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(p.bias + nb * NB + 32 * nf + 8 * g + 4 * kh);
+#pragma unroll
+          for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+            for (int c = 0; c < 4; ++c) acc[mf][nf][4 * g + c] = b[c];
+        }
+    }
+  }
   // Folded BatchNorm (sf_conv3x3_fwd_folded): the accumulators START at the group's bias of each pixel's border class (the epilogue
   // then adds no bias) - here, before the K loop, nothing else is live yet.
   if constexpr (EPI == EPI_LINEAR && !DUAL) {
@@ -303,6 +320,9 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     // which pairs waves of different SIMDs, gains nothing; spreading the pieces over the taps loses the gain).
     const bool stage_late = WAVES == 8 && wave >= 4;
     auto stage_next = [&]() {
+#ifdef SF_EXP_NOSTAGE   // ablation (tools/ablate_lstm_cell.sh): no staging of the next chunk - MFMAs on whatever the LDS holds
+      return;
+#endif
       if (ci + 1 < nch) {
         if constexpr (!WS) issue_weights(ci + 1, cur ^ 1);
         stage_input(ci + 1);
@@ -377,8 +397,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf)
+#ifdef SF_EXP_NOMFMA   // ablation: the fragment reads stay (one cheap use each), the matrix instructions go
+          acc[mf][nf][0] += (float)fb[tap & 1][nf][0] + (float)fa[tap & 1][mf][0];
+#else
           acc[mf][nf] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1][mf], acc[mf][nf], 0, 0, 0)
                            : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
+#endif
       // scheduling: one LDS read (the next tap's operands) after each of the first MFMAs of this tap, the remaining
       // MFMAs behind them - a clump of 2+NF reads between two MFMA groups measured 2 % (NF=4) to 15 % (NF=5) slower
       if (tap + 1 < 9) {
@@ -422,6 +446,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     conv_epilogue_tr_bnb<NF>(acc, p, n, nb, y0, x0, wave, r, kh, lds_coef);
     return;
   } else if constexpr (TR) {
+#ifdef SF_EXP_NOEPI   // ablation: no epilogue (one never-taken store keeps the accumulators alive)
+    {
+      float keep = 0.f;
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) keep += acc[mf][nf][i];
+      if (keep == 12345.678f) p.c_out[0] = keep;
+    }
+    return;
+#endif
     if (!DUAL || n_w < p.N) conv_epilogue_tr<NF, EPI>(acc, p, n_w, nb, y0, x0, wl, r, kh);
     return;
   } else {

@@ -247,35 +247,58 @@ __device__ __forceinline__ void conv_epilogue_tr(f32x16 (&acc)[2][NF], const Con
     static_assert(NF == 4, "LSTM epilogue needs the 4 gates in one wave");
     const int hb = nb * 32 + 4 * kh;
     const size_t pix_safe = (size_t)(n * p.H + y0) * p.W + x0;  // the tile origin is always inside the image
-    f32x4 bias[4][4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        bias[q][g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nb * NB + 32 * q + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
+    // The bias is ALREADY in the accumulators (the kernel starts them at the bias, conv3x3_bf16.hip), and the previous cell state of BOTH pixel
+    // fragments is requested before anything is stored: the stores of fragment 0 may alias the loads of fragment 1 as far as the compiler
+    // knows, so left in the loop the two load latencies (and the bias loads' before them) were serial - 34 of the cell's 97 us were epilogue
+    // (tools/ablate_lstm_cell.sh: without sigmoid / tanh 94 us, without the saved gates 91 us, without any epilogue 62 us).
+    f32x4 cpa[2][4];
 #pragma unroll
     for (int mf = 0; mf < 2; ++mf) {
       const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
-      const bool ok = py < p.H && px < p.W;
-      const size_t pix = ok ? (size_t)(n * p.H + py) * p.W + px : pix_safe;
-      f32x4 cp[4];
+      const size_t pix = (py < p.H && px < p.W) ? (size_t)(n * p.H + py) * p.W + px : pix_safe;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {  // unconditional loads from clamped addresses (see conv_epilogue)
         const int hq = (hb + 8 * g < p.hidp) ? hb + 8 * g : 0;
-        cp[g] = p.c_prev ? *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.cprev_s + hq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#ifdef SF_EXP_LSTM_NOCPREV   // ablation: no previous-cell-state loads
+        cpa[mf][g] = f32x4{0.f, 0.f, 0.f, 0.f};
+#else
+        cpa[mf][g] = p.c_prev ? *reinterpret_cast<const f32x4*>(p.c_prev + pix * p.cprev_s + hq) : f32x4{0.f, 0.f, 0.f, 0.f};
+#endif
       }
+    }
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf) {
+      const int py = y0 + 4 * wave + 2 * mf + (r >> 4), px = x0 + (r & 15);
+#ifdef SF_EXP_LSTM_NOSTORE   // ablation: every store of the epilogue predicated off by a value the compiler cannot know
+      const bool ok = py < p.H && px < p.W && acc[mf][0][0] == 12345.678f;
+#else
+      const bool ok = py < p.H && px < p.W;
+#endif
+      const size_t pix = ok ? (size_t)(n * p.H + py) * p.W + px : pix_safe;
+      const f32x4 (&cp)[4] = cpa[mf];
       f32x4 gi[4], gf[4], go[4], gg[4], cn[4], hn[4];
+      // Ablation builds of tools/ablate_lstm_cell.sh (never part of the shipped library): -DSF_EXP_LSTM_NOTRANS replaces the five transcendental
+      // functions per element by one multiply each - the difference to the shipped kernel is what the gate arithmetic costs with the matrix pipes idle.
+#ifdef SF_EXP_LSTM_NOTRANS
+#define SF_LSTM_SIG(v) (0.25f * (v))
+#define SF_LSTM_TANH(v) (0.5f * (v))
+#else
+#define SF_LSTM_SIG(v) sf_sigmoid(v)
+#define SF_LSTM_TANH(v) sf_tanh(v)
+#endif
 #pragma unroll
       for (int g = 0; g < 4; ++g)
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
-          gi[g][c] = sf_sigmoid(acc[mf][0][4 * g + c] + bias[0][g][c]);
-          gf[g][c] = sf_sigmoid(acc[mf][1][4 * g + c] + bias[1][g][c]);
-          go[g][c] = sf_sigmoid(acc[mf][2][4 * g + c] + bias[2][g][c]);
-          gg[g][c] = sf_tanh(acc[mf][3][4 * g + c] + bias[3][g][c]);
+          gi[g][c] = SF_LSTM_SIG(acc[mf][0][4 * g + c]);
+          gf[g][c] = SF_LSTM_SIG(acc[mf][1][4 * g + c]);
+          go[g][c] = SF_LSTM_SIG(acc[mf][2][4 * g + c]);
+          gg[g][c] = SF_LSTM_TANH(acc[mf][3][4 * g + c]);
           cn[g][c] = gf[g][c] * cp[g][c] + gi[g][c] * gg[g][c];
-          hn[g][c] = go[g][c] * sf_tanh(cn[g][c]);
+          hn[g][c] = go[g][c] * SF_LSTM_TANH(cn[g][c]);
         }
+#undef SF_LSTM_SIG
+#undef SF_LSTM_TANH
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         if (ok && hb + 8 * g < p.hidp) {
