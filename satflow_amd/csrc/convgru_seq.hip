@@ -197,6 +197,12 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 
   if (p.T > 0 && chunks > 0) issue_weights(0, 0);
 
+  // bias of the candidate's h-part (z / r biases ride on the x-part): loaded ONCE - inside the time loop the DMA statements' memory clobbers keep
+  // the compiler from hoisting it, and every step's epilogue then began with an exposed L2 round trip
+  f32x4 b2[4];
+#pragma unroll
+  for (int g = 0; g < 4; ++g) b2[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbk * NBG + 64 + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
+
   using GXV = typename std::conditional<GXBF, bf16x4, f32x4>::type;
   for (int t = 0; t < p.T; ++t) {
     f32x16 acc[MFW][3];
@@ -266,9 +272,6 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
     __syncthreads();  // every wave is done reading the state tile of step t - 1
 
     // ---- epilogue: gates, new state (registers), outputs, bf16 image of the new state into the tile ----
-    f32x4 b2[4];  // bias of the candidate's h-part (z / r biases ride on the x-part)
-#pragma unroll
-    for (int g = 0; g < 4; ++g) b2[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbk * NBG + 64 + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int mf = 0; mf < MFW; ++mf) {
       if constexpr (!GXBF) load_gx(mf);
