@@ -9,6 +9,10 @@ for m in bf16a bf16 f32; do
   bash tools/prof_stats.sh ${R}_convlstm_$m --workload convlstm --dtype $m --no-cpu-baseline > /dev/null 2>&1
 done
 for m in bf16a bf16; do bash tools/prof_pmc.sh ${R}_pmc_metnet_$m $m > /dev/null 2>&1; done
+# the full bench lines below read the sha-stamped traffic record from profiles/: refresh it on this box first (collect_profiles.sh repeats this at home)
+KFA="conv3x3_bf16_persist_kernel<4, 0>"; KFB="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"
+python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16a profiles/${R}_metnet_bf16a_pmc_conv256.json "$KFA" > /dev/null 2>&1
+python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16 profiles/${R}_metnet_bf16_pmc_conv256.json "$KFB" > /dev/null 2>&1
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_metnet_bf16a_bench_full.json 2> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload convlstm --steps 20 --warmup 5 > gpurun_out/${R}_convlstm_bf16a_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload cloudgan --steps 40 --warmup 20 --no-extra > gpurun_out/${R}_cloudgan_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
