@@ -49,7 +49,16 @@ class GANLoss(nn.Module):
             raise NotImplementedError("gan mode %s not implemented" % gan_mode)
 
     def labels(self, target_is_real: bool) -> float:
-        return float(self.real_label if target_is_real else self.fake_label)
+        """The label as a host number (a kernel argument).  The buffers are device scalars as in the reference; reading one is a device-to-host
+        copy - a synchronisation on every loss call and not capturable into a hipGraph - so the value is cached until the buffer is written
+        (``load_state_dict`` / ``.to()`` / in-place edits change its version or identity)."""
+        buf = self.real_label if target_is_real else self.fake_label
+        key = (id(buf), buf._version, buf.data_ptr())
+        cache = self.__dict__.setdefault("_label_cache", {})
+        hit = cache.get(target_is_real)
+        if hit is None or hit[0] != key:
+            hit = cache[target_is_real] = (key, float(buf))
+        return hit[1]
 
     def __call__(self, prediction, target_is_real):
         """``prediction [N,1,h,w]`` (NCHW, as the reference's discriminator returns it) -> scalar loss."""

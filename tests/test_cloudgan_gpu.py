@@ -301,3 +301,34 @@ def test_cloudgan_training_steps_bf16_modes_vs_golden(device, case):
         publish(rec)
     finally:
         satflow_amd.set_compute_dtype("f32")
+
+
+def test_cloudgan_step_hipgraph_replay_equals_eager(device):
+    """bench.py's CloudGAN workload: the generator half and the discriminator half capture into hipGraphs, and a replayed step leaves the
+    parameters (and the discriminator's BatchNorm statistics) the eager step leaves from the same state."""
+    import copy
+
+    import satflow_amd
+    import bench
+
+    satflow_amd.set_compute_dtype("bf16a")
+    try:
+        a = bench.CloudGANWorkload(device, 2, 0)
+        b = bench.CloudGANWorkload(device, 2, 0)
+        a.capture()
+        assert a.graphed
+        b.model.load_state_dict(copy.deepcopy(a.model.state_dict()))
+        for oa, ob in ((a.opt_g, b.opt_g), (a.opt_d, b.opt_d)):
+            ob.load_state_dict(copy.deepcopy(oa.state_dict()))
+        la, lb = a.step(), b._eager_step()
+        torch.cuda.synchronize()
+        assert_close(la, lb, "loss of the replayed step")
+        sa, sb = a.model.state_dict(), b.model.state_dict()
+        n = 0
+        for k, v in sa.items():
+            if v.dtype.is_floating_point:
+                assert_close(v.float(), sb[k].float(), f"{k} after a replayed step vs after the eager step")
+                n += 1
+        assert n > 20
+    finally:
+        satflow_amd.set_compute_dtype("f32")
