@@ -175,8 +175,18 @@ class ConvLSTMWorkload:
         alg_bytes = ((hid + hid + hid) * sb + 2 * hid * 4) * H * W * B + 9 * 2 * hid * 4 * hid * 4
         bf16 = satflow_amd.compute_dtype_name() in ("bf16", "bf16a")
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r03_convlstm_bf16a_pmc_cell.json")
+        if bf16 and st == torch.bfloat16 and (B, H, W, hid) == (8, 128, 128, 64) and os.path.exists(pmc):  # PMC passes of this launch shape (tools/prof_pmc_cell.sh)
+            rec = json.load(open(pmc))
+            if rec.get("kernel_src_sha") == kernel_source_sha():
+                traffic, traffic_src = rec["traffic_bytes"], ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; "
+                                                              f"profiles/r03_convlstm_bf16a_pmc_cell.json (kernel sources sha {rec['kernel_src_sha']}); "
+                                                              "includes the saved gates of the training step (67 MB), which SURVEY 8(d)'s algorithmic bytes leave out")
+            else:
+                traffic_src = "profiles/r03_convlstm_bf16a_pmc_cell.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
-                "frac": flops / t / 1e12 / peak, "traffic": None,
+                "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, %d->%d ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", 2 * hid, 4 * hid, B),
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,

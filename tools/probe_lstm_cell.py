@@ -15,7 +15,10 @@ st, gt = state_storage_dtype(), gate_storage_dtype()
 mk = lambda c, dt=torch.float32: torch.randn(B, H, W, c, device=dev).to(dt)
 x, h, c, ho, co, g = mk(hid, st), mk(hid, st), mk(hid), mk(hid, st), mk(hid), mk(4 * hid, gt)
 flops = 2 * 9 * 2 * hid * 4 * hid * H * W * B
-for name, fn in (("training step (saved gates)", lambda: eng.step(T(x), h, c, B, H, W, ho, co, g)),
-                 ("no saved gates", lambda: eng.step(T(x), h, c, B, H, W, ho, co, None))):
+variants = (("training step (saved gates)", lambda: eng.step(T(x), h, c, B, H, W, ho, co, g)),
+            ("no saved gates", lambda: eng.step(T(x), h, c, B, H, W, ho, co, None)))
+if tag == "pmc":   # counter passes (tools/prof_pmc_cell.sh): only the training step's launch shape
+    variants = variants[:1]
+for name, fn in variants:
     t = bench.event_time(fn, iters=30)
     print(f"{tag:8s} {name:28s} {t * 1e6:7.1f} us  {flops / t / 1e12:7.1f} TF/s")
