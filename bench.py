@@ -511,20 +511,43 @@ class STLSTMWorkload:
             dec = dec + (dc * dm).mean()
         return ((h - y) ** 2).mean() + 0.01 * dec
 
-    def step(self):
+    def _fwd_bwd(self):
         self.opt.zero_grad()
         z = torch.zeros(self.B, self.H, self.W, self.hid, device=self.dev)
-        # (functional.batched_weight_grads() around this unroll would compute each layer's weight gradient once per sequence; this step is
+        # (functional.batched_weight_grads() around this unroll would compute each layer's weight gradient once per sequence; the eager step is
         # host-bound at 64x64 - measured 4.32 ms with it against 3.82 ms without: the concatenations cost more host time than 20 launches)
-        loss = self._loss(self.cell.run, self.x, self.y, z)
-        loss.backward()
+        self._loss_t = self._loss(self.cell.run, self.x, self.y, z)
+        self._loss_t.backward()
+
+    def capture(self):
+        """hipGraph capture of forward + loss + backward (the step is ~250 small launches: host-bound in eager mode); Adam stays eager."""
+        side = torch.cuda.Stream()
+        side.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(side):
+            for _ in range(2):
+                self._fwd_bwd()
+                self.opt.step()
+        torch.cuda.current_stream().wait_stream(side)
+        torch.cuda.synchronize()
+        self.g1 = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self.g1):
+            self._fwd_bwd()
         self.opt.step()
-        return loss.detach()
+        torch.cuda.synchronize()
+        self.graphed = True
+
+    def step(self):
+        if getattr(self, "graphed", False):
+            self.g1.replay()
+        else:
+            self._fwd_bwd()
+        self.opt.step()
+        return self._loss_t.detach()
 
     def config(self, world):
         return {"workload": "ST-LSTM cell with memory decoupling (PredRNN v2; SURVEY 8f-4), 12 -> 64 hidden channels, 64x64, T=6 unrolled",
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
-                "step": "fwd over T cells + mse + decoupling term + bwd + adam"}
+                "step": "fwd over T cells + mse + decoupling term + bwd + adam", "launch": getattr(self, "graph_note", "eager")}
 
     def roofline(self):
         from satflow_amd import kernels as K
@@ -914,10 +937,10 @@ def main(argv=None):
 
     wl = build_workload(args.workload, dev, batch, rank)
     # (CloudGANWorkload.capture() exists and is pinned by a test, but its replay is not faster than the eager step: 9.67 vs 9.54 ms - GPU-bound)
-    if args.workload == "dgmr" and world == 1 and not os.environ.get("SF_NO_GRAPH"):
+    if args.workload in ("dgmr", "stlstm") and world == 1 and not os.environ.get("SF_NO_GRAPH"):
         try:
             wl.capture()
-            wl.graph_note = "hipGraph replay of the two half-steps (torch.cuda.CUDAGraph), Adam updates eager"
+            wl.graph_note = ("hipGraph replay of the two half-steps" if args.workload == "dgmr" else "hipGraph replay of forward + loss + backward") + " (torch.cuda.CUDAGraph), Adam updates eager"
         except Exception as e:  # noqa: BLE001 - the eager step is the fallback, and the line says so
             wl.graphed, wl.graph_note = False, f"eager (capture failed: {type(e).__name__}: {str(e)[:200]})"
     elapsed, final_loss = timed_steps(wl, args.steps, args.warmup, world, dev, sync)
