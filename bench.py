@@ -728,7 +728,16 @@ class DGMRWorkload:
         flops = 2.0 * 9 * cin * cout * self.H * self.H * n
         bf16 = satflow_amd_mode() != "f32"
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
-        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak, "traffic": None,
+        traffic, traffic_src = None, None
+        pmc = os.path.join(ROOT, "profiles", "r03_dgmr_bf16_pmc_conv.json")
+        if bf16 and (n, self.H, cin) == (16, 256, 128) and os.path.exists(pmc):   # PMC passes of this launch (tools/prof_pmc_dgmr.sh)
+            rec = json.load(open(pmc))
+            if rec.get("kernel_src_sha") == kernel_source_sha():
+                traffic, traffic_src = rec["traffic_bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2; profiles/r03_dgmr_bf16_pmc_conv.json (sha {rec['kernel_src_sha']})"
+            else:
+                traffic_src = "profiles/r03_dgmr_bf16_pmc_conv.json is stale (kernel sources changed): dropped"
+        return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak, "traffic": traffic,
+                "traffic_source": traffic_src, "algorithmic_bytes": n * self.H * self.H * (cpad(cin) + cpad(cout)) * 4 + 9 * cin * cout * 2,
                 "kernel": f"sf_conv3x3_fwd {cin}->{cout} @256x256 x {n} frames", "us_per_launch": t * 1e6,
                 "algorithmic_hbm_GBps": (n * self.H * self.H * (cpad(cin) + cpad(cout)) * 4) / t / 1e9}
 

@@ -22,6 +22,7 @@ PY
   if [ $m = bf16a ]; then KF="conv3x3_bf16_persist_kernel<4, 0>"; else KF="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"; fi
   [ -d $d ] && python tools/parse_pmc.py $d profiles/${R}_metnet_${m}_pmc_conv256.json "$KF" > /dev/null
 done
+[ -s gpurun_out/${R}_pmc_dgmr_conv/${R}_dgmr_bf16_pmc_conv.json ] && cp gpurun_out/${R}_pmc_dgmr_conv/${R}_dgmr_bf16_pmc_conv.json profiles/
 [ -s gpurun_out/${R}_pmc_convlstm_cell/${R}_convlstm_bf16a_pmc_cell.json ] && cp gpurun_out/${R}_pmc_convlstm_cell/${R}_convlstm_bf16a_pmc_cell.json profiles/
 [ -s gpurun_out/${R}_cloudgan_bench.json ] && cp gpurun_out/${R}_cloudgan_bench.json profiles/${R}_cloudgan_bf16a_bench.json
 for f in stlstm_bf16a_bench stlstm_f32_bench; do [ -s gpurun_out/${R}_$f.json ] && cp gpurun_out/${R}_$f.json profiles/${R}_$f.json; done

@@ -13,6 +13,7 @@ for m in bf16a bf16; do bash tools/prof_pmc.sh ${R}_pmc_metnet_$m $m > /dev/null
 KFA="conv3x3_bf16_persist_kernel<4, 0>"; KFB="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"
 python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16a profiles/${R}_metnet_bf16a_pmc_conv256.json "$KFA" > /dev/null 2>&1
 python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16 profiles/${R}_metnet_bf16_pmc_conv256.json "$KFB" > /dev/null 2>&1
+ROUND=$R bash tools/prof_pmc_dgmr.sh ${R}_pmc_dgmr_conv > /dev/null 2>&1           # DGMR line's roofline launch
 ROUND=$R bash tools/prof_pmc_cell.sh ${R}_pmc_convlstm_cell > /dev/null 2>&1   # fused ConvLSTM cell: traffic record for the ConvLSTM line
 python bench.py --steps 20 --warmup 5 > gpurun_out/${R}_metnet_bf16a_bench_full.json 2> gpurun_out/${R}_metnet_bf16a_bench_full.err
 python bench.py --workload convlstm --steps 20 --warmup 5 > gpurun_out/${R}_convlstm_bf16a_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
