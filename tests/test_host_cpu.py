@@ -292,3 +292,25 @@ def test_weight_grad_batch_protocol():
         outs.append(x)
     with pytest.raises(RuntimeError, match="WeightGradBatch"):
         outs[1].sum().backward()
+
+
+def test_conv4x4_weight_embeddings_on_cpu():
+    """The host-side algebra of functional_gan.conv4x4_as_3x3, checked with torch's own convolutions on the CPU (no kernel involved):
+    * stride 2: pad by 1, fold 2x2 pixel blocks into channels, a 3x3 'same' convolution with ``regroup4x4s2``'s weight, first h/2 x w/2 outputs;
+    * stride 1: the 4x4 kernel as a 5x5 kernel with a zero first row / column, last output row / column dropped."""
+    import torch.nn.functional as TF
+
+    from satflow_amd import functional_gan as FG
+
+    g = torch.Generator().manual_seed(3)
+    n, C, O, h, w, cp = 2, 5, 7, 8, 10, 8
+    x, W, b = torch.randn(n, C, h, w, generator=g), torch.randn(O, C, 4, 4, generator=g), torch.randn(O, generator=g)
+    ref = TF.conv2d(x, W, b, stride=2, padding=1)
+    xp = TF.pad(TF.pad(x.permute(0, 2, 3, 1), (0, cp - C)), (0, 0, 1, 1, 1, 1))          # NHWC, lanes padded, border of 1
+    H2, W2 = h // 2 + 1, w // 2 + 1
+    ys = torch.cat([xp[:, dy:dy + 2 * H2:2, dx:dx + 2 * W2:2, :] for dy in (0, 1) for dx in (0, 1)], -1)   # what sf_pad_s2d_fwd writes
+    out = TF.conv2d(ys.permute(0, 3, 1, 2), FG.regroup4x4s2(W, cp), b, padding=1)[:, :, : h // 2, : w // 2]
+    assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    ref1 = TF.conv2d(x, W, b, stride=1, padding=1)
+    out1 = TF.conv2d(x, TF.pad(W, (1, 0, 1, 0)), b, padding=2)[:, :, : h - 1, : w - 1]
+    assert torch.allclose(out1, ref1, rtol=1e-5, atol=1e-5)
