@@ -995,6 +995,15 @@ def main(argv=None):
             out["cpu_baseline"]["gpu_speedup"] = out["value"] / out["cpu_baseline"]["value"]
         if not args.no_extra and world == 1 and args.workload == "metnet":
             out["extra"] = extra_figures(wl, dev, args, batch)
+        if not args.no_extra and world == 1 and args.workload == "convlstm":
+            # SURVEY 8(d) cfg 2: per-GPU batch 1, 8 and 16 (the line itself is the given --batch, 8 by default)
+            out["extra"] = {}
+            for b in (1, 16):
+                if b != batch:
+                    wb = ConvLSTMWorkload(dev, b, 0)
+                    el, _ = timed_steps(wb, 20, 10, 1, dev, sync)
+                    out["extra"][f"batch{b}_samples_per_s"], out["extra"][f"batch{b}_ms_per_step"] = 20 * b / el, el / 20 * 1e3
+                    del wb
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
