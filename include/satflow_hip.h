@@ -30,7 +30,8 @@
 extern "C" {
 #endif
 
-#define SF_ABI_VERSION 1
+/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word) */
+#define SF_ABI_VERSION 2
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */
@@ -384,10 +385,15 @@ int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h
                        const float* bias_packed, int32_t hidp, sfTensor hs, sfTensor gates, void* workspace,
                        size_t workspace_bytes, int32_t dtype, sfStream stream);
 /* workspace (nullable): with sf_convgru_seq_fwd_workspace_bytes(n, h, hidp) bytes (0 = not applicable) the launch may split every
- * map over TWO workgroups of 8 rows each (maps of more than 8 rows, hidp 48..64, 2n <= number of CUs - MetNet's 96 maps then use
- * 192 of the 256 CUs): after every step a workgroup hands the bf16 image of its boundary row to its partner inside the launch
- * ({epoch, value} granules, one write-through store each; the workspace is zeroed by the call).  Same arithmetic, same results.
- * Word [workspace_bytes / 8 - 2] is non-zero afterwards if a receiver gave up waiting (results invalid; it never hangs). */
+ * map over TWO workgroups of 8 rows each (maps of more than 8 rows, hidp 48..64; used when 2n <= number of CUs - MetNet's 96 maps
+ * then run on 192 of the 256 CUs): after every step a workgroup hands the bf16 image of its boundary row to its partner inside the
+ * launch ({epoch, value} granules, one write-through store each).  Same arithmetic, same results.
+ * Residency is NOT assumed: a workgroup takes a start-order ticket (ticket k = map k / 2, half k % 2), so the launch completes
+ * whenever two workgroups can be resident at a time, whatever else occupies the device (e.g. an RCCL kernel on another stream).
+ * Layout (64-bit words): [0] STICKY error word - zeroed by the CALLER when it allocates the workspace, never cleared by the
+ * library, OR-ed with 1 if a receiver gave up waiting (bounded spin: it never hangs); that workgroup's states are NaN from the
+ * failed step on, so the failure also surfaces in the loss without any host synchronisation.  [1] ticket counter and [2 ..] the
+ * granule slots are zeroed by every call (on `stream`).  A workspace serves one launch at a time. */
 size_t sf_convgru_seq_fwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
 /* The backward time loop of the same sequence in ONE launch (one workgroup per image, maps of at most 16x16, hidp 32 or 64,
  * SF_BF16 kernels, bf16-stored gates): for t = T-1 .. 0 the gate backward (as sf_convgru_bwd_gates) and the recurrent
@@ -399,8 +405,13 @@ int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor
                        const void* wpacked_t, int32_t hidp, sfTensor dgx, sfTensor dgh, void* workspace, size_t workspace_bytes,
                        int32_t dtype, sfStream stream);
 /* workspace (nullable, sf_convgru_seq_bwd_workspace_bytes(n, h, hidp) bytes, 0 = not applicable): as for sf_convgru_seq_fwd - two
- * workgroups per map of more than 8 rows (hidp 64, 2n <= number of CUs), the boundary row of dgh handed over inside the launch. */
+ * workgroups per map of more than 8 rows (hidp 64), the boundary row of dgh handed over inside the launch; same workspace layout,
+ * tickets and failure behaviour (every gradient of the failing workgroup is NaN from the failed step on). */
 size_t sf_convgru_seq_bwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
+/* Test hooks of the two-workgroup kernels (process-wide; tests/test_convgru_seq_gpu.py): polls before a receiver gives up
+ * (<= 0: the default, seconds) and a half (0 / 1, -1 = none) that never sends its boundary row - to exercise the failure path
+ * (error word + NaN results) on purpose. */
+void sf_convgru_seq_debug(int32_t spin_limit, int32_t mute_half);
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
  * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
  * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */

@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os
 SF_F32, SF_BF16 = 0, 1
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 1
+ABI_VERSION = 2  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
@@ -98,6 +98,7 @@ PROTOTYPES = {
     "sf_convgru_seq_fwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "sf_convgru_seq_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _i32, sfTensor, sfTensor, _vp, _sz, _i32, _vp]),
     "sf_convgru_seq_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
+    "sf_convgru_seq_debug": (None, [_i32, _i32]),
     "sf_convgru_bwd_gates": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
@@ -193,6 +194,53 @@ def require_device(t: torch.Tensor, name: str) -> None:
 
 
 NULL = sfTensor(None, 0, 0, 0, 0, 0)
+
+
+# ----------------------------------------------------------------------------------------------
+# Device-side error words.  Kernels that can fail at run time (today: the two-workgroup ConvGRU sequence kernels, whose
+# boundary-row hand-off has a bounded spin) OR into the STICKY first word of their workspace and poison their outputs with NaN.
+# The workspaces are allocated here, zeroed once, cached per (kind, shape, device, stream) and never handed back to the
+# allocator, so that the words can be inspected at any later time: ``device_errors()`` / ``check_device_errors()``
+# (one synchronisation; FlatAdam.step() calls the latter every ``check_errors_every`` steps).
+# ----------------------------------------------------------------------------------------------
+_WORKSPACES: dict = {}
+
+
+def sticky_workspace(kind: str, shape_key, nbytes: int, device) -> Optional[torch.Tensor]:
+    """The cached, zero-initialised int64 workspace of ``nbytes`` for kernels of ``kind`` on the current stream (None if 0)."""
+    if nbytes <= 0:
+        return None
+    key = (kind, tuple(shape_key), str(device), torch.cuda.current_stream(device).cuda_stream)
+    ws = _WORKSPACES.get(key)
+    if ws is None or ws.numel() * 8 < nbytes:
+        ws = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
+def device_errors() -> dict:
+    """{workspace key: error word} for every workspace whose sticky error word is non-zero (synchronises the device)."""
+    out = {}
+    for key, ws in _WORKSPACES.items():
+        v = int(ws[0].item())
+        if v:
+            out[key] = v
+    return out
+
+
+def check_device_errors() -> None:
+    bad = device_errors()
+    if bad:
+        raise RuntimeError(
+            "satflow_amd: a kernel reported a run-time failure (its outputs were set to NaN): "
+            + "; ".join(f"{k[0]} {k[1]} on {k[2]}: word {v:#x}" for k, v in bad.items())
+            + " - for the ConvGRU sequence kernels this means a boundary-row hand-off between the two workgroups of a map timed "
+            "out (SF_GRU_NO_SPLIT=1 selects the one-workgroup kernels)")
+
+
+def clear_device_errors() -> None:
+    for ws in _WORKSPACES.values():
+        ws[0].zero_()
 
 
 def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0, idiv: int = 0, imod: int = 0) -> sfTensor:

@@ -43,15 +43,28 @@ struct GruSeqParams {
   const void* wp; const float* bias;      // packed weights [nblk][chunks][9][96][16] bf16; bias [nblk*96] or null
   int T, n, H, W, hidp, chunks;
   unsigned long long* mbox;               // SPLIT kernel: boundary-row mailbox (see convgru_seq_fwd_kernel), zeroed before the launch
+  unsigned spin_limit; int mute_half;     // polls before a receiver gives up; test hook: this half never sends (sf_convgru_seq_debug)
 };
 
 // SPLIT: boundary-row hand-off between the two workgroups of an image.  One row of the bf16 state = chunks x 16 pixels x 2 octets x
 // 4 dwords; every dword travels as an 8-byte {tag = epoch, value} granule written by ONE write-through store - the data is the flag
 // (cdna_hip_programming.md Guideline 16, form R2): no fence, no separate flag.  Slots alternate with the epoch's parity: a sender
 // can be at most one state ahead of its receiver.
+// Workspace layout (u64 words): [0] STICKY error word (zeroed by the caller when it allocates the workspace, only ever OR-ed into by the
+// kernels, read by the host mirror: satflow_amd.device_errors()), [1] ticket counter, [2 ..] the granule slots.  Words 1.. are zeroed
+// by the library before every launch.
+// Residency: nothing is assumed.  A workgroup takes a TICKET when it starts (ticket k -> map k / 2, half k % 2), so partners are
+// always two workgroups that the hardware has actually started, in start order: the holder of the highest issued ticket K either has
+// its partner running (K odd) or waits for ticket K + 1, which the next free slot receives while every other pair keeps making
+// progress.  The launch completes whenever at least two workgroups can be resident at a time - whatever else holds CUs (an RCCL
+// kernel on the exchange stream, another process, a CU mask).  The spin is bounded anyway; a receiver that gives up sets the error
+// word AND poisons its workgroup's state with NaN, so that a failed hand-off can never pass as a result.
+constexpr int MB_HDR = 2;                                    // error word + ticket counter
 constexpr int MB_ROW = 4 * 16 * 2 * 4;                       // granules of one boundary row (4 chunks max)
-__host__ __device__ constexpr long long mbox_slot(long long img, int half, int parity) { return ((img * 2 + half) * 2 + parity) * MB_ROW; }
-constexpr unsigned MB_SPIN_LIMIT = 1u << 21;                 // polls before a receiver gives up (then: error word set, results invalid)
+__host__ __device__ constexpr long long mbox_slot(long long img, int half, int parity) { return MB_HDR + ((img * 2 + half) * 2 + parity) * MB_ROW; }
+constexpr unsigned MB_SPIN_LIMIT = 1u << 22;                 // default polls before a receiver gives up (seconds; then: error word + NaN state)
+// test hooks (sf_convgru_seq_debug): a shorter spin and a half that never sends, to exercise the failure path on purpose
+int g_spin_limit = (int)MB_SPIN_LIMIT, g_mute_half = -1;
 
 // LDS-DMA hidden from hipcc (see conv3x3_bf16.hip): wave-uniform descriptor + scalar offset + constant per-lane offset.
 __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
@@ -85,8 +98,14 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int nbk = wave >> 2;
   const int r = lane & 31, kh = lane >> 5;
-  const int img = SPLIT ? blockIdx.x >> 1 : blockIdx.x;
-  const int half = SPLIT ? blockIdx.x & 1 : 0;
+  __shared__ unsigned s_ctl[2];  // SPLIT: [0] this workgroup's ticket, [1] "a hand-off timed out"
+  if constexpr (SPLIT) {
+    if (tid == 0) { s_ctl[0] = atomicAdd(reinterpret_cast<unsigned*>(p.mbox + 1), 1u); s_ctl[1] = 0u; }
+    __syncthreads();
+  }
+  const int ticket = SPLIT ? __builtin_amdgcn_readfirstlane((int)s_ctl[0]) : (int)blockIdx.x;
+  const int img = SPLIT ? ticket >> 1 : ticket;
+  const int half = SPLIT ? ticket & 1 : 0;
   // first tile row of this wave's fragments: 4-row band wl of the map (SPLIT: band (wave & 3) >> 1 of this half, fragment wave & 1)
   const int wrow = SPLIT ? 8 * half + 4 * ((wave & 3) >> 1) + 2 * (wave & 1) : 4 * (wave & 3);
   const int chunks = p.chunks;
@@ -141,7 +160,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
           char* dst = lds_h + (ch >> 4) * CHUNK_B + (iy * HALO + ix) * PIX_B + 16 * (((ch >> 3) & 1) ^ (iy & 1));
           *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
           if constexpr (SPLIT) {
-            if (has_partner && py[mf] == send_row) {  // the partner's halo row: four {epoch, dword} granules, write-through
+            if (has_partner && py[mf] == send_row && half != p.mute_half) {  // the partner's halo row: four {epoch, dword} granules, write-through
               unsigned long long* g8 = p.mbox + mbox_slot(img, half, epoch & 1) + (ch >> 4) * 128 + px[mf] * 8 + ((ch >> 3) & 1) * 4;
               const unsigned long long tag = (unsigned long long)epoch << 32;
               __hip_atomic_store(g8 + 0, tag | sx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -174,7 +193,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
             all = all && (!need[k] || (unsigned)(x >> 32) == epoch);
           }
           if (__all(all)) break;
-          if (spins >= MB_SPIN_LIMIT) { mb_failed = 1; break; }   // wave-uniform (spins is): never hang the GPU
+          if (spins >= p.spin_limit) { mb_failed = 1; s_ctl[1] = 1u; break; }   // wave-uniform (spins is): never hang the GPU
           __builtin_amdgcn_s_sleep(2);
         }
         const int iy = recv_row + 1;
@@ -291,6 +310,12 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
           hst[mf][g][c] = sf_gru_blend(z, cand, hst[mf][g][c]);
         }
       }
+      if constexpr (SPLIT) {  // a hand-off of this workgroup timed out (flag set before one of the chunk barriers above): NaN from here on
+        if (s_ctl[1]) {
+#pragma unroll
+          for (int g = 0; g < 4; ++g) hst[mf][g] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+        }
+      }
       // SPLIT (one M fragment per wave): the new state's bf16 image - and with it the boundary row for the partner workgroup - leaves
       // BEFORE this step's outputs are stored: the hand-off's latency then runs under the stores
       if constexpr (SPLIT) write_state_tile((unsigned)t + 2u);
@@ -329,7 +354,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (SPLIT) {
-    if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox + mbox_slot(p.n, 0, 0)), 1u);  // error word behind the slots
+    if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox), 1u);  // the sticky error word
   }
 }
 
@@ -358,9 +383,10 @@ struct GruSeqBwdParams {
   const void* wp;                      // packed transposed weights [chunks = 3*hidp/16][9][hidp][16] bf16
   int T, n, H, W, hidp;
   unsigned long long* mbox;            // SPLIT kernel: boundary-row mailbox, zeroed before the launch
+  unsigned spin_limit; int mute_half;  // as in GruSeqParams
 };
 constexpr int MBB_ROW = 12 * 16 * 2 * 4;  // granules of one boundary row of dgh (3 * 64 channels = 12 K chunks)
-__host__ __device__ constexpr long long mbox_bwd_slot(long long img, int half, int parity) { return ((img * 2 + half) * 2 + parity) * MBB_ROW; }
+__host__ __device__ constexpr long long mbox_bwd_slot(long long img, int half, int parity) { return MB_HDR + ((img * 2 + half) * 2 + parity) * MBB_ROW; }
 
 constexpr int BP_CHUNK_B = (256 + 1) * PIX_B;  // 256 pixels + one zero pixel per K chunk
 
@@ -386,8 +412,14 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int r = lane & 31, kh = lane >> 5;
-  const int img = SPLIT ? blockIdx.x >> 1 : blockIdx.x;
-  const int half = SPLIT ? blockIdx.x & 1 : 0;
+  __shared__ unsigned s_ctl[2];  // SPLIT: [0] this workgroup's ticket, [1] "a hand-off timed out" (see the forward kernel)
+  if constexpr (SPLIT) {
+    if (tid == 0) { s_ctl[0] = atomicAdd(reinterpret_cast<unsigned*>(p.mbox + 1), 1u); s_ctl[1] = 0u; }
+    __syncthreads();
+  }
+  const int ticket = SPLIT ? __builtin_amdgcn_readfirstlane((int)s_ctl[0]) : (int)blockIdx.x;
+  const int img = SPLIT ? ticket >> 1 : ticket;
+  const int half = SPLIT ? ticket & 1 : 0;
   // first row of this wave's M fragment(s): band wl = wave & 3, fragments mf0 .. of it (SPLIT: band (wave & 3) >> 1 of this half, fragment wave & 1)
   const int wrow = SPLIT ? 8 * half + 4 * ((wave & 3) >> 1) + 2 * (wave & 1) : 4 * (wave & 3) + 2 * (MFW == 2 ? 0 : wave >> 2);
   const int nf0 = SPLIT ? wave >> 2 : 0;  // first channel fragment of this wave
@@ -512,7 +544,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
                   const int k = qh * HID + ch;
                   *reinterpret_cast<u32x4_t*>(lds_t + (k >> 4) * BP_CHUNK_B + (py[m] * 16 + px[m]) * PIX_B + 16 * (((ch >> 3) & 1) ^ (py[m] & 1))) = oct;
                   if constexpr (SPLIT) {
-                    if (has_partner && py[m] == send_row) {  // ... and the partner's, for its rows next to this one
+                    if (has_partner && py[m] == send_row && half != p.mute_half) {  // ... and the partner's, for its rows next to this one
                       const unsigned epoch = (unsigned)(p.T - t);
                       unsigned long long* g8 = p.mbox + mbox_bwd_slot(img, half, epoch & 1) + (k >> 4) * 128 + px[m] * 8 + ((ch >> 3) & 1) * 4;
                       const unsigned long long tag = (unsigned long long)epoch << 32;
@@ -547,7 +579,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
             all = all && (((gi >> 3) & 15) >= p.W || (unsigned)(x >> 32) == epoch);
           }
           if (__all(all)) break;
-          if (spins >= MB_SPIN_LIMIT) { mb_failed = 1; break; }
+          if (spins >= p.spin_limit) { mb_failed = 1; s_ctl[1] = 1u; break; }
           __builtin_amdgcn_s_sleep(2);
         }
 #pragma unroll
@@ -615,21 +647,29 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
           if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + ptm * p.gs_s + (nf0 + nf) * 32 + 8 * g + cq) + dd[m][nf][g];
 #pragma unroll
           for (int c = 0; c < 4; ++c) dh[m][nf][g][c] = base[c] + acc[m][nf][4 * g + c];
+          if constexpr (SPLIT) {  // a hand-off timed out (flag set before the K loop's barriers): every gradient from here on is NaN
+            if (s_ctl[1]) dh[m][nf][g] = f32x4{__builtin_nanf(""), __builtin_nanf(""), __builtin_nanf(""), __builtin_nanf("")};
+          }
         }
     }
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (SPLIT) {
-    if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox + mbox_bwd_slot(p.n, 0, 0)), 1u);
+    if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox), 1u);
   }
 }
 
 }  // namespace
 
 // mailbox of the two-workgroups-per-image kernel: 2 directions x 2 parities x one boundary row of granules per image + an error word
+extern "C" void sf_convgru_seq_debug(int32_t spin_limit, int32_t mute_half) {
+  g_spin_limit = spin_limit > 0 ? spin_limit : (int)MB_SPIN_LIMIT;
+  g_mute_half = mute_half;
+}
+
 extern "C" size_t sf_convgru_seq_fwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp) {
   if (n <= 0 || h <= 8 || hidp <= 32) return 0;
-  return (size_t)(mbox_slot(n, 0, 0) + 2) * sizeof(unsigned long long);
+  return (size_t)mbox_slot(n, 0, 0) * sizeof(unsigned long long);
 }
 
 extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n, int32_t h, int32_t w, const void* wpacked,
@@ -655,8 +695,9 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   p.T = T; p.n = n; p.H = h; p.W = w; p.hidp = hidp; p.chunks = hidp / 16;
   const int nblk = (hidp + 31) / 32;
   hipStream_t st = (hipStream_t)stream;
-  // two workgroups per image (8 rows each, boundary rows through the mailbox) when the map has more than 8 rows, both N blocks
-  // are in use and EVERY workgroup of the launch is resident at once (a receiver spins on its partner: 2n <= number of CUs)
+  // two workgroups per image (8 rows each, boundary rows through the mailbox) when the map has more than 8 rows and both N blocks
+  // are in use.  2n <= number of CUs is a SPEED heuristic only (one round of workgroups): correctness does not depend on residency,
+  // partners are assigned by start-order tickets (see the mailbox comment)
   static const bool no_split = getenv("SF_GRU_NO_SPLIT") != nullptr;
   static int cus = 0;
   if (!cus) {
@@ -666,9 +707,11 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   }
   const size_t need = sf_convgru_seq_fwd_workspace_bytes(n, h, hidp);
   const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
-  if (have_ws && hipMemsetAsync(workspace, 0, need, st) != hipSuccess) { sf_set_error("sf_convgru_seq_fwd: mailbox memset failed"); return 2; }
+  // ticket counter + granule slots; word 0 (the sticky error word) belongs to the caller
+  if (have_ws && hipMemsetAsync((char*)workspace + 8, 0, need - 8, st) != hipSuccess) { sf_set_error("sf_convgru_seq_fwd: mailbox memset failed"); return 2; }
   if (!no_split && nblk == 2 && h > 8 && 2 * n <= cus && have_ws) {
     p.mbox = (unsigned long long*)workspace;
+    p.spin_limit = (unsigned)g_spin_limit; p.mute_half = g_mute_half;
     if (p.gx_bf) hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, true, true>), dim3(2 * n), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, false, true>), dim3(2 * n), dim3(512), 0, st, p);
     SF_CHECK_LAUNCH("convgru_seq_fwd (split)");
@@ -684,7 +727,7 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
 
 extern "C" size_t sf_convgru_seq_bwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp) {
   if (n <= 0 || h <= 8 || hidp != 64) return 0;
-  return (size_t)(mbox_bwd_slot(n, 0, 0) + 2) * sizeof(unsigned long long);
+  return (size_t)mbox_bwd_slot(n, 0, 0) * sizeof(unsigned long long);
 }
 
 extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor hs, int32_t T, int32_t n, int32_t h, int32_t w,
@@ -722,9 +765,10 @@ extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gate
   }
   const size_t need = sf_convgru_seq_bwd_workspace_bytes(n, h, hidp);
   const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
-  if (have_ws && hipMemsetAsync(workspace, 0, need, st) != hipSuccess) { sf_set_error("sf_convgru_seq_bwd: mailbox memset failed"); return 2; }
+  if (have_ws && hipMemsetAsync((char*)workspace + 8, 0, need - 8, st) != hipSuccess) { sf_set_error("sf_convgru_seq_bwd: mailbox memset failed"); return 2; }
   if (!no_split && hidp == 64 && h > 8 && 2 * n <= cus && have_ws) {  // two workgroups per map (see sf_convgru_seq_fwd)
     p.mbox = (unsigned long long*)workspace;
+    p.spin_limit = (unsigned)g_spin_limit; p.mute_half = g_mute_half;
     hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1, true>), dim3(2 * n), dim3(512), 0, st, p);
     SF_CHECK_LAUNCH("convgru_seq_bwd (split)");
     return 0;

@@ -451,10 +451,11 @@ def convgru_seq_supported(h: int, w: int, hidp: int) -> bool:
 def convgru_seq_fwd(gx: Tensor, h0: Optional[Tensor], Tn: int, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor], hidp: int,
                     hs: Tensor, gates: Optional[Tensor]) -> Optional[Tensor]:
     """All Tn recurrent steps in one launch (sf_convgru_seq_fwd): gx ``[Tn*n,h,w,3*hidp]``, hs ``[Tn,n,h,w,hidp]``.
-    With a workspace the library may split every map over two workgroups (boundary rows exchanged inside the launch); ``check_split``
-    (tests) reads the workspace's error word back."""
+    With a workspace the library may split every map over two workgroups (boundary rows exchanged inside the launch).  The
+    workspace is the cached one of ``_hip.sticky_workspace``: its first word is the sticky error word that
+    ``satflow_amd.check_device_errors()`` reads."""
     nbytes = int(lib().sf_convgru_seq_fwd_workspace_bytes(n, h, hidp))
-    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=gx.device) if nbytes else None
+    ws = _hip.sticky_workspace("convgru_seq_fwd", (n, h, hidp), nbytes, gx.device)
     check(lib().sf_convgru_seq_fwd(T(gx), T(h0, hidp), Tn, n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None,
                                    hidp, T(hs), T(gates) if gates is not None else NULL, ws.data_ptr() if ws is not None else None, nbytes,
                                    _hip.compute_dtype(), stream_ptr()), "sf_convgru_seq_fwd")
@@ -468,10 +469,10 @@ def convgru_seq_bwd_supported(h: int, w: int, hidp: int, gates: Tensor) -> bool:
 
 def convgru_seq_bwd(g_seq: Optional[Tensor], g_last: Optional[Tensor], gates: Tensor, hs: Tensor, Tn: int, n: int, h: int, w: int,
                     packed_t: Tensor, hidp: int, dgx: Tensor, dgh: Tensor) -> Optional[Tensor]:
-    """The whole backward time loop in one launch (sf_convgru_seq_bwd); returns the split kernel's workspace (its error word is read by
-    the tests) or None."""
+    """The whole backward time loop in one launch (sf_convgru_seq_bwd); returns the split kernel's workspace (first word = sticky
+    error word, see ``convgru_seq_fwd``) or None."""
     nbytes = int(lib().sf_convgru_seq_bwd_workspace_bytes(n, h, hidp))
-    ws = torch.empty(nbytes // 8, dtype=torch.int64, device=gates.device) if nbytes else None
+    ws = _hip.sticky_workspace("convgru_seq_bwd", (n, h, hidp), nbytes, gates.device)
     check(lib().sf_convgru_seq_bwd(T(g_seq, hidp), T(g_last, hidp), T(gates), T(hs), Tn, n, h, w, packed_t.data_ptr(), hidp, T(dgx), T(dgh),
                                    ws.data_ptr() if ws is not None else None, nbytes, _hip.SF_BF16, stream_ptr()), "sf_convgru_seq_bwd")
     return ws

@@ -14,7 +14,7 @@ from typing import Iterable, List, Optional
 import torch
 import torch.distributed as dist
 
-from ._hip import bump_generation, check, lib, stream_ptr
+from ._hip import bump_generation, check, check_device_errors, lib, stream_ptr
 
 
 def _round_up(n: int, k: int) -> int:
@@ -36,7 +36,8 @@ class FlatAdam(torch.optim.Optimizer):
 
     def __init__(self, params: Iterable[torch.nn.Parameter], lr: float = 1e-3, betas=(0.9, 0.999), eps: float = 1e-8,
                  process_group: Optional["dist.ProcessGroup"] = None, distributed: Optional[bool] = None,
-                 overlap: bool = False, buckets: int = 3, buffers: Optional[Iterable[torch.Tensor]] = None) -> None:
+                 overlap: bool = False, buckets: int = 3, buffers: Optional[Iterable[torch.Tensor]] = None,
+                 check_errors_every: int = 100) -> None:
         self.params: List[torch.nn.Parameter] = [p for p in params if p.requires_grad]
         assert self.params, "no parameters"
         dev = self.params[0].device
@@ -57,6 +58,9 @@ class FlatAdam(torch.optim.Optimizer):
             p.data = self.flat_p[off : off + n].view(p.shape)
             p.grad = self.flat_g[off : off + n].view(p.shape)
         self.t = 0
+        # every `check_errors_every` steps (0 = never) step() reads the kernels' sticky error words (one synchronisation:
+        # _hip.check_device_errors) and raises - a failed in-launch hand-off has already turned the loss into NaN by then
+        self.check_errors_every = int(check_errors_every)
         self.group = process_group
         self.distributed = dist.is_available() and dist.is_initialized() if distributed is None else distributed
         self.world = dist.get_world_size(process_group) if self.distributed else 1
@@ -222,3 +226,5 @@ class FlatAdam(torch.optim.Optimizer):
         )
         # the update went through raw pointers: invalidate the packed-weight caches explicitly
         bump_generation()
+        if self.check_errors_every > 0 and self.t % self.check_errors_every == 0 and not torch.cuda.is_current_stream_capturing():
+            check_device_errors()

@@ -44,7 +44,7 @@ def test_persistent_sequence_matches_per_step_kernel(device, bf16_mode, Tn, n, H
         ws = K.convgru_seq_fwd(gx, h0, Tn, n, H, W, packed, bp, hidp, hs, gates)
         if ws is not None:  # the two-workgroups-per-map kernel ran (H > 8, hidp > 32): no receiver gave up on its partner's boundary row
             torch.cuda.synchronize()
-            assert int(ws[-2]) == 0, "split kernel: a boundary-row hand-off timed out"
+            assert int(ws[0]) == 0, "split kernel: a boundary-row hand-off timed out"
         # reference: one launch per step on the fp32 widening of the same x-part
         gxf = gx.float().view(Tn, n, H, W, 3 * hidp)
         hs_ref = torch.zeros(Tn, n, H, W, hidp, device=device)
@@ -121,7 +121,7 @@ def test_persistent_backward_matches_per_step_kernels(device, bf16_mode, Tn, n, 
     ws = K.convgru_seq_bwd(g_seq, g_last, gates, hs, Tn, n, H, W, packed_t, hidp, dgx, dgh)
     if ws is not None:  # the two-workgroups-per-map kernel ran: no receiver gave up on its partner's boundary row
         torch.cuda.synchronize()
-        assert int(ws[-2]) == 0, "split kernel: a boundary-row hand-off timed out"
+        assert int(ws[0]) == 0, "split kernel: a boundary-row hand-off timed out"
     # reference: the per-step kernels
     rgx, rgh = torch.zeros_like(dgx), torch.zeros_like(dgh)
     direct = torch.empty(n, H, W, hidp, device=device)
@@ -214,3 +214,116 @@ def test_persistent_sequence_kernels_against_oracle(device, mode, B, T, cin, hid
         e = rel_l2(p_.grad, P[f"rnn.{k}"].grad)
         print(f"   {mode}: d{k} rel L2 {e:.2e}")
         assert e < (6e-3 if tight else 3e-2), (k, e)
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The two-workgroups-per-map kernels when the launch does NOT own the GPU: partners are assigned by
+# start-order tickets, so nothing depends on every workgroup being resident.  A parked kernel holds most CUs on a second
+# stream (what an RCCL kernel under FlatAdam(overlap=True), another process or a CU mask do) while the sequence kernels run.
+# ----------------------------------------------------------------------------------------------------------------------
+def _seq_problem(device, Tn, n, H, W, hid, seed=5):
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import cpad
+    from satflow_amd.functional import GRUEngine
+
+    g = torch.Generator().manual_seed(seed)
+    hidp = cpad(hid)
+    eng = GRUEngine(16, hid)
+    Wh = (torch.randn(3 * hid, hid, 3, 3, generator=g) * (0.6 / hid**0.5)).to(device)
+    bh = torch.cat((torch.zeros(2 * hid), torch.randn(hid, generator=g) * 0.3)).to(device)
+    packed, bp = K.pack_weights(Wh, bh, eng.h_fwd, False)
+    packed_t = K.pack_weights(Wh, None, eng.h_bwd, True)[0]
+    gx = torch.randn(Tn * n, H, W, 3 * hidp, generator=g).to(device).to(torch.bfloat16)
+    g_seq = torch.randn(Tn, n, H, W, hidp, generator=g).to(device)
+    return dict(eng=eng, hidp=hidp, packed=packed, bp=bp, packed_t=packed_t, gx=gx, g_seq=g_seq)
+
+
+def _run_seq(device, pr, Tn, n, H, W):
+    from satflow_amd import kernels as K
+
+    hidp = pr["hidp"]
+    hs = torch.full((Tn, n, H, W, hidp), float("nan"), device=device)
+    gates = torch.full((Tn, n, H, W, 4 * hidp), float("nan"), device=device).to(torch.bfloat16)
+    dgx = torch.full((Tn, n, H, W, 3 * hidp), float("nan"), device=device).to(torch.bfloat16)
+    dgh = torch.full_like(dgx, float("nan"))
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    wf = K.convgru_seq_fwd(pr["gx"], None, Tn, n, H, W, pr["packed"], pr["bp"], hidp, hs, gates)
+    wb = K.convgru_seq_bwd(pr["g_seq"], None, gates, hs, Tn, n, H, W, pr["packed_t"], hidp, dgx, dgh)
+    e1.record()
+    return hs, gates, dgx, dgh, wf, wb, (e0, e1)
+
+
+@pytest.mark.parametrize("parked,n", [(96, 96), (200, 96), (250, 96), (200, 128)])
+def test_split_kernels_with_most_cus_held_by_another_stream(device, bf16_mode, parked, n):
+    """n = 96 / 128 maps (192 / 256 workgroups of 152 KB LDS: one per CU) while `parked` CUs are held by a kernel on another
+    stream for 20 ms: results bit-identical to the undisturbed run, error words clear, and the sequence kernels really ran
+    NEXT TO the parked kernel (they finish long before it does unless fewer than ~8 CUs are left)."""
+    from tests import native
+
+    Tn, H, W, hid = 24, 16, 16, 64
+    pr = _seq_problem(device, Tn, n, H, W, hid)
+    satflow_amd.clear_device_errors()
+    ref = _run_seq(device, pr, Tn, n, H, W)
+    torch.cuda.synchronize()
+    assert ref[4] is not None and ref[5] is not None, "the two-workgroup kernels did not run"
+    assert not satflow_amd.device_errors()
+    t_free = ref[6][0].elapsed_time(ref[6][1])
+
+    side = torch.cuda.Stream(device)
+    census = torch.zeros(parked, dtype=torch.int32, device=device)
+    torch.cuda.synchronize()
+    park_us = 20000
+    p0, p1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    with torch.cuda.stream(side):
+        p0.record()
+        native.occupy_cus(parked, 96 * 1024, park_us, side, census)
+        p1.record()
+    import time
+    time.sleep(0.002)  # the parked workgroups are on their CUs before the sequence kernels are enqueued
+    got = _run_seq(device, pr, Tn, n, H, W)
+    torch.cuda.synchronize()
+    t_busy, t_park = got[6][0].elapsed_time(got[6][1]), p0.elapsed_time(p1)
+    cus_held = len(set(int(v) >> 6 for v in census.tolist()))  # HW_ID without the wave / SIMD bits, per XCC
+    print(f"   parked {parked} workgroups on {cus_held} CUs for {t_park:.1f} ms; sequence kernels {t_free:.2f} ms alone, {t_busy:.2f} ms beside them")
+    assert not satflow_amd.device_errors(), satflow_amd.device_errors()
+    for name, a, b in zip(("hs", "gates", "dgx", "dgh"), got[:4], ref[:4]):
+        assert torch.isfinite(a.float()).all(), name
+        assert torch.equal(a, b), f"{name} differs next to a parked kernel"
+    assert t_park >= 0.9 * park_us / 1000
+    if parked <= 200:  # >= 56 CUs left: the sequence kernels complete while the other kernel is still parked
+        assert t_busy < 0.75 * t_park, (t_busy, t_park)
+
+
+def test_split_kernel_failed_handoff_is_loud(device, bf16_mode):
+    """A boundary row that never arrives (test hook: half 1 never sends; spin bound lowered to milliseconds): the kernel does not
+    hang, sets the sticky error word, and every state / gradient of the starved workgroups is NaN - the product path
+    (`check_device_errors`, called by FlatAdam.step) raises."""
+    from satflow_amd._hip import lib
+
+    Tn, n, H, W, hid = 6, 8, 16, 16, 64
+    pr = _seq_problem(device, Tn, n, H, W, hid)
+    satflow_amd.clear_device_errors()
+    good = _run_seq(device, pr, Tn, n, H, W)
+    torch.cuda.synchronize()
+    assert not satflow_amd.device_errors()
+    lib().sf_convgru_seq_debug(2000, 1)
+    try:
+        bad = _run_seq(device, pr, Tn, n, H, W)
+        torch.cuda.synchronize()
+    finally:
+        lib().sf_convgru_seq_debug(0, -1)
+    errs = satflow_amd.device_errors()
+    assert len(errs) == 2 and all(k[0].startswith("convgru_seq_") for k in errs), errs
+    hs, dgx = bad[0], bad[2]
+    assert torch.isnan(hs[-1, :, :8]).all(), "the starved halves' last states must be NaN"   # rows 0..7 = half 0, which never received
+    assert torch.isnan(hs[-1]).any(dim=(1, 2, 3)).all(), "every map must carry the failure"
+    assert torch.isnan(dgx.float()[0]).any(dim=(1, 2, 3)).all()
+    with pytest.raises(RuntimeError, match="hand-off"):
+        satflow_amd.check_device_errors()
+    satflow_amd.clear_device_errors()
+    again = _run_seq(device, pr, Tn, n, H, W)
+    torch.cuda.synchronize()
+    assert not satflow_amd.device_errors()
+    for a, b in zip(again[:4], good[:4]):
+        assert torch.equal(a, b)
