@@ -272,6 +272,7 @@ int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p0, int nf, int nblk, 
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int grid = items < cus ? items : cus;
+  if (sf_conv_bf16_persist4_ok(p, nf)) return sf_launch_conv_bf16_persist4(p, nblk, st);  // one wave per SIMD (conv3x3_bf16_persist4.hip)
   if (p.stats) return launch_mode<PM_STATS>(p, nf, nblk, items, grid, st);
   return launch_mode<PM_TR>(p, nf, nblk, items, grid, st);
 }

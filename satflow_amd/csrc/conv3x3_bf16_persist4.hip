@@ -1,0 +1,382 @@
+// ONE-WAVE-PER-SIMD persistent bf16 3x3 convolution (round 4): the MetNet encoder's large launches (conv2 / conv3 / conv4 forward,
+// 256 -> 256 @32x32 x 2304 images and alike) on four 512-register waves per CU instead of eight 256-register ones.
+//
+// Why: in the 8-wave kernels every wave owns 2 pixel x 4 channel fragments (8 MFMAs per 6 fragment
+// reads) and the two waves of a SIMD run the same mixed stream - MFMAs, LDS reads, LDS-DMA issue, chunk barrier - so whenever both
+// are not issuing MFMAs the matrix pipe idles (measured: pipe busy ~61 %), and between two items nothing covers the epilogue.  Here
+//   * a wave owns 4 pixel x 4 channel fragments (256 accumulator registers): 16 MFMAs per 8 fragment reads, 0.5 reads per MFMA
+//     instead of 0.75, and the single wave of a SIMD issues its MFMAs back to back with at most a few other instructions per gap;
+//   * NOTHING in the K loop waits: the weights stream through a THREE-stage LDS ring (the DMA of chunk g + 2 is issued in the
+//     middle of chunk g, behind the only barrier of the chunk, which is also where every wave has waited - counted `vmcnt` - for
+//     its own pieces of chunk g + 1); the input halo rows are PRIVATE to the wave that reads them (10 rows of 18 pixels, two
+//     stages; 2 of 10 rows are fetched twice) so they need no barrier at all, only the issuing wave's own counted wait; the first
+//     tap's fragments of chunk g + 1 are read during the last tap of chunk g;
+//   * the EPILOGUE OF ITEM k RUNS INSIDE THE FIRST TAP OF ITEM k + 1: fragment by fragment the accumulators are rounded, paired
+//     (`v_permlane32_swap`) and stored as 16-byte channel octets - through a buffer descriptor with out-of-range offsets for
+//     pixels / channels outside the tensor, so that every wave issues exactly 32 stores per item and the counted waits stay exact -
+//     and the fragment's first MFMA of the next item is issued right behind them with the folded-BatchNorm bias (from an LDS copy
+//     of the 9-class table, DMA-fetched two chunks ahead) as its C operand.  The stores drain under the following taps' MFMAs;
+//     no `vmcnt(0)` anywhere between the prologue and the last item.
+// Same arithmetic as conv3x3_bf16_kernel<8, 4, EPI_LINEAR, false, true>: same products, same K order (chunks ascending, taps
+// ascending), accumulators started at the border-class bias: results are bit-identical (tests/test_conv_persist_gpu.py).
+// Scope: NF = 4 (128-channel N blocks), at least 3 K chunks, ONE bf16-stored source without image remap, bf16-stored output, linear
+// epilogue with no per-channel bias (plain, or grouped weights + border-class bias table = the folded BatchNorm).
+#include <cstdlib>
+#include <type_traits>
+
+#include "conv_common.h"
+
+namespace {
+
+using namespace sfconv;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2_t __attribute__((ext_vector_type(2)));
+
+constexpr int HALO_W = TILE_W + 2;  // 18
+constexpr int PIX_B = 32;
+constexpr unsigned DMA_SENT = 0x80000000u;  // >= any descriptor's num_records
+
+// LDS-DMA hidden from hipcc (conv3x3_bf16.hip explains why).  M0 is declared clobbered instead of being saved and restored around every
+// piece: this kernel issues ~15 pieces per 144 MFMAs from the only wave of its SIMD, every scalar instruction next to them counts.
+__device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
+               : : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");  // (M0 is not declared: hipcc treats it as reserved and never keeps a value in it across statements here)
+}
+__device__ __forceinline__ void* uniform_ptr(const void* q) {  // inline asm "s" operands are not legalised
+  const uintptr_t v = (uintptr_t)q;
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+  return (void*)(((uintptr_t)hi << 32) | lo);
+}
+__device__ __forceinline__ unsigned pk2(float a, float b) {
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f32x2_t{a, b}, bf16x2_t));
+}
+// One accumulator element AGPR -> VGPR.  As an asm operand constrained to "a" the accumulators stay in the AGPR half through the
+// loop-header phis; read by plain VALU code hipcc gives the PHIS the VGPR class and copies all 256 accumulators across at every
+// loop header (264 v_accvgpr_read + 75 spilled registers, scratch reloads - and their vmcnt(0) - inside the chunk loop).
+__device__ __forceinline__ float acc_read(float x) {
+  float v;
+  asm("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(x));
+  return v;
+}
+#define SF_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+
+constexpr int NF = 4, MFR = 4, NB = 32 * NF;         // fragments per wave: 4 pixel x 4 channel; 128-channel N block
+constexpr int W_B = 9 * NB * PIX_B;                   // 36864: one weight chunk
+constexpr int WST = 3;                                // weight ring stages
+constexpr int PROWS = 10;                             // private halo rows per wave: 8 + 2
+constexpr int PIN_B = PROWS * HALO_W * PIX_B;         // 5760 per wave and stage
+constexpr int PPIECES = PROWS * HALO_W * 2;           // 360 16-byte pieces
+constexpr int NPJ = (PPIECES + 63) / 64;              // 6 DMA instructions per wave and chunk
+constexpr int TAB_B = 10 * NB * 4;                    // border-class bias table: 9 classes (+ 1 row of padding) x 128 fp32
+constexpr int IN0 = WST * W_B, TAB0 = IN0 + 4 * 2 * PIN_B;
+
+template <int MODE>
+__global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const ConvParams p, const int items, const int nblk) {
+  __shared__ __attribute__((aligned(1024))) char lds[TAB0 + TAB_B];  // 110592 + 46080 + 5120 = 161792 of 163840
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int r = lane & 31, kh = lane >> 5;
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  const int nch = p.c0 / KC;
+  const int tiles_total = items / nblk;
+  const bool xcd_order = tiles_total % 8 == 0 && nblk > 1;  // the N blocks of a tile on ONE XCD (conv3x3_bf16.hip)
+  const int grid = gridDim.x;
+  const int K = (items - (int)blockIdx.x + grid - 1) / grid;  // items of this workgroup (the launcher keeps grid <= items)
+
+  // ---- work items: a handful of scalars (everything else is derived where it is used) + the per-lane input offsets ----
+  struct Item {
+    int valid, n, grp, nb, x0, y0;
+    unsigned in_mask;  // per lane: bit j = input piece j of this lane lies inside the image
+  };
+  // per-lane byte offsets of the six input pieces relative to the wave's halo origin (the same for every item; validity is the item's mask)
+  unsigned in_base_off[NPJ];
+#pragma unroll
+  for (int j = 0; j < NPJ; ++j) {
+    const int pc = lane + j * 64, pix = pc >> 1;
+    const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+    const int half = (pc & 1) ^ (iy & 1);  // the DMA writes lane-linearly: physical half pc & 1 holds the logical half (bank swizzle)
+    in_base_off[j] = (unsigned)(((iy * p.W + ix) * p.s0 + 8 * half) * 2);
+  }
+  auto setup = [&](int k, Item& it) __attribute__((always_inline)) {
+    it.valid = k < K;
+    const int w = it.valid ? (int)blockIdx.x + k * grid : (int)blockIdx.x;  // past the end: some valid item (its descriptors get 0 records)
+    int tile;
+    if (xcd_order) { const int xcd = w & 7, j = w >> 3; tile = (j / nblk) * 8 + xcd; it.nb = j % nblk; }
+    else { tile = w % tiles_total; it.nb = w / tiles_total; }
+    const int tx = tile % p.tiles_x; tile /= p.tiles_x;
+    const int ty = tile % p.tiles_y;
+    it.n = tile / p.tiles_y;
+    it.grp = p.wgroup ? it.n / p.wgroup : 0;
+    it.x0 = tx * TILE_W; it.y0 = ty * 32;
+    int l = lane;
+    asm volatile("" : "+v"(l));  // recomputed per call: hoisted out of the loops these per-lane pixel coordinates are 18 live-through (spilled) registers
+    unsigned m = 0;
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) {
+      const int pc = l + j * 64, pix = pc >> 1;
+      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int gy = it.y0 + 8 * wave + iy - 1, gx = it.x0 + ix - 1;
+      const bool ok = pc < PPIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+      m |= ok ? 1u << j : 0u;
+    }
+    it.in_mask = m;
+  };
+  const int pxb = 2 * p.s0;
+  const int in_bytes = __builtin_amdgcn_readfirstlane((int)((long long)pxb * ((long long)p.H * p.W + 2 * (p.W + 1))));
+  const int w_bytes = __builtin_amdgcn_readfirstlane(p.chunks_total * W_B);
+  const int tab_bytes = __builtin_amdgcn_readfirstlane(p.bias_tab ? 9 * p.np * 4 : 0);
+  const int out_bytes = __builtin_amdgcn_readfirstlane(p.H * p.W * p.out_s * 2);
+  const long long img_in = (long long)p.H * p.W * pxb, lead_in = (long long)(p.W + 1) * pxb;
+
+  // descriptors (wave-uniform by construction; `valid` = 0 gives 0 records: every piece is zero-filled, nothing is read)
+  auto rs_input = [&](const Item& it) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.src0 + it.n * img_in - lead_in), 0, __builtin_amdgcn_readfirstlane(it.valid ? in_bytes : 0), 0x00020000);
+  };
+  auto rs_weights = [&](const Item& it) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.wp + (long long)it.grp * p.wgroup_bytes + (size_t)it.nb * p.chunks_total * W_B), 0,
+                                             __builtin_amdgcn_readfirstlane(it.valid ? w_bytes : 0), 0x00020000);
+  };
+  auto rs_table = [&](const Item& it) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)(p.bias_tab + (size_t)it.grp * 9 * p.np + it.nb * NB)), 0,
+                                             __builtin_amdgcn_readfirstlane(it.valid ? tab_bytes : 0), 0x00020000);
+  };
+  auto rs_output = [&](int n) __attribute__((always_inline)) {
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.out + (size_t)n * p.H * p.W * p.out_s * 2), 0, out_bytes, 0x00020000);
+  };
+  // one input piece (j: 0..5) of chunk ci of item `it` into this wave's private stage
+  auto dma_in = [&](const Item& it, __amdgpu_buffer_rsrc_t rs, int ci, int stage, int j) __attribute__((always_inline)) {
+    const unsigned dst = lds0 + (unsigned)(IN0 + (wave * 2 + stage) * PIN_B + j * 1024);
+    const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((it.y0 + 8 * wave) * p.W + it.x0) * pxb + ci * KC * 2));
+    if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16((it.in_mask >> j) & 1u ? in_base_off[j] : DMA_SENT, rs, so, dst);  // the last instruction: 40 lanes (the rest is masked off)
+  };
+  // one weight piece (i: 0..8 -> 1 KiB piece wave + 4 i) of chunk ci
+  auto dma_w = [&](__amdgpu_buffer_rsrc_t rs, int ci, int stage, int i) __attribute__((always_inline)) {
+    const int pc = wave + 4 * i;
+    bufdma16(lane * 16, rs, __builtin_amdgcn_readfirstlane((unsigned)(ci * W_B + pc * 1024)), lds0 + (unsigned)(stage * W_B + pc * 1024));
+  };
+  // the bias table of item `it`: two pieces per wave (1 KiB = two classes; pieces past the table repeat piece 4 = {class 8, class 8})
+  auto dma_tab = [&](__amdgpu_buffer_rsrc_t rs, int i) __attribute__((always_inline)) {
+    int pp = wave + 4 * i; pp = pp < 4 ? pp : 4;
+    int cls = 2 * pp + (lane >> 5); cls = cls < 8 ? cls : 8;
+    bufdma16((unsigned)(cls * p.np * 4 + (lane & 31) * 16), rs, 0u, lds0 + (unsigned)(TAB0 + pp * 1024));
+  };
+
+  // ---- per-lane constants of the fragment reads (as conv3x3_bf16.hip; the halo rows are wave-local) ----
+  const int rowpar = (r >> 4) & 1;
+  const int a_lane = ((r >> 4) * HALO_W + (r & 15)) * PIX_B;
+  const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);
+  const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
+  auto load_tap = [&](int sw, int si, int tap, bf16x8 (&a)[MFR], bf16x8 (&b)[NF]) __attribute__((always_inline)) {
+    const int ky = tap / 3, kx = tap % 3;
+    const char* inb = lds + IN0 + (wave * 2 + si) * PIN_B + a_lane;
+    const char* wb = lds + sw * W_B + b_lane;
+#pragma unroll
+    for (int mf = 0; mf < MFR; ++mf)
+      a[mf] = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO_W + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
+  };
+
+  // ---- epilogue of one fragment: 32 channels x this lane's pixel -> two 16-byte stores (always issued) ----
+  auto epi_frag = [&](const f32x16& a, __amdgpu_buffer_rsrc_t rs_out, unsigned voff, int nb_item, int nf) __attribute__((always_inline)) {
+    const int cb = nb_item * NB + nf * 32;
+#pragma unroll
+    for (int g = 0; g < 4; g += 2) {
+      // (+ 0.f: the one-item kernel adds a zero bias here, which turns -0 into +0)
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) v[i] = acc_read(a[4 * g + i]) + 0.f;
+      const unsigned ax = pk2(v[0], v[1]), ay = pk2(v[2], v[3]);
+      const unsigned bx = pk2(v[4], v[5]), by = pk2(v[6], v[7]);
+      const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+      const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+      // the octet's position goes into the SCALAR offset (an out-of-range one past out_c: voff + soff never wraps back into range)
+      const unsigned soff = cb + 8 * g < p.out_c ? (unsigned)((nf * 32 + 8 * g) * 2) : 0x40000000u;
+      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{sx[0], sy[0], sx[1], sy[1]}, rs_out, voff, soff, 0);
+    }
+  };
+  // byte offset of this lane's pixel of fragment mf inside the item's output image (+ this N block's first octet), or the sentinel
+  auto out_voff = [&](const Item& it, int mf) __attribute__((always_inline)) -> unsigned {
+    const int py = it.y0 + 8 * wave + 2 * mf + (r >> 4), px = it.x0 + (r & 15);
+    return (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * kh) * 2) : DMA_SENT;
+  };
+
+  Item cur, nxt;
+  setup(0, cur);
+  nxt = cur; nxt.valid = 0;  // (set up for real inside the first chunk)
+
+  // ---- prologue: chunks 0 and 1 of the weights, chunk 0 of the input, the first bias table ----
+  {
+    const __amdgpu_buffer_rsrc_t rw = rs_weights(cur), ri = rs_input(cur), rt = rs_table(cur);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dma_w(rw, 0, 0, i);
+#pragma unroll
+    for (int i = 0; i < 9; ++i) dma_w(rw, 1, 1, i);
+#pragma unroll
+    for (int j = 0; j < NPJ; ++j) dma_in(cur, ri, 0, 0, j);
+    dma_tab(rt, 0); dma_tab(rt, 1);
+  }
+  SF_VMCNT(0);
+  __builtin_amdgcn_s_barrier();
+
+  f32x16 acc[MFR][NF];
+  // accumulators of an item START at the border-class bias of each lane's pixel (the folded BatchNorm; zeros without a table), read from the LDS copy
+  auto init_acc = [&](const Item& it) __attribute__((always_inline)) {
+#pragma unroll
+    for (int mf = 0; mf < MFR; ++mf) {
+      const int cls = border_cls(it.y0 + 8 * wave + 2 * mf + (r >> 4), it.x0 + (r & 15), p.H, p.W);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        const char* t = lds + TAB0 + cls * (NB * 4) + (nf * 32 + 4 * kh) * 4;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const f32x4 b = *reinterpret_cast<const f32x4*>(t + q * 32);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) acc[mf][nf][4 * q + c] = b[c];
+        }
+      }
+    }
+  };
+  auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t rs_out = rs_output(it.n);
+#pragma unroll
+    for (int mf = 0; mf < MFR; ++mf) {
+      const unsigned voff = out_voff(it, mf);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        epi_frag(acc[mf][nf], rs_out, voff, it.nb, nf);
+        __builtin_amdgcn_sched_barrier(0);  // (one fragment's temporaries at a time)
+      }
+    }
+  };
+  init_acc(cur);
+
+  // fragment sets rotate modulo 3 (tap t uses set t % 3, the next tap's operands are read into set (t + 1) % 3): nine taps per chunk, so the
+  // rotation is the same in every chunk and the next chunk's first tap lands in set 0; only two sets are live at any time
+  bf16x8 fa[3][MFR], fb[3][NF];
+  load_tap(0, 0, 0, fa[0], fb[0]);
+
+  int sw = 0;    // weight ring stage of the current chunk
+  int gpar = 0;  // parity of the chunk counter: the private input stage
+  // K >= 1 items of nch >= 3 chunks (the launcher's contract; do-while loops: no empty-loop join points for the 256 accumulators)
+  int k = 0;
+  do {
+    int ci = 0;
+    do {
+      const bool first = ci == 0;  // the previous item's 32 epilogue stores are in flight
+      const bool last = ci + 1 == nch, last2 = ci + 2 >= nch;
+      const int sw1 = sw == 2 ? 0 : sw + 1, sw2 = sw == 0 ? 2 : sw - 1;  // stages of chunks g + 1, g + 2
+      const int si = gpar, si1 = gpar ^ 1;
+      // everything the chunk's 15 DMA pieces need, computed ONCE here (scalar code in front of the first tap's MFMAs, which the scheduler
+      // spreads between them): descriptors, scalar offsets, LDS destinations; a piece is then `s_mov m0` + the load, issued BETWEEN two MFMAs
+      const Item& it1 = last ? nxt : cur;
+      const Item& it2 = last2 ? nxt : cur;
+      const __amdgpu_buffer_rsrc_t ri = rs_input(it1);
+      const __amdgpu_buffer_rsrc_t rw = rs_weights(it2);
+      const unsigned so_in = __builtin_amdgcn_readfirstlane((unsigned)(((it1.y0 + 8 * wave) * p.W + it1.x0) * pxb + (last ? 0 : ci + 1) * KC * 2));
+      const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((last2 ? ci + 2 - nch : ci + 2) * W_B + wave * 1024));
+      const unsigned dst_in = lds0 + (unsigned)(IN0 + (wave * 2 + si1) * PIN_B);
+      const unsigned dst_w = lds0 + (unsigned)(sw2 * W_B + wave * 1024);
+      const unsigned m1 = it1.in_mask;
+      auto piece_in = [&](int j) __attribute__((always_inline)) {
+        const unsigned voff = (m1 >> j) & 1u ? in_base_off[j] : DMA_SENT;
+        if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16(voff, ri, so_in, dst_in + j * 1024);  // the last instruction: 40 lanes
+      };
+      auto piece_w = [&](int i) __attribute__((always_inline)) { bufdma16(lane * 16, rw, so_w + i * 4096, dst_w + i * 4096); };
+
+#pragma unroll
+      for (int tap = 0; tap < 9; ++tap) {
+        if (tap == 8) {
+          // this wave's input pieces of chunk g + 1 have landed: everything younger (the 9 weight pieces of chunk g + 2 and, in the second-to-last
+          // chunk of an item, the two table pieces behind them) may stay in flight
+          if (ci + 2 == nch) SF_VMCNT(11); else SF_VMCNT(9);
+          __builtin_amdgcn_sched_barrier(0);
+          load_tap(sw1, si1, 0, fa[0], fb[0]);  // first tap of the next chunk
+        } else {
+          load_tap(sw, si, tap + 1, fa[(tap + 1) % 3], fb[(tap + 1) % 3]);
+        }
+        // MFMAs 0 .. 7 with one fragment read behind each | DMA piece | MFMAs 8 .. 11 | DMA piece | MFMAs 12 .. 15
+        auto mfmas = [&](int lo, int hi) __attribute__((always_inline)) {
+#pragma unroll
+          for (int f = lo; f < hi; ++f) {
+            const int mf = f / NF, nf = f % NF;
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap % 3][nf], fa[tap % 3][mf], acc[mf][nf], 0, 0, 0);
+          }
+        };
+        mfmas(0, 8);
+#pragma unroll
+        for (int q = 0; q < MFR + NF; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        // taps 0 .. 2: input of chunk g + 1 (other private stage); taps 3 .. 7: weights of chunk g + 2 (stage sw2, free behind the rendezvous)
+        if (tap < 3) piece_in(2 * tap); else if (tap < 8) piece_w(2 * (tap - 3));
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(8, 12);
+        __builtin_amdgcn_sched_barrier(0);
+        if (tap < 3) piece_in(2 * tap + 1); else if (tap < 7) piece_w(2 * (tap - 3) + 1);
+        if (tap == 7 && ci + 2 == nch) {  // the next item's bias table (read when its accumulators are initialised)
+          const __amdgpu_buffer_rsrc_t rt = rs_table(nxt);
+          dma_tab(rt, 0); dma_tab(rt, 1);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        mfmas(12, 16);
+        __builtin_amdgcn_sched_barrier(0);
+
+        if (tap == 2) {
+          // rendezvous of the chunk: this wave's weight pieces of chunk g + 1 (and a table behind them) have landed - only this chunk's six input
+          // pieces (and, in an item's first chunk, the previous item's 32 stores in front of them) are younger -, then everybody's; stage sw2
+          // (chunk g - 1) is free behind the barrier
+          if (first) SF_VMCNT(38); else SF_VMCNT(6);
+          __builtin_amdgcn_s_barrier();
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tap == 4 && first) {  // the item after this one (needed from the top of the second-to-last chunk on: nch >= 3)
+          setup(k + 1, nxt);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
+      sw = sw1; gpar ^= 1;
+    } while (++ci < nch);
+    // ---- item switch: this item's epilogue (32 stores per wave, always), the next item's accumulators ----
+    epilogue(cur);
+    cur = nxt;
+    init_acc(cur);
+  } while (++k < K);
+}
+
+}  // namespace
+
+// Does this launch qualify?  (sf_conv_bf16_persist_ok has already established: linear epilogue, single bf16-stored source without
+// image remap, bf16 output, 32-row tiles, >= 1024 tiles.)
+bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf) {
+  static const bool off = getenv("SF_NO_CONV_W4") != nullptr;
+  if (off || nf != 4 || p.stats || p.bias || p.bnb_coef || p.c0 / sfconv::KC < 3 || p.src1) return false;
+  if ((long long)p.H * p.W * p.out_s * 2 >= 0x7fffffffll || (long long)p.H * p.W * p.s0 * 2 >= 0x7fffffffll) return false;
+  return true;
+}
+
+int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStream_t st) {
+  sfconv::ConvParams p = p0;
+  p.tiles_x = (p.W + sfconv::TILE_W - 1) / sfconv::TILE_W;
+  p.tiles_y = (p.H + 31) / 32;
+  const int items = p.tiles_x * p.tiles_y * p.N * nblk;
+  static int cus = 0;
+  if (!cus) {
+    int dev = 0;
+    hipDeviceProp_t prop;
+    if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: device query failed"); return 2; }
+    cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+  }
+  const int grid = items < cus ? items : cus;
+  hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: launch failed: %s", hipGetErrorString(e)); return 2; }
+  return 0;
+}

@@ -485,6 +485,9 @@ int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, 
 // persistent variant for the large single-source bf16-stored launches (conv3x3_bf16_persist.hip); bit-identical results
 bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf);
 int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p, int nf, int nblk, hipStream_t st);
+// one-wave-per-SIMD persistent variant (conv3x3_bf16_persist4.hip): NF = 4, >= 2 K chunks, no per-channel bias; bit-identical results
+bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf);
+int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p, int nblk, hipStream_t st);
 // kscale (nullable): [groups][Kp] per-input-lane factors -> `groups` packed images back to back (folded BatchNorm scale)
 void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
                           void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale = nullptr, int groups = 1);

@@ -81,3 +81,72 @@ def test_maxpool_with_recorded_routing_matches_recomputed_argmax(device, monkeyp
     y0, g0 = run(True)
     assert torch.equal(y1, y0) and torch.equal(g1, g0)
     assert float(g1.float().abs().sum()) > 0
+
+
+# ----------------------------------------------------------------------------------------------------------------------
+# The one-wave-per-SIMD persistent kernel (conv3x3_bf16_persist4.hip): 128-channel N blocks, >= 3 K chunks, no per-channel bias
+# (plain, or the folded BatchNorm's grouped weights + border-class bias table).  Bit-identical to the one-item kernel.
+# ----------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("n,cin,cout,H,W", [(520, 48, 128, 32, 32), (400, 160, 256, 40, 24), (1040, 256, 256, 32, 16), (500, 64, 384, 33, 17), (2304, 256, 256, 32, 32)])
+def test_one_wave_per_simd_kernel_matches_one_item_kernel(device, bf16_mode, n, cin, cout, H, W):
+    """No bias: a launch over n images (>= 1024 tiles: persistent, one wave per SIMD) == two launches over the halves (one-item kernel)."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import NULL, T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(n + cin + 1)
+    eng = ConvEngine([cin], cout)
+    assert eng.fwd_map.nf == 4
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+    packed, _ = K.pack_weights(w, None, eng.fwd_map, False)
+    x = torch.randn(n, H, W, cpad(cin), generator=g).to(device).to(torch.bfloat16)
+    tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
+    assert tiles * n >= 1024 and (n > 2000 or tiles * (n // 2) < 1024)
+
+    def run(xs):
+        m = xs.shape[0]
+        y = torch.full((m, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
+        K.conv3x3(T(xs), NULL, m, H, W, packed, None, eng.fwd_map, T(y))
+        return y
+
+    y = run(x)
+    parts = 2 if n <= 2000 else 6   # every part below the persistent kernels' threshold
+    step = n // parts
+    torch.cuda.synchronize()
+    assert torch.isfinite(y[..., :cout].float()).all()
+    for i in range(parts):
+        yi = run(x[i * step:(i + 1) * step].contiguous())
+        assert torch.equal(y[i * step:(i + 1) * step, ..., :cout], yi[..., :cout]), f"part {i} differs"
+    assert float(y[..., :cout].float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(1040, 4, 160, 256, 32, 32), (2304, 12, 256, 256, 32, 32), (1080, 6, 96, 128, 40, 24)])
+def test_one_wave_per_simd_kernel_folded_batchnorm(device, bf16_mode, n, groups, cin, cout, H, W):
+    """Grouped weights + border-class bias table (sf_conv3x3_fwd_folded): the persistent launch over all groups == one launch per group
+    (each below the persistent threshold: the one-item kernel), bit for bit."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(n + cin + groups)
+    eng = ConvEngine([cin], cout)
+    gm = eng.fwd_map
+    assert gm.nf == 4
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+    scale = (0.5 + torch.rand(groups, gm.Kp, generator=g)).to(device)
+    shift = torch.randn(groups, gm.Kp, generator=g).to(device)
+    packed, tab = K.conv3x3_fold_pack(w, b, gm, scale, shift)
+    x = torch.randn(n, H, W, cpad(cin), generator=g).to(device).to(torch.bfloat16)
+    tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
+    ipg = n // groups
+    assert tiles * n >= 1024 and tiles * ipg < 1024
+    y = torch.full((n, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
+    K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y))
+    torch.cuda.synchronize()
+    assert torch.isfinite(y[..., :cout].float()).all()
+    img = gm.Np * gm.Kp * 9
+    for gi in range(groups):
+        yg = torch.full((ipg, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
+        K.conv3x3_folded(T(x[gi * ipg:(gi + 1) * ipg].contiguous()), ipg, H, W, packed[gi * img:(gi + 1) * img], tab[gi:gi + 1].contiguous(), gm, T(yg))
+        assert torch.equal(y[gi * ipg:(gi + 1) * ipg, ..., :cout], yg[..., :cout]), f"group {gi} differs"
