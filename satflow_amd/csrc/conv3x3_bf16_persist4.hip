@@ -187,10 +187,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     const int cb = nb_item * NB + nf * 32;
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
-      // (+ 0.f: the one-item kernel adds a zero bias here, which turns -0 into +0)
+      // (the one-item kernel adds a zero bias vector here, which turns an accumulator that is exactly -0 into +0: the two kernels agree
+      // in every VALUE - torch.equal - and differ in the sign bit of such zeros; 256 additions per item are not worth that bit)
       float v[8];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) v[i] = acc_read(a[4 * g + i]) + 0.f;
+      for (int i = 0; i < 8; ++i) v[i] = acc_read(a[4 * g + i]);
       const unsigned ax = pk2(v[0], v[1]), ay = pk2(v[2], v[3]);
       const unsigned bx = pk2(v[4], v[5]), by = pk2(v[6], v[7]);
       const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
@@ -206,6 +207,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     return (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * kh) * 2) : DMA_SENT;
   };
 
+#ifdef SF_EXP_W4_CLK
+  const unsigned long long clk0 = __builtin_readcyclecounter(), wall0 = wall_clock64();
+#endif
   Item cur, nxt;
   setup(0, cur);
   nxt = cur; nxt.valid = 0;  // (set up for real inside the first chunk)
@@ -283,22 +287,41 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       const unsigned dst_in = lds0 + (unsigned)(IN0 + (wave * 2 + si1) * PIN_B);
       const unsigned dst_w = lds0 + (unsigned)(sw2 * W_B + wave * 1024);
       const unsigned m1 = it1.in_mask;
+      // (-DSF_EXP_W4_*: ablation builds of tools/ablate_w4.sh, never part of the shipped library)
       auto piece_in = [&](int j) __attribute__((always_inline)) {
+#ifdef SF_EXP_W4_NODMA
+        return;
+#endif
         const unsigned voff = (m1 >> j) & 1u ? in_base_off[j] : DMA_SENT;
         if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16(voff, ri, so_in, dst_in + j * 1024);  // the last instruction: 40 lanes
       };
-      auto piece_w = [&](int i) __attribute__((always_inline)) { bufdma16(lane * 16, rw, so_w + i * 4096, dst_w + i * 4096); };
+      auto piece_w = [&](int i) __attribute__((always_inline)) {
+#ifdef SF_EXP_W4_NODMA
+        return;
+#endif
+        bufdma16(lane * 16, rw, so_w + i * 4096, dst_w + i * 4096);
+      };
 
 #pragma unroll
       for (int tap = 0; tap < 9; ++tap) {
+#ifdef SF_EXP_W4_NOREAD
+        if (tap == 8 && ci + 100 == nch) {
+#else
         if (tap == 8) {
+#endif
           // this wave's input pieces of chunk g + 1 have landed: everything younger (the 9 weight pieces of chunk g + 2 and, in the second-to-last
           // chunk of an item, the two table pieces behind them) may stay in flight
+#ifndef SF_EXP_W4_NOSYNC
           if (ci + 2 == nch) SF_VMCNT(11); else SF_VMCNT(9);
+#endif
           __builtin_amdgcn_sched_barrier(0);
           load_tap(sw1, si1, 0, fa[0], fb[0]);  // first tap of the next chunk
         } else {
+#ifndef SF_EXP_W4_NOREAD
           load_tap(sw, si, tap + 1, fa[(tap + 1) % 3], fb[(tap + 1) % 3]);
+#else
+          if (ci + 100 == nch) load_tap(sw, si, tap + 1, fa[(tap + 1) % 3], fb[(tap + 1) % 3]);
+#endif
         }
         // MFMAs 0 .. 7 with one fragment read behind each | DMA piece | MFMAs 8 .. 11 | DMA piece | MFMAs 12 .. 15
         auto mfmas = [&](int lo, int hi) __attribute__((always_inline)) {
@@ -329,12 +352,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
         mfmas(12, 16);
         __builtin_amdgcn_sched_barrier(0);
 
+
         if (tap == 2) {
           // rendezvous of the chunk: this wave's weight pieces of chunk g + 1 (and a table behind them) have landed - only this chunk's six input
           // pieces (and, in an item's first chunk, the previous item's 32 stores in front of them) are younger -, then everybody's; stage sw2
           // (chunk g - 1) is free behind the barrier
+#ifndef SF_EXP_W4_NOSYNC
           if (first) SF_VMCNT(38); else SF_VMCNT(6);
           __builtin_amdgcn_s_barrier();
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         if (tap == 4 && first) {  // the item after this one (needed from the top of the second-to-last chunk on: nch >= 3)
@@ -345,10 +371,21 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       sw = sw1; gpar ^= 1;
     } while (++ci < nch);
     // ---- item switch: this item's epilogue (32 stores per wave, always), the next item's accumulators ----
+#ifndef SF_EXP_W4_NOEPI
     epilogue(cur);
     cur = nxt;
     init_acc(cur);
+#else
+    if (k + 100 == K) epilogue(cur);
+    cur = nxt;
+#endif
   } while (++k < K);
+#ifdef SF_EXP_W4_CLK
+  if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
+    const unsigned long long c = __builtin_readcyclecounter() - clk0, w = wall_clock64() - wall0;
+    printf("wg %d: %llu shader cycles in %llu ticks of 10 ns = %.3f GHz; %.0f cycles per chunk\n", (int)blockIdx.x, c, w, (double)c / (double)w / 10.0, (double)c / (K * nch));
+  }
+#endif
 }
 
 }  // namespace
