@@ -6,6 +6,9 @@
 //     reduce (fp64 accumulation across blocks) -> finalize (scale/shift, running stats) ->
 //     apply; backward = reduce + apply.
 // All NHWC, 16-byte accesses along the channel axis, one pass each.
+#include <cstdlib>
+#include <type_traits>
+
 #include "sf_common.h"
 
 namespace {
@@ -848,6 +851,13 @@ __global__ __launch_bounds__(512) void leadbias_pool_fwd_stats_kernel(const TA* 
 constexpr int LEAD_REG = 12;
 constexpr int LEADBIAS_BLOCKS = 512, LEADBIAS_BORDER_BLOCKS = 256;  // border: 4 x 56 edge workgroups + 32 corner workgroups, one per CU (138 KB of LDS each at L = 12)
 
+// border window r (0 .. 2 Wo + 2 (Ho - 2) - 1) of a frame: top row, bottom row, then left / right of the rows between (Ho, Wo >= 3)
+__device__ __forceinline__ void border_window(int r, int Ho, int Wo, int& yo, int& xo) {
+  if (r < Wo) { yo = 0; xo = r; }
+  else if (r < 2 * Wo) { yo = Ho - 1; xo = r - Wo; }
+  else { r -= 2 * Wo; yo = 1 + (r >> 1); xo = (r & 1) ? Wo - 1 : 0; }
+}
+
 __device__ __forceinline__ int argmax4(float a0, float a1, float a2, float a3) {
   int am = 0; float m = a0;  // first maximum in row-major window order, as max_pool2d
   if (a1 > m) { m = a1; am = 1; }
@@ -920,15 +930,257 @@ __global__ __launch_bounds__(512) void leadbias_pool_bwd_kernel(const TA* __rest
   for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// Round 4: the same two kernels with the INTERIOR windows (every position of the 2x2 window has border class 4: all but the outermost ring of
+// pooled pixels, 88 % at 32x32) on a short path.  rocprofv3 counters of the kernels above (profiles/r04_leadbias_pmc_before.json) show them bound
+// by vector ALU work, not by HBM: 27k / 50k VALU instructions per wave, the VALU of a SIMD busy 70 % / 80 % of the kernel - per window, lead time
+// and channel 4 adds + 3 max (+ rounding, statistics) forward; 4 adds + an argmax + 4 routed accumulations backward.
+//  * Forward: for an interior window all four positions take the SAME constant b_l, and x -> fl(x + b) is monotone, so
+//        max_i fl(v_i + b_l) = fl(max_i v_i + b_l)    EXACTLY:
+//    three max per channel ONCE, then one add per lead time.
+//  * Backward: the winner of lead time l is the first maximum of fl(v_i + b_l).  It is the first maximum of v itself for EVERY l unless two
+//    different v_i collide after the addition.  With m = max v and s = the largest v_i < m: fl(m + b) > fl(s + b) whenever m - s exceeds one
+//    ulp at the magnitude of the sums, which (m - s) > 2^-21 (max(|m|, |s|) + max_l |b_l|) guarantees with a factor two to spare.  One
+//    argmax per channel, the per-lead-time work is `G += g_l` (and the interior class sum); a wave in which ANY lane fails the test (needs
+//    |v| < ~1e-5 |b|: a fraction of a percent of the waves) takes the general path for that window - a wave-uniform branch, no divergence.
+// Border windows keep the general arithmetic: forward in a second loop of the same kernel; backward their input gradient is written by the border
+// kernel, which visits them anyway for the class sums (inlined next to the short path the general body made hipcc spill 400-500 registers).
+// A thread owns a channel OCTET (16-byte accesses for bf16 storage) instead of a quad; the forward kernel splits the lead times over two
+// threads per octet so that its 2 x 6 x 8 statistics sums fit the registers.  Same results as the kernels above, bit for bit.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ f32x8_t ld8f(const float* p) { const f32x4 a = ld4(p), b = ld4(p + 4); return f32x8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]}; }
+template <typename T> __device__ __forceinline__ f32x8_t rnd8(f32x8_t v);
+template <> __device__ __forceinline__ f32x8_t rnd8<float>(f32x8_t v) { return v; }
+template <> __device__ __forceinline__ f32x8_t rnd8<__bf16>(f32x8_t v) { return __builtin_convertvector(__builtin_convertvector(v, bf16x8_t), f32x8_t); }
+__device__ __forceinline__ f32x8_t max8(f32x8_t a, f32x8_t b) {
+  f32x8_t r;
+#pragma unroll
+  for (int j = 0; j < 8; ++j) r[j] = fmaxf(a[j], b[j]);
+  return r;
+}
+
+constexpr int LB_LH = 6;  // lead times per thread of the forward kernel (two threads per channel octet)
+template <typename TA>
+__global__ __launch_bounds__(512) void leadbias_pool_fwd_stats2_kernel(const TA* __restrict__ base, int bs, long long F, int H, int W, int C, int L,
+                                                                      const float* __restrict__ ptab_g, TA* __restrict__ out, int os,
+                                                                      float* __restrict__ stats) {
+  extern __shared__ float P[];  // [L][9][C] table | [L][C][2] sums
+  const int nP = L * 9 * C;
+  float* S = P + nP;
+  for (int i = threadIdx.x; i < nP; i += blockDim.x) P[i] = ptab_g[i];
+  for (int i = threadIdx.x; i < L * C * 2; i += blockDim.x) S[i] = 0.f;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2, o8 = C / 8, slots = 2 * o8;
+  const int lanes = blockDim.x / slots;
+  const int slot = threadIdx.x % slots, wl = threadIdx.x / slots;
+  const int hh = slot / o8, c = (slot - hh * o8) * 8, l0 = hh * LB_LH;
+  f32x8_t s1[LB_LH], s2[LB_LH];
+#pragma unroll
+  for (int i = 0; i < LB_LH; ++i) { s1[i] = f32x8_t{0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f}; s2[i] = s1[i]; }
+  auto emit = [&](int i, long long f, int yo, int xo, f32x8_t a) __attribute__((always_inline)) {
+    stv8(out + ((((long long)(l0 + i) * F + f) * Ho + yo) * Wo + xo) * os + c, a);
+    const f32x8_t r = rnd8<TA>(a);  // the stored values
+    s1[i] += r; s2[i] += r * r;
+  };
+  if (wl < lanes) {
+    // ---- interior windows ----
+    const int Hi = Ho - 2, Wi = Wo - 2;
+    const long long nint = F * Hi * Wi;
+    // (window indices fit 32 bits - the launcher checks -: a 64-bit division is ~130 instructions with a branch, and three of them per window were a
+    // third of this loop's instructions)
+    for (unsigned op = blockIdx.x * lanes + wl; op < (unsigned)nint; op += gridDim.x * lanes) {
+      const unsigned row = op / (unsigned)Wi;
+      const int xo = 1 + (int)(op - row * Wi);
+      const long long f = row / (unsigned)Hi;
+      const int yo = 1 + (int)(row - (unsigned)f * Hi);
+      const TA* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
+      const f32x8_t m = max8(max8(ldv8(p), ldv8(p + bs)), max8(ldv8(p + (long long)W * bs), ldv8(p + (long long)W * bs + bs)));
+#pragma unroll
+      for (int i = 0; i < LB_LH; ++i)
+        if (l0 + i < L) emit(i, f, yo, xo, m + ld8f(P + ((size_t)(l0 + i) * 9 + 4) * C + c));
+    }
+    // ---- border windows: the general arithmetic ----
+    const int nb = 2 * Wo + 2 * (Ho - 2);
+    const long long nbor = F * nb;
+    for (unsigned op = blockIdx.x * lanes + wl; op < (unsigned)nbor; op += gridDim.x * lanes) {
+      const long long f = op / (unsigned)nb;
+      int yo, xo;
+      border_window((int)(op - (unsigned)f * nb), Ho, Wo, yo, xo);
+      const TA* p = base + ((f * H + 2 * yo) * W + 2 * xo) * bs + c;
+      const f32x8_t v0 = ldv8(p), v1 = ldv8(p + bs), v2 = ldv8(p + (long long)W * bs), v3 = ldv8(p + (long long)W * bs + bs);
+      const int k0 = border_class(2 * yo, 2 * xo, H, W), k1 = border_class(2 * yo, 2 * xo + 1, H, W);
+      const int k2 = border_class(2 * yo + 1, 2 * xo, H, W), k3 = border_class(2 * yo + 1, 2 * xo + 1, H, W);
+#pragma unroll
+      for (int i = 0; i < LB_LH; ++i)
+        if (l0 + i < L) {
+          const float* pt = P + (size_t)(l0 + i) * 9 * C + c;
+          emit(i, f, yo, xo, max8(max8(v0 + ld8f(pt + k0 * C), v1 + ld8f(pt + k1 * C)), max8(v2 + ld8f(pt + k2 * C), v3 + ld8f(pt + k3 * C))));
+        }
+    }
+  }
+  // window lanes in order: lane w adds its sums in round w (deterministic)
+  for (int w = 0; w < lanes; ++w) {
+    if (wl == w) {
+#pragma unroll
+      for (int i = 0; i < LB_LH; ++i)
+        if (l0 + i < L) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { S[((size_t)(l0 + i) * C + c + j) * 2] += s1[i][j]; S[((size_t)(l0 + i) * C + c + j) * 2 + 1] += s2[i][j]; }
+        }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < L * C * 2; i += blockDim.x) {
+    const int l = i / (C * 2), rest = i - l * C * 2;
+    stats[((size_t)l * gridDim.x + blockIdx.x) * C * 2 + rest] = S[i];
+  }
+}
+
+template <typename TA, bool PLDS>
+__global__ __launch_bounds__(512) void leadbias_pool_bwd2_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
+                                                                long long F, int H, int W, int C, int L, const float* __restrict__ ptab_g,
+                                                                TA* __restrict__ dbase, int dbs, float* __restrict__ main_part) {
+  extern __shared__ float S[];  // [L][C] interior-class sums | [C] max_l |b_l| of the interior class (+ [L][9][C] table copy)
+  const int nS = L * C, nP = L * 9 * C;
+  float* Bc = S + nS;
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
+  for (int i = threadIdx.x; i < C; i += blockDim.x) {
+    float b = 0.f;
+    for (int l = 0; l < L; ++l) b = fmaxf(b, fabsf(ptab_g[((size_t)l * 9 + 4) * C + i]));
+    Bc[i] = b;
+  }
+  if (PLDS)
+    for (int i = threadIdx.x; i < nP; i += blockDim.x) S[nS + C + i] = ptab_g[i];
+  const float* ptab = PLDS ? S + nS + C : ptab_g;
+  __syncthreads();
+  const int Ho = H / 2, Wo = W / 2, o8 = C / 8;
+  const int lanes = blockDim.x / o8;  // windows in flight per block
+  const int oc = threadIdx.x % o8, wl = threadIdx.x / o8;
+  const int c = oc * 8;
+  const bool active = wl < lanes;
+  typedef typename std::conditional<std::is_same<TA, float>::value, f32x8_t, bf16x8_t>::type raw8;  // an octet as stored
+  auto ldraw = [](const TA* q) __attribute__((always_inline)) -> raw8 {
+    if constexpr (std::is_same<TA, float>::value) return ld8f(q);
+    else return *reinterpret_cast<const bf16x8_t*>(q);
+  };
+  f32x8_t s4[LEAD_REG];
+  const f32x8_t zero8 = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int l = 0; l < LEAD_REG; ++l) s4[l] = zero8;
+  const long long lead_stride = F * Ho * Wo * dos;  // elements between two lead times of dout
+  // ---- interior windows ----
+  {
+    const int Hi = Ho - 2, Wi = Wo - 2;
+    const long long nint = F * Hi * Wi;
+    const long long rounds = (nint + (long long)gridDim.x * lanes - 1) / ((long long)gridDim.x * lanes);  // every wave runs every round (wave votes inside)
+    for (long long rd = 0; rd < rounds; ++rd) {
+      const long long op = (rd * gridDim.x + blockIdx.x) * lanes + wl;
+      const bool on = active && op < nint;
+      const unsigned opc = on ? (unsigned)op : 0u;  // (32-bit window indices: see the forward kernel)
+      const unsigned row = opc / (unsigned)Wi;
+      const int xo = 1 + (int)(opc - row * Wi);
+      const long long f = row / (unsigned)Hi;
+      const int yo = 1 + (int)(row - (unsigned)f * Hi);
+      const long long b0 = (f * H + 2 * yo) * W + 2 * xo;
+#ifdef SF_EXP_LB_NOBASE
+      const TA* p = base + (b0 & 0xffff) * bs + c;
+#else
+      const TA* p = base + b0 * bs + c;
+#endif
+      const raw8 r0 = ldraw(p), r1 = ldraw(p + bs), r2 = ldraw(p + (long long)W * bs), r3 = ldraw(p + (long long)W * bs + bs);
+      raw8 gr[LEAD_REG];
+      // a scalar base per lead time + ONE 32-bit element offset per window (a lead time's tensor is below 2^31 elements, the launcher checks): the
+      // 64-bit multiply-add chains in front of every load were a fifth of this loop's instructions
+      const unsigned goff = ((((unsigned)f * Ho + yo) * Wo + xo) * (unsigned)dos) + c;
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l)  // all lead times requested before the first use; clamped index: unconditional loads
+#ifdef SF_EXP_LB_NODOUT   // (ablation builds only: tools/ablate_leadbias.sh)
+        gr[l] = ldraw(dout + (long long)(l < L ? l : 0) * lead_stride + (goff & 0xffffu));
+#else
+        gr[l] = ldraw(dout + (long long)(l < L ? l : 0) * lead_stride + goff);
+#endif
+      // first maximum of v, the largest value below it, and the collision test
+      int am[8];
+      bool safe = true;
+      {
+      const f32x8_t v0 = __builtin_convertvector(r0, f32x8_t), v1 = __builtin_convertvector(r1, f32x8_t), v2 = __builtin_convertvector(r2, f32x8_t),
+                    v3 = __builtin_convertvector(r3, f32x8_t);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float m = v0[j]; int a = 0;
+        if (v1[j] > m) { m = v1[j]; a = 1; }
+        if (v2[j] > m) { m = v2[j]; a = 2; }
+        if (v3[j] > m) { m = v3[j]; a = 3; }
+        float sc = -INFINITY;
+        sc = v0[j] < m ? fmaxf(sc, v0[j]) : sc; sc = v1[j] < m ? fmaxf(sc, v1[j]) : sc;
+        sc = v2[j] < m ? fmaxf(sc, v2[j]) : sc; sc = v3[j] < m ? fmaxf(sc, v3[j]) : sc;
+        am[j] = a;
+        const float mag = fmaxf(fabsf(m), sc == -INFINITY ? 0.f : fabsf(sc)) + Bc[c + j];
+        safe = safe && (sc == -INFINITY || (m - sc) > mag * 4.76837158203125e-07f);  // 2^-21
+      }
+      }
+      f32x8_t G = zero8;
+#pragma unroll
+      for (int l = 0; l < LEAD_REG; ++l) {
+        const f32x8_t g = l < L ? __builtin_convertvector(gr[l], f32x8_t) : zero8;
+        G += g;
+        if (on) s4[l] += g;  // (off only in a workgroup's last round: no per-element select)
+      }
+      if (__all(safe || !on)) {
+        if (on) {
+          f32x8_t gp[4];
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { gp[0][j] = am[j] == 0 ? G[j] : 0.f; gp[1][j] = am[j] == 1 ? G[j] : 0.f; gp[2][j] = am[j] == 2 ? G[j] : 0.f; gp[3][j] = am[j] == 3 ? G[j] : 0.f; }
+#ifdef SF_EXP_LB_NOSTORE
+          TA* d = dbase + (b0 & 0xffff) * dbs + c;
+#else
+          TA* d = dbase + b0 * dbs + c;
+#endif
+          stv8(d, gp[0]); stv8(d + dbs, gp[1]); stv8(d + (long long)W * dbs, gp[2]); stv8(d + (long long)W * dbs + dbs, gp[3]);
+        }
+      } else if (on) {
+        // a lane of this wave failed the collision test (a fraction of a percent of the waves): the general arithmetic for this window, lead time by
+        // lead time in a rolled loop (all four positions have class 4) - slow, rare, and small in registers
+        const f32x8_t v0 = __builtin_convertvector(r0, f32x8_t), v1 = __builtin_convertvector(r1, f32x8_t), v2 = __builtin_convertvector(r2, f32x8_t),
+                      v3 = __builtin_convertvector(r3, f32x8_t);
+        f32x8_t gp[4] = {zero8, zero8, zero8, zero8};
+#pragma unroll 1
+        for (int l = 0; l < L; ++l) {
+          const f32x8_t g = __builtin_convertvector(ldraw(dout + ((((long long)l * F + f) * Ho + yo) * Wo + xo) * dos + c), f32x8_t);
+          const f32x8_t bl = ld8f(ptab + ((size_t)l * 9 + 4) * C + c);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const int a = argmax4(v0[j] + bl[j], v1[j] + bl[j], v2[j] + bl[j], v3[j] + bl[j]);
+            gp[0][j] += a == 0 ? g[j] : 0.f; gp[1][j] += a == 1 ? g[j] : 0.f; gp[2][j] += a == 2 ? g[j] : 0.f; gp[3][j] += a == 3 ? g[j] : 0.f;
+          }
+        }
+        TA* d = dbase + b0 * dbs + c;
+        stv8(d, gp[0]); stv8(d + dbs, gp[1]); stv8(d + (long long)W * dbs, gp[2]); stv8(d + (long long)W * dbs + dbs, gp[3]);
+      }
+    }
+  }
+#pragma unroll
+  for (int l = 0; l < LEAD_REG; ++l)
+    if (l < L && active) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) atomicAdd(S + (size_t)l * C + c + j, s4[l][j]);
+    }
+  __syncthreads();
+  float* dstp = main_part + (size_t)blockIdx.x * nS;
+  for (int i = threadIdx.x; i < nS; i += blockDim.x) dstp[i] = S[i];
+}
+
 // Border windows.  Blocks take roles: 4 x EDGE blocks (top / bottom / left / right edge without the corners: the two
 // positions on the image border share one class, the two inner ones are class 4, so two register sums per lead time
 // suffice and the loop is atomics-free like the main kernel's) and the last LEADBIAS_CORNER_BLOCKS blocks for the corner
 // windows (4 classes; LDS atomics) - or for every border window when the image is too small to have plain edges.
 constexpr int LEADBIAS_CORNER_BLOCKS = 32;  // (8 were the tail of the kernel: 290 us of per-window serial loads)
+// dbase (nullable, round 4): also write the input gradient of the windows visited here - the main kernel then covers the interior windows only
+// (leadbias_pool_bwd2_kernel).
 template <typename TA, bool PLDS>
 __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
                                                              long long F, int H, int W, int C, int L, const float* __restrict__ ptab_g,
-                                                             float* __restrict__ border_part) {
+                                                             float* __restrict__ border_part, TA* __restrict__ dbase, int dbs) {
   extern __shared__ float S[];  // [L][9][C] (+ table copy)
   const int nS = L * 9 * C;
   for (int i = threadIdx.x; i < nS; i += blockDim.x) S[i] = 0.f;
@@ -967,6 +1219,7 @@ __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restri
         f32x4 gl[LEAD_REG];
 #pragma unroll
         for (int l = 0; l < LEAD_REG; ++l) gl[l] = ldv4(dout + ((((l < L ? l : 0) * F + f) * Ho + yo) * Wo + xo) * dos + c);
+        f32x4 gp0 = {0.f, 0.f, 0.f, 0.f}, gp1 = gp0, gp2 = gp0, gp3 = gp0;
 #pragma unroll
         for (int l = 0; l < LEAD_REG; ++l) {
           const float* pt = ptab + (size_t)(l < L ? l : 0) * 9 * C + c;
@@ -974,9 +1227,15 @@ __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restri
           const f32x4 g = l < L ? gl[l] : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
-            const bool outer = (outer_mask >> argmax4(a0[j], a1[j], a2[j], a3[j])) & 1;
+            const int am = argmax4(a0[j], a1[j], a2[j], a3[j]);
+            const bool outer = (outer_mask >> am) & 1;
             so[l][j] += outer ? g[j] : 0.f; si[l][j] += outer ? 0.f : g[j];
+            if (dbase) { gp0[j] += am == 0 ? g[j] : 0.f; gp1[j] += am == 1 ? g[j] : 0.f; gp2[j] += am == 2 ? g[j] : 0.f; gp3[j] += am == 3 ? g[j] : 0.f; }
           }
+        }
+        if (dbase) {
+          TA* d = dbase + ((f * H + 2 * yo) * W + 2 * xo) * dbs + c;
+          stv4(d, gp0); stv4(d + dbs, gp1); stv4(d + (long long)W * dbs, gp2); stv4(d + (long long)W * dbs + dbs, gp3);
         }
       }
 #pragma unroll
@@ -1006,6 +1265,7 @@ __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restri
       f32x4 gl[LEAD_REG];  // the first LEAD_REG lead times' gradients requested together (clamped index: unconditional loads)
 #pragma unroll
       for (int l = 0; l < LEAD_REG; ++l) gl[l] = ldv4(dout + ((((l < L ? l : 0) * F + f) * Ho + yo) * Wo + xo) * dos + c);
+      f32x4 gq[4] = {f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}, f32x4{0.f, 0.f, 0.f, 0.f}};
       for (int l = 0; l < L; ++l) {
         const float* pt = ptab + (size_t)l * 9 * C + c;
         const f32x4 a0 = v[0] + ld4(pt + k[0] * C), a1 = v[1] + ld4(pt + k[1] * C), a2 = v[2] + ld4(pt + k[2] * C), a3 = v[3] + ld4(pt + k[3] * C);
@@ -1017,7 +1277,15 @@ __global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restri
         } else g = ldv4(dout + (((l * F + f) * Ho + yo) * Wo + xo) * dos + c);
         float* Sl = S + (size_t)l * 9 * C + c;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) atomicAdd(Sl + k[argmax4(a0[j], a1[j], a2[j], a3[j])] * C + j, g[j]);
+        for (int j = 0; j < 4; ++j) {
+          const int am = argmax4(a0[j], a1[j], a2[j], a3[j]);
+          atomicAdd(Sl + k[am] * C + j, g[j]);
+          gq[0][j] += am == 0 ? g[j] : 0.f; gq[1][j] += am == 1 ? g[j] : 0.f; gq[2][j] += am == 2 ? g[j] : 0.f; gq[3][j] += am == 3 ? g[j] : 0.f;
+        }
+      }
+      if (dbase) {
+        TA* d = dbase + ((f * H + 2 * yo) * W + 2 * xo) * dbs + c;
+        stv4(d, gq[0]); stv4(d + dbs, gq[1]); stv4(d + (long long)W * dbs, gq[2]); stv4(d + (long long)W * dbs + dbs, gq[3]);
       }
     }
   }
@@ -1142,6 +1410,19 @@ int sf_leadtime_pool_fwd_stats(sfTensor base, int64_t frames, int32_t h, int32_t
     (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_stats_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
+  static const bool old_kernels = getenv("SF_LEADBIAS_V1") != nullptr;  // A/B switch: the kernels of rounds 1-3
+  if (!old_kernels && h >= 6 && w >= 6 && C % 8 == 0 && 2 * (C / 8) <= 512 && L <= 2 * LB_LH && frames * (h / 2) * (w / 2) < 0x7fffffffll) {  // interior windows on the short path
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_stats2_kernel<float>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_fwd_stats2_kernel<__bf16>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2_set = true;
+    }
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_stats2_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(512), lds, st, (const TA*)base.ptr,
+                                                   base.stride, (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride, stats));
+    SF_CHECK_LAUNCH("leadbias_pool_fwd_stats2");
+    return 0;
+  }
   SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_fwd_stats_kernel<TA>), dim3(LEADBIAS_BLOCKS), dim3(512), lds, st, (const TA*)base.ptr,
                                                  base.stride, (long long)frames, h, w, C, L, (const float*)workspace, (TA*)out.ptr, out.stride, stats));
   SF_CHECK_LAUNCH("leadbias_pool_fwd_stats");
@@ -1176,7 +1457,28 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
   float* cls_sum = main_part + (size_t)LEADBIAS_BLOCKS * L * C;
   const size_t f4 = sizeof(float), lds_main = (size_t)L * C * f4, lds_border = (size_t)nt * f4, lds_tab = (size_t)nt * f4;
 #define SF_LB_ARGS (const TA*)base.ptr, base.stride, (const TA*)dout.ptr, dout.stride, (long long)frames, h, w, C, L, (const float*)workspace
-  if (lds_main + lds_tab <= 160 * 1024)
+  static const bool old_kernels = getenv("SF_LEADBIAS_V1") != nullptr;  // A/B switch: the main kernel of rounds 1-3
+  bool border_dbase = false;
+  if (!old_kernels && base.dtype == SF_BF16 && h >= 6 && w >= 6 && C % 8 == 0 && C / 8 <= 512 && L <= LEAD_REG && frames * (h / 2) * (w / 2) * dout.stride < 0x7fffffffll) {  // interior windows on the short path (bf16 storage:
+                                                                                                               // with fp32 octets the kernel spills 60 registers)
+    static bool attr2_set = false;
+    if (!attr2_set) {
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd2_kernel<float, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd2_kernel<__bf16, false>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd2_kernel<float, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)leadbias_pool_bwd2_kernel<__bf16, true>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr2_set = true;
+    }
+    const size_t lds2 = lds_main + (size_t)C * f4;
+    if (lds2 + lds_tab <= 160 * 1024)
+      SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd2_kernel<TA, true>), dim3(LEADBIAS_BLOCKS), dim3(512), lds2 + lds_tab, st,
+                                                     SF_LB_ARGS, (TA*)dbase.ptr, dbase.stride, main_part));
+    else
+      SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd2_kernel<TA, false>), dim3(LEADBIAS_BLOCKS), dim3(512), lds2, st,
+                                                     SF_LB_ARGS, (TA*)dbase.ptr, dbase.stride, main_part));
+    SF_CHECK_LAUNCH("leadbias_pool_bwd2");
+    border_dbase = true;  // the border ring's input gradient comes from the border kernel
+  } else if (lds_main + lds_tab <= 160 * 1024)
     SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_pool_bwd_kernel<TA, true>), dim3(LEADBIAS_BLOCKS), dim3(512), lds_main + lds_tab, st,
                                                    SF_LB_ARGS, (TA*)dbase.ptr, dbase.stride, main_part));
   else
@@ -1185,10 +1487,10 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
   SF_CHECK_LAUNCH("leadbias_pool_bwd");
   if (lds_border + lds_tab <= 160 * 1024)
     SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, true>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(256), lds_border + lds_tab, st,
-                                                   SF_LB_ARGS, border_part));
+                                                   SF_LB_ARGS, border_part, border_dbase ? (TA*)dbase.ptr : (TA*)nullptr, dbase.stride));
   else
     SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, false>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(256), lds_border, st,
-                                                   SF_LB_ARGS, border_part));
+                                                   SF_LB_ARGS, border_part, border_dbase ? (TA*)dbase.ptr : (TA*)nullptr, dbase.stride));
 #undef SF_LB_ARGS
   SF_CHECK_LAUNCH("leadbias_border");
   hipLaunchKernelGGL(leadbias_reduce_kernel, dim3((nt + 63) / 64), dim3(64, 8), 0, st, main_part, LEADBIAS_BLOCKS, border_part, LEADBIAS_BORDER_BLOCKS, L,

@@ -19,7 +19,7 @@ for _ in range(10): run()
 e1.record(); torch.cuda.synchronize()
 print(f"leadtime_pool bwd ({st}): {e0.elapsed_time(e1)/10:.3f} ms (incl. table/reduce kernels and torch glue)")
 def fwd():
-    return leadtime_pool(base.detach(), w.detach(), 96, 12)
+    return leadtime_pool(base.detach(), w.detach(), 96, 12, want_stats=True)  # what the MetNet step runs (sf_leadtime_pool_fwd_stats)
 for _ in range(3): fwd()
 e0.record()
 for _ in range(10): fwd()

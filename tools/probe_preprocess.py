@@ -1,5 +1,5 @@
 import os, sys
-sys.path.insert(0, "/root/repo")
+sys.path.insert(0, __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__))))
 import torch, satflow_amd
 from satflow_amd import kernels as K
 satflow_amd.set_compute_dtype("bf16a")

@@ -6,7 +6,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT -o pmc_$C -- python3 /root/repo/tools/probe_roofline.py $MODE > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT -o pmc_$C -- python3 $GRAFT_REPO_ROOT/tools/probe_roofline.py $MODE > $OUT/pmc_$C.log 2>&1
   tail -1 $OUT/pmc_$C.log
 done
 ls $OUT

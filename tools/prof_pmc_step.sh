@@ -7,7 +7,7 @@ OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
 for C in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT -o pmc_$C -- python3 /root/repo/bench.py "$@" > $OUT/pmc_$C.log 2>&1
+  rocprofv3 --pmc $C --kernel-trace --output-format csv -d $OUT -o pmc_$C -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/pmc_$C.log 2>&1
   tail -1 $OUT/pmc_$C.log | cut -c1-200
   rm -f $OUT/pmc_${C}_kernel_trace.csv
 done

@@ -6,7 +6,7 @@ NAME=$1; shift
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$NAME
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python3 /root/repo/bench.py "$@" > $OUT/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d $OUT -o prof -- python3 $GRAFT_REPO_ROOT/bench.py "$@" > $OUT/bench.log 2>&1
 grep '"metric"' $OUT/bench.log > $OUT/bench.json
 ls -la $OUT
 rm -f $OUT/prof_kernel_trace.csv  # large; the stats file is what we keep
