@@ -33,6 +33,7 @@ if ROOT not in sys.path:
 PEAK_F32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
+PROFILE_ROUND = "r04"        # prefix of the sha-stamped PMC / parity records under profiles/ this file reads
 
 
 def event_time(fn, iters: int, warm: int = 3) -> float:
@@ -49,7 +50,7 @@ def event_time(fn, iters: int, warm: int = 3) -> float:
     return e0.elapsed_time(e1) * 1e-3 / iters
 
 
-def kernel_source_sha(files=("conv3x3_bf16.hip", "conv3x3_bf16_persist.hip", "conv_common.h", "sf_common.h")) -> str:
+def kernel_source_sha(files=("conv3x3_bf16.hip", "conv3x3_bf16_persist.hip", "conv3x3_bf16_persist4.hip", "conv3x3_wgrad_bf16_dma.hip", "wgrad_common.h", "conv_common.h", "sf_common.h")) -> str:
     """sha256 (16 hex digits) of the dominant kernel's sources: stamps the PMC records under profiles/ so that a stale
     `roofline.traffic` cannot outlive a kernel change."""
     import hashlib
@@ -176,15 +177,15 @@ class ConvLSTMWorkload:
         bf16 = satflow_amd.compute_dtype_name() in ("bf16", "bf16a")
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_convlstm_bf16a_pmc_cell.json")
+        pmc = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_convlstm_bf16a_pmc_cell.json")
         if bf16 and st == torch.bfloat16 and (B, H, W, hid) == (8, 128, 128, 64) and os.path.exists(pmc):  # PMC passes of this launch shape (tools/prof_pmc_cell.sh)
             rec = json.load(open(pmc))
             if rec.get("kernel_src_sha") == kernel_source_sha():
                 traffic, traffic_src = rec["traffic_bytes"], ("rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; "
-                                                              f"profiles/r03_convlstm_bf16a_pmc_cell.json (kernel sources sha {rec['kernel_src_sha']}); "
+                                                              f"profiles/{PROFILE_ROUND}_convlstm_bf16a_pmc_cell.json (kernel sources sha {rec['kernel_src_sha']}); "
                                                               "includes the saved gates of the training step (67 MB), which SURVEY 8(d)'s algorithmic bytes leave out")
             else:
-                traffic_src = "profiles/r03_convlstm_bf16a_pmc_cell.json is stale (kernel sources changed): dropped"
+                traffic_src = f"profiles/{PROFILE_ROUND}_convlstm_bf16a_pmc_cell.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, %d->%d ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", 2 * hid, 4 * hid, B),
@@ -245,9 +246,108 @@ class MetNetWorkload:
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
                 "temporal_dropout": self.dropout, "step": "fwd + mse + bwd (gradient slices all-reduced from autograd hooks as they complete) + adam"}
 
+    def kernel_table(self):
+        """The five kernels that are three quarters of the step, each timed LIVE at the step's launch shape with HIP events
+        (synthetic operands of the right storage types): us per launch, launches per step, algorithmic flops, fraction of the 2.5 PF bf16 MFMA
+        peak, and the HBM traffic per launch from the sha-stamped PMC record of a profiled step (profiles/r04_metnet_<mode>_pmc_step.json:
+        rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x 2 per MI355X_MICROARCH.md), or null."""
+        import satflow_amd
+        from satflow_amd import kernels as K
+        from satflow_amd._hip import T, cpad, lib
+        from satflow_amd.functional import ConvEngine
+
+        mode = satflow_amd.compute_dtype_name()
+        if mode != "bf16a":
+            return None
+        dev, n, H, W, G = self.dev, self.B * self.T * self.L, 32, 32, self.L
+        pmc_path = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_metnet_{mode}_pmc_step.json")
+        pmc, pmc_note = {}, "no PMC record"
+        if os.path.exists(pmc_path) and n == 2304:
+            rec = json.load(open(pmc_path))
+            if rec.get("kernel_src_sha") == kernel_source_sha():
+                pmc, pmc_note = rec["kernels"], f"profiles/{PROFILE_ROUND}_metnet_{mode}_pmc_step.json (kernel sources sha {rec['kernel_src_sha']})"
+            else:
+                pmc_note = f"profiles/{PROFILE_ROUND}_metnet_{mode}_pmc_step.json is stale (kernel sources changed): dropped"
+
+        def traffic(sub):
+            for k, v in pmc.items():
+                if sub in k:
+                    return {"read_bytes": v["read_bytes"], "write_bytes": v["write_bytes"], "bytes": v["read_bytes"] + v["write_bytes"]}
+            return None
+
+        bf = torch.bfloat16
+        rows = []
+
+        def row(name, pmc_sub, launches, cin, cout, fn, what):
+            t = event_time(fn, iters=10)
+            fl = 2 * 9 * cin * cout * H * W * n
+            alg = (cin + cout) * H * W * n * 2 + 9 * cin * cout * 2
+            rows.append({"kernel": name, "replaces": what, "launches_per_step": launches, "launch_us": t * 1e6, "ms_per_step": launches * t * 1e3,
+                         "algorithmic_flops": fl, "achieved_tflops": fl / t / 1e12, "frac": fl / t / 1e12 / PEAK_BF16_TFLOPS,
+                         "algorithmic_bytes": alg, "traffic": traffic(pmc_sub)})
+
+        for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_kernel<8, 4, 0, false, true, true"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
+            eng = ConvEngine([cin], cout)
+            gm = eng.fwd_map
+            w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
+            b = torch.randn(cout, device=dev)
+            scale = 0.5 + torch.rand(G, gm.Kp, device=dev)
+            shift = torch.randn(G, gm.Kp, device=dev)
+            packed, tab = K.conv3x3_fold_pack(w, b, gm, scale, shift)
+            x = torch.randn(n, H, W, cpad(cin), device=dev).to(bf)
+            y = torch.empty(n, H, W, eng.coutp, device=dev, dtype=bf)
+            if fwd_plain:  # conv4 forward
+                row("conv3x3_bf16_persist4_kernel (folded BatchNorm, 4 waves x 512 registers)", "conv3x3_bf16_persist4_kernel", 1, cin, cout,
+                    lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)), "DownSampler conv4 forward")
+            tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
+            st = torch.empty(n * tiles, gm.Np, 2, device=dev)
+            row(f"conv3x3_bf16_persist_kernel<4, STATS> {cin}->{cout}", "conv3x3_bf16_persist_kernel<4, 1>", 1, cin, cout,
+                lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), stats=st), f"DownSampler conv{2 if cin == 160 else 3} forward + BatchNorm statistics")
+            # input gradient with the BatchNorm backward in its epilogue (dx = A conv^T(dout) + B x + K)
+            need = (True,)
+            gmb = eng.bwd_map(need)
+            packed_t = K.pack_weights(w, None, gmb, True)[0]
+            dout = torch.randn(n, H, W, eng.coutp, device=dev).to(bf)
+            coef = torch.randn(G, 3, cpad(cin), device=dev)
+            dx = torch.empty(n, H, W, cpad(cin), device=dev, dtype=bf)
+            row(f"conv3x3_bf16_kernel<8, NF={gmb.nf}, TR, BNB> {cout}->{cin} (input gradient + BatchNorm backward)", dgrad_name, 2 if cin == 256 else 1, cout, cin,
+                lambda: K.conv3x3_bwd_data_bn(T(dout), n, H, W, packed_t, gmb, T(x), coef, T(dx)),
+                "input gradients of conv3 / conv4 with the BatchNorm backward folded in" if cin == 256 else "input gradient of conv2 with BatchNorm 1's backward folded in")
+            dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
+            mean, rstd = torch.randn(G, cpad(cin), device=dev), 0.5 + torch.rand(G, cpad(cin), device=dev)
+            sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
+            row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true>", 2 if cin == 256 else 1, cin, cout,
+                lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums)),
+                "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)" if cin == 256 else "weight gradient of conv2")
+            del x, y, dout, dx, st
+        rows.sort(key=lambda r: -r["ms_per_step"])
+        return {"rows": rows, "traffic_source": pmc_note,
+                "note": "launch_us of the weight-gradient rows includes the small helper kernels of sf_conv3x3_bwd_weight_folded (border sums, reduce, BatchNorm sums: ~0.15 ms)"}
+
     def roofline(self):
-        """Dominant kernel: the 256->256 3x3 convolution at 32x32 (DownSampler conv3/conv4 forward and their
-        input gradients: 4 of the ~11 big launches per step and the largest share of the FLOPs)."""
+        """The kernel with the largest share of the step: the grouped weight gradient of the folded 256 -> 256 convolutions
+        (wgrad_bf16_dma_kernel<FAST, GROUPED>, 2 launches per step + 1 at 160 -> 256), timed live; the other four big kernels are in
+        extra.kernels.  Modes without the bf16-stored encoder report the forward convolution as before."""
+        import satflow_amd
+        mode = satflow_amd.compute_dtype_name()
+        if mode == "bf16a":
+            tab = self.kernel_table()
+            self._kernel_table = tab
+            r = next(x for x in tab["rows"] if x["kernel"].startswith("wgrad_bf16_dma_kernel") and "256->256" in x["kernel"])
+            tr = r["traffic"]
+            return {"bound": "mfma", "achieved": r["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
+                    "traffic": tr["bytes"] if tr else None, "traffic_source": tab["traffic_source"],
+                    "kernel": "wgrad_bf16_dma_kernel<FAST=true, GROUPED=true> (sf_conv3x3_bwd_weight_folded, 256->256 ch, 32x32, 2304 images, 12 BatchNorm groups): "
+                              "the largest kernel of the step by time (3 launches, ~23 %)",
+                    "launch_us": r["launch_us"], "algorithmic_flops": r["algorithmic_flops"], "algorithmic_bytes": r["algorithmic_bytes"],
+                    "hbm_gbps_algorithmic": r["algorithmic_bytes"] / (r["launch_us"] * 1e-6) / 1e9,
+                    "hbm_frac_algorithmic": r["algorithmic_bytes"] / (r["launch_us"] * 1e-6) / 1e9 / PEAK_HBM_GBPS,
+                    "note": "bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), bf16 activations and gradients in HBM, NHWC tiles by LDS-DMA, transposing "
+                            "ds_read_b64_tr_b16 fragment reads; launch_us includes the helper kernels of the call (~0.15 ms: the kernel alone is faster by that much)"}
+        return self._roofline_forward_conv()
+
+    def _roofline_forward_conv(self):
+        """The 256->256 3x3 forward convolution at 32x32 (the modes with fp32-stored activations)."""
         from satflow_amd import kernels as K
         from satflow_amd._hip import NULL, T
         from satflow_amd.functional import ConvEngine
@@ -269,14 +369,14 @@ class MetNetWorkload:
         alg_bytes = 2 * C * H * W * n * esz + 9 * C * C * (2 if bf16 else 4)
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", f"r03_metnet_{mode}_pmc_conv256.json")
+        pmc = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_metnet_{mode}_pmc_conv256.json")
         if n == 2304 and os.path.exists(pmc):  # PMC pass of this very launch shape (tools/prof_pmc.sh), per launch
             rec = json.load(open(pmc))
             if rec.get("kernel_src_sha") == kernel_source_sha():  # a record of another kernel version is NOT this kernel's traffic
                 traffic, traffic_src = rec["traffic_bytes"], (f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2 per MI355X_MICROARCH.md; "
-                                                              f"profiles/r03_metnet_{mode}_pmc_conv256.json (kernel sources sha {rec['kernel_src_sha']})")
+                                                              f"profiles/{PROFILE_ROUND}_metnet_{mode}_pmc_conv256.json (kernel sources sha {rec['kernel_src_sha']})")
             else:
-                traffic_src = f"profiles/r03_metnet_{mode}_pmc_conv256.json is stale (kernel sources changed): dropped"
+                traffic_src = f"profiles/{PROFILE_ROUND}_metnet_{mode}_pmc_conv256.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
                 "kernel": (f"conv3x3_bf16_persist_kernel<NF=4,TR> (sf_conv3x3_fwd, 256->256 ch, 32x32, {n} images; one persistent workgroup per CU)" if act16 else
@@ -729,13 +829,13 @@ class DGMRWorkload:
         bf16 = satflow_amd_mode() != "f32"
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
-        pmc = os.path.join(ROOT, "profiles", "r03_dgmr_bf16_pmc_conv.json")
+        pmc = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_dgmr_bf16_pmc_conv.json")
         if bf16 and (n, self.H, cin) == (16, 256, 128) and os.path.exists(pmc):   # PMC passes of this launch (tools/prof_pmc_dgmr.sh)
             rec = json.load(open(pmc))
             if rec.get("kernel_src_sha") == kernel_source_sha():
-                traffic, traffic_src = rec["traffic_bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2; profiles/r03_dgmr_bf16_pmc_conv.json (sha {rec['kernel_src_sha']})"
+                traffic, traffic_src = rec["traffic_bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2; profiles/{PROFILE_ROUND}_dgmr_bf16_pmc_conv.json (sha {rec['kernel_src_sha']})"
             else:
-                traffic_src = "profiles/r03_dgmr_bf16_pmc_conv.json is stale (kernel sources changed): dropped"
+                traffic_src = f"profiles/{PROFILE_ROUND}_dgmr_bf16_pmc_conv.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s", "frac": flops / t / 1e12 / peak, "traffic": traffic,
                 "traffic_source": traffic_src, "algorithmic_bytes": n * self.H * self.H * (cpad(cin) + cpad(cout)) * 4 + 9 * cin * cout * 2,
                 "kernel": f"sf_conv3x3_fwd {cin}->{cout} @256x256 x {n} frames", "us_per_launch": t * 1e6,
@@ -827,7 +927,7 @@ def build_workload(name: str, dev, batch: int, rank: int):
     raise SystemExit(f"unknown workload {name}")
 
 
-def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
+def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync, pause_gc: bool = True):
     """W untimed steps, then exactly K steps between barrier + device sync on both sides; MAX over ranks."""
     def barrier():
         if world > 1:
@@ -840,7 +940,8 @@ def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync):
     # objects: tools/probe_steps.py) - a host hiccup that says nothing about the path and, on N ranks, stalls every rank at the next
     # collective.  Collected now, paused for the K timed steps (what large training loops do: collect at chosen steps), re-enabled after.
     gc.collect()
-    gc.disable()
+    if pause_gc:
+        gc.disable()
     use_events = dev.type == "cuda"
     if use_events:  # HIP events on the step's stream beside the wall clock (BASELINE.md section 3 / SURVEY 8d)
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -971,6 +1072,7 @@ def main(argv=None):
             "config": wl.config(world), "final_loss": final_loss,
             # the same K steps between two HIP events on the launch stream (this rank); `ms_per_step` is the wall clock incl. the barriers
             "ms_per_step_hip_events": (event_ms / args.steps) if event_ms is not None else None,
+            "gc": "collected before, paused during the timed steps (extra.gc_enabled_ms_per_step: the same run with the collector left on)",
         }
         out["config"]["arithmetic"] = {
             "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",
@@ -983,7 +1085,7 @@ def main(argv=None):
         out["config"]["mode"] = args.dtype
         out["config"]["parity"] = ("ConvLSTM, CloudGAN and ST-LSTM paths pinned to reference-generated goldens; MetNet arithmetic checked against "
                                    "oracle/metnet.py, which is UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this "
-                                   "mode at this size: profiles/r03_parity_observed.jsonl")
+                                   f"mode at this size: profiles/{PROFILE_ROUND}_parity_observed.jsonl")
         out["roofline"] = wl.roofline()
     if world > 1 or rank == 0:
         comm = comm_report(wl, world, dev)  # collective: every rank takes part
@@ -1018,6 +1120,11 @@ def extra_figures(wl, dev, args, batch: int) -> dict:
 
     ex = {"axial_attention": wl.attention_mfma(), "convgru_sequence_kernels": convgru_seq_figures(dev, wl.T if hasattr(wl, "T") else 24, wl.B * wl.L, wl.hid)}
     sync = torch.cuda.synchronize
+    if getattr(wl, "_kernel_table", None) is not None:
+        ex["kernels"] = wl._kernel_table  # the five big kernels: ms/step, launches/step, flops, frac, traffic
+    # the same workload with Python's cyclic garbage collector LEFT ON (the timed region pauses it, see timed_steps): what an unmodified training loop sees
+    el, _ = timed_steps(wl, args.steps, 2, 1, dev, sync, pause_gc=False)
+    ex["gc_enabled_ms_per_step"], ex["gc_enabled_samples_per_s"] = el / args.steps * 1e3, args.steps * batch / el
     w32 = MetNetWorkload(dev, batch, 0, hidden=32)
     el, _ = timed_steps(w32, 4, 1, 1, dev, sync)
     ex[f"hidden32_{args.dtype}_samples_per_s"] = 4 * batch / el

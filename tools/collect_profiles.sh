@@ -2,13 +2,14 @@
 # After tools/refresh_profiles.sh (gpurun): copy the judged summaries from gpurun_out/ into profiles/ (tracked).
 set -u
 cd "$(dirname "$0")/.."
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 for m in bf16a bf16 f32; do for w in metnet convlstm; do
   d=gpurun_out/${R}_${w}_$m
   [ -f $d/prof_kernel_stats.csv ] && cp $d/prof_kernel_stats.csv profiles/${R}_${w}_${m}_kernel_stats.csv
   [ -s $d/bench.json ] && cp $d/bench.json profiles/${R}_${w}_${m}_bench.json
 done; done
-for m in bf16a bf16; do
+[ -s gpurun_out/${R}_pmc_step_bf16a/${R}_metnet_bf16a_pmc_step.json ] && cp gpurun_out/${R}_pmc_step_bf16a/${R}_metnet_bf16a_pmc_step.json profiles/
+for m in bf16; do
   d=gpurun_out/${R}_pmc_metnet_$m
   for c in FETCH_SIZE WRITE_SIZE; do [ -f $d/pmc_${c}_counter_collection.csv ] && python - $d/pmc_${c}_counter_collection.csv profiles/${R}_metnet_${m}_pmc_$c.csv <<'PY'
 import csv, sys

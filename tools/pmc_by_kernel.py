@@ -1,5 +1,9 @@
-"""Per-kernel HBM traffic of a tools/prof_pmc_step.sh run: python tools/pmc_by_kernel.py gpurun_out/<name> [top]"""
-import collections, csv, sys
+"""Per-kernel HBM traffic of a tools/prof_pmc_step.sh run: python tools/pmc_by_kernel.py gpurun_out/<name> [top] [--json out.json]
+(--json: a sha-stamped record {kernel: {launches, read_bytes, write_bytes}} per launch, what bench.py's kernel table reads)"""
+import collections, csv, json, os, sys
+js = None
+if "--json" in sys.argv:
+    i = sys.argv.index("--json"); js = sys.argv[i + 1]; del sys.argv[i:i + 2]
 d, top = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 25
 tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
 for c, scale, col in (("FETCH_SIZE", 2.0, 1), ("WRITE_SIZE", 1.0, 2)):   # FETCH_SIZE counts 32-byte... corrected x2 on gfx950 (MI355X_MICROARCH.md)
@@ -12,3 +16,11 @@ print(f"{'launches':>8} {'read GB/launch':>15} {'write GB/launch':>16}  kernel")
 for k, (n, rd, wr) in sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:top]:
     n = max(n, 1)
     print(f"{n:8d} {rd / n / 1e9:15.3f} {wr / n / 1e9:16.3f}  {k}")
+
+if js:
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from bench import kernel_source_sha
+    rec = {"what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of a short bench.py run, per-launch means by kernel; FETCH_SIZE x 2 (MI355X_MICROARCH.md)",
+           "source": d, "kernel_src_sha": kernel_source_sha(),
+           "kernels": {k: {"launches": n, "read_bytes": rd / max(n, 1), "write_bytes": wr / max(n, 1)} for k, (n, rd, wr) in tot.items() if rd + wr > 50e6 * max(n, 1)}}
+    json.dump(rec, open(js, "w"), indent=1)

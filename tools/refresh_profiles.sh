@@ -1,17 +1,20 @@
 #!/bin/bash
 # ONE gpurun call: kernel-trace stats of every (workload, mode), PMC traffic passes of the dominant kernel, one full bench line.
-# Results under gpurun_out/r03_*; tools/collect_profiles.sh copies the summaries into profiles/.
+# Results under gpurun_out/${ROUND}_*; tools/collect_profiles.sh copies the summaries into profiles/.
 set -u
 cd $GRAFT_REPO_ROOT
-R=${ROUND:-r03}
+R=${ROUND:-r04}
 for m in bf16a bf16 f32; do
   bash tools/prof_stats.sh ${R}_metnet_$m --dtype $m --no-cpu-baseline --no-extra > /dev/null 2>&1
   bash tools/prof_stats.sh ${R}_convlstm_$m --workload convlstm --dtype $m --no-cpu-baseline > /dev/null 2>&1
 done
-for m in bf16a bf16; do bash tools/prof_pmc.sh ${R}_pmc_metnet_$m $m > /dev/null 2>&1; done
+bash tools/prof_pmc.sh ${R}_pmc_metnet_bf16 bf16 > /dev/null 2>&1
+# bf16a: HBM traffic of EVERY kernel of a short profiled run (the bench line's kernel table reads it per kernel name)
+bash tools/prof_pmc_step.sh ${R}_pmc_step_bf16a --steps 3 --warmup 1 --no-cpu-baseline --no-extra > /dev/null 2>&1
+python tools/pmc_by_kernel.py gpurun_out/${R}_pmc_step_bf16a 30 --json profiles/${R}_metnet_bf16a_pmc_step.json > gpurun_out/${R}_pmc_step_bf16a/by_kernel.txt 2>&1
+cp profiles/${R}_metnet_bf16a_pmc_step.json gpurun_out/${R}_pmc_step_bf16a/
 # the full bench lines below read the sha-stamped traffic record from profiles/: refresh it on this box first (collect_profiles.sh repeats this at home)
-KFA="conv3x3_bf16_persist_kernel<4, 0>"; KFB="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"
-python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16a profiles/${R}_metnet_bf16a_pmc_conv256.json "$KFA" > /dev/null 2>&1
+KFB="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"
 python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16 profiles/${R}_metnet_bf16_pmc_conv256.json "$KFB" > /dev/null 2>&1
 ROUND=$R bash tools/prof_pmc_dgmr.sh ${R}_pmc_dgmr_conv > /dev/null 2>&1           # DGMR line's roofline launch
 ROUND=$R bash tools/prof_pmc_cell.sh ${R}_pmc_convlstm_cell > /dev/null 2>&1   # fused ConvLSTM cell: traffic record for the ConvLSTM line
