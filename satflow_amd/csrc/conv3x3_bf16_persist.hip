@@ -238,7 +238,7 @@ int launch_mode(const ConvParams& p, int nf, int nblk, int items, int grid, hipS
 #define SF_PCASE(NFV) \
   case NFV: hipLaunchKernelGGL((conv3x3_bf16_persist_kernel<NFV, MODE>), dim3(grid), dim3(512), 0, st, p, items, nblk); break;
   switch (nf) {
-    SF_PCASE(1) SF_PCASE(2) SF_PCASE(3) SF_PCASE(4) SF_PCASE(5)
+    SF_PCASE(1) SF_PCASE(2) SF_PCASE(3) SF_PCASE(4)  // (NF = 5 is never dispatched - sf_conv_bf16_persist_ok - and its statistics variant spilled 256 bytes)
     default: sf_set_error("bf16 conv (persistent): unsupported nf=%d", nf); return 1;
   }
 #undef SF_PCASE

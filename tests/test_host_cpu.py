@@ -314,3 +314,44 @@ def test_conv4x4_weight_embeddings_on_cpu():
     ref1 = TF.conv2d(x, W, b, stride=1, padding=1)
     out1 = TF.conv2d(x, TF.pad(W, (1, 0, 1, 0)), b, padding=2)[:, :, : h - 1, : w - 1]
     assert torch.allclose(out1, ref1, rtol=1e-5, atol=1e-5)
+
+
+def test_hot_kernels_do_not_spill():
+    """Register spills of the hot kernel instantiations: every kernel of the listed sources is compiled to gfx950 ISA (hipcc -S,
+    device only) and its `.amdhsa_private_segment_fixed_size` (scratch bytes per lane) is compared with a budget: 0 for everything that is not listed,
+    the recorded value for the known ones - all of which keep their scratch accesses OUT of the K loop (the spilled values are per-chunk staging
+    offsets / post-loop flush operands).  A change that makes any instantiation spill more fails here, on the CPU."""
+    import concurrent.futures as cf
+    import re
+    import subprocess
+    import tempfile
+
+    csrc = os.path.join(ROOT, "satflow_amd", "csrc")
+    budgets = {  # substring of the mangled kernel name -> scratch bytes allowed
+        "conv3x3_wgrad_bf16_dma.hip": {"wgrad_bf16_dma_kernelILb1ELb1E": 16},          # three offsets spilled before / reloaded after the K loop
+        "conv3x3_bf16.hip": {"conv3x3_bf16_kernelILi8ELi5E": 40},                        # NF = 5: 160 accumulators, staging offsets reloaded once per chunk
+        "conv3x3_bf16_persist.hip": {},
+        "conv3x3_bf16_persist4.hip": {},
+        "convgru_seq.hip": {"convgru_seq_fwd_kernelILi2ELb1ELb0E": 64},                  # the one-workgroup-per-map fallback (n > CUs / 2)
+        "conv3x3_wgrad_bf16.hip": {},
+    }
+
+    def scratch(src):
+        with tempfile.TemporaryDirectory() as d:
+            out = os.path.join(d, "k.s")
+            r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-S", "--cuda-device-only", os.path.join(csrc, src), "-o", out],
+                               capture_output=True, text=True)
+            assert r.returncode == 0, r.stderr[-2000:]
+            txt = open(out).read()
+        return src, {m.group(1): int(m.group(2)) for m in re.finditer(r"\.amdhsa_kernel (\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", txt, re.S)}
+
+    with cf.ThreadPoolExecutor(max_workers=6) as ex:
+        results = dict(ex.map(scratch, budgets))
+    bad = []
+    for src, kernels in results.items():
+        assert kernels, src
+        for name, sc in kernels.items():
+            allowed = max([v for k, v in budgets[src].items() if k in name], default=0)
+            if sc > allowed:
+                bad.append(f"{src}: {name} uses {sc} bytes of scratch per lane (budget {allowed})")
+    assert not bad, "\n".join(bad)
