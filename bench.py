@@ -693,8 +693,9 @@ class DGMRWorkload:
     (SpatialDiscriminator on every frame, TemporalDiscriminator on the 2x down-sampled clip, the DVD-GAN arrangement the file's comments
     describe).  The reference ships no training module for them (``configs/model/nowcasting_gan.yaml`` points at a class that is not in
     the tree), so the step is the standard hinge-loss pair: the generator runs ONCE per step; the discriminators are updated on
-    (real, generated.detach()), then the generator through the updated discriminators.  bf16 MFMA operands for every 3x3 / 3x3x3
-    convolution ("fp16" in BASELINE: this path's 16-bit operand type), fp32 everything else."""
+    (real, generated.detach()), then the generator through the updated discriminators.  `--dtype f16`: fp16 MFMA operands for
+    every 3x3 / 3x3x3 / 5x5 convolution and the attention products, fp32 accumulate and storage - BASELINE configs[4]'s "fp16" (the reference's
+    configs/trainer/half.yaml:33 `precision: 16`); `--dtype bf16`: the same kernels on bf16 operands."""
 
     name = "dgmr"
 
@@ -809,7 +810,10 @@ class DGMRWorkload:
                             "layers/Discriminator.py, layers/GResBlock.py, layers/Normalization.py",
                 "per_gpu_batch": self.B, "global_batch": self.B * world, "parallelism": f"dp{world}",
                 "step": "G forward once; D update: hinge loss on (real, generated.detach()), backward, Adam; G update: -D(generated) through the updated "
-                        "discriminators, backward, Adam", "launch": self.graph_note}
+                        "discriminators, backward, Adam", "launch": self.graph_note,
+                "parity": "SpectralNorm, ConditionalNorm, GResBlock, both discriminators pinned by reference-generated goldens; the generator is UNPINNED (reference "
+                          "Generator.py:5 imports a module that is not in its tree); the whole step - both losses, every discriminator gradient, spectral vectors, "
+                          "Adam-updated weights, generator gradients against float64 - against oracle.dgmr.gan_step (tests/test_dgmr_gpu.py::test_dgmr_gan_step_matches_oracle)"}
 
     def roofline(self):
         """The spatial discriminator's widest full-resolution convolution (pre_conv.2: 2chn -> 2chn, 3x3, 256x256 frames), timed live."""
@@ -830,7 +834,7 @@ class DGMRWorkload:
         peak = PEAK_BF16_TFLOPS if bf16 else PEAK_F32_TFLOPS
         traffic, traffic_src = None, None
         pmc = os.path.join(ROOT, "profiles", f"{PROFILE_ROUND}_dgmr_bf16_pmc_conv.json")
-        if bf16 and (n, self.H, cin) == (16, 256, 128) and os.path.exists(pmc):   # PMC passes of this launch (tools/prof_pmc_dgmr.sh)
+        if satflow_amd_mode() == "bf16" and (n, self.H, cin) == (16, 256, 128) and os.path.exists(pmc):   # PMC passes of this launch (tools/prof_pmc_dgmr.sh)
             rec = json.load(open(pmc))
             if rec.get("kernel_src_sha") == kernel_source_sha():
                 traffic, traffic_src = rec["traffic_bytes"], f"rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes), FETCH x2; profiles/{PROFILE_ROUND}_dgmr_bf16_pmc_conv.json (sha {rec['kernel_src_sha']})"
@@ -1015,10 +1019,13 @@ def main(argv=None):
     ap.add_argument("--global-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra figures (fp32 parity mode, hidden 32, attention) on rank 0")
-    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f32"],
+    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f16", "f32"],
                     help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default), the same with the MetNet "
-                         "encoder's activations also STORED as bf16 (bf16a), or exact fp32 (parity mode)")
+                         "encoder's activations also STORED as bf16 (bf16a), fp16 operands + fp32 accumulate (f16: the dgmr workload's "
+                         "`precision: 16`, BASELINE configs[4]), or exact fp32 (parity mode)")
     args = ap.parse_args(argv)
+    if args.dtype == "f16" and args.workload != "dgmr":
+        raise SystemExit("--dtype f16 is built for the DGMR-style layers (--workload dgmr): the recurrent cells and the folded BatchNorm have no fp16 instantiation")
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -1067,7 +1074,7 @@ def main(argv=None):
                          ("samples/sec + per-step ms, DGMR-style GAN generator+discriminator step 12ch 256x256" if args.workload == "dgmr" else "stub")))),
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": "f32" if args.dtype == "f32" else "bf16",
+            "dtype": {"f32": "f32", "f16": "f16"}.get(args.dtype, "bf16"),
             "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
             "config": wl.config(world), "final_loss": final_loss,
             # the same K steps between two HIP events on the launch stream (this rank); `ms_per_step` is the wall clock incl. the barriers
@@ -1077,13 +1084,17 @@ def main(argv=None):
         out["config"]["arithmetic"] = {
             "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",
             "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 storage of all activations",
+            "f16": "fp16 MFMA operands (v_mfma_f32_32x32x16_f16) for every 3x3 / 3x3x3 / 5x5 convolution (forward, input and weight gradients) and the attention "
+                   "products, fp32 accumulate, fp32 storage and parameters: configs/trainer/half.yaml:33 `precision: 16`",
             "bf16a": "bf16 MFMA operands, fp32 accumulate; MetNet image-encoder activations and their gradients stored as bf16 "
                      "(what torch.autocast(bfloat16) leaves between the reference's Conv2d layers), ConvLSTM hidden states (only ever read as bf16 "
                      "MFMA operands: bit-identical predictions) and the saved gates / gate gradients of both recurrent cells "
                      "(backward-only data) stored as bf16; parameters, cell states, the ConvGRU state, state gradients, attention, loss and optimizer state fp32",
         }[args.dtype]
         out["config"]["mode"] = args.dtype
-        out["config"]["parity"] = ("ConvLSTM, CloudGAN and ST-LSTM paths pinned to reference-generated goldens; MetNet arithmetic checked against "
+        out["config"].setdefault("parity", None)
+        if out["config"]["parity"] is None:
+            out["config"]["parity"] = ("ConvLSTM, CloudGAN and ST-LSTM paths pinned to reference-generated goldens; MetNet arithmetic checked against "
                                    "oracle/metnet.py, which is UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this "
                                    f"mode at this size: profiles/{PROFILE_ROUND}_parity_observed.jsonl")
         out["roofline"] = wl.roofline()

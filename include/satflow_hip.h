@@ -30,14 +30,17 @@
 extern "C" {
 #endif
 
-/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word) */
-#define SF_ABI_VERSION 2
+/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16) */
+#define SF_ABI_VERSION 3
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */
 
 /* Arithmetic/storage type of a kernel family. */
-enum { SF_F32 = 0, SF_BF16 = 1 };
+enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2 };
+/* SF_F16 (round 4): fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate, fp32-STORED tensors - the `precision: 16` of the reference's
+ * configs/trainer/half.yaml:33 (BASELINE configs[4]).  Accepted by sf_conv3x3_pack_weights, sf_conv3x3_fwd (linear / sigmoid epilogue),
+ * sf_conv3x3_fwd_splitk(+ _workspace_bytes) and sf_conv3x3_bwd_weight; the attention products have sf_bmm_f16.  Every other entry refuses it. */
 
 /* Epilogues of sf_conv3x3_fwd. */
 enum {
@@ -588,6 +591,10 @@ int sf_bmm_f32(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const floa
 int sf_bmm_bf16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
                 int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta,
                 sfStream stream);
+/* ... and rounded to fp16 (RNE; v_mfma_f32_32x32x16_f16): the SF_F16 compute mode's attention products (configs/trainer/half.yaml:33 `precision: 16`). */
+int sf_bmm_f16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
+               int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta,
+               sfStream stream);
 int sf_softmax_rows_fwd(const float* x, int64_t rows, int32_t L, float* y, sfStream stream);
 int sf_softmax_rows_bwd(const float* g, const float* y, int64_t rows, int32_t L, float* dx, sfStream stream);
 

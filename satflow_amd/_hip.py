@@ -13,10 +13,10 @@ import torch
 
 _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatflow_hip.so")
 
-SF_F32, SF_BF16 = 0, 1
+SF_F32, SF_BF16, SF_F16 = 0, 1, 2
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 2  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
+ABI_VERSION = 3  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
@@ -149,6 +149,7 @@ PROTOTYPES = {
     "sf_dvdgru_out_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _vp]),
     "sf_bmm_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sf_bmm_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
+    "sf_bmm_f16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sf_softmax_rows_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "sf_softmax_rows_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),
@@ -272,6 +273,9 @@ def generation():
 # Compute dtype of the convolution kernels: SF_F32 = exact-fp32 MFMA (parity mode, rtol 1e-4);
 # SF_BF16 = bf16 operands / fp32 accumulate / fp32 storage (the arithmetic of torch.autocast(bfloat16)
 # around the reference's Conv2d; throughput mode).  Weight gradients stay on the fp32 pipe.
+# SF_F16 ("f16") = fp16 operands / fp32 accumulate / fp32 storage: the `precision: 16` of the reference's configs/trainer/half.yaml:33 for the
+# DGMR-style layers (3x3 convolutions forward / input gradient / weight gradient, split-K launches, the attention products); kernels without an
+# fp16 instantiation (recurrent cells, folded BatchNorm, persistent kernels) refuse it.
 # "bf16a" = SF_BF16 kernels AND bf16 storage of the MetNet image encoder's activations and their gradients
 # (what torch.autocast(bfloat16) leaves in memory between the reference's Conv2d layers); everything from the
 # encoder's last pooling on (ConvGRU, attention, head, loss, parameters, optimizer state) stays fp32.
@@ -280,7 +284,8 @@ _ENCODER_BF16 = [False]
 
 
 def set_compute_dtype(name: str) -> None:
-    _COMPUTE[0] = {"f32": SF_F32, "fp32": SF_F32, "float32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "bf16a": SF_BF16}[name]
+    _COMPUTE[0] = {"f32": SF_F32, "fp32": SF_F32, "float32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "bf16a": SF_BF16,
+                   "f16": SF_F16, "fp16": SF_F16, "float16": SF_F16}[name]
     _ENCODER_BF16[0] = name == "bf16a"
 
 
@@ -291,7 +296,7 @@ def compute_dtype() -> int:
 def compute_dtype_name() -> str:
     if _COMPUTE[0] == SF_BF16:
         return "bf16a" if _ENCODER_BF16[0] else "bf16"
-    return "f32"
+    return "f16" if _COMPUTE[0] == SF_F16 else "f32"
 
 
 def gate_storage_dtype():

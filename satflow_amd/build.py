@@ -4,6 +4,7 @@ from __future__ import annotations
 import concurrent.futures as cf
 import glob
 import os
+import re
 import subprocess
 import sys
 
@@ -34,7 +35,9 @@ def build_library(force: bool = False, verbose: bool = True) -> str:
     jobs = []
     for src in _sources():
         obj = os.path.join(objdir, os.path.basename(src)[:-4] + ".o")
-        if force or _stale(obj, [src] + headers):
+        # a translation unit that #includes another .hip (the fp16 builds of the bf16 kernels) is stale when that file changes
+        included = [os.path.join(CSRC, m) for m in re.findall(r'#include "([^"]+\.hip)"', open(src).read())]
+        if force or _stale(obj, [src] + included + headers):
             jobs.append((src, obj))
 
     def compile_one(job):

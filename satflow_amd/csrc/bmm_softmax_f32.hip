@@ -113,17 +113,29 @@ __device__ __forceinline__ void bmm_load_block(const float* __restrict__ base, l
     }
   }
 }
-template <int MODE>
-__device__ __forceinline__ void bmm_store_block(__bf16* __restrict__ tile, const float (&v)[16]) {
+typedef _Float16 f16x8_t __attribute__((ext_vector_type(8)));
+// OT: the 16-bit operand type (__bf16: sf_bmm_bf16; _Float16: sf_bmm_f16)
+template <typename OT> struct bmm_ops;
+template <> struct bmm_ops<__bf16> {
+  typedef bf16x8_t v8;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0); }
+};
+template <> struct bmm_ops<_Float16> {
+  typedef f16x8_t v8;
+  static __device__ __forceinline__ f32x16 mfma(v8 a, v8 b, f32x16 c) { return __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0); }
+};
+template <int MODE, typename OT>
+__device__ __forceinline__ void bmm_store_block(OT* __restrict__ tile, const float (&v)[16]) {
+  typedef typename bmm_ops<OT>::v8 v8;
   const int t = threadIdx.x;
   if (MODE == 0) {
-    __bf16* d = tile + (t >> 1) * LROW + (t & 1) * 16;
+    OT* d = tile + (t >> 1) * LROW + (t & 1) * 16;
 #pragma unroll
     for (int hlf = 0; hlf < 2; ++hlf) {
       f32x8_t f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) f[c] = v[8 * hlf + c];
-      *reinterpret_cast<bf16x8_t*>(d + 8 * hlf) = __builtin_convertvector(f, bf16x8_t);
+      *reinterpret_cast<v8*>(d + 8 * hlf) = __builtin_convertvector(f, v8);
     }
   } else {
 #pragma unroll
@@ -131,14 +143,15 @@ __device__ __forceinline__ void bmm_store_block(__bf16* __restrict__ tile, const
       f32x8_t f;
 #pragma unroll
       for (int c = 0; c < 8; ++c) f[c] = v[8 * rr + c];
-      *reinterpret_cast<bf16x8_t*>(tile + ((t & 63) + 64 * rr) * LROW + (t >> 6) * 8) = __builtin_convertvector(f, bf16x8_t);
+      *reinterpret_cast<v8*>(tile + ((t & 63) + 64 * rr) * LROW + (t >> 6) * 8) = __builtin_convertvector(f, v8);
     }
   }
 }
 
-template <int AMODE, int BMODE>
+template <int AMODE, int BMODE, typename OT = __bf16>
 __global__ __launch_bounds__(256) void bmm_bf16_kernel(const BmmParams p) {
-  __shared__ __attribute__((aligned(16))) __bf16 lds[2][2][BT * LROW];   // [buffer][A | B][row][k]
+  typedef typename bmm_ops<OT>::v8 v8;
+  __shared__ __attribute__((aligned(16))) OT lds[2][2][BT * LROW];   // [buffer][A | B][row][k]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int i = lane & 31, h = lane >> 5;
   const int b = blockIdx.x / p.mtiles, mt = blockIdx.x - b * p.mtiles;
@@ -167,19 +180,19 @@ __global__ __launch_bounds__(256) void bmm_bf16_kernel(const BmmParams p) {
       bmm_load_block<AMODE>(Ab, p.sAm, p.sAk, p.M, m0, (kb + 1) * BK, p.K, va);
       bmm_load_block<BMODE>(Bb, p.sBn, p.sBk, p.N, n0, (kb + 1) * BK, p.K, vb);
     }
-    const __bf16* ta = lds[cur][0];
-    const __bf16* tb = lds[cur][1];
+    const OT* ta = lds[cur][0];
+    const OT* tb = lds[cur][1];
 #pragma unroll
     for (int ks = 0; ks < 2; ++ks) {
-      bf16x8_t fa[2], fb[2];
+      v8 fa[2], fb[2];
 #pragma unroll
-      for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const bf16x8_t*>(ta + (wm + 32 * x + i) * LROW + ks * 16 + 8 * h);
+      for (int x = 0; x < 2; ++x) fa[x] = *reinterpret_cast<const v8*>(ta + (wm + 32 * x + i) * LROW + ks * 16 + 8 * h);
 #pragma unroll
-      for (int y = 0; y < 2; ++y) fb[y] = *reinterpret_cast<const bf16x8_t*>(tb + (wn + 32 * y + i) * LROW + ks * 16 + 8 * h);
+      for (int y = 0; y < 2; ++y) fb[y] = *reinterpret_cast<const v8*>(tb + (wn + 32 * y + i) * LROW + ks * 16 + 8 * h);
 #pragma unroll
       for (int x = 0; x < 2; ++x)
 #pragma unroll
-        for (int y = 0; y < 2; ++y) acc[x][y] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[x], fb[y], acc[x][y], 0, 0, 0);
+        for (int y = 0; y < 2; ++y) acc[x][y] = bmm_ops<OT>::mfma(fa[x], fb[y], acc[x][y]);
     }
     if (more) {
       bmm_store_block<AMODE>(lds[cur ^ 1][0], va);
@@ -289,6 +302,25 @@ __global__ __launch_bounds__(256) void softmax_bwd_wave_kernel(const float* __re
   }
 }
 
+template <typename OT>
+int bmm16_launch(const char* name, const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
+                        int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta, sfStream stream) {
+  SF_REQUIRE(A && B && C && batch >= 0 && M >= 0 && N >= 0 && K >= 1, "%s: null operand or bad extents (%d x %d x %d, batch %d)", name, M, N, K, batch);
+  if (batch == 0 || M == 0 || N == 0) return 0;
+  BmmParams p{A, B, C, sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn, batch, M, N, K, (M + BT - 1) / BT, alpha, beta};
+  SF_REQUIRE((long long)batch * p.mtiles < 2147483647LL && (N + BT - 1) / BT <= 65535, "%s: grid too large", name);
+  const bool avec = sAk == 1 && ((uintptr_t)A & 15) == 0 && sAb % 4 == 0 && sAm % 4 == 0 && K % 4 == 0;
+  const bool bvec = sBk == 1 && ((uintptr_t)B & 15) == 0 && sBb % 4 == 0 && sBn % 4 == 0 && K % 4 == 0;
+  dim3 grid((unsigned)(batch * p.mtiles), (N + BT - 1) / BT), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (avec && bvec) hipLaunchKernelGGL((bmm_bf16_kernel<0, 0, OT>), grid, block, 0, st, p);
+  else if (avec) hipLaunchKernelGGL((bmm_bf16_kernel<0, 1, OT>), grid, block, 0, st, p);
+  else if (bvec) hipLaunchKernelGGL((bmm_bf16_kernel<1, 0, OT>), grid, block, 0, st, p);
+  else hipLaunchKernelGGL((bmm_bf16_kernel<1, 1, OT>), grid, block, 0, st, p);
+  SF_CHECK_LAUNCH(name);
+  return 0;
+}
+
 }  // namespace
 
 extern "C" {
@@ -313,20 +345,12 @@ int sf_bmm_f32(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const floa
 
 int sf_bmm_bf16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C, int64_t sCb, int64_t sCm,
                 int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta, sfStream stream) {
-  SF_REQUIRE(A && B && C && batch >= 0 && M >= 0 && N >= 0 && K >= 1, "sf_bmm_bf16: null operand or bad extents (%d x %d x %d, batch %d)", M, N, K, batch);
-  if (batch == 0 || M == 0 || N == 0) return 0;
-  BmmParams p{A, B, C, sAb, sAm, sAk, sBb, sBk, sBn, sCb, sCm, sCn, batch, M, N, K, (M + BT - 1) / BT, alpha, beta};
-  SF_REQUIRE((long long)batch * p.mtiles < 2147483647LL && (N + BT - 1) / BT <= 65535, "sf_bmm_bf16: grid too large");
-  const bool avec = sAk == 1 && ((uintptr_t)A & 15) == 0 && sAb % 4 == 0 && sAm % 4 == 0 && K % 4 == 0;
-  const bool bvec = sBk == 1 && ((uintptr_t)B & 15) == 0 && sBb % 4 == 0 && sBn % 4 == 0 && K % 4 == 0;
-  dim3 grid((unsigned)(batch * p.mtiles), (N + BT - 1) / BT), block(256);
-  hipStream_t st = (hipStream_t)stream;
-  if (avec && bvec) hipLaunchKernelGGL((bmm_bf16_kernel<0, 0>), grid, block, 0, st, p);
-  else if (avec) hipLaunchKernelGGL((bmm_bf16_kernel<0, 1>), grid, block, 0, st, p);
-  else if (bvec) hipLaunchKernelGGL((bmm_bf16_kernel<1, 0>), grid, block, 0, st, p);
-  else hipLaunchKernelGGL((bmm_bf16_kernel<1, 1>), grid, block, 0, st, p);
-  SF_CHECK_LAUNCH("bmm_bf16");
-  return 0;
+  return bmm16_launch<__bf16>("sf_bmm_bf16", A, sAb, sAm, sAk, B, sBb, sBk, sBn, C, sCb, sCm, sCn, batch, M, N, K, alpha, beta, stream);
+}
+
+int sf_bmm_f16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C, int64_t sCb, int64_t sCm,
+               int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta, sfStream stream) {
+  return bmm16_launch<_Float16>("sf_bmm_f16", A, sAb, sAm, sAk, B, sBb, sBk, sBn, C, sCb, sCm, sCn, batch, M, N, K, alpha, beta, stream);
 }
 
 int sf_softmax_rows_fwd(const float* x, int64_t rows, int32_t L, float* y, sfStream stream) {

@@ -19,11 +19,25 @@
 
 #include "conv_common.h"
 
+// The 16-bit OPERAND type is a compile-time choice of this translation unit: __bf16 here, _Float16 when the file is included by conv3x3_f16.hip
+// (SF_OPERAND_F16: the `precision: 16` of the reference's configs/trainer/half.yaml:33 - fp16 MFMA operands, fp32 accumulate, fp32 storage).  The f16
+// build renames the three launch entry points (sf_launch_conv_f16 / sf_conv_f16_tiles / sf_pack_weights_f16) and never takes the persistent kernels.
+#ifdef SF_OPERAND_F16
+#define SF_OP_T _Float16
+#define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define sf_launch_conv_bf16 sf_launch_conv_f16
+#define sf_conv_bf16_tiles sf_conv_f16_tiles
+#define sf_pack_weights_bf16 sf_pack_weights_f16
+#else
+#define SF_OP_T __bf16
+#define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+
 namespace {
 
 using namespace sfconv;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef SF_OP_T bf16x8 __attribute__((ext_vector_type(8)));  // eight operands of the translation unit's 16-bit type
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 
 constexpr int HALO_W = TILE_W + 2;  // 18
@@ -364,8 +378,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
         for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
           for (int mf = 0; mf < 2; ++mf)
-            acc[mf][nf] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb1[nf], fa[tap & 1][mf], acc[mf][nf], 0, 0, 0)
-                             : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb1[nf], acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = TR ? SF_MFMA_32X32X16(fb1[nf], fa[tap & 1][mf], acc[mf][nf])
+                             : SF_MFMA_32X32X16(fa[tap & 1][mf], fb1[nf], acc[mf][nf]);
           if (tap + 1 < 9) fb1[nf] = load_b(tap + 1, nf);
         }
         if (tap + 1 < 9) {   // 2 MFMAs, then reads and MFMAs alternate: every read sits behind the MFMAs that free its registers
@@ -400,8 +414,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 #ifdef SF_EXP_NOMFMA   // ablation: the fragment reads stay (one cheap use each), the matrix instructions go
           acc[mf][nf][0] += (float)fb[tap & 1][nf][0] + (float)fa[tap & 1][mf][0];
 #else
-          acc[mf][nf] = TR ? __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][nf], fa[tap & 1][mf], acc[mf][nf], 0, 0, 0)
-                           : __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf], 0, 0, 0);
+          acc[mf][nf] = TR ? SF_MFMA_32X32X16(fb[tap & 1][nf], fa[tap & 1][mf], acc[mf][nf])
+                           : SF_MFMA_32X32X16(fa[tap & 1][mf], fb[tap & 1][nf], acc[mf][nf]);
 #endif
       // scheduling: one LDS read (the next tap's operands) after each of the first MFMAs of this tap, the remaining
       // MFMAs behind them - a clump of 2+NF reads between two MFMA groups measured 2 % (NF=4) to 15 % (NF=5) slower
@@ -476,7 +490,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 
 // ---- weight repack (bf16 LDS image) ----------------------------------------------------------
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int I, const int* __restrict__ nmap, int Np,
-                                         const int* __restrict__ kmap, int Kp, int NB, int transpose, __bf16* __restrict__ packed,
+                                         const int* __restrict__ kmap, int Kp, int NB, int transpose, SF_OP_T* __restrict__ packed,
                                          const float* __restrict__ bias, float* __restrict__ bias_packed, const float* __restrict__ kscale, int groups) {
   const size_t image = (size_t)Np * Kp * 9, total = image * groups;
   const int chunks = Kp / KC;
@@ -497,7 +511,7 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int
     // physical position: the two 8-element halves of a row are swapped on rows with bit 3 set
     const int half = (k16 >> 3) ^ ((row >> 3) & 1);
     const size_t base = e - k16;
-    packed[base + half * 8 + (k16 & 7)] = (__bf16)v;
+    packed[base + half * 8 + (k16 & 7)] = (SF_OP_T)v;
   }
   if (bias_packed && blockIdx.x == 0)
     for (int i = threadIdx.x; i < Np; i += blockDim.x) {
@@ -585,8 +599,15 @@ int sf_conv_bf16_tiles(int h, int w) {
 
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st) {
   // large single-source bf16-stored launches: one persistent workgroup per CU (SF_NO_PERSIST_CONV=1: A/B switch)
+#ifndef SF_OPERAND_F16
   static const bool no_persist = getenv("SF_NO_PERSIST_CONV") != nullptr;
   if (!no_persist && !p.split_c && sf_conv_bf16_persist_ok(p, epi, nf)) return sf_launch_conv_bf16_persist(p, nf, nblk, st);
+#else
+  if (p.bf0 || p.bf1 || p.out_bf || p.stats || p.bias_tab || p.bnb_coef || epi == EPI_LSTM || epi == EPI_GRU) {
+    sf_set_error("f16 conv: fp32-stored tensors, linear / sigmoid epilogue only");
+    return 1;
+  }
+#endif
   switch (epi) {
     case EPI_LINEAR: return launch_e<EPI_LINEAR>(p, nf, nblk, st);
     case EPI_SIGMOID: return launch_e<EPI_SIGMOID>(p, nf, nblk, st);
@@ -602,5 +623,5 @@ void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np,
   const size_t total = (size_t)Np * Kp * 9 * groups;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, O, I, nmap, Np, kmap, Kp, NB, transpose,
-                     (__bf16*)packed, bias, bias_packed, kscale, groups);
+                     (SF_OP_T*)packed, bias, bias_packed, kscale, groups);
 }

@@ -286,12 +286,12 @@ size_t sf_conv3x3_packed_elems(int32_t Np, int32_t Kp) { return (size_t)Np * Kp 
 int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t* nmap, int32_t Np, const int32_t* kmap,
                             int32_t Kp, int32_t nf, int32_t transpose, void* packed, const float* bias,
                             float* bias_packed, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_pack_weights: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16, "sf_conv3x3_pack_weights: dtype %d not built", dtype);
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0, "pack: Np=%d must be a multiple of 32*nf (nf=%d)", Np, nf);
   SF_REQUIRE(Kp % KC == 0, "pack: Kp=%d must be a multiple of %d", Kp, KC);
-  if (dtype == SF_BF16) {
-    sf_pack_weights_bf16(w, O, I, nmap, Np, kmap, Kp, 32 * nf, transpose, packed, bias, bias_packed, (hipStream_t)stream);
-    SF_CHECK_LAUNCH("pack_weights_bf16");
+  if (dtype == SF_BF16 || dtype == SF_F16) {
+    (dtype == SF_BF16 ? sf_pack_weights_bf16 : sf_pack_weights_f16)(w, O, I, nmap, Np, kmap, Kp, 32 * nf, transpose, packed, bias, bias_packed, (hipStream_t)stream, nullptr, 1);
+    SF_CHECK_LAUNCH("pack_weights (16-bit)");
     return 0;
   }
   const size_t total = (size_t)Np * Kp * 9;
@@ -305,7 +305,7 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
 static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
                             const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, float* stats, int32_t dtype,
                             sfStream stream, int32_t fold_groups = 0) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_conv3x3_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16, "sf_conv3x3_fwd: dtype %d not built", dtype);
   if (check_src(src0, "conv3x3 src0") || check_src(src1, "conv3x3 src1")) return 1;
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && out.c <= Np, "conv3x3: bad Np=%d nf=%d out.c=%d", Np, nf, out.c);
   ConvParams p{};
@@ -318,19 +318,20 @@ static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, 
   const int nblk = Np / (32 * nf);
   p.bf0 = src0.ptr && src0.dtype == SF_BF16; p.bf1 = src1.ptr && src1.dtype == SF_BF16; p.out_bf = out.dtype == SF_BF16;
   SF_REQUIRE(dtype == SF_BF16 || !(p.bf0 || p.bf1 || p.out_bf), "conv3x3: bf16-stored tensors need the SF_BF16 kernel");
+  SF_REQUIRE(dtype != SF_F16 || !fold_groups, "conv3x3: the folded-BatchNorm launches are SF_BF16 only");
   SF_REQUIRE(!stats || (dtype == SF_BF16 && epilogue == SF_EPI_LINEAR), "conv3x3: output statistics need the SF_BF16 kernel with the linear epilogue");
   p.stats = stats; p.stats_np = Np;
   if (fold_groups) {  // bias_packed is the [groups][9][Np] border-class table, wpacked holds one image per group
     p.bias = nullptr; p.bias_tab = bias_packed; p.np = Np;
     p.wgroup = n / fold_groups; p.wgroup_bytes = (long long)Np * (src0.c + src1.c) * 9 * 2;
   }
-  if (dtype == SF_BF16) {
+  if (dtype == SF_BF16 || dtype == SF_F16) {
     SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
     // the SF_BF16 kernel stores 16-byte channel quads (fp32) / octets (bf16) per pixel
     SF_REQUIRE(out.ptr && ((uintptr_t)out.ptr & 15) == 0 && out.stride % (p.out_bf ? 8 : 4) == 0 && out.c % 8 == 0,
                "conv3x3: the SF_BF16 kernel needs a 16-byte aligned output (pointer, stride %d, channels %d)", out.stride, out.c);
     SF_REQUIRE(!bias_packed || ((uintptr_t)bias_packed & 15) == 0, "conv3x3: bias_packed must be 16-byte aligned");
-    return sf_launch_conv_bf16(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
+    return (dtype == SF_BF16 ? sf_launch_conv_bf16 : sf_launch_conv_f16)(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
   }
   if (epilogue == SF_EPI_LINEAR) return launch_conv<EPI_LINEAR>(p, nf, nblk, (hipStream_t)stream);
   if (epilogue == SF_EPI_SIGMOID) return launch_conv<EPI_SIGMOID>(p, nf, nblk, (hipStream_t)stream);
@@ -346,14 +347,15 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
 
 size_t sf_conv3x3_fwd_splitk_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t Kp, int32_t dtype) {
   int split_c;
-  if (dtype != SF_BF16) return 0;
+  if (dtype != SF_BF16 && dtype != SF_F16) return 0;
   const int s = splitk_plan(n, h, w, Np, nf, Kp, &split_c);
   return s > 1 ? (size_t)s * n * h * w * Np * sizeof(float) : 0;
 }
 
 int sf_conv3x3_fwd_splitk(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
                           sfTensor out, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_fwd_splitk: the SF_BF16 kernels only (dtype %d)", dtype);
+  SF_REQUIRE(dtype == SF_BF16 || dtype == SF_F16, "sf_conv3x3_fwd_splitk: the 16-bit operand kernels only (dtype %d)", dtype);
+  SF_REQUIRE(dtype == SF_BF16 || (src.dtype == SF_F32 && out.dtype == SF_F32), "sf_conv3x3_fwd_splitk: SF_F16 kernels take fp32-stored tensors");
   if (check_src(src, "conv3x3 split-K src")) return 1;
   SF_REQUIRE(src.ptr && src.idiv <= 1 && src.imod <= 0, "sf_conv3x3_fwd_splitk: one plain source (no image remap)");
   SF_REQUIRE(nf == 4 && Np % 128 == 0 && out.c <= Np && out.ptr && ((uintptr_t)out.ptr & 15) == 0 && out.c % 8 == 0 && out.stride % 8 == 0,
@@ -373,7 +375,7 @@ int sf_conv3x3_fwd_splitk(sfTensor src, int32_t n, int32_t h, int32_t w, const v
   p.bf0 = src.dtype == SF_BF16;
   p.stats_np = Np;
   p.split_c = split_c; p.split_out = (long long)slab;
-  if (int rc = sf_launch_conv_bf16(p, nf, Np / 128, EPI_LINEAR, (hipStream_t)stream)) return rc;
+  if (int rc = (dtype == SF_BF16 ? sf_launch_conv_bf16 : sf_launch_conv_f16)(p, nf, Np / 128, EPI_LINEAR, (hipStream_t)stream)) return rc;
   const long long pixels = (long long)n * h * w;
   const long long quads = pixels * (out.c / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,

@@ -30,7 +30,16 @@ namespace {
 
 using namespace sfwgrad;
 
-typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+// operand type of the translation unit: __bf16, or _Float16 when included by conv3x3_wgrad_f16.hip (SF_OPERAND_F16; fp32-stored tensors only)
+#ifdef SF_OPERAND_F16
+#define SF_OP_T _Float16
+#define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define sf_launch_wgrad_bf16 sf_launch_wgrad_f16
+#else
+#define SF_OP_T __bf16
+#define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0)
+#endif
+typedef SF_OP_T bf16x8 __attribute__((ext_vector_type(8)));
 typedef float f32x8 __attribute__((ext_vector_type(8)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -53,8 +62,8 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
   return __builtin_convertvector(v, bf16x8);
 }
 __device__ __forceinline__ float F(unsigned bits) { return __builtin_bit_cast(float, bits); }
-__device__ __forceinline__ unsigned bf16_bits(float x) {
-  __bf16 b = (__bf16)x;
+__device__ __forceinline__ unsigned bf16_bits(float x) {  // the 16 bits of x in the translation unit's operand type
+  SF_OP_T b = (SF_OP_T)x;
   return (unsigned)__builtin_bit_cast(unsigned short, b);
 }
 // bf16 storage: pixel j of a channel quad is {ch0 | ch1 << 16, ch2 | ch3 << 16}.  One LDS dword of channel c holds pixels
@@ -355,9 +364,9 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
           const int row = hrow - ky;
           if (row < 0 || row >= KR) continue;
           const bf16x8 a = arow[row & 3];
-          acc[ky * 3 + 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, mid), acc[ky * 3 + 1], 0, 0, 0);
-          acc[ky * 3 + 0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0], 0, 0, 0);
-          acc[ky * 3 + 2] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2], 0, 0, 0);
+          acc[ky * 3 + 1] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, mid), acc[ky * 3 + 1]);
+          acc[ky * 3 + 0] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0]);
+          acc[ky * 3 + 2] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2]);
         }
       }
       __syncthreads();

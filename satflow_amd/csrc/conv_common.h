@@ -482,6 +482,10 @@ inline int check_src(const sfTensor& t, const char* name) {
 int sf_conv_bf16_tiles(int h, int w);
 // bf16-MFMA launcher (conv3x3_bf16.hip); epi is one of sfconv::EPI_*
 int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
+// the same kernels compiled for fp16 operands (conv3x3_f16.hip; SF_F16: fp32-stored tensors, linear / sigmoid epilogue, split-K)
+int sf_launch_conv_f16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
+void sf_pack_weights_f16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
+                         void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale = nullptr, int groups = 1);
 // persistent variant for the large single-source bf16-stored launches (conv3x3_bf16_persist.hip); bit-identical results
 bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf);
 int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p, int nf, int nblk, hipStream_t st);

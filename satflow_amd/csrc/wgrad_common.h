@@ -50,3 +50,4 @@ sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int gr
 int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, float* workspace, hipStream_t st);
 // bf16-MFMA variant (conv3x3_wgrad_bf16.hip): fills the same partial slabs
 int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);
+int sf_launch_wgrad_f16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);  // fp16 operands (conv3x3_wgrad_f16.hip), fp32-stored tensors

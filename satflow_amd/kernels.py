@@ -129,7 +129,7 @@ def pack_weights(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, transpose:
     assert w.shape[2:] == (3, 3), "only 3x3 kernels are on the path"
     nmap, kmap = gm.tables(w.device)
     dt = _hip.compute_dtype()
-    packed = torch.empty(gm.Np * gm.Kp * 9, dtype=torch.bfloat16 if dt == _hip.SF_BF16 else torch.float32, device=w.device)
+    packed = torch.empty(gm.Np * gm.Kp * 9, dtype={_hip.SF_BF16: torch.bfloat16, _hip.SF_F16: torch.float16}.get(dt, torch.float32), device=w.device)
     bp = torch.empty(gm.Np, dtype=torch.float32, device=w.device) if (bias is not None and not transpose) else None
     check(
         lib().sf_conv3x3_pack_weights(
@@ -378,13 +378,14 @@ def linear_bwd_weight(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[T
 
 def bmm_raw(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: float = 0.0, lowp: bool = False) -> None:
     """``out[b] = alpha * A[b] @ B[b] + beta * out[b]`` for 3-D fp32 views with arbitrary strides.  sf_bmm_f32 (exact fp32 MFMA), or - ``lowp`` in a
-    bf16 compute mode - sf_bmm_bf16 (operands rounded to bf16 as torch.bmm's are under autocast)."""
+    16-bit compute mode - sf_bmm_bf16 / sf_bmm_f16 (operands rounded to the mode's 16-bit type as torch.bmm's are under autocast)."""
     assert A.dim() == B.dim() == out.dim() == 3 and A.dtype == B.dtype == out.dtype == torch.float32
     bsz, M, Kd = A.shape
     N = B.shape[2]
     assert B.shape[0] == bsz and B.shape[1] == Kd and out.shape == (bsz, M, N), (A.shape, B.shape, out.shape)
     sa, sb, sc = A.stride(), B.stride(), out.stride()
-    fn, name = (lib().sf_bmm_bf16, "sf_bmm_bf16") if (lowp and _hip.compute_dtype() == _hip.SF_BF16) else (lib().sf_bmm_f32, "sf_bmm_f32")
+    dt = _hip.compute_dtype() if lowp else _hip.SF_F32
+    fn, name = {_hip.SF_BF16: (lib().sf_bmm_bf16, "sf_bmm_bf16"), _hip.SF_F16: (lib().sf_bmm_f16, "sf_bmm_f16")}.get(dt, (lib().sf_bmm_f32, "sf_bmm_f32"))
     check(fn(A.data_ptr(), sa[0], sa[1], sa[2], B.data_ptr(), sb[0], sb[1], sb[2], out.data_ptr(), sc[0], sc[1], sc[2], bsz, M, N, Kd,
              alpha, beta, stream_ptr()), name)
 

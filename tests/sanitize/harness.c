@@ -38,6 +38,7 @@ int main(void) {
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, m16, SF_BF16, st));          /* misaligned output */
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, 9, a16, SF_F32, st));                       /* unknown epilogue */
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, 5, st));                /* unknown dtype */
+  REFUSED(sf_conv3x3_fwd(b16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F16, st));           /* bf16 storage with the fp16 kernels */
   REFUSED(sf_conv3x3_fwd_stats(a16, N0, 1, 8, 8, ok, 0, 32, 1, a16, ok, SF_F32, st));                /* stats need the bf16 kernels */
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 4, a16, ok, 1 << 20, SF_F32, st));         /* split-K: SF_BF16 kernels only */
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 2, a16, ok, 1 << 20, SF_BF16, st));        /* split-K: nf = 4 only */
@@ -173,6 +174,8 @@ int main(void) {
   REFUSED(sf_bmm_bf16(ok, 0, 8, 1, 0, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                  /* no B */
   REFUSED(sf_bmm_bf16(ok, 0, 8, 1, ok, 0, 8, 1, 0, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                  /* no C */
   REFUSED(sf_bmm_bf16(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                 /* empty inner dimension */
+  REFUSED(sf_bmm_f16(ok, 0, 8, 1, 0, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                   /* no B */
+  REFUSED(sf_bmm_f16(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                  /* empty inner dimension */
   REFUSED(sf_softmax_rows_fwd(ok, 4, 0, ok, st));                                                        /* empty rows */
   REFUSED(sf_softmax_rows_bwd(ok, 0, 4, 8, ok, st));                                                     /* no softmax output */
   REFUSED(sf_layernorm_chw_fwd(a64, 2, 64, 4, 12, 16, ok, ok, 1e-5f, 0, a64, st));                       /* no partial-sum buffer */

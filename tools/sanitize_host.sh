@@ -11,7 +11,7 @@ FLAGS="--offload-arch=gfx950 -O1 -g -std=c++17 -fPIC -fsanitize=address,undefine
 pids=()
 for f in satflow_amd/csrc/*.hip; do
   o=$OUT/$(basename ${f%.hip}).o
-  if [ ! -f $o ] || [ $f -nt $o ]; then $HIPCC $FLAGS -c $f -o $o & pids+=($!); fi
+  if [ ! -f $o ] || [ $f -nt $o ] || [ -n "$(find satflow_amd/csrc include -name '*.h' -newer $o 2>/dev/null)" ] || [ -n "$(find satflow_amd/csrc -name '*.hip' -newer $o 2>/dev/null)" ]; then $HIPCC $FLAGS -c $f -o $o & pids+=($!); fi
   if [ ${#pids[@]} -ge 6 ]; then wait ${pids[0]}; pids=("${pids[@]:1}"); fi
 done
 wait
