@@ -31,5 +31,6 @@ for f in metnet_bf16a_bench_full convlstm_bf16a_bench_full; do [ -s gpurun_out/$
 [ -s gpurun_out/${R}_parity_observed.jsonl ] && cp gpurun_out/${R}_parity_observed.jsonl profiles/${R}_parity_observed.jsonl
 [ -s gpurun_out/${R}_dgmr_bf16/prof_kernel_stats.csv ] && cp gpurun_out/${R}_dgmr_bf16/prof_kernel_stats.csv profiles/${R}_dgmr_bf16_kernel_stats.csv
 [ -s gpurun_out/${R}_dgmr_bench_full.json ] && cp gpurun_out/${R}_dgmr_bench_full.json profiles/${R}_dgmr_bf16_bench_full.json
+[ -s gpurun_out/${R}_dgmr_f16_bench.json ] && cp gpurun_out/${R}_dgmr_f16_bench.json profiles/${R}_dgmr_f16_bench.json
 [ -s gpurun_out/${R}_full_tests.log ] && cp gpurun_out/${R}_full_tests.log profiles/${R}_gpu_tests.log
 ls profiles | grep $R
