@@ -316,7 +316,7 @@ int sf_batchnorm_train_bwd_coef(const double* sums, int64_t pix_per_group, int32
  * satflow/models/layers/SpatioTemporalLSTMCell_memory_decoupling.py:20-62): per sample over all channels and pixels, affine
  * parameters gamma / beta in the reference's [C'][pixels] layout.  Activations NHWC with gate-major padded lanes: lane g*hidp + j is
  * channel g*hid + j (j < hid; pad lanes zero, excluded from the statistics).  partial: n * 32 * 2 doubles (written by _fwd, read by
- * _bwd); bwd_partial: scratch of the same size.  eps inside the square root, biased variance. */
+ * _bwd: per-sample slice sums, the finished (mean, rstd) in slice 0 - opaque to the caller); bwd_partial: scratch of the same size.  eps inside the square root, biased variance. */
 int sf_layernorm_chw_fwd(sfTensor x, int64_t n, int64_t pixels, int32_t gates, int32_t hid, int32_t hidp, const float* gamma,
                          const float* beta, float eps, double* partial, sfTensor y, sfStream stream);
 int sf_layernorm_chw_bwd(sfTensor x, sfTensor dy, int64_t n, int64_t pixels, int32_t gates, int32_t hid, int32_t hidp,

@@ -139,7 +139,8 @@ __global__ __launch_bounds__(256) void stlstm_out_bwd_kernel(const float* __rest
 // ---- nn.LayerNorm([C', W, W]) behind the cell's convolutions (layer_norm=True, reference :20-62) ---------------------------
 // Activations: NHWC with GATE-MAJOR PADDED lanes: lane l = g * hidp + j is channel g * hid + j of the reference (j < hid), pad lanes
 // are zero and take no part.  Statistics per sample over all real channels and pixels; the affine parameters keep the reference's
-// [C'][pixels] (CHW) layout.  Per sample the sums are taken by LN_SLICES workgroups in double precision; the consumers add the slices.
+// [C'][pixels] (CHW) layout.  Per sample the sums are taken by LN_SLICES workgroups in double precision; one thread per sample then adds the slices in slice order and leaves the
+// two finished per-sample values in slice 0 (ln_finalize_kernel) - every consumer reads those two values, not the 32 slices.
 #define LN_SLICES 32
 struct LnGeom { int gates, hid, hidp; long long pixels; };
 __device__ __forceinline__ int ln_channel(const LnGeom& g, int lane) {  // real channel of a lane or -1
@@ -152,14 +153,8 @@ __global__ __launch_bounds__(256) void ln_sums_kernel(const float* __restrict__ 
   __shared__ double red[2][4];
   const int lanes = g.gates * g.hidp;
   const long long n = blockIdx.y, per = (g.pixels + LN_SLICES - 1) / LN_SLICES, p0 = (long long)blockIdx.x * per, p1 = p0 + per < g.pixels ? p0 + per : g.pixels;
-  const double cnt = (double)g.pixels * g.gates * g.hid;
   float mean = 0.f, rstd = 0.f;
-  if (dy) {
-    double s0 = 0, s1 = 0;
-    for (int k = 0; k < LN_SLICES; ++k) { s0 += fwd_partial[(n * LN_SLICES + k) * 2]; s1 += fwd_partial[(n * LN_SLICES + k) * 2 + 1]; }
-    const double mu = s0 / cnt, var = s1 / cnt - mu * mu;
-    mean = (float)mu; rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
-  }
+  if (dy) { mean = (float)fwd_partial[n * LN_SLICES * 2]; rstd = (float)fwd_partial[n * LN_SLICES * 2 + 1]; }  // finished by ln_finalize_kernel
   double a = 0, b = 0;
   const long long work = (p1 > p0 ? p1 - p0 : 0) * lanes;
   for (long long e = threadIdx.x; e < work; e += 256) {
@@ -181,17 +176,27 @@ __global__ __launch_bounds__(256) void ln_sums_kernel(const float* __restrict__ 
     partial[(n * LN_SLICES + blockIdx.x) * 2 + 1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
   }
 }
-__device__ __forceinline__ void ln_stats(const double* partial, long long n, double cnt, float eps, float& mean, float& rstd) {
+// One thread per sample: slices added in slice order; slice 0 then holds (mean, rstd) [mode 0] or the two backward means [mode 1], as floats widened to
+// double.  The slices 1.. keep their sums (nobody reads them afterwards).
+__global__ __launch_bounds__(64) void ln_finalize_kernel(double* __restrict__ partial, long long n_samples, double cnt, float eps, int mode) {
+  const long long n = (long long)blockIdx.x * 64 + threadIdx.x;
+  if (n >= n_samples) return;
   double s0 = 0, s1 = 0;
   for (int k = 0; k < LN_SLICES; ++k) { s0 += partial[(n * LN_SLICES + k) * 2]; s1 += partial[(n * LN_SLICES + k) * 2 + 1]; }
-  const double mu = s0 / cnt, var = s1 / cnt - mu * mu;
-  mean = (float)mu; rstd = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  float a, b;
+  if (mode == 0) {
+    const double mu = s0 / cnt, var = s1 / cnt - mu * mu;
+    a = (float)mu; b = (float)(1.0 / sqrt((var > 0 ? var : 0) + (double)eps));
+  } else { a = (float)(s0 / cnt); b = (float)(s1 / cnt); }
+  partial[n * LN_SLICES * 2] = (double)a; partial[n * LN_SLICES * 2 + 1] = (double)b;
+}
+__device__ __forceinline__ void ln_stats(const double* partial, long long n, float& a, float& b) {
+  a = (float)partial[n * LN_SLICES * 2]; b = (float)partial[n * LN_SLICES * 2 + 1];
 }
 // y = (x - mean_n) * rstd_n * gamma[c][p] + beta[c][p]  (pad lanes: 0)
 __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__ x, const double* __restrict__ partial, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, float eps, LnGeom g, long long n_samples, float* __restrict__ y) {
   const int lanes = g.gates * g.hidp;
-  const double cnt = (double)g.pixels * g.gates * g.hid;
   const long long total = n_samples * g.pixels * lanes;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int lane = (int)(e % lanes), c = ln_channel(g, lane);
@@ -199,7 +204,7 @@ __global__ __launch_bounds__(256) void ln_apply_kernel(const float* __restrict__
     float o = 0.f;
     if (c >= 0) {
       float mean, rstd;
-      ln_stats(partial, n, cnt, eps, mean, rstd);
+      ln_stats(partial, n, mean, rstd);
       o = (x[e] - mean) * rstd * gamma[(long long)c * g.pixels + p] + beta[(long long)c * g.pixels + p];
     }
     y[e] = o;
@@ -210,18 +215,15 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
                                                            const double* __restrict__ bpart, const float* __restrict__ gamma, float eps, LnGeom g,
                                                            long long n_samples, float* __restrict__ dx) {
   const int lanes = g.gates * g.hidp;
-  const double cnt = (double)g.pixels * g.gates * g.hid;
   const long long total = n_samples * g.pixels * lanes;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int lane = (int)(e % lanes), c = ln_channel(g, lane);
     const long long pp = e / lanes, p = pp % g.pixels, n = pp / g.pixels;
     float o = 0.f;
     if (c >= 0) {
-      float mean, rstd;
-      ln_stats(fpart, n, cnt, eps, mean, rstd);
-      double s0 = 0, s1 = 0;
-      for (int k = 0; k < LN_SLICES; ++k) { s0 += bpart[(n * LN_SLICES + k) * 2]; s1 += bpart[(n * LN_SLICES + k) * 2 + 1]; }
-      const float m0 = (float)(s0 / cnt), m1 = (float)(s1 / cnt);
+      float mean, rstd, m0, m1;
+      ln_stats(fpart, n, mean, rstd);
+      ln_stats(bpart, n, m0, m1);
       const float xh = (x[e] - mean) * rstd;
       o = rstd * (dy[e] * gamma[(long long)c * g.pixels + p] - m0 - xh * m1);
     }
@@ -232,7 +234,6 @@ __global__ __launch_bounds__(256) void ln_bwd_apply_kernel(const float* __restri
 __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restrict__ x, const float* __restrict__ dy, const double* __restrict__ fpart, float eps,
                                                             LnGeom g, long long n_samples, float* __restrict__ dgamma, float* __restrict__ dbeta) {
   const int lanes = g.gates * g.hidp;
-  const double cnt = (double)g.pixels * g.gates * g.hid;
   const long long total = g.pixels * lanes;
   for (long long e = (long long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long long)gridDim.x * 256) {
     const int lane = (int)(e % lanes), c = ln_channel(g, lane);
@@ -241,7 +242,7 @@ __global__ __launch_bounds__(256) void ln_bwd_params_kernel(const float* __restr
     float sg = 0.f, sb = 0.f;
     for (long long n = 0; n < n_samples; ++n) {
       float mean, rstd;
-      ln_stats(fpart, n, cnt, eps, mean, rstd);
+      ln_stats(fpart, n, mean, rstd);
       const float d = dy[n * total + e];
       sg = __builtin_fmaf(d, (x[n * total + e] - mean) * rstd, sg); sb += d;
     }
@@ -315,6 +316,8 @@ int sf_layernorm_chw_fwd(sfTensor x, int64_t n, int64_t pixels, int32_t gates, i
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_sums_kernel, dim3(LN_SLICES, (unsigned)n), dim3(256), 0, st, (const float*)x.ptr, (const float*)nullptr, (const float*)nullptr,
                      (const double*)nullptr, eps, g, partial);
+  const double cnt = (double)pixels * gates * hid;
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, partial, (long long)n, cnt, eps, 0);
   hipLaunchKernelGGL(ln_apply_kernel, dim3(grid_of(n * pixels * gates * hidp)), dim3(256), 0, st, (const float*)x.ptr, (const double*)partial, gamma, beta, eps, g,
                      (long long)n, (float*)y.ptr);
   SF_CHECK_LAUNCH("layernorm_chw_fwd");
@@ -329,6 +332,7 @@ int sf_layernorm_chw_bwd(sfTensor x, sfTensor dy, int64_t n, int64_t pixels, int
   const LnGeom g{gates, hid, hidp, (long long)pixels};
   hipStream_t st = (hipStream_t)stream;
   hipLaunchKernelGGL(ln_sums_kernel, dim3(LN_SLICES, (unsigned)n), dim3(256), 0, st, (const float*)x.ptr, (const float*)dy.ptr, gamma, partial, eps, g, bwd_partial);
+  hipLaunchKernelGGL(ln_finalize_kernel, dim3((unsigned)((n + 63) / 64)), dim3(64), 0, st, bwd_partial, (long long)n, (double)pixels * gates * hid, eps, 1);
   hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3(grid_of(n * pixels * gates * hidp)), dim3(256), 0, st, (const float*)x.ptr, (const float*)dy.ptr, partial,
                      (const double*)bwd_partial, gamma, eps, g, (long long)n, (float*)dx.ptr);
   hipLaunchKernelGGL(ln_bwd_params_kernel, dim3(grid_of(pixels * gates * hidp)), dim3(256), 0, st, (const float*)x.ptr, (const float*)dy.ptr, partial, eps, g,

@@ -35,6 +35,21 @@ Tensor = torch.Tensor
 # ----------------------------------------------------------------------------------------------
 # the unrolled 4-cell encoder-decoder as one autograd node
 # ----------------------------------------------------------------------------------------------
+_SIDE: Dict[Any, "torch.cuda.Stream"] = {}
+
+
+def _diagonal() -> bool:
+    """Diagonal (wavefront) order of the two encoder cells on two streams; ``SF_LSTM_DIAG=0`` keeps the serial order (A/B switch)."""
+    import os
+    return os.environ.get("SF_LSTM_DIAG", "0") == "1"
+
+
+def _side_stream(dev) -> "torch.cuda.Stream":
+    key = str(dev)
+    if key not in _SIDE:
+        _SIDE[key] = torch.cuda.Stream(device=dev)
+    return _SIDE[key]
+
 class _StackFn(torch.autograd.Function):
     """x ``[T*B,H,W,Cp]`` time-major -> decoder-2 hidden states ``[Tout*B,H,W,hidp]`` time-major.
 
@@ -71,9 +86,23 @@ class _StackFn(torch.autograd.Function):
             eng.step(T(inp), Hs[k][t - 1] if t else None, Cs[k][t - 1] if t else None, B, H, W, Hs[k][t], Cs[k][t],
                      Gs[k][t] if keep else None)
 
-        for t in range(T_in):
-            run(0, e1, xs[t], t)
-            run(1, e2, Hs[0][t], t)
+        if _diagonal() and T_in > 1 and not torch.cuda.is_current_stream_capturing():
+            # diagonal order (reference conv_lstm.py:176-182: encoder_2 at step t only needs encoder_1 at step t): encoder 2 runs one step
+            # behind encoder 1 on a second stream, so two cell launches are in flight and one's epilogue meets the other's K loop
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            side.wait_stream(main)
+            for t in range(T_in):
+                run(0, e1, xs[t], t)
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    run(1, e2, Hs[0][t], t)
+            main.wait_stream(side)
+        else:
+            for t in range(T_in):
+                run(0, e1, xs[t], t)
+                run(1, e2, Hs[0][t], t)
         for s in range(T_out):
             run(2, d1, Hs[1][T_in - 1] if s == 0 else Hs[3][s - 1], s)
             run(3, d2, Hs[2][s], s)
@@ -127,13 +156,40 @@ class _StackFn(torch.autograd.Function):
             # decoder 2: head gradient + (decoder 1 consumed h4[s] as its input at step s+1)
             back(3, s, last, [T(g_out[s])] + ([] if last else [dx_of(2)]))
             back(2, s, last, [dx_of(3)])
-        for t in range(T_in - 1, -1, -1):
-            last = t == T_in - 1
-            # encoder 2: at the last input step its h feeds decoder 1's first step
-            back(1, t, last, [dx_of(2)] if last else [])
-            back(0, t, last, [dx_of(1)])
-            if ctx.need_dx:
-                dxs[t].copy_(dcat[0][..., : e1.cinp])
+        if _diagonal() and T_in > 1 and not torch.cuda.is_current_stream_capturing():
+            # the same diagonal backwards: encoder 1 at step t only needs encoder 2's input gradient of step t, so it runs on a second stream
+            # while encoder 2 goes on to step t-1.  Encoder 2's [dx ; dh] scratch is double-buffered by the parity of t; it may overwrite a
+            # buffer only after encoder 1 has consumed the dx in it (two steps earlier).
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            d1pair = [dcat[1], torch.empty_like(dcat[1])]
+            side.wait_stream(main)
+            read_done: List[Optional[torch.cuda.Event]] = [None, None]
+            for t in range(T_in - 1, -1, -1):
+                last = t == T_in - 1
+                if read_done[t & 1] is not None:
+                    main.wait_event(read_done[t & 1])
+                eng = e2
+                src = ([dx_of(2)] if last else []) + ([] if last else [T(d1pair[(t + 1) & 1], hidp, widths[1] - hidp)])
+                eng.bwd_gates(src, None if last else dc[1], Gs[1][t], Cs[1][t - 1] if t else None, Cs[1][t], Gs[1][t], dc[1] if t else None)
+                eng.bwd_data(Gs[1][t], B, H, W, True, d1pair[t & 1])
+                ev = torch.cuda.Event()
+                ev.record(main)
+                side.wait_event(ev)
+                with torch.cuda.stream(side):
+                    back(0, t, last, [T(d1pair[t & 1], e2.cinp, 0)])
+                    if ctx.need_dx:
+                        dxs[t].copy_(dcat[0][..., : e1.cinp])
+                    read_done[t & 1] = torch.cuda.Event()
+                    read_done[t & 1].record(side)
+            main.wait_stream(side)  # also covers the allocator: every buffer the side stream touched is free for reuse on the main stream
+        else:
+            for t in range(T_in - 1, -1, -1):
+                last = t == T_in - 1
+                # encoder 2: at the last input step its h feeds decoder 1's first step
+                back(1, t, last, [dx_of(2)] if last else [])
+                back(0, t, last, [dx_of(1)])
+                if ctx.need_dx:
+                    dxs[t].copy_(dcat[0][..., : e1.cinp])
 
         # weight gradients: one split-K GEMM per cell over all of its timesteps (Gs now hold dz)
         grads: List[Optional[Tensor]] = []
