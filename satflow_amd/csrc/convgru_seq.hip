@@ -84,9 +84,11 @@ __device__ __forceinline__ unsigned pk(float a, float b) {
 // every step a workgroup hands the bf16 image of its boundary row to its partner through the mailbox and reads the partner's
 // into its halo row; everything else (K order, roundings, epilogue formulas, the lane that owns an element) is unchanged, so the
 // states stay bit-identical to the per-step kernel.
-template <int NBLK, bool GXBF, bool SPLIT = false>
+// F4 (SPLIT, GXBF): the counted-wait time loop for hidp = 64 with bf16 gates (see chunk4) - its own instantiation, chosen by the launcher.
+template <int NBLK, bool GXBF, bool SPLIT = false, bool F4 = false>
 __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const GruSeqParams p) {
   static_assert(!SPLIT || NBLK == 2, "the split kernel is the 8-wave layout");
+  static_assert(!F4 || (SPLIT && GXBF), "the counted-wait loop is the split kernel with a bf16 x-part");
   constexpr int MFW = SPLIT ? 1 : 2;   // M fragments per wave
   constexpr int WAVES = 4 * NBLK, THREADS = 64 * WAVES;
   constexpr int STAGE_B = NBLK * W_B;
@@ -160,7 +162,12 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
           char* dst = lds_h + (ch >> 4) * CHUNK_B + (iy * HALO + ix) * PIX_B + 16 * (((ch >> 3) & 1) ^ (iy & 1));
           *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
           if constexpr (SPLIT) {
-            if (has_partner && py[mf] == send_row && half != p.mute_half) {  // the partner's halo row: four {epoch, dword} granules, write-through
+#ifndef SF_EXP_GRU_NOSEND
+            if (has_partner && py[mf] == send_row && half != p.mute_half)
+#else
+            if (false)
+#endif
+            {  // the partner's halo row: four {epoch, dword} granules, write-through
               unsigned long long* g8 = p.mbox + mbox_slot(img, half, epoch & 1) + (ch >> 4) * 128 + px[mf] * 8 + ((ch >> 3) & 1) * 4;
               const unsigned long long tag = (unsigned long long)epoch << 32;
               __hip_atomic_store(g8 + 0, tag | sx[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -174,6 +181,9 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
   };
   // SPLIT: wave 0 sweeps the partner's granules of `epoch` (8 per lane) until every tag matches, then writes them into the halo row
   auto receive_row = [&](unsigned epoch) {
+#ifdef SF_EXP_GRU_NOPOLL
+    return;
+#endif
     if constexpr (SPLIT) {
       if (has_partner && wave == 0) {
         const unsigned long long* src = p.mbox + mbox_slot(img, half ^ 1, epoch & 1);
@@ -205,6 +215,11 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
       }
     }
   };
+#ifdef SF_EXP_GRU_STAGGER   // timing experiment: maps start up to one step apart, so that the chip does not see every workgroup's traffic at the same moment
+  if constexpr (SPLIT) {
+    for (int i = 0; i < (img % 16) * SF_EXP_GRU_STAGGER; ++i) __builtin_amdgcn_s_sleep(16);
+  }
+#endif
   __syncthreads();  // the zero fill is complete
   if (p.h0) { write_state_tile(1u); receive_row(1u); }
 
@@ -223,6 +238,70 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
   for (int g = 0; g < 4; ++g) b2[g] = p.bias ? *reinterpret_cast<const f32x4*>(p.bias + nbk * NBG + 64 + 8 * g + 4 * kh) : f32x4{0.f, 0.f, 0.f, 0.f};
 
   using GXV = typename std::conditional<GXBF, bf16x4, f32x4>::type;
+  // SPLIT with bf16 gates: a step's outputs (state + saved gates) are STORED ONE STEP LATE, in the middle of the next step's last K chunk.  Stored right
+  // after the epilogue they were the youngest vector-memory operations at the next step's first `s_waitcnt vmcnt(0)` (needed for that chunk's weights),
+  // and the whole workgroup sat out their round trip to memory every step.  The state is still in `hst` until the next epilogue; the gates wait as 32
+  // packed dwords (`pend`).  The outputs of the last step leave after the time loop.
+  constexpr int NPEND = SPLIT ? 4 : 1;
+  u32x4_t pend[NPEND][2];
+  const bool defer = SPLIT && p.gates && p.gates_bf;
+  // the counted-wait path of the time loop (see chunk4): hidp = 64, bf16 x-part, bf16 gates, outputs addressable through 32-bit buffer offsets
+  const long long out_px = (long long)p.T * p.n * img_px;
+  constexpr bool fast4 = F4;  // launcher: hidp == 64, bf16 gates present, out_px * stride * element size < 2^31 for both outputs
+  const bool sender = has_partner && half != p.mute_half && (wrow == send_row || wrow + 1 == send_row);  // this wave issues the 8 hand-off stores
+  const __amdgpu_buffer_rsrc_t rs_hs = __builtin_amdgcn_make_buffer_rsrc((void*)p.hs, 0, (int)(fast4 ? out_px * p.hs_s * 4 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc((void*)p.gates, 0, (int)(fast4 ? out_px * p.gates_s * 2 : 0), 0x00020000);
+  // Row-pair exchange (SPLIT): a lane pair (r, kh = 0 / 1) holds 2 x 16 bytes of its pixel per register pair, so a store instruction wrote 32-byte
+  // runs - and the L2 takes one request per run: the 590 k partial-line requests per step WERE the store cost (tools/ablate_gru.sh).  After one
+  // v_permlane16_swap per dword the four 16-lane rows of a register hold four consecutive 16-byte pieces of ONE pixel (rows 0 / 1 of the fragment
+  // alternate between the two result registers): 64-byte runs, half the requests.  Lane (row rho = lane >> 4, i = lane & 15) then addresses pixel
+  // (wrow + j, i) for result j and piece 2 * (rho & 1) + (rho >> 1) of the run.
+  const int rho = lane >> 4, piece = 2 * (rho & 1) + (rho >> 1);
+  bool okj[2]; long long pixj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    okj[j] = (wrow + j) < p.H && (lane & 15) < p.W;
+    pixj[j] = (long long)img * img_px + (okj[j] ? (wrow + j) * p.W + (lane & 15) : 0);
+  }
+  auto rows16 = [&](const u32x4_t& a, const u32x4_t& b, u32x4_t& r0, u32x4_t& r1) {  // (A, B) of a lane pair -> the two per-row registers
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(a[d], b[d], false, false);
+      r0[d] = sw[0]; r1[d] = sw[1];
+    }
+  };
+  auto store_pending = [&](int ts) {
+#ifdef SF_EXP_GRU_NOSTORE
+#pragma unroll
+    for (int q = 0; q < NPEND; ++q) { asm volatile("" ::"v"(pend[q][0]), "v"(pend[q][1])); }
+    return;
+#endif
+    if constexpr (SPLIT) {
+      const long long step = (long long)ts * p.n * img_px;
+#pragma unroll
+      for (int gp2 = 0; gp2 < 4; gp2 += 2) {  // state quads (g, g + 1): 16 channels = 64 bytes per pixel
+        u32x4_t r0, r1;
+        rows16(__builtin_bit_cast(u32x4_t, hst[0][gp2]), __builtin_bit_cast(u32x4_t, hst[0][gp2 + 1]), r0, r1);
+        const int ch = nbk * 32 + 8 * gp2 + 4 * piece;
+        if (okj[0] && ch < p.hidp) *reinterpret_cast<u32x4_t*>(p.hs + (step + pixj[0]) * p.hs_s + ch) = r0;
+        if (okj[1] && ch < p.hidp) *reinterpret_cast<u32x4_t*>(p.hs + (step + pixj[1]) * p.hs_s + ch) = r1;
+      }
+      const int chg = nbk * 32 + 8 * piece;
+#pragma unroll
+      for (int q = 0; q < 4; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          if (okj[j] && chg < p.hidp)
+            *reinterpret_cast<u32x4_t*>(reinterpret_cast<__bf16*>(p.gates) + (step + pixj[j]) * p.gates_s + q * p.hidp + chg) = pend[q][j];
+    }
+  };
+  u32x4_t gxr[3][2];  // SPLIT: the x-part as loaded (F4: of the NEXT step from the last chunk on)
+#ifdef SF_EXP_GRU_CLK
+  unsigned long long ph[6] = {0, 0, 0, 0, 0, 0}, stamp = wall_clock64();
+#define SF_GRU_STAMP(i) { const unsigned long long now_ = wall_clock64(); ph[i] += now_ - stamp; stamp = now_; }
+#else
+#define SF_GRU_STAMP(i) {}
+#endif
   for (int t = 0; t < p.T; ++t) {
     f32x16 acc[MFW][3];
 #pragma unroll
@@ -237,6 +316,15 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
     GXV gxv[MFW][3][4];
     const long long pix_t = ((long long)t * p.n + img) * img_px;
     auto load_gx = [&](int mf) {
+#ifdef SF_EXP_GRU_NOGX
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+#pragma unroll
+          for (int c = 0; c < 4; ++c) gxv[mf][q][g][c] = 0;
+      return;
+#endif
     {
       const long long pix = pix_t + (ok[mf] ? py[mf] * p.W + px[mf] : 0);  // clamped: loads are unconditional
 #pragma unroll
@@ -249,22 +337,73 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
         }
     }
     };
-    if constexpr (GXBF) {
+    if constexpr (GXBF && !SPLIT) {
 #pragma unroll
       for (int mf = 0; mf < MFW; ++mf) load_gx(mf);
     }
+    // SPLIT, bf16 x-part: the mirror image of the stores - six 16-byte loads per lane in 64-byte runs per pixel (rows 0 / 1 of the fragment per
+    // register), un-swapped by v_permlane16_swap into the octets of the lane pair's own pixel and by v_permlane32_swap into this lane's channel
+    // quads (twelve 8-byte loads in 16-byte runs before: twice the instructions, four times the requests)
+    auto load_gx_rows = [&]() {
+#ifdef SF_EXP_GRU_NOGX
+#pragma unroll
+      for (int q = 0; q < 3; ++q) { gxr[q][0] = u32x4_t{0, 0, 0, 0}; gxr[q][1] = u32x4_t{0, 0, 0, 0}; }
+      return;
+#endif
+      const int chg = nbk * 32 + 8 * piece < p.hidp ? nbk * 32 + 8 * piece : 0;  // clamped: loads are unconditional
+      const long long step = (long long)t * p.n * img_px;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)
+          gxr[q][j] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const __bf16*>(p.gx) + (step + pixj[j]) * p.gx_s + q * p.hidp + chg);
+    };
+    auto unpack_gx = [&]() {
+      if constexpr (GXBF && SPLIT) {
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          u32x4_t oc[2];  // octets of this lane's pixel: channels 8 * kh .. and 16 + 8 * kh ..
+          rows16(gxr[q][0], gxr[q][1], oc[0], oc[1]);
+#pragma unroll
+          for (int o = 0; o < 2; ++o) {  // octet (low quad, high quad) of the lane pair -> quads 2o and 2o + 1 of this lane
+            const auto s0 = __builtin_amdgcn_permlane32_swap(oc[o][0], oc[o][2], false, false);
+            const auto s1 = __builtin_amdgcn_permlane32_swap(oc[o][1], oc[o][3], false, false);
+            typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+            gxv[0][q][2 * o] = __builtin_bit_cast(bf16x4, u32x2_t{s0[0], s1[0]});
+            gxv[0][q][2 * o + 1] = __builtin_bit_cast(bf16x4, u32x2_t{s0[1], s1[1]});
+          }
+        }
+      }
+    };
     // SPLIT: the partner's boundary row of the state this step reads (epoch t + 1: the state after step t - 1)
     if (t > 0) receive_row((unsigned)t + 1u);
+    SF_GRU_STAMP(0)   // top of the step: accumulator clear + the partner's row
 
-    for (int ci = 0; ci < chunks; ++ci) {
+    // one K chunk; LAST = the step's last chunk, peeled out of the loop in the SPLIT kernel (straight-line code: see below)
+    auto chunk = [&](int ci, auto last_tag) {
+      constexpr bool LAST = decltype(last_tag)::value;
       const int it = t * chunks + ci, cur = it & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weights have landed (and this step's x-part, last step's stores)
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weights have landed (and everything older)
       __syncthreads();                                   // ... everybody's; the previous step's state tile writes are visible
+      if (ci == 0) SF_GRU_STAMP(1)                       // wait + barrier of the first chunk
+      else if (LAST) SF_GRU_STAMP(2)                     // chunks 0 .. n-2 and the last chunk's wait
+      if constexpr (SPLIT && LAST) {
+        // this step's x-part was requested a chunk ago and the wait above covered it: consumed HERE (the compiler's own wait for these loads lands
+        // where the counter is already zero), or its conservative wait at the epilogue's first use would also wait for the stores that follow
+        if constexpr (GXBF) unpack_gx();
+        // last step's outputs: the next vmcnt(0) is a whole chunk of MFMAs, the epilogue and the hand-off away
+        if (defer && t > 0) store_pending(t - 1);
+      }
       // the two waves of a SIMD (w, w + 4) issue the next chunk's DMA at different taps: one's MFMAs cover the other's issue stall
       const bool stage_late = NBLK == 2 && wave >= 4;
       const bool more = it + 1 < p.T * chunks;
       const int nci = ci + 1 < chunks ? ci + 1 : 0;
       if (more && !stage_late) issue_weights(nci, cur ^ 1);
+      if constexpr (GXBF && SPLIT && !LAST) {
+        // x-part of this step: requested behind the last-but-one wait, complete at the last one (under a chunk of MFMAs).  Requested at the top of
+        // the step it was the youngest operation at the first chunk's wait: an exposed round trip to HBM per step.
+        if (ci == chunks - 2) load_gx_rows();
+      }
       const char* inb = lds_h + ci * CHUNK_B + a_lane;
       const char* wb = lds + cur * STAGE_B + b_lane;
       auto load_tap = [&](int tap, bf16x8 (&a)[MFW], bf16x8 (&b)[3]) {
@@ -283,12 +422,125 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 #pragma unroll
         for (int mf = 0; mf < MFW; ++mf)
 #pragma unroll
-          for (int g = 0; g < 3; ++g)  // transposed product: D[channel][pixel] - a lane owns one pixel and channel quads
+          for (int g = 0; g < 3; ++g) {  // transposed product: D[channel][pixel] - a lane owns one pixel and channel quads
+#ifdef SF_EXP_GRU_NOMFMA
+            if (tap > 0) { asm volatile("" ::"v"(fb[tap & 1][g]), "v"(fa[tap & 1][mf])); continue; }
+#endif
             acc[mf][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][g], fa[tap & 1][mf], acc[mf][g], 0, 0, 0);
+          }
         if (tap == 3 && more && stage_late) issue_weights(nci, cur ^ 1);
       }
+    };
+    // ---- hidp = 64 (four K chunks) with bf16 x-part and bf16 gates: MetNet's configuration.  NOTHING here waits for a store or for the x-part:
+    // the 12 output stores of the previous step and the 6 x-part loads of this one are spread over the K loop (a store per tap at taps 5..7 of every
+    // chunk, a load pair at tap 4 of chunks 0..2), each behind the chunk's weight DMA, and every chunk wait is COUNTED: it leaves exactly the
+    // operations issued after the awaited weights in flight (loads and stores retire from vmcnt in order: tools/ubench/vmcnt_order.hip).  Issued in
+    // one burst, the 96 KB of stores per workgroup - 18 MB from the 192 workgroups at the same moment - held the issuing waves for 3.8 us per step
+    // (the HBM write rate), wherever in the step the burst sat (tools/ablate_gru.sh, CLK variants).  All stores are buffer stores that are ALWAYS
+    // issued (invalid lanes / the first step: an offset outside the descriptor), so the counts are static.
+    auto load_gx4 = [&](int ts) {
+      const int chg = nbk * 32 + 8 * piece;
+#pragma unroll
+      for (int q = 0; q < 3; ++q)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+#ifdef SF_EXP_GRU_NOGX   // timing only: the same instructions on one hot line per workgroup (no HBM traffic)
+          gxr[q][j] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const __bf16*>(p.gx) + (long long)img * img_px * p.gx_s + (lane & 7) * 8);
+#else
+          gxr[q][j] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const __bf16*>(p.gx) + ((long long)ts * p.n * img_px + pixj[j]) * p.gx_s + q * 64 + chg);
+#endif
+        }
+    };
+    if constexpr (F4) {
+      if (t == 0) load_gx4(0);
+    }
+    auto chunk4 = [&](auto ci_tag) {
+      if constexpr (F4) {
+        constexpr int CI = decltype(ci_tag)::value;
+        const int it = t * 4 + CI, cur = it & 1;
+        if constexpr (CI == 0) {  // younger than this chunk's weights: the last chunk's 6 loads + 3 stores and the epilogue's hand-off (8 granule stores)
+          if (t == 0) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          else if (sender) asm volatile("s_waitcnt vmcnt(17)" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(3)" ::: "memory");  // the previous chunk's stores (chunk 1: the x-part loads are older - a K loop old)
+        __syncthreads();
+        if (CI == 0) SF_GRU_STAMP(1)
+        else if (CI == 3) SF_GRU_STAMP(2)
+        if constexpr (CI == 3) unpack_gx();
+        const bool stage_late = wave >= 4;
+        const bool more = it + 1 < p.T * 4;
+        constexpr int nci = (CI + 1) & 3;
+        if (more && !stage_late) issue_weights(nci, cur ^ 1);
+        const char* inb = lds_h + CI * CHUNK_B + a_lane;
+        const char* wb = lds + cur * STAGE_B + b_lane;
+        auto load_tap = [&](int tap, bf16x8& a, bf16x8 (&b)[3]) {
+          const int ky = tap / 3, kx = tap % 3;
+          a = *reinterpret_cast<const bf16x8*>(inb + (ky * HALO + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
+#pragma unroll
+          for (int g = 0; g < 3; ++g) b[g] = *reinterpret_cast<const bf16x8*>(wb + (tap * NBG + g * 32) * PIX_B);
+        };
+        bf16x8 fa[2], fb[2][3];
+        load_tap(0, fa[0], fb[0]);
+        u32x4_t hr0, hr1;  // state quads after the row exchange (chunk 0: quads 0 / 1, and 2 / 3 for its third store; chunk 1: quads 2 / 3)
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+#pragma unroll
+          for (int g = 0; g < 3; ++g) {
+#ifdef SF_EXP_GRU_NOMFMA
+            if (tap > 0) { asm volatile("" ::"v"(fb[tap & 1][g]), "v"(fa[tap & 1])); continue; }
+#endif
+            acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][g], fa[tap & 1], acc[0][g], 0, 0, 0);
+          }
+          if (tap == 3 && more && stage_late) issue_weights(nci, cur ^ 1);
+          if constexpr (CI == 3) {
+            // the NEXT step's x-part (this step's was unpacked at the top of this chunk: the registers are free): a whole step ahead of its use;
+            // the last step reloads its own (always issued: the counts are static)
+            if (tap == 4) load_gx4(t + 1 < p.T ? t + 1 : t);
+          }
+          if (tap >= 5 && tap <= 7) {  // store k of the previous step's twelve
+            const int k = 3 * CI + tap - 5;
+            const unsigned off_bad = 0x80000000u;  // beyond both descriptors' ranges (checked by the launcher)
+            const long long stepm = (long long)(t - 1) * p.n * img_px;
+            if (k < 4) {
+              const int gp2 = k & 2, j = k & 1;
+              if (k == 0 || k == 2 || k == 3) rows16(__builtin_bit_cast(u32x4_t, hst[0][gp2]), __builtin_bit_cast(u32x4_t, hst[0][gp2 + 1]), hr0, hr1);
+              const int ch = nbk * 32 + 8 * gp2 + 4 * piece;
+#ifdef SF_EXP_GRU_NOSTORE   // timing only: the same instructions, every lane outside the descriptor's range (no traffic)
+              const unsigned off = off_bad | (unsigned)ch;
+#else
+              const unsigned off = t > 0 && okj[j] ? (unsigned)(((stepm + pixj[j]) * p.hs_s + ch) * 4) : off_bad;
+#endif
+              __builtin_amdgcn_raw_buffer_store_b128(j ? hr1 : hr0, rs_hs, (int)off, 0, 0);
+            } else {
+              const int q = (k - 4) >> 1, j = (k - 4) & 1;
+#ifdef SF_EXP_GRU_NOSTORE
+              const unsigned off = off_bad | (unsigned)q;
+#else
+              const unsigned off = t > 0 && okj[j] ? (unsigned)(((stepm + pixj[j]) * p.gates_s + q * 64 + nbk * 32 + 8 * piece) * 2) : off_bad;
+#endif
+              __builtin_amdgcn_raw_buffer_store_b128(pend[q][j], rs_g, (int)off, 0, 0);
+            }
+          }
+        }
+      }
+    };
+    if constexpr (SPLIT) {
+      if constexpr (fast4) {
+        chunk4(std::integral_constant<int, 0>{}); chunk4(std::integral_constant<int, 1>{});
+        chunk4(std::integral_constant<int, 2>{}); chunk4(std::integral_constant<int, 3>{});
+      } else {
+        if constexpr (GXBF) {
+          if (chunks < 2) load_gx_rows();  // a single chunk: no earlier wait to hide behind
+        }
+        for (int ci = 0; ci + 1 < chunks; ++ci) chunk(ci, std::false_type{});
+        chunk(chunks - 1, std::true_type{});
+      }
+    } else {
+      for (int ci = 0; ci < chunks; ++ci) chunk(ci, std::false_type{});
     }
     __syncthreads();  // every wave is done reading the state tile of step t - 1
+    SF_GRU_STAMP(3)   // the last chunk (with the deferred stores and the prefetch) + the barrier behind the K loop
 
     // ---- epilogue: gates, new state (registers), outputs, bf16 image of the new state into the tile ----
 #pragma unroll
@@ -302,10 +554,17 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
                     gn = __builtin_convertvector(gxv[mf][2][g], f32x4);
 #pragma unroll
         for (int c = 0; c < 4; ++c) {
+#ifdef SF_EXP_GRU_NOTRANS
+          const float z = 0.5f * (acc[mf][0][4 * g + c] + gz[c]);
+          const float rg = 0.5f * (acc[mf][1][4 * g + c] + gr[c]);
+          const float h2 = acc[mf][2][4 * g + c] + b2[g][c];
+          const float cand = 0.25f * sf_gru_cand_arg(gn[c], rg, h2);
+#else
           const float z = sf_sigmoid(acc[mf][0][4 * g + c] + gz[c]);
           const float rg = sf_sigmoid(acc[mf][1][4 * g + c] + gr[c]);
           const float h2 = acc[mf][2][4 * g + c] + b2[g][c];
           const float cand = sf_tanh(sf_gru_cand_arg(gn[c], rg, h2));
+#endif
           zz[g][c] = z; rr[g][c] = rg; nn[g][c] = cand; hh2[g][c] = h2;
           hst[mf][g][c] = sf_gru_blend(z, cand, hst[mf][g][c]);
         }
@@ -319,6 +578,25 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
       // SPLIT (one M fragment per wave): the new state's bf16 image - and with it the boundary row for the partner workgroup - leaves
       // BEFORE this step's outputs are stored: the hand-off's latency then runs under the stores
       if constexpr (SPLIT) write_state_tile((unsigned)t + 2u);
+      if constexpr (SPLIT) {
+        if (defer) {  // pack the gates; they and the state are stored during the next step (or after the loop)
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            const f32x4* v = q == 0 ? zz : q == 1 ? rr : q == 2 ? nn : hh2;
+            u32x4_t oc[2];
+#pragma unroll
+            for (int g = 0; g < 4; g += 2) {
+              const unsigned ax = pk(v[g][0], v[g][1]), ay = pk(v[g][2], v[g][3]);
+              const unsigned bx = pk(v[g + 1][0], v[g + 1][1]), by = pk(v[g + 1][2], v[g + 1][3]);
+              const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+              const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+              oc[g >> 1] = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+            }
+            rows16(oc[0], oc[1], pend[q][0], pend[q][1]);
+          }
+          continue;
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g)
         if (ok[mf] && hb + 8 * g < p.hidp) *reinterpret_cast<f32x4*>(p.hs + pix * p.hs_s + hb + 8 * g) = hst[mf][g];
@@ -351,6 +629,15 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
       }
     }
     if constexpr (!SPLIT) write_state_tile((unsigned)t + 2u);
+    SF_GRU_STAMP(4)   // epilogue
+  }
+#ifdef SF_EXP_GRU_CLK
+  if (SPLIT && lane == 0 && (ticket == 100 || ticket == 101) && (wave == 0 || wave == 5))
+    printf("ticket %d wave %d: per step (ns) top+poll %.0f | chunk-0 wait %.0f | chunks 0..n-2 %.0f | last chunk %.0f | epilogue %.0f | sum %.0f\n", ticket, wave,
+           10.0 * ph[0] / p.T, 10.0 * ph[1] / p.T, 10.0 * ph[2] / p.T, 10.0 * ph[3] / p.T, 10.0 * ph[4] / p.T, 10.0 * (ph[0] + ph[1] + ph[2] + ph[3] + ph[4]) / p.T);
+#endif
+  if constexpr (SPLIT) {
+    if (defer && p.T > 0) store_pending(p.T - 1);
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (SPLIT) {
@@ -712,7 +999,11 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   if (!no_split && nblk == 2 && h > 8 && 2 * n <= cus && have_ws) {
     p.mbox = (unsigned long long*)workspace;
     p.spin_limit = (unsigned)g_spin_limit; p.mute_half = g_mute_half;
-    if (p.gx_bf) hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, true, true>), dim3(2 * n), dim3(512), 0, st, p);
+    const long long out_px = (long long)T * n * h * w;
+    static const bool no_f4 = getenv("SF_GRU_NO_F4") != nullptr;  // A/B switch: the vmcnt(0) time loop with the outputs stored in one burst
+    const bool f4 = !no_f4 && p.gx_bf && p.gates_bf && hidp == 64 && out_px * p.hs_s * 4 < (1ll << 31) && out_px * p.gates_s * 2 < (1ll << 31);
+    if (f4) hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, true, true, true>), dim3(2 * n), dim3(512), 0, st, p);
+    else if (p.gx_bf) hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, true, true>), dim3(2 * n), dim3(512), 0, st, p);
     else hipLaunchKernelGGL((convgru_seq_fwd_kernel<2, false, true>), dim3(2 * n), dim3(512), 0, st, p);
     SF_CHECK_LAUNCH("convgru_seq_fwd (split)");
     return 0;

@@ -124,3 +124,26 @@ def test_model_vs_oracle_no_grad(device):
         out = net(x.to(device), 3)
     assert out.shape == ref.shape
     assert_close(out, ref, "pred (no_grad)")
+
+
+@pytest.mark.parametrize("case", ["cfg1_h32_hot", "rect_h16_o12"])
+def test_diagonal_encoder_schedule_is_bit_identical(device, case, monkeypatch):
+    """SF_LSTM_DIAG=1 (encoder cell 2 one step behind encoder cell 1 on a second stream, forward and backward; reference
+    conv_lstm.py:176-182 only orders them within a time step) runs the same launches on the same operands: predictions, the input
+    gradient and every parameter gradient must be bit-identical to the serial order."""
+    G = _load(f"convlstm_model_{case}.npz")
+
+    def run(diag):
+        monkeypatch.setenv("SF_LSTM_DIAG", "1" if diag else "0")
+        m, fs = _model_from_golden(G, device)
+        x = G["x"].to(device).requires_grad_()
+        pred = m(x, fs)
+        (pred * G["cot"].to(device)).sum().backward()
+        torch.cuda.synchronize()
+        return pred.detach(), x.grad, {k: p.grad.clone() for k, p in m.model.named_parameters()}
+
+    p0, dx0, g0 = run(False)
+    p1, dx1, g1 = run(True)
+    assert torch.equal(p0, p1) and torch.equal(dx0, dx1)
+    for k in g0:
+        assert torch.equal(g0[k], g1[k]), k
