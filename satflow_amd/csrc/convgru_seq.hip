@@ -684,9 +684,12 @@ constexpr int BP_CHUNK_B = (256 + 1) * PIX_B;  // 256 pixels + one zero pixel pe
 // wave owns ONE 32-pixel fragment x ONE 32-channel fragment (NFW = 1), still 8 waves.  After the gate backward of a step the bf16
 // dgh values of the workgroup's boundary row go to the partner through the mailbox (12 K chunks x 16 pixels x 2 octets x 4 dwords
 // = 1536 granules) and the partner's row lands in the tile before the K loop; everything else is unchanged (bit-identical results).
-template <int NFR, int MFW, bool SPLIT = false>
+// CW (SPLIT): counted waits - the step's 12 output stores and the next step's 24 loads are spread over the K loop (four per chunk, each behind the
+// chunk's weight DMA), no chunk wait covers them (see the forward kernel's chunk4 for the measurements behind this).
+template <int NFR, int MFW, bool SPLIT = false, bool CW = false>
 __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(const GruSeqBwdParams p) {
   static_assert(!SPLIT || (NFR == 2 && MFW == 1), "the split kernel is the hidp = 64, one-fragment-per-wave layout");
+  static_assert(!CW || SPLIT, "counted waits: the split kernel");
   constexpr int NFW = SPLIT ? 1 : NFR;  // channel fragments per wave
   constexpr int HID = 32 * NFR, CHUNKS = 3 * HID / 16;
   constexpr int WB = 9 * HID * PIX_B;          // weights of one chunk
@@ -789,11 +792,159 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
         }
     }
   };
-  request(p.T - 1);
+  if constexpr (!CW) request(p.T - 1);
+  // ---- CW: state of the spread stores / loads ----
+  // rows of the fragment per register after v_permlane16_swap (64-byte runs per pixel, see the forward kernel): lane (rho = lane >> 4, i = lane & 15)
+  // addresses pixel (wrow + j, i) for register j and 16-byte piece 2 * (rho & 1) + (rho >> 1) of the wave's 32 channels
+  const int rho = lane >> 4, piece = 2 * (rho & 1) + (rho >> 1);
+  bool okj[2]; long long pixj[2];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    okj[j] = (wrow + j) < p.H && (lane & 15) < p.W;
+    pixj[j] = (long long)img * img_px + (okj[j] ? (wrow + j) * p.W + (lane & 15) : 0);
+  }
+  u32x4_t pendb[4][2];   // az, ar, an, d2 of the step just processed, per fragment row
+  f32x4 gsv[4];          // g_seq of the step about to be processed (CW: loaded inside the K loop)
+  const long long out_px = (long long)p.T * step_px;
+  const __amdgpu_buffer_rsrc_t rs_dgx = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgx, 0, (int)(CW ? out_px * p.dgx_s * 2 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_dgh = __builtin_amdgcn_make_buffer_rsrc((void*)p.dgh, 0, (int)(CW ? out_px * p.dgh_s * 2 : 0), 0x00020000);
+  const bool sender = has_partner && half != p.mute_half && (wrow == send_row || wrow + 1 == send_row);  // this wave issues the 24 hand-off stores
+  const __amdgpu_buffer_rsrc_t rs_gates = __builtin_amdgcn_make_buffer_rsrc((void*)p.gates, 0, (int)(CW ? out_px * p.gates_s * 2 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_hsb = __builtin_amdgcn_make_buffer_rsrc((void*)p.hs, 0, (int)(CW ? out_px * p.hs_s * 4 : 0), 0x00020000);
+  const __amdgpu_buffer_rsrc_t rs_gs = __builtin_amdgcn_make_buffer_rsrc((void*)p.g_seq, 0, (int)(CW && p.g_seq ? out_px * p.gs_s * 4 : 0), 0x00020000);
+  unsigned pxl32 = (unsigned)pix_i[0];   // this lane's pixel (within the step), laundered per chunk in the K loop
+  unsigned pxj32[2] = {(unsigned)pixj[0], (unsigned)pixj[1]};
+  // store k (0..11) of step ts: dgx = [az | ar | an], dgh = [az | ar | d2]
+  auto store_k = [&](int k, int ts) {
+    const int qs = k < 8 ? k >> 2 : (k < 10 ? 2 : 3), j = k & 1;
+    const bool to_dgh = k < 8 ? ((k >> 1) & 1) : k >= 10;
+    const int qd = qs == 3 ? 2 : qs;
+    const int chg = nf0 * 32 + 8 * piece;
+    const int stride = to_dgh ? p.dgh_s : p.dgx_s;
+    const unsigned bad = 0x80000000u;
+#ifdef SF_EXP_GRU_NOSTORE
+    const unsigned off = bad | (unsigned)k;
+    (void)chg; (void)qd;
+#else
+    const unsigned off = okj[j] ? (unsigned)((pxj32[j] * stride + qd * HID + chg) * 2) : bad;
+#endif
+    __builtin_amdgcn_raw_buffer_store_b128(pendb[qs][j], to_dgh ? rs_dgh : rs_dgx, (int)off, (int)(unsigned)((long long)ts * step_px * stride * 2), 0);
+  };
+  // load k (0..15) for step ts (clamped at 0; always issued): 0..7 the saved gates as loaded - gate k >> 1, fragment row k & 1, 16 bytes per lane in
+  // 64-byte runs per pixel (the mirror image of the stores; unpacked by the gate backward) -, 8..11 h_{ts-1}, 12..15 g_seq_ts
+  u32x4_t gvr[4][2];
+  auto load_k = [&](int k, int ts) {
+    const int tc = ts > 0 ? ts : 0;
+    const int g = k & 3;
+#ifdef SF_EXP_GRU_NOGX   // timing only: one hot line per workgroup
+    const long long hot = (long long)img * img_px;
+    if (k < 8) gvr[k >> 1][k & 1] = *reinterpret_cast<const u32x4_t*>(p.gates + hot * p.gates_s + (lane & 7) * 8);
+    else if (k < 12) hp[0][0][g] = *reinterpret_cast<const f32x4*>(p.hs + hot * p.hs_s + (lane & 15) * 4);
+    else gsv[g] = *reinterpret_cast<const f32x4*>(p.hs + hot * p.hs_s + (lane & 15) * 4);
+    (void)tc;
+#else
+    // descriptor + per-lane 32-bit offset rebuilt from the (per-chunk laundered) pixel index + scalar step offset: no per-lane addresses kept across the loop
+    const unsigned so_g = (unsigned)(tc * step_px * p.gates_s * 2), so_h = (unsigned)((tc > 0 ? tc - 1 : 0) * step_px * p.hs_s * 4);
+    const unsigned cl = (unsigned)(nf0 * 32 + cq);
+    if (k < 8) gvr[k >> 1][k & 1] = __builtin_bit_cast(u32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs_gates, (int)((pxj32[k & 1] * p.gates_s + (k >> 1) * HID + nf0 * 32 + 8 * piece) * 2), (int)so_g, 0));
+    else if (k < 12) hp[0][0][g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_hsb, (int)((pxl32 * p.hs_s + cl + 8 * g) * 4), (int)so_h, 0));
+    else if (p.g_seq) gsv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_gs, (int)((pxl32 * p.gs_s + cl + 8 * g) * 4), (int)(unsigned)(tc * step_px * p.gs_s * 4), 0));
+    else gsv[g] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_hsb, (int)((pxl32 * p.hs_s + cl + 8 * g) * 4), (int)so_h, 0));
+#endif
+  };
+  if constexpr (CW) {
+#pragma unroll
+    for (int k = 0; k < 12; ++k) load_k(k, p.T - 1);  // the first step's gates and previous state (its g_seq is part of dh already)
+  }
+#ifdef SF_EXP_GRU_CLK
+  unsigned long long bph[6] = {0, 0, 0, 0, 0, 0}, bstamp = wall_clock64();
+#define SF_GRUB_STAMP(i) { const unsigned long long now_ = wall_clock64(); bph[i] += now_ - bstamp; bstamp = now_; }
+#else
+#define SF_GRUB_STAMP(i) {}
+#endif
 
   for (int t = p.T - 1; t >= 0; --t) {
     // ---- gate backward of step t ----
     f32x4 dd[MFW][NFW][4];
+    if constexpr (CW) {
+      // the same arithmetic, two channel quads (one octet per gate) at a time: at most 40 fp32 results are live before they are packed (all 80 at
+      // once pushed the 256-register budget of two waves per SIMD into scratch once the packed octets have to survive into the K loop)
+      u32x4_t octs[4][2];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // saved gates: rows of the fragment -> octets of this lane pair's pixel -> this lane's channel quads
+        u32x4_t oc[2];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(gvr[q][0][d], gvr[q][1][d], false, false);
+          oc[0][d] = sw[0]; oc[1][d] = sw[1];
+        }
+#pragma unroll
+        for (int o = 0; o < 2; ++o) {
+          const auto s0 = __builtin_amdgcn_permlane32_swap(oc[o][0], oc[o][2], false, false);
+          const auto s1 = __builtin_amdgcn_permlane32_swap(oc[o][1], oc[o][3], false, false);
+          typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+          gv[0][q][0][2 * o] = __builtin_bit_cast(bf16x4, u32x2_t{s0[0], s1[0]});
+          gv[0][q][0][2 * o + 1] = __builtin_bit_cast(bf16x4, u32x2_t{s0[1], s1[1]});
+        }
+      }
+#pragma unroll
+      for (int gp = 0; gp < 4; gp += 2) {
+        f32x4 o4[4][2];  // [az, ar, an, d2][quad of the pair]
+#pragma unroll
+        for (int gi = 0; gi < 2; ++gi) {
+          const int g = gp + gi;
+          const f32x4 z = __builtin_convertvector(gv[0][0][0][g], f32x4), rr = __builtin_convertvector(gv[0][1][0][g], f32x4),
+                      nn = __builtin_convertvector(gv[0][2][0][g], f32x4), h2 = __builtin_convertvector(gv[0][3][0][g], f32x4);
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            const sfGruBwd o = sf_gru_bwd(dh[0][0][g][c], z[c], rr[c], nn[c], h2[c], t == 0 ? 0.f : hp[0][0][g][c]);
+            o4[0][gi][c] = o.az; o4[1][gi][c] = o.ar; o4[2][gi][c] = o.an; o4[3][gi][c] = o.d2; dd[0][0][g][c] = o.dd;
+          }
+        }
+        const int ch = nf0 * 32 + 8 * (gp + kh);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const unsigned ax = pk(o4[q][0][0], o4[q][0][1]), ay = pk(o4[q][0][2], o4[q][0][3]);
+          const unsigned bx = pk(o4[q][1][0], o4[q][1][1]), by = pk(o4[q][1][2], o4[q][1][3]);
+          const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+          const u32x4_t oct = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+          octs[q][gp >> 1] = oct;
+          if (ok[0] && q != 2 && t > 0) {  // dgh = [az | ar | d2]: the next convolution's operand, and the partner's rows next to this one
+            const int k = (q == 3 ? 2 : q) * HID + ch;
+            *reinterpret_cast<u32x4_t*>(lds_t + (k >> 4) * BP_CHUNK_B + (py[0] * 16 + px[0]) * PIX_B + 16 * (((ch >> 3) & 1) ^ (py[0] & 1))) = oct;
+            if (has_partner && py[0] == send_row && half != p.mute_half) {
+              const unsigned epoch = (unsigned)(p.T - t);
+              unsigned long long* g8 = p.mbox + mbox_bwd_slot(img, half, epoch & 1) + (k >> 4) * 128 + px[0] * 8 + ((ch >> 3) & 1) * 4;
+              const unsigned long long tag = (unsigned long long)epoch << 32;
+              __hip_atomic_store(g8 + 0, tag | oct[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(g8 + 1, tag | oct[1], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(g8 + 2, tag | oct[2], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+              __hip_atomic_store(g8 + 3, tag | oct[3], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+          }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#pragma unroll
+      for (int q = 0; q < 4; ++q)  // the two octets of the lane pair -> the two fragment rows (64-byte runs)
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const auto sw = __builtin_amdgcn_permlane16_swap(octs[q][0][d], octs[q][1][d], false, false);
+          pendb[q][0][d] = sw[0]; pendb[q][1][d] = sw[1];
+        }
+      // the 12 stores leave NOW: they drain while the hand-off and the first chunk's wait keep the memory pipe idle anyway (the K loop's share of the
+      // CU's ~10 B/clk is taken by the 24 loads of the next step); the counted waits of chunks 0 and 1 leave them in flight
+      // (the polling wave's stores wait until its poll is over: the poll's own loads could only return behind them; and nobody's stores enter the CU's
+      // memory pipe before every wave's hand-off stores have - the partner workgroup is waiting for exactly those)
+#ifndef SF_EXP_GRU_NOSENDBAR
+      if (has_partner && t > 0) __syncthreads();
+#endif
+      if (!(has_partner && wave == 0) || t == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) store_k(k, t);
+      }
+    } else
 #pragma unroll
     for (int m = 0; m < MFW; ++m) {
       const long long pt = (long long)t * step_px + pix_i[m];
@@ -848,19 +999,24 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
         }
       }
     }
+    SF_GRUB_STAMP(0)  // gate backward, stores, tile writes, hand-off stores
     if (t == 0) break;
-    request(t - 1);  // arrives under the K loop
+    if constexpr (!CW) request(t - 1);  // arrives under the K loop
     if constexpr (SPLIT) {
       if (has_partner && wave == 0) {  // the partner's boundary row of dgh_t: 1536 granules, 24 per lane, swept until every tag matches
         const unsigned epoch = (unsigned)(p.T - t);
         const unsigned long long* src = p.mbox + mbox_bwd_slot(img, half ^ 1, epoch & 1);
         constexpr int PER = MBB_ROW / 64;
         unsigned v[PER];
+        // the lane id through an empty asm: the 24 LDS addresses below are recomputed per step (a v_add each) instead of being kept - and spilled -
+        // across the time loop
+        int lane_l = lane;
+        asm volatile("" : "+v"(lane_l));
         for (unsigned spins = 0;; ++spins) {
           bool all = true;
 #pragma unroll
           for (int kk = 0; kk < PER; ++kk) {
-            const int gi = lane + 64 * kk;
+            const int gi = lane_l + 64 * kk;
             const unsigned long long x = __hip_atomic_load(src + gi, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             v[kk] = (unsigned)x;
             all = all && (((gi >> 3) & 15) >= p.W || (unsigned)(x >> 32) == epoch);
@@ -871,12 +1027,19 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
         }
 #pragma unroll
         for (int kk = 0; kk < PER; ++kk) {
-          const int gi = lane + 64 * kk, ck = gi >> 7, pxl = (gi >> 3) & 15, oh = (gi >> 2) & 1, dw = gi & 3;
+          const int gi = lane_l + 64 * kk, ck = gi >> 7, pxl = (gi >> 3) & 15, oh = (gi >> 2) & 1, dw = gi & 3;
           if (pxl < p.W) *reinterpret_cast<unsigned*>(lds_t + ck * BP_CHUNK_B + (recv_row * 16 + pxl) * PIX_B + 16 * (oh ^ (recv_row & 1)) + 4 * dw) = v[kk];
         }
       }
     }
 
+    if constexpr (CW) {
+      if (has_partner && wave == 0) {
+#pragma unroll
+        for (int k = 0; k < 12; ++k) store_k(k, t);
+      }
+    }
+    SF_GRUB_STAMP(1)  // request + the partner's row
     // ---- carry = conv3x3^T(dgh_t, Wh): D[channel][pixel], K = 3 * hidp ----
     f32x16 acc[MFW][NFW];
 #pragma unroll
@@ -885,6 +1048,63 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
       for (int nf = 0; nf < NFW; ++nf)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[m][nf][i] = 0.f;
+    // CW: the K loop unrolled, every wait counted.  A CU moves ~10 bytes per clock to and from HBM (MI355X_MICROARCH.md) - 224 KB per step here,
+    // 10 us - so its memory pipe has to be busy all the time, never with a burst that the next wait sits out: the step's 12 stores are issued by the
+    // gate backward and drain during the hand-off, the 24 loads of the next step to process go two per chunk (taps 4 and 7, behind the chunk's
+    // weight DMA) through the whole K loop.  At chunk ci the awaited weights (chunk `it`) were issued two chunks ago; younger than them are the
+    // loads of chunks ci-2 and ci-1, this wave's pieces of chunk it+1 and - for ci < 2 - the gate backward's 12 stores and its hand-off stores (24
+    // in a sending wave): exactly those may stay in flight.
+    auto chunk_cw = [&](auto ci_tag) {
+      if constexpr (CW) {
+        constexpr int CI = decltype(ci_tag)::value;
+        const int it = (p.T - 1 - t) * CHUNKS + CI, cur = it % RING;
+        asm volatile("" : "+v"(pxl32), "+v"(pxj32[0]), "+v"(pxj32[1]));  // offsets derived from these are rebuilt per chunk, not kept (and spilled)
+        // loads per chunk: two in chunks 0..3 (taps 4 and 7), one in chunks 4..11 (tap 4); S2 = those of the two previous chunks (+ this step's 12 stores)
+        constexpr int SC[14] = {1, 1, 2, 2, 2, 2, 1, 1, 1, 1, 1, 1, 1, 1};  // s(ci - 2), s(ci - 1) at [ci], [ci + 1]
+        constexpr int S2 = SC[CI] + SC[CI + 1] + (CI < 2 ? 12 : 0);
+        constexpr int PW = PIECES / WAVES;
+        if (CI < 2 && t == p.T - 1) {  // the first step processed: no spread operations behind it yet - the plain count (waits for more, never less)
+          if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + 1) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW) : "memory");
+        } else if (it + 1 < total_chunks) {
+          const int extra = (many ? 1 : 0) + 2 * (CI < 2 && sender ? 1 : 0);
+          if (extra == 0) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2) : "memory");
+          else if (extra == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2 + 1) : "memory");
+          else if (extra == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2 + 24) : "memory");
+          else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2 + 25) : "memory");
+        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (CI == 0) SF_GRUB_STAMP(2)
+        const bool more = it + 2 < total_chunks;
+        const bool stage_late = wave >= 4;
+        const int nci = (CI + 2) % CHUNKS, nbuf = (it + 2) % RING;
+        if (more && !stage_late) issue_weights(nci, nbuf);
+        const char* inb = lds_t + CI * BP_CHUNK_B;
+        const char* wb = lds + cur * WB + b_lane;
+        bf16x8 fa[2], fb[2];
+        auto load_tap = [&](int tap, bf16x8& a, bf16x8& b) __attribute__((always_inline)) {
+          a = *reinterpret_cast<const bf16x8*>(inb + a_off[0][tap]);
+          b = *reinterpret_cast<const bf16x8*>(wb + (tap * HID + nf0 * 32) * PIX_B);
+        };
+        load_tap(0, fa[0], fb[0]);
+#pragma unroll
+        for (int tap = 0; tap < 9; ++tap) {
+          if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+          acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1], fa[tap & 1], acc[0][0], 0, 0, 0);
+          if (tap == 3 && more && stage_late) issue_weights(nci, nbuf);
+          if (tap == 4 || (tap == 7 && CI < 4)) {
+            const int i = CI < 4 ? 2 * CI + (tap == 7) : CI + 4;  // issue order: g_seq (needed first, by the carry sum), the saved gates, h_{t-1}
+            load_k(i < 4 ? 12 + i : i - 4, t - 1);
+          }
+        }
+      }
+    };
+    if constexpr (CW) {
+      chunk_cw(std::integral_constant<int, 0>{}); chunk_cw(std::integral_constant<int, 1>{}); chunk_cw(std::integral_constant<int, 2>{});
+      chunk_cw(std::integral_constant<int, 3>{}); chunk_cw(std::integral_constant<int, 4>{}); chunk_cw(std::integral_constant<int, 5>{});
+      chunk_cw(std::integral_constant<int, 6>{}); chunk_cw(std::integral_constant<int, 7>{}); chunk_cw(std::integral_constant<int, 8>{});
+      chunk_cw(std::integral_constant<int, 9>{}); chunk_cw(std::integral_constant<int, 10>{}); chunk_cw(std::integral_constant<int, 11>{});
+    } else
     for (int ci = 0; ci < CHUNKS; ++ci) {
       const int it = (p.T - 1 - t) * CHUNKS + ci, cur = it % RING;
       // chunk `it` has landed; chunk it + 1 (this wave's pieces of it: the youngest DMA) may stay in flight.  Counted wait: loads
@@ -895,6 +1115,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / WAVES) : "memory");
       } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // ... everybody's; the tile writes of this step are visible; stage (it + 2) % RING (chunk it - 1) is free
+      if (ci == 0) SF_GRUB_STAMP(2)  // first chunk's wait + barrier
       const bool more = it + 2 < total_chunks;
       const bool stage_late = MFW == 1 && wave >= 4;  // two waves per SIMD: they issue at different taps
       const int nci = (ci + 2) % CHUNKS, nbuf = (it + 2) % RING;
@@ -921,6 +1142,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
       }
     }
     __syncthreads();  // every wave is done reading the tile of step t
+    SF_GRUB_STAMP(3)  // K loop
 
     // dh_{t-1} = [g_seq_{t-1}] + dd_t + carry   (summation order of the per-step path: (g_seq + direct) + carry)
 #pragma unroll
@@ -931,7 +1153,8 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
           f32x4 base = dd[m][nf][g];
-          if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + ptm * p.gs_s + (nf0 + nf) * 32 + 8 * g + cq) + dd[m][nf][g];
+          if constexpr (CW) { if (p.g_seq) base = gsv[g] + dd[m][nf][g]; }
+          else if (p.g_seq) base = *reinterpret_cast<const f32x4*>(p.g_seq + ptm * p.gs_s + (nf0 + nf) * 32 + 8 * g + cq) + dd[m][nf][g];
 #pragma unroll
           for (int c = 0; c < 4; ++c) dh[m][nf][g][c] = base[c] + acc[m][nf][4 * g + c];
           if constexpr (SPLIT) {  // a hand-off timed out (flag set before the K loop's barriers): every gradient from here on is NaN
@@ -939,7 +1162,13 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
           }
         }
     }
+    SF_GRUB_STAMP(4)  // carry sum
   }
+#ifdef SF_EXP_GRU_CLK
+  if (SPLIT && lane == 0 && ticket == 100 && (wave == 0 || wave == 5))
+    printf("bwd ticket %d wave %d: per step (ns) gate backward + stores %.0f | request + poll %.0f | chunk-0 wait %.0f | K loop %.0f | carry sum %.0f | sum %.0f\n", ticket, wave,
+           10.0 * bph[0] / p.T, 10.0 * bph[1] / p.T, 10.0 * bph[2] / p.T, 10.0 * bph[3] / p.T, 10.0 * bph[4] / p.T, 10.0 * (bph[0] + bph[1] + bph[2] + bph[3] + bph[4]) / p.T);
+#endif
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   if constexpr (SPLIT) {
     if (mb_failed && lane == 0) atomicOr(reinterpret_cast<unsigned*>(p.mbox), 1u);
@@ -1060,7 +1289,13 @@ extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gate
   if (!no_split && hidp == 64 && h > 8 && 2 * n <= cus && have_ws) {  // two workgroups per map (see sf_convgru_seq_fwd)
     p.mbox = (unsigned long long*)workspace;
     p.spin_limit = (unsigned)g_spin_limit; p.mute_half = g_mute_half;
-    hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1, true>), dim3(2 * n), dim3(512), 0, st, p);
+    const long long out_px = (long long)T * n * h * w;
+    static const bool no_cw = getenv("SF_GRU_NO_F4") != nullptr;  // A/B switch, as in the forward launcher
+    if (!no_cw && out_px * p.dgx_s * 2 < (1ll << 31) && out_px * p.dgh_s * 2 < (1ll << 31) && out_px * p.gates_s * 2 < (1ll << 31) && out_px * p.hs_s * 4 < (1ll << 31) &&
+        (!p.g_seq || out_px * p.gs_s * 4 < (1ll << 31)))
+      hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1, true, true>), dim3(2 * n), dim3(512), 0, st, p);
+    else
+      hipLaunchKernelGGL((convgru_seq_bwd_kernel<2, 1, true>), dim3(2 * n), dim3(512), 0, st, p);
     SF_CHECK_LAUNCH("convgru_seq_bwd (split)");
     return 0;
   }
