@@ -438,12 +438,13 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
     // one burst, the 96 KB of stores per workgroup - 18 MB from the 192 workgroups at the same moment - held the issuing waves for 3.8 us per step
     // (the HBM write rate), wherever in the step the burst sat (tools/ablate_gru.sh, CLK variants).  All stores are buffer stores that are ALWAYS
     // issued (invalid lanes / the first step: an offset outside the descriptor), so the counts are static.
-    auto load_gx4 = [&](int ts) {
+    auto load_gx4 = [&](int ts, int lo = 0, int hi = 6) {  // loads lo .. hi-1 of the six (gate q = i >> 1, fragment row j = i & 1)
       const int chg = nbk * 32 + 8 * piece;
 #pragma unroll
       for (int q = 0; q < 3; ++q)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
+          if (2 * q + j < lo || 2 * q + j >= hi) continue;
 #ifdef SF_EXP_GRU_NOGX   // timing only: the same instructions on one hot line per workgroup (no HBM traffic)
           gxr[q][j] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const __bf16*>(p.gx) + (long long)img * img_px * p.gx_s + (lane & 7) * 8);
 #else
@@ -493,11 +494,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
             acc[0][g] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap & 1][g], fa[tap & 1], acc[0][g], 0, 0, 0);
           }
           if (tap == 3 && more && stage_late) issue_weights(nci, cur ^ 1);
-          if constexpr (CI == 3) {
-            // the NEXT step's x-part (this step's was unpacked at the top of this chunk: the registers are free): a whole step ahead of its use;
-            // the last step reloads its own (always issued: the counts are static)
-            if (tap == 4) load_gx4(t + 1 < p.T ? t + 1 : t);
-          }
+
           if (tap >= 5 && tap <= 7) {  // store k of the previous step's twelve
             const int k = 3 * CI + tap - 5;
             const unsigned off_bad = 0x80000000u;  // beyond both descriptors' ranges (checked by the launcher)
@@ -567,6 +564,17 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
 #endif
           zz[g][c] = z; rr[g][c] = rg; nn[g][c] = cand; hh2[g][c] = h2;
           hst[mf][g][c] = sf_gru_blend(z, cand, hst[mf][g][c]);
+        }
+        if constexpr (F4) {
+          // the NEXT step's x-part (this step's was unpacked at the top of the last chunk: gxr is free), its six loads spread through the gate
+          // arithmetic - the CU's memory pipe is idle here, and by the time the hand-off stores are issued below they have been taken; the last step
+          // reloads its own (always issued: the counts are static)
+          const int ts = t + 1 < p.T ? t + 1 : t;
+          if (g == 0) load_gx4(ts, 0, 2);
+          else if (g == 1) load_gx4(ts, 2, 3);
+          else if (g == 2) load_gx4(ts, 3, 5);
+          else load_gx4(ts, 5, 6);
+          __builtin_amdgcn_sched_barrier(0);
         }
       }
       if constexpr (SPLIT) {  // a hand-off of this workgroup timed out (flag set before one of the chunk barriers above): NaN from here on
