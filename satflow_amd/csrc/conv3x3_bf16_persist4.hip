@@ -182,9 +182,16 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
   };
 
-  // ---- epilogue of one fragment: 32 channels x this lane's pixel -> two 16-byte stores (always issued) ----
-  auto epi_frag = [&](const f32x16& a, __amdgpu_buffer_rsrc_t rs_out, unsigned voff, int nb_item, int nf) __attribute__((always_inline)) {
+  // ---- epilogue of one fragment: 32 channels x 32 pixels -> two 16-byte stores per lane (always issued) ----
+  // A lane pair (r, kh = 0 / 1) holds 2 x 16 bytes of its pixel per octet: stored as they are, an instruction writes 32-byte runs 512 bytes apart, and the
+  // L2 takes a request per run.  One v_permlane16_swap per dword turns the two octets of a lane pair into the two pixel ROWS of the fragment: the
+  // four 16-lane rows of a register then hold four consecutive 16-byte pieces of one pixel - 64-byte runs, half the requests (the same exchange as in
+  // convgru_seq.hip).  Lane (rho = lane >> 4, i = lane & 15) addresses pixel (row j of the fragment, i) for register j and piece
+  // 2 * (rho & 1) + (rho >> 1) of the fragment's 32 channels.
+  const int rho = lane >> 4, piece = 2 * (rho & 1) + (rho >> 1);
+  auto epi_frag = [&](const f32x16& a, __amdgpu_buffer_rsrc_t rs_out, unsigned voff0, unsigned voff1, int nb_item, int nf) __attribute__((always_inline)) {
     const int cb = nb_item * NB + nf * 32;
+    u32x4_t oc[2];
 #pragma unroll
     for (int g = 0; g < 4; g += 2) {
       // (the one-item kernel adds a zero bias vector here, which turns an accumulator that is exactly -0 into +0: the two kernels agree
@@ -196,15 +203,23 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       const unsigned bx = pk2(v[4], v[5]), by = pk2(v[6], v[7]);
       const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
       const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
-      // the octet's position goes into the SCALAR offset (an out-of-range one past out_c: voff + soff never wraps back into range)
-      const unsigned soff = cb + 8 * g < p.out_c ? (unsigned)((nf * 32 + 8 * g) * 2) : 0x40000000u;
-      __builtin_amdgcn_raw_buffer_store_b128(u32x4_t{sx[0], sy[0], sx[1], sy[1]}, rs_out, voff, soff, 0);
+      oc[g >> 1] = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
     }
+    u32x4_t r0, r1;
+#pragma unroll
+    for (int d = 0; d < 4; ++d) {
+      const auto sw = __builtin_amdgcn_permlane16_swap(oc[0][d], oc[1][d], false, false);
+      r0[d] = sw[0]; r1[d] = sw[1];
+    }
+    // the fragment's position goes into the SCALAR offset (an out-of-range one past out_c - a multiple of 32 here: voff + soff never wraps back)
+    const unsigned soff = cb < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
+    __builtin_amdgcn_raw_buffer_store_b128(r0, rs_out, voff0, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(r1, rs_out, voff1, soff, 0);
   };
-  // byte offset of this lane's pixel of fragment mf inside the item's output image (+ this N block's first octet), or the sentinel
-  auto out_voff = [&](const Item& it, int mf) __attribute__((always_inline)) -> unsigned {
-    const int py = it.y0 + 8 * wave + 2 * mf + (r >> 4), px = it.x0 + (r & 15);
-    return (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * kh) * 2) : DMA_SENT;
+  // byte offset of this lane's piece of pixel (row j of fragment mf, lane & 15) inside the item's output image (+ this N block's first channel), or the sentinel
+  auto out_voff = [&](const Item& it, int mf, int j) __attribute__((always_inline)) -> unsigned {
+    const int py = it.y0 + 8 * wave + 2 * mf + j, px = it.x0 + (lane & 15);
+    return (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * piece) * 2) : DMA_SENT;
   };
 
 #ifdef SF_EXP_W4_CLK
@@ -250,10 +265,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     const __amdgpu_buffer_rsrc_t rs_out = rs_output(it.n);
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
-      const unsigned voff = out_voff(it, mf);
+      const unsigned voff0 = out_voff(it, mf, 0), voff1 = out_voff(it, mf, 1);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
-        epi_frag(acc[mf][nf], rs_out, voff, it.nb, nf);
+        epi_frag(acc[mf][nf], rs_out, voff0, voff1, it.nb, nf);
         __builtin_amdgcn_sched_barrier(0);  // (one fragment's temporaries at a time)
       }
     }
@@ -394,7 +409,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 // image remap, bf16 output, 32-row tiles, >= 1024 tiles.)
 bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf) {
   static const bool off = getenv("SF_NO_CONV_W4") != nullptr;
-  if (off || nf != 4 || p.stats || p.bias || p.bnb_coef || p.c0 / sfconv::KC < 3 || p.src1) return false;
+  if (off || nf != 4 || p.stats || p.bias || p.bnb_coef || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
   if ((long long)p.H * p.W * p.out_s * 2 >= 0x7fffffffll || (long long)p.H * p.W * p.s0 * 2 >= 0x7fffffffll) return false;
   return true;
 }
