@@ -297,11 +297,11 @@ class MetNetWorkload:
             x = torch.randn(n, H, W, cpad(cin), device=dev).to(bf)
             y = torch.empty(n, H, W, eng.coutp, device=dev, dtype=bf)
             if fwd_plain:  # conv4 forward
-                row("conv3x3_bf16_persist4_kernel (folded BatchNorm, 4 waves x 512 registers)", "conv3x3_bf16_persist4_kernel", 1, cin, cout,
+                row("conv3x3_bf16_persist4_kernel (folded BatchNorm, 4 waves x 512 registers)", "conv3x3_bf16_persist4_kernel<0>", 1, cin, cout,
                     lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)), "DownSampler conv4 forward")
             tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
             st = torch.empty(n * tiles, gm.Np, 2, device=dev)
-            row(f"conv3x3_bf16_persist_kernel<4, STATS> {cin}->{cout}", "conv3x3_bf16_persist_kernel<4, 1>", 1, cin, cout,
+            row(f"conv3x3_bf16_persist4_kernel<STATS> {cin}->{cout} (4 waves x 512 registers, BatchNorm statistics in the epilogue)", "conv3x3_bf16_persist4_kernel<1>", 1, cin, cout,
                 lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), stats=st), f"DownSampler conv{2 if cin == 160 else 3} forward + BatchNorm statistics")
             # input gradient with the BatchNorm backward in its epilogue (dx = A conv^T(dout) + B x + K)
             need = (True,)
@@ -322,7 +322,8 @@ class MetNetWorkload:
             del x, y, dout, dx, st
         rows.sort(key=lambda r: -r["ms_per_step"])
         return {"rows": rows, "traffic_source": pmc_note,
-                "note": "launch_us of the weight-gradient rows includes the small helper kernels of sf_conv3x3_bwd_weight_folded (border sums, reduce, BatchNorm sums: ~0.15 ms)"}
+                "note": "launch_us of the weight-gradient rows includes the small helper kernels of sf_conv3x3_bwd_weight_folded (border sums, reduce, BatchNorm sums: ~0.15 ms); "
+                        "traffic = mean per launch over ALL launches of that kernel NAME in the profiled step (a name that runs at both 256->256 and 160->256 reports the mix)"}
 
     def roofline(self):
         """The kernel with the largest share of the step: the grouped weight gradient of the folded 256 -> 256 convolutions

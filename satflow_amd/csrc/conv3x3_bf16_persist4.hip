@@ -63,6 +63,17 @@ __device__ __forceinline__ float acc_read(float x) {
   return v;
 }
 #define SF_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// One level of a reduce-scatter over the 32 lanes of a half-wave: 2 * M values per lane in, M out - the lane keeps the half its bit M selects and adds
+// the partner's (lane ^ M) copy of that half.  After the levels 16, 8, 4, 2, 1 lane r holds entry r of the 32, summed over the 32 lanes.
+template <int M>
+__device__ __forceinline__ void reduce_scatter_level(float (&L)[32], int r) {
+  const bool bit = (r & M) != 0;
+#pragma unroll
+  for (int k = 0; k < M; ++k) {
+    const float keep = bit ? L[M + k] : L[k], send = bit ? L[k] : L[M + k];
+    L[k] = keep + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, send), 0x1F | (M << 10)));
+  }
+}
 
 constexpr int NF = 4, MFR = 4, NB = 32 * NF;         // fragments per wave: 4 pixel x 4 channel; 128-channel N block
 constexpr int W_B = 9 * NB * PIX_B;                   // 36864: one weight chunk
@@ -189,7 +200,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   // convgru_seq.hip).  Lane (rho = lane >> 4, i = lane & 15) addresses pixel (row j of the fragment, i) for register j and piece
   // 2 * (rho & 1) + (rho >> 1) of the fragment's 32 channels.
   const int rho = lane >> 4, piece = 2 * (rho & 1) + (rho >> 1);
-  auto epi_frag = [&](const f32x16& a, __amdgpu_buffer_rsrc_t rs_out, unsigned voff0, unsigned voff1, int nb_item, int nf) __attribute__((always_inline)) {
+  auto epi_frag = [&](const f32x16& a, __amdgpu_buffer_rsrc_t rs_out, unsigned voff0, unsigned voff1, int nb_item, int nf, float* s1 = nullptr,
+                      float* s2 = nullptr, bool own_ok = true) __attribute__((always_inline)) {
     const int cb = nb_item * NB + nf * 32;
     u32x4_t oc[2];
 #pragma unroll
@@ -201,6 +213,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       for (int i = 0; i < 8; ++i) v[i] = acc_read(a[4 * g + i]);
       const unsigned ax = pk2(v[0], v[1]), ay = pk2(v[2], v[3]);
       const unsigned bx = pk2(v[4], v[5]), by = pk2(v[6], v[7]);
+      if constexpr (MODE == 1) {  // BatchNorm statistics of the STORED (rounded) values of this lane's own pixel: channels 8g + 4kh + c and 8(g+1) + 4kh + c
+        const unsigned pk4[4] = {ax, ay, bx, by};
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const float lo = own_ok ? __builtin_bit_cast(float, pk4[i] << 16) : 0.f, hi = own_ok ? __builtin_bit_cast(float, pk4[i] & 0xffff0000u) : 0.f;
+          s1[4 * g + 2 * i] += lo; s2[4 * g + 2 * i] = __builtin_fmaf(lo, lo, s2[4 * g + 2 * i]);
+          s1[4 * g + 2 * i + 1] += hi; s2[4 * g + 2 * i + 1] = __builtin_fmaf(hi, hi, s2[4 * g + 2 * i + 1]);
+        }
+      }
       const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
       const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
       oc[g >> 1] = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
@@ -261,8 +282,54 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       }
     }
   };
-  auto epilogue = [&](const Item& it) __attribute__((always_inline)) {
+  auto epilogue = [&](const Item& it, int free_stage) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs_out = rs_output(it.n);
+    if constexpr (MODE == 1) {
+      // ---- with the BatchNorm statistics of the tile (sf_conv3x3_fwd_stats semantics: per-tile sum and sum of squares of the stored values) ----
+      // channel fragments outermost: 16 + 16 running sums per lane over its four pixels, then a reduce-scatter over the 32 lanes of a half-wave
+      // (ds_swizzle xor 16 .. 1: 31 exchanges instead of 160 for a plain butterfly of every value) that leaves entry r of
+      // [sum of the 16 channels | sum of squares] in lane r; the four waves' partial sums meet in each wave's FREE private input stage
+      // (nobody else touches it), one workgroup barrier, 256 threads add the four partials in wave order and store the tile's row,
+      // one more barrier before the stages are filled again.
+      unsigned vo0[MFR], vo1[MFR];
+      unsigned okm = 0;
+#pragma unroll
+      for (int mf = 0; mf < MFR; ++mf) {
+        vo0[mf] = out_voff(it, mf, 0); vo1[mf] = out_voff(it, mf, 1);
+        const int py = it.y0 + 8 * wave + 2 * mf + (r >> 4), px = it.x0 + (r & 15);
+        okm |= (py < p.H && px < p.W) ? 1u << mf : 0u;
+      }
+      float* part = reinterpret_cast<float*>(lds + IN0 + (wave * 2 + free_stage) * PIN_B);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        float L[32];
+#pragma unroll
+        for (int i = 0; i < 32; ++i) L[i] = 0.f;
+#pragma unroll
+        for (int mf = 0; mf < MFR; ++mf) {
+          epi_frag(acc[mf][nf], rs_out, vo0[mf], vo1[mf], it.nb, nf, L, L + 16, (okm >> mf) & 1u);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        reduce_scatter_level<16>(L, r); reduce_scatter_level<8>(L, r); reduce_scatter_level<4>(L, r); reduce_scatter_level<2>(L, r);
+        reduce_scatter_level<1>(L, r);
+        part[(nf * 2 + kh) * 32 + r] = L[0];
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      {
+        const int c = tid & 127, which = tid >> 7;
+        const int cc = c & 31, idx = (((c >> 5) * 2 + ((cc >> 2) & 1)) * 32 + which * 16 + 4 * (cc >> 3) + (cc & 3));
+        float t = 0.f;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) t += *reinterpret_cast<const float*>(lds + IN0 + (w * 2 + free_stage) * PIN_B + idx * 4);
+        const size_t tile_lin = (size_t)(it.n * p.tiles_y + it.y0 / 32) * p.tiles_x + it.x0 / TILE_W;
+        if (it.nb * NB + c < p.stats_np) p.stats[(tile_lin * p.stats_np + it.nb * NB + c) * 2 + which] = t;
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      return;
+    }
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
       const unsigned voff0 = out_voff(it, mf, 0), voff1 = out_voff(it, mf, 1);
@@ -373,7 +440,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           // pieces (and, in an item's first chunk, the previous item's 32 stores in front of them) are younger -, then everybody's; stage sw2
           // (chunk g - 1) is free behind the barrier
 #ifndef SF_EXP_W4_NOSYNC
-          if (first) SF_VMCNT(38); else SF_VMCNT(6);
+          if (first) { if constexpr (MODE == 1) SF_VMCNT(39); else SF_VMCNT(38); } else SF_VMCNT(6);
           __builtin_amdgcn_s_barrier();
 #endif
           __builtin_amdgcn_sched_barrier(0);
@@ -387,11 +454,11 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     } while (++ci < nch);
     // ---- item switch: this item's epilogue (32 stores per wave, always), the next item's accumulators ----
 #ifndef SF_EXP_W4_NOEPI
-    epilogue(cur);
+    epilogue(cur, gpar ^ 1);
     cur = nxt;
     init_acc(cur);
 #else
-    if (k + 100 == K) epilogue(cur);
+    if (k + 100 == K) epilogue(cur, gpar ^ 1);
     cur = nxt;
 #endif
   } while (++k < K);
@@ -409,7 +476,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 // image remap, bf16 output, 32-row tiles, >= 1024 tiles.)
 bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf) {
   static const bool off = getenv("SF_NO_CONV_W4") != nullptr;
-  if (off || nf != 4 || p.stats || p.bias || p.bnb_coef || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
+  static const bool no_stats = getenv("SF_NO_CONV_W4_STATS") != nullptr;  // A/B switch: statistics on the 8-wave persistent kernel
+  if (off || nf != 4 || (p.stats && no_stats) || p.bias || p.bnb_coef || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
   if ((long long)p.H * p.W * p.out_s * 2 >= 0x7fffffffll || (long long)p.H * p.W * p.s0 * 2 >= 0x7fffffffll) return false;
   return true;
 }
@@ -427,7 +495,8 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int grid = items < cus ? items : cus;
-  hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  if (p.stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;

@@ -150,3 +150,48 @@ def test_one_wave_per_simd_kernel_folded_batchnorm(device, bf16_mode, n, groups,
         yg = torch.full((ipg, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
         K.conv3x3_folded(T(x[gi * ipg:(gi + 1) * ipg].contiguous()), ipg, H, W, packed[gi * img:(gi + 1) * img], tab[gi:gi + 1].contiguous(), gm, T(yg))
         assert torch.equal(y[gi * ipg:(gi + 1) * ipg, ..., :cout], yg[..., :cout]), f"group {gi} differs"
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(1040, 4, 160, 256, 32, 32), (2304, 12, 256, 256, 32, 32), (1080, 6, 96, 128, 40, 24)])
+def test_one_wave_per_simd_kernel_statistics(device, bf16_mode, n, groups, cin, cout, H, W):
+    """The statistics-emitting launch of the one-wave-per-SIMD kernel (sf_conv3x3_fwd_folded with a stats buffer: the DownSampler's conv2 /
+    conv3 in bf16a mode): the outputs are bit-identical to the launch without statistics, and every tile's (sum, sum of squares) row equals
+    the sums of the STORED bf16 values over the tile's valid pixels (float64 on the device; fp32 summation order differs: 1e-5 of the
+    tile's sum of squares), ragged tiles included (40 x 24)."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(7 * n + cin + groups)
+    eng = ConvEngine([cin], cout)
+    gm = eng.fwd_map
+    assert gm.nf == 4
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+    scale = (0.5 + torch.rand(groups, gm.Kp, generator=g)).to(device)
+    shift = torch.randn(groups, gm.Kp, generator=g).to(device)
+    packed, tab = K.conv3x3_fold_pack(w, b, gm, scale, shift)
+    x = torch.randn(n, H, W, cpad(cin), generator=g).to(device).to(torch.bfloat16)
+    tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
+    y0 = torch.full((n, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
+    K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y0))
+    y1 = torch.full_like(y0, float("nan"))
+    st = torch.full((n * tiles, gm.Np, 2), float("nan"), device=device)
+    K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y1), stats=st)
+    torch.cuda.synchronize()
+    assert torch.equal(y0[..., :cout], y1[..., :cout])
+    # tiles: 32 rows x 16 columns, row-major over (tile row, tile column) inside an image
+    tx, ty = (W + 15) // 16, (H + 31) // 32
+    assert tiles == tx * ty
+    yd = y1[..., :cout].double()
+    ref = torch.zeros(n, ty, tx, cout, 2, dtype=torch.float64, device=device)
+    for j in range(ty):
+        for i in range(tx):
+            blk = yd[:, 32 * j:32 * j + 32, 16 * i:16 * i + 16]
+            ref[:, j, i, :, 0] = blk.sum((1, 2))
+            ref[:, j, i, :, 1] = (blk * blk).sum((1, 2))
+    got = st.view(n, ty, tx, gm.Np, 2)[..., :cout, :].double()
+    assert torch.isfinite(got).all()
+    scale_sq = ref[..., 1].abs().max().clamp_min(1.0)
+    err = (got - ref).abs().max() / scale_sq
+    assert float(err) < 1e-5, float(err)
