@@ -34,12 +34,8 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TR = 4, TW = 16;             // K tile: 4 rows x 16 pixels
 constexpr int HR = TR + 2, HW = TW + 2;    // halo tile 6 x 18
-constexpr int A_PIX = 2 * DMA_CO_T;        // 256 bytes per dout pixel
-constexpr int B_PIX = 2 * DMA_CI_T;        // 128 bytes per input pixel
-constexpr int A_BYTES = TR * TW * A_PIX;   // 16384 = 16 DMA blocks of 1 KiB
-constexpr int B_BYTES = 16384;             // 108 px x 128 B = 13824, padded to 16 DMA blocks
-constexpr int STAGE = A_BYTES + B_BYTES;
-constexpr int NS = 4;                      // ring depth (tiles): 3, 4 and 5 measured alike (the DMA's latency is covered)
+constexpr int NS_REG = 4;                  // ring depth (tiles) of the regular slab: 3, 4 and 5 measured alike (the DMA's latency is covered)
+constexpr int LDS_BYTES = NS_REG * 32768;  // regular: 4 stages x (16 KiB dout + 16 KiB input); wide: 3 x 40 KiB
 constexpr int THREADS = 512;
 
 __device__ __forceinline__ bf16x4_t tr_read(unsigned lds_addr) {
@@ -78,28 +74,28 @@ __device__ __forceinline__ void* uniform_ptr(const void* q) {
 // GROUPED (folded BatchNorm, sf_conv3x3_bwd_weight_folded): the images come in groups of p.tpg tiles whose raw gradients are
 // scaled differently afterwards, so a slice that crosses a group boundary stores its accumulators there (segment 0, 1, ...
 // of the slice: partial[ks * maxseg + seg]) and starts again from zero.
-template <bool FAST, bool GROUPED = false>
-__global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
-                                                                     const int xcd_groups) {
-  __shared__ __attribute__((aligned(1024))) char lds[NS * STAGE];
+// WIDE (FAST only): the slab geometry of the LAST ci tile when it holds at most 32 valid channels (160 = 64 + 64 + 32 input channels: conv2 of
+// MetNet's DownSampler).  With the regular geometry the four waves of the upper ci half multiply zeros - a sixth of the launch.  A wide workgroup
+// instead takes the live halves of TWO co tiles: slab 256 (co) x 32 (ci), wave w owns co fragment w of the 8 and the one ci fragment; its stage
+// holds 64 pixels x 512 bytes of dout and the halo x 64 bytes of input (40 KiB, three stages), five DMA instructions per wave and tile instead
+// of four.  Every workgroup of the launch then does the same MFMA work on live operands, and the plan cuts the K slices shorter (2.5 slab units
+// per co-tile pair instead of 3).
+template <bool FAST, bool GROUPED, bool WIDE>
+__device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int per_slice, const char* __restrict__ zero, char* lds, const int ks,
+                                               const int cot, const int cit) {
+  static_assert(!WIDE || FAST, "the wide slab uses the descriptor DMA path");
+  constexpr int A_PIX = WIDE ? 4 * DMA_CO_T : 2 * DMA_CO_T;   // bytes per dout pixel in a stage (256 / 128 channels)
+  constexpr int B_PIX = WIDE ? DMA_CI_T : 2 * DMA_CI_T;       // bytes per input pixel (32 / 64 channels)
+  constexpr int A_BYTES = TR * TW * A_PIX;                    // 32768 / 16384
+  constexpr int B_BYTES = WIDE ? 8192 : 16384;                // 108 px x 64 B = 6912 / x 128 B = 13824, padded to whole DMA blocks
+  constexpr int STAGE = A_BYTES + B_BYTES;
+  constexpr int NS = WIDE ? 3 : ::NS_REG;                     // ring depth
+  constexpr int NA = A_BYTES / 1024 / 8, NBK = B_BYTES / 1024 / 8, NDMA = NA + NBK;  // DMA instructions per wave and tile: 4 + 1 / 2 + 2
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave & 3, wc = wave >> 2;  // co fragment / ci half of this wave
-
-  // block id -> (ks, cot, cit): the (cot, cit) combinations of one K slice are consecutive on one XCD (blocks are dealt
-  // round-robin to the 8 XCDs), so a slice's tiles are shared through that XCD's L2 (pure speed choice).
-  const int combos = gridDim.y * gridDim.z;
-  int ks, cot, cit;
-  {
-    const int id = blockIdx.x + gridDim.x * (blockIdx.y + gridDim.y * blockIdx.z);
-    if (xcd_groups) {
-      const int x = id % 8, j = id / 8;
-      ks = (j / combos) * 8 + x;
-      const int combo = j % combos;
-      cot = combo % gridDim.y; cit = combo / gridDim.y;
-    } else { ks = blockIdx.x; cot = blockIdx.y; cit = blockIdx.z; }
-  }
+  const int wq = wave & 3, wc = WIDE ? 0 : wave >> 2;  // co fragment / ci half of this wave
+  const int cotw = WIDE ? wave >> 2 : 0;               // WIDE: which of the two co tiles
   // a slice owns a CONTIGUOUS run of tiles: vertically adjacent tiles re-read two halo rows, which are then L2 hits
   const int t_begin = ks * per_slice;
   const int t_end = t_begin + per_slice < p.ntiles ? t_begin + per_slice : p.ntiles;
@@ -108,7 +104,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
   // ---- per-lane constants of the DMA pieces this wave issues: dout blocks {wave, wave + 8}, input blocks {wave, wave + 8} ----
   // dout block a = pixels 4a .. 4a+3 (row a / 4, x = 4 * (a % 4) + lane / 16); piece c = lane % 16 sits in physical quarter
   // c / 4 and carries logical quarter (c / 4) ^ (pixel & 3)
-  const int a_px = lane >> 4;
+  const int a_px = lane >> 4;  // (regular geometry; the wide one has its own per-block constants in the fast path below)
   const int a_ch = cot * DMA_CO_T + ((((lane >> 2) & 3) ^ a_px) * 4 + (lane & 3)) * 8;
   const bool a_chok = a_ch < p.dc;
   const long long a_pxb = 2ll * p.ds;  // bytes per dout pixel in HBM
@@ -174,23 +170,37 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
   // tile class = (ty == 0) | (ty == tiles_y - 1) << 1 | (tx == 0) << 2 | (tx == tiles_x - 1) << 3: the validity of a piece depends
   // on the tile only through its class (first / last tile row and column: image borders and ragged edges)
   constexpr unsigned SENT = 0x80000000u;  // >= any descriptor's num_records (the launcher checks image bytes < 2^31)
-  unsigned fa_off[2] = {0, 0}, fb_off[2] = {0, 0}, fa_mask[2] = {0, 0}, fb_mask[2] = {0, 0};
+  unsigned fb_off[NBK], fb_mask[NBK];
   const bool from0 = cit * DMA_CI_T < p.c0;  // block-uniform; exact when FAST
   const float* bsrc = from0 ? p.src0 : p.src1;
   const int bs = from0 ? p.s0 : p.s1, bidiv = from0 ? p.idiv0 : p.idiv1, bimod = from0 ? p.imod0 : p.imod1;
+  // dout block a = pixels PPB * a .. of the tile (regular: 4 pixels of 256 bytes, piece lane % 16 in physical quarter (lane / 4) % 4 carrying logical
+  // quarter ^ (pixel & 3); wide: 2 pixels of 512 bytes, piece lane % 32 in physical eighth, the xor on its low two bits).  Row and first column of a
+  // block are WAVE constants (scalar offset of the DMA), the lane adds its pixel within the block and its channel piece: one per-lane offset for all
+  // of a wave's blocks, validity from two comparisons per block instead of a class mask per block (registers: the wide body holds four blocks)
+  constexpr int PPB = WIDE ? 2 : 4;
+  const int a_pl = WIDE ? lane >> 5 : lane >> 4;
+  unsigned fa_voff = 0;
   if constexpr (FAST) {
+    const int P3 = (PPB * wave + a_pl) & 3;  // (pixel & 3) of this lane's pixel: the same in every block of the wave (blocks are 8 apart)
+    const int c16 = WIDE ? lane & 31 : lane & 15, pq = c16 >> 2, lq = (pq & 4) | ((pq & 3) ^ P3);
+    const int ch = cot * DMA_CO_T + lq * 32 + (c16 & 3) * 8;
+    fa_voff = ch < p.dc ? (unsigned)((a_pl * p.ds + ch) * 2) : 0x80000000u;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) {
-      const int a = wave + 8 * u, row = a >> 2, x = 4 * (a & 3) + a_px;
-      fa_off[u] = (unsigned)(((row * p.W + x) * p.ds + a_ch) * 2);
-      const int kc = cit * DMA_CI_T + (((((lane >> 2) & 1) ^ ((b_hx[u] >> 1) & 1)) * 4) + (lane & 3)) * 8;
+    for (int u = 0; u < NBK; ++u) {
+      // input block b: regular = halo pixels 8b .. 8b+7 (128 bytes each), piece lane % 8 in physical half carrying logical half ^ ((hx >> 1) & 1);
+      // wide = halo pixels 16b .. 16b+15 (64 bytes each), piece lane % 4, no swizzle (four consecutive pixels are one 256-byte bank row)
+      const int b = wave + 8 * u;
+      const int hp = WIDE ? 16 * b + (lane >> 2) : 8 * b + (lane >> 3);
+      const int hy = hp / HW, hx = hp % HW;
+      const int kc = cit * DMA_CI_T + (WIDE ? (lane & 3) * 8 : (((((lane >> 2) & 1) ^ ((hx >> 1) & 1)) * 4) + (lane & 3)) * 8);
       const int ch = from0 ? kc : kc - p.c0;
-      const bool chok = 8 * (wave + 8 * u) + (lane >> 3) < HR * HW && bsrc != nullptr && ch < (from0 ? p.c0 : p.c1);
-      fb_off[u] = (unsigned)(((b_hy[u] * p.W + b_hx[u]) * bs + ch) * 2);
+      const bool chok = hp < HR * HW && bsrc != nullptr && ch < (from0 ? p.c0 : p.c1);
+      fb_off[u] = (unsigned)(((hy * p.W + hx) * bs + ch) * 2);
+      fb_mask[u] = 0;
       for (int cls = 0; cls < 16; ++cls) {
         const int y0 = (cls & 2) ? (p.tiles_y - 1) * TR : ((cls & 1) ? 0 : TR), x0 = (cls & 8) ? (p.tiles_x - 1) * TW : ((cls & 4) ? 0 : TW);
-        if (a_chok && y0 + row < p.H && x0 + x < p.W) fa_mask[u] |= 1u << cls;
-        const int gy = y0 - 1 + b_hy[u], gx = x0 - 1 + b_hx[u];
+        const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
         if (chok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) fb_mask[u] |= 1u << cls;
       }
     }
@@ -205,8 +215,13 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     const unsigned stage = lds0 + (unsigned)(nx_stage * STAGE);
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.dout + n * a_img), 0, __builtin_amdgcn_readfirstlane((int)a_img), 0x00020000);
     const unsigned soa = (unsigned)px0 * (unsigned)a_pxb;
+    const int rows_left = p.H - nx_ty * TR, cols_left = p.W - nx_tx * TW;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) bufdma16((fa_mask[u] & sel) ? fa_off[u] : SENT, rsa, soa, stage + (wave + 8 * u) * 1024);
+    for (int u = 0; u < NA; ++u) {
+      const int a = wave + 8 * u, row_a = (PPB * a) >> 4, x_a = (PPB * a) & 15;
+      const bool ok = live && row_a < rows_left && x_a + a_pl < cols_left;
+      bufdma16(ok ? fa_voff : SENT, rsa, soa + (unsigned)((row_a * p.W + x_a) * (int)a_pxb), stage + a * 1024);
+    }
     int ns = n;
     if (remap) { ns = n / bidiv; if (bimod) ns %= bimod; }
     // descriptor starts one image row + one pixel BEFORE the image so that the halo origin has a non-negative offset
@@ -214,7 +229,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)bsrc + ns * b_img - lead), 0, __builtin_amdgcn_readfirstlane((int)(b_img + 2 * lead)), 0x00020000);
     const unsigned sob = (unsigned)px0 * b_pxb;
 #pragma unroll
-    for (int u = 0; u < 2; ++u) bufdma16((fb_mask[u] & sel) ? fb_off[u] : SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
+    for (int u = 0; u < NBK; ++u) bufdma16((fb_mask[u] & sel) ? fb_off[u] : SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
     ++nx_i;
     nx_stage = nx_stage + 1 == NS ? 0 : nx_stage + 1;
     if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; } }
@@ -222,15 +237,16 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
   auto issue = [&]() {
     if constexpr (FAST) issue_fast(); else issue_slow();
   };
+  (void)a_px; (void)a_chok; (void)b_ok; (void)b_s1; (void)b_off; (void)b_hy; (void)b_hx;
 
   // ---- per-lane LDS read addresses (transposing reads: lane l of a 16-lane group supplies pixel (l >> 2) & 3, 8-byte chunk l & 3) ----
   const int m = (lane >> 2) & 3, khalf = lane >> 5;
   const int cbyte = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
-  const unsigned a_base = lds0 + (8 * khalf + m) * A_PIX + ((wq ^ m) * 64) + cbyte;  // + row * 4096 + r * 1024
+  const unsigned a_base = lds0 + (8 * khalf + m) * A_PIX + ((cotw * 4 + (wq ^ m)) * 64) + cbyte;  // + row * TW * A_PIX + r * 4 * A_PIX
   unsigned b_base[3];                                                               // + hrow * 2304 + r * 512
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
-    b_base[kx] = lds0 + A_BYTES + (8 * khalf + m + kx) * B_PIX + ((wc ^ (((m + kx) >> 1) & 1)) * 64) + cbyte;
+    b_base[kx] = lds0 + A_BYTES + (8 * khalf + m + kx) * B_PIX + (WIDE ? 0 : ((wc ^ (((m + kx) >> 1) & 1)) * 64)) + cbyte;
 
   f32x16 acc[9];
 #pragma unroll
@@ -238,12 +254,12 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
   float bsum = 0.f;
-  const bool want_bias = cit == 0 && wc == 0;  // wave-uniform
+  const bool want_bias = cit == 0 && wc == 0;  // wave-uniform (wide: every wave has its own co fragment)
 
   // prologue: NS - 1 tiles in flight, tile 0 visible
 #pragma unroll
   for (int i = 0; i < NS - 1; ++i) issue();
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 2)) : "memory");
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 2)) : "memory");
   __builtin_amdgcn_s_barrier();
 
   // fragment reads of ring stage st (base & 0x3ffff: tells the compiler the LDS address is non-negative so that it folds the row /
@@ -258,7 +274,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
   };
   auto load_a = [&](unsigned aA, bf16x8 (&arow)[TR]) {
 #pragma unroll
-    for (int row = 0; row < TR; ++row) arow[row] = cat8(tr_read(aA + row * 4096), tr_read(aA + row * 4096 + 1024));
+    for (int row = 0; row < TR; ++row) arow[row] = cat8(tr_read(aA + row * (TW * A_PIX)), tr_read(aA + row * (TW * A_PIX) + 4 * A_PIX));
   };
   auto load_b = [&](const unsigned (&aB)[3], int hrow, bf16x8 (&b)[3]) {
 #pragma unroll
@@ -312,7 +328,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     mfma_row(2, cur, bq0);
     __builtin_amdgcn_sched_barrier(0);
     load_b(aB, 4, bq0);
-    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(4 * (NS - 3)) : "memory");
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (!stage_late) issue();
     __builtin_amdgcn_sched_barrier(0);
@@ -341,13 +357,14 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
       for (int reg = 0; reg < 16; ++reg) {
-        const int co = cot * DMA_CO_T + 32 * wq + frag_row(reg, kh);
+        const int co = (cot + cotw) * DMA_CO_T + 32 * wq + frag_row(reg, kh);
         const int ci = cit * DMA_CI_T + 32 * wc + r;
         p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
+        if constexpr (WIDE) p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci + 32] = 0.f;  // the tile's dead half: nobody else writes it
       }
     if (want_bias) {
       const float tot = bsum + __shfl_xor(bsum, 32);
-      if (kh == 0) p.partial_db[(size_t)slot * p.NpT + cot * DMA_CO_T + 32 * wq + r] = tot;
+      if (kh == 0) p.partial_db[(size_t)slot * p.NpT + (cot + cotw) * DMA_CO_T + 32 * wq + r] = tot;
     }
   };
   int seg = 0, next_flush = 0x7fffffff;
@@ -377,9 +394,36 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
   store_partial(GROUPED ? ks * p.maxseg + seg : ks);
 }
 
+// Workgroup -> (K slice, slab).  Grid = (KS, units): `units` = the regular (co tile, ci tile) slabs - all of them, or, with `wide_pairs` > 0, those of
+// the ci tiles but the last - followed by one wide slab per PAIR of co tiles of the last ci tile.  The slabs of one K slice are consecutive on one XCD
+// (blocks are dealt round-robin to the 8 XCDs), so a slice's tiles are shared through that XCD's L2 (pure speed choice).
+template <bool FAST, bool GROUPED = false>
+__global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
+                                                                     const int xcd_groups, const int cot_n, const int cit_n, const int wide_pairs) {
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  const int units = gridDim.y;
+  int ks, unit;
+  {
+    const int id = blockIdx.x + gridDim.x * blockIdx.y;
+    if (xcd_groups) {
+      const int x = id % 8, j = id / 8;
+      ks = (j / units) * 8 + x;
+      unit = j % units;
+    } else { ks = blockIdx.x; unit = blockIdx.y; }
+  }
+  const int regular = wide_pairs > 0 ? cot_n * (cit_n - 1) : cot_n * cit_n;
+  if constexpr (FAST) {
+    if (unit >= regular) {  // block-uniform
+      wgrad_dma_body<true, GROUPED, true>(p, per_slice, zero, lds, ks, 2 * (unit - regular), cit_n - 1);
+      return;
+    }
+  }
+  wgrad_dma_body<FAST, GROUPED, false>(p, per_slice, zero, lds, ks, unit % cot_n, unit / cot_n);
+}
+
 }  // namespace
 
-sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups) {
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups, int single_source) {
   using namespace sfwgrad;
   Plan pl;
   pl.tiles_x = (w + TW - 1) / TW;
@@ -387,8 +431,13 @@ sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int gr
   pl.ntiles = pl.tiles_x * pl.tiles_y * n;
   pl.cot = (Np + DMA_CO_T - 1) / DMA_CO_T;
   pl.cit = (Kp + DMA_CI_T - 1) / DMA_CI_T;
+  // the last ci tile holds at most 32 channels, the co tiles pair up, one input tensor: wide slabs for that tile (see wgrad_dma_body)
+  static const bool no_wide = getenv("SF_NO_WGRAD_WIDE") != nullptr;  // A/B switch
+  const int tail = Kp - (pl.cit - 1) * DMA_CI_T;
+  pl.wide_pairs = (!no_wide && single_source && tail > 0 && tail <= 32 && pl.cot % 2 == 0) ? pl.cot / 2 : 0;
+  pl.units = pl.wide_pairs ? pl.cot * (pl.cit - 1) + pl.wide_pairs : pl.cot * pl.cit;
   // one workgroup per CU (128 KiB of LDS): as many K slices as fill the 256 CUs once, in whole groups of 8 (one per XCD)
-  int want = 256 / (pl.cot * pl.cit);
+  int want = 256 / pl.units;
   want = want / 8 * 8;
   if (want < 8) want = 8;
   const int per_min = 6;  // a slice shorter than the ring + pipeline fill is all prologue
@@ -431,11 +480,13 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   const int per_slice = (pl.ntiles + pl.KS - 1) / pl.KS;
   const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
   const bool fast = !(p.src0 && p.src1 && p.c1 > 0) || p.c0 % DMA_CI_T == 0;
+  if (pl.wide_pairs && (!fast || (p.src0 && p.src1 && p.c1 > 0))) { sf_set_error("wgrad_bf16_dma: the plan's wide slabs need a single input source"); return 1; }
+  const dim3 grid(pl.KS, pl.units);
   if (pl.tpg > 0) {
     if (!fast) { sf_set_error("wgrad_bf16_dma: grouped slices need a single input source"); return 1; }
-    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
-  } else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
-  else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, dim3(pl.KS, pl.cot, pl.cit), dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups);
+    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.wide_pairs);
+  } else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.wide_pairs);
+  else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("wgrad_bf16_dma: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;

@@ -430,7 +430,7 @@ extern "C" {
 
 size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups) {
   if (groups < 1 || n % groups) return 0;
-  return fold_layout(sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups), Np, n, groups).total_floats * sizeof(float);
+  return fold_layout(sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1), Np, n, groups).total_floats * sizeof(float);
 }
 
 int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
@@ -444,7 +444,7 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
   SF_REQUIRE(scale && shift && dw, "bwd_weight_folded: null argument");
   SF_REQUIRE(!bn_sums || (weight && mean && rstd && ((uintptr_t)workspace & 7) == 0), "bwd_weight_folded: bn_sums needs weight, mean, rstd (and an 8-byte aligned workspace)");
   const int Np = dout.c, Kp = src.c;
-  const Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups);
+  const Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1);
   const FoldLayout fl = fold_layout(pl, Np, n, groups);
   SF_REQUIRE(workspace && workspace_bytes >= fl.total_floats * sizeof(float), "bwd_weight_folded: workspace too small (%zu < %zu)", workspace_bytes,
              fl.total_floats * sizeof(float));
@@ -494,8 +494,9 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
 size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w) {
   // the loader-wave bf16 variant uses taller K tiles, i.e. never more tiles / a larger KS than this plan; the all-bf16-storage
   // variant has its own plan
-  const size_t a = make_plan(Np, Kp, n, h, w, KT_H).ws_floats, b = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w).ws_floats;
-  return (a > b ? a : b) * sizeof(float);
+  const size_t a = make_plan(Np, Kp, n, h, w, KT_H).ws_floats, b = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w).ws_floats,
+               c = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, 1).ws_floats;  // (the single-source plan may cut more K slices)
+  return (a > b ? (a > c ? a : c) : (b > c ? b : c)) * sizeof(float);
 }
 
 int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h, int32_t w,
@@ -508,7 +509,8 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   const int Np = dout.c, Kp = src0.c + src1.c;
   const bool all_bf16 = dtype == SF_BF16 && dout.dtype == SF_BF16 && (!src0.ptr || src0.dtype == SF_BF16) && (!src1.ptr || src1.dtype == SF_BF16) &&
                         (src0.ptr || src1.ptr);
-  const Plan pl = all_bf16 ? sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w) : make_plan(Np, Kp, n, h, w, (dtype == SF_BF16 || dtype == SF_F16) ? 8 : KT_H);
+  const int one_src = (src0.ptr && src0.c > 0) != (src1.ptr && src1.c > 0);
+  const Plan pl = all_bf16 ? sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, one_src) : make_plan(Np, Kp, n, h, w, (dtype == SF_BF16 || dtype == SF_F16) ? 8 : KT_H);
   SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
              workspace_bytes, pl.ws_floats * sizeof(float));
   WgradParams p{};
