@@ -74,28 +74,31 @@ __device__ __forceinline__ void* uniform_ptr(const void* q) {
 // GROUPED (folded BatchNorm, sf_conv3x3_bwd_weight_folded): the images come in groups of p.tpg tiles whose raw gradients are
 // scaled differently afterwards, so a slice that crosses a group boundary stores its accumulators there (segment 0, 1, ...
 // of the slice: partial[ks * maxseg + seg]) and starts again from zero.
-// WIDE (FAST only): the slab geometry of the LAST ci tile when it holds at most 32 valid channels (160 = 64 + 64 + 32 input channels: conv2 of
-// MetNet's DownSampler).  With the regular geometry the four waves of the upper ci half multiply zeros - a sixth of the launch.  A wide workgroup
-// instead takes the live halves of TWO co tiles: slab 256 (co) x 32 (ci), wave w owns co fragment w of the 8 and the one ci fragment; its stage
-// holds 64 pixels x 512 bytes of dout and the halo x 64 bytes of input (40 KiB, three stages), five DMA instructions per wave and tile instead
-// of four.  Every workgroup of the launch then does the same MFMA work on live operands, and the plan cuts the K slices shorter (2.5 slab units
-// per co-tile pair instead of 3).
-template <bool FAST, bool GROUPED, bool WIDE>
+// GEO (1, 2: FAST only): slab geometries for half-empty edge tiles.  With the regular geometry (0: 128 co x 64 ci) the waves of a dead half multiply
+// zeros.  GEO 1 - the LAST ci tile holds at most 32 channels (160 = 64 + 64 + 32 input channels: conv2 of MetNet's DownSampler): a workgroup takes the
+// live halves of TWO co tiles, slab 256 co x 32 ci, wave w owns co fragment w of the 8; stage = 64 pixels x 512 bytes of dout + halo x 64 bytes of
+// input.  GEO 2 - the LAST co tile holds at most 64 channels (192 = 128 + 64 output channels: the ConvGRU's gates; 160 = 128 + 32: conv1): a workgroup
+// takes the live halves of TWO ci tiles, slab 64 co x 128 ci, wave w owns co fragment w & 1 and ci fragment w >> 1; stage = 64 pixels x 128 bytes of
+// dout + halo x 256 bytes of input.  Both: 40 KiB per stage, three stages, five DMA instructions per wave and tile instead of four.  Every workgroup
+// of the launch then does the same MFMA work on live operands, and the plan cuts the K slices shorter.
+template <bool FAST, bool GROUPED, int GEO>
 __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int per_slice, const char* __restrict__ zero, char* lds, const int ks,
                                                const int cot, const int cit) {
-  static_assert(!WIDE || FAST, "the wide slab uses the descriptor DMA path");
-  constexpr int A_PIX = WIDE ? 4 * DMA_CO_T : 2 * DMA_CO_T;   // bytes per dout pixel in a stage (256 / 128 channels)
-  constexpr int B_PIX = WIDE ? DMA_CI_T : 2 * DMA_CI_T;       // bytes per input pixel (32 / 64 channels)
-  constexpr int A_BYTES = TR * TW * A_PIX;                    // 32768 / 16384
-  constexpr int B_BYTES = WIDE ? 8192 : 16384;                // 108 px x 64 B = 6912 / x 128 B = 13824, padded to whole DMA blocks
+  static_assert(GEO == 0 || FAST, "the edge geometries use the descriptor DMA path");
+  constexpr bool WIDE = GEO != 0;
+  constexpr int A_PIX = GEO == 1 ? 4 * DMA_CO_T : GEO == 2 ? DMA_CO_T : 2 * DMA_CO_T;   // bytes per dout pixel in a stage (256 / 64 / 128 channels)
+  constexpr int B_PIX = GEO == 1 ? DMA_CI_T : GEO == 2 ? 4 * DMA_CI_T : 2 * DMA_CI_T;   // bytes per input pixel (32 / 128 / 64 channels)
+  constexpr int A_BYTES = TR * TW * A_PIX;                                              // 32768 / 8192 / 16384
+  constexpr int B_BYTES = GEO == 1 ? 8192 : GEO == 2 ? 32768 : 16384;                   // 108 px x B_PIX, padded to whole 8-block rounds
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int NS = WIDE ? 3 : ::NS_REG;                     // ring depth
-  constexpr int NA = A_BYTES / 1024 / 8, NBK = B_BYTES / 1024 / 8, NDMA = NA + NBK;  // DMA instructions per wave and tile: 4 + 1 / 2 + 2
+  constexpr int NA = A_BYTES / 1024 / 8, NBK = B_BYTES / 1024 / 8, NDMA = NA + NBK;  // DMA instructions per wave and tile: 2 + 2 / 4 + 1 / 1 + 4
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wq = wave & 3, wc = WIDE ? 0 : wave >> 2;  // co fragment / ci half of this wave
-  const int cotw = WIDE ? wave >> 2 : 0;               // WIDE: which of the two co tiles
+  const int wq = GEO == 2 ? wave & 1 : wave & 3;                 // co fragment of this wave (within its co tile)
+  const int wc = GEO == 1 ? 0 : GEO == 2 ? wave >> 1 : wave >> 2;  // ci fragment
+  const int cotw = GEO == 1 ? wave >> 2 : 0;                     // GEO 1: which of the two co tiles
   // a slice owns a CONTIGUOUS run of tiles: vertically adjacent tiles re-read two halo rows, which are then L2 hits
   const int t_begin = ks * per_slice;
   const int t_end = t_begin + per_slice < p.ntiles ? t_begin + per_slice : p.ntiles;
@@ -178,12 +181,15 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   // quarter ^ (pixel & 3); wide: 2 pixels of 512 bytes, piece lane % 32 in physical eighth, the xor on its low two bits).  Row and first column of a
   // block are WAVE constants (scalar offset of the DMA), the lane adds its pixel within the block and its channel piece: one per-lane offset for all
   // of a wave's blocks, validity from two comparisons per block instead of a class mask per block (registers: the wide body holds four blocks)
-  constexpr int PPB = WIDE ? 2 : 4;
-  const int a_pl = WIDE ? lane >> 5 : lane >> 4;
+  constexpr int PPB = 1024 / A_PIX;          // pixels per dout block: 4 / 2 / 8
+  const int a_pl = lane / (64 / PPB);
   unsigned fa_voff = 0;
   if constexpr (FAST) {
-    const int P3 = (PPB * wave + a_pl) & 3;  // (pixel & 3) of this lane's pixel: the same in every block of the wave (blocks are 8 apart)
-    const int c16 = WIDE ? lane & 31 : lane & 15, pq = c16 >> 2, lq = (pq & 4) | ((pq & 3) ^ P3);
+    const int P = PPB * wave + a_pl;         // (pixel & 3) of this lane's pixel is the same in every block of the wave (blocks are 8 apart)
+    const int c16 = lane & (A_PIX / 16 - 1), pq = c16 >> 2;
+    // 64-byte channel groups of a pixel are xor-ed so that the four pixels of a transposing read fall on disjoint banks: with 256 / 512 bytes per
+    // pixel by (pixel & 3) on the low two bits, with 128 bytes per pixel (two groups; pixels m and m + 2 share banks) by (pixel >> 1) & 1
+    const int lq = GEO == 2 ? pq ^ ((P >> 1) & 1) : (pq & 4) | ((pq & 3) ^ (P & 3));
     const int ch = cot * DMA_CO_T + lq * 32 + (c16 & 3) * 8;
     fa_voff = ch < p.dc ? (unsigned)((a_pl * p.ds + ch) * 2) : 0x80000000u;
 #pragma unroll
@@ -191,9 +197,12 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
       // input block b: regular = halo pixels 8b .. 8b+7 (128 bytes each), piece lane % 8 in physical half carrying logical half ^ ((hx >> 1) & 1);
       // wide = halo pixels 16b .. 16b+15 (64 bytes each), piece lane % 4, no swizzle (four consecutive pixels are one 256-byte bank row)
       const int b = wave + 8 * u;
-      const int hp = WIDE ? 16 * b + (lane >> 2) : 8 * b + (lane >> 3);
+      constexpr int PPBB = 1024 / B_PIX;     // halo pixels per input block: 8 / 16 / 4
+      const int hp = PPBB * b + lane / (64 / PPBB);
       const int hy = hp / HW, hx = hp % HW;
-      const int kc = cit * DMA_CI_T + (WIDE ? (lane & 3) * 8 : (((((lane >> 2) & 1) ^ ((hx >> 1) & 1)) * 4) + (lane & 3)) * 8);
+      const int cb = lane & (B_PIX / 16 - 1), pqb = cb >> 2;
+      const int lqb = GEO == 1 ? 0 : GEO == 2 ? pqb ^ (hx & 3) : pqb ^ ((hx >> 1) & 1);  // (64 bytes per pixel: four consecutive pixels are one bank row)
+      const int kc = cit * DMA_CI_T + lqb * 32 + (cb & 3) * 8;
       const int ch = from0 ? kc : kc - p.c0;
       const bool chok = hp < HR * HW && bsrc != nullptr && ch < (from0 ? p.c0 : p.c1);
       fb_off[u] = (unsigned)(((hy * p.W + hx) * bs + ch) * 2);
@@ -242,11 +251,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   // ---- per-lane LDS read addresses (transposing reads: lane l of a 16-lane group supplies pixel (l >> 2) & 3, 8-byte chunk l & 3) ----
   const int m = (lane >> 2) & 3, khalf = lane >> 5;
   const int cbyte = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
-  const unsigned a_base = lds0 + (8 * khalf + m) * A_PIX + ((cotw * 4 + (wq ^ m)) * 64) + cbyte;  // + row * TW * A_PIX + r * 4 * A_PIX
+  const unsigned a_base = lds0 + (8 * khalf + m) * A_PIX + ((GEO == 2 ? wq ^ ((m >> 1) & 1) : cotw * 4 + (wq ^ m)) * 64) + cbyte;  // + row * TW * A_PIX + r * 4 * A_PIX
   unsigned b_base[3];                                                               // + hrow * 2304 + r * 512
 #pragma unroll
   for (int kx = 0; kx < 3; ++kx)
-    b_base[kx] = lds0 + A_BYTES + (8 * khalf + m + kx) * B_PIX + (WIDE ? 0 : ((wc ^ (((m + kx) >> 1) & 1)) * 64)) + cbyte;
+    b_base[kx] = lds0 + A_BYTES + (8 * khalf + m + kx) * B_PIX + (GEO == 1 ? 0 : GEO == 2 ? (wc ^ ((m + kx) & 3)) * 64 : (wc ^ (((m + kx) >> 1) & 1)) * 64) + cbyte;
 
   f32x16 acc[9];
 #pragma unroll
@@ -360,7 +369,9 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
         const int co = (cot + cotw) * DMA_CO_T + 32 * wq + frag_row(reg, kh);
         const int ci = cit * DMA_CI_T + 32 * wc + r;
         p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
-        if constexpr (WIDE) p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci + 32] = 0.f;  // the tile's dead half: nobody else writes it
+        // the tile's dead half: nobody else writes it
+        if constexpr (GEO == 1) p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci + 32] = 0.f;
+        if constexpr (GEO == 2) p.partial[(((size_t)slot * 9 + tap) * p.NpT + co + 64) * p.KpT + ci] = 0.f;
       }
     if (want_bias) {
       const float tot = bsum + __shfl_xor(bsum, 32);
@@ -394,12 +405,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   store_partial(GROUPED ? ks * p.maxseg + seg : ks);
 }
 
-// Workgroup -> (K slice, slab).  Grid = (KS, units): `units` = the regular (co tile, ci tile) slabs - all of them, or, with `wide_pairs` > 0, those of
-// the ci tiles but the last - followed by one wide slab per PAIR of co tiles of the last ci tile.  The slabs of one K slice are consecutive on one XCD
-// (blocks are dealt round-robin to the 8 XCDs), so a slice's tiles are shared through that XCD's L2 (pure speed choice).
+// Workgroup -> (K slice, slab).  Grid = (KS, units); `units` = the regular (co tile, ci tile) slabs followed by the edge slabs (edge_mode 1: one GEO-1
+// slab per PAIR of co tiles of the last ci tile; edge_mode 2: one GEO-2 slab per PAIR of ci tiles of the last co tile, a leftover ci tile stays
+// regular).  The slabs of one K slice are consecutive on one XCD (blocks are dealt round-robin to the 8 XCDs), so a slice's tiles are shared
+// through that XCD's L2 (pure speed choice).
 template <bool FAST, bool GROUPED = false>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
-                                                                     const int xcd_groups, const int cot_n, const int cit_n, const int wide_pairs) {
+                                                                     const int xcd_groups, const int cot_n, const int cit_n, const int edge_mode) {
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
   const int units = gridDim.y;
   int ks, unit;
@@ -411,14 +423,21 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
       unit = j % units;
     } else { ks = blockIdx.x; unit = blockIdx.y; }
   }
-  const int regular = wide_pairs > 0 ? cot_n * (cit_n - 1) : cot_n * cit_n;
-  if constexpr (FAST) {
-    if (unit >= regular) {  // block-uniform
-      wgrad_dma_body<true, GROUPED, true>(p, per_slice, zero, lds, ks, 2 * (unit - regular), cit_n - 1);
-      return;
-    }
+  int geo = 0, cot = unit % cot_n, cit = unit / cot_n;  // (block-uniform)
+  if (FAST && edge_mode == 1) {
+    const int regular = cot_n * (cit_n - 1);
+    if (unit >= regular) { geo = 1; cot = 2 * (unit - regular); cit = cit_n - 1; }
+  } else if (FAST && edge_mode == 2) {
+    const int regular = (cot_n - 1) * cit_n, pairs = cit_n / 2;
+    if (unit < regular) { cot = unit % (cot_n - 1); cit = unit / (cot_n - 1); }
+    else if (unit < regular + pairs) { geo = 2; cot = cot_n - 1; cit = 2 * (unit - regular); }
+    else { cot = cot_n - 1; cit = cit_n - 1; }  // the odd ci tile out
   }
-  wgrad_dma_body<FAST, GROUPED, false>(p, per_slice, zero, lds, ks, unit % cot_n, unit / cot_n);
+  if constexpr (FAST) {
+    if (geo == 1) { wgrad_dma_body<true, GROUPED, 1>(p, per_slice, zero, lds, ks, cot, cit); return; }
+    if (geo == 2) { wgrad_dma_body<true, GROUPED, 2>(p, per_slice, zero, lds, ks, cot, cit); return; }
+  }
+  wgrad_dma_body<FAST, GROUPED, 0>(p, per_slice, zero, lds, ks, cot, cit);
 }
 
 }  // namespace
@@ -433,9 +452,18 @@ sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int gr
   pl.cit = (Kp + DMA_CI_T - 1) / DMA_CI_T;
   // the last ci tile holds at most 32 channels, the co tiles pair up, one input tensor: wide slabs for that tile (see wgrad_dma_body)
   static const bool no_wide = getenv("SF_NO_WGRAD_WIDE") != nullptr;  // A/B switch
-  const int tail = Kp - (pl.cit - 1) * DMA_CI_T;
-  pl.wide_pairs = (!no_wide && single_source && tail > 0 && tail <= 32 && pl.cot % 2 == 0) ? pl.cot / 2 : 0;
-  pl.units = pl.wide_pairs ? pl.cot * (pl.cit - 1) + pl.wide_pairs : pl.cot * pl.cit;
+  const int tail = Kp - (pl.cit - 1) * DMA_CI_T, ctail = Np - (pl.cot - 1) * DMA_CO_T;
+  pl.wide_pairs = 0; pl.edge_mode = 0;
+  pl.units = pl.cot * pl.cit;
+  if (!no_wide && single_source) {
+    if (tail > 0 && tail <= 32 && pl.cot % 2 == 0) {            // GEO 1: half-empty last ci tile
+      pl.edge_mode = 1; pl.wide_pairs = pl.cot / 2;
+      pl.units = pl.cot * (pl.cit - 1) + pl.wide_pairs;
+    } else if (ctail > 0 && ctail <= 64 && pl.cit >= 2) {        // GEO 2: half-empty last co tile
+      pl.edge_mode = 2; pl.wide_pairs = pl.cit / 2;
+      pl.units = (pl.cot - 1) * pl.cit + pl.wide_pairs + (pl.cit & 1);
+    }
+  }
   // one workgroup per CU (128 KiB of LDS): as many K slices as fill the 256 CUs once, in whole groups of 8 (one per XCD)
   int want = 256 / pl.units;
   want = want / 8 * 8;
@@ -484,8 +512,8 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   const dim3 grid(pl.KS, pl.units);
   if (pl.tpg > 0) {
     if (!fast) { sf_set_error("wgrad_bf16_dma: grouped slices need a single input source"); return 1; }
-    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.wide_pairs);
-  } else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.wide_pairs);
+    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
+  } else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
   else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("wgrad_bf16_dma: launch failed: %s", hipGetErrorString(e)); return 2; }

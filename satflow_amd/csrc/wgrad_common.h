@@ -21,7 +21,7 @@ struct WgradParams {
 };
 
 
-struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; int tpg = 0, maxseg = 1; int wide_pairs = 0, units = 0; };
+struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; int tpg = 0, maxseg = 1; int wide_pairs = 0, units = 0, edge_mode = 0; };
 
 // kt_h: K-tile height of the kernel variant (4 rows fp32, 8 rows bf16)
 inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {

@@ -358,3 +358,36 @@ def test_convgru_bf16a_vs_bf16(device, B, T, cin, hid, h, w, layers):
     worst = max(rel(res["bf16a"][1][k], res["bf16"][1][k]) for k in res["bf16"][1])
     print(f"bf16a ConvGRU: states rel L2 vs fp32-stored x-part {fwd:.2e}; worst gradient rel L2 vs fp32-stored gates {worst:.2e}")
     assert worst < 1e-2
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [
+    (160, 256, 40, 32, 32),   # last input-channel tile half empty: 256 x 32 slabs (conv2 of the DownSampler)
+    (96, 256, 24, 24, 40),    # the same with two input tiles
+    (256, 192, 40, 16, 16),   # last output-channel tile half empty: 64 x 128 slabs (the ConvGRU's gates)
+    (108, 160, 24, 32, 32),   # ... with a single pair of input tiles and 32 live output channels (conv1)
+    (192, 64, 24, 20, 20),    # ... one output tile, three input tiles: one pair + an odd tile on the regular geometry
+])
+def test_weight_gradient_edge_slabs(device, bf16a_mode, cin, cout, n, h, w):
+    """sf_conv3x3_bwd_weight on bf16-stored tensors for channel counts whose last 64-channel input tile / last 128-channel output tile is half
+    empty (the wide and the tall slab geometry of conv3x3_wgrad_bf16_dma.hip) against a float64 evaluation of exactly its operands:
+    products of bf16 values are exact in fp32, only the summation order differs (2e-5 of the gradient's norm)."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    eng = ConvEngine([cin], cout)
+    x = torch.zeros(n, h, w, cpad(cin), device=device, dtype=torch.bfloat16)
+    x[..., :cin] = torch.randn(n, h, w, cin, generator=g).to(device).to(torch.bfloat16)
+    gy = torch.zeros(n, h, w, eng.coutp, device=device, dtype=torch.bfloat16)
+    gy[..., :cout] = torch.randn(n, h, w, cout, generator=g).to(device).to(torch.bfloat16)
+    dw = torch.full((cout, cin, 3, 3), float("nan"), device=device)
+    db = torch.full((cout,), float("nan"), device=device)
+    K.conv3x3_bwd_weight(T(x), T(None), T(gy), n, h, w, eng.wgrad_map, dw, db, False)
+    wz = torch.zeros(cout, cin, 3, 3, dtype=torch.float64, device=device, requires_grad=True)
+    out = torch.nn.functional.conv2d(x[..., :cin].double().permute(0, 3, 1, 2), wz, None, padding=1)
+    (ref,) = torch.autograd.grad((out * gy[..., :cout].double().permute(0, 3, 1, 2)).sum(), wz)
+    rel = lambda a, b: float((a.double() - b).norm() / b.norm())
+    assert torch.isfinite(dw).all() and torch.isfinite(db).all()
+    assert rel(dw, ref) < 2e-5, rel(dw, ref)
+    assert rel(db, gy[..., :cout].double().sum((0, 1, 2))) < 2e-5
