@@ -455,11 +455,11 @@ sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int gr
   const int tail = Kp - (pl.cit - 1) * DMA_CI_T, ctail = Np - (pl.cot - 1) * DMA_CO_T;
   pl.wide_pairs = 0; pl.edge_mode = 0;
   pl.units = pl.cot * pl.cit;
-  if (!no_wide && single_source) {
+  if (!no_wide && single_source) {  // 1: one input tensor; 2: two, the first a whole number of ci tiles wide (every tile has one source)
     if (tail > 0 && tail <= 32 && pl.cot % 2 == 0) {            // GEO 1: half-empty last ci tile
       pl.edge_mode = 1; pl.wide_pairs = pl.cot / 2;
       pl.units = pl.cot * (pl.cit - 1) + pl.wide_pairs;
-    } else if (ctail > 0 && ctail <= 64 && pl.cit >= 2) {        // GEO 2: half-empty last co tile
+    } else if (single_source == 1 && ctail > 0 && ctail <= 64 && pl.cit >= 2) {  // GEO 2: half-empty last co tile (a pair of ci tiles = one source)
       pl.edge_mode = 2; pl.wide_pairs = pl.cit / 2;
       pl.units = (pl.cot - 1) * pl.cit + pl.wide_pairs + (pl.cit & 1);
     }
@@ -508,7 +508,7 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   const int per_slice = (pl.ntiles + pl.KS - 1) / pl.KS;
   const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
   const bool fast = !(p.src0 && p.src1 && p.c1 > 0) || p.c0 % DMA_CI_T == 0;
-  if (pl.wide_pairs && (!fast || (p.src0 && p.src1 && p.c1 > 0))) { sf_set_error("wgrad_bf16_dma: the plan's wide slabs need a single input source"); return 1; }
+  if (pl.wide_pairs && (!fast || (pl.edge_mode == 2 && p.src0 && p.src1 && p.c1 > 0))) { sf_set_error("wgrad_bf16_dma: the plan's edge slabs need tile-aligned sources"); return 1; }
   const dim3 grid(pl.KS, pl.units);
   if (pl.tpg > 0) {
     if (!fast) { sf_set_error("wgrad_bf16_dma: grouped slices need a single input source"); return 1; }

@@ -495,7 +495,7 @@ size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, 
   // the loader-wave bf16 variant uses taller K tiles, i.e. never more tiles / a larger KS than this plan; the all-bf16-storage
   // variant has its own plan
   const size_t a = make_plan(Np, Kp, n, h, w, KT_H).ws_floats, b = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w).ws_floats,
-               c = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, 1).ws_floats;  // (the single-source plan may cut more K slices)
+               c = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, 1).ws_floats;  // (the edge-slab plans may cut more K slices; mode 2's are a subset of mode 1's)
   return (a > b ? (a > c ? a : c) : (b > c ? b : c)) * sizeof(float);
 }
 
@@ -509,7 +509,8 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   const int Np = dout.c, Kp = src0.c + src1.c;
   const bool all_bf16 = dtype == SF_BF16 && dout.dtype == SF_BF16 && (!src0.ptr || src0.dtype == SF_BF16) && (!src1.ptr || src1.dtype == SF_BF16) &&
                         (src0.ptr || src1.ptr);
-  const int one_src = (src0.ptr && src0.c > 0) != (src1.ptr && src1.c > 0);
+  // 1: one input tensor; 2: two, the first a whole number of 64-channel tiles wide (every tile of the K space has one source)
+  const int one_src = (src0.ptr && src0.c > 0) != (src1.ptr && src1.c > 0) ? 1 : (src0.c % DMA_CI_T == 0 ? 2 : 0);
   const Plan pl = all_bf16 ? sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, one_src) : make_plan(Np, Kp, n, h, w, (dtype == SF_BF16 || dtype == SF_F16) ? 8 : KT_H);
   SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
              workspace_bytes, pl.ws_floats * sizeof(float));

@@ -113,8 +113,12 @@ def lstm_bwd_map(cin: int, hid: int, need_dx: bool) -> GemmMap:
     return _finish(nm, lstm_dz_kmap(hid))
 
 
-def lstm_wgrad_map(cin: int, hid: int) -> GemmMap:
-    """Weight-gradient index maps: dout lanes = dz (gate-major), K lanes = [x ; h]."""
+def lstm_wgrad_map(cin: int, hid: int, h_first: bool = False) -> GemmMap:
+    """Weight-gradient index maps: dout lanes = dz (gate-major), K lanes = [x ; h] - or [h ; x] (``h_first``: the order the bf16-storage
+    kernel likes when the hidden width is a multiple of its 64-channel tile: every tile then has ONE source, and the narrow x tile at the
+    end takes the 256 x 32 slab instead of multiplying three quarters of zeros)."""
+    if h_first:
+        return GemmMap(lstm_dz_kmap(hid), _padded(hid, cin) + _padded(cin), 0, 4 * cpad(hid))
     return GemmMap(lstm_dz_kmap(hid), _padded(cin) + _padded(hid, cin), 0, 4 * cpad(hid))
 
 

@@ -33,7 +33,9 @@ class CellEngine:
         self.cinp, self.hidp = cpad(input_dim), cpad(hidden_dim)
         self.fwd_map = K.lstm_fwd_map(input_dim, hidden_dim)
         self.bwd_maps = {nd: K.lstm_bwd_map(input_dim, hidden_dim, nd) for nd in (False, True)}
-        self.wgrad_map = K.lstm_wgrad_map(input_dim, hidden_dim)
+        # K order of the weight gradient: [h ; x] when the hidden lanes fill whole 64-channel tiles of the bf16-storage kernel (see lstm_wgrad_map)
+        self.h_first = cpad(hidden_dim) % 64 == 0
+        self.wgrad_map = K.lstm_wgrad_map(input_dim, hidden_dim, self.h_first)
         self._key = None
         self._packed = {}
 
@@ -78,7 +80,10 @@ class CellEngine:
 
     def bwd_weight(self, x: sfTensor, h_prev: sfTensor, dz: sfTensor, n: int, h: int, w: int, dw: Tensor, db: Optional[Tensor],
                    accumulate: bool) -> None:
-        K.conv3x3_bwd_weight(x, h_prev, dz, n, h, w, self.wgrad_map, dw, db, accumulate)
+        if self.h_first:
+            K.conv3x3_bwd_weight(h_prev, x, dz, n, h, w, self.wgrad_map, dw, db, accumulate)
+        else:
+            K.conv3x3_bwd_weight(x, h_prev, dz, n, h, w, self.wgrad_map, dw, db, accumulate)
 
 
 class _CellStepFn(torch.autograd.Function):
