@@ -408,8 +408,8 @@ class MetNetWorkload:
         return time_cpu(one, f"oracle fwd + mse + bwd + Adam (dropout off), B=1, all {self.L} lead times, fp32")
 
     def attention_mfma(self):
-        """north_star: "MFMA utilisation on axial attention".  The layer = one fused q/kv projection GEMM (fp32 MFMA), the
-        attention core (VALU: sequences of length 16 fit a lane's registers, no matrix instruction applies) and the output GEMM."""
+        """north_star: "MFMA utilisation on axial attention".  The layer = one fused q/kv projection GEMM (fp32 MFMA), the attention core
+        (round 4: v_mfma_f32_16x16x4_f32, one wave per line, attn_{fwd,bwd}_mfma_kernel) and the output GEMM."""
         layer = self.model.model.temporal_agg[0]
         n, s, hid = self.B * self.L, 16, self.hid
         x = torch.randn(n, s, s, hid, device=self.dev).requires_grad_()
@@ -420,12 +420,14 @@ class MetNetWorkload:
 
         t = event_time(fb, iters=10)
         rows = n * s * s
-        mfma_flops = 3 * (2 * rows * hid * 6 * hid + 2 * rows * 2 * hid * hid)  # projections fwd + dgrad + wgrad; the core has none
-        core_flops = 3 * 2 * 2 * 2 * n * s * s * s * hid                          # qk^T and pv along both axes, fwd + 2x bwd
-        return {"fwd_bwd_us": t * 1e6, "mfma_flops": mfma_flops, "valu_core_flops": core_flops,
+        proj_flops = 3 * (2 * rows * hid * 6 * hid + 2 * rows * 2 * hid * hid)    # projections fwd + dgrad + wgrad
+        core_flops = 3 * 2 * 2 * 2 * n * s * s * s * hid                          # qk^T and pv along both axes, fwd + 2x bwd (useful flops)
+        mfma_flops = proj_flops + core_flops
+        return {"fwd_bwd_us": t * 1e6, "mfma_flops": mfma_flops, "projection_flops": proj_flops, "core_flops": core_flops,
                 "mfma_utilisation": mfma_flops / t / (PEAK_F32_TFLOPS * 1e12),
-                "note": "fraction of the 157.3 TF fp32 MFMA peak over the layer's forward+backward wall time; latency-bound by design "
-                        "(19 MFLOP per layer, SURVEY 8d)"}
+                "note": "fraction of the 157.3 TF fp32 MFMA peak over the layer's forward+backward wall time (HIP events around the autograd "
+                        "calls: includes the host's enqueue time of ~12 small launches); the core kernels are bound by reading / writing the fp32 "
+                        "q|k|v tensor (38 MB per pass), not by their 20 MFMAs per (line, head)"}
 
 
 def convgru_seq_figures(dev, Tn: int, n: int, hid: int) -> dict:

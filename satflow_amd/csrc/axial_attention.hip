@@ -324,6 +324,176 @@ __global__ __launch_bounds__(L * L) void attn_bwd_sq_kernel(const AttnParams p) 
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------------------------------------
+// The same core on the matrix cores (16 x 16 maps, head dim 8: MetNet's temporal_agg; exact-fp32 `v_mfma_f32_16x16x4_f32`).
+// One wave per (line, head): the line's 16 positions are the 16 rows / columns of the MFMA tile.
+//   S^T[j][i] = sum_e K[j][e] Q[i][e]      2 MFMAs (e = 0..3, 4..7): lane (i = lane % 16, g = lane / 16) then holds the scores of QUERY i against
+//                                          keys 4g .. 4g+3 ("query-major" layout: A operand lane (j, kk) = K[j][kk], B operand lane (i, kk) = Q[i][kk])
+//   softmax over the keys of a query       in-lane over the 4 registers, across the 4 lane groups by two xor-shuffles (16, 32)
+//   O[i][e]   = sum_j P[i][j] V[j][e]      4 MFMAs with the K index permuted (step r uses keys r, 4+r, 8+r, 12+r): the A operand of step r is
+//                                          simply register r of P - no data movement; B operand lane (e, g) = V[4g + r][e] (e < 8, else 0)
+// The backward also needs P and dS with a KEY per lane (dK = dS^T Q, dV = P^T dO): the same two products with the operands swapped land in that
+// layout directly (2 + 2 more MFMAs; the row statistics come over by ds_bpermute) - 20 MFMAs per (line, head), no LDS memory, no atomics.
+// Block = (image, axis, quarter of the lines), one line per wave, its 8 heads back to back.  sf_axial_attention_core_fwd/bwd, reference call site satflow/models/pl_metnet.py:46-59.
+typedef float f32x4v __attribute__((ext_vector_type(4)));
+
+struct AttnLine {  // per-lane addressing of one line: pixel of position `pos` = base + pos * step
+  long long base; int step;
+};
+__device__ __forceinline__ float shfl_xor_f(float v, int m) { return __shfl_xor(v, m); }
+
+// A wave first pulls its line's rows - 16 positions x [q | k | v] = 192 floats each - into LDS with 16-byte loads (all in flight at once), pitch 196
+// floats: the per-head operand reads ([pos][column]: 16 positions x 4 columns, or 4 positions x 16 columns) then hit 64 different banks.  The
+// backward writes dq / dk / dv of a head over that head's q / k / v columns (nobody reads them again) and the whole line leaves with 16-byte stores.
+constexpr int AT_PITCH = 196, AT_OPITCH = 68;
+
+__device__ __forceinline__ void attn_load_rows(const float* __restrict__ src, long long base, int step, int stride, int col0, int ncol4, int lane,
+                                               float* lds_rows, int pitch) {
+  // rows of ncol4 float4 starting at column col0, 16 positions
+  for (int idx = lane; idx < 16 * ncol4; idx += 64) {
+    const int pos = idx / ncol4, c4 = idx - pos * ncol4;
+    *reinterpret_cast<f32x4v*>(lds_rows + pos * pitch + 4 * c4) = *reinterpret_cast<const f32x4v*>(src + (base + (long long)pos * step) * stride + col0 + 4 * c4);
+  }
+}
+__device__ __forceinline__ void attn_store_rows(float* __restrict__ dst, long long base, int step, int stride, int col0, int ncol4, int lane,
+                                                const float* lds_rows, int pitch) {
+  for (int idx = lane; idx < 16 * ncol4; idx += 64) {
+    const int pos = idx / ncol4, c4 = idx - pos * ncol4;
+    *reinterpret_cast<f32x4v*>(dst + (base + (long long)pos * step) * stride + col0 + 4 * c4) = *reinterpret_cast<const f32x4v*>(lds_rows + pos * pitch + 4 * c4);
+  }
+}
+
+__global__ __launch_bounds__(256) void attn_fwd_mfma_kernel(const AttnParams p) {
+  constexpr int L = 16, E = 8;
+  __shared__ __attribute__((aligned(16))) float rows[4][L * AT_PITCH], outs[4][L * AT_OPITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long img = blockIdx.x >> 3;
+  const int axis = (blockIdx.x >> 2) & 1;
+  const int pos = lane & 15, g = lane >> 4;
+  const int line = 4 * (blockIdx.x & 3) + wave;  // one line per wave: 16 x 2 x nimg waves, the eight heads of a line back to back
+  // axis 0: attend along H, the line is column `line`; axis 1: along W, the line is row `line`
+  const long long base = axis == 0 ? img * L * L + line : (img * L + line) * (long long)L;
+  const int step = axis == 0 ? L : 1;
+  float* R = rows[wave];
+  float* O = outs[wave];
+  attn_load_rows(p.qkv, base, step, p.qs, axis * 3 * p.hidp, 48, lane, R, AT_PITCH);
+  __syncthreads();
+#pragma unroll 2
+  for (int head = 0; head < 8; ++head) {
+    const int ho = head * E;
+    const float* rp = R + pos * AT_PITCH + ho + g;
+    const float q0 = rp[0], q1 = rp[4], k0 = rp[64], k1 = rp[68];
+    float vv[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) vv[r] = pos < E ? R[(4 * g + r) * AT_PITCH + 128 + ho + pos] : 0.f;
+    f32x4v st = {0.f, 0.f, 0.f, 0.f};
+    st = __builtin_amdgcn_mfma_f32_16x16x4f32(k0, q0, st, 0, 0, 0);
+    st = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, q1, st, 0, 0, 0);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] *= p.scale; m = fmaxf(m, st[r]); }
+    m = fmaxf(m, shfl_xor_f(m, 16)); m = fmaxf(m, shfl_xor_f(m, 32));
+    float z = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] = expf(st[r] - m); z += st[r]; }
+    z += shfl_xor_f(z, 16); z += shfl_xor_f(z, 32);
+    const float inv = 1.f / z;
+    f32x4v o = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int r = 0; r < 4; ++r) o = __builtin_amdgcn_mfma_f32_16x16x4f32(st[r] * inv, vv[r], o, 0, 0, 0);
+    if (pos < E) {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) O[(4 * g + r) * AT_OPITCH + ho + pos] = o[r];
+    }
+  }
+  __syncthreads();
+  attn_store_rows(p.att, base, step, p.as, axis * p.hidp, 16, lane, O, AT_OPITCH);
+}
+
+__global__ __launch_bounds__(256) void attn_bwd_mfma_kernel(const AttnParams p) {
+  constexpr int L = 16, E = 8;
+  __shared__ __attribute__((aligned(16))) float rows[4][L * AT_PITCH], grows[4][L * AT_OPITCH];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const long long img = blockIdx.x >> 3;
+  const int axis = (blockIdx.x >> 2) & 1;
+  const int pos = lane & 15, g = lane >> 4;
+  const int line = 4 * (blockIdx.x & 3) + wave;
+  const long long base = axis == 0 ? img * L * L + line : (img * L + line) * (long long)L;
+  const int step = axis == 0 ? L : 1;
+  float* R = rows[wave];
+  float* G = grows[wave];
+  attn_load_rows(p.qkv, base, step, p.qs, axis * 3 * p.hidp, 48, lane, R, AT_PITCH);
+  attn_load_rows(p.datt, base, step, p.das, axis * p.hidp, 16, lane, G, AT_OPITCH);
+  __syncthreads();
+#pragma unroll 2
+  for (int head = 0; head < 8; ++head) {
+    const int ho = head * E;
+    // operands with this lane's own position (lane (pos, kk = g)): e = g and g + 4
+    const float* rp = R + pos * AT_PITCH + ho + g;
+    const float q0 = rp[0], q1 = rp[4], k0 = rp[64], k1 = rp[68], v0 = rp[128], v1 = rp[132];
+    const float d0 = G[pos * AT_OPITCH + ho + g], d1 = G[pos * AT_OPITCH + ho + g + 4];
+    // operands with positions 4g + r and channel e = pos (B operands of the K = position products)
+    float kb[4], qb[4], db[4];
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float* rr = R + (4 * g + r) * AT_PITCH + ho + pos;
+      qb[r] = pos < E ? rr[0] : 0.f;
+      kb[r] = pos < E ? rr[64] : 0.f;
+      db[r] = pos < E ? G[(4 * g + r) * AT_OPITCH + ho + pos] : 0.f;
+    }
+    const f32x4v zero = {0.f, 0.f, 0.f, 0.f};
+    // query-major: lane (i, g) <- X[i][4g + r]
+    f32x4v st = __builtin_amdgcn_mfma_f32_16x16x4f32(k1, q1, __builtin_amdgcn_mfma_f32_16x16x4f32(k0, q0, zero, 0, 0, 0), 0, 0, 0);
+    f32x4v dpt = __builtin_amdgcn_mfma_f32_16x16x4f32(v1, d1, __builtin_amdgcn_mfma_f32_16x16x4f32(v0, d0, zero, 0, 0, 0), 0, 0, 0);
+    // key-major: lane (j, g) <- X[4g + r][j]
+    f32x4v sn = __builtin_amdgcn_mfma_f32_16x16x4f32(q1, k1, __builtin_amdgcn_mfma_f32_16x16x4f32(q0, k0, zero, 0, 0, 0), 0, 0, 0);
+    f32x4v dpn = __builtin_amdgcn_mfma_f32_16x16x4f32(d1, v1, __builtin_amdgcn_mfma_f32_16x16x4f32(d0, v0, zero, 0, 0, 0), 0, 0, 0);
+    float m = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] *= p.scale; m = fmaxf(m, st[r]); }
+    m = fmaxf(m, shfl_xor_f(m, 16)); m = fmaxf(m, shfl_xor_f(m, 32));
+    float z = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] = expf(st[r] - m); z += st[r]; }
+    z += shfl_xor_f(z, 16); z += shfl_xor_f(z, 32);
+    const float inv = 1.f / z;
+    float spd = 0.f;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) { st[r] *= inv; spd += st[r] * dpt[r]; }
+    spd += shfl_xor_f(spd, 16); spd += shfl_xor_f(spd, 32);
+    f32x4v dst;  // dS, query-major
+#pragma unroll
+    for (int r = 0; r < 4; ++r) dst[r] = st[r] * (dpt[r] - spd) * p.scale;
+    // the statistics of query 4g + r, for the key-major layout (any lane of that query holds them: take lane 4g + r)
+    f32x4v pn, dsn;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int src = 4 * g + r;
+      const float mi = __shfl(m, src), ii = __shfl(inv, src), si = __shfl(spd, src);
+      const float pr = expf(sn[r] * p.scale - mi) * ii;
+      pn[r] = pr;
+      dsn[r] = pr * (dpn[r] - si) * p.scale;
+    }
+    f32x4v dq = zero, dk = zero, dv = zero;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      dq = __builtin_amdgcn_mfma_f32_16x16x4f32(dst[r], kb[r], dq, 0, 0, 0);   // dQ[i][e] = sum_j dS[i][j] K[j][e]
+      dk = __builtin_amdgcn_mfma_f32_16x16x4f32(dsn[r], qb[r], dk, 0, 0, 0);   // dK[j][e] = sum_i dS[i][j] Q[i][e]
+      dv = __builtin_amdgcn_mfma_f32_16x16x4f32(pn[r], db[r], dv, 0, 0, 0);    // dV[j][e] = sum_i P[i][j] dO[i][e]
+    }
+    if (pos < E) {  // over this head's q / k / v columns: every read of them is above
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        float* d = R + (4 * g + r) * AT_PITCH + ho + pos;
+        d[0] = dq[r]; d[64] = dk[r]; d[128] = dv[r];
+      }
+    }
+  }
+  __syncthreads();
+  attn_store_rows(p.dqkv, base, step, p.dqs, axis * 3 * p.hidp, 48, lane, R, AT_PITCH);
+}
+
 int check(const AttnParams& p, sfTensor qkv, int c_other, const char* what) {
   if (p.hid % p.heads != 0 || p.hid / p.heads > MAXE || p.H > MAXL || p.W > MAXL || p.hid > p.hidp || qkv.c < 6 * p.hidp || c_other < 2 * p.hidp) {
     sf_set_error("%s: unsupported shape hid=%d heads=%d H=%d W=%d (need hid%%heads==0, hid/heads<=%d, H,W<=%d)", what, p.hid, p.heads, p.H,
@@ -354,7 +524,9 @@ int sf_axial_attention_core_fwd(sfTensor qkv, int64_t nimg, int32_t h, int32_t w
   const int e = hid / heads;
   const bool vec = h == w && (((uintptr_t)qkv.ptr | (uintptr_t)att.ptr) & 15) == 0 && qkv.stride % 4 == 0 && att.stride % 4 == 0 && hidp % 4 == 0;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
-  if (vec && h == 16 && e == 8) hipLaunchKernelGGL((attn_fwd_sq_kernel<16, 8>), grid, block, 0, (hipStream_t)stream, p);
+  static const bool no_mfma = getenv("SF_ATTN_NO_MFMA") != nullptr;  // A/B switch: the thread-per-row kernels
+  if (!no_mfma && vec && h == 16 && w == 16 && e == 8 && heads == 8 && hidp == 64) hipLaunchKernelGGL(attn_fwd_mfma_kernel, dim3((unsigned)(8 * nimg)), block, 0, (hipStream_t)stream, p);
+  else if (vec && h == 16 && e == 8) hipLaunchKernelGGL((attn_fwd_sq_kernel<16, 8>), grid, block, 0, (hipStream_t)stream, p);
   else if (vec && h == 16 && e == 4) hipLaunchKernelGGL((attn_fwd_sq_kernel<16, 4>), grid, block, 0, (hipStream_t)stream, p);
   else hipLaunchKernelGGL(attn_fwd_kernel, grid, block, 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("axial_attention_fwd");
@@ -381,7 +553,10 @@ int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32
   const int e = hid / heads;
   const bool vec = h == w && (((uintptr_t)qkv.ptr | (uintptr_t)datt.ptr | (uintptr_t)dqkv.ptr) & 15) == 0 && qkv.stride % 4 == 0 &&
                    datt.stride % 4 == 0 && dqkv.stride % 4 == 0 && hidp % 4 == 0;
-  if (vec && h == 16 && (e == 8 || e == 4)) {
+  static const bool no_mfma = getenv("SF_ATTN_NO_MFMA") != nullptr;
+  if (!no_mfma && vec && h == 16 && w == 16 && e == 8 && heads == 8 && hidp == 64) {
+    hipLaunchKernelGGL(attn_bwd_mfma_kernel, dim3((unsigned)(8 * nimg)), dim3(256), 0, (hipStream_t)stream, p);
+  } else if (vec && h == 16 && (e == 8 || e == 4)) {
     const dim3 grid((unsigned)nimg, 2 * heads), block(256);
     if (e == 8) hipLaunchKernelGGL((attn_bwd_sq_kernel<16, 8>), grid, block, 0, (hipStream_t)stream, p);
     else hipLaunchKernelGGL((attn_bwd_sq_kernel<16, 4>), grid, block, 0, (hipStream_t)stream, p);
