@@ -530,7 +530,11 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
   if constexpr (EPI == EPI_LSTM) {
     if (nf != 4) { sf_set_error("bf16 conv: LSTM epilogue needs nf=4"); return 1; }
     if constexpr (WAVES == 4 && !DUAL) {
-      static const bool ws = getenv("SF_LSTM_WS") != nullptr;  // experiment switch (with SF_LSTM_W4=1): single weight buffer, two workgroups per CU
+      // single weight buffer, 58 KB of LDS, two workgroups per CU: one's epilogue (224 KB of stores per item: ~10 us of the CU's memory pipe) runs
+      // under the other's K loop.  Default for the large launches of the training shapes since round 4 (cfg 2: 813 -> 819 samples/s, three A/B
+      // pairs on one box); SF_LSTM_WS=1 forces it, SF_LSTM_W8=1 restores the 8-wave double-buffered kernel.
+      static const bool ws_env = getenv("SF_LSTM_WS") != nullptr, w8 = getenv("SF_LSTM_W8") != nullptr;
+      const bool ws = ws_env || (!w8 && (long long)grid.x * grid.y >= 1024);
       if (ws) hipLaunchKernelGGL((conv3x3_bf16_kernel<4, 4, EPI, false, true, false, true>), grid, block, 0, st, p);
       else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, DUAL, true>), grid, block, 0, st, p);
     } else
@@ -581,9 +585,10 @@ int launch_e(const ConvParams& p, int nf, int nblk, hipStream_t st) {
   // where that kernel fits only one workgroup per CU (NF >= 4: 94 KB LDS) and there are enough images to fill the chip
   // with 8-wave workgroups holding two images each (measured 192->256 @16x16 x 2304: 811 -> 574 us; NF = 3 and the
   // 96-image ConvGRU steps are faster on the 4-wave kernel)
-  if constexpr (EPI == EPI_LSTM) {  // SF_LSTM_W4=1: the fused cell on 16x16 tiles, two workgroups per CU (experiment switch)
-    static const bool w4 = getenv("SF_LSTM_W4") != nullptr;
-    if (w4) return launch_w<4, EPI>(p, nf, nblk, st);
+  if constexpr (EPI == EPI_LSTM) {  // the fused cell on 16x16 tiles, two workgroups per CU, when that gives at least 1024 workgroups (see launch_w)
+    static const bool w4 = getenv("SF_LSTM_W4") != nullptr, w8 = getenv("SF_LSTM_W8") != nullptr;
+    const long long wgs16 = (long long)((p.W + TILE_W - 1) / TILE_W) * ((p.H + 15) / 16) * p.N * nblk;
+    if (w4 || (!w8 && p.H > 16 && wgs16 >= 1024)) return launch_w<4, EPI>(p, nf, nblk, st);
   }
   if (p.H > 16) return launch_w<8, EPI>(p, nf, nblk, st);
   if (p.W <= 16 && !p.stats && nf >= 4 && p.N >= 512) return launch_w<8, EPI, true>(p, nf, nblk, st);
