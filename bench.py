@@ -188,7 +188,8 @@ class ConvLSTMWorkload:
                 traffic_src = f"profiles/{PROFILE_ROUND}_convlstm_bf16a_pmc_cell.json is stale (kernel sources changed): dropped"
         return {"bound": "mfma", "achieved": flops / t / 1e12, "peak": peak, "unit": "TFLOP/s",
                 "frac": flops / t / 1e12 / peak, "traffic": traffic, "traffic_source": traffic_src,
-                "kernel": "conv3x3_%s_kernel<4,LSTM> (sf_convlstm_cell_fwd, %d->%d ch, 128x128, B=%d)" % ("bf16" if bf16 else "f32", 2 * hid, 4 * hid, B),
+                "kernel": "conv3x3_%s_kernel<NF=4, LSTM epilogue%s> (sf_convlstm_cell_fwd, %d->%d ch, 128x128, B=%d)" % (
+                    "bf16" if bf16 else "f32", "; 4 waves, 16x16 tiles, one weight buffer: two workgroups per CU" if bf16 else "", 2 * hid, 4 * hid, B),
                 "launch_us": t * 1e6, "algorithmic_flops": flops, "algorithmic_bytes": alg_bytes,
                 "hbm_gbps_algorithmic": alg_bytes / t / 1e9, "hbm_frac_algorithmic": alg_bytes / t / 1e9 / PEAK_HBM_GBPS,
                 "note": ("bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16); bf16-stored x / h / gates: intensity 922 F/B vs ridge "
