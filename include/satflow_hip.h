@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16) */
-#define SF_ABI_VERSION 3
+/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*) */
+#define SF_ABI_VERSION 4
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */
@@ -595,6 +595,18 @@ int sf_bmm_bf16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const flo
 int sf_bmm_f16(const float* A, int64_t sAb, int64_t sAm, int64_t sAk, const float* B, int64_t sBb, int64_t sBk, int64_t sBn, float* C,
                int64_t sCb, int64_t sCm, int64_t sCn, int32_t batch, int32_t M, int32_t N, int32_t K, float alpha, float beta,
                sfStream stream);
+/* softmax(q k^T * scale) v in ONE pass, the score matrix never in memory (round 4): the self-attention of both discriminators
+ * (Discriminator.py:104-126: `energy = torch.bmm(q, k^T)`, `softmax(dim=-1)`, `torch.bmm(attention, v)`; Attention.py:173-223) as the reference's 16-bit
+ * mode computes it - operands and probabilities rounded to the compute type (SF_BF16 / SF_F16: the only dtypes built), fp32 accumulation and
+ * softmax statistics.  q, k [batch][n][ld >= dqk], v, out [batch][n][ld >= dv], fp32, rows 16-byte aligned; n a multiple of 128, dqk 16 or 32
+ * (narrower operands: zero-padded lanes), dv 32 / 64 / 128 / 256.  lse [batch][n] (nullable in _fwd) receives max + log(sum) of each query's scaled
+ * scores: _bwd recomputes the probabilities from it.  _bwd: dq, dk [..][ld >= dqk], dv [..][ld >= dv] are overwritten (lanes >= dqk untouched),
+ * delta [batch][n] is scratch.  Deterministic (no atomics). */
+int sf_flash_attention_fwd(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, int32_t batch, int32_t n, int32_t dqk,
+                           int32_t dv, float scale, float* out, int32_t ldo, float* lse, int32_t dtype, sfStream stream);
+int sf_flash_attention_bwd(const float* q, int32_t ldq, const float* k, int32_t ldk, const float* v, int32_t ldv, const float* out, int32_t ldo,
+                           const float* lse, const float* dout, int32_t lddo, int32_t batch, int32_t n, int32_t dqk, int32_t dv, float scale, float* dq,
+                           int32_t lddq, float* dk, int32_t lddk, float* dvg, int32_t lddv, float* delta, int32_t dtype, sfStream stream);
 int sf_softmax_rows_fwd(const float* x, int64_t rows, int32_t L, float* y, sfStream stream);
 int sf_softmax_rows_bwd(const float* g, const float* y, int64_t rows, int32_t L, float* dx, sfStream stream);
 

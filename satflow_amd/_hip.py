@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os
 SF_F32, SF_BF16, SF_F16 = 0, 1, 2
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 3  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
+ABI_VERSION = 4  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
@@ -150,6 +150,9 @@ PROTOTYPES = {
     "sf_bmm_f32": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sf_bmm_bf16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
     "sf_bmm_f16": (C.c_int, [_vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, C.c_float, C.c_float, _vp]),
+    "sf_flash_attention_fwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp, _i32, _vp, _i32, _vp]),
+    "sf_flash_attention_bwd": (C.c_int, [_vp, _i32, _vp, _i32, _vp, _i32, _vp, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, C.c_float, _vp, _i32, _vp, _i32,
+                                         _vp, _i32, _vp, _i32, _vp]),
     "sf_softmax_rows_fwd": (C.c_int, [_vp, _i64, _i32, _vp, _vp]),
     "sf_softmax_rows_bwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp, _vp]),
     "sf_nhwc_to_nchw": (C.c_int, [sfTensor, _i32, _i32, _i32, _i32, _i32, _vp, _i64, _i64, _i64, _i32, _vp]),

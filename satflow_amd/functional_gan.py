@@ -562,6 +562,33 @@ class _BmmFn(torch.autograd.Function):
         return dA, dB, None
 
 
+class _FlashAttnFn(torch.autograd.Function):
+    """``softmax(q k^T) v`` of the self-attention layers in the 16-bit compute modes, fused (sf_flash_attention_fwd / _bwd): what
+    ``bmm(softmax_last(bmm(q, k^T, lowp)), v, lowp)`` computes, without the ``[n, HW, HW]`` score tensor."""
+
+    @staticmethod
+    def forward(ctx, q: Tensor, k: Tensor, v: Tensor, scale: float):
+        out, lse = K.flash_attention_fwd(q, k, v, scale)
+        ctx.save_for_backward(q, k, v, out, lse)
+        ctx.scale = scale
+        return out
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        q, k, v, out, lse = ctx.saved_tensors
+        dq, dk, dv = K.flash_attention_bwd(q, k, v, out, lse, g, ctx.scale)
+        return dq, dk, dv, None
+
+
+def attention(q: Tensor, k: Tensor, v: Tensor) -> Tensor:
+    """``bmm(softmax(bmm(q, k^T)), v)`` of reference ``Discriminator.py:118-124`` / ``Attention.py:206-217`` on ``[n, HW, lanes]`` operands: the fused
+    kernel where it applies (16-bit compute modes, HW a multiple of 128, operand widths it is built for), the three materialised steps otherwise."""
+    if K.flash_attention_ok(q, k, v):
+        return _FlashAttnFn.apply(q, k, v, 1.0)
+    att = softmax_last(bmm(q, k.transpose(1, 2), lowp=True))
+    return bmm(att, v, lowp=True)
+
+
 def bmm(A: Tensor, B: Tensor, lowp: bool = False) -> Tensor:
     """``lowp=False``: exact fp32 in every compute mode (selection matrices, dot products of embeddings)."""
     require_device(A, "A")

@@ -394,6 +394,40 @@ def bmm_raw(A: Tensor, B: Tensor, out: Tensor, alpha: float = 1.0, beta: float =
              alpha, beta, stream_ptr()), name)
 
 
+def flash_attention_ok(q: Tensor, k: Tensor, v: Tensor) -> bool:
+    """Shapes sf_flash_attention_* takes in the current compute mode: a 16-bit mode, [batch, n, lanes] fp32 with contiguous rows, n a multiple of 128,
+    q / k 16 or 32 lanes wide, v 32 / 64 / 128 / 256."""
+    if _hip.compute_dtype() not in (_hip.SF_BF16, _hip.SF_F16) or q.dim() != 3:
+        return False
+    b, n, dqk = q.shape
+    return (n % 128 == 0 and dqk in (16, 32) and k.shape == q.shape and v.shape[:2] == (b, n) and v.shape[2] in (32, 64, 128, 256)
+            and all(t.dtype == torch.float32 and t.stride(2) == 1 and t.stride(1) % 4 == 0 and t.stride(0) == n * t.stride(1) and t.data_ptr() % 16 == 0 for t in (q, k, v)))
+
+
+def flash_attention_fwd(q: Tensor, k: Tensor, v: Tensor, scale: float) -> Tuple[Tensor, Tensor]:
+    """``softmax(scale * q k^T) v`` without the score matrix; returns (out, log-sum-exp per query).  sf_flash_attention_fwd."""
+    b, n, dqk = q.shape
+    dv = v.shape[2]
+    out = torch.empty(b, n, dv, dtype=torch.float32, device=q.device)
+    lse = torch.empty(b, n, dtype=torch.float32, device=q.device)
+    check(lib().sf_flash_attention_fwd(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1), b, n, dqk, dv, scale, out.data_ptr(),
+                                       out.stride(1), lse.data_ptr(), _hip.compute_dtype(), stream_ptr()), "sf_flash_attention_fwd")
+    return out, lse
+
+
+def flash_attention_bwd(q: Tensor, k: Tensor, v: Tensor, out: Tensor, lse: Tensor, dout: Tensor, scale: float) -> Tuple[Tensor, Tensor, Tensor]:
+    """Gradients of flash_attention_fwd (probabilities recomputed from ``lse``).  sf_flash_attention_bwd."""
+    b, n, dqk = q.shape
+    dv = v.shape[2]
+    dout = dout.contiguous()
+    dq, dk, dvg = torch.zeros_like(q), torch.zeros_like(k), torch.empty(b, n, dv, dtype=torch.float32, device=q.device)
+    delta = torch.empty(b, n, dtype=torch.float32, device=q.device)
+    check(lib().sf_flash_attention_bwd(q.data_ptr(), q.stride(1), k.data_ptr(), k.stride(1), v.data_ptr(), v.stride(1), out.data_ptr(), out.stride(1), lse.data_ptr(),
+                                       dout.data_ptr(), dout.stride(1), b, n, dqk, dv, scale, dq.data_ptr(), dq.stride(1), dk.data_ptr(), dk.stride(1),
+                                       dvg.data_ptr(), dvg.stride(1), delta.data_ptr(), _hip.compute_dtype(), stream_ptr()), "sf_flash_attention_bwd")
+    return dq, dk, dvg
+
+
 def linear_bwd_weight_any(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[Tensor, Optional[Tensor]]:
     """``linear_bwd_weight`` for any K: the split-K MFMA kernel up to K = 256, beyond that (the 1x1 convolutions of the DGMR
     discriminators, up to 2048 channels) the strided batched product over row slices plus a product with a ones vector that sums

@@ -55,8 +55,7 @@ class SelfAttention(nn.Module):
         q = F.linear(x, self.query_conv.weight.view(d, c), self.query_conv.bias).view(n, h * w, -1)   # pad lanes are zero
         k = F.linear(x, self.key_conv.weight.view(d, c), self.key_conv.bias).view(n, h * w, -1)
         v = F.linear(x, self.value_conv.weight.view(c, c), self.value_conv.bias, out_lanes=cp).view(n, h * w, cp)
-        att = FG.softmax_last(FG.bmm(q, k.transpose(1, 2), lowp=True))
-        out = FG.bmm(att, v, lowp=True).view(n, h, w, cp)
+        out = FG.attention(q, k, v).view(n, h, w, cp)
         return FG.gamma_residual(out, x, self.gamma)
 
     def forward(self, x):

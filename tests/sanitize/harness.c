@@ -176,6 +176,13 @@ int main(void) {
   REFUSED(sf_bmm_bf16(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                 /* empty inner dimension */
   REFUSED(sf_bmm_f16(ok, 0, 8, 1, 0, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 8, 1.f, 0.f, st));                   /* no B */
   REFUSED(sf_bmm_f16(ok, 0, 8, 1, ok, 0, 8, 1, ok, 0, 8, 1, 1, 8, 8, 0, 1.f, 0.f, st));                  /* empty inner dimension */
+  REFUSED(sf_flash_attention_fwd(ok, 32, ok, 32, ok, 256, 1, 128, 32, 256, 1.f, ok, 256, ok, SF_F32, st));     /* fp32: only the 16-bit modes have the fused form */
+  REFUSED(sf_flash_attention_fwd(ok, 32, ok, 32, ok, 256, 1, 100, 32, 256, 1.f, ok, 256, ok, SF_BF16, st));    /* n not a multiple of 128 */
+  REFUSED(sf_flash_attention_fwd(ok, 32, ok, 32, ok, 256, 1, 128, 24, 256, 1.f, ok, 256, ok, SF_BF16, st));    /* key width */
+  REFUSED(sf_flash_attention_fwd(ok, 32, ok, 32, 0, 256, 1, 128, 32, 256, 1.f, ok, 256, ok, SF_F16, st));      /* no v */
+  REFUSED(sf_flash_attention_bwd(ok, 32, ok, 32, ok, 256, ok, 256, 0, ok, 256, 1, 128, 32, 256, 1.f, ok, 32, ok, 32, ok, 256, ok, SF_BF16, st));   /* no lse */
+  REFUSED(sf_flash_attention_bwd(ok, 32, ok, 32, ok, 256, ok, 256, ok, ok, 256, 1, 128, 32, 96, 1.f, ok, 32, ok, 32, ok, 256, ok, SF_BF16, st));   /* value width */
+  REFUSED(sf_flash_attention_bwd(ok, 32, ok, 32, ok, 256, ok, 256, ok, ok, 256, 1, 128, 32, 256, 1.f, ok, 32, ok, 32, ok, 256, ok, SF_F32, st));   /* fp32 */
   REFUSED(sf_softmax_rows_fwd(ok, 4, 0, ok, st));                                                        /* empty rows */
   REFUSED(sf_softmax_rows_bwd(ok, 0, 4, 8, ok, st));                                                     /* no softmax output */
   REFUSED(sf_layernorm_chw_fwd(a64, 2, 64, 4, 12, 16, ok, ok, 1e-5f, 0, a64, st));                       /* no partial-sum buffer */
