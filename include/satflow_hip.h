@@ -160,7 +160,8 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
                          sfStream stream);
 
 /* Pointwise part of the cell's backward (autograd of layers/ConvLSTM.py:48-55):
- *   dh = sum of up to three incoming hidden-state gradients (NULL ptr = absent)
+ *   dh = sum of up to three incoming hidden-state gradients (NULL ptr = absent; each SF_F32 or SF_BF16: the input-gradient convolutions'
+ *        output is stored as bf16 in "bf16a" mode, as a 16-bit autocast leaves it; summed in fp32)
  *   dc_next (nullable) gradient flowing into c'; gates = saved i,f,o,g; c_prev nullable (zeros)
  *   -> dz [.., 4*hidp] gradient wrt the pre-activation conv output, dc_prev (nullable out).
  *   gates and dz share one storage type (SF_F32 or SF_BF16; dz may overwrite gates in place). */

@@ -7,7 +7,8 @@
 namespace {
 
 struct GateBwdParams {
-  const float* dh0; const float* dh1; const float* dh2; int s_dh0, s_dh1, s_dh2;
+  const void* dh0; const void* dh1; const void* dh2; int s_dh0, s_dh1, s_dh2;
+  int bf_dh0, bf_dh1, bf_dh2;   // per source: stored as bf16 (the input-gradient convolutions' output in "bf16a" mode) or fp32
   const float* dc_next; int s_dcn;
   const void* gates; int s_g;
   const float* c_prev; int s_cp;
@@ -27,9 +28,14 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long pix = idx / q;
     const int c = (int)(idx - pix * q) * 4;
-    f32x4 dh = ld4(p.dh0 + pix * p.s_dh0 + c);
-    if (p.dh1) dh += ld4(p.dh1 + pix * p.s_dh1 + c);
-    if (p.dh2) dh += ld4(p.dh2 + pix * p.s_dh2 + c);
+    // (kernel-uniform branches; the sum is taken in fp32 whatever the storage)
+    auto ldh = [&](const void* q, int stride, int bf) -> f32x4 {
+      if (bf) return __builtin_convertvector(*reinterpret_cast<const bf16x4*>(reinterpret_cast<const __bf16*>(q) + pix * stride + c), f32x4);
+      return ld4(reinterpret_cast<const float*>(q) + pix * stride + c);
+    };
+    f32x4 dh = ldh(p.dh0, p.s_dh0, p.bf_dh0);
+    if (p.dh1) dh += ldh(p.dh1, p.s_dh1, p.bf_dh1);
+    if (p.dh2) dh += ldh(p.dh2, p.s_dh2, p.bf_dh2);
     const TG* g = reinterpret_cast<const TG*>(p.gates) + pix * p.s_g + c;
     const f32x4 gi = ldv4(g), gf = ldv4(g + p.hidp), go = ldv4(g + 2 * p.hidp), gg = ldv4(g + 3 * p.hidp);
     const f32x4 cn = ld4(p.c_new + pix * p.s_cn + c);
@@ -56,9 +62,12 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
 }
 
 bool aligned4(const sfTensor& t) { return t.ptr == nullptr || ((((uintptr_t)t.ptr) & 15) == 0 && t.stride % 4 == 0 && t.dtype == SF_F32); }  // fp32 storage only
+bool aligned4g0(const sfTensor& t);
 bool aligned4g(const sfTensor& t) {  // gates / dz: fp32 or bf16 storage
   return ((((uintptr_t)t.ptr) & (t.dtype == SF_BF16 ? 7 : 15)) == 0 && t.stride % 4 == 0 && (t.dtype == SF_F32 || t.dtype == SF_BF16));
 }
+
+bool aligned4g0(const sfTensor& t) { return t.ptr == nullptr || aligned4g(t); }  // nullable dh source, fp32 or bf16
 
 }  // namespace
 
@@ -68,11 +77,12 @@ extern "C" int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor d
   SF_REQUIRE(dtype == SF_F32, "sf_convlstm_cell_bwd_gates: dtype %d not built", dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && hidp > 0, "bwd_gates: hidp=%d", hidp);
   SF_REQUIRE(dh0.ptr && gates.ptr && c_new.ptr && dz.ptr, "bwd_gates: dh0, gates, c_new, dz must be non-null");
-  SF_REQUIRE(aligned4(dh0) && aligned4(dh1) && aligned4(dh2) && aligned4(dc_next) && aligned4g(gates) && aligned4(c_prev) &&
+  SF_REQUIRE(aligned4g0(dh0) && aligned4g0(dh1) && aligned4g0(dh2) && aligned4(dc_next) && aligned4g(gates) && aligned4(c_prev) &&
                  aligned4(c_new) && aligned4g(dz) && aligned4(dc_prev) && gates.dtype == dz.dtype,
-             "bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0, fp32 (gates / dz: fp32 or bf16, both alike)");
+             "bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0, fp32 (gates / dz: fp32 or bf16, both alike; dh sources: fp32 or bf16 each)");
   GateBwdParams p{};
-  p.dh0 = (const float*)dh0.ptr; p.dh1 = (const float*)dh1.ptr; p.dh2 = (const float*)dh2.ptr;
+  p.dh0 = dh0.ptr; p.dh1 = dh1.ptr; p.dh2 = dh2.ptr;
+  p.bf_dh0 = dh0.dtype == SF_BF16; p.bf_dh1 = dh1.ptr && dh1.dtype == SF_BF16; p.bf_dh2 = dh2.ptr && dh2.dtype == SF_BF16;
   p.s_dh0 = dh0.stride; p.s_dh1 = dh1.stride; p.s_dh2 = dh2.stride;
   p.dc_next = (const float*)dc_next.ptr; p.s_dcn = dc_next.stride;
   p.gates = gates.ptr; p.s_g = gates.stride;

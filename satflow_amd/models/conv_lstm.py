@@ -131,7 +131,11 @@ class _StackFn(torch.autograd.Function):
         need_dx = [ctx.need_dx, True, True, True]
         # per cell: [dx (if needed) ; dh_prev] scratch of the input-gradient conv, and the dc carry
         widths = [(eng.cinp if nd else 0) + hidp for eng, nd in zip(engines, need_dx)]
-        dcat = [torch.empty(B, H, W, wd, dtype=torch.float32, device=dev) for wd in widths]
+        # [dx ; dh] of the input-gradient convolutions: bf16 in "bf16a" mode (what a 16-bit autocast leaves between a convolution's backward and
+        # the gate arithmetic; summed in fp32 by the gate backward) - half the stores of those launches, a tenth of the gate backward's bytes
+        import os
+        dcat_dt = torch.float32 if os.environ.get("SF_LSTM_DCAT_F32") else gate_storage_dtype()   # (A/B switch)
+        dcat = [torch.empty(B, H, W, wd, dtype=dcat_dt, device=dev) for wd in widths]
         dc = [torch.empty(B, H, W, hidp, dtype=torch.float32, device=dev) for _ in range(4)]
         dxs = torch.empty(xs.shape, dtype=torch.float32, device=dev) if ctx.need_dx else None
 
