@@ -211,7 +211,7 @@ int sf_conv3x3_bwd_data_bn(sfTensor dout, int32_t n, int32_t h, int32_t w, const
  * x[B,T,C,H,W] in, [B,C,T,H,W] out, satflow/models/conv_lstm.py:205-228,198-201).
  * The NCHW-side tensor is addressed as  base[b*stride_b + t*stride_t + c*stride_c + y*w + x]
  * for b < nb, t < nt; the NHWC side holds nb*nt images, image index j = t*nb + b (time-major).
- *   nchw_to_nhwc: gathers c real channels, zero-fills the pad lanes dst.c - c
+ *   nchw_to_nhwc: gathers c real channels, zero-fills the pad lanes dst.c - c; dst storage SF_F32 or SF_BF16 (rounded to nearest even)
  *   nhwc_to_nchw: scatters the first c channels back.
  * ------------------------------------------------------------------------------------------- */
 int sf_nchw_to_nhwc(const float* src, int64_t stride_b, int64_t stride_t, int64_t stride_c, int32_t nb,

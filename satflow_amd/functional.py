@@ -25,17 +25,17 @@ class _ToNHWC(torch.autograd.Function):
     """``src`` addressed as [nb][nt] images with element strides ``(sb, st, sc)`` -> ``[nt*nb,H,W,Cp]``."""
 
     @staticmethod
-    def forward(ctx, src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int]):
+    def forward(ctx, src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int], out_dtype=torch.float32):
         src = src.contiguous()
         ctx.meta = (src.shape, nb, nt, c, h, w, strides)
-        return K.to_nhwc(src, nb, nt, c, h, w, strides)
+        return K.to_nhwc(src, nb, nt, c, h, w, strides, out_dtype=out_dtype)
 
     @staticmethod
     def backward(ctx, g: Tensor):
         shape, nb, nt, c, h, w, strides = ctx.meta
         out = torch.empty(shape, dtype=torch.float32, device=g.device)
-        K.from_nhwc(g.contiguous(), nb, nt, c, h, w, out, strides)
-        return out, None, None, None, None, None, None
+        K.from_nhwc(g.contiguous().float(), nb, nt, c, h, w, out, strides)
+        return out, None, None, None, None, None, None, None
 
 
 class _FromNHWC(torch.autograd.Function):

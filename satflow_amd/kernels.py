@@ -262,11 +262,12 @@ def conv3x3_bwd_data_bn(dout: sfTensor, n: int, h: int, w: int, packed_t: Tensor
                                        stream_ptr()), "sf_conv3x3_bwd_data_bn")
 
 
-def to_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int], cp: Optional[int] = None) -> Tensor:
-    """NCHW-side tensor -> time-major NHWC ``[nt*nb, h, w, cp]`` (pad lanes zero).  sf_nchw_to_nhwc."""
+def to_nhwc(src: Tensor, nb: int, nt: int, c: int, h: int, w: int, strides: Tuple[int, int, int], cp: Optional[int] = None,
+            out_dtype=torch.float32) -> Tensor:
+    """NCHW-side tensor -> time-major NHWC ``[nt*nb, h, w, cp]`` (pad lanes zero), stored as fp32 or bf16.  sf_nchw_to_nhwc."""
     _hip.require_device(src, "input")
     cp = cp or cpad(c)
-    dst = torch.empty(nt * nb, h, w, cp, dtype=torch.float32, device=src.device)
+    dst = torch.empty(nt * nb, h, w, cp, dtype=out_dtype, device=src.device)
     check(lib().sf_nchw_to_nhwc(src.data_ptr(), *strides, nb, nt, c, h, w, T(dst), SF_F32, stream_ptr()), "sf_nchw_to_nhwc")
     return dst
 

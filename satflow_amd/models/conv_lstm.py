@@ -18,6 +18,7 @@ single split-K GEMM per cell over all timesteps at the end.
 from __future__ import annotations
 
 from typing import Any, Dict, List, Optional, Tuple, Union
+import os
 
 import torch
 from torch import nn
@@ -251,7 +252,9 @@ class ConvLSTM(nn.Module):
             raise RuntimeError("ConvLSTM needs at least one input frame and forecast_steps >= 1 (torch.stack of an empty list "
                                "fails in the reference too, conv_lstm.py:198)")
         x = x.float()
-        xs = _ToNHWC.apply(x, B, T_in, C, H, W, (T_in * C * H * W, C * H * W, H * W))  # [T*B,H,W,Cp]
+        # [T*B,H,W,Cp], written directly in the storage type the stack reads its frames in (bf16 in "bf16a" mode: no fp32 copy + cast pass)
+        xs = _ToNHWC.apply(x, B, T_in, C, H, W, (T_in * C * H * W, C * H * W, H * W),
+                            torch.float32 if os.environ.get("SF_LSTM_X_F32") else state_storage_dtype())   # (A/B switch)
         cells = self.cells()
         params = [p for c in cells for p in (c.conv.weight, c.conv.bias)]
         hseq = _StackFn.apply([c.engine for c in cells], B, T_in, forecast_steps, xs, *params)
