@@ -531,6 +531,15 @@ int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32
  * row / column masked, lanes >= I zero-padded; _bwd gathers the gradient of the 5x5 weight (dense [O][I][5][5]) back out of the 3x3 form. */
 int sf_regroup5x5_fwd(const float* w5, int64_t row_pitch, int32_t O, int32_t I, int32_t lanes, float* w3, sfStream stream);
 int sf_regroup5x5_bwd(const float* g3, int32_t O, int32_t I, int32_t lanes, float* g5, sfStream stream);
+/* The same 5x5 'same' convolution on the HALF-RESOLUTION domain - the route the generator's ConvGRU SEQUENCE takes (Generator.py:91-117; kernel_sizes 5 at
+ * :42-45): 2x2 pixel blocks of input and output folded into channels, xs[n][Y][X][(2 py + px) * C + c] = x[n][2Y + py][2X + px][c] (sf_space_to_depth2,
+ * inverse != 0: the way back; a permutation, so each direction is the other's adjoint), then ONE 3x3 'same' convolution from 4C to 4R lanes with
+ * w3[(g * 4 + po) * hp + o][pi * lanes + i][ey + 1][ex + 1] = w5[g * hp + o][i][2 ey + qy - py + 2][2 ex + qx - px + 2] (0 outside the 5x5 kernel / for i >= I):
+ * `hp` rows per gate block, gate-major then output phase (the z | r halves of the gate tensor stay halves).  No padded domain, no copies, no crop; the
+ * pointwise stages of the cell are layout-blind, so a whole sequence stays in this layout.  _bwd: the gradient of the dense [R][I][5][5] weight. */
+int sf_space_to_depth2(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t inverse, sfTensor y, sfStream stream);
+int sf_regroup5x5_s2d_fwd(const float* w5, int64_t row_pitch, int32_t R, int32_t hp, int32_t I, int32_t lanes, float* w3, sfStream stream);
+int sf_regroup5x5_s2d_bwd(const float* g3, int32_t R, int32_t hp, int32_t I, int32_t lanes, float* g5, sfStream stream);
 /* A 4x4 stride-2 Conv2d with padding 1 - the down-sampling layers of the PatchGAN discriminator (satflow/models/gan/discriminators.py:166-186,
  * called by CloudGAN, satflow/models/cloudgan.py) - as ONE 3x3 convolution: x padded by 1 with its 2x2 pixel blocks folded into channels,
  * y[n][Y][X][(2 dy + dx) C + c] = x[n][2Y + dy - 1][2X + dx - 1][c] for Y < h/2 + 1, X < w/2 + 1 (h, w even); the 4x4 kernel becomes the taps

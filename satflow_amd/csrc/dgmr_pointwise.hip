@@ -253,6 +253,60 @@ __global__ __launch_bounds__(256) void regroup5_bwd_kernel(const float* __restri
     g5[idx] = g3[((o * 4 + 2 * ty + tx) * lanes + i) * 9 + (y - 2 * ty) * 3 + (x - 2 * tx)];
   }
 }
+// ---- the same 5x5 'same' convolution as ONE 3x3 convolution on the HALF-RESOLUTION domain (the ConvGRU sequence path) ---------------
+// Fold the 2x2 pixel blocks of input AND output into channels (a pure permutation, sf_space_to_depth2):
+//   xs[n][Y][X][(2 py + px) * C + c] = x[n][2 Y + py][2 X + px][c]
+// A 5x5 tap (dy, dx) in [-2, 2]^2 of output phase (py, px) reads block (Y + ey, X + ex), phase (qy, qx) with py + dy = 2 ey + qy: ey in {-1, 0, 1},
+// i.e. a 3x3 'same' convolution from 4C to 4O channels whose zero padding IS the 5x5 convolution's.  Against the four-shifted-copies route above:
+// the same 36 / 25 tap overhead, but no domain padded by 2 (68 x 68 pixels in 16 x 32 tiles run at 60 %), no copy written four times per call and
+// no crop - and since every pointwise stage of a recurrent cell is layout-blind the WHOLE sequence stays in this layout (two permutations per cell).
+//   w3[(g * 4 + po) * hp + o][pi * lanes + i][ey + 1][ex + 1] = w5[g * hp + o][i][dy + 2][dx + 2],  dy = 2 ey + qy - py (0 where |dy| > 2, i >= I)
+// (rows: `hp` per gate block, gate-major then output phase: the z | r halves of a GRU's gate tensor stay halves).
+__global__ __launch_bounds__(256) void s2d2_kernel(const float* __restrict__ x, long long n, int H2, int W2, int q, float* __restrict__ y, int inverse) {
+  const int C = q * 4;
+  const long long total = n * H2 * W2 * 4 * q;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int c = (int)(idx % q) * 4;
+    long long r = idx / q;
+    const int s = (int)(r % 4); r /= 4;
+    const int X = (int)(r % W2); r /= W2;
+    const int Y = (int)(r % H2); const long long img = r / H2;
+    const long long full = ((img * (2 * H2) + 2 * Y + (s >> 1)) * (long long)(2 * W2) + 2 * X + (s & 1)) * C + c;
+    if (inverse) st4(y + full, ld4(x + idx * 4));
+    else st4(y + idx * 4, ld4(x + full));
+  }
+}
+__global__ __launch_bounds__(256) void regroup5_s2d_fwd_kernel(const float* __restrict__ w5, long long so, int R, int hp, int I, int lanes, float* __restrict__ w3) {
+  const long long total = (long long)R * 4 * 4 * lanes * 9;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int k = (int)(idx % 9); long long r = idx / 9;
+    const int i = (int)(r % lanes); r /= lanes;
+    const int pi = (int)(r % 4); r /= 4;
+    const int o = (int)(r % hp); r /= hp;
+    const int po = (int)(r % 4); const long long g = r / 4;
+    const int dy = 2 * (k / 3 - 1) + (pi >> 1) - (po >> 1), dx = 2 * (k % 3 - 1) + (pi & 1) - (po & 1);
+    const bool live = i < I && dy >= -2 && dy <= 2 && dx >= -2 && dx <= 2;
+    w3[idx] = live ? w5[(g * hp + o) * so + (long long)i * 25 + (dy + 2) * 5 + dx + 2] : 0.f;
+  }
+}
+__global__ __launch_bounds__(256) void regroup5_s2d_bwd_kernel(const float* __restrict__ g3, int R, int hp, int I, int lanes, float* __restrict__ g5) {
+  const long long total = (long long)R * I * 25;
+  for (long long idx = (long long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long long)gridDim.x * 256) {
+    const int x = (int)(idx % 5); long long r = idx / 5;
+    const int y = (int)(r % 5); r /= 5;
+    const int i = (int)(r % I); const long long row = r / I;
+    const long long g = row / hp; const int o = (int)(row % hp);
+    float a = 0.f;
+#pragma unroll
+    for (int po = 0; po < 4; ++po) {  // every output phase reads this tap once: py + dy = 2 ey + qy
+      const int ty = (po >> 1) + y - 2, tx = (po & 1) + x - 2;
+      const int ey = (ty + 2) / 2 - 1, ex = (tx + 2) / 2 - 1;   // floor(t / 2) for t in [-2, 3]
+      const int pi = 2 * (ty - 2 * ey) + (tx - 2 * ex);
+      a += g3[((((g * 4 + po) * hp + o) * 4 + pi) * lanes + i) * 9 + (ey + 1) * 3 + ex + 1];
+    }
+    g5[idx] = a;
+  }
+}
 // 4x4 stride-2 convolution with padding 1 (the PatchGAN discriminator's down-sampling layers, gan/discriminators.py:166-197) on the 3x3 kernels:
 // pad by 1 and fold 2x2 pixel blocks into channels,
 //   ys[n][Y][X][(2 dy + dx) * C + c] = x[n][2 Y + dy - 1][2 X + dx - 1][c]  (zero outside the image),  Y in [0, h/2 + 1), X in [0, w/2 + 1)
@@ -739,6 +793,32 @@ int sf_regroup5x5_bwd(const float* g3, int32_t O, int32_t I, int32_t lanes, floa
   SF_REQUIRE(g3 && g5 && O >= 1 && I >= 1 && lanes >= I, "sf_regroup5x5_bwd: null pointer or lanes (%d) < I (%d)", lanes, I);
   hipLaunchKernelGGL(regroup5_bwd_kernel, dim3(grid_of((long long)O * I * 25)), dim3(256), 0, (hipStream_t)stream, g3, O, I, lanes, g5);
   SF_CHECK_LAUNCH("regroup5x5_bwd");
+  return 0;
+}
+
+int sf_space_to_depth2(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t inverse, sfTensor y, sfStream stream) {
+  const sfTensor& full = inverse ? y : x;
+  const sfTensor& half = inverse ? x : y;
+  SF_REQUIRE(x.ptr && y.ptr && h >= 2 && w >= 2 && h % 2 == 0 && w % 2 == 0 && okd(full, full.c) && okd(half, 4 * full.c),
+             "sf_space_to_depth2: dense fp32 [n][h][w][C] <-> [n][h/2][w/2][4C], h and w even (h %d w %d)", h, w);
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(s2d2_kernel, dim3(grid_of(n * h * w * (full.c / 4))), dim3(256), 0, (hipStream_t)stream, (const float*)x.ptr, (long long)n, h / 2, w / 2,
+                     full.c / 4, (float*)y.ptr, inverse);
+  SF_CHECK_LAUNCH("space_to_depth2");
+  return 0;
+}
+
+int sf_regroup5x5_s2d_fwd(const float* w5, int64_t row_pitch, int32_t R, int32_t hp, int32_t I, int32_t lanes, float* w3, sfStream stream) {
+  SF_REQUIRE(w5 && w3 && R >= 1 && hp >= 1 && R % hp == 0 && I >= 1 && lanes >= I && row_pitch >= (int64_t)I * 25,
+             "sf_regroup5x5_s2d_fwd: null pointer, rows (%d) not a multiple of the gate block (%d), lanes (%d) < I (%d) or row pitch too small", R, hp, lanes, I);
+  hipLaunchKernelGGL(regroup5_s2d_fwd_kernel, dim3(grid_of((long long)R * 16 * lanes * 9)), dim3(256), 0, (hipStream_t)stream, w5, (long long)row_pitch, R, hp, I, lanes, w3);
+  SF_CHECK_LAUNCH("regroup5x5_s2d_fwd");
+  return 0;
+}
+int sf_regroup5x5_s2d_bwd(const float* g3, int32_t R, int32_t hp, int32_t I, int32_t lanes, float* g5, sfStream stream) {
+  SF_REQUIRE(g3 && g5 && R >= 1 && hp >= 1 && R % hp == 0 && I >= 1 && lanes >= I, "sf_regroup5x5_s2d_bwd: null pointer, rows (%d) not a multiple of the gate block (%d) or lanes (%d) < I (%d)", R, hp, lanes, I);
+  hipLaunchKernelGGL(regroup5_s2d_bwd_kernel, dim3(grid_of((long long)R * I * 25)), dim3(256), 0, (hipStream_t)stream, g3, R, hp, I, lanes, g5);
+  SF_CHECK_LAUNCH("regroup5x5_s2d_bwd");
   return 0;
 }
 

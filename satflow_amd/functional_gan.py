@@ -242,6 +242,63 @@ def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.Co
     return _CropFn.apply(F.conv3x3(eng, _PadShift4Fn.apply(x.contiguous()), w3, bias, wbatch=wbatch), 2)
 
 
+class _S2D2Fn(torch.autograd.Function):
+    """``[n,h,w,C] <-> [n,h/2,w/2,4C]`` (``sf_space_to_depth2``; a permutation: the backward pass is the other direction)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, inverse: bool):
+        n, a, b, c = x.shape
+        h, w, cf = (2 * a, 2 * b, c // 4) if inverse else (a, b, c)
+        y = torch.empty((n, h, w, cf) if inverse else (n, h // 2, w // 2, 4 * c), dtype=torch.float32, device=x.device)
+        check(lib().sf_space_to_depth2(T(x), n, h, w, int(inverse), T(y), stream_ptr()), "sf_space_to_depth2")
+        ctx.meta = (n, h, w, inverse)
+        return y
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        n, h, w, inverse = ctx.meta
+        g = g.contiguous()
+        c = g.shape[-1]
+        gx = torch.empty((n, h // 2, w // 2, 4 * c) if inverse else (n, h, w, c // 4), dtype=torch.float32, device=g.device)
+        check(lib().sf_space_to_depth2(T(g), n, h, w, int(not inverse), T(gx), stream_ptr()), "sf_space_to_depth2")
+        return gx, None
+
+
+def space_to_depth2(x: Tensor) -> Tensor:
+    """NHWC ``[n,h,w,C] -> [n,h/2,w/2,4C]``, lane ``(2 py + px) * C + c`` = pixel ``(2Y + py, 2X + px)``."""
+    return _S2D2Fn.apply(x.contiguous(), False)
+
+
+def depth_to_space2(x: Tensor) -> Tensor:
+    return _S2D2Fn.apply(x.contiguous(), True)
+
+
+class _Regroup5S2DFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, weight: Tensor, lanes: int, hp: int):
+        R, I = weight.shape[0], weight.shape[1]
+        if not (weight.stride(3) == 1 and weight.stride(2) == 5 and weight.stride(1) == 25):   # anything but a column slice of a dense weight
+            weight = weight.contiguous()
+        w3 = torch.empty(4 * R, 4 * lanes, 3, 3, dtype=torch.float32, device=weight.device)
+        check(lib().sf_regroup5x5_s2d_fwd(weight.data_ptr(), weight.stride(0), R, hp, I, lanes, w3.data_ptr(), stream_ptr()), "sf_regroup5x5_s2d_fwd")
+        ctx.meta = (R, I, lanes, hp)
+        return w3
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        R, I, lanes, hp = ctx.meta
+        g5 = torch.empty(R, I, 5, 5, dtype=torch.float32, device=g.device)
+        check(lib().sf_regroup5x5_s2d_bwd(g.contiguous().data_ptr(), R, hp, I, lanes, g5.data_ptr(), stream_ptr()), "sf_regroup5x5_s2d_bwd")
+        return g5, None, None
+
+
+def regroup5x5_s2d(weight: Tensor, lanes: int, hp: int) -> Tensor:
+    """``[R, I, 5, 5]`` (``R`` = gate blocks of ``hp`` rows) -> ``[4R, 4 * lanes, 3, 3]``: the weight of the ONE 3x3 convolution on the
+    ``space_to_depth2`` domain that equals the 5x5 convolution (``sf_regroup5x5_s2d_*``); output rows gate-major, then output phase."""
+    require_device(weight, "weight")
+    return _Regroup5S2DFn.apply(weight.float(), lanes, hp)
+
+
 # ----------------------------------------------------------------------------------------------
 # 4x4 convolutions (PatchGAN, reference gan/discriminators.py:139-223) on the 3x3 MFMA kernels
 # ----------------------------------------------------------------------------------------------

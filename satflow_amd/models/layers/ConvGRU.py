@@ -8,8 +8,10 @@ from (parity UNPINNED, oracle/dgmr.py): ``ConvGRU(input_size, hidden_sizes, kern
 Execution on the HIP kernels: every gate convolution is split into its x-part and its h-part (a convolution over a concatenation is
 the sum of the convolutions of the parts), so nothing is concatenated; over a SEQUENCE (``run_sequence``) the x-parts of a layer
 run for all frames in one launch and only the h-parts + the two fused gate stages (``sf_dvdgru_*``) are sequential.
-3x3 kernels run on the MFMA convolution, and so do 5x5 kernels: as ONE 3x3 convolution over four shifted copies of the padded input
-(``functional_gan.conv5x5_as_3x3``); other sizes on the direct ``sf_conv2d_*``.
+3x3 kernels run on the MFMA convolution, and so do 5x5 kernels: a single call as ONE 3x3 convolution over four shifted copies of the padded input
+(``functional_gan.conv5x5_as_3x3``), a sequence as ONE 3x3 convolution on the half-resolution layout (2x2 pixel blocks folded into channels,
+``functional_gan.space_to_depth2`` / ``regroup5x5_s2d``: no padded domain, no copies, no crop; ``SF_GRU5_STACK4=1`` is the A/B switch back);
+other sizes on the direct ``sf_conv2d_*``.
 """
 from __future__ import annotations
 
@@ -49,9 +51,10 @@ class ConvGRUCell(nn.Module):
     def _as_tiles(self) -> bool:
         return self.kernel_size == 5 and not os.environ.get("SF_CONV5_DIRECT")
 
-    def weights(self, x_lanes: Optional[int] = None):
+    def weights(self, x_lanes: Optional[int] = None, s2d: bool = False):
         """The six derived weights of a call / a sequence.  5x5 kernels are regrouped HERE into the weight of the 3x3 convolution over four shifted
-        copies (``x_lanes``: channel lanes of the cell's input tensor) - once per sequence, not once per frame."""
+        copies (``x_lanes``: channel lanes of the cell's input tensor) - once per sequence, not once per frame.  ``s2d``: for tensors in the
+        ``space_to_depth2`` layout instead (``run_sequence``): weights by ``regroup5x5_s2d``, biases repeated per output phase."""
         ci, hp, hid = self.input_size, self._hp, self.hidden_size
         wz, wr, wo = self._rows(self.update_gate.weight), self._rows(self.reset_gate.weight), self._rows(self.out_gate.weight)
         pb = (lambda b: TF.pad(b, (0, hp - hid))) if hp != hid else (lambda b: b)
@@ -61,14 +64,20 @@ class ConvGRUCell(nn.Module):
         if self._as_tiles():
             xl = cpad(ci) if x_lanes is None else x_lanes
             for k, lanes in (("zr_x", xl), ("o_x", xl), ("zr_h", hp), ("o_h", hp)):
-                W[k] = FG.regroup5x5(W[k], lanes)
+                W[k] = FG.regroup5x5_s2d(W[k], lanes, hp) if s2d else FG.regroup5x5(W[k], lanes)
+            if s2d:
+                W["b_zr"] = W["b_zr"].view(2, 1, hp).expand(2, 4, hp).reshape(-1)
+                W["b_o"] = W["b_o"].view(1, hp).expand(4, hp).reshape(-1)
+                W["s2d"] = True
         else:
             for k in ("zr_x", "zr_h", "o_x", "o_h"):
                 W[k] = W[k].contiguous()
         return W
 
-    def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor], wbatch=None) -> Tensor:
+    def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor], wbatch=None, s2d: bool = False) -> Tensor:
         k = self.kernel_size
+        if s2d:
+            k = 3   # weights and tensors are in the space_to_depth2 layout: a plain 3x3 convolution
         if k == 3 or self._as_tiles():
             cin = w.shape[1]   # 5x5: already regrouped over four shifted copies of the (padded) input lanes
             key = (tag, cin, w.shape[0])
@@ -82,16 +91,18 @@ class ConvGRUCell(nn.Module):
 
     def x_parts(self, x: Tensor, W: dict):
         """x-parts of the three gates for any number of frames at once: ``(gx_zr [.., 2*hidp], gx_o [.., hidp])`` incl. the biases."""
-        return self._conv("zr_x", x, W["zr_x"], W["b_zr"]), self._conv("o_x", x, W["o_x"], W["b_o"])
+        s2d = bool(W.get("s2d"))
+        return self._conv("zr_x", x, W["zr_x"], W["b_zr"], s2d=s2d), self._conv("o_x", x, W["o_x"], W["b_o"], s2d=s2d)
 
     def step(self, gx_zr: Tensor, gx_o: Tensor, h: Optional[Tensor], W: dict) -> Tensor:
-        hp = self._hp
+        s2d = bool(W.get("s2d"))
+        hp = 4 * self._hp if s2d else self._hp   # the pointwise stages are layout-blind: [z | r] halves of 4 * hidp lanes each
         if h is None:  # zero state: the h-parts vanish
             zr, _ = FG.dvdgru_gates(gx_zr, None, None, hp)
             return FG.dvdgru_out(gx_o, None, zr, None, hp)
-        gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"))
+        gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"), s2d)
         zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp)
-        gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"))
+        gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"), s2d)
         return FG.dvdgru_out(gx_o, gh_o, zr, h, hp)
 
     def run(self, x: Tensor, h: Optional[Tensor]) -> Tensor:
@@ -133,9 +144,14 @@ class ConvGRU(nn.Module):
         """The generator's frame loop (reference ``Generator.py:91-117``): frame i calls the stack with frame i-1's hidden list.
         ``x``: time-major NHWC ``[T*n,H,W,Cp]`` (or ``[n,H,W,Cp]`` fed to every frame when ``constant_input``).  Returns the last
         layer's states, time-major ``[T*n,H,W,hidp]``.  Layer by layer: a layer's x-parts for all frames in one launch."""
-        seq, const = x, constant_input
+        seq, const, folded = x, constant_input, False
         for cell in self.cells:
-            W = cell.weights(seq.shape[-1])
+            # 5x5 cells run on the half-resolution layout (2x2 pixel blocks folded into channels: sf_space_to_depth2) - ONE permutation of the
+            # sequence on the way in and one on the way out instead of a padded, four-times-copied input and a crop per convolution
+            fold = cell._as_tiles() and seq.shape[1] % 2 == 0 and seq.shape[2] % 2 == 0 and not os.environ.get("SF_GRU5_STACK4")
+            if fold != folded:
+                seq, folded = (FG.space_to_depth2(seq) if fold else FG.depth_to_space2(seq)), fold
+            W = cell.weights(seq.shape[-1] // 4 if fold else seq.shape[-1], s2d=fold)
             if cell.kernel_size in (3, 5) and not os.environ.get("SF_GRU_WGRAD_PER_FRAME"):
                 # the state convolutions' weight gradients: once per sequence over all frames, not once per frame (functional.WeightGradBatch)
                 W["batch_zr_h"], W["batch_o_h"] = F.WeightGradBatch(), F.WeightGradBatch()
@@ -149,7 +165,7 @@ class ConvGRU(nn.Module):
                 h = cell.step(zr_t[t], o_t[t], h, W)
                 outs.append(h)
             seq, const = torch.cat(outs, 0), False
-        return seq
+        return FG.depth_to_space2(seq) if folded else seq
 
     def forward(self, x, hidden=None):
         require_device(x, "x")

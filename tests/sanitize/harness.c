@@ -150,6 +150,12 @@ int main(void) {
   REFUSED(sf_regroup5x5_fwd(ok, 100, 4, 8, 4, ok, st));                                                /* lanes < I */
   REFUSED(sf_regroup5x5_fwd(ok, 10, 4, 8, 16, ok, st));                                                /* row pitch smaller than a row */
   REFUSED(sf_regroup5x5_bwd(0, 4, 8, 16, ok, st));                                                     /* no gradient */
+  REFUSED(sf_space_to_depth2(a16, 1, 8, 8, 0, a48, st));                                               /* y must carry 4C lanes */
+  REFUSED(sf_space_to_depth2(a16, 1, 7, 8, 0, a64, st));                                               /* odd height */
+  REFUSED(sf_space_to_depth2(a16, 1, 8, 8, 1, a64, st));                                               /* inverse: x is the 4C side */
+  REFUSED(sf_regroup5x5_s2d_fwd(ok, 100, 24, 16, 8, 16, ok, st));                                      /* rows not whole gate blocks */
+  REFUSED(sf_regroup5x5_s2d_fwd(ok, 100, 32, 16, 8, 4, ok, st));                                       /* lanes < I */
+  REFUSED(sf_regroup5x5_s2d_bwd(0, 32, 16, 8, 16, ok, st));                                            /* no gradient */
   REFUSED(sf_pad_s2d_fwd(a16, 1, 8, 8, a48, st));                                                      /* y must carry 4C lanes */
   REFUSED(sf_pad_s2d_fwd(a16, 1, 7, 8, a64, st));                                                      /* odd height */
   REFUSED(sf_pad_s2d_bwd(a48, 1, 8, 8, a16, st));                                                      /* gy must carry 4C lanes */
