@@ -32,7 +32,11 @@ inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
   pl.cot = (Np + CO_T - 1) / CO_T;
   pl.cit = (Kp + CI_T - 1) / CI_T;
   int want = 512 / (pl.cot * pl.cit);  // ~2 workgroups per CU in total: fewer, longer K slices than 1024 measured faster (less split-K reduce)
-  if (want < 8) want = 8;
+  // at least 8 slices while that keeps the launch under ~2048 workgroups; a weight of thousands of slabs (the generator's half-resolution ConvGRU
+  // convolutions: 2048 x 4096 channels = 2048 slabs of 147 KB) fills the chip unsplit - 8 partial copies of a 302 MB gradient were 2.4 GB written and re-read
+  int floor_ks = 2048 / (pl.cot * pl.cit);
+  floor_ks = floor_ks < 1 ? 1 : floor_ks > 8 ? 8 : floor_ks;
+  if (want < floor_ks) want = floor_ks;
   if (want > 256) want = 256;
   pl.KS = pl.ntiles < want ? pl.ntiles : want;
   if (pl.KS < 1) pl.KS = 1;
