@@ -256,7 +256,8 @@ bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf) {
   if (epi != sfconv::EPI_LINEAR || p.H <= 16 || !p.src0 || !p.bf0 || p.src1 || p.idiv0 > 1 || p.imod0 > 0 || !p.out_bf) return false;
   // the BatchNorm-backward epilogue spills next to the persistent loop's state (340 bytes at NF = 4): measured in round 4, 2.88 ms against the
   // one-item kernel's 2.38 ms for the 256 -> 256 input gradient - one-item kernel
-  if (p.bnb_coef) return false;
+  // (the one-wave-per-SIMD kernel has the registers for it: conv3x3_bf16_persist4.hip, MODE 2)
+  if (p.bnb_coef && !sf_conv_bf16_persist4_ok(p, nf)) return false;
   const int tiles = ((p.W + sfconv::TILE_W - 1) / sfconv::TILE_W) * ((p.H + 31) / 32) * p.N;
   return tiles >= 4 * 256;
 }

@@ -63,6 +63,18 @@ __device__ __forceinline__ float acc_read(float x) {
   return v;
 }
 #define SF_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// A 16-byte buffer load hipcc does not see (MODE 2: the BatchNorm input read in the epilogue).  Issued through the builtin, hipcc would have to drain
+// `vmcnt` to 0 at every use: the epilogue's stores share the counter and LLVM does not assume loads and stores retire in order (they do:
+// tools/ubench/vmcnt_order.hip).  The wait is counted by hand and TIED to the loaded registers, so no use can move above it.
+__device__ __forceinline__ u32x4_t bufload16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+  u32x4_t v;
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+  return v;
+}
+template <int N>
+__device__ __forceinline__ void wait_loaded(u32x4_t& a, u32x4_t& b) {
+  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+}
 // One level of a reduce-scatter over the 32 lanes of a half-wave: 2 * M values per lane in, M out - the lane keeps the half its bit M selects and adds
 // the partner's (lane ^ M) copy of that half.  After the levels 16, 8, 4, 2, 1 lane r holds entry r of the 32, summed over the 32 lanes.
 template <int M>
@@ -153,11 +165,19 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
                                              __builtin_amdgcn_readfirstlane(it.valid ? w_bytes : 0), 0x00020000);
   };
   auto rs_table = [&](const Item& it) __attribute__((always_inline)) {
+    if constexpr (MODE == 2) {  // the (A, B, K) rows of the item's BatchNorm group, from this N block's first channel on ([3][bnb_c] floats per group)
+      const int g = it.n / p.bnb_group;
+      return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)(p.bnb_coef + (size_t)g * 3 * p.bnb_c + it.nb * NB)), 0,
+                                               __builtin_amdgcn_readfirstlane(it.valid ? (3 * p.bnb_c - it.nb * NB) * 4 : 0), 0x00020000);
+    }
     return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)(p.bias_tab + (size_t)it.grp * 9 * p.np + it.nb * NB)), 0,
                                              __builtin_amdgcn_readfirstlane(it.valid ? tab_bytes : 0), 0x00020000);
   };
   auto rs_output = [&](int n) __attribute__((always_inline)) {
     return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.out + (size_t)n * p.H * p.W * p.out_s * 2), 0, out_bytes, 0x00020000);
+  };
+  auto rs_bnb_x = [&](int n) __attribute__((always_inline)) {  // MODE 2: the BatchNorm's input, laid out like the output (the launcher checks)
+    return __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.bnb_x + (size_t)n * p.H * p.W * p.out_s * 2), 0, out_bytes, 0x00020000);
   };
   // one input piece (j: 0..5) of chunk ci of item `it` into this wave's private stage
   auto dma_in = [&](const Item& it, __amdgpu_buffer_rsrc_t rs, int ci, int stage, int j) __attribute__((always_inline)) {
@@ -173,8 +193,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   // the bias table of item `it`: two pieces per wave (1 KiB = two classes; pieces past the table repeat piece 4 = {class 8, class 8})
   auto dma_tab = [&](__amdgpu_buffer_rsrc_t rs, int i) __attribute__((always_inline)) {
     int pp = wave + 4 * i; pp = pp < 4 ? pp : 4;
-    int cls = 2 * pp + (lane >> 5); cls = cls < 8 ? cls : 8;
-    bufdma16((unsigned)(cls * p.np * 4 + (lane & 31) * 16), rs, 0u, lds0 + (unsigned)(TAB0 + pp * 1024));
+    constexpr int CLS_MAX = MODE == 2 ? 2 : 8;  // MODE 2: the three coefficient rows land as [3][NB] floats at TAB0 (piece 1 = {K, K}; later pieces repeat it)
+    int cls = 2 * pp + (lane >> 5); cls = cls < CLS_MAX ? cls : CLS_MAX;
+    bufdma16((unsigned)(cls * (MODE == 2 ? p.bnb_c : p.np) * 4 + (lane & 31) * 16), rs, 0u, lds0 + (unsigned)(TAB0 + pp * 1024));
   };
 
   // ---- per-lane constants of the fragment reads (as conv3x3_bf16.hip; the halo rows are wave-local) ----
@@ -267,6 +288,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   f32x16 acc[MFR][NF];
   // accumulators of an item START at the border-class bias of each lane's pixel (the folded BatchNorm; zeros without a table), read from the LDS copy
   auto init_acc = [&](const Item& it) __attribute__((always_inline)) {
+    if constexpr (MODE == 2) {  // (the table region holds the epilogue's coefficients, not a bias)
+#pragma unroll
+      for (int mf = 0; mf < MFR; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
+      return;
+    }
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
       const int cls = border_cls(it.y0 + 8 * wave + 2 * mf + (r >> 4), it.x0 + (r & 15), p.H, p.W);
@@ -328,6 +358,82 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
       __builtin_amdgcn_s_barrier();
+      return;
+    }
+    if constexpr (MODE == 2) {
+      // ---- BatchNorm backward in the epilogue (sf_conv3x3_bwd_data_bn): out = A * acc + B * x + K, x = the BatchNorm's input at the output's own
+      // pixels and channels.  x is read the way the result is stored (two 16-byte loads per fragment at the store's offsets: 64-byte runs) and taken
+      // back to the accumulator layout by the store path's two exchanges in reverse (both are involutions); loads run two fragments ahead of
+      // their use (24 registers), every wave issues exactly 32 loads and 32 stores per item and waits by count.  Channel fragments outermost: the
+      // 3 x 16 coefficients of a lane's channels are read from the LDS copy once per fragment column.
+      const __amdgpu_buffer_rsrc_t rs_x = rs_bnb_x(it.n);
+      unsigned vo0[MFR], vo1[MFR];
+#pragma unroll
+      for (int mf = 0; mf < MFR; ++mf) { vo0[mf] = out_voff(it, mf, 0); vo1[mf] = out_voff(it, mf, 1); }
+      u32x4_t xq[3][2];
+      auto request = [&](int f) __attribute__((always_inline)) {
+        const int mf = f % MFR, nf = f / MFR;
+        const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
+        xq[f % 3][0] = bufload16(vo0[mf], rs_x, soff);
+        xq[f % 3][1] = bufload16(vo1[mf], rs_x, soff);
+      };
+      request(0); request(1);
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        f32x4 cA[4], cB[4], cK[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const char* lc = lds + TAB0 + (nf * 32 + 8 * g + 4 * kh) * 4;
+          cA[g] = *reinterpret_cast<const f32x4*>(lc); cB[g] = *reinterpret_cast<const f32x4*>(lc + NB * 4); cK[g] = *reinterpret_cast<const f32x4*>(lc + 2 * NB * 4);
+        }
+#pragma unroll
+        for (int mf = 0; mf < MFR; ++mf) {
+          const int f = nf * MFR + mf;
+          if (f + 2 < MFR * NF) request(f + 2);
+          // younger than this fragment's two loads: the loads of the next two fragments and the stores of the previous two
+          u32x4_t& x0 = xq[f % 3][0]; u32x4_t& x1 = xq[f % 3][1];
+          if (f == 0 || f == MFR * NF - 1) wait_loaded<4>(x0, x1); else if (f == 1 || f == MFR * NF - 2) wait_loaded<6>(x0, x1); else wait_loaded<8>(x0, x1);
+          // store layout -> accumulator layout: rows back (v_permlane16_swap), then quads back (v_permlane32_swap)
+          u32x4_t oc[2];
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(x0[d], x1[d], false, false);
+            oc[0][d] = sw[0]; oc[1][d] = sw[1];
+          }
+          const f32x16& a = acc[mf][nf];
+          u32x4_t so[2];
+#pragma unroll
+          for (int g = 0; g < 4; g += 2) {
+            const auto qx = __builtin_amdgcn_permlane32_swap(oc[g >> 1][0], oc[g >> 1][2], false, false);   // (ax, bx): channels 0, 1 of octets g, g + 1
+            const auto qy = __builtin_amdgcn_permlane32_swap(oc[g >> 1][1], oc[g >> 1][3], false, false);   // (ay, by): channels 2, 3
+            float v[8];
+#pragma unroll
+            for (int gg = 0; gg < 2; ++gg) {
+              const unsigned w0 = qx[gg], w1 = qy[gg];
+              const float xv[4] = {__builtin_bit_cast(float, w0 << 16), __builtin_bit_cast(float, w0 & 0xffff0000u),
+                                   __builtin_bit_cast(float, w1 << 16), __builtin_bit_cast(float, w1 & 0xffff0000u)};
+#pragma unroll
+              for (int c = 0; c < 4; ++c)
+                v[4 * gg + c] = __builtin_fmaf(cA[g + gg][c], acc_read(a[4 * (g + gg) + c]), __builtin_fmaf(cB[g + gg][c], xv[c], cK[g + gg][c]));
+            }
+            const unsigned ax = pk2(v[0], v[1]), ay = pk2(v[2], v[3]);
+            const unsigned bx = pk2(v[4], v[5]), by = pk2(v[6], v[7]);
+            const auto sx = __builtin_amdgcn_permlane32_swap(ax, bx, false, false);
+            const auto sy = __builtin_amdgcn_permlane32_swap(ay, by, false, false);
+            so[g >> 1] = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+          }
+          u32x4_t r0, r1;
+#pragma unroll
+          for (int d = 0; d < 4; ++d) {
+            const auto sw = __builtin_amdgcn_permlane16_swap(so[0][d], so[1][d], false, false);
+            r0[d] = sw[0]; r1[d] = sw[1];
+          }
+          const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
+          __builtin_amdgcn_raw_buffer_store_b128(r0, rs_out, vo0[mf], soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(r1, rs_out, vo1[mf], soff, 0);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+      }
       return;
     }
 #pragma unroll
@@ -427,7 +533,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
         __builtin_amdgcn_sched_barrier(0);
         if (tap < 3) piece_in(2 * tap + 1); else if (tap < 7) piece_w(2 * (tap - 3) + 1);
         if (tap == 7 && ci + 2 == nch) {  // the next item's bias table (read when its accumulators are initialised)
-          const __amdgpu_buffer_rsrc_t rt = rs_table(nxt);
+          const __amdgpu_buffer_rsrc_t rt = rs_table(MODE == 2 ? cur : nxt);  // (MODE 2: THIS item's coefficients, read by its epilogue)
           dma_tab(rt, 0); dma_tab(rt, 1);
         }
         __builtin_amdgcn_sched_barrier(0);
@@ -477,7 +583,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf) {
   static const bool off = getenv("SF_NO_CONV_W4") != nullptr;
   static const bool no_stats = getenv("SF_NO_CONV_W4_STATS") != nullptr;  // A/B switch: statistics on the 8-wave persistent kernel
-  if (off || nf != 4 || (p.stats && no_stats) || p.bias || p.bnb_coef || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
+  static const bool no_bnb = getenv("SF_NO_CONV_W4_BNB") != nullptr;      // A/B switch: the BatchNorm-backward epilogue on the 8-wave one-item kernel
+  if (off || nf != 4 || (p.stats && no_stats) || p.bias || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
+  // BatchNorm-backward epilogue: x is read at the output's own offsets
+  if (p.bnb_coef && (no_bnb || p.stats || p.bias_tab || p.wgroup || p.bnb_xs != p.out_s || p.bnb_c < p.out_c || p.bnb_group < 1)) return false;
   if ((long long)p.H * p.W * p.out_s * 2 >= 0x7fffffffll || (long long)p.H * p.W * p.s0 * 2 >= 0x7fffffffll) return false;
   return true;
 }
@@ -495,7 +604,8 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int grid = items < cus ? items : cus;
-  if (p.stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  else if (p.stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: launch failed: %s", hipGetErrorString(e)); return 2; }

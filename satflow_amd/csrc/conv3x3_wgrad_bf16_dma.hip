@@ -467,7 +467,10 @@ sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int gr
   // one workgroup per CU (128 KiB of LDS): as many K slices as fill the 256 CUs once, in whole groups of 8 (one per XCD)
   int want = 256 / pl.units;
   want = want / 8 * 8;
-  if (want < 8) want = 8;
+  // (a weight of thousands of slabs fills the chip unsplit: no 8 partial copies of a 300 MB gradient - the floor of make_plan, wgrad_common.h)
+  int floor_ks = 2048 / pl.units;
+  floor_ks = groups > 0 ? 8 : floor_ks < 1 ? 1 : floor_ks > 8 ? 8 : floor_ks;
+  if (want < floor_ks) want = floor_ks;
   const int per_min = 6;  // a slice shorter than the ring + pipeline fill is all prologue
   int ks = want;
   while (ks > 8 && (pl.ntiles + ks - 1) / ks < per_min) ks -= 8;

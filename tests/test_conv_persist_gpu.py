@@ -195,3 +195,36 @@ def test_one_wave_per_simd_kernel_statistics(device, bf16_mode, n, groups, cin, 
     scale_sq = ref[..., 1].abs().max().clamp_min(1.0)
     err = (got - ref).abs().max() / scale_sq
     assert float(err) < 1e-5, float(err)
+
+
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(1040, 4, 256, 160, 32, 32), (2304, 12, 256, 256, 32, 32), (1080, 6, 128, 96, 40, 24), (1056, 6, 64, 384, 33, 17)])
+def test_one_wave_per_simd_kernel_batchnorm_backward(device, bf16_mode, n, groups, cin, cout, H, W):
+    """sf_conv3x3_bwd_data_bn on the one-wave-per-SIMD kernel (MODE 2: dx = A * conv^T(dout, W) + B * x + K in the epilogue, x read at the
+    store's offsets and permuted back to the accumulator layout): the persistent launch over all groups == one launch per group (each below
+    the persistent threshold: the 8-wave one-item kernel), bit for bit - ragged tiles and a half-empty last N block included."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(3 * n + cin + groups)
+    eng = ConvEngine([cin], cout)
+    gm = eng.bwd_map((True,))
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+    packed_t = eng.packed(w, None, "bwd", (True,))[0]
+    gy = torch.randn(n, H, W, eng.coutp, generator=g).to(device).to(torch.bfloat16)
+    gy[..., cout:] = 0
+    x = torch.randn(n, H, W, cpad(cin), generator=g).to(device).to(torch.bfloat16)
+    coef = torch.randn(groups, 3, cpad(cin), generator=g).to(device).contiguous()
+    tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
+    ipg = n // groups
+    assert tiles * n >= 1024 and tiles * ipg < 1024 and gm.nf == 4
+    dx = torch.full((n, H, W, cpad(cin)), float("nan"), device=device).to(torch.bfloat16)
+    K.conv3x3_bwd_data_bn(T(gy), n, H, W, packed_t, gm, T(x), coef, T(dx))
+    torch.cuda.synchronize()
+    assert torch.isfinite(dx[..., :cin].float()).all()
+    for gi in range(groups):
+        sl = slice(gi * ipg, (gi + 1) * ipg)
+        dg = torch.full((ipg, H, W, cpad(cin)), float("nan"), device=device).to(torch.bfloat16)
+        K.conv3x3_bwd_data_bn(T(gy[sl].contiguous()), ipg, H, W, packed_t, gm, T(x[sl].contiguous()), coef[gi:gi + 1].contiguous(), T(dg))
+        assert torch.equal(dx[sl][..., :cin], dg[..., :cin]), f"group {gi} differs"
+    assert float(dx[..., :cin].float().abs().max()) > 0.1

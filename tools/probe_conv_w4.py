@@ -42,3 +42,18 @@ for cin, cout in ((256, 256), (160, 256)):
     ms = timeit(lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)))
     fl = 2 * 9 * cin * cout * H * W * n
     print(f"folded conv {cin}->{cout} @32x32 x {n} (W4 {'off' if os.environ.get('SF_NO_CONV_W4') else 'on'}): {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")
+
+# the input gradient with the BatchNorm-backward epilogue (sf_conv3x3_bwd_data_bn; SF_NO_CONV_W4_BNB=1: the 8-wave one-item kernel)
+for cin, cout in ((256, 256),):
+    n, H, W, groups = 2304, 32, 32, 12
+    eng = ConvEngine([cin], cout)
+    gmb = eng.bwd_map((True,))
+    w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
+    packed_t = eng.packed(w, None, "bwd", (True,))[0]
+    gy = torch.randn(n, H, W, eng.coutp, device=dev).to(torch.bfloat16)
+    x = torch.randn(n, H, W, cpad(cin), device=dev).to(torch.bfloat16)
+    coef = torch.randn(groups, 3, cpad(cin), device=dev)
+    dx = torch.empty_like(x)
+    ms = timeit(lambda: K.conv3x3_bwd_data_bn(T(gy), n, H, W, packed_t, gmb, T(x), coef, T(dx)))
+    fl = 2 * 9 * cin * cout * H * W * n
+    print(f"input gradient + BatchNorm backward {cout}->{cin} @32x32 x {n} (W4 {'off' if os.environ.get('SF_NO_CONV_W4_BNB') else 'on'}): {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")

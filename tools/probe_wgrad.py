@@ -8,7 +8,11 @@ from satflow_amd.functional import ConvEngine
 satflow_amd.set_compute_dtype("bf16")
 dev = torch.device("cuda:0")
 st = torch.bfloat16 if os.environ.get("SF_ACT", "f32") == "bf16" else torch.float32
-shapes = ((2304, 256, 256, 32, 32), (2304, 160, 256, 32, 32), (192, 96, 160, 64, 64), (2304, 256, 192, 16, 16))
+if os.environ.get("SF_SHAPES") == "gru":   # the generator's half-resolution ConvGRU weight gradients (DGMR line)
+    shapes = ((14, 2048, 4096, 32, 32), (14, 1024, 2048, 64, 64), (16, 1024, 4096, 32, 32), (14, 2048, 4096, 16, 16), (16, 512, 2048, 64, 64),
+              (14, 2048, 4096, 8, 8), (16, 512, 512, 64, 64), (16, 128, 128, 256, 256), (16, 256, 256, 128, 128))
+else:
+  shapes = ((2304, 256, 256, 32, 32), (2304, 160, 256, 32, 32), (192, 96, 160, 64, 64), (2304, 256, 192, 16, 16))
 for (n, cin, cout, H, W) in shapes[: int(os.environ.get('SF_ONLY', len(shapes)))]:
     eng = ConvEngine([cin], cout)
     x = torch.randn(n, H, W, eng.fwd_map.Kp, device=dev).to(st); gy = torch.randn(n, H, W, eng.coutp, device=dev).to(st)
