@@ -312,6 +312,10 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       }
     }
   };
+  // (Measured and removed, round 4: half of an item's stores held back in 64 spare registers and issued one per tap under the next item's first two
+  // chunks - or two per tap under its first chunk.  2.167 against 2.128 ms same box, 6990 against 6560 cycles per chunk: a 1 KiB store blocks the only wave
+  // of its SIMD for ~400 cycles wherever it is issued - the CU's ~10 B/clk store path shared by four waves that store at the same time - so spreading the
+  // stores moves the idle matrix-pipe time, it does not hide it; profiles/r04_conv_w4_ablation.txt.)
   auto epilogue = [&](const Item& it, int free_stage) __attribute__((always_inline)) {
     const __amdgpu_buffer_rsrc_t rs_out = rs_output(it.n);
     if constexpr (MODE == 1) {
@@ -546,7 +550,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           // pieces (and, in an item's first chunk, the previous item's 32 stores in front of them) are younger -, then everybody's; stage sw2
           // (chunk g - 1) is free behind the barrier
 #ifndef SF_EXP_W4_NOSYNC
-          if (first) { if constexpr (MODE == 1) SF_VMCNT(39); else SF_VMCNT(38); } else SF_VMCNT(6);
+          // (MODE 2: 32 loads + 32 stores + 6 pieces are younger - the counter's field ends at 63; the seven oldest of them are long complete)
+          if (first) { if constexpr (MODE == 1) SF_VMCNT(39); else if constexpr (MODE == 2) SF_VMCNT(63); else SF_VMCNT(38); } else SF_VMCNT(6);
           __builtin_amdgcn_s_barrier();
 #endif
           __builtin_amdgcn_sched_barrier(0);

@@ -197,11 +197,11 @@ def test_one_wave_per_simd_kernel_statistics(device, bf16_mode, n, groups, cin, 
     assert float(err) < 1e-5, float(err)
 
 
-@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(1040, 4, 256, 160, 32, 32), (2304, 12, 256, 256, 32, 32), (1080, 6, 128, 96, 40, 24), (1056, 6, 64, 384, 33, 17)])
+@pytest.mark.parametrize("n,groups,cin,cout,H,W", [(1040, 4, 256, 160, 32, 32), (2304, 12, 256, 256, 32, 32), (1080, 6, 128, 96, 40, 24), (1056, 6, 384, 64, 33, 17)])
 def test_one_wave_per_simd_kernel_batchnorm_backward(device, bf16_mode, n, groups, cin, cout, H, W):
     """sf_conv3x3_bwd_data_bn on the one-wave-per-SIMD kernel (MODE 2: dx = A * conv^T(dout, W) + B * x + K in the epilogue, x read at the
     store's offsets and permuted back to the accumulator layout): the persistent launch over all groups == one launch per group (each below
-    the persistent threshold: the 8-wave one-item kernel), bit for bit - ragged tiles and a half-empty last N block included."""
+    the persistent threshold: the 8-wave one-item kernel), bit for bit - ragged tiles, one to three N blocks, 4 to 24 K chunks."""
     from satflow_amd import kernels as K
     from satflow_amd._hip import T, cpad, lib
     from satflow_amd.functional import ConvEngine
