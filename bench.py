@@ -287,7 +287,7 @@ class MetNetWorkload:
                          "algorithmic_flops": fl, "achieved_tflops": fl / t / 1e12, "frac": fl / t / 1e12 / PEAK_BF16_TFLOPS,
                          "algorithmic_bytes": alg, "traffic": traffic(pmc_sub)})
 
-        for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_kernel<8, 4, 0, false, true, true"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
+        for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_persist4_kernel<2>"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
             eng = ConvEngine([cin], cout)
             gm = eng.fwd_map
             w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
@@ -311,7 +311,8 @@ class MetNetWorkload:
             dout = torch.randn(n, H, W, eng.coutp, device=dev).to(bf)
             coef = torch.randn(G, 3, cpad(cin), device=dev)
             dx = torch.empty(n, H, W, cpad(cin), device=dev, dtype=bf)
-            row(f"conv3x3_bf16_kernel<8, NF={gmb.nf}, TR, BNB> {cout}->{cin} (input gradient + BatchNorm backward)", dgrad_name, 2 if cin == 256 else 1, cout, cin,
+            row((f"conv3x3_bf16_persist4_kernel<BNB> {cout}->{cin} (4 waves x 512 registers; input gradient + BatchNorm backward in the epilogue)" if gmb.nf == 4 else
+                 f"conv3x3_bf16_kernel<8, NF={gmb.nf}, TR, BNB> {cout}->{cin} (input gradient + BatchNorm backward)"), dgrad_name, 2 if cin == 256 else 1, cout, cin,
                 lambda: K.conv3x3_bwd_data_bn(T(dout), n, H, W, packed_t, gmb, T(x), coef, T(dx)),
                 "input gradients of conv3 / conv4 with the BatchNorm backward folded in" if cin == 256 else "input gradient of conv2 with BatchNorm 1's backward folded in")
             dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
