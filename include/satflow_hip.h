@@ -425,7 +425,10 @@ int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor gate
 
 /* Pointwise linear map over pixels (axial-attention to_q/to_kv/to_out, MetNet 1x1 head):
  *   y[p][n] = sum_k x[p][k]*W[n][k] + bias[n],  W row-major [N][x.c];  lanes N..y.c-1 are zeroed.
- * bwd_weight: dW[n][k] = sum_p dy[p][n]*x[p][k], db[n] = sum_p dy[p][n] (db nullable). */
+ * bwd_weight: dW[n][k] = sum_p dy[p][n]*x[p][k], db[n] = sum_p dy[p][n] (db nullable).
+ * sf_linear_fwd with dtype SF_BF16 / SF_F16 (more than 64 rows): the operands are rounded to that type as they are loaded (RNE), fp32 accumulate, fp32-stored
+ * tensors - a 1x1 Conv2d / Linear under the reference's 16-bit autocast (the DGMR discriminators' 1x1 convolutions, Discriminator.py:36-60,186-190;
+ * configs/trainer/half.yaml:33); SF_F32: exact fp32 products. */
 int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const float* bias, sfTensor y,
                   int32_t dtype, sfStream stream);
 size_t sf_linear_bwd_weight_workspace_bytes(int32_t N, int32_t K, int64_t rows);

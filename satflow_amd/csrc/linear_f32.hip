@@ -8,6 +8,8 @@
 // These are tall-skinny GEMMs (P ~ 25k pixels, N, K <= 384): no LDS staging; every lane loads its
 // MFMA operand element(s) straight from global memory (16-byte loads in fwd, coalesced 128-byte
 // rows in wgrad), weights stay L2/L1 resident.  v_mfma_f32_32x32x2_f32, exact fp32.
+#include <type_traits>
+
 #include "sf_common.h"
 
 namespace {
@@ -56,6 +58,79 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const float* __restrict
       for (int nf = 0; nf < NF; ++nf) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x2f32(b[nf][j], a[j], acc[nf], 0, 0, 0);  // transposed product
   }
   // D[i][j]: i = output column within the fragment (8g + 4kh + c), j = this lane's row: 16-byte stores of column quads
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int n = n0 + nf * 32 + 8 * g + 4 * kh;
+      if (row_ok && n < yc) {
+        f32x4 v = {acc[nf][4 * g], acc[nf][4 * g + 1], acc[nf][4 * g + 2], acc[nf][4 * g + 3]};
+        if (bias) {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) v[c] += (n + c < N) ? bias[n + c] : 0.f;
+        }
+        if (vec_out && n + 3 < yc) *reinterpret_cast<f32x4*>(y + row * ys + n) = v;
+        else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) if (n + c < yc) y[row * ys + n + c] = v[c];
+        }
+      }
+    }
+  }
+}
+
+// The same map with 16-BIT OPERANDS (bf16 or fp16, fp32 accumulate: what the reference's 16-bit autocast runs a 1x1 Conv2d / Linear in; the 1x1
+// convolutions of the DGMR discriminators and attention blocks in the bf16 / f16 modes, Discriminator.py:36-60,186-190): tensors stay fp32 in memory, a
+// lane converts its 8 floats per 16-K step (RNE) and ONE v_mfma_f32_32x32x16 replaces eight 32x32x2 fp32 steps - the kernel is then bound by its loads
+// (65536 x 256 -> 256: 134 MB), not by the 157 TF/s fp32 matrix rate.  Same tiling, same transposed product, same epilogue as linear_fwd_kernel.
+template <int NF, typename OT>
+__global__ __launch_bounds__(256) void linear_fwd_lowp_kernel(const float* __restrict__ x, int xs, long long rows, int K,
+                                                              const float* __restrict__ W, int N, const float* __restrict__ bias,
+                                                              float* __restrict__ y, int ys, int yc) {
+  typedef OT ot8 __attribute__((ext_vector_type(8)));
+  typedef float f32x8 __attribute__((ext_vector_type(8)));
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int r = lane & 31, kh = lane >> 5;
+  const long long row0 = (long long)blockIdx.x * 128 + wave * 32;
+  const int n0 = blockIdx.y * 32 * NF;
+  f32x16 acc[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[nf][i] = 0.f;
+  const long long row = row0 + r;
+  const bool row_ok = row < rows;
+  const bool vec_out = (((uintptr_t)y) & 15) == 0 && ys % 4 == 0;
+  const float* xr = x + (row_ok ? row : rows - 1) * xs;
+  const float* wr[NF]; bool n_ok[NF];
+#pragma unroll
+  for (int nf = 0; nf < NF; ++nf) {
+    const int n = n0 + nf * 32 + r;
+    n_ok[nf] = n < N;
+    wr[nf] = W + (long long)(n_ok[nf] ? n : N - 1) * K;
+  }
+  auto cvt = [](const f32x4 lo, const f32x4 hi, bool ok) {
+    const f32x8 v = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    const f32x8 z = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    return __builtin_convertvector(ok ? v : z, ot8);
+  };
+#pragma unroll 2
+  for (int q = 0; q < (K + 15) / 16; ++q) {
+    // this lane's eight K values of the step: 16 q + 8 kh ..; K is a multiple of 8, so the half is whole or absent (clamped: unconditional loads)
+    const bool k_ok = q * 16 + kh * 8 < K;
+    const int ko = k_ok ? q * 16 + kh * 8 : 0;
+    const f32x4 a0 = ld4(xr + ko), a1 = ld4(xr + ko + 4);
+    f32x4 b0[NF], b1[NF];
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) { b0[nf] = ld4(wr[nf] + ko); b1[nf] = ld4(wr[nf] + ko + 4); }
+    const ot8 av = cvt(a0, a1, row_ok && k_ok);
+#pragma unroll
+    for (int nf = 0; nf < NF; ++nf) {
+      const ot8 bv = cvt(b0[nf], b1[nf], n_ok[nf] && k_ok);
+      if constexpr (std::is_same<OT, _Float16>::value) acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_f16(bv, av, acc[nf], 0, 0, 0);
+      else acc[nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(bv, av, acc[nf], 0, 0, 0);
+    }
+  }
 #pragma unroll
   for (int nf = 0; nf < NF; ++nf) {
 #pragma unroll
@@ -228,7 +303,7 @@ extern "C" {
 
 int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const float* bias, sfTensor y, int32_t dtype,
                   sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32, "sf_linear_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16, "sf_linear_fwd: dtype %d not built", dtype);
   SF_F32_ONLY(x, "sf_linear_fwd");
   SF_F32_ONLY(y, "sf_linear_fwd");
   SF_REQUIRE(x.c % 8 == 0 && x.stride % 4 == 0 && (((uintptr_t)x.ptr) & 15) == 0 && (((uintptr_t)W) & 15) == 0,
@@ -253,7 +328,14 @@ int sf_linear_fwd(sfTensor x, int64_t rows, const float* W, int32_t N, const flo
 #define SF_LIN(NFV)                                                                                                         \
   hipLaunchKernelGGL((linear_fwd_kernel<NFV>), grid, dim3(256), 0, st, (const float*)x.ptr, x.stride, (long long)rows, x.c, W, N, \
                      bias, (float*)y.ptr, y.stride, y.c)
+#define SF_LINL(NFV, OTV)                                                                                                                \
+  hipLaunchKernelGGL((linear_fwd_lowp_kernel<NFV, OTV>), grid, dim3(256), 0, st, (const float*)x.ptr, x.stride, (long long)rows, x.c, W, N, \
+                     bias, (float*)y.ptr, y.stride, y.c)
+  if (dtype == SF_BF16) { switch (nf) { case 1: SF_LINL(1, __bf16); break; case 2: SF_LINL(2, __bf16); break; case 3: SF_LINL(3, __bf16); break; default: SF_LINL(4, __bf16); break; } }
+  else if (dtype == SF_F16) { switch (nf) { case 1: SF_LINL(1, _Float16); break; case 2: SF_LINL(2, _Float16); break; case 3: SF_LINL(3, _Float16); break; default: SF_LINL(4, _Float16); break; } }
+  else
   switch (nf) { case 1: SF_LIN(1); break; case 2: SF_LIN(2); break; case 3: SF_LIN(3); break; default: SF_LIN(4); break; }
+#undef SF_LINL
 #undef SF_LIN
   SF_CHECK_LAUNCH("linear_fwd");
   return 0;

@@ -581,11 +581,11 @@ class _LinearFn(torch.autograd.Function):
     """``y[..., :N] = x @ W.T + b`` with ``W [N, Kp]`` (zero-padded columns); output lanes ``out_lanes``."""
 
     @staticmethod
-    def forward(ctx, x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int):
+    def forward(ctx, x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int, lowp: bool = False):
         W = W.contiguous()
         ctx.save_for_backward(x, W)
-        ctx.has_bias = bias is not None
-        return K.linear_fwd(x, W, bias, out_lanes)
+        ctx.has_bias, ctx.lowp = bias is not None, lowp
+        return K.linear_fwd(x, W, bias, out_lanes, lowp)
 
     @staticmethod
     def backward(ctx, gy: Tensor):
@@ -597,19 +597,20 @@ class _LinearFn(torch.autograd.Function):
             # dx = gy[..., :N] @ W : the same kernel with the transposed weight (tiny host-side transpose)
             Wt = torch.zeros(Kp, gy.shape[-1], dtype=torch.float32, device=W.device)
             Wt[:, :N] = W.t()
-            dx = K.linear_fwd(gy, Wt, None, Kp)
+            dx = K.linear_fwd(gy, Wt, None, Kp, ctx.lowp)
         if not (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])):
-            return dx, None, None, None
+            return dx, None, None, None, None
         dW, db = K.linear_bwd_weight_any(gy, x, N, ctx.has_bias)
-        return dx, dW, db, None
+        return dx, dW, db, None, None
 
 
-def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], out_lanes: Optional[int] = None) -> Tensor:
-    """Pointwise linear map; ``weight [N, K]`` with K <= x lanes (padded with zero columns here, autograd-tracked)."""
+def linear(x: Tensor, weight: Tensor, bias: Optional[Tensor], out_lanes: Optional[int] = None, lowp: bool = False) -> Tensor:
+    """Pointwise linear map; ``weight [N, K]`` with K <= x lanes (padded with zero columns here, autograd-tracked).  ``lowp``: forward and input
+    gradient with the operands rounded to the 16-bit compute mode's type (1x1 convolutions under the reference's autocast; ignored in f32 mode)."""
     Kp = x.shape[-1]
     if weight.shape[1] != Kp:
         weight = torch.nn.functional.pad(weight, (0, Kp - weight.shape[1]))
-    return _LinearFn.apply(x, weight, bias, out_lanes or cpad(weight.shape[0]))
+    return _LinearFn.apply(x, weight, bias, out_lanes or cpad(weight.shape[0]), lowp)
 
 
 class _AttnCoreFn(torch.autograd.Function):

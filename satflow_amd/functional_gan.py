@@ -162,7 +162,7 @@ def conv_nhwc(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: Optional[F
     """``nn.Conv2d(k, padding=k//2)`` on NHWC ``x``: 1x1 -> ``sf_linear_*``, 3x3 -> the MFMA kernels (``eng``), else ``sf_conv2d_*``."""
     k = weight.shape[-1]
     if k == 1:
-        return F.linear(x, weight.reshape(weight.shape[0], weight.shape[1]), bias)
+        return F.linear(x, weight.reshape(weight.shape[0], weight.shape[1]), bias, lowp=True)   # 16-bit operands in the 16-bit modes, as a Conv2d under autocast
     if k == 3:
         assert eng is not None
         return F.conv3x3(eng, x, weight, bias)

@@ -9,6 +9,8 @@ from __future__ import annotations
 from dataclasses import dataclass, field
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import torch
 
 from . import _hip
@@ -359,12 +361,14 @@ def maxpool2_bwd(x: Tensor, gy: Tensor, perm: Optional[Tuple[int, int]] = None, 
     return gx
 
 
-def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int) -> Tensor:
-    """y[..., n] = x[..., :] @ W[n, :] + b.  x [..., Kp], W [N, Kp] -> y [..., out_lanes].  sf_linear_fwd."""
+def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int, lowp: bool = False) -> Tensor:
+    """y[..., n] = x[..., :] @ W[n, :] + b.  x [..., Kp], W [N, Kp] -> y [..., out_lanes].  sf_linear_fwd.  ``lowp``: in a 16-bit compute mode the
+    operands are rounded to the mode's type (a 1x1 convolution under the reference's autocast); exact fp32 products otherwise."""
     rows = x.numel() // x.shape[-1]
     assert W.shape[1] == x.shape[-1] and W.is_contiguous()
     y = torch.empty(*x.shape[:-1], out_lanes, dtype=torch.float32, device=x.device)
-    check(lib().sf_linear_fwd(T(x), rows, W.data_ptr(), W.shape[0], bias.data_ptr() if bias is not None else None, T(y), SF_F32,
+    dt = _hip.compute_dtype() if lowp and not os.environ.get("SF_LINEAR_F32") else SF_F32   # (SF_LINEAR_F32=1: A/B switch)
+    check(lib().sf_linear_fwd(T(x), rows, W.data_ptr(), W.shape[0], bias.data_ptr() if bias is not None else None, T(y), dt,
                               stream_ptr()), "sf_linear_fwd")
     return y
 

@@ -37,7 +37,7 @@ def _untokens(t: Tensor, C: int) -> Tensor:
 
 def _project(tokens: Tensor, conv: nn.Module, out_lanes=None) -> Tensor:
     w = conv.weight
-    return F.linear(tokens, w.reshape(w.shape[0], w.shape[1]), conv.bias, out_lanes=out_lanes)
+    return F.linear(tokens, w.reshape(w.shape[0], w.shape[1]), conv.bias, out_lanes=out_lanes, lowp=True)   # a 1x1 convolution under autocast
 
 
 class SeparableAttn(nn.Module):

@@ -52,9 +52,10 @@ class SelfAttention(nn.Module):
         """NHWC ``[N,H,W,Cp]``: ``energy = q k^T`` ``[N, HW, HW]``, softmax over the keys, ``out = attention v``, ``gamma * out + x``."""
         n, h, w, cp = x.shape
         d, c = self.chanel_in // 8, self.chanel_in
-        q = F.linear(x, self.query_conv.weight.view(d, c), self.query_conv.bias).view(n, h * w, -1)   # pad lanes are zero
-        k = F.linear(x, self.key_conv.weight.view(d, c), self.key_conv.bias).view(n, h * w, -1)
-        v = F.linear(x, self.value_conv.weight.view(c, c), self.value_conv.bias, out_lanes=cp).view(n, h * w, cp)
+        # (lowp: 1x1 convolutions take the 16-bit compute mode's operands, as under the reference's autocast; exact fp32 products in f32 mode)
+        q = F.linear(x, self.query_conv.weight.view(d, c), self.query_conv.bias, lowp=True).view(n, h * w, -1)   # pad lanes are zero
+        k = F.linear(x, self.key_conv.weight.view(d, c), self.key_conv.bias, lowp=True).view(n, h * w, -1)
+        v = F.linear(x, self.value_conv.weight.view(c, c), self.value_conv.bias, out_lanes=cp, lowp=True).view(n, h * w, cp)
         out = FG.attention(q, k, v).view(n, h, w, cp)
         return FG.gamma_residual(out, x, self.gamma)
 
@@ -187,7 +188,7 @@ def conv3d_run(sn: SpectralNorm, x: Tensor, T_frames: int) -> Tensor:
     w = sn.compute_weight()                                  # [O, I, kt, kh, kw]
     O, I = w.shape[0], w.shape[1]
     if w.shape[2:] == (1, 1, 1):
-        return F.linear(x, w.view(O, I), m.bias)
+        return F.linear(x, w.view(O, I), m.bias, lowp=True)
     if w.shape[2:] != (3, 3, 3):
         raise NotImplementedError("Conv3d kernels 1 and 3 are implemented")
     cp = x.shape[-1]

@@ -83,6 +83,37 @@ def test_bmm_f16_operands(device, f16_mode, bsz, M, N, Kd):
     assert rel_l2(Bd.grad, torch.bmm(_r(A).double().transpose(1, 2), _r(cot).double())) < 2e-6
 
 
+@pytest.mark.parametrize("mode", ["f16", "bf16"])
+@pytest.mark.parametrize("rows,K,N", [(300, 16, 12), (1000, 64, 384), (77, 136, 64), (4096, 40, 96), (1024, 512, 1024), (65, 8, 40)])
+def test_linear_16bit_operands(device, mode, rows, K, N):
+    """sf_linear_fwd with SF_F16 / SF_BF16 (a 1x1 convolution under the reference's autocast): forward and input gradient equal the float64 product
+    of the ROUNDED operands (fp32 accumulation order is the only difference), K not a multiple of 16 and ragged N included; the weight gradient
+    stays an exact fp32 product; lowp=False stays exact in every mode."""
+    from satflow_amd import functional as F
+
+    rt = torch.float16 if mode == "f16" else torch.bfloat16
+    rnd = lambda t: t.to(rt).float()
+    g = torch.Generator().manual_seed(rows + K)
+    x = torch.randn(rows, K, generator=g)
+    w = torch.randn(N, K, generator=g) / K**0.5
+    b = torch.randn(N, generator=g)
+    cot = torch.randn(rows, N, generator=g)
+    satflow_amd.set_compute_dtype(mode)
+    try:
+        xd, wd, bd = (t.to(device).requires_grad_() for t in (x, w, b))
+        y = F.linear(xd, wd, bd, lowp=True)[..., :N]
+        (y * cot.to(device)).sum().backward()
+        exact = F.linear(xd.detach(), wd.detach(), bd.detach())[..., :N]
+    finally:
+        satflow_amd.set_compute_dtype("f32")
+    ref = rnd(x).double() @ rnd(w).double().t() + b.double()
+    assert rel_l2(y, ref) < 2e-6, rel_l2(y, ref)
+    assert rel_l2(exact, x.double() @ w.double().t() + b.double()) < 1e-6
+    assert rel_l2(xd.grad, rnd(cot).double() @ rnd(w).double()) < 2e-6
+    assert rel_l2(wd.grad, cot.double().t() @ x.double()) < 1e-5
+    assert rel_l2(bd.grad, cot.double().sum(0)) < 1e-5
+
+
 @pytest.mark.parametrize("name", ["spatial", "temporal"])
 def test_discriminator_f16_mode_close_to_reference(device, name):
     """bench.py --workload dgmr --dtype f16: fp16 operands for every 3x3 / 3x3x3 convolution and the attention products, against the fp32 reference
