@@ -366,7 +366,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     }
     if constexpr (MODE == 2) {
       // ---- BatchNorm backward in the epilogue (sf_conv3x3_bwd_data_bn): out = A * acc + B * x + K, x = the BatchNorm's input at the output's own
-      // pixels and channels.  x is read the way the result is stored (two 16-byte loads per fragment at the store's offsets: 64-byte runs) and taken
+      // pixels and channels.  x is read in the 64-byte runs the result is stored in (two 16-byte loads per fragment) and taken
       // back to the accumulator layout by the store path's two exchanges in reverse (both are involutions); loads run two fragments ahead of
       // their use (24 registers), every wave issues exactly 32 loads and 32 stores per item and waits by count.  PIXEL fragments outermost, as in the
       // plain epilogue: the four channel fragments of a pixel row are the four 64-byte quarters of two 128-byte lines and must be touched back to back -
@@ -376,12 +376,32 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       unsigned vo0[MFR], vo1[MFR];
 #pragma unroll
       for (int mf = 0; mf < MFR; ++mf) { vo0[mf] = out_voff(it, mf, 0); vo1[mf] = out_voff(it, mf, 1); }
+      // The LOADS address x with ADJACENT lanes on one 64-byte run - lane L = (pixel L / 4, 16-byte piece L % 4): in the store's lane order (a
+      // quarter-wave = one piece of 16 different pixels) a load instruction is four passes that each touch 16 lines, and the four requests for a line
+      // are not merged on their way to memory: 2.93 GB fetched per launch for this 1.21 GB tensor (PMC, against a build without the read:
+      // -DSF_EXP_W4_NOX).  One ds_bpermute per dword then hands every lane the piece the store order gives it (source lane 4 * pixel + piece; no LDS
+      // memory involved): 2.53 GB and 1 % faster.  Still 2.1x: the two 64-byte halves of a 128-byte line belong to neighbouring channel fragments and are
+      // requested back to back by two instructions - both miss.  (Whole lines per request would need a lane-dependent choice between two loaded
+      // registers in front of every ds_bpermute: twice the exchanges; not built.)
+      unsigned lo0[MFR], lo1[MFR];
+#pragma unroll
+      for (int mf = 0; mf < MFR; ++mf)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int py = it.y0 + 8 * wave + 2 * mf + j, px = it.x0 + (lane >> 2);
+          (j ? lo1[mf] : lo0[mf]) = (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * (lane & 3)) * 2) : DMA_SENT;
+        }
+      const int bp_idx = (4 * (lane & 15) + piece) * 4;
       u32x4_t xq[3][2];
       auto request = [&](int f) __attribute__((always_inline)) {
         const int mf = f / NF, nf = f % NF;
         const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
-        xq[f % 3][0] = bufload16(vo0[mf], rs_x, soff);
-        xq[f % 3][1] = bufload16(vo1[mf], rs_x, soff);
+#ifdef SF_EXP_W4_NOX   // ablation build (tools/ablate_w4.sh): no read of x - what the input tiles alone cost in this mode
+        xq[f % 3][0] = u32x4_t{soff, 0u, 0u, 0u}; xq[f % 3][1] = u32x4_t{soff, 0u, 0u, 0u};
+        return;
+#endif
+        xq[f % 3][0] = bufload16(lo0[mf], rs_x, soff);
+        xq[f % 3][1] = bufload16(lo1[mf], rs_x, soff);
       };
       request(0); request(1);
 #pragma unroll
@@ -399,11 +419,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           // younger than this fragment's two loads: the loads of the next two fragments and the stores of the previous two
           u32x4_t& x0 = xq[f % 3][0]; u32x4_t& x1 = xq[f % 3][1];
           if (f == 0 || f == MFR * NF - 1) wait_loaded<4>(x0, x1); else if (f == 1 || f == MFR * NF - 2) wait_loaded<6>(x0, x1); else wait_loaded<8>(x0, x1);
-          // store layout -> accumulator layout: rows back (v_permlane16_swap), then quads back (v_permlane32_swap)
+          // load order -> store order (ds_bpermute) -> accumulator layout: rows back (v_permlane16_swap), then quads back (v_permlane32_swap)
           u32x4_t oc[2];
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
-            const auto sw = __builtin_amdgcn_permlane16_swap(x0[d], x1[d], false, false);
+            const unsigned s0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp_idx, (int)x0[d]), s1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp_idx, (int)x1[d]);
+            const auto sw = __builtin_amdgcn_permlane16_swap(s0, s1, false, false);
             oc[0][d] = sw[0]; oc[1][d] = sw[1];
           }
           const f32x16& a = acc[mf][nf];
