@@ -203,16 +203,36 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   const int a_lane = ((r >> 4) * HALO_W + (r & 15)) * PIX_B;
   const int a_half_even = 16 * (kh ^ rowpar), a_half_odd = 16 * (kh ^ rowpar ^ 1);
   const int b_lane = r * PIX_B + 16 * (kh ^ ((r >> 3) & 1));
-  auto load_tap = [&](int sw, int si, int tap, bf16x8 (&a)[MFR], bf16x8 (&b)[NF]) __attribute__((always_inline)) {
-    const int ky = tap / 3, kx = tap % 3;
+  // Pixel fragments are SHARED between the taps of a column: fragment mf of tap (ky = 2, kx) is rows 2 mf + 2, 2 mf + 3 of the halo = fragment mf + 1 of
+  // tap (0, kx).  The three fragments mf = 1 .. 3 of a top-row tap are read into `keep[kx]` and used again six taps later, whose own read is then the
+  // one new fragment (rows 8, 9): 63 fragment reads per chunk instead of 72 (the reads are paid in clock: the chip is power-limited and a build without
+  // them runs at 2.04 instead of 1.80 GHz, profiles/r04_conv_w4_ablation.txt).  Same operands, same order of the products: results unchanged bit for bit.
+#ifdef SF_EXP_W4_NOREUSE   // ablation build: every tap reads its four pixel fragments
+  constexpr bool REUSE = false;
+#else
+  constexpr bool REUSE = true;
+#endif
+  bf16x8 fa[3][MFR], fb[3][NF], keep[3][MFR - 1];
+  auto load_tap = [&](int sw, int si, int tap) __attribute__((always_inline)) {  // operands of `tap` into set tap % 3 (and keep[kx])
+    const int ky = tap / 3, kx = tap % 3, set = tap % 3;
     const char* inb = lds + IN0 + (wave * 2 + si) * PIN_B + a_lane;
     const char* wb = lds + sw * W_B + b_lane;
 #pragma unroll
-    for (int mf = 0; mf < MFR; ++mf)
-      a[mf] = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO_W + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
+    for (int mf = 0; mf < MFR; ++mf) {
+      if (REUSE && ky == 2 && mf + 1 < MFR) continue;  // in keep[kx][mf] since tap kx
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(inb + ((2 * mf + ky) * HALO_W + kx) * PIX_B + ((ky & 1) ? a_half_odd : a_half_even));
+      if (REUSE && ky == 0 && mf >= 1) keep[kx][mf - 1] = v; else fa[set][mf] = v;
+    }
 #pragma unroll
-    for (int nf = 0; nf < NF; ++nf) b[nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
+    for (int nf = 0; nf < NF; ++nf) fb[set][nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
   };
+  auto frag_a = [&](int tap, int mf) __attribute__((always_inline)) -> const bf16x8& {
+    const int ky = tap / 3, kx = tap % 3;
+    if (REUSE && ky == 0 && mf >= 1) return keep[kx][mf - 1];
+    if (REUSE && ky == 2 && mf + 1 < MFR) return keep[kx][mf];
+    return fa[tap % 3][mf];
+  };
+  auto tap_reads = [](int tap) { return NF + ((REUSE && tap / 3 == 2) ? 1 : MFR); };
 
   // ---- epilogue of one fragment: 32 channels x 32 pixels -> two 16-byte stores per lane (always issued) ----
   // A lane pair (r, kh = 0 / 1) holds 2 x 16 bytes of its pixel per octet: stored as they are, an instruction writes 32-byte runs 512 bytes apart, and the
@@ -477,8 +497,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 
   // fragment sets rotate modulo 3 (tap t uses set t % 3, the next tap's operands are read into set (t + 1) % 3): nine taps per chunk, so the
   // rotation is the same in every chunk and the next chunk's first tap lands in set 0; only two sets are live at any time
-  bf16x8 fa[3][MFR], fb[3][NF];
-  load_tap(0, 0, 0, fa[0], fb[0]);
+  load_tap(0, 0, 0);
 
   int sw = 0;    // weight ring stage of the current chunk
   int gpar = 0;  // parity of the chunk counter: the private input stage
@@ -530,12 +549,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           if (ci + 2 == nch) SF_VMCNT(11); else SF_VMCNT(9);
 #endif
           __builtin_amdgcn_sched_barrier(0);
-          load_tap(sw1, si1, 0, fa[0], fb[0]);  // first tap of the next chunk
+          load_tap(sw1, si1, 0);  // first tap of the next chunk
         } else {
 #ifndef SF_EXP_W4_NOREAD
-          load_tap(sw, si, tap + 1, fa[(tap + 1) % 3], fb[(tap + 1) % 3]);
+          load_tap(sw, si, tap + 1);
 #else
-          if (ci + 100 == nch) load_tap(sw, si, tap + 1, fa[(tap + 1) % 3], fb[(tap + 1) % 3]);
+          if (ci + 100 == nch) load_tap(sw, si, tap + 1);
 #endif
         }
         // MFMAs 0 .. 7 with one fragment read behind each | DMA piece | MFMAs 8 .. 11 | DMA piece | MFMAs 12 .. 15
@@ -543,12 +562,12 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 #pragma unroll
           for (int f = lo; f < hi; ++f) {
             const int mf = f / NF, nf = f % NF;
-            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap % 3][nf], fa[tap % 3][mf], acc[mf][nf], 0, 0, 0);
+            acc[mf][nf] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fb[tap % 3][nf], frag_a(tap, mf), acc[mf][nf], 0, 0, 0);
           }
         };
         mfmas(0, 8);
 #pragma unroll
-        for (int q = 0; q < MFR + NF; ++q) {
+        for (int q = 0; q < tap_reads(tap == 8 ? 0 : tap + 1); ++q) {  // one read of the NEXT tap's operands behind each of the first MFMAs
           __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
           __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
         }
