@@ -21,6 +21,11 @@
 // ascending), accumulators started at the border-class bias: results are bit-identical (tests/test_conv_persist_gpu.py).
 // Scope: NF = 4 (128-channel N blocks), at least 3 K chunks, ONE bf16-stored source without image remap, bf16-stored output, linear
 // epilogue with no per-channel bias (plain, or grouped weights + border-class bias table = the folded BatchNorm).
+// Three instantiations: MODE 0 as above; MODE 1 adds the BatchNorm statistics of the stored values (per-tile sums, reduce-scatter over the half-waves,
+// partials through each wave's free private input stage); MODE 2 is the input gradient with the BatchNorm BACKWARD in the epilogue
+// (out = A * acc + B * x + K: x read in the store's 64-byte runs with hand-counted waits, coefficients in the bias table's LDS slot).
+// (The item switch is: epilogue of item k - 32 stores per wave -, accumulators of item k + 1 from the LDS table, first tap; deferring half of the stores
+// under the next item's K loop was built and measured: no gain, see the note in front of `epilogue`.)
 #include <cstdlib>
 #include <type_traits>
 
