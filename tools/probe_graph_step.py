@@ -1,5 +1,5 @@
-"""Can the MetNet training step (forward + loss + backward) be captured into a hipGraph, and what would a replay cost?  DIAGNOSTIC: a replay repeats the
-captured dropout masks (host-drawn seeds are kernel arguments).  Usage: python tools/probe_graph_metnet.py [fwd|fwdbwd]"""
+"""Can the MetNet (or, SF_PROBE_WL=convlstm, the ConvLSTM) training step (forward + loss + backward) be captured into a hipGraph, and what would a replay cost?  DIAGNOSTIC: a replay repeats the
+captured dropout masks (host-drawn seeds are kernel arguments).  Usage: python tools/probe_graph_step.py [fwd|fwdbwd]"""
 import os
 import sys
 import time
@@ -13,7 +13,7 @@ import bench
 what = sys.argv[1] if len(sys.argv) > 1 else "fwdbwd"
 satflow_amd.set_compute_dtype("bf16a")
 dev = torch.device("cuda:0")
-wl = bench.MetNetWorkload(dev, 8, 0)
+wl = bench.ConvLSTMWorkload(dev, 8, 0) if os.environ.get("SF_PROBE_WL") == "convlstm" else bench.MetNetWorkload(dev, 8, 0)
 side = torch.cuda.Stream()
 side.wait_stream(torch.cuda.current_stream())
 with torch.cuda.stream(side):
