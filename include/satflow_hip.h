@@ -534,6 +534,19 @@ int sf_border(sfTensor x, int64_t n, int32_t h, int32_t w, int32_t border, int32
  * row / column masked, lanes >= I zero-padded; _bwd gathers the gradient of the 5x5 weight (dense [O][I][5][5]) back out of the 3x3 form. */
 int sf_regroup5x5_fwd(const float* w5, int64_t row_pitch, int32_t O, int32_t I, int32_t lanes, float* w3, sfStream stream);
 int sf_regroup5x5_bwd(const float* g3, int32_t O, int32_t I, int32_t lanes, float* g5, sfStream stream);
+/* The same 5x5 convolution WITHOUT the stacked tensor (16-bit compute modes, fp32-stored x): the 3x3 kernels read x as four shifted views (view s = x
+ * displaced by (2 (s>>1) - 1, 2 (s&1) - 1), zero outside the image) in their halo loader, with the weights of sf_regroup5x5_fwd packed for Kp = 4 * x.c - no padded
+ * domain (64 x 64 pixels fill their tiles; 68 x 68 run at 60 %), no copies, no crop, and none of the half-resolution form's 4x weight bytes.  Few small images
+ * with many channels are split over the virtual channel axis when a workspace of sf_conv5x5_fwd_workspace_bytes is handed in (0: never split).  The input
+ * gradient is the same call on the output gradient with the flipped, transposed 5x5 weight (a 5x5 convolution again). */
+size_t sf_conv5x5_fwd_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t xc, int32_t dtype);
+int sf_conv5x5_fwd(sfTensor x, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf, sfTensor out,
+                   void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream);
+/* Its weight gradient: dW3 [O][4 * x.c][3][3] of that 3x3 convolution (sf_regroup5x5_bwd takes it back to the 5x5 weight), the four views of x read in
+ * place by the loader waves; maps / workspace / accumulate as sf_conv3x3_bwd_weight (I = 4 * x lanes); x.c a multiple of 32. */
+size_t sf_conv5x5_bwd_weight_workspace_bytes(int32_t Np, int32_t xc, int32_t n, int32_t h, int32_t w);
+int sf_conv5x5_bwd_weight(sfTensor x, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I, float* dw,
+                          float* db, int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream);
 /* The same 5x5 'same' convolution on the HALF-RESOLUTION domain - the route the generator's ConvGRU SEQUENCE takes (Generator.py:91-117; kernel_sizes 5 at
  * :42-45): 2x2 pixel blocks of input and output folded into channels, xs[n][Y][X][(2 py + px) * C + c] = x[n][2Y + py][2X + px][c] (sf_space_to_depth2,
  * inverse != 0: the way back; a permutation, so each direction is the other's adjoint), then ONE 3x3 'same' convolution from 4C to 4R lanes with

@@ -130,6 +130,10 @@ PROTOTYPES = {
     "sf_pad_shift_stack4_bwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _vp]),
     "sf_regroup5x5_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp]),
     "sf_regroup5x5_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _vp, _vp]),
+    "sf_conv5x5_fwd_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
+    "sf_conv5x5_fwd": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, sfTensor, _vp, _sz, _i32, _vp]),
+    "sf_conv5x5_bwd_weight_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32]),
+    "sf_conv5x5_bwd_weight": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp]),
     "sf_space_to_depth2": (C.c_int, [sfTensor, _i64, _i32, _i32, _i32, sfTensor, _vp]),
     "sf_regroup5x5_s2d_fwd": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _i32, _vp, _vp]),
     "sf_regroup5x5_s2d_bwd": (C.c_int, [_vp, _i32, _i32, _i32, _i32, _vp, _vp]),

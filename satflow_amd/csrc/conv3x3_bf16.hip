@@ -74,7 +74,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     const int z = blockIdx.z;
     p_split = p_in;
     const int cbeg = z * p_in.split_c;
-    p_split.src0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p_in.src0) + (size_t)cbeg * (p_in.bf0 ? 2 : 4));
+    if (p_in.shift4) p_split.chunk0 = cbeg / KC;   // shifted views: the slice starts at a virtual chunk, the tensor pointer stays
+    else p_split.src0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p_in.src0) + (size_t)cbeg * (p_in.bf0 ? 2 : 4));
     p_split.c0 = p_in.c0 - cbeg < p_in.split_c ? p_in.c0 - cbeg : p_in.split_c;
     p_split.wp = reinterpret_cast<const char*>(p_in.wp) + (size_t)(cbeg / KC) * (9 * 32 * NF * PIX_B);
     p_split.out = p_in.out + (size_t)z * p_in.split_out;
@@ -232,11 +233,19 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     const float* src; int cbase, stride, idiv, imod;
     if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; idiv = p.idiv0; imod = p.imod0; }
     else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; idiv = p.idiv1; imod = p.imod1; }
+    // (compiled into the plain linear launches only, and not into NF = 5: the 160-accumulator kernels spill 12 more bytes with it)
+    constexpr bool SHIFT_OK = EPI == EPI_LINEAR && !BNB && !WS && NF != 5;
+    int sdy = 0, sdx = 0;
+    if (SHIFT_OK && p.shift4) {  // four shifted views of src0 (ConvParams::shift4): this chunk's view and its pixel shift
+      const int cg = ci + p.chunk0, sv = cg / p.shift4;
+      cbase = (cg - sv * p.shift4) * KC; sdy = 2 * (sv >> 1) - 1; sdx = 2 * (sv & 1) - 1;
+    }
 #pragma unroll
     for (int j = 0; j < NPIECE; ++j) {
       const int pc = tid + j * THREADS;
       int ni, gy, gx, iy;
-      const bool ok = halo(pc >> 1, ni, gy, gx, iy) && pc < PIECES;
+      bool ok = halo(pc >> 1, ni, gy, gx, iy) && pc < PIECES;
+      if (SHIFT_OK && p.shift4) { gy += sdy; gx += sdx; ok = pc < PIECES && ni < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W; }
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (ok) {
         int ns = ni / idiv; if (imod) ns %= imod;

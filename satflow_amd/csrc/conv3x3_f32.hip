@@ -384,6 +384,51 @@ int sf_conv3x3_fwd_splitk(sfTensor src, int32_t n, int32_t h, int32_t w, const v
   return 0;
 }
 
+// A 5x5 'same' convolution as ONE 3x3 convolution over four shifted VIEWS of x (ConvParams::shift4): the weights of sf_regroup5x5_fwd (packed for
+// Kp = 4 * x.c), no padded domain, no copies.  16-bit operand kernels, fp32-stored x.  Few small images with many channels are split over the
+// virtual channel axis like sf_conv3x3_fwd_splitk (workspace from sf_conv5x5_fwd_workspace_bytes; 0 = not split).
+size_t sf_conv5x5_fwd_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t xc, int32_t dtype) {
+  int split_c;
+  if (dtype != SF_BF16 && dtype != SF_F16) return 0;
+  const int s = splitk_plan(n, h, w, Np, nf, 4 * xc, &split_c);
+  return s > 1 ? (size_t)s * n * h * w * Np * sizeof(float) : 0;
+}
+
+int sf_conv5x5_fwd(sfTensor x, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf, sfTensor out,
+                   void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16 || dtype == SF_F16, "sf_conv5x5_fwd: the 16-bit operand kernels only (dtype %d)", dtype);
+  if (check_src(x, "conv5x5 x")) return 1;
+  SF_REQUIRE(x.ptr && x.dtype == SF_F32 && x.idiv <= 1 && x.imod <= 0 && x.c >= KC, "sf_conv5x5_fwd: one plain fp32-stored source of at least %d lanes", KC);
+  SF_REQUIRE(nf >= 1 && nf <= 4 && Np % (32 * nf) == 0 && out.c <= Np, "sf_conv5x5_fwd: bad Np=%d nf=%d out.c=%d (the NF = 5 kernels have no shifted-view loader)", Np, nf, out.c);
+  SF_REQUIRE(out.ptr && out.dtype == SF_F32 && ((uintptr_t)out.ptr & 15) == 0 && out.stride % 4 == 0 && out.c % 8 == 0,
+             "sf_conv5x5_fwd: a 16-byte aligned fp32-stored output (stride %d, channels %d)", out.stride, out.c);
+  SF_REQUIRE(!bias_packed || ((uintptr_t)bias_packed & 15) == 0, "sf_conv5x5_fwd: bias_packed must be 16-byte aligned");
+  ConvParams p{};
+  p.src0 = (const float*)x.ptr; p.c0 = 4 * x.c; p.s0 = x.stride;
+  p.idiv0 = 1; p.idiv1 = 1;
+  p.N = n; p.H = h; p.W = w; p.tiles_x = (w + TILE - 1) / TILE; p.tiles_y = (h + TILE - 1) / TILE;
+  p.wp = (const float*)wpacked; p.chunks_total = 4 * x.c / KC;
+  p.shift4 = x.c / KC; p.chunk0 = 0;
+  p.stats_np = Np;
+  int split_c = 0;
+  const int splits = splitk_plan(n, h, w, Np, nf, 4 * x.c, &split_c);
+  const size_t slab = (size_t)n * h * w * Np;
+  if (splits > 1 && workspace && ((uintptr_t)workspace & 15) == 0 && workspace_bytes >= slab * splits * sizeof(float)) {
+    p.bias = nullptr;
+    p.out = (float*)workspace; p.out_c = Np; p.out_s = Np;
+    p.split_c = split_c; p.split_out = (long long)slab;
+    if (int rc = (dtype == SF_BF16 ? sf_launch_conv_bf16 : sf_launch_conv_f16)(p, nf, Np / 128, EPI_LINEAR, (hipStream_t)stream)) return rc;
+    const long long pixels = (long long)n * h * w, quads = pixels * (out.c / 4);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256 < 4096 ? (quads + 255) / 256 : 4096)), dim3(256), 0, (hipStream_t)stream,
+                       (const float*)workspace, (long long)slab, splits, Np, pixels, bias_packed, out.ptr, out.c, out.stride, 0);
+    SF_CHECK_LAUNCH("conv5x5 split-K reduce");
+    return 0;
+  }
+  p.bias = bias_packed;
+  p.out = (float*)out.ptr; p.out_c = out.c; p.out_s = out.stride;
+  return (dtype == SF_BF16 ? sf_launch_conv_bf16 : sf_launch_conv_f16)(p, nf, Np / (32 * nf), EPI_LINEAR, (hipStream_t)stream);
+}
+
 int32_t sf_conv3x3_stats_tiles(int32_t h, int32_t w) { return sf_conv_bf16_tiles(h, w); }
 
 int sf_conv3x3_fwd_stats(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,

@@ -141,7 +141,12 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const bool from0 = cit * CI_T < p.c0;  // block-uniform; exact for plain kernels
     const bool lane0 = b_item && kcb < p.c0, lane1 = b_item && kcb >= p.c0 && kcb - p.c0 < p.c1;
     const unsigned b_px0 = (unsigned)p.s0 * ESZ, b_px1 = (unsigned)p.s1 * ESZ;
-    const unsigned b_const0 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s0 + kcb) * ESZ;
+    // four shifted views of src0 (WgradParams::shift4; fp32 tensors, plain kernel): this block's view, its pixel shift, the channel inside the view
+    constexpr bool SHIFT_OK = !ABF && !BBF && !MIXED;
+    const int sview = (SHIFT_OK && p.shift4) ? (cit * CI_T) / p.shift4 : 0;
+    const int sdy = (SHIFT_OK && p.shift4) ? 2 * (sview >> 1) - 1 : 0, sdx = (SHIFT_OK && p.shift4) ? 2 * (sview & 1) - 1 : 0;
+    const int kreal = (SHIFT_OK && p.shift4) ? kcb - sview * p.shift4 : kcb;
+    const unsigned b_const0 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s0 + kreal) * ESZ;
     const unsigned b_const1 = (unsigned)((bhrow * p.W + 8 * bhalf) * p.s1 + (kcb - p.c0)) * ESZ;
     // bf16 storage: dout is fetched as 16-byte channel OCTETS, one item (octet 16, row 8, half 2) per loader thread - half
     // the load instructions of the quad form for the same registers; fp32 storage keeps two quad items per thread.
@@ -158,8 +163,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     // non-negative (nothing is read there); a null source gives a zero-length descriptor (every load returns zeros)
     auto halo_srd = [&](const float* src, int n, int idiv, int imod, unsigned px) {
       int ns = n / idiv; if (imod) ns %= imod;
-      const char* base = (const char*)src + ((long long)ns * p.H * p.W - (p.W + 1)) * px;
-      return __builtin_amdgcn_make_buffer_rsrc((void*)(src ? base : nullptr), 0, src ? (int)((unsigned)(p.H * p.W + p.W + 1) * px) : 0, 0x00020000);
+      // (shifted views: two rows + two pixels of lead, so that the view displaced by (-1, -1) still has non-negative offsets)
+      const int lead = (SHIFT_OK && p.shift4) ? 2 * (p.W + 1) : p.W + 1;
+      const char* base = (const char*)src + ((long long)ns * p.H * p.W - lead) * px;
+      return __builtin_amdgcn_make_buffer_rsrc((void*)(src ? base : nullptr), 0, src ? (int)((unsigned)(p.H * p.W + lead) * px) : 0, 0x00020000);
     };
     auto load_tile = [&](int i, Stage& s) {
       int t = ks + i * p.KS;
@@ -189,7 +196,8 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
         }
       }
       // input halo tile: items (cq 8, halo row 10, half 2) = 160 items; pixels x0-1+8*half .. +9
-      const int gy = y0 + bhrow - 1, gx0 = x0 - 1 + 8 * bhalf;
+      const int gy = y0 + bhrow - 1 + sdy, gx0 = x0 - 1 + 8 * bhalf + sdx;
+      const unsigned shift_px = (SHIFT_OK && p.shift4) ? (unsigned)((sdy + 1) * p.W + sdx + 1) : 0u;  // the displacement, on top of the longer lead
       const bool rok = gy >= 0 && gy < p.H;
       const int lo = rok ? -gx0 : 99, hi = rok ? p.W - gx0 : 0;  // pixels lo <= j < hi are inside the image
       if constexpr (MIXED) {
@@ -205,7 +213,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
         const bool lane = from0 ? lane0 : lane1;
         const __amdgpu_buffer_rsrc_t rs = halo_srd(from0 ? p.src0 : p.src1, n, from0 ? p.idiv0 : p.idiv1, from0 ? p.imod0 : p.imod1, px);
 #pragma unroll
-        for (int j = 0; j < 10; ++j) s.vb[j] = ld(rs, (lane && j >= lo && j < hi) ? bc : SENT, (tile_px + j) * px);
+        for (int j = 0; j < 10; ++j) s.vb[j] = ld(rs, (lane && j >= lo && j < hi) ? bc : SENT, (tile_px + shift_px + j) * px);
       }
     };
     auto store_tile = [&](int i, Stage& s) {

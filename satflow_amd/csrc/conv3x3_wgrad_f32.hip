@@ -550,4 +550,33 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
   return 0;
 }
 
+// Weight gradient of sf_conv5x5_fwd: dW3 [O][4 * lanes][3][3] of the 3x3 convolution over the four shifted views of x (sf_regroup5x5_bwd takes it to the 5x5
+// weight), x read in place.  16-bit operand kernels, fp32-stored x / dout, x.c a multiple of 32.
+size_t sf_conv5x5_bwd_weight_workspace_bytes(int32_t Np, int32_t xc, int32_t n, int32_t h, int32_t w) { return make_plan(Np, 4 * xc, n, h, w, 8).ws_floats * sizeof(float); }
+
+int sf_conv5x5_bwd_weight(sfTensor x, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I, float* dw,
+                          float* db, int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16 || dtype == SF_F16, "sf_conv5x5_bwd_weight: the 16-bit operand kernels only (dtype %d)", dtype);
+  SF_REQUIRE(x.ptr && x.dtype == SF_F32 && x.idiv <= 1 && x.imod <= 0 && x.c >= CI_T && x.c % CI_T == 0 && dout.ptr && dout.dtype == SF_F32 && dout.c % 4 == 0,
+             "sf_conv5x5_bwd_weight: fp32-stored x (lanes a multiple of %d: %d) and dout", CI_T, x.c);
+  const int Np = dout.c, Kp = 4 * x.c;
+  const Plan pl = make_plan(Np, Kp, n, h, w, 8);
+  SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "sf_conv5x5_bwd_weight: workspace too small (%zu < %zu)", workspace_bytes, pl.ws_floats * sizeof(float));
+  WgradParams p{};
+  p.src0 = (const float*)x.ptr; p.c0 = Kp; p.s0 = x.stride; p.idiv0 = 1; p.idiv1 = 1;
+  p.shift4 = x.c;
+  p.dout = (const float*)dout.ptr; p.dc = dout.c; p.ds = dout.stride;
+  p.N = n; p.H = h; p.W = w; p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.KS = pl.KS;
+  p.NpT = pl.cot * CO_T; p.KpT = pl.cit * CI_T;
+  p.partial = (float*)workspace;
+  p.partial_db = p.partial + (size_t)pl.KS * 9 * p.NpT * p.KpT;
+  if (int rc = (dtype == SF_BF16 ? sf_launch_wgrad_bf16 : sf_launch_wgrad_f16)(p, pl, (hipStream_t)stream)) return rc;
+  const size_t slab = (size_t)9 * p.NpT * p.KpT;
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((slab + 255) / 256)), dim3(256), 0, (hipStream_t)stream, p.partial, p.partial_db, pl.KS, p.NpT, p.KpT, Np, Kp,
+                     nmap, kmap, I, dw, db, accumulate);
+  SF_CHECK_LAUNCH("conv5x5 wgrad_reduce");
+  (void)O;
+  return 0;
+}
+
 }  // extern "C"

@@ -47,6 +47,11 @@ struct ConvParams {
   // bf16 kernel, split-K launches (sf_conv3x3_fwd_splitk; few small images with many input channels): workgroup z handles input channels
   // [z * split_c, (z + 1) * split_c) of src0 and stores its raw fp32 partial sums to out + z * split_out (no bias); 0 = not split
   int split_c; long long split_out;
+  // bf16 / f16 kernel, fp32-stored src0 only: src0 is read as FOUR SHIFTED VIEWS of one tensor stacked as channels - virtual channel chunk g
+  // (g = chunk0 + ci; shift4 = chunks per view) is chunk g % shift4 of view s = g / shift4, whose pixel (y, x) is the tensor's pixel
+  // (y + 2 (s >> 1) - 1, x + 2 (s & 1) - 1), zero outside the image: a 5x5 'same' convolution as ONE 3x3 convolution without the padded,
+  // four-times-copied input of sf_pad_shift_stack4_fwd (sf_conv5x5_fwd).  c0 = the virtual channel count of this launch / slice; 0 = off.
+  int shift4, chunk0;
 };
 
 // border class of an output pixel (needs H, W >= 2); pixels outside the image (ragged tiles) get some valid class

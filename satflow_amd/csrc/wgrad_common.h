@@ -18,6 +18,9 @@ struct WgradParams {
   int bf;       // bf16 kernel only: the input sources src0 / src1 are stored as bf16
   int bf_dout;  // bf16 kernel only: dout is stored as bf16 (with fp32 sources: the ConvLSTM's bf16-stored gate gradients)
   int tpg, maxseg;  // all-bf16 kernel, folded BatchNorm: tiles per group (0: ungrouped), partial slots per slice
+  // loader-wave kernel, fp32-stored tensors: src0 is read as four shifted views stacked as channels (sfconv::ConvParams::shift4; here in CHANNELS per
+  // view, a multiple of the 32-channel ci tile): input channel block cit belongs to view (32 cit) / shift4 - sf_conv5x5_bwd_weight.  0 = off
+  int shift4;
 };
 
 

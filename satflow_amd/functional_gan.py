@@ -8,6 +8,8 @@ from __future__ import annotations
 
 from typing import Optional, Tuple
 
+import os
+
 import torch
 
 from . import functional as F
@@ -240,6 +242,67 @@ def conv5x5_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], eng: "F.Co
     w3 = regroup5x5(weight, x.shape[-1]) if weight.shape[-1] == 5 else weight
     assert w3.shape[1] == 4 * x.shape[-1] and w3.shape[-1] == 3, (w3.shape, x.shape)
     return _CropFn.apply(F.conv3x3(eng, _PadShift4Fn.apply(x.contiguous()), w3, bias, wbatch=wbatch), 2)
+
+
+class _Conv5x5ShiftFn(torch.autograd.Function):
+    """``nn.Conv2d(k=5, padding=2)`` on the 16-bit 3x3 kernels WITHOUT a stacked tensor (``sf_conv5x5_fwd``): ``w3 = regroup5x5(weight, x lanes)`` for the
+    forward pass and the weight gradient, ``w3t = regroup5x5(flipped transposed weight, output lanes)`` for the input gradient (the input gradient of a
+    5x5 convolution is a 5x5 convolution of the output gradient).  ``eng`` / ``eng_t``: ConvEngines ``[4 * x lanes] -> cout`` / ``[4 * out lanes] -> cin``
+    (packed images cached on the cell's parameters).  ``wbatch``: as ``functional._ConvFn``."""
+
+    @staticmethod
+    def forward(ctx, eng, eng_t, x: Tensor, w3: Tensor, w3t: Tensor, bias: Optional[Tensor], wbatch):
+        n, h, w, _ = x.shape
+        ctx.wbatch = wbatch
+        if wbatch is not None:
+            wbatch.register()
+        packed, bp = eng.packed(w3, bias, "fwd")
+        y = torch.empty(n, h, w, eng.coutp, dtype=torch.float32, device=x.device)
+        K.conv5x5_shift4(x, n, h, w, packed, bp, eng.fwd_map, y)
+        ctx.eng, ctx.eng_t, ctx.has_bias = eng, eng_t, bias is not None
+        ctx.save_for_backward(x, w3, w3t)
+        ctx.bias = bias
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, w3, w3t = ctx.saved_tensors
+        eng, eng_t = ctx.eng, ctx.eng_t
+        gy = gy.contiguous()
+        n, h, w, _ = x.shape
+        dx = None
+        if ctx.needs_input_grad[2]:
+            dx = torch.empty(n, h, w, eng_t.coutp, dtype=torch.float32, device=gy.device)
+            K.conv5x5_shift4(gy, n, h, w, eng_t.packed(w3t, None, "fwd")[0], None, eng_t.fwd_map, dx)
+        if not (ctx.needs_input_grad[3] or (ctx.has_bias and ctx.needs_input_grad[5])):
+            return None, None, dx, None, None, None, None
+        if ctx.wbatch is not None:
+            if not ctx.wbatch.add(x, gy):
+                return None, None, dx, None, None, None, None
+            x, gy = ctx.wbatch.take()
+            n = x.shape[0]
+        dw3 = torch.empty(w3.shape, dtype=torch.float32, device=gy.device)
+        db = torch.empty(w3.shape[0], dtype=torch.float32, device=gy.device) if ctx.has_bias else None
+        K.conv5x5_shift4_bwd_weight(x, gy, n, h, w, eng.wgrad_map, dw3, db)
+        return None, None, dx, dw3, None, db, None
+
+
+def conv5x5_shift4_ok(x_lanes: int, out_lanes: int, eng, eng_t) -> bool:
+    """Shapes ``sf_conv5x5_fwd`` / ``sf_conv5x5_bwd_weight`` take in the current compute mode: 16-bit operands, lanes in whole 32-channel weight-gradient
+    tiles on both sides (the input gradient is the same call with the roles swapped), N blocks the shifted loader is compiled for."""
+    from ._hip import SF_BF16, SF_F16, compute_dtype
+    return (compute_dtype() in (SF_BF16, SF_F16) and x_lanes % 32 == 0 and out_lanes % 32 == 0 and eng.fwd_map.nf <= 4 and eng_t.fwd_map.nf <= 4
+            and not os.environ.get("SF_CONV5_NO_SHIFT4"))
+
+
+def conv5x5_shift4(x: Tensor, w3: Tensor, w3t: Tensor, bias: Optional[Tensor], eng, eng_t, wbatch=None) -> Tensor:
+    return _Conv5x5ShiftFn.apply(eng, eng_t, x.contiguous(), w3, w3t, bias, wbatch)
+
+
+def regroup5x5_transposed(weight: Tensor, lanes: int) -> Tensor:
+    """``regroup5x5`` of the input-gradient kernel of a 5x5 convolution: ``weight [O, I, 5, 5]`` flipped in both spatial axes with O and I swapped,
+    ``[I, 4 * lanes, 3, 3]`` (``lanes`` = channel lanes of the OUTPUT gradient, >= O).  No gradient flows through it."""
+    return regroup5x5(weight.detach().flip(2, 3).transpose(0, 1).contiguous(), lanes)
 
 
 class _S2D2Fn(torch.autograd.Function):

@@ -194,6 +194,27 @@ def convlstm_cell_bwd_gates(dh: Sequence[sfTensor], dc_next: sfTensor, gates: sf
     )
 
 
+def conv5x5_shift4(x: Tensor, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor], gm: "GemmMap", out: Tensor) -> None:
+    """A 5x5 'same' convolution of fp32-stored NHWC ``x`` on the 16-bit 3x3 kernels: four shifted views of ``x`` read in place, ``packed`` = the packed
+    image of ``regroup5x5(weight, x lanes)`` for ``Kp = 4 * x lanes``.  sf_conv5x5_fwd (split over the virtual channels for few small images)."""
+    dt = _hip.compute_dtype()
+    nbytes = lib().sf_conv5x5_fwd_workspace_bytes(n, h, w, gm.Np, gm.nf, x.shape[-1], dt)
+    ws = torch.empty(nbytes // 4 + 4, dtype=torch.float32, device=x.device) if nbytes else None
+    check(lib().sf_conv5x5_fwd(T(x), n, h, w, packed.data_ptr(), bias_packed.data_ptr() if bias_packed is not None else None, gm.Np, gm.nf, T(out),
+                               ws.data_ptr() if ws is not None else None, nbytes, dt, stream_ptr()), "sf_conv5x5_fwd")
+
+
+def conv5x5_shift4_bwd_weight(x: Tensor, dout: Tensor, n: int, h: int, w: int, gm: "GemmMap", dw: Tensor, db: Optional[Tensor]) -> None:
+    """dW3 ``[O, 4 * x lanes, 3, 3]`` (and db) of ``conv5x5_shift4``.  sf_conv5x5_bwd_weight."""
+    nmap, kmap = gm.tables(dw.device)
+    nbytes = lib().sf_conv5x5_bwd_weight_workspace_bytes(dout.shape[-1], x.shape[-1], n, h, w)
+    ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=dw.device)
+    assert dw.is_contiguous() and (db is None or db.is_contiguous())
+    check(lib().sf_conv5x5_bwd_weight(T(x), T(dout), n, h, w, nmap.data_ptr(), kmap.data_ptr(), dw.shape[0], dw.shape[1], dw.data_ptr(),
+                                      db.data_ptr() if db is not None else None, 0, ws.data_ptr(), nbytes, _hip.compute_dtype(), stream_ptr()),
+          "sf_conv5x5_bwd_weight")
+
+
 def conv3x3_bwd_weight(src0: sfTensor, src1: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, dw: Tensor,
                        db: Optional[Tensor], accumulate: bool) -> None:
     """dW/db of a 3x3 conv into the reference's OIHW gradient tensors.  sf_conv3x3_bwd_weight."""

@@ -51,7 +51,23 @@ class ConvGRUCell(nn.Module):
     def _as_tiles(self) -> bool:
         return self.kernel_size == 5 and not os.environ.get("SF_CONV5_DIRECT")
 
-    def weights(self, x_lanes: Optional[int] = None, s2d: bool = False):
+    def _engine(self, tag: str, cin: int, cout: int) -> "F.ConvEngine":
+        key = (tag, cin, cout)
+        if key not in self._eng:
+            self._eng[key] = F.ConvEngine([cin], cout)
+        # the regrouped weights are fresh tensors every call but functions of the cell's parameters only: the packed images are
+        # cached on THOSE (identity + version + optimizer generation) - one pack per step, not one per frame
+        self._eng[key].key_tensors = tuple(self.parameters())
+        return self._eng[key]
+
+    def shift4_ok(self, x_lanes: int) -> bool:
+        """Can this 5x5 cell's four convolutions take the shifted-view route (``functional_gan.conv5x5_shift4``) on an input of ``x_lanes`` lanes?"""
+        hp, hid = self._hp, self.hidden_size
+        pairs = ((x_lanes, 2 * hp, self.input_size), (x_lanes, hp, self.input_size), (hp, 2 * hp, hid), (hp, hp, hid))
+        return self._as_tiles() and all(FG.conv5x5_shift4_ok(li, rows, self._engine("s4", 4 * li, rows), self._engine("s4t", 4 * rows, ci))
+                                        for li, rows, ci in pairs)
+
+    def weights(self, x_lanes: Optional[int] = None, s2d: bool = False, shift4: bool = False):
         """The six derived weights of a call / a sequence.  5x5 kernels are regrouped HERE into the weight of the 3x3 convolution over four shifted
         copies (``x_lanes``: channel lanes of the cell's input tensor) - once per sequence, not once per frame.  ``s2d``: for tensors in the
         ``space_to_depth2`` layout instead (``run_sequence``): weights by ``regroup5x5_s2d``, biases repeated per output phase."""
@@ -64,7 +80,11 @@ class ConvGRUCell(nn.Module):
         if self._as_tiles():
             xl = cpad(ci) if x_lanes is None else x_lanes
             for k, lanes in (("zr_x", xl), ("o_x", xl), ("zr_h", hp), ("o_h", hp)):
+                if shift4:   # + the input-gradient kernel (flipped, transposed) of the shifted-view route, over the lanes of the output gradient
+                    W[k + "_t"] = FG.regroup5x5_transposed(W[k], W[k].shape[0])
                 W[k] = FG.regroup5x5_s2d(W[k], lanes, hp) if s2d else FG.regroup5x5(W[k], lanes)
+            if shift4:
+                W["shift4"] = True
             if s2d:
                 W["b_zr"] = W["b_zr"].view(2, 1, hp).expand(2, 4, hp).reshape(-1)
                 W["b_o"] = W["b_o"].view(1, hp).expand(4, hp).reshape(-1)
@@ -74,8 +94,11 @@ class ConvGRUCell(nn.Module):
                 W[k] = W[k].contiguous()
         return W
 
-    def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor], wbatch=None, s2d: bool = False) -> Tensor:
+    def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor], wbatch=None, s2d: bool = False, wt: Optional[Tensor] = None) -> Tensor:
         k = self.kernel_size
+        if wt is not None:   # shifted-view route: w = regroup5x5(weight), wt = regroup5x5_transposed(weight)
+            eng, eng_t = self._engine("s4", w.shape[1], w.shape[0]), self._engine("s4t", wt.shape[1], wt.shape[0])
+            return FG.conv5x5_shift4(x, w, wt, b, eng, eng_t, wbatch)
         if s2d:
             k = 3   # weights and tensors are in the space_to_depth2 layout: a plain 3x3 convolution
         if k == 3 or self._as_tiles():
@@ -92,7 +115,8 @@ class ConvGRUCell(nn.Module):
     def x_parts(self, x: Tensor, W: dict):
         """x-parts of the three gates for any number of frames at once: ``(gx_zr [.., 2*hidp], gx_o [.., hidp])`` incl. the biases."""
         s2d = bool(W.get("s2d"))
-        return self._conv("zr_x", x, W["zr_x"], W["b_zr"], s2d=s2d), self._conv("o_x", x, W["o_x"], W["b_o"], s2d=s2d)
+        return (self._conv("zr_x", x, W["zr_x"], W["b_zr"], s2d=s2d, wt=W.get("zr_x_t")),
+                self._conv("o_x", x, W["o_x"], W["b_o"], s2d=s2d, wt=W.get("o_x_t")))
 
     def step(self, gx_zr: Tensor, gx_o: Tensor, h: Optional[Tensor], W: dict) -> Tensor:
         s2d = bool(W.get("s2d"))
@@ -100,9 +124,9 @@ class ConvGRUCell(nn.Module):
         if h is None:  # zero state: the h-parts vanish
             zr, _ = FG.dvdgru_gates(gx_zr, None, None, hp)
             return FG.dvdgru_out(gx_o, None, zr, None, hp)
-        gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"), s2d)
+        gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"), s2d, W.get("zr_h_t"))
         zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp)
-        gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"), s2d)
+        gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"), s2d, W.get("o_h_t"))
         return FG.dvdgru_out(gx_o, gh_o, zr, h, hp)
 
     def run(self, x: Tensor, h: Optional[Tensor]) -> Tensor:
@@ -148,10 +172,15 @@ class ConvGRU(nn.Module):
         for cell in self.cells:
             # 5x5 cells run on the half-resolution layout (2x2 pixel blocks folded into channels: sf_space_to_depth2) - ONE permutation of the
             # sequence on the way in and one on the way out instead of a padded, four-times-copied input and a crop per convolution
-            fold = cell._as_tiles() and seq.shape[1] % 2 == 0 and seq.shape[2] % 2 == 0 and not os.environ.get("SF_GRU5_STACK4")
+            # ... or, in the 16-bit modes with lanes in whole 32-channel tiles, on the shifted-view route: the 3x3 kernels read the four displaced views of
+            # the unchanged tensors in their loaders - no permutation either, and none of the half-resolution form's 4x weight bytes
+            lanes_in = seq.shape[-1] // 4 if folded else seq.shape[-1]
+            shift = not os.environ.get("SF_GRU5_STACK4") and cell.shift4_ok(lanes_in)
+            fold = (not shift and cell._as_tiles() and seq.shape[1] % (1 if folded else 2) == 0 and seq.shape[2] % (1 if folded else 2) == 0
+                    and not os.environ.get("SF_GRU5_STACK4"))
             if fold != folded:
                 seq, folded = (FG.space_to_depth2(seq) if fold else FG.depth_to_space2(seq)), fold
-            W = cell.weights(seq.shape[-1] // 4 if fold else seq.shape[-1], s2d=fold)
+            W = cell.weights(seq.shape[-1] // 4 if fold else seq.shape[-1], s2d=fold, shift4=shift)
             if cell.kernel_size in (3, 5) and not os.environ.get("SF_GRU_WGRAD_PER_FRAME"):
                 # the state convolutions' weight gradients: once per sequence over all frames, not once per frame (functional.WeightGradBatch)
                 W["batch_zr_h"], W["batch_o_h"] = F.WeightGradBatch(), F.WeightGradBatch()

@@ -150,6 +150,11 @@ int main(void) {
   REFUSED(sf_regroup5x5_fwd(ok, 100, 4, 8, 4, ok, st));                                                /* lanes < I */
   REFUSED(sf_regroup5x5_fwd(ok, 10, 4, 8, 16, ok, st));                                                /* row pitch smaller than a row */
   REFUSED(sf_regroup5x5_bwd(0, 4, 8, 16, ok, st));                                                     /* no gradient */
+  REFUSED(sf_conv5x5_fwd(b16, 1, 8, 8, ok, 0, 128, 4, a16, 0, 0, SF_BF16, st));                          /* bf16-stored x: fp32 storage only */
+  REFUSED(sf_conv5x5_fwd(a16, 1, 8, 8, ok, 0, 128, 4, a16, 0, 0, SF_F32, st));                           /* 16-bit operand kernels only */
+  REFUSED(sf_conv5x5_fwd(a16, 1, 8, 8, ok, 0, 160, 5, a16, 0, 0, SF_BF16, st));                          /* NF = 5 has no shifted-view loader */
+  REFUSED(sf_conv5x5_bwd_weight(a16, a16, 1, 8, 8, ok, ok, 16, 64, ok, 0, 0, ok, 1 << 20, SF_BF16, st)); /* lanes not a multiple of 32 */
+  REFUSED(sf_conv5x5_bwd_weight(a64, a16, 1, 8, 8, ok, ok, 16, 256, ok, 0, 0, ok, 16, SF_BF16, st));     /* workspace too small */
   REFUSED(sf_space_to_depth2(a16, 1, 8, 8, 0, a48, st));                                               /* y must carry 4C lanes */
   REFUSED(sf_space_to_depth2(a16, 1, 7, 8, 0, a64, st));                                               /* odd height */
   REFUSED(sf_space_to_depth2(a16, 1, 8, 8, 1, a64, st));                                               /* inverse: x is the 4C side */
