@@ -65,8 +65,12 @@ __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t r
 // partner workgroup's MFMAs, prologue and epilogue run in those gaps: for the fused LSTM cell, whose epilogue moves 5 state / gate
 // tensors per tile, that overlap is worth more than the double buffer (ConvLSTM cell).
 // SPLITK: grid z = slice of the input channels (ConvParams::split_c): the same kernel on a shifted source / weight / output pointer.
-template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false, bool WS = false, bool SPLITK = false>
+// SHIFT: src0 is four displaced views of one fp32-stored tensor (ConvParams::shift4 - a 5x5 convolution, sf_conv5x5_fwd): the halo loader applies the view's
+// pixel shift, and the taps the view does not own (first row of the lower views, first column of the right ones: sf_regroup5x5_fwd masks those weights) are
+// loaded but not multiplied - 25 instead of 36 taps' worth of MFMAs over the four views.  Its own instantiations: the plain kernels keep their code.
+template <int WAVES, int NF, int EPI, bool DUAL = false, bool TR = false, bool BNB = false, bool WS = false, bool SPLITK = false, bool SHIFT = false>
 __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x3_bf16_kernel(const ConvParams p_in) {
+  static_assert(!SHIFT || (EPI == EPI_LINEAR && TR && !BNB && !WS && NF != 5), "shifted views: plain linear launches, NF <= 4");
   static_assert(!WS || (WAVES == 4 && !DUAL), "the single-weight-buffer variant is a 4-wave layout");
   static_assert(!SPLITK || (EPI == EPI_LINEAR && !DUAL && TR && !BNB && !WS), "split-K: plain linear launches only");
   ConvParams p_split;
@@ -74,7 +78,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     const int z = blockIdx.z;
     p_split = p_in;
     const int cbeg = z * p_in.split_c;
-    if (p_in.shift4) p_split.chunk0 = cbeg / KC;   // shifted views: the slice starts at a virtual chunk, the tensor pointer stays
+    if constexpr (SHIFT) p_split.chunk0 = cbeg / KC;   // shifted views: the slice starts at a virtual chunk, the tensor pointer stays
     else p_split.src0 = reinterpret_cast<const float*>(reinterpret_cast<const char*>(p_in.src0) + (size_t)cbeg * (p_in.bf0 ? 2 : 4));
     p_split.c0 = p_in.c0 - cbeg < p_in.split_c ? p_in.c0 - cbeg : p_in.split_c;
     p_split.wp = reinterpret_cast<const char*>(p_in.wp) + (size_t)(cbeg / KC) * (9 * 32 * NF * PIX_B);
@@ -233,10 +237,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     const float* src; int cbase, stride, idiv, imod;
     if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; idiv = p.idiv0; imod = p.imod0; }
     else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; idiv = p.idiv1; imod = p.imod1; }
-    // (compiled into the plain linear launches only, and not into NF = 5: the 160-accumulator kernels spill 12 more bytes with it)
-    constexpr bool SHIFT_OK = EPI == EPI_LINEAR && !BNB && !WS && NF != 5;
     int sdy = 0, sdx = 0;
-    if (SHIFT_OK && p.shift4) {  // four shifted views of src0 (ConvParams::shift4): this chunk's view and its pixel shift
+    if constexpr (SHIFT) {  // four shifted views of src0 (ConvParams::shift4): this chunk's view and its pixel shift
       const int cg = ci + p.chunk0, sv = cg / p.shift4;
       cbase = (cg - sv * p.shift4) * KC; sdy = 2 * (sv >> 1) - 1; sdx = 2 * (sv & 1) - 1;
     }
@@ -245,7 +247,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       const int pc = tid + j * THREADS;
       int ni, gy, gx, iy;
       bool ok = halo(pc >> 1, ni, gy, gx, iy) && pc < PIECES;
-      if (SHIFT_OK && p.shift4) { gy += sdy; gx += sdx; ok = pc < PIECES && ni < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W; }
+      if constexpr (SHIFT) { gy += sdy; gx += sdx; ok = pc < PIECES && ni < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W; }
       f32x8 v = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
       if (ok) {
         int ns = ni / idiv; if (imod) ns %= imod;
@@ -416,6 +418,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap) {
       if (tap + 1 < 9) load_tap(tap + 1, fa[(tap + 1) & 1], fb[(tap + 1) & 1]);
+      bool dead = false;
+      if constexpr (SHIFT) {  // a tap this chunk's view does not own (block-uniform): operands read, products skipped
+        const int sv = (ci + p.chunk0) / p.shift4;
+        dead = ((sv >> 1) && tap / 3 == 0) || ((sv & 1) && tap % 3 == 0);
+      }
+      if (!dead)
 #pragma unroll
       for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
@@ -529,6 +537,18 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int
     }
 }
 
+// the shifted-view instantiation of a plain linear launch (ConvParams::shift4 set); false = not such a launch
+template <int WAVES, int NFV, int EPI, bool DUAL>
+bool launch_shifted(const ConvParams& p, dim3 grid, dim3 block, hipStream_t st) {
+  if constexpr (EPI == EPI_LINEAR && NFV != 5) {
+    if (p.shift4) {
+      hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true, false, false, false, true>), grid, block, 0, st, p);
+      return true;
+    }
+  }
+  return false;
+}
+
 template <int WAVES, int EPI, bool DUAL = false>
 int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
   ConvParams p = p0;
@@ -558,7 +578,8 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
       if (p.split_c > 0) {   // split-K (sf_conv3x3_fwd_splitk planned it): grid z = channel slices
         if (nf != 4 || p.stats || p.bnb_coef || p.bias_tab || p.src1) { sf_set_error("bf16 conv: split-K takes plain nf=4 single-source launches"); return 1; }
         grid.z = (p.c0 + p.split_c - 1) / p.split_c;
-        hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, false, true, false, false, true>), grid, block, 0, st, p);
+        if (p.shift4) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, false, true, false, false, true, true>), grid, block, 0, st, p);
+        else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, 4, EPI, false, true, false, false, true>), grid, block, 0, st, p);
         hipError_t es = hipGetLastError();
         if (es != hipSuccess) { sf_set_error("conv3x3_bf16 (split-K): launch failed: %s", hipGetErrorString(es)); return 2; }
         return 0;
@@ -571,8 +592,10 @@ int launch_w(const ConvParams& p0, int nf, int nblk, hipStream_t st) {
     if (tr) {                                                                                                          \
       if constexpr (EPI == EPI_LINEAR && !DUAL) {                                                                      \
         if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true, true>), grid, block, 0, st, p); \
-        else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);            \
-      } else hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);            \
+        else if (!launch_shifted<WAVES, NFV, EPI, DUAL>(p, grid, block, st))                                           \
+          hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);               \
+      } else if (!launch_shifted<WAVES, NFV, EPI, DUAL>(p, grid, block, st))                                           \
+        hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, true>), grid, block, 0, st, p);                 \
     }                                                                                                                  \
     else if constexpr (EPI == EPI_LINEAR && !DUAL) hipLaunchKernelGGL((conv3x3_bf16_kernel<WAVES, NFV, EPI, DUAL, false>), grid, block, 0, st, p); \
     else { sf_set_error("bf16 conv: statistics need the linear epilogue on single-image tiles"); return 1; }          \

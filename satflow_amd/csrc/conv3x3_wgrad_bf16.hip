@@ -332,6 +332,11 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const int l_off = kh ? A_BYTES + b_q + 12 : A_BYTES + B_BYTES + h_off, l_pitch = kh ? 128 : 8;
     const int r_off = kh ? A_BYTES + B_BYTES + h_off + 4 : A_BYTES + b_q + 64, r_pitch = kh ? 8 : 128;
 
+    // shifted views (WgradParams::shift4): view (ty, tx) = 2 ty + tx of the 5x5 kernel's four 3x3 tiles owns no taps in its first row when ty = 1 and none
+    // in its first column when tx = 1 (sf_regroup5x5_fwd masks them: the 5x5 kernel's middle row / column belongs to the upper / left tile) - their
+    // products are skipped, the accumulators stay zero: 25 instead of 36 taps' worth of MFMAs over the four views
+    const int view_c = (!ABF && !BBF && !MIXED && p.shift4) ? (cit * CI_T) / p.shift4 : 0;
+    const bool dead_ky0 = (view_c >> 1) != 0, dead_kx0 = (view_c & 1) != 0;
     __syncthreads();  // tile 0 staged
     for (int i = 0; i < my_tiles; ++i) {
       const char* la = lds + (i & 1) * BUF;
@@ -371,9 +376,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
         for (int ky = 0; ky < 3; ++ky) {
           const int row = hrow - ky;
           if (row < 0 || row >= KR) continue;
+          if (ky == 0 && dead_ky0) continue;
           const bf16x8 a = arow[row & 3];
           acc[ky * 3 + 1] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, mid), acc[ky * 3 + 1]);
-          acc[ky * 3 + 0] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0]);
+          if (!dead_kx0) acc[ky * 3 + 0] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, b0), acc[ky * 3 + 0]);
           acc[ky * 3 + 2] = SF_MFMA_32X32X16(a, __builtin_bit_cast(bf16x8, b2), acc[ky * 3 + 2]);
         }
       }
