@@ -20,7 +20,7 @@ for r in rows: w.writerow({k: r[k] for k in w.fieldnames})
 PY
   done
   # the probe's launch: bf16-stored activations take the persistent kernel, fp32-stored ones the one-item kernel
-  if [ $m = bf16a ]; then KF="conv3x3_bf16_persist_kernel<4, 0>"; else KF="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"; fi
+  if [ $m = bf16a ]; then KF="conv3x3_bf16_persist_kernel<4, 0>"; else KF="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false, false>"; fi
   [ -d $d ] && python tools/parse_pmc.py $d profiles/${R}_metnet_${m}_pmc_conv256.json "$KF" > /dev/null
 done
 [ -s gpurun_out/${R}_pmc_dgmr_conv/${R}_dgmr_bf16_pmc_conv.json ] && cp gpurun_out/${R}_pmc_dgmr_conv/${R}_dgmr_bf16_pmc_conv.json profiles/

@@ -14,7 +14,7 @@ bash tools/prof_pmc_step.sh ${R}_pmc_step_bf16a --steps 3 --warmup 1 --no-cpu-ba
 python tools/pmc_by_kernel.py gpurun_out/${R}_pmc_step_bf16a 30 --json profiles/${R}_metnet_bf16a_pmc_step.json > gpurun_out/${R}_pmc_step_bf16a/by_kernel.txt 2>&1
 cp profiles/${R}_metnet_bf16a_pmc_step.json gpurun_out/${R}_pmc_step_bf16a/
 # the full bench lines below read the sha-stamped traffic record from profiles/: refresh it on this box first (collect_profiles.sh repeats this at home)
-KFB="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false>"
+KFB="conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false, false>"
 python tools/parse_pmc.py gpurun_out/${R}_pmc_metnet_bf16 profiles/${R}_metnet_bf16_pmc_conv256.json "$KFB" > /dev/null 2>&1
 ROUND=$R bash tools/prof_pmc_dgmr.sh ${R}_pmc_dgmr_conv > /dev/null 2>&1           # DGMR line's roofline launch
 ROUND=$R bash tools/prof_pmc_cell.sh ${R}_pmc_convlstm_cell > /dev/null 2>&1   # fused ConvLSTM cell: traffic record for the ConvLSTM line
