@@ -30,8 +30,8 @@
 extern "C" {
 #endif
 
-/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*) */
-#define SF_ABI_VERSION 4
+/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*; 5: sf_space_to_depth2, sf_regroup5x5_s2d_*, sf_conv5x5_*, sf_linear_fwd with 16-bit operands) */
+#define SF_ABI_VERSION 5
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */

@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os
 SF_F32, SF_BF16, SF_F16 = 0, 1, 2
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 4  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
+ABI_VERSION = 5  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
