@@ -40,7 +40,7 @@ def d_wgrad(s0, s1, dout, n, h, w, gm, dw, db, accumulate=False):
     return (n, h, w, s0.c + s1.c, dout.c), 2.0 * 9 * n * h * w * (s0.c + s1.c) * dout.c
 
 
-def d_lin(x, W, bias, out_lanes):
+def d_lin(x, W, bias, out_lanes, lowp=False):
     rows = x.numel() // x.shape[-1]
     return (rows, x.shape[-1], W.shape[0]), 2.0 * rows * x.shape[-1] * W.shape[0]
 
@@ -49,6 +49,16 @@ def d_bmm(A, B, out, alpha=1.0, beta=0.0, lowp=False):
     return (tuple(A.shape), tuple(B.shape)), 2.0 * A.shape[0] * A.shape[1] * A.shape[2] * B.shape[2]
 
 
+def d_conv5(x, n, h, w, packed, bp, gm, out):   # shifted-view 5x5 route: K = four views; 25 of the 36 taps are multiplied
+    return (n, h, w, gm.Kp, gm.Np, "5x5 shifted views"), 2.0 * 25 / 4 * n * h * w * gm.Kp * gm.Np
+
+
+def d_wgrad5(x, dout, n, h, w, gm, dw, db):
+    return (n, h, w, 4 * x.shape[-1], dout.shape[-1], "5x5 shifted views"), 2.0 * 25 / 4 * n * h * w * 4 * x.shape[-1] * dout.shape[-1]
+
+
+K.conv5x5_shift4 = timed("conv5x5", K.conv5x5_shift4, d_conv5)
+K.conv5x5_shift4_bwd_weight = timed("wgrad5x5", K.conv5x5_shift4_bwd_weight, d_wgrad5)
 K.conv3x3 = timed("conv3x3", K.conv3x3, d_conv)
 K.conv3x3_bwd_weight = timed("wgrad", K.conv3x3_bwd_weight, d_wgrad)
 K.linear_fwd = timed("linear_fwd", K.linear_fwd, d_lin)
