@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 PEAK_F32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
-PROFILE_ROUND = "r04"        # prefix of the sha-stamped PMC / parity records under profiles/ this file reads
+PROFILE_ROUND = "r05"        # prefix of the sha-stamped PMC / parity records under profiles/ this file reads
 
 
 def event_time(fn, iters: int, warm: int = 3) -> float:
@@ -250,7 +250,7 @@ class MetNetWorkload:
     def kernel_table(self):
         """The five kernels that are three quarters of the step, each timed LIVE at the step's launch shape with HIP events
         (synthetic operands of the right storage types): us per launch, launches per step, algorithmic flops, fraction of the 2.5 PF bf16 MFMA
-        peak, and the HBM traffic per launch from the sha-stamped PMC record of a profiled step (profiles/r04_metnet_<mode>_pmc_step.json:
+        peak, and the HBM traffic per launch from the sha-stamped PMC record of a profiled step (profiles/r05_metnet_<mode>_pmc_step.json:
         rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x 2 per MI355X_MICROARCH.md), or null."""
         import satflow_amd
         from satflow_amd import kernels as K
@@ -270,22 +270,30 @@ class MetNetWorkload:
             else:
                 pmc_note = f"profiles/{PROFILE_ROUND}_metnet_{mode}_pmc_step.json is stale (kernel sources changed): dropped"
 
-        def traffic(sub):
+        def traffic(sub, write_bytes):
+            """Per-launch HBM bytes of the kernel whose name contains `sub`, at THIS row's shape: a name that runs at several shapes in the step carries one
+            record per shape (tools/pmc_by_kernel.py groups a name's launches by their write bytes); the one nearest the row's algorithmic writes is taken."""
             for k, v in pmc.items():
                 if sub in k:
-                    return {"read_bytes": v["read_bytes"], "write_bytes": v["write_bytes"], "bytes": v["read_bytes"] + v["write_bytes"]}
+                    shapes = v.get("shapes") or [v]
+                    c = min(shapes, key=lambda c_: abs(c_["write_bytes"] - write_bytes))
+                    return {"read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"], "bytes": c["read_bytes"] + c["write_bytes"],
+                            "per_shape": bool(v.get("shapes")) and len(shapes) > 1}
             return None
 
         bf = torch.bfloat16
         rows = []
 
-        def row(name, pmc_sub, launches, cin, cout, fn, what):
+        def row(name, pmc_sub, launches, cin, cout, fn, what, extra_read_lanes=0, out_lanes=None):
+            """extra_read_lanes: channel lanes of a second tensor the launch reads per pixel (the x read of the BatchNorm-backward epilogue);
+            out_lanes: lanes of the tensor written per pixel (None: cout; 0: the weight gradient writes no activation)."""
             t = event_time(fn, iters=10)
             fl = 2 * 9 * cin * cout * H * W * n
-            alg = (cin + cout) * H * W * n * 2 + 9 * cin * cout * 2
+            alg = (cin + cout + extra_read_lanes) * H * W * n * 2 + 9 * cin * cout * 2
+            wr = (cout if out_lanes is None else out_lanes) * H * W * n * 2 + (9 * cin * cout * 4 if out_lanes == 0 else 0)
             rows.append({"kernel": name, "replaces": what, "launches_per_step": launches, "launch_us": t * 1e6, "ms_per_step": launches * t * 1e3,
                          "algorithmic_flops": fl, "achieved_tflops": fl / t / 1e12, "frac": fl / t / 1e12 / PEAK_BF16_TFLOPS,
-                         "algorithmic_bytes": alg, "traffic": traffic(pmc_sub)})
+                         "algorithmic_bytes": alg, "traffic": traffic(pmc_sub, wr)})
 
         for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_persist4_kernel<2>"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
             eng = ConvEngine([cin], cout)
@@ -314,18 +322,21 @@ class MetNetWorkload:
             row((f"conv3x3_bf16_persist4_kernel<BNB> {cout}->{cin} (4 waves x 512 registers; input gradient + BatchNorm backward in the epilogue)" if gmb.nf == 4 else
                  f"conv3x3_bf16_kernel<8, NF={gmb.nf}, TR, BNB> {cout}->{cin} (input gradient + BatchNorm backward)"), dgrad_name, 2 if cin == 256 else 1, cout, cin,
                 lambda: K.conv3x3_bwd_data_bn(T(dout), n, H, W, packed_t, gmb, T(x), coef, T(dx)),
-                "input gradients of conv3 / conv4 with the BatchNorm backward folded in" if cin == 256 else "input gradient of conv2 with BatchNorm 1's backward folded in")
+                "input gradients of conv3 / conv4 with the BatchNorm backward folded in" if cin == 256 else "input gradient of conv2 with BatchNorm 1's backward folded in",
+                extra_read_lanes=cin)   # dout + x read, dx written
             dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
             mean, rstd = torch.randn(G, cpad(cin), device=dev), 0.5 + torch.rand(G, cpad(cin), device=dev)
             sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
             row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true>", 2 if cin == 256 else 1, cin, cout,
                 lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums)),
-                "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)" if cin == 256 else "weight gradient of conv2")
+                "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)" if cin == 256 else "weight gradient of conv2", out_lanes=0)
             del x, y, dout, dx, st
         rows.sort(key=lambda r: -r["ms_per_step"])
         return {"rows": rows, "traffic_source": pmc_note,
                 "note": "launch_us of the weight-gradient rows includes the small helper kernels of sf_conv3x3_bwd_weight_folded (border sums, reduce, BatchNorm sums: ~0.15 ms); "
-                        "traffic = mean per launch over ALL launches of that kernel NAME in the profiled step (a name that runs at both 256->256 and 160->256 reports the mix)"}
+                        "traffic = mean per launch over the launches of that kernel name AT THIS ROW'S SHAPE in the profiled step (a name that runs at both 256->256 and 160->256 "
+                        "carries one record per shape, told apart by the launches' write bytes; per_shape false = a record without shape classes: the mix); "
+                        "algorithmic_bytes of the input-gradient rows = dout + x (BatchNorm-backward epilogue) read + dx written"}
 
     def roofline(self):
         """The kernel with the largest share of the step: the grouped weight gradient of the folded 256 -> 256 convolutions

@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*; 5: sf_space_to_depth2, sf_regroup5x5_s2d_*, sf_conv5x5_*, sf_linear_fwd with 16-bit operands) */
-#define SF_ABI_VERSION 5
+#define SF_ABI_VERSION 6
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */
@@ -412,10 +412,8 @@ int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gates, sfTensor
  * workgroups per map of more than 8 rows (hidp 64), the boundary row of dgh handed over inside the launch; same workspace layout,
  * tickets and failure behaviour (every gradient of the failing workgroup is NaN from the failed step on). */
 size_t sf_convgru_seq_bwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
-/* Test hooks of the two-workgroup kernels (process-wide; tests/test_convgru_seq_gpu.py): polls before a receiver gives up
- * (<= 0: the default, seconds) and a half (0 / 1, -1 = none) that never sends its boundary row - to exercise the failure path
- * (error word + NaN results) on purpose. */
-void sf_convgru_seq_debug(int32_t spin_limit, int32_t mute_half);
+/* (ABI 6: the test hook sf_convgru_seq_debug and its two process-wide variables left the product library - tests/native builds
+ * convgru_seq.hip a second time with -DSF_TEST_HOOKS for the failure-path test.) */
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
  * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
  * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */

@@ -16,7 +16,7 @@ _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os
 SF_F32, SF_BF16, SF_F16 = 0, 1, 2
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 5  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
+ABI_VERSION = 6  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
@@ -98,7 +98,6 @@ PROTOTYPES = {
     "sf_convgru_seq_fwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
     "sf_convgru_seq_bwd": (C.c_int, [sfTensor, sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _i32, _vp, _i32, sfTensor, sfTensor, _vp, _sz, _i32, _vp]),
     "sf_convgru_seq_bwd_workspace_bytes": (_sz, [_i32, _i32, _i32]),
-    "sf_convgru_seq_debug": (None, [_i32, _i32]),
     "sf_convgru_bwd_gates": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, sfTensor, sfTensor, _i64, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
@@ -224,8 +223,15 @@ def sticky_workspace(kind: str, shape_key, nbytes: int, device) -> Optional[torc
     key = (kind, tuple(shape_key), str(device), torch.cuda.current_stream(device).cuda_stream)
     ws = _WORKSPACES.get(key)
     if ws is None or ws.numel() * 8 < nbytes:
-        ws = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
-        _WORKSPACES[key] = ws
+        # never allocate under hipGraph capture: the tensor would live in the graph's private pool and its zeroing would be a memset node
+        # replayed with every launch, while the tensor is cached here and reused by eager launches
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(f"satflow_amd: the {kind} workspace for shape {tuple(shape_key)} must exist before hipGraph capture - "
+                               "run the step once eagerly on this stream first")
+        new = torch.zeros((nbytes + 7) // 8, dtype=torch.int64, device=device)
+        if ws is not None:   # a grown workspace keeps the sticky error word of the one it replaces (stream-ordered, no synchronisation)
+            new[0].copy_(ws[0])
+        _WORKSPACES[key] = ws = new
     return ws
 
 

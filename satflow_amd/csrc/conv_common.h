@@ -494,7 +494,7 @@ void sf_pack_weights_f16(const float* w, int O, int I, const int* nmap, int Np, 
 // persistent variant for the large single-source bf16-stored launches (conv3x3_bf16_persist.hip); bit-identical results
 bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf);
 int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p, int nf, int nblk, hipStream_t st);
-// one-wave-per-SIMD persistent variant (conv3x3_bf16_persist4.hip): NF = 4, >= 2 K chunks, no per-channel bias; bit-identical results
+// one-wave-per-SIMD persistent variant (conv3x3_bf16_persist4.hip): NF = 4, >= 3 K chunks (the next-item set-up assumes them), no per-channel bias; bit-identical results
 bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf);
 int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p, int nblk, hipStream_t st);
 // kscale (nullable): [groups][Kp] per-input-lane factors -> `groups` packed images back to back (folded BatchNorm scale)

@@ -63,8 +63,13 @@ constexpr int MB_HDR = 2;                                    // error word + tic
 constexpr int MB_ROW = 4 * 16 * 2 * 4;                       // granules of one boundary row (4 chunks max)
 __host__ __device__ constexpr long long mbox_slot(long long img, int half, int parity) { return MB_HDR + ((img * 2 + half) * 2 + parity) * MB_ROW; }
 constexpr unsigned MB_SPIN_LIMIT = 1u << 22;                 // default polls before a receiver gives up (seconds; then: error word + NaN state)
-// test hooks (sf_convgru_seq_debug): a shorter spin and a half that never sends, to exercise the failure path on purpose
+// The product library has NO process-wide state here: spin bound and muted half are constants.  tests/native builds this file a second time
+// with -DSF_TEST_HOOKS (libsatflow_hip_hooks.so, never shipped): a shorter spin and a half that never sends, to exercise the failure path.
+#ifdef SF_TEST_HOOKS
 int g_spin_limit = (int)MB_SPIN_LIMIT, g_mute_half = -1;
+#else
+constexpr int g_spin_limit = (int)MB_SPIN_LIMIT, g_mute_half = -1;
+#endif
 
 // LDS-DMA hidden from hipcc (see conv3x3_bf16.hip): wave-uniform descriptor + scalar offset + constant per-lane offset.
 __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff, unsigned lds_dst) {
@@ -1186,10 +1191,12 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
 }  // namespace
 
 // mailbox of the two-workgroups-per-image kernel: 2 directions x 2 parities x one boundary row of granules per image + an error word
+#ifdef SF_TEST_HOOKS
 extern "C" void sf_convgru_seq_debug(int32_t spin_limit, int32_t mute_half) {
   g_spin_limit = spin_limit > 0 ? spin_limit : (int)MB_SPIN_LIMIT;
   g_mute_half = mute_half;
 }
+#endif
 
 extern "C" size_t sf_convgru_seq_fwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp) {
   if (n <= 0 || h <= 8 || hidp <= 32) return 0;

@@ -63,9 +63,9 @@ class ConvGRUCell(nn.Module):
     def shift4_ok(self, x_lanes: int) -> bool:
         """Can this 5x5 cell's four convolutions take the shifted-view route (``functional_gan.conv5x5_shift4``) on an input of ``x_lanes`` lanes?"""
         hp, hid = self._hp, self.hidden_size
-        pairs = ((x_lanes, 2 * hp, self.input_size), (x_lanes, hp, self.input_size), (hp, 2 * hp, hid), (hp, hp, hid))
-        return self._as_tiles() and all(FG.conv5x5_shift4_ok(li, rows, self._engine("s4", 4 * li, rows), self._engine("s4t", 4 * rows, ci))
-                                        for li, rows, ci in pairs)
+        pairs = (("zr_x", x_lanes, 2 * hp, self.input_size), ("o_x", x_lanes, hp, self.input_size), ("zr_h", hp, 2 * hp, hid), ("o_h", hp, hp, hid))
+        return self._as_tiles() and all(FG.conv5x5_shift4_ok(li, rows, self._engine("s4:" + tag, 4 * li, rows), self._engine("s4t:" + tag, 4 * rows, ci))
+                                        for tag, li, rows, ci in pairs)
 
     def weights(self, x_lanes: Optional[int] = None, s2d: bool = False, shift4: bool = False):
         """The six derived weights of a call / a sequence.  5x5 kernels are regrouped HERE into the weight of the 3x3 convolution over four shifted
@@ -97,7 +97,9 @@ class ConvGRUCell(nn.Module):
     def _conv(self, tag: str, x: Tensor, w: Tensor, b: Optional[Tensor], wbatch=None, s2d: bool = False, wt: Optional[Tensor] = None) -> Tensor:
         k = self.kernel_size
         if wt is not None:   # shifted-view route: w = regroup5x5(weight), wt = regroup5x5_transposed(weight)
-            eng, eng_t = self._engine("s4", w.shape[1], w.shape[0]), self._engine("s4t", wt.shape[1], wt.shape[0])
+            # the weight's identity is part of the engine key: with input lanes == hidden lanes the x-part and h-part weights have the
+            # same shape, and one engine's pack cache (keyed on the cell's parameters) would hand the h-convolution the x weights
+            eng, eng_t = self._engine("s4:" + tag, w.shape[1], w.shape[0]), self._engine("s4t:" + tag, wt.shape[1], wt.shape[0])
             return FG.conv5x5_shift4(x, w, wt, b, eng, eng_t, wbatch)
         if s2d:
             k = 3   # weights and tensors are in the space_to_depth2 layout: a plain 3x3 convolution

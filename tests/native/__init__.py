@@ -19,6 +19,30 @@ def build(force: bool = False) -> str:
     return LIB
 
 
+HOOKS_LIB = os.path.join(HERE, "libsatflow_hip_hooks.so")
+
+
+def build_hooks(force: bool = False) -> str:
+    """The product library with convgru_seq.hip compiled a SECOND time with -DSF_TEST_HOOKS (exports sf_convgru_seq_debug: a shorter
+    hand-off spin and a half that never sends).  Test infrastructure: selected per process through SATFLOW_HIP_LIB, never shipped."""
+    from satflow_amd.build import CSRC, FLAGS, LIBDIR, build_library
+
+    build_library(force=False, verbose=False)
+    src = os.path.join(CSRC, "convgru_seq.hip")
+    objdir = os.path.join(LIBDIR, "obj")
+    deps = [src] + [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h")] + [os.path.join(LIBDIR, "libsatflow_hip.so")]
+    if force or not os.path.exists(HOOKS_LIB) or any(os.path.getmtime(d) > os.path.getmtime(HOOKS_LIB) for d in deps):
+        obj = os.path.join(HERE, "convgru_seq_hooks.o")
+        r = subprocess.run([HIPCC, *FLAGS, "-DSF_TEST_HOOKS", "-c", src, "-o", obj], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"hipcc failed for {src} (-DSF_TEST_HOOKS):\n{r.stdout}{r.stderr}")
+        objs = [os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o") and f != "convgru_seq.o"] + [obj]
+        r = subprocess.run([HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", *objs, "-o", HOOKS_LIB], capture_output=True, text=True)
+        if r.returncode != 0:
+            raise RuntimeError(f"link failed for {HOOKS_LIB}:\n{r.stdout}{r.stderr}")
+    return HOOKS_LIB
+
+
 _lib = None
 
 

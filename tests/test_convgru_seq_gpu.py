@@ -298,8 +298,28 @@ def test_split_kernels_with_most_cus_held_by_another_stream(device, bf16_mode, p
 def test_split_kernel_failed_handoff_is_loud(device, bf16_mode):
     """A boundary row that never arrives (test hook: half 1 never sends; spin bound lowered to milliseconds): the kernel does not
     hang, sets the sticky error word, and every state / gradient of the starved workgroups is NaN - the product path
-    (`check_device_errors`, called by FlatAdam.step) raises."""
+    (`check_device_errors`, called by FlatAdam.step) raises.
+    The hook is NOT in the product library (no process-wide state there, ABI 6): this test re-runs itself in a child process whose
+    SATFLOW_HIP_LIB is tests/native/libsatflow_hip_hooks.so - the product objects with convgru_seq.hip rebuilt with -DSF_TEST_HOOKS."""
+    import ctypes as C
+    import os
+    import subprocess
+    import sys
+
     from satflow_amd._hip import lib
+
+    if not os.environ.get("SF_TEST_HOOKS_CHILD"):
+        from tests import native
+
+        assert not hasattr(lib(), "sf_convgru_seq_debug"), "the product library must not export the test hook"
+        env = dict(os.environ, SATFLOW_HIP_LIB=native.build_hooks(), SF_TEST_HOOKS_CHILD="1")
+        root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+        r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-s", f"{__file__}::test_split_kernel_failed_handoff_is_loud"],
+                           cwd=root, env=env, capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, r.stdout[-4000:] + r.stderr[-2000:]
+        return
+    debug = lib().sf_convgru_seq_debug
+    debug.restype, debug.argtypes = None, [C.c_int32, C.c_int32]
 
     Tn, n, H, W, hid = 6, 8, 16, 16, 64
     pr = _seq_problem(device, Tn, n, H, W, hid)
@@ -307,12 +327,12 @@ def test_split_kernel_failed_handoff_is_loud(device, bf16_mode):
     good = _run_seq(device, pr, Tn, n, H, W)
     torch.cuda.synchronize()
     assert not satflow_amd.device_errors()
-    lib().sf_convgru_seq_debug(2000, 1)
+    debug(2000, 1)
     try:
         bad = _run_seq(device, pr, Tn, n, H, W)
         torch.cuda.synchronize()
     finally:
-        lib().sf_convgru_seq_debug(0, -1)
+        debug(0, -1)
     errs = satflow_amd.device_errors()
     assert len(errs) == 2 and all(k[0].startswith("convgru_seq_") for k in errs), errs
     hs, dgx = bad[0], bad[2]

@@ -6,12 +6,34 @@ if "--json" in sys.argv:
     i = sys.argv.index("--json"); js = sys.argv[i + 1]; del sys.argv[i:i + 2]
 d, top = sys.argv[1], int(sys.argv[2]) if len(sys.argv) > 2 else 25
 tot = collections.defaultdict(lambda: [0, 0.0, 0.0])
+seq = collections.defaultdict(lambda: ([], []))   # per kernel name: the launches' bytes in dispatch order, (reads, writes) - the two passes replay the same program
 for c, scale, col in (("FETCH_SIZE", 2.0, 1), ("WRITE_SIZE", 1.0, 2)):   # FETCH_SIZE counts 32-byte... corrected x2 on gfx950 (MI355X_MICROARCH.md)
-    for r in csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv")):
+    rows = list(csv.DictReader(open(f"{d}/pmc_{c}_counter_collection.csv")))
+    if rows and "Dispatch_Id" in rows[0]:
+        rows.sort(key=lambda r: int(r["Dispatch_Id"]))
+    for r in rows:
         k = r["Kernel_Name"][:110]
-        tot[k][col] += float(r["Counter_Value"]) * 1024 * scale
+        v = float(r["Counter_Value"]) * 1024 * scale
+        tot[k][col] += v
+        seq[k][col - 1].append(v)
         if col == 1:
             tot[k][0] += 1
+
+
+def shape_classes(reads, writes):
+    """A kernel NAME that runs at several shapes in a step (256->256 and 160->256 launches of the same instantiation) reports a mix when averaged by name.
+    The i-th launch of a name is the same launch in both passes; launches are grouped by their WRITE bytes (deterministic per shape, 3 % bins)."""
+    if len(reads) != len(writes) or not writes:
+        return None
+    cls = []
+    for rd, wr in zip(reads, writes):
+        for c in cls:
+            if abs(wr - c["write_bytes"] / c["launches"]) <= 0.03 * max(wr, 1.0):
+                c["launches"] += 1; c["read_bytes"] += rd; c["write_bytes"] += wr
+                break
+        else:
+            cls.append({"launches": 1, "read_bytes": rd, "write_bytes": wr})
+    return [{"launches": c["launches"], "read_bytes": c["read_bytes"] / c["launches"], "write_bytes": c["write_bytes"] / c["launches"]} for c in cls]
 print(f"{'launches':>8} {'read GB/launch':>15} {'write GB/launch':>16}  kernel")
 for k, (n, rd, wr) in sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:top]:
     n = max(n, 1)
@@ -22,5 +44,6 @@ if js:
     from bench import kernel_source_sha
     rec = {"what": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) of a short bench.py run, per-launch means by kernel; FETCH_SIZE x 2 (MI355X_MICROARCH.md)",
            "source": d, "kernel_src_sha": kernel_source_sha(),
-           "kernels": {k: {"launches": n, "read_bytes": rd / max(n, 1), "write_bytes": wr / max(n, 1)} for k, (n, rd, wr) in tot.items() if rd + wr > 50e6 * max(n, 1)}}
+           "kernels": {k: {"launches": n, "read_bytes": rd / max(n, 1), "write_bytes": wr / max(n, 1), "shapes": shape_classes(*seq[k])}
+                       for k, (n, rd, wr) in tot.items() if rd + wr > 50e6 * max(n, 1)}}
     json.dump(rec, open(js, "w"), indent=1)

@@ -11,5 +11,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   tail -1 $OUT/pmc_$C.log
 done
 cd $GRAFT_REPO_ROOT
-python tools/parse_pmc.py gpurun_out/$NAME profiles/${ROUND:-r04}_convlstm_bf16a_pmc_cell.json "conv3x3_bf16_kernel<4, 4, 2, false, true, false, true" | tail -8
-cp profiles/${ROUND:-r04}_convlstm_bf16a_pmc_cell.json gpurun_out/$NAME/
+python tools/parse_pmc.py gpurun_out/$NAME profiles/${ROUND:-r05}_convlstm_bf16a_pmc_cell.json "conv3x3_bf16_kernel<4, 4, 2, false, true, false, true" | tail -8
+cp profiles/${ROUND:-r05}_convlstm_bf16a_pmc_cell.json gpurun_out/$NAME/

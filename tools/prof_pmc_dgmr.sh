@@ -10,5 +10,5 @@ for C in FETCH_SIZE WRITE_SIZE; do
   tail -1 $OUT/pmc_$C.log
 done
 cd $GRAFT_REPO_ROOT
-python tools/parse_pmc.py gpurun_out/$NAME profiles/${ROUND:-r04}_dgmr_bf16_pmc_conv.json "conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false, false>" | tail -8
-cp profiles/${ROUND:-r04}_dgmr_bf16_pmc_conv.json gpurun_out/$NAME/
+python tools/parse_pmc.py gpurun_out/$NAME profiles/${ROUND:-r05}_dgmr_bf16_pmc_conv.json "conv3x3_bf16_kernel<8, 4, 0, false, true, false, false, false, false>" | tail -8
+cp profiles/${ROUND:-r05}_dgmr_bf16_pmc_conv.json gpurun_out/$NAME/

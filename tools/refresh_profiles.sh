@@ -3,7 +3,7 @@
 # Results under gpurun_out/${ROUND}_*; tools/collect_profiles.sh copies the summaries into profiles/.
 set -u
 cd $GRAFT_REPO_ROOT
-R=${ROUND:-r04}
+R=${ROUND:-r05}
 for m in bf16a bf16 f32; do
   bash tools/prof_stats.sh ${R}_metnet_$m --dtype $m --no-cpu-baseline --no-extra > /dev/null 2>&1
   bash tools/prof_stats.sh ${R}_convlstm_$m --workload convlstm --dtype $m --no-cpu-baseline > /dev/null 2>&1

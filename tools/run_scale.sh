@@ -40,3 +40,29 @@ except Exception as e:  # noqa: BLE001
 PY
   done
 done
+# ONE SCALE-shaped record of the whole sweep ($OUT/SCALE.json): per leg N, samples/s, ms/step, exposed communication, efficiency against the N = 1 leg of
+# the same mode (weak: value_N / (N * value_1); strong: the same ratio - a fixed global batch N times faster is 1.0) - what the driver's SCALE_rNN.json
+# holds, so that the first 8-GPU run needs no hand work.
+python - "$OUT" <<'PY'
+import glob, json, os, sys
+out = sys.argv[1]
+rec = {"what": "tools/run_scale.sh: bench.py at N = 1, 2, 4, 8 ranks of one node (RCCL over xGMI)", "legs": {}}
+for mode in ("weak", "strong"):
+    legs = []
+    for f in sorted(glob.glob(os.path.join(out, f"{mode}_n*.json")), key=lambda p: int(p.rsplit("_n", 1)[1][:-5])):
+        try:
+            d = json.loads([l for l in open(f) if l.startswith("{")][-1])
+        except Exception as e:  # noqa: BLE001
+            legs.append({"file": os.path.basename(f), "error": str(e)})
+            continue
+        comm = d.get("comm") or {}
+        legs.append({"n_gpus": d["n_gpus"], "value": d["value"], "unit": d["unit"], "ms_per_step": d["ms_per_step"], "per_gpu_batch": d["config"]["per_gpu_batch"],
+                     "global_batch": d["config"]["global_batch"], "exposed_comm_ms": comm.get("exposed_comm_ms"), "comm": comm or None, "dtype": d["dtype"]})
+    base = next((l for l in legs if l.get("n_gpus") == 1), None)
+    for l in legs:
+        if base and "value" in l:
+            l["efficiency_vs_n1"] = l["value"] / (l["n_gpus"] * base["value"])
+    rec["legs"][mode] = legs
+json.dump(rec, open(os.path.join(out, "SCALE.json"), "w"), indent=1)
+print(json.dumps(rec))
+PY
