@@ -138,6 +138,17 @@ int sf_conv3x3_fold_pack(const float* w, int32_t O, int32_t I, const int32_t* nm
                          float* bias_tab, int32_t dtype, sfStream stream);
 int sf_conv3x3_fwd_folded(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_tab, int32_t Np,
                           int32_t nf, int32_t groups, sfTensor out, float* stats, int32_t dtype, sfStream stream);
+/* (ABI 6) The same folded convolution WITH THE MaxPool2d((2, 2), stride 2) BEHIND IT IN ITS EPILOGUE: the DownSampler's conv4 -> pooling pair
+ * (upstream metnet DownSampler, reached from satflow/models/pl_metnet.py:46-59).  The convolution's own output is never written: `pooled`
+ * [n][h/2][w/2][c] bf16 receives max over each 2x2 window of the bf16-ROUNDED convolution results (= sf_maxpool2_route_fwd of
+ * sf_conv3x3_fwd_folded's output, bit for bit), stored as image perm(i) (perm_l, perm_t as sf_maxpool2_fwd), and `route` [n][h/2][w/2][c/8] uint16
+ * (8-byte aligned) the routing record of sf_maxpool2_route_fwd (2 bits per channel: first maximum in row-major window order), so that
+ * sf_maxpool2_route_bwd is the backward of the pooling.  No dropout here (sf_dropout2_bf16 on `pooled` applies MetNet's two masks).
+ * One-wave-per-SIMD kernel only: even h, w, nf = 4, c a multiple of 64, >= 48 input channels, >= 1024 tiles -
+ * sf_conv3x3_fwd_folded_pool_supported says whether a shape is taken (1) or the two separate calls must be used (0). */
+int32_t sf_conv3x3_fwd_folded_pool_supported(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t cin, int32_t cout, int32_t groups);
+int sf_conv3x3_fwd_folded_pool(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_tab, int32_t Np, int32_t nf,
+                               int32_t groups, sfTensor pooled, int32_t perm_l, int32_t perm_t, void* route, int32_t dtype, sfStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Fused ConvLSTM cell step.  Replaces ConvLSTMCell.forward,
@@ -456,6 +467,8 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
  * channel quad: the backward calls the same function on the gradient with the same seeds. */
 int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
                 float* y, sfStream stream);
+/* (ABI 6) The same masks on a bf16-stored tensor (x == y allowed; n a multiple of 8): the pooled encoder output of sf_conv3x3_fwd_folded_pool. */
+int sf_dropout2_bf16(const void* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* y, sfStream stream);
 
 /* =============================================================================================
  * CloudGAN around the ConvLSTM generator: the PatchGAN discriminator's convolutions and the GAN / L1 losses.

@@ -38,6 +38,8 @@ PROTOTYPES = {
     "sf_conv3x3_fwd_stats": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, sfTensor, _vp, _i32, _vp]),
     "sf_conv3x3_fold_pack": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _vp, _vp, _vp, _i32, _vp, _vp, _i32, _vp]),
     "sf_conv3x3_fwd_folded": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _vp, _i32, _vp]),
+    "sf_conv3x3_fwd_folded_pool_supported": (_i32, [_i32] * 8),
+    "sf_conv3x3_fwd_folded_pool": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _i32, _i32, _vp, _i32, _vp]),
     "sf_convlstm_cell_fwd": (
         C.c_int,
         [sfTensor, sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, sfTensor, sfTensor, sfTensor, _i32, _vp],
@@ -109,6 +111,7 @@ PROTOTYPES = {
     "sf_axial_attention_core_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_mse_loss": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sf_dropout2": (C.c_int, [_vp, _i64, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "sf_dropout2_bf16": (C.c_int, [_vp, _i64, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp, _vp]),
     "sf_conv2d_fwd": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, sfTensor, _i32, _vp]),
     "sf_conv2d_bwd_data": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_conv2d_bwd_weight_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),

@@ -24,6 +24,13 @@
 // Three instantiations: MODE 0 as above; MODE 1 adds the BatchNorm statistics of the stored values (per-tile sums, reduce-scatter over the half-waves,
 // partials through each wave's free private input stage); MODE 2 is the input gradient with the BatchNorm BACKWARD in the epilogue
 // (out = A * acc + B * x + K: x read in the store's 64-byte runs with hand-counted waits, coefficients in the bias table's LDS slot).
+// MODE 3 (round 5) is conv4 of the MetNet encoder WITH THE 2x2 MAX-POOLING BEHIND IT IN THE EPILOGUE (sf_conv3x3_fwd_folded_pool).  The lane <-> pixel
+// map of the MFMA's pixel operand is WINDOW-MAJOR there: lane r of fragment mf = 2 dy + dx holds pixel (2 wy + dy, 2 wx + dx) of the wave's 8 x 16 band
+// (wy = r >> 3, wx = r & 7), so the four pixels of a pooling window are four REGISTERS of one lane: the maximum and the 2-bit routing code
+// (sf_maxpool2_route_fwd's: first maximum of the STORED bf16 values in row-major order) are in-lane arithmetic, no value changes lanes, and an item
+// stores 8 + 2 instead of 32 KiB-sized pieces per wave.  The same map shares pixel fragments between taps twice over - fragment (dy, dx) of tap
+// (ky, kx) is rows 2 wy + dy + ky, columns 2 wx + dx + kx: 16 distinct fragments per chunk instead of 27 - with the private halo rows stored
+// even columns first, odd columns second (the DMA's lane-linear LDS order is free: a fragment then reads 8 consecutive 32-byte pixels per window row).
 // (The item switch is: epilogue of item k - 32 stores per wave -, accumulators of item k + 1 from the LDS table, first tap; deferring half of the stores
 // under the next item's K loop was built and measured: no gain, see the note in front of `epilogue`.)
 #include <cstdlib>
@@ -121,13 +128,17 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     int valid, n, grp, nb, x0, y0;
     unsigned in_mask;  // per lane: bit j = input piece j of this lane lies inside the image
   };
+  // LDS slot of a private halo row -> halo column.  MODE 3 stores a row's even columns first, then its odd columns (window-major fragments read 8
+  // consecutive pixels per window row), and swizzles the 16-byte halves by the parity of the window row instead of the pixel row.
+  auto slot_col = [](int s) __attribute__((always_inline)) { return MODE == 3 ? (s < 9 ? 2 * s : 2 * (s - 9) + 1) : s; };
+  auto half_flip = [](int iy) __attribute__((always_inline)) { return MODE == 3 ? (iy >> 1) & 1 : iy & 1; };
   // per-lane byte offsets of the six input pieces relative to the wave's halo origin (the same for every item; validity is the item's mask)
   unsigned in_base_off[NPJ];
 #pragma unroll
   for (int j = 0; j < NPJ; ++j) {
     const int pc = lane + j * 64, pix = pc >> 1;
-    const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
-    const int half = (pc & 1) ^ (iy & 1);  // the DMA writes lane-linearly: physical half pc & 1 holds the logical half (bank swizzle)
+    const int iy = pix / HALO_W, ix = slot_col(pix - iy * HALO_W);
+    const int half = (pc & 1) ^ half_flip(iy);  // the DMA writes lane-linearly: physical half pc & 1 holds the logical half (bank swizzle)
     in_base_off[j] = (unsigned)(((iy * p.W + ix) * p.s0 + 8 * half) * 2);
   }
   auto setup = [&](int k, Item& it) __attribute__((always_inline)) {
@@ -147,7 +158,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 #pragma unroll
     for (int j = 0; j < NPJ; ++j) {
       const int pc = l + j * 64, pix = pc >> 1;
-      const int iy = pix / HALO_W, ix = pix - iy * HALO_W;
+      const int iy = pix / HALO_W, ix = slot_col(pix - iy * HALO_W);
       const int gy = it.y0 + 8 * wave + iy - 1, gx = it.x0 + ix - 1;
       const bool ok = pc < PPIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       m |= ok ? 1u << j : 0u;
@@ -218,10 +229,30 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   constexpr bool REUSE = true;
 #endif
   bf16x8 fa[3][MFR], fb[3][NF], keep[3][MFR - 1];
+  // MODE 3, window-major pixel fragments: F[a][b] = pixels (2 wy + a, 2 wx + b) of the halo, a, b = 0 .. 3; fragment mf = 2 dy + dx of tap (ky, kx) is
+  // F[dy + ky][dx + kx].  F[a][b] is first needed at tap 3 max(a - 1, 0) + max(b - 1, 0) and last at tap 3 min(a, 2) + min(b, 2): one set of 16 serves
+  // the whole chunk loop - a fragment is re-read (for the next chunk) one tap before its first use, always after its last use in this chunk.
+  bf16x8 F[4][4];
+  const int wwy = r >> 3, wwx = r & 7;
+  const int p_lane = (2 * wwy * HALO_W + wwx) * PIX_B;
+  const int p_half0 = 16 * (kh ^ (wwy & 1)), p_half1 = 16 * (kh ^ (wwy & 1) ^ 1);   // by the parity of the halo's window row (2 wy + a) >> 1 = wy + (a >> 1)
+  auto pool_first_use = [](int a, int b) { return 3 * (a > 1 ? a - 1 : 0) + (b > 1 ? b - 1 : 0); };
   auto load_tap = [&](int sw, int si, int tap) __attribute__((always_inline)) {  // operands of `tap` into set tap % 3 (and keep[kx])
     const int ky = tap / 3, kx = tap % 3, set = tap % 3;
     const char* inb = lds + IN0 + (wave * 2 + si) * PIN_B + a_lane;
     const char* wb = lds + sw * W_B + b_lane;
+    if constexpr (MODE == 3) {
+      const char* pb = lds + IN0 + (wave * 2 + si) * PIN_B + p_lane;
+#pragma unroll
+      for (int a = 0; a < 4; ++a)
+#pragma unroll
+        for (int b = 0; b < 4; ++b)
+          if (pool_first_use(a, b) == tap)
+            F[a][b] = *reinterpret_cast<const bf16x8*>(pb + (a * HALO_W + (b & 1) * 9 + (b >> 1)) * PIX_B + ((a >> 1) ? p_half1 : p_half0));
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) fb[set][nf] = *reinterpret_cast<const bf16x8*>(wb + (tap * NB + nf * 32) * PIX_B);
+      return;
+    }
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
       if (REUSE && ky == 2 && mf + 1 < MFR) continue;  // in keep[kx][mf] since tap kx
@@ -233,11 +264,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   };
   auto frag_a = [&](int tap, int mf) __attribute__((always_inline)) -> const bf16x8& {
     const int ky = tap / 3, kx = tap % 3;
+    if constexpr (MODE == 3) return F[(mf >> 1) + ky][(mf & 1) + kx];
     if (REUSE && ky == 0 && mf >= 1) return keep[kx][mf - 1];
     if (REUSE && ky == 2 && mf + 1 < MFR) return keep[kx][mf];
     return fa[tap % 3][mf];
   };
-  auto tap_reads = [](int tap) { return NF + ((REUSE && tap / 3 == 2) ? 1 : MFR); };
+  auto tap_reads = [](int tap) {
+    if (MODE == 3) return NF + (tap == 0 ? 4 : (tap == 4 || tap == 5 || tap == 7 || tap == 8) ? 1 : 2);
+    return NF + ((REUSE && tap / 3 == 2) ? 1 : MFR);
+  };
 
   // ---- epilogue of one fragment: 32 channels x 32 pixels -> two 16-byte stores per lane (always issued) ----
   // A lane pair (r, kh = 0 / 1) holds 2 x 16 bytes of its pixel per octet: stored as they are, an instruction writes 32-byte runs 512 bytes apart, and the
@@ -324,7 +359,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     }
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
-      const int cls = border_cls(it.y0 + 8 * wave + 2 * mf + (r >> 4), it.x0 + (r & 15), p.H, p.W);
+      const int cls = MODE == 3 ? border_cls(it.y0 + 8 * wave + 2 * wwy + (mf >> 1), it.x0 + 2 * wwx + (mf & 1), p.H, p.W)
+                                : border_cls(it.y0 + 8 * wave + 2 * mf + (r >> 4), it.x0 + (r & 15), p.H, p.W);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
         const char* t = lds + TAB0 + cls * (NB * 4) + (nf * 32 + 4 * kh) * 4;
@@ -488,6 +524,85 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       }
       return;
     }
+    if constexpr (MODE == 3) {
+      // ---- 2x2 max-pooling in the epilogue (sf_conv3x3_fwd_folded_pool): the four fragments of a channel block are the four pixels of this lane's
+      // window.  Values are rounded to bf16 FIRST (the unfused path pools the stored tensor: ties between values that differ only below bf16
+      // precision must go to the first window element), the maximum is taken as fmax(fmax(v0, v1), fmax(v2, v3)) like maxpool_fwd_kernel, the code is
+      // the first maximum in row-major order: c01 = v1 > v0, c23 = v3 > v2, bottom = max23 > max01, code = bottom ? 2 + c23 : c01.
+      // Stores: per channel block two 16-byte pieces per lane exactly as the plain epilogue's (quads paired over the half-waves, then rows of 16
+      // lanes exchanged so that a register holds 64-byte runs) - a register then belongs to window rows wy = 0, 1 (r0) or 2, 3 (r1) - and the routing
+      // words: a lane holds one byte of each of the block's four 16-bit words, the half-wave partner the other; 8 + 2 stores per wave, always issued.
+      const int Ho = p.H >> 1, Wo = p.W >> 1;
+      long long n_out = it.n;
+      if (p.pool_L > 0) { const long long b = it.n % p.pool_B, t = (it.n / p.pool_B) % p.pool_T, l = it.n / ((long long)p.pool_B * p.pool_T); n_out = (t * p.pool_L + l) * p.pool_B + b; }
+      const int pool_bytes = __builtin_amdgcn_readfirstlane(Ho * Wo * p.pool_s * 2);
+      const int q8 = p.out_c >> 3;   // routing words per pooled pixel
+      const __amdgpu_buffer_rsrc_t rs_pool = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.pool_out + (size_t)n_out * Ho * Wo * p.pool_s * 2), 0, pool_bytes, 0x00020000);
+      const __amdgpu_buffer_rsrc_t rs_route = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.pool_route + (size_t)it.n * Ho * Wo * q8 * 2), 0,
+                                                                                __builtin_amdgcn_readfirstlane(Ho * Wo * q8 * 2), 0x00020000);
+      unsigned pv[2];
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {   // register j of the store path: window rows 2 j + ((lane >> 3) & 1), window column lane & 7, piece as in the plain epilogue
+        const int pyo = (it.y0 >> 1) + 4 * wave + 2 * j + ((lane >> 3) & 1), pxo = (it.x0 >> 1) + (lane & 7);
+        pv[j] = (pyo < Ho && pxo < Wo) ? (unsigned)(((pyo * Wo + pxo) * p.pool_s + it.nb * NB + 8 * piece) * 2) : DMA_SENT;
+      }
+      const int ryo = (it.y0 >> 1) + 4 * wave + wwy, rxo = (it.x0 >> 1) + wwx;   // this lane's own window
+      const unsigned rv_off = (ryo < Ho && rxo < Wo) ? (unsigned)(((ryo * Wo + rxo) * q8 + it.nb * (NB / 8)) * 2 + 8 * kh) : DMA_SENT;
+      unsigned rd[NF][2];
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf) {
+        unsigned P[8], Wc = 0;
+#pragma unroll
+        for (int jj = 7; jj >= 0; --jj) {   // channel pairs (i = 2 jj, 2 jj + 1 of the lane's 16), high to low: the code word is shifted in
+          float rv[4][2];
+#pragma unroll
+          for (int mf = 0; mf < MFR; ++mf) {
+            const unsigned pk = pk2(acc_read(acc[mf][nf][2 * jj]), acc_read(acc[mf][nf][2 * jj + 1]));
+            rv[mf][0] = __builtin_bit_cast(float, pk << 16); rv[mf][1] = __builtin_bit_cast(float, pk & 0xffff0000u);
+          }
+          float mx[2];
+#pragma unroll
+          for (int e = 1; e >= 0; --e) {
+            const float m01 = fmaxf(rv[0][e], rv[1][e]), m23 = fmaxf(rv[2][e], rv[3][e]);
+            const bool c01 = rv[1][e] > rv[0][e], c23 = rv[3][e] > rv[2][e], bot = m23 > m01;
+            mx[e] = fmaxf(m01, m23);
+            Wc = (Wc << 2) | (bot ? 2u : 0u) | ((bot ? c23 : c01) ? 1u : 0u);
+          }
+          P[jj] = (__builtin_bit_cast(unsigned, mx[0]) >> 16) | (__builtin_bit_cast(unsigned, mx[1]) & 0xffff0000u);
+        }
+        // pooled values: quads -> octets over the half-waves, rows of 16 lanes -> 64-byte runs (as epi_frag)
+        u32x4_t oc[2];
+#pragma unroll
+        for (int g = 0; g < 4; g += 2) {
+          const auto sx = __builtin_amdgcn_permlane32_swap(P[2 * g], P[2 * g + 2], false, false);
+          const auto sy = __builtin_amdgcn_permlane32_swap(P[2 * g + 1], P[2 * g + 3], false, false);
+          oc[g >> 1] = u32x4_t{sx[0], sy[0], sx[1], sy[1]};
+        }
+        u32x4_t r0, r1;
+#pragma unroll
+        for (int d = 0; d < 4; ++d) {
+          const auto sw16 = __builtin_amdgcn_permlane16_swap(oc[0][d], oc[1][d], false, false);
+          r0[d] = sw16[0]; r1[d] = sw16[1];
+        }
+        const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
+        __builtin_amdgcn_raw_buffer_store_b128(r0, rs_pool, pv[0], soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(r1, rs_pool, pv[1], soff, 0);
+        // routing words of this block's four octets: word g = byte g of the kh = 0 lane | byte g of the kh = 1 lane << 8
+        const auto wsw = __builtin_amdgcn_permlane32_swap(Wc, Wc, false, false);   // [0]: the kh = 0 lane's word, [1]: the kh = 1 lane's (in both lanes)
+        rd[nf][0] = __builtin_amdgcn_perm(wsw[1], wsw[0], 0x05010400u);
+        rd[nf][1] = __builtin_amdgcn_perm(wsw[1], wsw[0], 0x07030602u);
+        __builtin_amdgcn_sched_barrier(0);  // (one channel block's temporaries at a time)
+      }
+      // 8 bytes of routing per channel block: blocks 0, 2 leave from the kh = 0 lane, blocks 1, 3 from the kh = 1 lane (its offset carries + 8)
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+        const u32x2_t v = kh ? u32x2_t{rd[2 * q + 1][0], rd[2 * q + 1][1]} : u32x2_t{rd[2 * q][0], rd[2 * q][1]};
+        const unsigned soff = it.nb * NB + q * 64 < p.out_c ? (unsigned)(q * 16) : 0x40000000u;
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs_route, rv_off, soff, 0);
+      }
+      return;
+    }
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
       const unsigned voff0 = out_voff(it, mf, 0), voff1 = out_voff(it, mf, 1);
@@ -598,7 +713,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           // (chunk g - 1) is free behind the barrier
 #ifndef SF_EXP_W4_NOSYNC
           // (MODE 2: 32 loads + 32 stores + 6 pieces are younger - the counter's field ends at 63; the seven oldest of them are long complete)
-          if (first) { if constexpr (MODE == 1) SF_VMCNT(39); else if constexpr (MODE == 2) SF_VMCNT(63); else SF_VMCNT(38); } else SF_VMCNT(6);
+          if (first) { if constexpr (MODE == 1) SF_VMCNT(39); else if constexpr (MODE == 2) SF_VMCNT(63); else if constexpr (MODE == 3) SF_VMCNT(16); else SF_VMCNT(38); } else SF_VMCNT(6);   // (MODE 3: 8 + 2 stores + 6 pieces)
           __builtin_amdgcn_s_barrier();
 #endif
           __builtin_amdgcn_sched_barrier(0);
@@ -637,6 +752,9 @@ bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf) {
   static const bool no_stats = getenv("SF_NO_CONV_W4_STATS") != nullptr;  // A/B switch: statistics on the 8-wave persistent kernel
   static const bool no_bnb = getenv("SF_NO_CONV_W4_BNB") != nullptr;      // A/B switch: the BatchNorm-backward epilogue on the 8-wave one-item kernel
   if (off || nf != 4 || (p.stats && no_stats) || p.bias || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
+  // pooled epilogue: whole windows per tile (even H, W), no statistics / BatchNorm backward, routing words of whole 64-channel pairs
+  if (p.pool_out && (p.stats || p.bnb_coef || (p.H & 1) || (p.W & 1) || p.out_c % 64 || !p.pool_route || p.pool_s % 8 ||
+                     (long long)(p.H / 2) * (p.W / 2) * p.pool_s * 2 >= 0x7fffffffll)) return false;
   // BatchNorm-backward epilogue: x is read at the output's own offsets
   if (p.bnb_coef && (no_bnb || p.stats || p.bias_tab || p.wgroup || p.bnb_xs != p.out_s || p.bnb_c < p.out_c || p.bnb_group < 1)) return false;
   if ((long long)p.H * p.W * p.out_s * 2 >= 0x7fffffffll || (long long)p.H * p.W * p.s0 * 2 >= 0x7fffffffll) return false;
@@ -656,7 +774,8 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int grid = items < cus ? items : cus;
-  if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  if (p.pool_out) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<3>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  else if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else if (p.stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   hipError_t e = hipGetLastError();

@@ -465,6 +465,47 @@ int sf_conv3x3_fwd_folded(sfTensor src, int32_t n, int32_t h, int32_t w, const v
   return conv3x3_fwd_impl(src, none, n, h, w, wpacked, bias_tab, Np, nf, SF_EPI_LINEAR, out, stats, dtype, stream, groups);
 }
 
+// conv3x3 (folded BatchNorm in front) + MaxPool2d(2) in one launch: the one-wave-per-SIMD kernel with the pooling in its epilogue
+// (conv3x3_bf16_persist4.hip, MODE 3).  The convolution's own output is never written.
+static void pool_params(ConvParams& p, sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_tab, int32_t Np, int32_t groups,
+                        sfTensor pooled, int32_t perm_l, int32_t perm_t, void* route) {
+  p.src0 = (const float*)src.ptr; p.c0 = src.c; p.s0 = src.stride; p.bf0 = src.dtype == SF_BF16;
+  p.idiv0 = src.idiv > 0 ? src.idiv : 1; p.imod0 = src.imod; p.idiv1 = 1;
+  p.N = n; p.H = h; p.W = w;
+  p.wp = wpacked; p.chunks_total = src.c / KC;
+  p.out = nullptr; p.out_c = pooled.c; p.out_s = pooled.stride; p.out_bf = 1;   // (out_c / out_s describe the channel lanes; nothing is stored through `out`)
+  p.bias_tab = bias_tab; p.np = Np; p.stats_np = Np;
+  p.wgroup = n / groups; p.wgroup_bytes = (long long)Np * src.c * 9 * 2;
+  p.pool_out = pooled.ptr; p.pool_s = pooled.stride; p.pool_route = (unsigned short*)route;
+  p.pool_L = perm_l > 0 ? perm_l : 0; p.pool_T = perm_l > 0 ? perm_t : 0; p.pool_B = perm_l > 0 && perm_t > 0 ? n / (perm_l * perm_t) : 0;
+}
+
+int32_t sf_conv3x3_fwd_folded_pool_supported(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t cin, int32_t cout, int32_t groups) {
+  if (n <= 0 || groups < 1 || n % groups || h < 2 || w < 2 || cin % KC || nf != 4 || Np % 128 || cout % 64 || cout > Np) return 0;
+  ConvParams p{};
+  sfTensor src{(void*)16, cin, cin, 0, 0, SF_BF16}, pooled{(void*)16, cout, cout, 0, 0, SF_BF16};
+  pool_params(p, src, n, h, w, (const void*)16, (const float*)16, Np, groups, pooled, 0, 0, (void*)16);
+  return sf_conv_bf16_persist_ok(p, EPI_LINEAR, nf) && sf_conv_bf16_persist4_ok(p, nf) ? 1 : 0;
+}
+
+int sf_conv3x3_fwd_folded_pool(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_tab, int32_t Np, int32_t nf,
+                               int32_t groups, sfTensor pooled, int32_t perm_l, int32_t perm_t, void* route, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_fwd_folded_pool: dtype %d not built (SF_BF16 kernels only)", dtype);
+  if (check_src(src, "conv3x3 folded+pool src")) return 1;
+  SF_REQUIRE(src.ptr && src.dtype == SF_BF16 && src.idiv <= 1 && src.imod <= 0, "fwd_folded_pool: one bf16-stored source without image remap");
+  SF_REQUIRE(pooled.ptr && pooled.dtype == SF_BF16 && ((uintptr_t)pooled.ptr & 15) == 0 && pooled.stride % 8 == 0 && pooled.c <= Np,
+             "fwd_folded_pool: bf16-stored pooled tensor with 16-byte aligned pixels, at most Np = %d channels", Np);
+  SF_REQUIRE(route && ((uintptr_t)route & 7) == 0, "fwd_folded_pool: route null / not 8-byte aligned");
+  SF_REQUIRE(bias_tab && ((uintptr_t)bias_tab & 15) == 0, "fwd_folded_pool: bias_tab null / not 16-byte aligned");
+  SF_REQUIRE(perm_l <= 0 || (perm_t > 0 && n % (perm_l * perm_t) == 0), "fwd_folded_pool: n=%d not divisible by perm dims %d x %d", n, perm_l, perm_t);
+  SF_REQUIRE(sf_conv3x3_fwd_folded_pool_supported(n, h, w, Np, nf, src.c, pooled.c, groups),
+             "fwd_folded_pool: shape not taken by the pooled-epilogue kernel (n=%d h=%d w=%d Np=%d nf=%d cin=%d cout=%d groups=%d): ask "
+             "sf_conv3x3_fwd_folded_pool_supported first and run sf_conv3x3_fwd_folded + sf_maxpool2_route_fwd otherwise", n, h, w, Np, nf, src.c, pooled.c, groups);
+  ConvParams p{};
+  pool_params(p, src, n, h, w, wpacked, bias_tab, Np, groups, pooled, perm_l, perm_t, route);
+  return sf_launch_conv_bf16_persist4(p, Np / 128, (hipStream_t)stream);
+}
+
 int sf_conv3x3_bwd_data_bn(sfTensor dout, int32_t n, int32_t h, int32_t w, const void* wpacked, int32_t Np, int32_t nf, sfTensor x,
                            const float* coef, int32_t groups, sfTensor dx, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_BF16, "sf_conv3x3_bwd_data_bn: dtype %d not built (SF_BF16 kernels only)", dtype);

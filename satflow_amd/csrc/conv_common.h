@@ -52,6 +52,12 @@ struct ConvParams {
   // (y + 2 (s >> 1) - 1, x + 2 (s & 1) - 1), zero outside the image: a 5x5 'same' convolution as ONE 3x3 convolution without the padded,
   // four-times-copied input of sf_pad_shift_stack4_fwd (sf_conv5x5_fwd).  c0 = the virtual channel count of this launch / slice; 0 = off.
   int shift4, chunk0;
+  // one-wave-per-SIMD bf16 kernel (conv3x3_bf16_persist4.hip, MODE 3): the 2x2 / stride-2 max-pooling behind this convolution taken in the epilogue
+  // (sf_conv3x3_fwd_folded_pool): `out` is NOT written; pool_out = the pooled tensor (bf16, [n][H/2][W/2][pool_s]), image i stored as image
+  // perm(i) (pool_L > 0: (l * pool_T + t) * pool_B + b  ->  (t * pool_L + l) * pool_B + b, as sf_maxpool2_fwd); pool_route = sf_maxpool2_route_fwd's
+  // routing record (one 16-bit word per pooled pixel and channel octet of the out_c channels, 2 bits per channel: first maximum in row-major order)
+  void* pool_out; int pool_s, pool_L, pool_T, pool_B;
+  unsigned short* pool_route;
 };
 
 // border class of an output pixel (needs H, W >= 2); pixels outside the image (ragged tiles) get some valid class

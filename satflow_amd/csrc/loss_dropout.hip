@@ -79,6 +79,19 @@ __global__ __launch_bounds__(256) void dropout2_kernel(const float* __restrict__
   }
 }
 
+// the same masks on a bf16-stored tensor, 8 elements (two mask groups) per thread, in place or not: the pooled encoder output behind
+// sf_conv3x3_fwd_folded_pool (the pooling epilogue does not hash: ~100 cycles per mask group on a wave that is alone on its SIMD)
+__global__ __launch_bounds__(256) void dropout2_bf16_kernel(const __bf16* __restrict__ x, long long n, const sfDrop d, long long period, __bf16* __restrict__ y) {
+  const long long n8 = n >> 3, per4 = period >> 2;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (long long)gridDim.x * blockDim.x) {
+    const unsigned long long g = 2ull * (unsigned long long)i;
+    const f32x4 a = sf_drop_scales(d, g, d.p2 > 0.f ? g % per4 : 0), b = sf_drop_scales(d, g + 1, d.p2 > 0.f ? (g + 1) % per4 : 0);
+    f32x8_t v = ldv8(x + i * 8);
+    v = v * f32x8_t{a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
+    stv8(y + i * 8, v);
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -113,6 +126,18 @@ int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, u
   hipLaunchKernelGGL(dropout2_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, (long long)n, sf_make_drop(p1, p2, seed1, seed2),
                      (long long)period, y);
   SF_CHECK_LAUNCH("dropout2");
+  return 0;
+}
+
+int sf_dropout2_bf16(const void* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* y, sfStream stream) {
+  SF_REQUIRE(n % 8 == 0 && ((((uintptr_t)x) | ((uintptr_t)y)) & 15) == 0 && p1 >= 0.f && p1 < 1.f && p2 >= 0.f && p2 < 1.f && period > 0 &&
+                 period % 4 == 0, "dropout2_bf16: n=%lld p1=%f p2=%f period=%lld (n a multiple of 8, period of 4)", (long long)n, p1, p2, (long long)period);
+  if (n == 0) return 0;
+  const long long n8 = n >> 3;
+  const int blocks = (int)((n8 + 255) / 256 < 16384 ? (n8 + 255) / 256 : 16384);
+  hipLaunchKernelGGL(dropout2_bf16_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, (const __bf16*)x, (long long)n, sf_make_drop(p1, p2, seed1, seed2),
+                     (long long)period, (__bf16*)y);
+  SF_CHECK_LAUNCH("dropout2_bf16");
   return 0;
 }
 

@@ -433,7 +433,11 @@ class _BNConvFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, eng: ConvEngine, x: Tensor, gamma: Tensor, beta: Tensor, running_mean: Optional[Tensor], running_var: Optional[Tensor],
-                groups: int, eps: float, momentum: float, in_stats, weight: Tensor, bias: Optional[Tensor], out_dtype, out_stats: Optional[Tensor]):
+                groups: int, eps: float, momentum: float, in_stats, weight: Tensor, bias: Optional[Tensor], out_dtype, out_stats: Optional[Tensor],
+                pool=None):
+        """``pool = (perm, drop)``: the 2x2 max-pooling behind the convolution (and MetNet's two dropouts, ``drop = (p1, p2, period, seed1, seed2)`` or
+        None) taken in the convolution's epilogue - the result is the POOLED tensor, the backward pass first routes its gradient back
+        (``batchnorm_conv3x3_maxpool`` checks that the launch qualifies)."""
         n, H, W, C = x.shape
         creal = gamma.shape[0]
         pixels = n * H * W
@@ -455,17 +459,30 @@ class _BNConvFn(torch.autograd.Function):
                                                      in_stats.np, NULL, SF_F32, stream_ptr()), "sf_batchnorm_train_fwd_stats")
         w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
         packed, tab = K.conv3x3_fold_pack(w4, bias, gm, stats[2], stats[3])
-        y = torch.empty(n, H, W, eng.coutp, dtype=out_dtype or torch.bfloat16, device=dev)
-        K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), out_stats)
         ctx.eng, ctx.groups, ctx.creal, ctx.has_bias = eng, groups, creal, bias is not None
         ctx.bias = bias
+        ctx.pool = pool
+        if pool is not None:
+            assert out_stats is None
+            y, route = K.conv3x3_folded_pool(T(x), n, H, W, packed, tab, gm, eng.coutp, pool[0], pool[1], dev)
+            ctx.save_for_backward(x, gamma, stats, weight, route)
+            return y
+        y = torch.empty(n, H, W, eng.coutp, dtype=out_dtype or torch.bfloat16, device=dev)
+        K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), out_stats)
         ctx.save_for_backward(x, gamma, stats, weight)
         return y
 
     @staticmethod
     def backward(ctx, gy: Tensor):
         eng: ConvEngine = ctx.eng
-        x, gamma, stats, weight = ctx.saved_tensors
+        if ctx.pool is not None:   # the gradient of the POOLED tensor: dropout masks + routing first (sf_maxpool2_route_bwd reads the recorded codes)
+            x, gamma, stats, weight, route = ctx.saved_tensors
+            gy = gy.contiguous()
+            if gy.dtype != torch.bfloat16:
+                gy = gy.to(torch.bfloat16)
+            gy = K.maxpool2_route_bwd(route, gy, (x.shape[0], x.shape[1], x.shape[2], eng.coutp), torch.bfloat16, ctx.pool[0], ctx.pool[1])
+        else:
+            x, gamma, stats, weight = ctx.saved_tensors
         n, H, W, C = x.shape
         groups = ctx.groups
         gy = gy.contiguous()
@@ -497,7 +514,7 @@ class _BNConvFn(torch.autograd.Function):
                                                     stats[1].data_ptr(), coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32, stream_ptr()),
                   "sf_batchnorm_train_bwd_coef")
             K.conv3x3_bwd_data_bn(T(gy), n, H, W, packed_t, gm, T(x), coef, T(dx))
-        return None, dx, dgamma, dbeta, None, None, None, None, None, None, dw4.reshape(weight.shape), db, None, None
+        return None, dx, dgamma, dbeta, None, None, None, None, None, None, dw4.reshape(weight.shape), db, None, None, None
 
 
 def bn_fold_enabled() -> bool:
@@ -524,6 +541,32 @@ def batchnorm_conv3x3(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, in_stats
     y = _BNConvFn.apply(eng, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups, bn.eps, momentum if momentum is not None else 0.0,
                         in_stats, weight, bias, out_dtype, st.data if st is not None else None)
     return y, st
+
+
+def batchnorm_conv3x3_maxpool(x: Tensor, bn: torch.nn.BatchNorm2d, groups: int, in_stats: Optional["ConvStats"], eng: ConvEngine, weight: Tensor,
+                              bias: Optional[Tensor], perm: Optional[Tuple[int, int]] = None, out_dtype=None,
+                              dropout: Optional[Tuple[float, float, int]] = None) -> Tensor:
+    """Training-mode ``dropout2(maxpool2(conv3x3(bn(x))))`` (the DownSampler's conv4 -> pooling pair with MetNet's two dropouts behind it): ONE
+    convolution launch with the pooling in its epilogue when the folded one-wave-per-SIMD kernel takes the shape (bf16-stored x and result),
+    otherwise ``batchnorm_conv3x3`` + ``maxpool2``.  Same values either way: the maximum of the bf16-rounded convolution results, the same routing
+    record for the backward pass, the same dropout masks."""
+    n, H, W, _ = x.shape
+    fused = (x.dtype == torch.bfloat16 and (out_dtype or x.dtype) == torch.bfloat16 and bn_fold_enabled() and torch.is_grad_enabled()
+             and K.conv3x3_fold_supported(n, H, W, eng.fwd_map, groups, False)
+             and K.conv3x3_folded_pool_supported(n, H, W, eng.fwd_map, eng.coutp, groups))
+    if not fused:
+        y, _ = batchnorm_conv3x3(x, bn, groups, in_stats, eng, weight, bias, out_dtype=x.dtype)
+        return maxpool2(y, perm, out_dtype=out_dtype, dropout=dropout)
+    momentum = bn.momentum
+    if bn.track_running_stats and bn.num_batches_tracked is not None:
+        if momentum is None:
+            momentum = -(float(bn.num_batches_tracked) + 1.0)
+        bn.num_batches_tracked += groups
+    drop = None
+    if dropout is not None and (dropout[0] > 0 or dropout[1] > 0):
+        drop = (float(dropout[0]), float(dropout[1]), int(dropout[2]), *_draw_seeds())
+    return _BNConvFn.apply(eng, x, bn.weight, bn.bias, bn.running_mean, bn.running_var, groups, bn.eps, momentum if momentum is not None else 0.0,
+                           in_stats, weight, bias, torch.bfloat16, None, (perm, drop))
 
 
 class _BatchNormEvalFn(torch.autograd.Function):

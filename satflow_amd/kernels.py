@@ -252,6 +252,27 @@ def conv3x3_folded(src: sfTensor, n: int, h: int, w: int, packed: Tensor, tab: T
                                       stats.data_ptr() if stats is not None else None, _hip.SF_BF16, stream_ptr()), "sf_conv3x3_fwd_folded")
 
 
+def conv3x3_folded_pool_supported(n: int, h: int, w: int, gm: GemmMap, cout_lanes: int, groups: int) -> bool:
+    """Does the pooled-epilogue kernel take this shape (sf_conv3x3_fwd_folded_pool_supported; SF_NO_POOL_FUSE=1: A/B switch)?"""
+    return (not os.environ.get("SF_NO_POOL_FUSE")
+            and bool(lib().sf_conv3x3_fwd_folded_pool_supported(n, h, w, gm.Np, gm.nf, gm.Kp, cout_lanes, groups)))
+
+
+def conv3x3_folded_pool(src: sfTensor, n: int, h: int, w: int, packed: Tensor, tab: Tensor, gm: GemmMap, cout_lanes: int,
+                        perm: Optional[Tuple[int, int]], drop, device) -> Tuple[Tensor, Tensor]:
+    """Folded convolution + 2x2 max-pooling in ONE launch (sf_conv3x3_fwd_folded_pool) -> (pooled bf16 [n,h/2,w/2,c] in the permuted image order,
+    routing record for ``maxpool2_route_bwd``).  ``drop = (p1, p2, period, seed1, seed2)``: the two dropout masks of ``maxpool2_route_fwd`` applied to the
+    pooled tensor in place (sf_dropout2_bf16: same masks, same rounding - one multiplication in fp32, one rounding to bf16)."""
+    y = torch.empty(n, h // 2, w // 2, cout_lanes, dtype=torch.bfloat16, device=device)
+    route = torch.empty(n, h // 2, w // 2, cout_lanes // 8, dtype=torch.int16, device=device)
+    pl, pt = perm or (0, 0)
+    check(lib().sf_conv3x3_fwd_folded_pool(src, n, h, w, packed.data_ptr(), tab.data_ptr(), gm.Np, gm.nf, tab.shape[0], T(y), pl, pt, route.data_ptr(),
+                                           _hip.SF_BF16, stream_ptr()), "sf_conv3x3_fwd_folded_pool")
+    if drop is not None and (drop[0] > 0 or drop[1] > 0):
+        check(lib().sf_dropout2_bf16(y.data_ptr(), y.numel(), drop[0], drop[1], drop[2], drop[3], drop[4], y.data_ptr(), stream_ptr()), "sf_dropout2_bf16")
+    return y, route
+
+
 def conv3x3_fold_supported(n: int, h: int, w: int, gm: GemmMap, groups: int, stats: bool) -> bool:
     """Shapes sf_conv3x3_fwd_folded takes (the two-images-per-workgroup kernel of small images has one weight stream)."""
     table_lds = ((gm.Kp + groups) * 9 + 2 * groups * gm.Kp) * 4  # sf_conv3x3_fold_pack's table kernel stages scale / shift of all groups

@@ -45,6 +45,11 @@ def _diagonal() -> bool:
     return os.environ.get("SF_LSTM_DIAG", "0") == "1"
 
 
+def _diagonal_bwd() -> bool:
+    """Anti-phase diagonal order of the two encoder cells' BACKWARD on two streams (round 5); ``SF_LSTM_DIAG_BWD=0`` keeps the serial order."""
+    return os.environ.get("SF_LSTM_DIAG_BWD", "1") == "1" or _diagonal()
+
+
 def _side_stream(dev) -> "torch.cuda.Stream":
     key = str(dev)
     if key not in _SIDE:
@@ -156,54 +161,12 @@ class _StackFn(torch.autograd.Function):
             if t or need_dx[k]:
                 eng.bwd_data(Gs[k][t], B, H, W, need_dx[k], dcat[k])
 
-        for s in range(T_out - 1, -1, -1):
-            last = s == T_out - 1
-            # decoder 2: head gradient + (decoder 1 consumed h4[s] as its input at step s+1)
-            back(3, s, last, [T(g_out[s])] + ([] if last else [dx_of(2)]))
-            back(2, s, last, [dx_of(3)])
-        if _diagonal() and T_in > 1 and not torch.cuda.is_current_stream_capturing():
-            # the same diagonal backwards: encoder 1 at step t only needs encoder 2's input gradient of step t, so it runs on a second stream
-            # while encoder 2 goes on to step t-1.  Encoder 2's [dx ; dh] scratch is double-buffered by the parity of t; it may overwrite a
-            # buffer only after encoder 1 has consumed the dx in it (two steps earlier).
-            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
-            d1pair = [dcat[1], torch.empty_like(dcat[1])]
-            side.wait_stream(main)
-            read_done: List[Optional[torch.cuda.Event]] = [None, None]
-            for t in range(T_in - 1, -1, -1):
-                last = t == T_in - 1
-                if read_done[t & 1] is not None:
-                    main.wait_event(read_done[t & 1])
-                eng = e2
-                src = ([dx_of(2)] if last else []) + ([] if last else [T(d1pair[(t + 1) & 1], hidp, widths[1] - hidp)])
-                eng.bwd_gates(src, None if last else dc[1], Gs[1][t], Cs[1][t - 1] if t else None, Cs[1][t], Gs[1][t], dc[1] if t else None)
-                eng.bwd_data(Gs[1][t], B, H, W, True, d1pair[t & 1])
-                ev = torch.cuda.Event()
-                ev.record(main)
-                side.wait_event(ev)
-                with torch.cuda.stream(side):
-                    back(0, t, last, [T(d1pair[t & 1], e2.cinp, 0)])
-                    if ctx.need_dx:
-                        dxs[t].copy_(dcat[0][..., : e1.cinp])
-                    read_done[t & 1] = torch.cuda.Event()
-                    read_done[t & 1].record(side)
-            main.wait_stream(side)  # also covers the allocator: every buffer the side stream touched is free for reuse on the main stream
-        else:
-            for t in range(T_in - 1, -1, -1):
-                last = t == T_in - 1
-                # encoder 2: at the last input step its h feeds decoder 1's first step
-                back(1, t, last, [dx_of(2)] if last else [])
-                back(0, t, last, [dx_of(1)])
-                if ctx.need_dx:
-                    dxs[t].copy_(dcat[0][..., : e1.cinp])
-
         # weight gradients: one split-K GEMM per cell over all of its timesteps (Gs now hold dz)
-        grads: List[Optional[Tensor]] = []
         zeros = torch.zeros(B, H, W, hidp, dtype=Hs[0].dtype, device=dev)
+        cell_grads: List[Optional[Tuple[Tensor, Tensor]]] = [None] * 4
 
-        def wgrad(eng: CellEngine, inp: sfTensor, hprev: sfTensor, dz: Tensor, steps: int, dw: Tensor, db: Tensor, acc: bool):
-            eng.bwd_weight(inp, hprev, T(dz), steps * B, H, W, dw, db, acc)
-
-        for k, eng in enumerate(engines):
+        def wgrad_cell(k: int) -> None:
+            eng = engines[k]
             dw = torch.empty_like(eng.conv.weight)
             db = torch.empty_like(eng.conv.bias)
             steps = T_in if k < 2 else T_out
@@ -216,10 +179,87 @@ class _StackFn(torch.autograd.Function):
                 first_in, rest_in = Hs[1][T_in - 1], Hs[3][: T_out - 1]
             else:
                 first_in, rest_in = Hs[2][0], Hs[2][1:]
-            wgrad(eng, T(first_in), T(zeros), Gs[k][0], 1, dw, db, False)
+            eng.bwd_weight(T(first_in), T(zeros), T(Gs[k][0]), B, H, W, dw, db, False)
             if steps > 1:
-                wgrad(eng, T(rest_in), T(Hs[k][: steps - 1]), Gs[k][1:], steps - 1, dw, db, True)
-            grads += [dw, db]
+                eng.bwd_weight(T(rest_in), T(Hs[k][: steps - 1]), T(Gs[k][1:]), (steps - 1) * B, H, W, dw, db, True)
+            cell_grads[k] = (dw, db)
+
+        for s in range(T_out - 1, -1, -1):
+            last = s == T_out - 1
+            # decoder 2: head gradient + (decoder 1 consumed h4[s] as its input at step s+1)
+            back(3, s, last, [T(g_out[s])] + ([] if last else [dx_of(2)]))
+            back(2, s, last, [dx_of(3)])
+        # The decoder cells' dz are complete here.  SF_LSTM_WGRAD_SIDE=1 (A/B switch, round 5): their weight gradients - MFMA-bound - go to a second
+        # stream now, next to the encoder's backward unroll whose gate kernels are HBM-bound (complementary resources); default: after the unroll.
+        wg_side = (os.environ.get("SF_LSTM_WGRAD_SIDE") == "1" and not torch.cuda.is_current_stream_capturing())
+        if wg_side:
+            main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
+            side_s.wait_stream(main_s)
+            with torch.cuda.stream(side_s):
+                wgrad_cell(3)
+                wgrad_cell(2)
+        if _diagonal_bwd() and T_in > 1 and not torch.cuda.is_current_stream_capturing():
+            # Diagonal backwards, in ANTI-PHASE (round 5): encoder 1 at step t only needs encoder 2's input gradient of step t, so it runs on a
+            # second stream while encoder 2 goes on to step t-1.  The round-4 form released encoder 1's step as soon as its input existed - and a
+            # kernel trace (tools/trace_overlap.sh) showed the two streams in lockstep: gate kernel next to gate kernel (both HBM-bound), input-gradient
+            # convolution next to input-gradient convolution (both MFMA-bound), no gain.  Here encoder 1's gate kernel of step t is held until encoder
+            # 2's gate kernel of step t-1 has FINISHED, i.e. it starts together with encoder 2's convolution: HBM-bound next to MFMA-bound, and the
+            # two kernels fit one CU together (the convolution's 2 x 232 registers per SIMD lane leave room for one 48-register wave of the gate
+            # kernel, tools/kernel_regs.py).  Encoder 2's [dx ; dh] scratch is double-buffered by the parity of t; it may overwrite a buffer only
+            # after encoder 1's gate kernel has consumed the dx in it (two steps earlier).
+            main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            d1pair = [dcat[1], torch.empty_like(dcat[1])]
+            e1.packed_bwd(need_dx[0]), e2.packed_bwd(True)   # packed on the main stream, before the second stream reads them
+            side.wait_stream(main)
+            read_done: List[Optional[torch.cuda.Event]] = [None, None]
+            data_done: Optional[torch.cuda.Event] = None   # encoder 2's convolution of the step encoder 1 handles next
+
+            def enc1(t: int, gate2_done: Optional[torch.cuda.Event]) -> None:
+                side.wait_event(data_done)
+                if gate2_done is not None:
+                    side.wait_event(gate2_done)
+                with torch.cuda.stream(side):
+                    eng = e1
+                    lastt = t == T_in - 1
+                    src = [T(d1pair[t & 1], e2.cinp, 0)] + ([] if lastt else [dh_of(0)])
+                    eng.bwd_gates(src, None if lastt else dc[0], Gs[0][t], Cs[0][t - 1] if t else None, Cs[0][t], Gs[0][t], dc[0] if t else None)
+                    read_done[t & 1] = torch.cuda.Event()
+                    read_done[t & 1].record(side)
+                    if t or need_dx[0]:
+                        eng.bwd_data(Gs[0][t], B, H, W, need_dx[0], dcat[0])
+                    if ctx.need_dx:
+                        dxs[t].copy_(dcat[0][..., : e1.cinp])
+
+            for t in range(T_in - 1, -1, -1):
+                last = t == T_in - 1
+                src = ([dx_of(2)] if last else []) + ([] if last else [T(d1pair[(t + 1) & 1], hidp, widths[1] - hidp)])
+                e2.bwd_gates(src, None if last else dc[1], Gs[1][t], Cs[1][t - 1] if t else None, Cs[1][t], Gs[1][t], dc[1] if t else None)
+                if not last:
+                    g_done = torch.cuda.Event()
+                    g_done.record(main)
+                    enc1(t + 1, g_done)
+                if read_done[t & 1] is not None:
+                    main.wait_event(read_done[t & 1])
+                e2.bwd_data(Gs[1][t], B, H, W, True, d1pair[t & 1])
+                data_done = torch.cuda.Event()
+                data_done.record(main)
+            enc1(0, None)
+            main.wait_stream(side)  # also covers the allocator: every buffer the side stream touched is free for reuse on the main stream
+        else:
+            for t in range(T_in - 1, -1, -1):
+                last = t == T_in - 1
+                # encoder 2: at the last input step its h feeds decoder 1's first step
+                back(1, t, last, [dx_of(2)] if last else [])
+                back(0, t, last, [dx_of(1)])
+                if ctx.need_dx:
+                    dxs[t].copy_(dcat[0][..., : e1.cinp])
+
+        for k in range(4):
+            if cell_grads[k] is None:
+                wgrad_cell(k)
+        if wg_side:
+            main_s.wait_stream(side_s)  # (also covers the allocator: the side stream's buffers are free for reuse on the main stream)
+        grads: List[Optional[Tensor]] = [g for pair in cell_grads for g in pair]
         gx = dxs.view(x.shape) if ctx.need_dx else None
         return (None, None, None, None, gx, *grads)
 

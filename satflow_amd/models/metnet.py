@@ -97,6 +97,11 @@ class DownSampler(nn.Module):
                 raise RuntimeError("pooled_stats were taken for a different number of BatchNorm groups")
             y, cs = F.batchnorm_conv3x3(y, m[3], groups, pooled_stats, self._eng[1], m[4].weight, m[4].bias, out_dtype=st, want_stats=True)
             y, cs = F.batchnorm_conv3x3(y, m[5], groups, cs, self._eng[2], m[6].weight, m[6].bias, out_dtype=st, want_stats=True)
+            if self.capture is None:
+                # conv4 + the last pooling (+ the two dropouts): the pooling rides in the convolution's epilogue where the kernel allows
+                n, h, w, c = y.shape
+                drop = (dropout[0], dropout[1], (n // dropout[2]) * (h // 2) * (w // 2) * self._eng[3].coutp) if dropout is not None else None
+                return F.batchnorm_conv3x3_maxpool(y, m[7], groups, cs, self._eng[3], m[8].weight, m[8].bias, perm, out_dtype, drop)
             y, _ = F.batchnorm_conv3x3(y, m[7], groups, cs, self._eng[3], m[8].weight, m[8].bias, out_dtype=st)
             return self._exit(y, perm, dropout, out_dtype)
         y = F.batchnorm(y, m[3], groups, self.training)

@@ -1,7 +1,7 @@
 """GPU parity of whole TRAINING STEPS at BASELINE.json's sizes: configs[1] (ConvLSTM 12ch 128x128
 T=12->6 hid 64) and configs[2] (MetNet 12ch 256x256 T=24->12 hid 64) at B=2, output and EVERY parameter gradient
 against the CPU oracle - in the fp32 parity mode at rtol 1e-4 / atol 1e-5, and in the benchmarked "bf16a" mode against
-the same fp32 oracle with the observed errors published (gpurun_out/r04_parity_observed.jsonl -> profiles/).
+the same fp32 oracle with the observed errors published (gpurun_out/r05_parity_observed.jsonl -> profiles/).
 Plus configs[0] exactly: 2-layer ConvGRU, 4 ch 64x64, T=4 -> T_out=4, B=2, hidden 8 / 64.
 
 The oracle side runs on the host cores (seconds per sample on the GPU box).  MetNet's max-poolings follow the routing

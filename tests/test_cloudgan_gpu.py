@@ -287,6 +287,7 @@ def test_cloudgan_training_steps_bf16_modes_vs_golden(device, case):
             e_loss, ey_loss = abs(float(out["loss"]) - ref_loss) / abs(ref_loss), abs(y_loss - ref_loss) / abs(ref_loss)
             assert e_loss <= max(1.5 * ey_loss, 2e-2), (tag, float(out["loss"]), y_loss, ref_loss)
             worst = ("", 0.0, 0.0)
+            worst_upd = ("", 0.0, 0.0)   # ... among the parameters THIS step's optimizer updates (the generator step leaves gradients on the discriminator too)
             live = [(net, pre, k, p) for net, pre in ((m.generator, "gen"), (m.discriminator, "disc")) for k, p in net.named_parameters()
                     if p.grad is not None and f"{pre}.{k}" in y_grads and float(G[f"{tag}_grad.{pre}.{k}"].float().abs().max()) >= 1e-6]
             y_worst = max(rel(y_grads[f"{pre}.{k}"], G[f"{tag}_grad.{pre}.{k}"].float()) for _, pre, k, _ in live)   # the autocast run's own worst parameter
@@ -296,8 +297,12 @@ def test_cloudgan_training_steps_bf16_modes_vs_golden(device, case):
                     assert err <= max(1.5 * yerr, y_worst, 2e-2), (tag, pre, k, err, yerr, y_worst)
                     if err > worst[1]:
                         worst = (f"{pre}.{k}", err, yerr)
+                    if pre == ("gen" if tag == "g" else "disc") and err > worst_upd[1]:
+                        worst_upd = (f"{pre}.{k}", err, yerr)
             rec.update({f"{tag}_loss_rel": e_loss, f"{tag}_loss_rel_autocast": ey_loss, f"{tag}_step_worst_grad": worst[0],
-                        f"{tag}_step_worst_grad_rel_l2": worst[1], f"{tag}_step_that_grad_autocast_rel_l2": worst[2]})
+                        f"{tag}_step_worst_grad_rel_l2": worst[1], f"{tag}_step_that_grad_autocast_rel_l2": worst[2],
+                        f"{tag}_step_worst_updated_grad": worst_upd[0], f"{tag}_step_worst_updated_grad_rel_l2": worst_upd[1],
+                        f"{tag}_step_that_updated_grad_autocast_rel_l2": worst_upd[2]})
         publish(rec)
     finally:
         satflow_amd.set_compute_dtype("f32")

@@ -228,3 +228,54 @@ def test_one_wave_per_simd_kernel_batchnorm_backward(device, bf16_mode, n, group
         K.conv3x3_bwd_data_bn(T(gy[sl].contiguous()), ipg, H, W, packed_t, gm, T(x[sl].contiguous()), coef[gi:gi + 1].contiguous(), T(dg))
         assert torch.equal(dx[sl][..., :cin], dg[..., :cin]), f"group {gi} differs"
     assert float(dx[..., :cin].float().abs().max()) > 0.1
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,groups,perm,drop", [
+    (512, 256, 256, 32, 32, 4, (4, 16), (0.2, 0.1)),      # MetNet's conv4 shape family: two N blocks, image permutation, both dropouts
+    (1024, 48, 128, 32, 16, 2, None, None),               # the minimum K (3 chunks), one tile per image, one N block
+    (256, 64, 384, 34, 30, 2, (2, 8), (0.0, 0.3)),        # ragged tiles (34 x 30), three N blocks
+    (288, 160, 128, 64, 64, 12, (12, 3), (0.25, 0.0)),    # 12 BatchNorm groups, several tile rows per image
+])
+def test_pooling_in_the_convolution_epilogue(device, bf16_mode, n, cin, cout, H, W, groups, perm, drop):
+    """sf_conv3x3_fwd_folded_pool (the one-wave-per-SIMD kernel with window-major pixel fragments and the 2x2 max-pooling in its epilogue) against the
+    two launches it replaces, sf_conv3x3_fwd_folded + sf_maxpool2_route_fwd: the pooled tensor AND the routing record bit for bit (ties between
+    values that differ only below bf16 precision included: the epilogue pools the ROUNDED values), with the image permutation, and with MetNet's two
+    dropout masks applied by sf_dropout2_bf16 against the masks fused into the pooling kernel."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    g = torch.Generator().manual_seed(n + cin + cout)
+    eng = ConvEngine([cin], cout)
+    gm = eng.fwd_map
+    w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+    scale = (0.5 + torch.rand(groups, gm.Kp, generator=g)).to(device)
+    shift = torch.randn(groups, gm.Kp, generator=g).to(device)
+    packed, tab = K.conv3x3_fold_pack(w, b, gm, scale, shift)
+    # coarse values: many windows hold values that tie after the bf16 rounding
+    x = (torch.randint(-4, 5, (n, H, W, cpad(cin)), generator=g).float() * 0.25).to(device).to(torch.bfloat16)
+    x[..., cin:] = 0
+    assert K.conv3x3_folded_pool_supported(n, H, W, gm, eng.coutp, groups), "the pooled-epilogue kernel must take this shape"
+    y = torch.full((n, H, W, eng.coutp), float("nan"), device=device).to(torch.bfloat16)
+    K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y))
+    d5 = None
+    if drop is not None:
+        per = (n // (perm[1] if perm else 1)) * (H // 2) * (W // 2) * eng.coutp
+        d5 = (drop[0], drop[1], per, 1234567, 7654321)
+    ref, ref_route = K.maxpool2_route_fwd(y, perm, torch.bfloat16, d5)
+    got, route = K.conv3x3_folded_pool(T(x), n, H, W, packed, tab, gm, eng.coutp, perm, d5, device)
+    torch.cuda.synchronize()
+    assert torch.isfinite(got[..., :cout].float()).all()
+    assert torch.equal(got[..., :cout], ref[..., :cout]), float((got[..., :cout].float() - ref[..., :cout].float()).abs().max())
+    # routing: 2 bits per channel, 16-bit word per channel octet; only the real channels' words are defined
+    words = cout // 8
+    assert torch.equal(route[..., :words], ref_route[..., :words]), int((route[..., :words] != ref_route[..., :words]).sum())
+    ties = int(((y[:, 0::2, 0::2, :cout] == y[:, 0::2, 1::2, :cout]) & (y[:, 0::2, 0::2, :cout] >= y[:, 1::2, 0::2, :cout])
+                & (y[:, 0::2, 0::2, :cout] >= y[:, 1::2, 1::2, :cout])).sum())
+    print(f"   {ties} windows whose maximum is tied in the top row")
+    # and the backward of the pair through the recorded routing: the gradient lands where the unfused path puts it
+    gy = torch.randn(got.shape, generator=g).to(device).to(torch.bfloat16)
+    d1 = K.maxpool2_route_bwd(route, gy, tuple(y.shape), torch.bfloat16, perm, d5)
+    d2 = K.maxpool2_route_bwd(ref_route, gy, tuple(y.shape), torch.bfloat16, perm, d5)
+    assert torch.equal(d1[..., :cout], d2[..., :cout])
