@@ -75,6 +75,17 @@ __device__ __forceinline__ float acc_read(float x) {
   return v;
 }
 #define SF_VMCNT(N) asm volatile("s_waitcnt vmcnt(" #N ")" ::: "memory")
+// MODE 3's pooling arithmetic: a bare v_max_f32, and `w = 2 w + bit` with the bit taken per lane from a wave mask (v_addc_co_u32 with the mask as carry-in)
+__device__ __forceinline__ float vmax(float a, float b) {
+  float m;
+  asm("v_max_f32 %0, %1, %2" : "=v"(m) : "v"(a), "v"(b));
+  return m;
+}
+__device__ __forceinline__ unsigned shift_in(unsigned w, unsigned long long mask) {
+  unsigned o;
+  asm("v_addc_co_u32 %0, vcc, %1, %1, %2" : "=v"(o) : "v"(w), "s"(mask) : "vcc");
+  return o;
+}
 // A 16-byte buffer load hipcc does not see (MODE 2: the BatchNorm input read in the epilogue).  Issued through the builtin, hipcc would have to drain
 // `vmcnt` to 0 at every use: the epilogue's stores share the counter and LLVM does not assume loads and stores retire in order (they do:
 // tools/ubench/vmcnt_order.hip).  The wait is counted by hand and TIED to the loaded registers, so no use can move above it.
@@ -109,7 +120,9 @@ constexpr int NPJ = (PPIECES + 63) / 64;              // 6 DMA instructions per 
 constexpr int TAB_B = 10 * NB * 4;                    // border-class bias table: 9 classes (+ 1 row of padding) x 128 fp32
 constexpr int IN0 = WST * W_B, TAB0 = IN0 + 4 * 2 * PIN_B;
 
-template <int MODE>
+// WIN: window-major lane <-> pixel map of the pixel fragments (always with MODE 3; for MODE 0 / 1 a launch-time choice, SF_CONV_W4_WIN): 16 instead of
+// 27 pixel-fragment reads per chunk, same products in the same order, the same 64-byte store runs (a store register then covers two window rows).
+template <int MODE, bool WIN = (MODE == 3)>
 __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const ConvParams p, const int items, const int nblk) {
   __shared__ __attribute__((aligned(1024))) char lds[TAB0 + TAB_B];  // 110592 + 46080 + 5120 = 161792 of 163840
 
@@ -130,8 +143,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   };
   // LDS slot of a private halo row -> halo column.  MODE 3 stores a row's even columns first, then its odd columns (window-major fragments read 8
   // consecutive pixels per window row), and swizzles the 16-byte halves by the parity of the window row instead of the pixel row.
-  auto slot_col = [](int s) __attribute__((always_inline)) { return MODE == 3 ? (s < 9 ? 2 * s : 2 * (s - 9) + 1) : s; };
-  auto half_flip = [](int iy) __attribute__((always_inline)) { return MODE == 3 ? (iy >> 1) & 1 : iy & 1; };
+  auto slot_col = [](int s) __attribute__((always_inline)) { return WIN ? (s < 9 ? 2 * s : 2 * (s - 9) + 1) : s; };
+  auto half_flip = [](int iy) __attribute__((always_inline)) { return WIN ? (iy >> 1) & 1 : iy & 1; };
   // per-lane byte offsets of the six input pieces relative to the wave's halo origin (the same for every item; validity is the item's mask)
   unsigned in_base_off[NPJ];
 #pragma unroll
@@ -241,7 +254,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     const int ky = tap / 3, kx = tap % 3, set = tap % 3;
     const char* inb = lds + IN0 + (wave * 2 + si) * PIN_B + a_lane;
     const char* wb = lds + sw * W_B + b_lane;
-    if constexpr (MODE == 3) {
+    if constexpr (WIN) {
       const char* pb = lds + IN0 + (wave * 2 + si) * PIN_B + p_lane;
 #pragma unroll
       for (int a = 0; a < 4; ++a)
@@ -264,13 +277,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   };
   auto frag_a = [&](int tap, int mf) __attribute__((always_inline)) -> const bf16x8& {
     const int ky = tap / 3, kx = tap % 3;
-    if constexpr (MODE == 3) return F[(mf >> 1) + ky][(mf & 1) + kx];
+    if constexpr (WIN) return F[(mf >> 1) + ky][(mf & 1) + kx];
     if (REUSE && ky == 0 && mf >= 1) return keep[kx][mf - 1];
     if (REUSE && ky == 2 && mf + 1 < MFR) return keep[kx][mf];
     return fa[tap % 3][mf];
   };
   auto tap_reads = [](int tap) {
-    if (MODE == 3) return NF + (tap == 0 ? 4 : (tap == 4 || tap == 5 || tap == 7 || tap == 8) ? 1 : 2);
+    if (WIN) return NF + (tap == 0 ? 4 : (tap == 4 || tap == 5 || tap == 7 || tap == 8) ? 1 : 2);
     return NF + ((REUSE && tap / 3 == 2) ? 1 : MFR);
   };
 
@@ -320,7 +333,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   };
   // byte offset of this lane's piece of pixel (row j of fragment mf, lane & 15) inside the item's output image (+ this N block's first channel), or the sentinel
   auto out_voff = [&](const Item& it, int mf, int j) __attribute__((always_inline)) -> unsigned {
-    const int py = it.y0 + 8 * wave + 2 * mf + j, px = it.x0 + (lane & 15);
+    // (window-major: store register j of fragment mf = (dy, dx) holds the windows of rows 2 j + ((lane >> 3) & 1), column lane & 7)
+    const int py = WIN ? it.y0 + 8 * wave + 2 * (2 * j + ((lane >> 3) & 1)) + (mf >> 1) : it.y0 + 8 * wave + 2 * mf + j;
+    const int px = WIN ? it.x0 + 2 * (lane & 7) + (mf & 1) : it.x0 + (lane & 15);
     return (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * piece) * 2) : DMA_SENT;
   };
 
@@ -359,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     }
 #pragma unroll
     for (int mf = 0; mf < MFR; ++mf) {
-      const int cls = MODE == 3 ? border_cls(it.y0 + 8 * wave + 2 * wwy + (mf >> 1), it.x0 + 2 * wwx + (mf & 1), p.H, p.W)
+      const int cls = WIN ? border_cls(it.y0 + 8 * wave + 2 * wwy + (mf >> 1), it.x0 + 2 * wwx + (mf & 1), p.H, p.W)
                                 : border_cls(it.y0 + 8 * wave + 2 * mf + (r >> 4), it.x0 + (r & 15), p.H, p.W);
 #pragma unroll
       for (int nf = 0; nf < NF; ++nf) {
@@ -391,7 +406,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
 #pragma unroll
       for (int mf = 0; mf < MFR; ++mf) {
         vo0[mf] = out_voff(it, mf, 0); vo1[mf] = out_voff(it, mf, 1);
-        const int py = it.y0 + 8 * wave + 2 * mf + (r >> 4), px = it.x0 + (r & 15);
+        const int py = WIN ? it.y0 + 8 * wave + 2 * wwy + (mf >> 1) : it.y0 + 8 * wave + 2 * mf + (r >> 4);
+        const int px = WIN ? it.x0 + 2 * wwx + (mf & 1) : it.x0 + (r & 15);
         okm |= (py < p.H && px < p.W) ? 1u << mf : 0u;
       }
       float* part = reinterpret_cast<float*>(lds + IN0 + (wave * 2 + free_stage) * PIN_B);
@@ -563,10 +579,13 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           float mx[2];
 #pragma unroll
           for (int e = 1; e >= 0; --e) {
-            const float m01 = fmaxf(rv[0][e], rv[1][e]), m23 = fmaxf(rv[2][e], rv[3][e]);
-            const bool c01 = rv[1][e] > rv[0][e], c23 = rv[3][e] > rv[2][e], bot = m23 > m01;
-            mx[e] = fmaxf(m01, m23);
-            Wc = (Wc << 2) | (bot ? 2u : 0u) | ((bot ? c23 : c01) ? 1u : 0u);
+            // (v_max_f32 through asm: the operands come out of bit operations, and hipcc would canonicalise each of them - one more v_max apiece -
+            // before an fmaxf; the comparisons as wave masks, the code bits combined on the scalar unit and shifted into the word through the carry)
+            const float m01 = vmax(rv[0][e], rv[1][e]), m23 = vmax(rv[2][e], rv[3][e]);
+            const unsigned long long c01 = __builtin_amdgcn_ballot_w64(rv[1][e] > rv[0][e]), c23 = __builtin_amdgcn_ballot_w64(rv[3][e] > rv[2][e]);
+            const unsigned long long bot = __builtin_amdgcn_ballot_w64(m23 > m01);
+            mx[e] = vmax(m01, m23);
+            Wc = shift_in(shift_in(Wc, bot), (c23 & bot) | (c01 & ~bot));
           }
           P[jj] = (__builtin_bit_cast(unsigned, mx[0]) >> 16) | (__builtin_bit_cast(unsigned, mx[1]) & 0xffff0000u);
         }
@@ -774,10 +793,16 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int grid = items < cus ? items : cus;
+  static const bool win = getenv("SF_CONV_W4_WIN") != nullptr;  // A/B switch (round 5): window-major pixel fragments for the plain / statistics launches too
   if (p.pool_out) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<3>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-  else if (p.stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-  else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  else if (p.stats) {
+    if (win) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+    else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  } else {
+    if (win) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+    else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  }
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;

@@ -40,14 +40,14 @@ _SIDE: Dict[Any, "torch.cuda.Stream"] = {}
 
 
 def _diagonal() -> bool:
-    """Diagonal (wavefront) order of the two encoder cells on two streams; ``SF_LSTM_DIAG=0`` keeps the serial order (A/B switch)."""
-    import os
-    return os.environ.get("SF_LSTM_DIAG", "0") == "1"
+    """Diagonal (wavefront) order of the two encoder cells on two streams in the FORWARD pass (default since round 5: +0.5 % with the anti-phase
+    backward below, +1 % with the side-stream weight gradients on top - small, but consistent over five A/B pairs); ``SF_LSTM_DIAG=0``: serial."""
+    return os.environ.get("SF_LSTM_DIAG", "1") == "1"
 
 
 def _diagonal_bwd() -> bool:
     """Anti-phase diagonal order of the two encoder cells' BACKWARD on two streams (round 5); ``SF_LSTM_DIAG_BWD=0`` keeps the serial order."""
-    return os.environ.get("SF_LSTM_DIAG_BWD", "1") == "1" or _diagonal()
+    return os.environ.get("SF_LSTM_DIAG_BWD", "1") == "1"
 
 
 def _side_stream(dev) -> "torch.cuda.Stream":
@@ -96,6 +96,7 @@ class _StackFn(torch.autograd.Function):
             # diagonal order (reference conv_lstm.py:176-182: encoder_2 at step t only needs encoder_1 at step t): encoder 2 runs one step
             # behind encoder 1 on a second stream, so two cell launches are in flight and one's epilogue meets the other's K loop
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
+            e1.packed_fwd(), e2.packed_fwd()   # packed on the main stream, before the second stream reads them
             side.wait_stream(main)
             for t in range(T_in):
                 run(0, e1, xs[t], t)
@@ -189,9 +190,9 @@ class _StackFn(torch.autograd.Function):
             # decoder 2: head gradient + (decoder 1 consumed h4[s] as its input at step s+1)
             back(3, s, last, [T(g_out[s])] + ([] if last else [dx_of(2)]))
             back(2, s, last, [dx_of(3)])
-        # The decoder cells' dz are complete here.  SF_LSTM_WGRAD_SIDE=1 (A/B switch, round 5): their weight gradients - MFMA-bound - go to a second
-        # stream now, next to the encoder's backward unroll whose gate kernels are HBM-bound (complementary resources); default: after the unroll.
-        wg_side = (os.environ.get("SF_LSTM_WGRAD_SIDE") == "1" and not torch.cuda.is_current_stream_capturing())
+        # The decoder cells' dz are complete here.  Round 5 (SF_LSTM_WGRAD_SIDE=0: the A/B switch back): their weight gradients - MFMA-bound - go to a second
+        # stream now, next to the encoder's backward unroll whose gate kernels are HBM-bound (complementary resources; measured: +0.5 %).
+        wg_side = (os.environ.get("SF_LSTM_WGRAD_SIDE", "1") == "1" and not torch.cuda.is_current_stream_capturing())
         if wg_side:
             main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
             side_s.wait_stream(main_s)

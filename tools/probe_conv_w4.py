@@ -41,7 +41,15 @@ for cin, cout in ((256, 256), (160, 256)):
     y = torch.empty(n, H, W, eng.coutp, device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)))
     fl = 2 * 9 * cin * cout * H * W * n
-    print(f"folded conv {cin}->{cout} @32x32 x {n} (W4 {'off' if os.environ.get('SF_NO_CONV_W4') else 'on'}): {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")
+    tag = f"W4 {'off' if os.environ.get('SF_NO_CONV_W4') else 'on'}{', window-major' if os.environ.get('SF_CONV_W4_WIN') else ''}"
+    print(f"folded conv {cin}->{cout} @32x32 x {n} ({tag}): {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")
+    from satflow_amd._hip import lib  # noqa: E402
+    st = torch.empty(n * int(lib().sf_conv3x3_stats_tiles(H, W)), gm.Np, 2, device=dev)
+    ms = timeit(lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), stats=st))
+    print(f"   + BatchNorm statistics ({tag}): {ms:.3f} ms = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")
+    if K.conv3x3_folded_pool_supported(n, H, W, gm, eng.coutp, groups):
+        ms = timeit(lambda: K.conv3x3_folded_pool(T(x), n, H, W, packed, tab, gm, eng.coutp, (12, 24), None, dev))
+        print(f"   + 2x2 max-pooling in the epilogue (incl. the two output allocations): {ms:.3f} ms = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")
 
 # the input gradient with the BatchNorm-backward epilogue (sf_conv3x3_bwd_data_bn; SF_NO_CONV_W4_BNB=1: the 8-wave one-item kernel)
 for cin, cout in ((256, 256),):
