@@ -254,7 +254,7 @@ class MetNetWorkload:
         rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes, FETCH x 2 per MI355X_MICROARCH.md), or null."""
         import satflow_amd
         from satflow_amd import kernels as K
-        from satflow_amd._hip import T, cpad, lib
+        from satflow_amd._hip import T, check, cpad, lib
         from satflow_amd.functional import ConvEngine
 
         mode = satflow_amd.compute_dtype_name()
@@ -289,13 +289,13 @@ class MetNetWorkload:
             out_lanes: lanes of the tensor written per pixel (None: cout; 0: the weight gradient writes no activation)."""
             t = event_time(fn, iters=10)
             fl = 2 * 9 * cin * cout * H * W * n
-            alg = (cin + cout + extra_read_lanes) * H * W * n * 2 + 9 * cin * cout * 2
             wr = (cout if out_lanes is None else out_lanes) * H * W * n * 2 + (9 * cin * cout * 4 if out_lanes == 0 else 0)
+            alg = (cin + extra_read_lanes) * H * W * n * 2 + 9 * cin * cout * 2 + (cout * H * W * n * 2 if out_lanes in (None, 0) else wr)
             rows.append({"kernel": name, "replaces": what, "launches_per_step": launches, "launch_us": t * 1e6, "ms_per_step": launches * t * 1e3,
                          "algorithmic_flops": fl, "achieved_tflops": fl / t / 1e12, "frac": fl / t / 1e12 / PEAK_BF16_TFLOPS,
                          "algorithmic_bytes": alg, "traffic": traffic(pmc_sub, wr)})
 
-        for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_persist4_kernel<2>"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
+        for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_persist4_kernel<2"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
             eng = ConvEngine([cin], cout)
             gm = eng.fwd_map
             w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
@@ -305,12 +305,23 @@ class MetNetWorkload:
             packed, tab = K.conv3x3_fold_pack(w, b, gm, scale, shift)
             x = torch.randn(n, H, W, cpad(cin), device=dev).to(bf)
             y = torch.empty(n, H, W, eng.coutp, device=dev, dtype=bf)
-            if fwd_plain:  # conv4 forward
-                row("conv3x3_bf16_persist4_kernel (folded BatchNorm, 4 waves x 512 registers)", "conv3x3_bf16_persist4_kernel<0>", 1, cin, cout,
-                    lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)), "DownSampler conv4 forward")
+            if fwd_plain:  # conv4 forward - since round 5 with the encoder's last max-pooling in its epilogue (the pooled tensor and the routing record
+                # are what the launch writes: a quarter of the output bytes + 2 bytes per 8 pooled values)
+                if K.conv3x3_folded_pool_supported(n, H, W, gm, eng.coutp, G):
+                    yp = torch.empty(n, H // 2, W // 2, eng.coutp, device=dev, dtype=bf)
+                    rt = torch.empty(n, H // 2, W // 2, eng.coutp // 8, device=dev, dtype=torch.int16)
+                    row("conv3x3_bf16_persist4_kernel<3> (folded BatchNorm + 2x2 max-pooling in the epilogue, window-major pixel fragments; 4 waves x 512 registers)",
+                        "conv3x3_bf16_persist4_kernel<3", 1, cin, cout,
+                        lambda: check(lib().sf_conv3x3_fwd_folded_pool(T(x), n, H, W, packed.data_ptr(), tab.data_ptr(), gm.Np, gm.nf, tab.shape[0], T(yp), self.L, self.T,
+                                                                       rt.data_ptr(), 1, torch.cuda.current_stream().cuda_stream), "sf_conv3x3_fwd_folded_pool"),
+                        "DownSampler conv4 forward + MaxPool2d (the pooled tensor is all that is written)", out_lanes=cout // 4 + cout // 32)
+                    del yp, rt
+                else:
+                    row("conv3x3_bf16_persist4_kernel (folded BatchNorm, 4 waves x 512 registers)", "conv3x3_bf16_persist4_kernel<0", 1, cin, cout,
+                        lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)), "DownSampler conv4 forward")
             tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
             st = torch.empty(n * tiles, gm.Np, 2, device=dev)
-            row(f"conv3x3_bf16_persist4_kernel<STATS> {cin}->{cout} (4 waves x 512 registers, BatchNorm statistics in the epilogue)", "conv3x3_bf16_persist4_kernel<1>", 1, cin, cout,
+            row(f"conv3x3_bf16_persist4_kernel<STATS> {cin}->{cout} (4 waves x 512 registers, BatchNorm statistics in the epilogue)", "conv3x3_bf16_persist4_kernel<1", 1, cin, cout,
                 lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), stats=st), f"DownSampler conv{2 if cin == 160 else 3} forward + BatchNorm statistics")
             # input gradient with the BatchNorm backward in its epilogue (dx = A conv^T(dout) + B x + K)
             need = (True,)

@@ -793,14 +793,18 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
   const int grid = items < cus ? items : cus;
-  static const bool win = getenv("SF_CONV_W4_WIN") != nullptr;  // A/B switch (round 5): window-major pixel fragments for the plain / statistics launches too
+  // window-major pixel fragments outside the pooled mode (round 5; bit-identical results): the statistics launches take them by default (-0.8 .. -1.0 %:
+  // 2.255 -> 2.236 ms at 256 -> 256, 1.536 -> 1.520 at 160 -> 256, two A/B pairs on one box), the plain launches do not (2.25 -> 2.49 ms: their
+  // pixel-fragment-outermost store order meets the stride-2 pixel set of a store register badly).  SF_CONV_W4_WIN=0: none, =1: both.
+  static const char* win_env = getenv("SF_CONV_W4_WIN");
+  static const bool win_stats = !win_env || win_env[0] != '0', win_plain = win_env && win_env[0] == '1';
   if (p.pool_out) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<3>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else if (p.stats) {
-    if (win) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+    if (win_stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
     else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   } else {
-    if (win) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+    if (win_plain) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
     else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   }
   hipError_t e = hipGetLastError();

@@ -51,6 +51,10 @@ int main(void) {
   REFUSED(sf_conv3x3_fwd_folded(b16, 3, 8, 8, ok, ok, 32, 1, 2, b16, 0, SF_BF16, st));                   /* images do not split into the groups */
   REFUSED(sf_conv3x3_fwd_folded(b16, 2, 1, 8, ok, ok, 32, 1, 2, b16, 0, SF_BF16, st));                   /* one-row image: no border classes */
   REFUSED(sf_conv3x3_fwd_folded(b16, 2, 8, 8, ok, mis, 32, 1, 2, b16, 0, SF_BF16, st));                  /* misaligned table */
+  REFUSED(sf_conv3x3_fwd_folded_pool(b16, 2, 8, 8, ok, ok, 128, 4, 2, b16, 0, 0, ok, SF_BF16, st));      /* a shape the pooled-epilogue kernel does not take */
+  REFUSED(sf_conv3x3_fwd_folded_pool(b16, 2048, 32, 32, ok, ok, 128, 4, 2, b16, 0, 0, 0, SF_BF16, st));  /* no routing buffer */
+  REFUSED(sf_conv3x3_fwd_folded_pool(a16, 2048, 32, 32, ok, ok, 128, 4, 2, b16, 0, 0, ok, SF_BF16, st)); /* fp32-stored source */
+  REFUSED(sf_conv3x3_fwd_folded_pool(b16, 2048, 32, 32, ok, ok, 128, 4, 2, b16, 3, 5, ok, SF_BF16, st)); /* images do not split into the permutation */
   /* ConvLSTM cell */
   REFUSED(sf_convlstm_cell_fwd(a16, a64, a64, 1, 8, 8, ok, 0, 48, a64, a64, N0, SF_F32, st));        /* hidp inconsistent with the tensors */
   REFUSED(sf_convlstm_cell_fwd(odd, a64, a64, 1, 8, 8, ok, 0, 64, a64, a64, N0, SF_F32, st));
@@ -111,6 +115,8 @@ int main(void) {
   REFUSED(sf_mse_loss(ok, ok, 100, 7, 3, 0, ok, ok, st));                                            /* n not divisible into frames */
   REFUSED(sf_dropout2(ok, 64, 1.0f, 0.f, 64, 1, 2, ok, st));                                         /* p >= 1 */
   REFUSED(sf_dropout2(ok, 64, 0.1f, 0.1f, 30, 1, 2, ok, st));                                        /* period not a multiple of 4 */
+  REFUSED(sf_dropout2_bf16(ok, 60, 0.1f, 0.1f, 64, 1, 2, ok, st));                                   /* n not a multiple of 8 */
+  REFUSED(sf_dropout2_bf16(ok, 64, 0.1f, 1.0f, 64, 1, 2, ok, st));                                   /* p >= 1 */
   /* CloudGAN side network */
   REFUSED(sf_conv2d_fwd(odd, 1, 8, 8, ok, 0, 12, 16, 4, 4, 2, 1, 0.2f, a16, SF_F32, st));            /* channels not padded to 8 */
   REFUSED(sf_conv2d_fwd(a16, 1, 2, 2, ok, 0, 16, 16, 4, 4, 1, 0, 1.f, a16, SF_F32, st));             /* empty output */

@@ -236,10 +236,10 @@ def test_sanitizer_harness_covers_every_entry_point():
     from satflow_amd import _hip
 
     src = open(os.path.join(ROOT, "tests", "sanitize", "harness.c")).read()
-    entries = [n for n, (res, _) in _hip.PROTOTYPES.items() if res is not None and n not in ("sf_abi_version", "sf_last_error_string") and not n.endswith(("_bytes", "_elems", "_floats", "_tiles"))]
+    entries = [n for n, (res, _) in _hip.PROTOTYPES.items() if res is not None and n not in ("sf_abi_version", "sf_last_error_string") and not n.endswith(("_bytes", "_elems", "_floats", "_tiles", "_supported"))]
     missing = [n for n in entries if f"REFUSED({n}(" not in src]
     assert not missing, f"entry points without a refusal case in the sanitizer harness: {missing}"
-    log = open(os.path.join(ROOT, "profiles", "r04_host_asan_ubsan.log")).read()
+    log = open(os.path.join(ROOT, "profiles", "r05_host_asan_ubsan.log")).read()
     assert "0 not refused" in log and "exit code 0" in log and "ERROR: AddressSanitizer" not in log and "runtime error" not in log
     if os.environ.get("SF_RUN_SANITIZER"):
         r = subprocess.run(["bash", os.path.join(ROOT, "tools", "sanitize_host.sh"), "/tmp/sf_host_sanitize.log"], capture_output=True, text=True, timeout=1200)
