@@ -120,7 +120,7 @@ constexpr int NPJ = (PPIECES + 63) / 64;              // 6 DMA instructions per 
 constexpr int TAB_B = 10 * NB * 4;                    // border-class bias table: 9 classes (+ 1 row of padding) x 128 fp32
 constexpr int IN0 = WST * W_B, TAB0 = IN0 + 4 * 2 * PIN_B;
 
-// WIN: window-major lane <-> pixel map of the pixel fragments (always with MODE 3; for MODE 0 / 1 a launch-time choice, SF_CONV_W4_WIN): 16 instead of
+// WIN: window-major lane <-> pixel map of the pixel fragments (always with MODE 3; for MODE 1 a launch-time choice, SF_CONV_W4_WIN): 16 instead of
 // 27 pixel-fragment reads per chunk, same products in the same order, the same 64-byte store runs (a store register then covers two window rows).
 template <int MODE, bool WIN = (MODE == 3)>
 __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const ConvParams p, const int items, const int nblk) {
@@ -794,19 +794,17 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
   }
   const int grid = items < cus ? items : cus;
   // window-major pixel fragments outside the pooled mode (round 5; bit-identical results): the statistics launches take them by default (-0.8 .. -1.0 %:
-  // 2.255 -> 2.236 ms at 256 -> 256, 1.536 -> 1.520 at 160 -> 256, two A/B pairs on one box), the plain launches do not (2.25 -> 2.49 ms: their
-  // pixel-fragment-outermost store order meets the stride-2 pixel set of a store register badly).  SF_CONV_W4_WIN=0: none, =1: both.
+  // 2.255 -> 2.236 ms at 256 -> 256, 1.536 -> 1.520 at 160 -> 256, two A/B pairs on one box; SF_CONV_W4_WIN=0: the A/B switch back).  The plain
+  // launches do not: that instantiation spilled 68 bytes per lane (the fragment set next to the pixel-fragment-outermost epilogue) and ran 2.25 -> 2.49 ms;
+  // the MetNet step has no plain launch of this kernel since conv4 took the pooled mode, so it is not instantiated.
   static const char* win_env = getenv("SF_CONV_W4_WIN");
-  static const bool win_stats = !win_env || win_env[0] != '0', win_plain = win_env && win_env[0] == '1';
+  static const bool win_stats = !win_env || win_env[0] != '0';
   if (p.pool_out) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<3>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   else if (p.stats) {
     if (win_stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
     else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-  } else {
-    if (win_plain) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-    else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-  }
+  } else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;

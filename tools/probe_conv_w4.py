@@ -41,7 +41,7 @@ for cin, cout in ((256, 256), (160, 256)):
     y = torch.empty(n, H, W, eng.coutp, device=dev, dtype=torch.bfloat16)
     ms = timeit(lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y)))
     fl = 2 * 9 * cin * cout * H * W * n
-    tag = f"W4 {'off' if os.environ.get('SF_NO_CONV_W4') else 'on'}{', window-major' if os.environ.get('SF_CONV_W4_WIN') else ''}"
+    tag = f"W4 {'off' if os.environ.get('SF_NO_CONV_W4') else 'on'}{', statistics launches row-major' if os.environ.get('SF_CONV_W4_WIN') == '0' else ''}"
     print(f"folded conv {cin}->{cout} @32x32 x {n} ({tag}): {ms:.3f} ms = {fl / ms / 1e9:.0f} TF/s = {fl / ms / 1e9 / 2500:.3f} of 2.5 PF")
     from satflow_amd._hip import lib  # noqa: E402
     st = torch.empty(n * int(lib().sf_conv3x3_stats_tiles(H, W)), gm.Np, 2, device=dev)
