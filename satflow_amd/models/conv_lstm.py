@@ -50,8 +50,10 @@ def _diagonal_bwd() -> bool:
     return os.environ.get("SF_LSTM_DIAG_BWD", "1") == "1"
 
 
-def _side_stream(dev) -> "torch.cuda.Stream":
-    key = str(dev)
+def _side_stream(dev, which: int = 0) -> "torch.cuda.Stream":
+    """Second streams of the stack, per device: 0 = the diagonal partner (encoder 2 forward / encoder 1 backward), 1 = the decoder cells' weight
+    gradients (their own queue: on the partner's they would sit in front of encoder 1's first gate kernel)."""
+    key = (str(dev), which)
     if key not in _SIDE:
         _SIDE[key] = torch.cuda.Stream(device=dev)
     return _SIDE[key]
@@ -194,7 +196,7 @@ class _StackFn(torch.autograd.Function):
         # stream now, next to the encoder's backward unroll whose gate kernels are HBM-bound (complementary resources; measured: +0.5 %).
         wg_side = (os.environ.get("SF_LSTM_WGRAD_SIDE", "1") == "1" and not torch.cuda.is_current_stream_capturing())
         if wg_side:
-            main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev)
+            main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev, 1)
             side_s.wait_stream(main_s)
             with torch.cuda.stream(side_s):
                 wgrad_cell(3)

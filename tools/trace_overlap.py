@@ -35,6 +35,21 @@ print("kernel time per queue (ms):", {k: round(v / 1e6, 3) for k, v in qs.items(
 print("top overlapping pairs (ms):")
 for (a, b), v in pair.most_common(8):
     print(f"  {v / 1e6:8.3f}  {a}  ||  {b}")
+# what co-running costs: mean duration of a kernel name when >= half of its run time is shared with another kernel, against running alone
+iv = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"]), short(r["Kernel_Name"])) for r in rows]
+stat = collections.defaultdict(lambda: [0, 0.0, 0, 0.0])
+for i, (s0, e0, nm) in enumerate(iv):
+    shared = 0
+    for j in range(max(0, i - 8), min(len(iv), i + 9)):
+        if j != i:
+            shared += max(0, min(e0, iv[j][1]) - max(s0, iv[j][0]))
+    k = 2 if shared >= 0.5 * (e0 - s0) else 0
+    stat[nm][k] += 1
+    stat[nm][k + 1] += e0 - s0
+print("mean duration alone / co-running (us), kernels with >= 10 co-running launches:")
+for nm, (na, ta, nc, tc) in sorted(stat.items(), key=lambda kv: -kv[1][3]):
+    if nc >= 10 and na >= 3:
+        print(f"  {ta / na / 1e3:8.1f} ({na:4d})  {tc / nc / 1e3:8.1f} ({nc:4d})  {nm}")
 print("timeline slice (us since window start; queue; duration):")
 mid = len(rows) // 2
 for r in rows[mid:mid + 24]:
