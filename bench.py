@@ -270,21 +270,26 @@ class MetNetWorkload:
             else:
                 pmc_note = f"profiles/{PROFILE_ROUND}_metnet_{mode}_pmc_step.json is stale (kernel sources changed): dropped"
 
-        def traffic(sub, write_bytes):
-            """Per-launch HBM bytes of the kernel whose name contains `sub`, at THIS row's shape: a name that runs at several shapes in the step carries one
-            record per shape (tools/pmc_by_kernel.py groups a name's launches by their write bytes); the one nearest the row's algorithmic writes is taken."""
+        def traffic(sub, rank, nshapes, by="bytes"):
+            """Per-launch HBM bytes of the kernel whose name contains `sub`, at THIS row's shape.  A name that runs at several shapes in the step carries
+            one record per shape (tools/pmc_by_kernel.py groups a name's launches by their read / write bytes); `rank` of `nshapes` = this row's place
+            among the shapes the step runs that name at (160 -> 256: 0, 256 -> 256: 1), the records ordered by total bytes or - where the larger shape does
+            not move more bytes (the weight gradient's edge slabs re-read x more often at 160 -> 256) - by launch count (256 -> 256 runs twice per step)."""
             for k, v in pmc.items():
                 if sub in k:
                     shapes = v.get("shapes") or [v]
-                    c = min(shapes, key=lambda c_: abs(c_["write_bytes"] - write_bytes))
+                    if by == "launches":
+                        shapes = sorted(shapes, key=lambda c_: c_["launches"])
+                    per_shape = bool(v.get("shapes")) and len(shapes) == nshapes
+                    c = shapes[rank] if per_shape else (shapes[0] if len(shapes) == 1 else v)
                     return {"read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"], "bytes": c["read_bytes"] + c["write_bytes"],
-                            "per_shape": bool(v.get("shapes")) and len(shapes) > 1}
+                            "per_shape": per_shape or nshapes == 1}
             return None
 
         bf = torch.bfloat16
         rows = []
 
-        def row(name, pmc_sub, launches, cin, cout, fn, what, extra_read_lanes=0, out_lanes=None):
+        def row(name, pmc_sub, launches, cin, cout, fn, what, extra_read_lanes=0, out_lanes=None, shape=(0, 1)):
             """extra_read_lanes: channel lanes of a second tensor the launch reads per pixel (the x read of the BatchNorm-backward epilogue);
             out_lanes: lanes of the tensor written per pixel (None: cout; 0: the weight gradient writes no activation)."""
             t = event_time(fn, iters=10)
@@ -293,7 +298,7 @@ class MetNetWorkload:
             alg = (cin + extra_read_lanes) * H * W * n * 2 + 9 * cin * cout * 2 + (cout * H * W * n * 2 if out_lanes in (None, 0) else wr)
             rows.append({"kernel": name, "replaces": what, "launches_per_step": launches, "launch_us": t * 1e6, "ms_per_step": launches * t * 1e3,
                          "algorithmic_flops": fl, "achieved_tflops": fl / t / 1e12, "frac": fl / t / 1e12 / PEAK_BF16_TFLOPS,
-                         "algorithmic_bytes": alg, "traffic": traffic(pmc_sub, wr)})
+                         "algorithmic_bytes": alg, "traffic": traffic(pmc_sub, *shape)})
 
         for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_persist4_kernel<2"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
             eng = ConvEngine([cin], cout)
@@ -322,7 +327,8 @@ class MetNetWorkload:
             tiles = int(lib().sf_conv3x3_stats_tiles(H, W))
             st = torch.empty(n * tiles, gm.Np, 2, device=dev)
             row(f"conv3x3_bf16_persist4_kernel<STATS> {cin}->{cout} (4 waves x 512 registers, BatchNorm statistics in the epilogue)", "conv3x3_bf16_persist4_kernel<1", 1, cin, cout,
-                lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), stats=st), f"DownSampler conv{2 if cin == 160 else 3} forward + BatchNorm statistics")
+                lambda: K.conv3x3_folded(T(x), n, H, W, packed, tab, gm, T(y), stats=st), f"DownSampler conv{2 if cin == 160 else 3} forward + BatchNorm statistics",
+                shape=(1 if cin == 256 else 0, 2))
             # input gradient with the BatchNorm backward in its epilogue (dx = A conv^T(dout) + B x + K)
             need = (True,)
             gmb = eng.bwd_map(need)
@@ -340,7 +346,8 @@ class MetNetWorkload:
             sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
             row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true>", 2 if cin == 256 else 1, cin, cout,
                 lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums)),
-                "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)" if cin == 256 else "weight gradient of conv2", out_lanes=0)
+                "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)" if cin == 256 else "weight gradient of conv2", out_lanes=0,
+                shape=(1 if cin == 256 else 0, 2, "launches"))
             del x, y, dout, dx, st
         rows.sort(key=lambda r: -r["ms_per_step"])
         return {"rows": rows, "traffic_source": pmc_note,

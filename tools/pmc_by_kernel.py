@@ -22,18 +22,24 @@ for c, scale, col in (("FETCH_SIZE", 2.0, 1), ("WRITE_SIZE", 1.0, 2)):   # FETCH
 
 def shape_classes(reads, writes):
     """A kernel NAME that runs at several shapes in a step (256->256 and 160->256 launches of the same instantiation) reports a mix when averaged by name.
-    The i-th launch of a name is the same launch in both passes; launches are grouped by their WRITE bytes (deterministic per shape, 3 % bins)."""
+    The i-th launch of a name is the same launch in both passes; launches are grouped by their bytes: writes within 3 % (deterministic per shape) AND
+    reads within 12 % (cache effects move them run to run; the shapes of one name differ by >= 25 %).  Classes are returned sorted by total bytes."""
     if len(reads) != len(writes) or not writes:
         return None
     cls = []
     for rd, wr in zip(reads, writes):
         for c in cls:
-            if abs(wr - c["write_bytes"] / c["launches"]) <= 0.03 * max(wr, 1.0):
+            mw, mr = c["write_bytes"] / c["launches"], c["read_bytes"] / c["launches"]
+            if abs(wr - mw) <= 0.03 * max(wr, mw, 1.0) and abs(rd - mr) <= 0.12 * max(rd, mr, 1.0):
                 c["launches"] += 1; c["read_bytes"] += rd; c["write_bytes"] += wr
                 break
         else:
             cls.append({"launches": 1, "read_bytes": rd, "write_bytes": wr})
-    return [{"launches": c["launches"], "read_bytes": c["read_bytes"] / c["launches"], "write_bytes": c["write_bytes"] / c["launches"]} for c in cls]
+    out = [{"launches": c["launches"], "read_bytes": c["read_bytes"] / c["launches"], "write_bytes": c["write_bytes"] / c["launches"]} for c in cls]
+    out = [c for c in out if c["launches"] >= max(2, len(writes) // 20)] or out   # (stray launches - warm-up shapes - do not make a class)
+    return sorted(out, key=lambda c: c["read_bytes"] + c["write_bytes"])
+
+
 print(f"{'launches':>8} {'read GB/launch':>15} {'write GB/launch':>16}  kernel")
 for k, (n, rd, wr) in sorted(tot.items(), key=lambda kv: -(kv[1][1] + kv[1][2]))[:top]:
     n = max(n, 1)
