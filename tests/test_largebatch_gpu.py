@@ -20,6 +20,11 @@ def _model(device, dropout):
 
 
 def _free_gib():
+    import gc
+
+    gc.collect()
+    torch.cuda.synchronize()
+    torch.cuda.empty_cache()   # blocks cached for earlier tests of the same process (the full-size DGMR step) are free memory, not used memory
     free, _ = torch.cuda.mem_get_info()
     return free / 2**30
 
