@@ -623,7 +623,10 @@ int launch_e(const ConvParams& p, int nf, int nblk, hipStream_t st) {
     if (w4 || (!w8 && p.H > 16 && wgs16 >= 1024)) return launch_w<4, EPI>(p, nf, nblk, st);
   }
   if (p.H > 16) return launch_w<8, EPI>(p, nf, nblk, st);
-  if (p.W <= 16 && !p.stats && nf >= 4 && p.N >= 512) return launch_w<8, EPI, true>(p, nf, nblk, st);
+  // round 5: NF = 3 with a bf16-STORED source (the x-part of MetNet's ConvGRU, 256 -> 192 on 2304 maps: LDS-DMA operands) takes the two-image kernel too:
+  // 601 -> 525 us, two A/B pairs in one call (tools/probe_gru_xpart.py; SF_CONV_NO_DUAL_NF3=1: back); fp32-stored NF = 3 launches stay on the 4-wave kernel
+  static const bool no_dual3 = getenv("SF_CONV_NO_DUAL_NF3") != nullptr;
+  if (p.W <= 16 && !p.stats && (nf >= 4 || (nf == 3 && p.bf0 && !p.src1 && !no_dual3)) && p.N >= 512) return launch_w<8, EPI, true>(p, nf, nblk, st);
   return launch_w<4, EPI>(p, nf, nblk, st);
 }
 
