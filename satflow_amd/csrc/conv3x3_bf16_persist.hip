@@ -259,7 +259,9 @@ bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf) {
   // (the one-wave-per-SIMD kernel has the registers for it: conv3x3_bf16_persist4.hip, MODE 2)
   if (p.bnb_coef && !sf_conv_bf16_persist4_ok(p, nf)) return false;
   const int tiles = ((p.W + sfconv::TILE_W - 1) / sfconv::TILE_W) * ((p.H + 31) / 32) * p.N;
-  return tiles >= 4 * 256;
+  static const char* mt = getenv("SF_PERSIST_MIN_TILES");   // experiment switch (round 5): the tile count from which the persistent kernels take a launch
+  static const int min_tiles = mt ? atoi(mt) : 4 * 256;
+  return tiles >= min_tiles;
 }
 
 int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p0, int nf, int nblk, hipStream_t st) {
