@@ -209,6 +209,18 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
                                  int32_t groups, float* dw, float* db, int32_t accumulate, const float* weight,
                                  const float* mean, const float* rstd, double* bn_sums, void* workspace,
                                  size_t workspace_bytes, int32_t dtype, sfStream stream);
+/* (ABI 6) The same weight gradient for a dout that is the gradient BEHIND A 2x2 / stride-2 MAX-POOLING (sf_maxpool2_route_bwd's output: the DownSampler's conv4,
+ * upstream metnet DownSampler via satflow/models/pl_metnet.py:46-59): one non-zero per pooling window and channel, hence at most two in any four consecutive
+ * pixels of an image row - dout goes in as the sparse operand of the 2:4 structured-sparse matrix instruction (v_smfmac_f32_32x32x32_bf16): half the matrix
+ * instructions for exactly the same products.  THE CALLER GUARANTEES THE STRUCTURE (at most one non-zero per aligned horizontal pixel pair and channel; the
+ * entry point cannot check 1.2 GB cheaply): a dout that breaks it is multiplied wrongly.  sf_conv3x3_bwd_weight_folded_sparse24_supported (Np = dout lanes,
+ * Kp = src lanes): 1 if the shape takes the path (even h, w; regular 128 x 64 slabs), else call sf_conv3x3_bwd_weight_folded.  Same workspace. */
+int32_t sf_conv3x3_bwd_weight_folded_sparse24_supported(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups);
+int sf_conv3x3_bwd_weight_folded_sparse24(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap,
+                                 const int32_t* kmap, int32_t O, int32_t I, const float* scale, const float* shift,
+                                 int32_t groups, float* dw, float* db, int32_t accumulate, const float* weight,
+                                 const float* mean, const float* rstd, double* bn_sums, void* workspace,
+                                 size_t workspace_bytes, int32_t dtype, sfStream stream);
 /* Input gradient of the same convolution THROUGH the folded BatchNorm in one launch: dx = A_g * conv^T(dout, W) + B_g * x + K_g
  * with coef [groups][3][x.c] = (A, B, K) from sf_batchnorm_train_bwd_coef (the affine form of the training-mode BatchNorm
  * backward) applied in the convolution's epilogue; wpacked = the transposed weight image (sf_conv3x3_pack_weights, transpose 1).

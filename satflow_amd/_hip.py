@@ -58,6 +58,11 @@ PROTOTYPES = {
         C.c_int,
         [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp],
     ),
+    "sf_conv3x3_bwd_weight_folded_sparse24_supported": (_i32, [_i32] * 6),
+    "sf_conv3x3_bwd_weight_folded_sparse24": (
+        C.c_int,
+        [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp],
+    ),
     "sf_conv3x3_bwd_data_bn": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _i32, _i32, sfTensor, _vp, _i32, sfTensor, _i32, _vp]),
     "sf_batchnorm_train_bwd_coef": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
     "sf_nchw_to_nhwc": (C.c_int, [_vp, _i64, _i64, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),

@@ -31,6 +31,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x16 __attribute__((ext_vector_type(16)));
 
 constexpr int TR = 4, TW = 16;             // K tile: 4 rows x 16 pixels
 constexpr int HR = TR + 2, HW = TW + 2;    // halo tile 6 x 18
@@ -81,7 +82,14 @@ __device__ __forceinline__ void* uniform_ptr(const void* q) {
 // takes the live halves of TWO ci tiles, slab 64 co x 128 ci, wave w owns co fragment w & 1 and ci fragment w >> 1; stage = 64 pixels x 128 bytes of
 // dout + halo x 256 bytes of input.  Both: 40 KiB per stage, three stages, five DMA instructions per wave and tile instead of four.  Every workgroup
 // of the launch then does the same MFMA work on live operands, and the plan cuts the K slices shorter.
-template <bool FAST, bool GROUPED, int GEO>
+// SPARSE (GEO 0; round 5): dout is the gradient behind a 2x2 max-pooling - one non-zero per window and channel, i.e. at most two in any four consecutive
+// pixels of a row - and goes in as the SPARSE operand of v_smfmac_f32_32x32x32_bf16 (operand layout and index encoding established on hardware:
+// tools/ubench/smfmac_probe.hip; 1.9x the dense stream on random data).  One sparse instruction multiplies TWO dout rows (K = 32 pixels): the dense
+// fragment of a row (a lane holds 8 consecutive pixels = two four-groups of its channel) is compressed in registers - per pixel pair the non-zero value and
+// its position bit - into 4 values + 2 index nibbles, rows r and r + 2 share an instruction; the dense operand is the halo rows (a, a + 2) read by the two
+// lane halves (the lane's 16 pixels of ITS row: four transposing reads).  18 instead of 36 matrix instructions per tile, the same products (zeros are
+// skipped), 48 instead of 36 fragment reads.  A dout that breaks the structure would be multiplied WRONGLY: the entry point is a separate one.
+template <bool FAST, bool GROUPED, int GEO, bool SPARSE = false>
 __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int per_slice, const char* __restrict__ zero, char* lds, const int ks,
                                                const int cot, const int cit) {
   static_assert(GEO == 0 || FAST, "the edge geometries use the descriptor DMA path");
@@ -300,14 +308,72 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     }
   };
 
+  // ---- SPARSE: operands of the 2:4 instruction ----
+  struct SpA { bf16x8 a02, a13; int i02, i13; float bias; };   // dout rows (0, 2) and (1, 3) of a tile, compressed; their index words; the tile's bias sum
+  // one dense row fragment (8 consecutive pixels of this lane's channel = 4 pixel pairs) -> 4 values + one index byte: per pair the non-zero value (a pair
+  // holds at most one; -0 counts as zero) and its position - slot 2q: position 0 / 1 of four-group q, slot 2q + 1: position 2 / 3
+  auto compress24 = [](const bf16x8& row, unsigned& v0, unsigned& v1, unsigned& nib2) __attribute__((always_inline)) {
+    const u32x4 d = __builtin_bit_cast(u32x4, row);
+    unsigned val[4], pos[4];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const bool lo = (d[q] & 0x7fffu) != 0u;
+      val[q] = lo ? d[q] : d[q] >> 16;
+      pos[q] = lo ? 0u : 1u;
+    }
+    v0 = __builtin_amdgcn_perm(val[1], val[0], 0x05040100u);
+    v1 = __builtin_amdgcn_perm(val[3], val[2], 0x05040100u);
+    nib2 = pos[0] | ((2u + pos[1]) << 2) | (pos[2] << 4) | ((2u + pos[3]) << 6);
+  };
+  // per-lane read addresses of the sparse instruction's DENSE operand: lane half kb reads the 16 pixels of halo row a + 2 kb (four transposing reads)
+  unsigned bs_base[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+    bs_base[kx] = lds0 + A_BYTES + (m + kx) * B_PIX + (GEO == 0 ? (wc ^ (((m + kx) >> 1) & 1)) * 64 : 0) + cbyte + khalf * (2 * HW * B_PIX);
+  auto load_b16 = [&](const unsigned (&aBS)[3], int a, bf16x16 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned ad = aBS[kx] + a * (HW * B_PIX);
+      const bf16x8 lo = cat8(tr_read(ad), tr_read(ad + 4 * B_PIX)), hi = cat8(tr_read(ad + 8 * B_PIX), tr_read(ad + 12 * B_PIX));
+      b[kx] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    }
+  };
+  // steps 2 and 3: the operand of halo rows (a, a + 2) from the operand of rows (a - 2, a) already in registers - its upper half (row a) moves to the lower
+  // lanes (v_permlane32_swap of a register with itself leaves the upper half's value in both halves of the second result), only the UPPER lanes read LDS (row
+  // a + 2): the wave's 64-lane read becomes a 32-lane one, and the tile's fragment reads go from 56 to 44 wave-equivalents
+  auto shift_b16 = [&](const unsigned (&aBS)[3], int a, bf16x16 (&b)[3]) __attribute__((always_inline)) {
+    typedef unsigned u32x8 __attribute__((ext_vector_type(8)));
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      u32x8 w = __builtin_bit_cast(u32x8, b[kx]);
+#pragma unroll
+      for (int d = 0; d < 8; ++d) w[d] = __builtin_amdgcn_permlane32_swap(w[d], w[d], false, false)[1];
+      if (khalf) {   // (aBS carries the upper lanes' + 2 rows already)
+        const unsigned ad = aBS[kx] + a * (HW * B_PIX);
+        const bf16x8 lo = cat8(tr_read(ad), tr_read(ad + 4 * B_PIX)), hi = cat8(tr_read(ad + 8 * B_PIX), tr_read(ad + 12 * B_PIX));
+        w = __builtin_bit_cast(u32x8, __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15));
+      }
+      b[kx] = __builtin_bit_cast(bf16x16, w);
+    }
+  };
+  auto stage_addr_s = [&](unsigned& aA, unsigned (&aBS)[3]) {
+    const unsigned so = (unsigned)(rd_stage * STAGE);
+    rd_stage = rd_stage + 1 == NS ? 0 : rd_stage + 1;
+    aA = (a_base + so) & 0x3ffffu;
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) aBS[kx] = (bs_base[kx] + so) & 0x3ffffu;
+  };
+
   // The two waves of a SIMD (w, w + 4) issue the next tile's DMA at different points of the tile so that one's MFMAs cover
   // the other's issue stall (see conv3x3_bf16.hip).
   const bool stage_late = wave >= 4;
   bf16x8 arow_a[TR], arow_b[TR], bq0[3], bq1[3];
   unsigned aA, aB[3];
-  stage_addr(aA, aB);
-  load_a(aA, arow_a);
-  load_b(aB, 0, bq0);
+  if constexpr (!SPARSE) {
+    stage_addr(aA, aB);
+    load_a(aA, arow_a);
+    load_b(aB, 0, bq0);
+  }
 
   // One tile: 36 MFMAs in two halves around the ring's rendezvous.  `cur` holds this tile's dout fragments (read during the
   // previous tile's second half), `nxt` receives the next tile's; halo row h + 1 is requested before row h's MFMAs.
@@ -359,6 +425,67 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) aB[kx] = nB[kx];
   };
+  // SPARSE tile: step a = 0 .. 3 reads the dense operand of halo rows (a, a + 2) at the three horizontal shifts and multiplies dout rows (0, 2) at vertical
+  // tap ky = a (a <= 2) and rows (1, 3) at ky = a - 1 (a >= 1): 3 + 6 + 6 + 3 instructions; the ring's rendezvous sits between steps 1 and 2 as in the
+  // dense tile; the next tile's dout rows are read and compressed, and its step-0 operands read, under steps 2 and 3.
+  [[maybe_unused]] SpA spa, spb;
+  [[maybe_unused]] bf16x16 sq0[3], sq1[3];
+  [[maybe_unused]] unsigned aBS[3];
+  auto smf = [&](const bf16x8& a, int idx, int ky, const bf16x16 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a, b[kx], acc[ky * 3 + kx], idx, 0, 0);
+  };
+  auto compress_rows = [&](const bf16x8 (&rows)[TR], SpA& sp) __attribute__((always_inline)) {
+    float bs_ = 0.f;
+    unsigned v[TR][2], nb[TR];
+#pragma unroll
+    for (int row = 0; row < TR; ++row) {
+      if (want_bias) {
+        const u32x4 d = __builtin_bit_cast(u32x4, rows[row]);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) bs_ += __builtin_bit_cast(float, d[k] << 16) + __builtin_bit_cast(float, d[k] & 0xffff0000u);
+      }
+      compress24(rows[row], v[row][0], v[row][1], nb[row]);
+    }
+    sp.a02 = __builtin_bit_cast(bf16x8, u32x4{v[0][0], v[0][1], v[2][0], v[2][1]});
+    sp.a13 = __builtin_bit_cast(bf16x8, u32x4{v[1][0], v[1][1], v[3][0], v[3][1]});
+    sp.i02 = (int)(nb[0] | (nb[2] << 8));
+    sp.i13 = (int)(nb[1] | (nb[3] << 8));
+    sp.bias = bs_;
+  };
+  auto tile_s = [&](SpA& cur, SpA& nxt) {
+    bsum += cur.bias;
+    load_b16(aBS, 1, sq1);
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a02, cur.i02, 0, sq0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(aBS, 2, sq0);
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a02, cur.i02, 1, sq1);
+    smf(cur.a13, cur.i13, 0, sq1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(aBS, 3, sq1);
+    asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 3)) : "memory");
+    __builtin_amdgcn_s_barrier();
+    if (!stage_late) issue();
+    // the next tile's dout rows are requested NOW (its stage is visible behind the barrier) and compressed under the six instructions of step 2
+    unsigned nA, nBS[3];
+    stage_addr_s(nA, nBS);
+    bf16x8 rows[TR];
+    load_a(nA, rows);
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a02, cur.i02, 2, sq0);
+    smf(cur.a13, cur.i13, 1, sq0);
+    compress_rows(rows, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(nBS, 0, sq0);
+    if (stage_late) issue();
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a13, cur.i13, 2, sq1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) aBS[kx] = nBS[kx];
+  };
   // partial[slot][tap][co][ci], slot = ks (or ks * maxseg + segment)
   const int r = lane & 31, kh = lane >> 5;
   auto store_partial = [&](int slot) __attribute__((always_inline)) {
@@ -396,6 +523,21 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
       }
     }
   };
+  if constexpr (SPARSE) {
+    {
+      unsigned sA;
+      stage_addr_s(sA, aBS);
+      bf16x8 rows0[TR];
+      load_a(sA, rows0);
+      compress_rows(rows0, spa);
+      load_b16(aBS, 0, sq0);
+    }
+    for (int i = 0; i < my_tiles; i += 2) {
+      group_boundary(i);
+      tile_s(spa, spb);
+      if (i + 1 < my_tiles) { group_boundary(i + 1); tile_s(spb, spa); }
+    }
+  } else
   for (int i = 0; i < my_tiles; i += 2) {
     group_boundary(i);
     tile(arow_a, arow_b);
@@ -409,7 +551,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
 // slab per PAIR of co tiles of the last ci tile; edge_mode 2: one GEO-2 slab per PAIR of ci tiles of the last co tile, a leftover ci tile stays
 // regular).  The slabs of one K slice are consecutive on one XCD (blocks are dealt round-robin to the 8 XCDs), so a slice's tiles are shared
 // through that XCD's L2 (pure speed choice).
-template <bool FAST, bool GROUPED = false>
+template <bool FAST, bool GROUPED = false, bool SPARSE = false>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
                                                                      const int xcd_groups, const int cot_n, const int cit_n, const int edge_mode) {
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -437,7 +579,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
     if (geo == 1) { wgrad_dma_body<true, GROUPED, 1>(p, per_slice, zero, lds, ks, cot, cit); return; }
     if (geo == 2) { wgrad_dma_body<true, GROUPED, 2>(p, per_slice, zero, lds, ks, cot, cit); return; }
   }
-  wgrad_dma_body<FAST, GROUPED, 0>(p, per_slice, zero, lds, ks, cot, cit);
+  wgrad_dma_body<FAST, GROUPED, 0, SPARSE>(p, per_slice, zero, lds, ks, cot, cit);
 }
 
 }  // namespace
@@ -513,10 +655,13 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   const bool fast = !(p.src0 && p.src1 && p.c1 > 0) || p.c0 % DMA_CI_T == 0;
   if (pl.wide_pairs && (!fast || (pl.edge_mode == 2 && p.src0 && p.src1 && p.c1 > 0))) { sf_set_error("wgrad_bf16_dma: the plan's edge slabs need tile-aligned sources"); return 1; }
   const dim3 grid(pl.KS, pl.units);
+  if (p.sparse24 && (!fast || pl.edge_mode != 0 || (p.W & 1))) { sf_set_error("wgrad_bf16_dma: the 2:4-sparse path takes regular slabs of a single-source launch with an even image width"); return 1; }
   if (pl.tpg > 0) {
     if (!fast) { sf_set_error("wgrad_bf16_dma: grouped slices need a single input source"); return 1; }
-    hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
-  } else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
+    if (p.sparse24) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
+    else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
+  } else if (p.sparse24) { sf_set_error("wgrad_bf16_dma: the 2:4-sparse path is built for the grouped (folded BatchNorm) launches"); return 1; }
+  else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
   else hipLaunchKernelGGL(wgrad_bf16_dma_kernel<false>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, 0);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("wgrad_bf16_dma: launch failed: %s", hipGetErrorString(e)); return 2; }

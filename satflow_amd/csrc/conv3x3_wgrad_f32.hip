@@ -433,10 +433,40 @@ size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int3
   return fold_layout(sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1), Np, n, groups).total_floats * sizeof(float);
 }
 
+static int bwd_weight_folded_impl(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
+                                  int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
+                                  int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
+                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream, int sparse24);
+
 int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
                                  int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
                                  int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  return bwd_weight_folded_impl(src, dout, n, h, w, nmap, kmap, O, I, scale, shift, groups, dw, db, accumulate, weight, mean, rstd, bn_sums, workspace,
+                                workspace_bytes, dtype, stream, 0);
+}
+
+int32_t sf_conv3x3_bwd_weight_folded_sparse24_supported(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups) {
+  static const bool off = getenv("SF_NO_WGRAD_SPARSE") != nullptr;   // A/B switch
+  if (off || groups < 1 || n <= 0 || n % groups || h < 2 || w < 2 || (w & 1) || (h & 1)) return 0;
+  const Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1);
+  return pl.edge_mode == 0 ? 1 : 0;
+}
+
+int sf_conv3x3_bwd_weight_folded_sparse24(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
+                                          int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
+                                          int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
+                                          void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
+  SF_REQUIRE(sf_conv3x3_bwd_weight_folded_sparse24_supported(dout.c, src.c, n, h, w, groups),
+             "sf_conv3x3_bwd_weight_folded_sparse24: shape not taken by the 2:4-sparse path (ask sf_conv3x3_bwd_weight_folded_sparse24_supported)");
+  return bwd_weight_folded_impl(src, dout, n, h, w, nmap, kmap, O, I, scale, shift, groups, dw, db, accumulate, weight, mean, rstd, bn_sums, workspace,
+                                workspace_bytes, dtype, stream, 1);
+}
+
+static int bwd_weight_folded_impl(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
+                                  int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
+                                  int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
+                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream, int sparse24) {
   SF_REQUIRE(dtype == SF_BF16 && src.ptr && dout.ptr && src.dtype == SF_BF16 && dout.dtype == SF_BF16,
              "sf_conv3x3_bwd_weight_folded: bf16-stored tensors and the SF_BF16 kernels only");
   SF_REQUIRE(groups >= 1 && n % groups == 0 && h >= 2 && w >= 2, "bwd_weight_folded: n=%d must split into %d groups of whole images, h, w >= 2", n, groups);
@@ -455,6 +485,7 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
   p.idiv0 = p.idiv1 = 1;
   p.dout = (const float*)dout.ptr; p.dc = dout.c; p.ds = dout.stride;
   p.N = n; p.H = h; p.W = w;
+  p.sparse24 = sparse24;
   if (int rc = sf_launch_wgrad_bf16_dma(p, pl, (float*)workspace, st)) return rc;
   float* bpart = (float*)workspace + fl.bpart_off;
   float* V = (float*)workspace + fl.v_off;

@@ -21,6 +21,10 @@ struct WgradParams {
   // loader-wave kernel, fp32-stored tensors: src0 is read as four shifted views stacked as channels (sfconv::ConvParams::shift4; here in CHANNELS per
   // view, a multiple of the 32-channel ci tile): input channel block cit belongs to view (32 cit) / shift4 - sf_conv5x5_bwd_weight.  0 = off
   int shift4;
+  // all-bf16 kernel (regular slabs): dout holds AT MOST ONE non-zero per aligned horizontal pixel pair and channel - the gradient behind a 2x2 / stride-2
+  // max-pooling - so any four consecutive pixels of a row hold at most two: the 2:4 structured-sparse MFMA (v_smfmac_f32_32x32x32_bf16) takes dout as its
+  // sparse operand, half the matrix instructions for the same products (sf_conv3x3_bwd_weight_folded_sparse24)
+  int sparse24;
 };
 
 

@@ -509,7 +509,8 @@ class _BNConvFn(torch.autograd.Function):
             # (sum dn = W . V_g, sum dn * x = W . dWraw_g), so d(normalised input) = conv^T(gy, W) is never materialised - the input
             # gradient convolution applies dx = A dn + B x + K in its epilogue.
             w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
-            K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db, bn=(w4, stats[0], stats[1], sums))
+            K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db, bn=(w4, stats[0], stats[1], sums),
+                                        pooled_gradient=ctx.pool is not None)   # (gy then comes out of maxpool2_route_bwd just above)
             check(lib().sf_batchnorm_train_bwd_coef(sums.data_ptr(), (n * H * W) // groups, groups, C, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
                                                     stats[1].data_ptr(), coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32, stream_ptr()),
                   "sf_batchnorm_train_bwd_coef")

@@ -280,10 +280,16 @@ def conv3x3_fold_supported(n: int, h: int, w: int, gm: GemmMap, groups: int, sta
 
 
 def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, scale: Tensor, shift: Tensor,
-                              dw: Tensor, db: Optional[Tensor], bn: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None) -> None:
+                              dw: Tensor, db: Optional[Tensor], bn: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None,
+                              pooled_gradient: bool = False) -> None:
     """sf_conv3x3_bwd_weight_folded: dW/db of a convolution behind a folded BatchNorm, from the un-normalised input.
-    ``bn = (weight OIHW, mean, rstd, sums[groups,2,C] float64)``: also fills ``sums`` with the BatchNorm backward's two reductions."""
+    ``bn = (weight OIHW, mean, rstd, sums[groups,2,C] float64)``: also fills ``sums`` with the BatchNorm backward's two reductions.
+    ``pooled_gradient``: ``dout`` is the output of ``maxpool2_route_bwd`` (one non-zero per 2x2 window and channel): where the shape allows, dout is the
+    sparse operand of the 2:4 structured-sparse matrix instruction (sf_conv3x3_bwd_weight_folded_sparse24; SF_NO_WGRAD_SPARSE=1: A/B switch)."""
     dev = dw.device
+    fn, fname = lib().sf_conv3x3_bwd_weight_folded, "sf_conv3x3_bwd_weight_folded"
+    if pooled_gradient and lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(dout.c, src.c, n, h, w, scale.shape[0]):
+        fn, fname = lib().sf_conv3x3_bwd_weight_folded_sparse24, "sf_conv3x3_bwd_weight_folded_sparse24"
     nmap, kmap = gm.tables(dev)
     groups = scale.shape[0]
     nbytes = lib().sf_conv3x3_bwd_weight_folded_workspace_bytes(dout.c, src.c, n, h, w, groups)
@@ -293,11 +299,11 @@ def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: 
         wgt, mean, rstd, sums = bn
         wgt = wgt.detach().contiguous()
         assert sums.dtype == torch.float64 and sums.is_contiguous() and mean.is_contiguous() and rstd.is_contiguous()
-    check(lib().sf_conv3x3_bwd_weight_folded(src, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), dw.shape[0], dw.shape[1], scale.data_ptr(),
-                                             shift.data_ptr(), groups, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
-                                             wgt.data_ptr() if bn is not None else None, mean.data_ptr() if bn is not None else None,
-                                             rstd.data_ptr() if bn is not None else None, sums.data_ptr() if bn is not None else None,
-                                             ws.data_ptr(), nbytes, _hip.SF_BF16, stream_ptr()), "sf_conv3x3_bwd_weight_folded")
+    check(fn(src, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), dw.shape[0], dw.shape[1], scale.data_ptr(),
+             shift.data_ptr(), groups, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
+             wgt.data_ptr() if bn is not None else None, mean.data_ptr() if bn is not None else None,
+             rstd.data_ptr() if bn is not None else None, sums.data_ptr() if bn is not None else None,
+             ws.data_ptr(), nbytes, _hip.SF_BF16, stream_ptr()), fname)
 
 
 def conv3x3_bwd_data_bn(dout: sfTensor, n: int, h: int, w: int, packed_t: Tensor, gm: GemmMap, x: sfTensor, coef: Tensor, dx: sfTensor) -> None:

@@ -315,3 +315,56 @@ def test_leadtime_pool_statistics_fall_back_beyond_the_register_budget(device):
     w1 = (torch.randn(32, 4 + 13, 3, 3, generator=g) * 0.3).to(device)
     out, st = F.leadtime_pool(base, w1, 4, 13, want_stats=True)
     assert st is None and torch.equal(out, F.leadtime_pool(base, w1, 4, 13))
+
+
+@pytest.mark.parametrize("n,cin,cout,H,W,groups,drop", [(48, 256, 256, 32, 32, 12, 0.2), (24, 160, 256, 32, 32, 4, 0.0), (12, 64, 128, 16, 48, 3, 0.5), (16, 128, 256, 64, 64, 2, 0.0)])
+def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(device, n, cin, cout, H, W, groups, drop):
+    """Round 5: sf_conv3x3_bwd_weight_folded_sparse24 - dout = the gradient behind a 2x2 max-pooling (one non-zero per window and channel, fewer after the
+    dropout) as the SPARSE operand of v_smfmac_f32_32x32x32_bf16 (two dout rows per instruction, compressed in registers).  Same products as the dense
+    kernel: dW, db and the BatchNorm-backward sums against the dense launch at fp32 summation distance, dW against float64 of exactly the operands."""
+    import satflow_amd
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T, cpad, lib
+    from satflow_amd.functional import ConvEngine
+
+    satflow_amd.set_compute_dtype("bf16a")
+    try:
+        g = torch.Generator().manual_seed(n + cin)
+        eng = ConvEngine([cin], cout)
+        gm = eng.wgrad_map
+        assert lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(eng.coutp, cpad(cin), n, H, W, groups), "this shape must take the sparse path"
+        x = torch.randn(n, H, W, cpad(cin), generator=g).to(device).to(torch.bfloat16)
+        x[..., cin:] = 0
+        y = torch.randn(n, H, W, eng.coutp, generator=g).to(device).to(torch.bfloat16)
+        pooled, route = K.maxpool2_route_fwd(y, None, torch.bfloat16, None)
+        gp = torch.randn(pooled.shape, generator=g).to(device).to(torch.bfloat16)
+        if drop:
+            gp = gp * (torch.rand(gp.shape, generator=g).to(device) >= drop).to(torch.bfloat16)   # zeros inside the structure (dropped positions) are fine
+        dout = K.maxpool2_route_bwd(route, gp, tuple(y.shape), torch.bfloat16, None, None)
+        nz = (dout.view(n, H, W // 2, 2, -1) != 0).sum(3)
+        assert int(nz.max()) <= 1, "at most one non-zero per aligned horizontal pixel pair and channel"
+        scale = (0.5 + torch.rand(groups, cpad(cin), generator=g)).to(device)
+        shift = torch.randn(groups, cpad(cin), generator=g).to(device)
+        w = (torch.randn(cout, cin, 3, 3, generator=g) * 0.05).to(device)
+        mean, rstd = torch.randn(groups, cpad(cin), generator=g).to(device), (0.5 + torch.rand(groups, cpad(cin), generator=g)).to(device)
+        res = []
+        for sparse in (False, True):
+            dw, db = torch.full_like(w, float("nan")), torch.full((cout,), float("nan"), device=device)
+            sums = torch.full((groups, 2, cpad(cin)), float("nan"), dtype=torch.float64, device=device)
+            K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, gm, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=sparse)
+            res.append((dw, db, sums))
+        torch.cuda.synchronize()
+        (dw0, db0, s0), (dw1, db1, s1) = res
+        assert torch.isfinite(dw1).all() and torch.isfinite(db1).all() and torch.isfinite(s1).all()
+        assert rel_l2(dw1, dw0) < 5e-6 and rel_l2(db1, db0) < 1e-6, (rel_l2(dw1, dw0), rel_l2(db1, db0))
+        assert float((s1 - s0).norm() / s0.norm()) < 5e-6
+        # float64: dW = sum_g scale_g (.) dWraw_g + shift_g (x) V_g  ==  the weight gradient of conv(scale_g * x + shift_g) for the group's images
+        xd = x[..., :cin].double().cpu().permute(0, 3, 1, 2)
+        per = n // groups
+        xn = torch.cat([xd[i * per:(i + 1) * per] * scale[i, :cin].double().cpu().view(1, -1, 1, 1) + shift[i, :cin].double().cpu().view(1, -1, 1, 1) for i in range(groups)])
+        wd = w.double().cpu().requires_grad_()
+        out = torch.nn.functional.conv2d(xn, wd, None, padding=1)
+        (gw,) = torch.autograd.grad(out, wd, dout[..., :cout].double().cpu().permute(0, 3, 1, 2))
+        assert rel_l2(dw1.cpu().double(), gw) < 2e-5, rel_l2(dw1.cpu().double(), gw)
+    finally:
+        satflow_amd.set_compute_dtype("f32")
