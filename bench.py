@@ -278,8 +278,8 @@ class MetNetWorkload:
             for k, v in pmc.items():
                 if sub in k:
                     shapes = v.get("shapes") or [v]
-                    if by == "launches":
-                        shapes = sorted(shapes, key=lambda c_: c_["launches"])
+                    if by in ("launches", "write_bytes"):
+                        shapes = sorted(shapes, key=lambda c_: c_[by])
                     per_shape = bool(v.get("shapes")) and len(shapes) == nshapes
                     c = shapes[rank] if per_shape else (shapes[0] if len(shapes) == 1 else v)
                     return {"read_bytes": c["read_bytes"], "write_bytes": c["write_bytes"], "bytes": c["read_bytes"] + c["write_bytes"],
@@ -344,10 +344,23 @@ class MetNetWorkload:
             dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
             mean, rstd = torch.randn(G, cpad(cin), device=dev), 0.5 + torch.rand(G, cpad(cin), device=dev)
             sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
-            row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true>", 2 if cin == 256 else 1, cin, cout,
+            sparse = cin == 256 and bool(lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(eng.coutp, cpad(cin), n, H, W, G))
+            row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true, false>", (1 if sparse else 2) if cin == 256 else 1, cin, cout,
                 lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums)),
-                "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)" if cin == 256 else "weight gradient of conv2", out_lanes=0,
-                shape=(1 if cin == 256 else 0, 2, "launches"))
+                ("weight gradient of conv3 (grouped slabs + BatchNorm-backward sums)" if sparse else "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)")
+                if cin == 256 else "weight gradient of conv2", out_lanes=0, shape=(1 if cin == 256 else 0, 2, "write_bytes" if sparse else "launches"))
+            if sparse:
+                # conv4's weight gradient: its dout comes out of the 2x2 max-pooling's backward - one non-zero per window and channel - and is the SPARSE operand
+                # of v_smfmac_f32_32x32x32_bf16.  The row keeps the dense flop count (what the launch replaces): frac is "dense-equivalent" of the 2.5 PF peak.
+                yp = torch.randn(n, H, W, eng.coutp, device=dev).to(bf)
+                pooled_, route_ = K.maxpool2_route_fwd(yp, None, bf, None)
+                dsp = K.maxpool2_route_bwd(route_, torch.randn_like(pooled_), tuple(yp.shape), bf, None, None)
+                del yp, pooled_, route_
+                row(f"wgrad_bf16_dma_kernel<FAST, GROUPED, SPARSE> {cin}->{cout}: dout behind the max-pooling as the 2:4 structured-sparse MFMA operand (+ folded-BatchNorm helpers)",
+                    "wgrad_bf16_dma_kernel<true, true, true>", 1, cin, cout,
+                    lambda: K.conv3x3_bwd_weight_folded(T(x), T(dsp), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=True),
+                    "weight gradient of conv4 (dense-equivalent flops: half the matrix instructions)", out_lanes=0)
+                del dsp
             del x, y, dout, dx, st
         rows.sort(key=lambda r: -r["ms_per_step"])
         return {"rows": rows, "traffic_source": pmc_note,
@@ -365,7 +378,7 @@ class MetNetWorkload:
         if mode == "bf16a":
             tab = self.kernel_table()
             self._kernel_table = tab
-            r = next(x for x in tab["rows"] if x["kernel"].startswith("wgrad_bf16_dma_kernel") and "256->256" in x["kernel"])
+            r = next(x for x in tab["rows"] if x["kernel"].startswith("wgrad_bf16_dma_kernel<FAST, GROUPED> 256->256"))
             tr = r["traffic"]
             return {"bound": "mfma", "achieved": r["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
                     "traffic": tr["bytes"] if tr else None, "traffic_source": tab["traffic_source"],

@@ -237,7 +237,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     for (int u = 0; u < NA; ++u) {
       const int a = wave + 8 * u, row_a = (PPB * a) >> 4, x_a = (PPB * a) & 15;
       const bool ok = live && row_a < rows_left && x_a + a_pl < cols_left;
+#ifdef SF_EXP_WG_NOADMA   // timing experiment: no dout traffic (zero-filled pieces)
+      bufdma16(ok && false ? fa_voff : SENT, rsa, soa + (unsigned)((row_a * p.W + x_a) * (int)a_pxb), stage + a * 1024);
+#else
       bufdma16(ok ? fa_voff : SENT, rsa, soa + (unsigned)((row_a * p.W + x_a) * (int)a_pxb), stage + a * 1024);
+#endif
     }
     int ns = n;
     if (remap) { ns = n / bidiv; if (bimod) ns %= bimod; }
@@ -246,7 +250,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)bsrc + ns * b_img - lead), 0, __builtin_amdgcn_readfirstlane((int)(b_img + 2 * lead)), 0x00020000);
     const unsigned sob = (unsigned)px0 * b_pxb;
 #pragma unroll
+#ifdef SF_EXP_WG_NOBDMA   // timing experiment: no input traffic
+    for (int u = 0; u < NBK; ++u) bufdma16(SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
+#else
     for (int u = 0; u < NBK; ++u) bufdma16((fb_mask[u] & sel) ? fb_off[u] : SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
+#endif
     ++nx_i;
     nx_stage = nx_stage + 1 == NS ? 0 : nx_stage + 1;
     if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; } }
@@ -453,17 +461,22 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     sp.i13 = (int)(nb[1] | (nb[3] << 8));
     sp.bias = bs_;
   };
+#ifdef SF_EXP_WG_NOSB   // experiment: leave the interleaving of fragment reads, compression and matrix instructions to the compiler
+#define SF_SPARSE_SB
+#else
+#define SF_SPARSE_SB __builtin_amdgcn_sched_barrier(0)
+#endif
   auto tile_s = [&](SpA& cur, SpA& nxt) {
     bsum += cur.bias;
     load_b16(aBS, 1, sq1);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     smf(cur.a02, cur.i02, 0, sq0);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     load_b16(aBS, 2, sq0);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     smf(cur.a02, cur.i02, 1, sq1);
     smf(cur.a13, cur.i13, 0, sq1);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     load_b16(aBS, 3, sq1);
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
@@ -473,16 +486,16 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     stage_addr_s(nA, nBS);
     bf16x8 rows[TR];
     load_a(nA, rows);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     smf(cur.a02, cur.i02, 2, sq0);
     smf(cur.a13, cur.i13, 1, sq0);
     compress_rows(rows, nxt);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     load_b16(nBS, 0, sq0);
     if (stage_late) issue();
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
     smf(cur.a13, cur.i13, 2, sq1);
-    __builtin_amdgcn_sched_barrier(0);
+    SF_SPARSE_SB;
 #pragma unroll
     for (int kx = 0; kx < 3; ++kx) aBS[kx] = nBS[kx];
   };

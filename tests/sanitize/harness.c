@@ -129,6 +129,9 @@ int main(void) {
   REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 16, SF_BF16, st));      /* workspace too small */
   REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, ok, ok, ok, ok, 1 << 30, SF_BF16, st)); /* bn_sums without the weights */
   REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 3, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* ragged groups */
+  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
+  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* 16 lanes: no 128 x 64 slabs */
+  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(b16, b16, 2, 7, 7, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* odd maps: no 2x2 windows */
   REFUSED(sf_conv3x3_bwd_data_bn(b16, 2, 8, 8, ok, 32, 1, a16, ok, 2, b16, SF_BF16, st));               /* fp32-stored x */
   REFUSED(sf_conv3x3_bwd_data_bn(b16, 3, 8, 8, ok, 32, 1, b16, ok, 2, b16, SF_BF16, st));               /* ragged groups */
   REFUSED(sf_conv3x3_bwd_data_bn(b16, 2, 8, 8, ok, 32, 1, b16, mis, 2, b16, SF_BF16, st));              /* misaligned coefficients */

@@ -317,7 +317,7 @@ def test_leadtime_pool_statistics_fall_back_beyond_the_register_budget(device):
     assert st is None and torch.equal(out, F.leadtime_pool(base, w1, 4, 13))
 
 
-@pytest.mark.parametrize("n,cin,cout,H,W,groups,drop", [(48, 256, 256, 32, 32, 12, 0.2), (24, 160, 256, 32, 32, 4, 0.0), (12, 64, 128, 16, 48, 3, 0.5), (16, 128, 256, 64, 64, 2, 0.0)])
+@pytest.mark.parametrize("n,cin,cout,H,W,groups,drop", [(48, 256, 256, 32, 32, 12, 0.2), (24, 128, 256, 32, 32, 4, 0.0), (12, 64, 128, 16, 48, 3, 0.5), (16, 128, 256, 64, 64, 2, 0.0)])
 def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(device, n, cin, cout, H, W, groups, drop):
     """Round 5: sf_conv3x3_bwd_weight_folded_sparse24 - dout = the gradient behind a 2x2 max-pooling (one non-zero per window and channel, fewer after the
     dropout) as the SPARSE operand of v_smfmac_f32_32x32x32_bf16 (two dout rows per instruction, compressed in registers).  Same products as the dense
