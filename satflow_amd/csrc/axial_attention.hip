@@ -520,7 +520,7 @@ int sf_axial_attention_core_fwd(sfTensor qkv, int64_t nimg, int32_t h, int32_t w
   const long long total = nimg * h * w * 2 * heads;
   if (total == 0) return 0;
   // pad lanes of att (hid..hidp) are never written by the kernel: zero them once
-  if (hid < hidp) SF_REQUIRE(hipMemsetAsync(att.ptr, 0, (size_t)nimg * h * w * att.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
+  if (hid < hidp) SF_REQUIRE(sf_fill_async(att.ptr, 0, (size_t)nimg * h * w * att.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
   const int e = hid / heads;
   const bool vec = h == w && (((uintptr_t)qkv.ptr | (uintptr_t)att.ptr) & 15) == 0 && qkv.stride % 4 == 0 && att.stride % 4 == 0 && hidp % 4 == 0;
   const dim3 grid((unsigned)((total + 255) / 256)), block(256);
@@ -548,7 +548,7 @@ int sf_axial_attention_core_bwd(sfTensor qkv, sfTensor datt, int64_t nimg, int32
   p.scale = 1.0f / sqrtf((float)(hid / heads));
   const long long total = nimg * h * w * 2 * heads;
   if (total == 0) return 0;
-  if (hid < hidp) SF_REQUIRE(hipMemsetAsync(dqkv.ptr, 0, (size_t)nimg * h * w * dqkv.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
+  if (hid < hidp) SF_REQUIRE(sf_fill_async(dqkv.ptr, 0, (size_t)nimg * h * w * dqkv.stride * sizeof(float), (hipStream_t)stream) == hipSuccess, "memset");
   const int npix = h * w;
   const int e = hid / heads;
   const bool vec = h == w && (((uintptr_t)qkv.ptr | (uintptr_t)datt.ptr | (uintptr_t)dqkv.ptr) & 15) == 0 && qkv.stride % 4 == 0 &&

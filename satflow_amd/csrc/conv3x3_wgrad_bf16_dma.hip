@@ -659,7 +659,7 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   p.tiles_x = pl.tiles_x; p.tiles_y = pl.tiles_y; p.ntiles = pl.ntiles; p.KS = pl.KS;
   p.NpT = pl.cot * DMA_CO_T; p.KpT = pl.cit * DMA_CI_T;
   // workspace: [zero page 64 floats][partial][partial_db]
-  if (hipMemsetAsync(workspace, 0, 64 * sizeof(float), st) != hipSuccess) { sf_set_error("wgrad_bf16_dma: memset failed"); return 2; }
+  if (sf_fill_async(workspace, 0, 64 * sizeof(float), st) != hipSuccess) { sf_set_error("wgrad_bf16_dma: memset failed"); return 2; }
   p.partial = workspace + 64;
   p.partial_db = p.partial + (size_t)pl.KS * pl.maxseg * 9 * p.NpT * p.KpT;
   p.tpg = pl.tpg; p.maxseg = pl.maxseg;

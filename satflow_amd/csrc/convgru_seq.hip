@@ -1239,7 +1239,7 @@ extern "C" int sf_convgru_seq_fwd(sfTensor gx, sfTensor h0, int32_t T, int32_t n
   const size_t need = sf_convgru_seq_fwd_workspace_bytes(n, h, hidp);
   const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
   // ticket counter + granule slots; word 0 (the sticky error word) belongs to the caller
-  if (have_ws && hipMemsetAsync((char*)workspace + 8, 0, need - 8, st) != hipSuccess) { sf_set_error("sf_convgru_seq_fwd: mailbox memset failed"); return 2; }
+  if (have_ws && sf_fill_async((char*)workspace + 8, 0, need - 8, st) != hipSuccess) { sf_set_error("sf_convgru_seq_fwd: mailbox memset failed"); return 2; }
   if (!no_split && nblk == 2 && h > 8 && 2 * n <= cus && have_ws) {
     p.mbox = (unsigned long long*)workspace;
     p.spin_limit = (unsigned)g_spin_limit; p.mute_half = g_mute_half;
@@ -1300,7 +1300,7 @@ extern "C" int sf_convgru_seq_bwd(sfTensor g_seq, sfTensor g_last, sfTensor gate
   }
   const size_t need = sf_convgru_seq_bwd_workspace_bytes(n, h, hidp);
   const bool have_ws = workspace && need > 0 && workspace_bytes >= need;
-  if (have_ws && hipMemsetAsync((char*)workspace + 8, 0, need - 8, st) != hipSuccess) { sf_set_error("sf_convgru_seq_bwd: mailbox memset failed"); return 2; }
+  if (have_ws && sf_fill_async((char*)workspace + 8, 0, need - 8, st) != hipSuccess) { sf_set_error("sf_convgru_seq_bwd: mailbox memset failed"); return 2; }
   if (!no_split && hidp == 64 && h > 8 && 2 * n <= cus && have_ws) {  // two workgroups per map (see sf_convgru_seq_fwd)
     p.mbox = (unsigned long long*)workspace;
     p.spin_limit = (unsigned)g_spin_limit; p.mute_half = g_mute_half;

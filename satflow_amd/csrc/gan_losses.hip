@@ -77,9 +77,9 @@ int launch(int mode, sfTensor pred, sfTensor target, float label, float label_od
   SF_REQUIRE(mode >= 0 && mode <= 3, "gan loss: mode %d (0 l1, 1 vanilla, 2 lsgan, 3 wgangp)", mode);
   SF_REQUIRE(mode != 0 || (target.ptr && target.dtype == SF_F32 && c <= target.stride), "l1 loss: target");
   SF_REQUIRE(!grad.ptr || (grad.dtype == SF_F32 && c <= grad.stride && grad.c <= grad.stride), "gan loss: grad layout");
-  if (hipMemsetAsync(sums, 0, sizeof(double) * (1 + groups), st) != hipSuccess) { sf_set_error("gan loss: memset failed"); return 2; }
+  if (sf_fill_async(sums, 0, sizeof(double) * (1 + groups), st) != hipSuccess) { sf_set_error("gan loss: memset failed"); return 2; }
   if (rows == 0) {  // an empty batch: torch's mean over nothing is NaN; never leave `out` uninitialised
-    if (hipMemsetAsync(out, 0xff, sizeof(float) * (1 + groups), st) != hipSuccess) { sf_set_error("gan loss: memset failed"); return 2; }
+    if (sf_fill_async(out, 0xff, sizeof(float) * (1 + groups), st) != hipSuccess) { sf_set_error("gan loss: memset failed"); return 2; }
     return 0;
   }
   const long long rpg = rows / groups, total = rpg * c;

@@ -102,7 +102,7 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
              "mse: n=%lld inner=%lld frames=%d", (long long)n, (long long)inner, frames);
   SF_REQUIRE(((((uintptr_t)pred) | ((uintptr_t)target) | ((uintptr_t)grad)) & 15) == 0, "mse: buffers must be 16-byte aligned");
   hipStream_t st = (hipStream_t)stream;
-  SF_REQUIRE(hipMemsetAsync(sums, 0, sizeof(double) * (1 + frames), st) == hipSuccess, "mse: memset");
+  SF_REQUIRE(sf_fill_async(sums, 0, sizeof(double) * (1 + frames), st) == hipSuccess, "mse: memset");
   const long long slabs = n / inner;
   int pieces = (int)(inner / 4096 < 16 ? inner / 4096 : 16);
   if (pieces < 1) pieces = 1;

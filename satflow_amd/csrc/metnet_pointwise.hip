@@ -568,7 +568,7 @@ static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_g
                             const float* rstd, double* sums, hipStream_t st) {
   const int C = x.c;
   SF_REQUIRE(C % 8 == 0 && C <= 2048 && ok8(x) && ok8(dy) && same_dtype(x, dy), "batchnorm: channels %d (multiple of 8, 16-byte aligned) / storage types", C);
-  hipError_t e = hipMemsetAsync(sums, 0, sizeof(double) * 2 * C * groups, st);
+  hipError_t e = sf_fill_async(sums, 0, sizeof(double) * 2 * C * groups, st);
   SF_REQUIRE(e == hipSuccess, "batchnorm: memset failed");
   const int q = C / 8, rows = 256 / q > 0 ? 256 / q : 1;
   long long chunks = pix_per_group / (rows * 16);

@@ -29,6 +29,10 @@ void sf_set_error(const char* fmt, ...);
     }                                                                      \
   } while (0)
 
+// Byte fill of device memory on a stream, implemented as a kernel (error.hip): use this, NOT hipMemsetAsync, wherever the call may be
+// captured into a hipGraph - memset nodes replayed a wrong pattern from the second graph launch on (ROCm 7.2 / gfx950).
+hipError_t sf_fill_async(void* ptr, int value, size_t bytes, hipStream_t st);
+
 // ---- MFMA C/D fragment geometry (32x32 tile, dtype independent on gfx950) --------------------
 // acc[reg] of lane l holds C[row][col] with col = l & 31, row = (reg&3) + 8*(reg>>2) + 4*(l>>5).
 __device__ __forceinline__ int frag_row(int reg, int lane_hi) { return (reg & 3) + 8 * (reg >> 2) + 4 * lane_hi; }

@@ -19,6 +19,85 @@ Tensor = torch.Tensor
 
 
 # ----------------------------------------------------------------------------------------------
+# gradient sink: weight-gradient kernels write straight into the optimizer's flat gradient buffer
+# ----------------------------------------------------------------------------------------------
+class GradSink:
+    """Where the backward kernels of this module put a PARAMETER's gradient when an optimizer has registered a destination for it
+    (``optim.FlatAdam``: the parameter's view of the flat gradient buffer): the kernel writes there and the ``Function`` hands autograd ``None``
+    for that input - the separate small ``add_`` launch autograd's AccumulateGrad would otherwise issue per parameter and step is never launched.
+
+    Same result as autograd's accumulation, by construction:
+    * a destination is handed out ONCE per parameter between two ``zero_grad()`` calls, and only during the first backward pass after
+      ``zero_grad()`` (the buffer is zero then: overwriting = accumulating); every later request - a second consumer of the parameter,
+      a second backward pass of a gradient-accumulation loop - gets ``None`` and the caller returns its gradient to autograd as before;
+    * autograd runs a parameter's AccumulateGrad node after ALL functions that consume the parameter, so an ``add_`` from another
+      consumer always lands on top of the written value, never under it;
+    * parameters no optimizer registered (tests on bare modules, frozen networks) are not in the table.
+    ``SF_NO_GRAD_SINK=1``: A/B switch (every gradient goes through autograd)."""
+
+    def __init__(self) -> None:
+        self.table: dict = {}      # (data_ptr, numel) of the parameter -> (gradient view, owner)
+        self.taken: dict = {}      # owner -> keys handed out since its zero_grad()
+        self.closed: set = set()   # owners whose first backward pass after zero_grad() is over
+        self._armed = False
+        self._pass_owners: set = set()
+        self.off = bool(os.environ.get("SF_NO_GRAD_SINK"))
+
+    def register(self, owner, param: Tensor, grad_view: Tensor) -> None:
+        import weakref
+
+        self.table[(param.data_ptr(), param.numel())] = (grad_view, id(owner), weakref.ref(owner), param.untyped_storage().data_ptr())
+        self.taken.setdefault(id(owner), set())
+
+    def unregister(self, owner) -> None:
+        self.table = {k: v for k, v in self.table.items() if v[1] != id(owner)}
+        self.taken.pop(id(owner), None)
+        self.closed.discard(id(owner))
+
+    def reopen(self, owner) -> None:
+        """``zero_grad()`` of ``owner``: its buffer is zero again."""
+        self.taken[id(owner)] = set()
+        self.closed.discard(id(owner))
+
+    def _end_of_backward(self) -> None:
+        self.closed |= self._pass_owners
+        self._pass_owners, self._armed = set(), False
+
+    def dest(self, param: Optional[Tensor]) -> Optional[Tensor]:
+        if param is None or self.off or not self.table or not param.is_contiguous():
+            return None
+        key = (param.data_ptr(), param.numel())
+        e = self.table.get(key)
+        if e is None:
+            return None
+        if e[2]() is None or param.untyped_storage().data_ptr() != e[3]:
+            # the optimizer is gone, or this tensor merely sits at an address one of its parameters had: not ours
+            del self.table[key]
+            return None
+        if e[1] in self.closed or key in self.taken[e[1]]:
+            return None
+        self.taken[e[1]].add(key)
+        self._pass_owners.add(e[1])
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        return e[0]
+
+
+GRAD_SINK = GradSink()
+
+
+def grad_out(param: Optional[Tensor], shape=None, zero: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+    """``(tensor the gradient kernel writes, value the Function returns for that input)`` for parameter ``param`` (fp32; ``shape``: the
+    kernel's view of it, e.g. OIHW with the taps split).  Call only from inside ``backward``."""
+    dst = GRAD_SINK.dest(param)
+    if dst is None:
+        t = (torch.zeros if zero else torch.empty)(tuple(shape) if shape is not None else param.shape, dtype=torch.float32, device=param.device)
+        return t, (t.reshape(param.shape) if shape is not None else t)
+    return (dst.view(tuple(shape)) if shape is not None else dst), None
+
+
+# ----------------------------------------------------------------------------------------------
 # layout ops: NCHW-side tensors <-> time-major NHWC
 # ----------------------------------------------------------------------------------------------
 class _ToNHWC(torch.autograd.Function):
@@ -226,12 +305,12 @@ class _ConvFn(torch.autograd.Function):
                 return None, d0, d1, None, None, None, None, None, None, None, None, None   # a later application's backward completes the set
             x0, gy = ctx.wbatch.take()
             n = x0.shape[0]
-        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=gy.device)
-        db = torch.empty(weight.shape[0], dtype=torch.float32, device=gy.device) if has_bias else None
+        dw4, dw_ret = grad_out(weight, (weight.shape[0], weight.shape[1], 3, 3))
+        db, db_ret = grad_out(ctx.bias) if has_bias else (None, None)
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
         K.conv3x3_bwd_weight(s0, s1, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
-        return None, d0, d1, dw4.reshape(weight.shape), db, None, None, None, None, None, None, None
+        return None, d0, d1, dw_ret, db_ret, None, None, None, None, None, None, None
 
 
 class ConvStats:
@@ -353,10 +432,10 @@ class _LeadTimePoolFn(torch.autograd.Function):
         g = g.contiguous()
         ws = torch.empty(lib().sf_leadtime_pool_workspace_floats(L, C), dtype=torch.float32, device=base.device)
         dbase = torch.empty_like(base)
-        dw1 = torch.zeros_like(w1)  # only the one-hot columns cimg..cimg+L-1 are written
+        dw1, dw1_ret = grad_out(w1, zero=True)  # only the one-hot columns cimg..cimg+L-1 are written (a sink destination is zero already)
         check(lib().sf_leadtime_pool_bwd(T(base), T(g), Fr, H, W, w1.data_ptr(), w1.shape[0], w1.shape[1], cimg, L, ws.data_ptr(), T(dbase),
                                          dw1.data_ptr(), SF_F32, stream_ptr()), "sf_leadtime_pool_bwd")
-        return dbase, dw1, None, None, None
+        return dbase, dw1_ret, None, None, None
 
 
 class PoolStats:
@@ -406,6 +485,7 @@ class _BatchNormTrainFn(torch.autograd.Function):
                                                      conv_stats.tiles * (conv_stats.n // groups), conv_stats.np, T(y), SF_F32, stream_ptr()),
                   "sf_batchnorm_train_fwd_stats")
         ctx.groups, ctx.creal = groups, creal
+        ctx.beta = beta  # (identity only: where its gradient goes)
         ctx.save_for_backward(x, gamma, stats)
         return y
 
@@ -417,12 +497,12 @@ class _BatchNormTrainFn(torch.autograd.Function):
         gy = gy.contiguous()
         dx = torch.empty_like(x)
         sums = torch.empty(ctx.groups, 2, C, dtype=torch.float64, device=x.device)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        (dgamma, dgamma_ret), (dbeta, dbeta_ret) = grad_out(gamma), grad_out(ctx.beta)
         coef = torch.empty(ctx.groups, 3, C, dtype=torch.float32, device=x.device)
         check(lib().sf_batchnorm_train_bwd(T(x), T(gy), pixels // ctx.groups, ctx.groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
                                            stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
                                            SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
-        return dx, dgamma, dbeta, None, None, None, None, None, None
+        return dx, dgamma_ret, dbeta_ret, None, None, None, None, None, None
 
 
 class _BNConvFn(torch.autograd.Function):
@@ -460,7 +540,7 @@ class _BNConvFn(torch.autograd.Function):
         w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
         packed, tab = K.conv3x3_fold_pack(w4, bias, gm, stats[2], stats[3])
         ctx.eng, ctx.groups, ctx.creal, ctx.has_bias = eng, groups, creal, bias is not None
-        ctx.bias = bias
+        ctx.bias, ctx.beta = bias, beta
         ctx.pool = pool
         if pool is not None:
             assert out_stats is None
@@ -489,11 +569,11 @@ class _BNConvFn(torch.autograd.Function):
         if gy.dtype != torch.bfloat16:
             gy = gy.to(torch.bfloat16)
         dev = gy.device
-        dw4 = torch.empty(weight.shape[0], weight.shape[1], 3, 3, dtype=torch.float32, device=dev)
-        db = torch.empty(weight.shape[0], dtype=torch.float32, device=dev) if ctx.has_bias else None
+        dw4, dw_ret = grad_out(weight, (weight.shape[0], weight.shape[1], 3, 3))
+        db, db_ret = grad_out(ctx.bias) if ctx.has_bias else (None, None)
         dx = torch.empty_like(x)
         sums = torch.empty(groups, 2, C, dtype=torch.float64, device=dev)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(gamma)
+        (dgamma, dgamma_ret), (dbeta, dbeta_ret) = grad_out(gamma), grad_out(ctx.beta)
         coef = torch.empty(groups, 3, C, dtype=torch.float32, device=dev)
         gm = eng.bwd_map((True,))
         packed_t = eng.packed(weight, ctx.bias, "bwd", (True,))[0]
@@ -515,7 +595,7 @@ class _BNConvFn(torch.autograd.Function):
                                                     stats[1].data_ptr(), coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32, stream_ptr()),
                   "sf_batchnorm_train_bwd_coef")
             K.conv3x3_bwd_data_bn(T(gy), n, H, W, packed_t, gm, T(x), coef, T(dx))
-        return None, dx, dgamma, dbeta, None, None, None, None, None, None, dw4.reshape(weight.shape), db, None, None, None
+        return None, dx, dgamma_ret, dbeta_ret, None, None, None, None, None, None, dw_ret, db_ret, None, None, None
 
 
 def bn_fold_enabled() -> bool:
@@ -628,7 +708,7 @@ class _LinearFn(torch.autograd.Function):
     def forward(ctx, x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int, lowp: bool = False):
         W = W.contiguous()
         ctx.save_for_backward(x, W)
-        ctx.has_bias, ctx.lowp = bias is not None, lowp
+        ctx.has_bias, ctx.lowp, ctx.bias = bias is not None, lowp, bias
         return K.linear_fwd(x, W, bias, out_lanes, lowp)
 
     @staticmethod
@@ -639,11 +719,18 @@ class _LinearFn(torch.autograd.Function):
         dx = None
         if ctx.needs_input_grad[0]:
             # dx = gy[..., :N] @ W : the same kernel with the transposed weight (tiny host-side transpose)
-            Wt = torch.zeros(Kp, gy.shape[-1], dtype=torch.float32, device=W.device)
-            Wt[:, :N] = W.t()
+            if gy.shape[-1] == N:
+                Wt = W.t().contiguous()
+            else:
+                Wt = torch.zeros(Kp, gy.shape[-1], dtype=torch.float32, device=W.device)
+                Wt[:, :N] = W.t()
             dx = K.linear_fwd(gy, Wt, None, Kp, ctx.lowp)
         if not (ctx.needs_input_grad[1] or (ctx.has_bias and ctx.needs_input_grad[2])):
             return dx, None, None, None, None
+        if Kp <= 256:  # (the split-K kernel writes where it is told: the parameters' own gradient slices if an optimizer registered them)
+            (dW, dW_ret), (db, db_ret) = grad_out(W), (grad_out(ctx.bias) if ctx.has_bias else (None, None))
+            K.linear_bwd_weight(gy, x, N, ctx.has_bias, out=(dW, db))
+            return dx, dW_ret, db_ret, None, None
         dW, db = K.linear_bwd_weight_any(gy, x, N, ctx.has_bias)
         return dx, dW, db, None, None
 
@@ -912,6 +999,7 @@ class _Conv2dFn(torch.autograd.Function):
         check(lib().sf_conv2d_fwd(T(x), N, H, W, w.data_ptr(), bias.data_ptr() if bias is not None else None, cin, cout, kh, kw, stride, pad, slope,
                                   T(y), SF_F32, stream_ptr()), "sf_conv2d_fwd")
         ctx.meta = (stride, pad, slope, bias is not None)
+        ctx.bias = bias
         ctx.save_for_backward(x, w, y if slope != 1.0 else x.new_empty(0))
         return y
 
@@ -931,13 +1019,12 @@ class _Conv2dFn(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             dx = torch.empty_like(x)
             check(lib().sf_conv2d_bwd_data(T(gy), N, H, W, w.data_ptr(), cin, cout, kh, kw, stride, pad, T(dx), SF_F32, stream_ptr()), "sf_conv2d_bwd_data")
-        dw = torch.empty_like(w)
-        db = torch.empty(cout, dtype=torch.float32, device=x.device) if has_bias else None
+        (dw, dw_ret), (db, db_ret) = grad_out(w), (grad_out(ctx.bias) if has_bias else (None, None))
         nbytes = lib().sf_conv2d_bwd_weight_workspace_bytes(N, oh, ow, cin, cout, kh, kw)
         ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
         check(lib().sf_conv2d_bwd_weight(T(x), T(gy), N, H, W, cin, cout, kh, kw, stride, pad, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
                                          ws.data_ptr(), nbytes, SF_F32, stream_ptr()), "sf_conv2d_bwd_weight")
-        return dx, dw, db, None, None, None
+        return dx, dw_ret, db_ret, None, None, None
 
 
 def conv2d(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int = 1, padding: int = 0, leaky_slope: float = 1.0) -> Tensor:

@@ -421,13 +421,15 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int, low
     return y
 
 
-def linear_bwd_weight(dy: Tensor, x: Tensor, N: int, want_bias: bool) -> Tuple[Tensor, Optional[Tensor]]:
+def linear_bwd_weight(dy: Tensor, x: Tensor, N: int, want_bias: bool, out: Optional[Tuple[Optional[Tensor], Optional[Tensor]]] = None) -> Tuple[Tensor, Optional[Tensor]]:
+    """``out = (dW [N, K] or None, db [N] or None)``: contiguous fp32 destinations to write instead of fresh tensors."""
     rows = x.numel() // x.shape[-1]
     K = x.shape[-1]
     nbytes = lib().sf_linear_bwd_weight_workspace_bytes(N, K, rows)
     ws = torch.empty(nbytes // 4 + 1, dtype=torch.float32, device=x.device)
-    dW = torch.empty(N, K, dtype=torch.float32, device=x.device)
-    db = torch.empty(N, dtype=torch.float32, device=x.device) if want_bias else None
+    dW = out[0] if out is not None and out[0] is not None else torch.empty(N, K, dtype=torch.float32, device=x.device)
+    db = (out[1] if out is not None and out[1] is not None else torch.empty(N, dtype=torch.float32, device=x.device)) if want_bias else None
+    assert dW.is_contiguous() and dW.numel() == N * K and (db is None or (db.is_contiguous() and db.numel() == N))
     check(lib().sf_linear_bwd_weight(T(dy), N, T(x), rows, dW.data_ptr(), db.data_ptr() if db is not None else None, ws.data_ptr(),
                                      nbytes, SF_F32, stream_ptr()), "sf_linear_bwd_weight")
     return dW, db

@@ -24,7 +24,7 @@ import torch
 from torch import nn
 
 from .. import kernels as K
-from ..functional import ConvEngine, _FromNHWC, _ToNHWC, conv3x3, nchw_to_nhwc, nhwc_to_nchw  # noqa: F401 (re-exported)
+from ..functional import ConvEngine, _FromNHWC, _ToNHWC, conv3x3, grad_out, nchw_to_nhwc, nhwc_to_nchw  # noqa: F401 (re-exported)
 from .._hip import (NULL, SF_EPI_LINEAR, SF_EPI_SIGMOID, T, cpad, gate_storage_dtype, generation, require_device, sfTensor,
                      state_storage_dtype)
 from .base import LightningModule, get_loss, register_model
@@ -166,12 +166,13 @@ class _StackFn(torch.autograd.Function):
 
         # weight gradients: one split-K GEMM per cell over all of its timesteps (Gs now hold dz)
         zeros = torch.zeros(B, H, W, hidp, dtype=Hs[0].dtype, device=dev)
-        cell_grads: List[Optional[Tuple[Tensor, Tensor]]] = [None] * 4
+        cell_grads: List[Optional[Tuple[Optional[Tensor], Optional[Tensor]]]] = [None] * 4
+        done = [False] * 4
 
         def wgrad_cell(k: int) -> None:
             eng = engines[k]
-            dw = torch.empty_like(eng.conv.weight)
-            db = torch.empty_like(eng.conv.bias)
+            # (the parameters' own gradient slices when an optimizer registered them with functional.GRAD_SINK: no add_ by autograd afterwards)
+            (dw, dw_ret), (db, db_ret) = grad_out(eng.conv.weight), grad_out(eng.conv.bias)
             steps = T_in if k < 2 else T_out
             # step 0 has a zero previous state; steps 1.. read h[t-1] straight from the sequence buffer
             if k == 0:
@@ -185,7 +186,8 @@ class _StackFn(torch.autograd.Function):
             eng.bwd_weight(T(first_in), T(zeros), T(Gs[k][0]), B, H, W, dw, db, False)
             if steps > 1:
                 eng.bwd_weight(T(rest_in), T(Hs[k][: steps - 1]), T(Gs[k][1:]), (steps - 1) * B, H, W, dw, db, True)
-            cell_grads[k] = (dw, db)
+            cell_grads[k] = (dw_ret, db_ret)
+            done[k] = True
 
         for s in range(T_out - 1, -1, -1):
             last = s == T_out - 1
@@ -258,7 +260,7 @@ class _StackFn(torch.autograd.Function):
                     dxs[t].copy_(dcat[0][..., : e1.cinp])
 
         for k in range(4):
-            if cell_grads[k] is None:
+            if not done[k]:
                 wgrad_cell(k)
         if wg_side:
             main_s.wait_stream(side_s)  # (also covers the allocator: the side stream's buffers are free for reuse on the main stream)

@@ -101,6 +101,14 @@ class FlatAdam(torch.optim.Optimizer):
             # one all-reduce after the backward pass: a backward that lands AFTER the exchange (explicit allreduce_grads(), then
             # another backward, then step()) would add rank-local gradients to the reduced sum - refuse it like the overlap path
             self._hooks = [p.register_post_accumulate_grad_hook(self._guard_hook) for p in self.params]
+        # Gradient sink (functional.GradSink): the weight-gradient kernels write a parameter's gradient straight into its slice of flat_g
+        # instead of returning a tensor that autograd adds to it (one small launch per parameter and step).  Not with an exchanging
+        # process group: there the post-accumulate hooks are what launches / guards the all-reduce, and they fire from AccumulateGrad.
+        self.direct_grads = not self.exchange
+        if self.direct_grads:
+            from .functional import GRAD_SINK
+            for p in self.params:
+                GRAD_SINK.register(self, p, p.grad)
 
     def disable_overlap(self) -> None:
         """Back to one all-reduce after the backward pass (removes the autograd hooks)."""
@@ -168,6 +176,9 @@ class FlatAdam(torch.optim.Optimizer):
     def zero_grad(self, set_to_none: bool = False) -> None:  # noqa: ARG002 (gradients are views of the flat buffer)
         self.flat_g.zero_()
         self._reduced = False
+        if self.direct_grads:
+            from .functional import GRAD_SINK
+            GRAD_SINK.reopen(self)
         if self.overlap:
             self._pending, self._work, self._done = list(self._count), {}, False
         for p, off in zip(self.params, self.offsets):  # re-attach if autograd replaced .grad
