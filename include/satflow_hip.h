@@ -31,7 +31,7 @@ extern "C" {
 #endif
 
 /* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*; 5: sf_space_to_depth2, sf_regroup5x5_s2d_*, sf_conv5x5_*, sf_linear_fwd with 16-bit operands) */
-#define SF_ABI_VERSION 6
+#define SF_ABI_VERSION 7
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */
@@ -479,6 +479,19 @@ int sf_mse_loss(const float* pred, const float* target, int64_t n, int64_t inner
  * channel quad: the backward calls the same function on the gradient with the same seeds. */
 int sf_dropout2(const float* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2,
                 float* y, sfStream stream);
+/* (ABI 7) Up to any number of two-dimensional fp32 block copies in one launch per SF_MAX_BLOCKS: dst[r * dst_stride + c] = src[r * src_stride + c]
+ * for r < rows, c < cols (strides in elements; src NULL: zeros).  `blocks` is a HOST array.  Regroups the reference's separate nn.Parameters into
+ * the matrices the fused kernels take - upstream ConvGRUCell's conv_zr over [x ; h] + conv_h1 + conv_h2 -> x-part and h-part (call site
+ * satflow/models/pl_metnet.py:46-59), the axial attention's to_q / to_kv / to_out of both axes -> one projection each - and scatters the
+ * gradients back, instead of torch.cat / slicing (9 launches per cell and step each way). */
+#define SF_MAX_BLOCKS 16
+typedef struct sfBlock {
+  const float* src;
+  float* dst;
+  int64_t rows, cols, src_stride, dst_stride;
+} sfBlock;
+int sf_copy_blocks(const sfBlock* blocks, int32_t n, sfStream stream);
+
 /* (ABI 6) The same masks on a bf16-stored tensor (x == y allowed; n a multiple of 8): the pooled encoder output of sf_conv3x3_fwd_folded_pool. */
 int sf_dropout2_bf16(const void* x, int64_t n, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* y, sfStream stream);
 

@@ -16,12 +16,17 @@ _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os
 SF_F32, SF_BF16, SF_F16 = 0, 1, 2
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 6  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
+ABI_VERSION = 7  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32), ("idiv", C.c_int32), ("imod", C.c_int32),
                 ("dtype", C.c_int32)]
+
+
+class sfBlock(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("rows", C.c_int64), ("cols", C.c_int64), ("src_stride", C.c_int64),
+                ("dst_stride", C.c_int64)]
 
 
 # name -> (restype, argtypes); mirrors include/satflow_hip.h one to one
@@ -116,6 +121,7 @@ PROTOTYPES = {
     "sf_axial_attention_core_bwd": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),
     "sf_mse_loss": (C.c_int, [_vp, _vp, _i64, _i64, _i32, _vp, _vp, _vp, _vp]),
     "sf_dropout2": (C.c_int, [_vp, _i64, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp, _vp]),
+    "sf_copy_blocks": (C.c_int, [C.POINTER(sfBlock), _i32, _vp]),
     "sf_dropout2_bf16": (C.c_int, [_vp, _i64, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp, _vp]),
     "sf_conv2d_fwd": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, _i32, _i32, _i32, C.c_float, sfTensor, _i32, _vp]),
     "sf_conv2d_bwd_data": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _i32, _i32, _i32, _i32, _i32, _i32, sfTensor, _i32, _vp]),

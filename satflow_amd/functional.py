@@ -98,6 +98,79 @@ def grad_out(param: Optional[Tensor], shape=None, zero: bool = False) -> Tuple[T
 
 
 # ----------------------------------------------------------------------------------------------
+# parameters regrouped into the matrices the fused kernels take (one launch each way: sf_copy_blocks)
+# ----------------------------------------------------------------------------------------------
+def _copy_blocks(blocks) -> None:
+    """``blocks``: [(src tensor or None, src_row0, src_col0, src_cols_total, dst tensor, dst_row0, dst_col0, dst_cols_total, rows, cols)] on fp32
+    tensors seen as 2-D ``[shape[0], numel / shape[0]]``."""
+    from ._hip import sfBlock
+
+    if not blocks:
+        return
+    arr = (sfBlock * len(blocks))()
+    for k, (src, sr, sc, sw, dst, dr, dc, dw, rows, cols) in enumerate(blocks):
+        arr[k].src = (src.data_ptr() + 4 * (sr * sw + sc)) if src is not None else None
+        arr[k].dst = dst.data_ptr() + 4 * (dr * dw + dc)
+        arr[k].rows, arr[k].cols, arr[k].src_stride, arr[k].dst_stride = rows, cols, sw, dw
+    check(lib().sf_copy_blocks(arr, len(blocks), stream_ptr()), "sf_copy_blocks")
+
+
+class _ParamBlocksFn(torch.autograd.Function):
+    """Outputs assembled from two-dimensional blocks of parameters (``torch.cat`` of slices, in one launch).  ``shapes``: the outputs' shapes;
+    ``blocks``: ``(param index or None = zeros, src_row0, src_col0, out index, dst_row0, dst_col0, rows, cols)`` with every tensor seen as
+    ``[shape[0], numel / shape[0]]``; together the blocks must cover every output exactly once.  Backward: the gradient blocks go back where they
+    came from, straight into the parameters' gradient slices when an optimizer registered them (``GRAD_SINK``)."""
+
+    @staticmethod
+    def forward(ctx, shapes, blocks, *params):
+        dev = params[0].device
+        params = tuple(p.contiguous() for p in params)
+        outs = tuple(torch.empty(tuple(sh), dtype=torch.float32, device=dev) for sh in shapes)
+        width = lambda t: t.numel() // t.shape[0]
+        area = [0] * len(outs)
+        table = []
+        for pi, sr, sc, oi, dr, dc, rows, cols in blocks:
+            src = params[pi] if pi is not None else None
+            assert src is None or (src.dtype == torch.float32 and sr + rows <= src.shape[0] and sc + cols <= width(src)), (pi, src.shape if src is not None else None)
+            assert dr + rows <= outs[oi].shape[0] and dc + cols <= width(outs[oi]), (oi, outs[oi].shape, dr, dc, rows, cols)
+            area[oi] += rows * cols
+            table.append((src, sr, sc, width(src) if src is not None else 0, outs[oi], dr, dc, width(outs[oi]), rows, cols))
+        assert all(a == o.numel() for a, o in zip(area, outs)), "the blocks must cover every output exactly once"
+        _copy_blocks(table)
+        ctx.blocks, ctx.nout = tuple(blocks), len(outs)
+        ctx.save_for_backward(*params)
+        return outs
+
+    @staticmethod
+    def backward(ctx, *gouts):
+        params = ctx.saved_tensors
+        width = lambda t: t.numel() // t.shape[0]
+        gouts = [g.contiguous() if g is not None else None for g in gouts]
+        covered = [0] * len(params)
+        for pi, sr, sc, oi, dr, dc, rows, cols in ctx.blocks:
+            if pi is not None and gouts[oi] is not None:
+                covered[pi] += rows * cols
+        dests, rets = [], []
+        for k, p in enumerate(params):
+            if not ctx.needs_input_grad[2 + k]:
+                dests.append(None), rets.append(None)
+                continue
+            d, r = grad_out(p, zero=covered[k] != p.numel())   # (a sink destination is zero where nothing is written)
+            dests.append(d), rets.append(r)
+        table = []
+        for pi, sr, sc, oi, dr, dc, rows, cols in ctx.blocks:
+            if pi is None or dests[pi] is None or gouts[oi] is None:
+                continue
+            table.append((gouts[oi], dr, dc, width(gouts[oi]), dests[pi], sr, sc, width(params[pi]), rows, cols))
+        _copy_blocks(table)
+        return (None, None, *rets)
+
+
+def param_blocks(shapes, blocks, params):
+    return _ParamBlocksFn.apply(tuple(tuple(s) for s in shapes), tuple(blocks), *params)
+
+
+# ----------------------------------------------------------------------------------------------
 # layout ops: NCHW-side tensors <-> time-major NHWC
 # ----------------------------------------------------------------------------------------------
 class _ToNHWC(torch.autograd.Function):

@@ -19,6 +19,7 @@ Execution (differs from upstream by design, same results):
 from __future__ import annotations
 
 import math
+import os
 from typing import List, Optional
 
 import torch
@@ -151,6 +152,14 @@ class ConvGRUCell(nn.Module):
         """(Wx, bx, Wh, bh): x-part [z|r|n] and h-part [z|r|h2] of the three convolutions (autograd-tracked cats)."""
         ci, hid = self.input_dim, self.hidden_dim
         wzr = self.conv_zr.weight
+        if wzr.is_cuda and not os.environ.get("SF_NO_PARAM_BLOCKS"):
+            # one launch (and one for all six gradients) instead of four cats, two copies and a fill: parameters as [rows, in * 9] blocks
+            params = (wzr, self.conv_h1.weight, self.conv_h2.weight, self.conv_zr.bias, self.conv_h1.bias, self.conv_h2.bias)
+            blocks = ((0, 0, 0, 0, 0, 0, 2 * hid, ci * 9), (1, 0, 0, 0, 2 * hid, 0, hid, ci * 9),           # Wx = [zr's x columns ; h1]
+                      (3, 0, 0, 1, 0, 0, 2 * hid, 1), (4, 0, 0, 1, 2 * hid, 0, hid, 1),                        # bx = [b_zr ; b_h1]
+                      (0, 0, ci * 9, 2, 0, 0, 2 * hid, hid * 9), (2, 0, 0, 2, 2 * hid, 0, hid, hid * 9),       # Wh = [zr's h columns ; h2]
+                      (None, 0, 0, 3, 0, 0, 2 * hid, 1), (5, 0, 0, 3, 2 * hid, 0, hid, 1))                     # bh = [0 ; b_h2]
+            return F.param_blocks(((3 * hid, ci, 3, 3), (3 * hid,), (3 * hid, hid, 3, 3), (3 * hid,)), blocks, params)
         Wx = torch.cat((wzr[:, :ci], self.conv_h1.weight), 0)
         bx = torch.cat((self.conv_zr.bias, self.conv_h1.bias), 0)
         Wh = torch.cat((wzr[:, ci:], self.conv_h2.weight), 0)
@@ -235,11 +244,18 @@ class AxialAttention(nn.Module):
             w = w.view(parts, hid, w.shape[1])
             return torch.nn.functional.pad(w, (0, 0, 0, hidp - hid)).reshape(parts * hidp, -1)
 
-        w_in = torch.cat((lanes(a0.to_q.weight, 1), lanes(a0.to_kv.weight, 2), lanes(a1.to_q.weight, 1), lanes(a1.to_kv.weight, 2)), 0)
+        if hid == hidp and x.is_cuda and not os.environ.get("SF_NO_PARAM_BLOCKS"):
+            # both projection matrices (and all six weight gradients) in one sf_copy_blocks launch each way
+            params = (a0.to_q.weight, a0.to_kv.weight, a1.to_q.weight, a1.to_kv.weight, a0.to_out.weight, a1.to_out.weight)
+            blocks = ((0, 0, 0, 0, 0, 0, hid, hid), (1, 0, 0, 0, hid, 0, 2 * hid, hid), (2, 0, 0, 0, 3 * hid, 0, hid, hid), (3, 0, 0, 0, 4 * hid, 0, 2 * hid, hid),
+                      (4, 0, 0, 1, 0, 0, hid, hid), (5, 0, 0, 1, 0, hid, hid, hid))
+            w_in, w_out = F.param_blocks(((6 * hid, hid), (hid, 2 * hid)), blocks, params)
+        else:
+            w_in = torch.cat((lanes(a0.to_q.weight, 1), lanes(a0.to_kv.weight, 2), lanes(a1.to_q.weight, 1), lanes(a1.to_kv.weight, 2)), 0)
+            pad_k = lambda w: w if hid == hidp else torch.nn.functional.pad(w, (0, hidp - hid))
+            w_out = torch.cat((pad_k(a0.to_out.weight), pad_k(a1.to_out.weight)), 1)  # [hid, 2*hidp]
         qkv = F.linear(x, w_in, None, 6 * hidp)
         att = F.attention_core(qkv, hid, self.heads)  # [n,h,w,2*hidp] = [axis0 | axis1]
-        pad_k = lambda w: w if hid == hidp else torch.nn.functional.pad(w, (0, hidp - hid))
-        w_out = torch.cat((pad_k(a0.to_out.weight), pad_k(a1.to_out.weight)), 1)  # [hid, 2*hidp]
         return F.linear(att, w_out, a0.to_out.bias + a1.to_out.bias, hidp)
 
     def forward(self, x: Tensor) -> Tensor:

@@ -115,6 +115,11 @@ int main(void) {
   REFUSED(sf_mse_loss(ok, ok, 100, 7, 3, 0, ok, ok, st));                                            /* n not divisible into frames */
   REFUSED(sf_dropout2(ok, 64, 1.0f, 0.f, 64, 1, 2, ok, st));                                         /* p >= 1 */
   REFUSED(sf_dropout2(ok, 64, 0.1f, 0.1f, 30, 1, 2, ok, st));                                        /* period not a multiple of 4 */
+  { sfBlock bad = {ok, ok, 4, 8, 4, 8};   /* source rows narrower than the block */
+    REFUSED(sf_copy_blocks(&bad, 1, st));
+    REFUSED(sf_copy_blocks(0, 1, st));     /* no table */
+    sfBlock nodst = {ok, 0, 4, 8, 8, 8};
+    REFUSED(sf_copy_blocks(&nodst, 1, st)); }
   REFUSED(sf_dropout2_bf16(ok, 60, 0.1f, 0.1f, 64, 1, 2, ok, st));                                   /* n not a multiple of 8 */
   REFUSED(sf_dropout2_bf16(ok, 64, 0.1f, 1.0f, 64, 1, 2, ok, st));                                   /* p >= 1 */
   /* CloudGAN side network */
