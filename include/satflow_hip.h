@@ -216,10 +216,15 @@ int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t
  * entry point cannot check 1.2 GB cheaply): a dout that breaks it is multiplied wrongly.  sf_conv3x3_bwd_weight_folded_sparse24_supported (Np = dout lanes,
  * Kp = src lanes): 1 if the shape takes the path (even h, w; regular 128 x 64 slabs), else call sf_conv3x3_bwd_weight_folded.  Same workspace. */
 int32_t sf_conv3x3_bwd_weight_folded_sparse24_supported(int32_t Np, int32_t Kp, int32_t n, int32_t h, int32_t w, int32_t groups);
+/* (ABI 7) pooled_dout / route / perm_l / perm_t: optionally the INPUTS of the sf_maxpool2_route_bwd call that produced dout - the pooled gradient (bf16,
+ * dout's lanes, [n][h/2][w/2] in the pooling's output image order), the routing record and the pooling's outer permutation.  With them (and whole 4 x 16
+ * pixel tiles, lanes in whole 128-channel tiles) the matrix kernel builds its sparse operand from 4.5 KB of pooled data per K tile instead of reading 16 KB
+ * of dout, which then only the small border-sum helper reads.  pooled_dout.ptr NULL: from dout.  Same results either way. */
 int sf_conv3x3_bwd_weight_folded_sparse24(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap,
                                  const int32_t* kmap, int32_t O, int32_t I, const float* scale, const float* shift,
                                  int32_t groups, float* dw, float* db, int32_t accumulate, const float* weight,
-                                 const float* mean, const float* rstd, double* bn_sums, void* workspace,
+                                 const float* mean, const float* rstd, double* bn_sums, sfTensor pooled_dout, const void* route,
+                                 int32_t perm_l, int32_t perm_t, void* workspace,
                                  size_t workspace_bytes, int32_t dtype, sfStream stream);
 /* Input gradient of the same convolution THROUGH the folded BatchNorm in one launch: dx = A_g * conv^T(dout, W) + B_g * x + K_g
  * with coef [groups][3][x.c] = (A, B, K) from sf_batchnorm_train_bwd_coef (the affine form of the training-mode BatchNorm
@@ -295,9 +300,11 @@ int sf_maxpool2_dropout_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, in
  * pass neither keeps nor re-reads the input tensor (the DownSampler's last pooling: 1.2 GB at the benchmark size). */
 int sf_maxpool2_route_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l, int32_t perm_t, float p1,
                           float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* route, int32_t dtype, sfStream stream);
+/* (ABI 7) masked_dout (nullable): also stores the pooled gradient AFTER the dropout masks, laid out like dout - the operand source of
+ * sf_conv3x3_bwd_weight_folded_sparse24's pooled form. */
 int sf_maxpool2_route_bwd(const void* route, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l,
-                          int32_t perm_t, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype,
-                          sfStream stream);
+                          int32_t perm_t, float p1, float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* masked_dout,
+                          int32_t dtype, sfStream stream);
 
 /* nn.BatchNorm2d of the DownSampler.  Training mode: `groups` independent batches of
  * pix_per_group pixels each (one per lead time: the reference calls the encoder once per lead

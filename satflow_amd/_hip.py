@@ -66,7 +66,8 @@ PROTOTYPES = {
     "sf_conv3x3_bwd_weight_folded_sparse24_supported": (_i32, [_i32] * 6),
     "sf_conv3x3_bwd_weight_folded_sparse24": (
         C.c_int,
-        [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, _vp, _sz, _i32, _vp],
+        [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _vp, _vp, _i32, _vp, _vp, _i32, _vp, _vp, _vp, _vp, sfTensor, _vp, _i32, _i32,
+         _vp, _sz, _i32, _vp],
     ),
     "sf_conv3x3_bwd_data_bn": (C.c_int, [sfTensor, _i32, _i32, _i32, _vp, _i32, _i32, sfTensor, _vp, _i32, sfTensor, _i32, _vp]),
     "sf_batchnorm_train_bwd_coef": (C.c_int, [_vp, _i64, _i32, _i32, _i32, _vp, _vp, _vp, _vp, _vp, _vp, _i32, _vp]),
@@ -82,7 +83,7 @@ PROTOTYPES = {
     "sf_maxpool2_route_fwd": (C.c_int, [sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64, _vp,
                                         _i32, _vp]),
     "sf_maxpool2_route_bwd": (C.c_int, [_vp, sfTensor, _i64, _i32, _i32, sfTensor, _i32, _i32, C.c_float, C.c_float, _i64, C.c_uint64, C.c_uint64,
-                                        _i32, _vp]),
+                                        _vp, _i32, _vp]),
     "sf_leadtime_pool_workspace_floats": (_sz, [_i32, _i32]),
     "sf_stlstm_gates_fwd": (C.c_int, [sfTensor] * 5 + [_i64, _i32, C.c_float] + [sfTensor] * 7 + [_i32, _vp]),
     "sf_stlstm_gates_bwd": (C.c_int, [sfTensor] * 9 + [_i64, _i32] + [sfTensor] * 5 + [_i32, _vp]),

@@ -89,7 +89,7 @@ __device__ __forceinline__ void* uniform_ptr(const void* q) {
 // its position bit - into 4 values + 2 index nibbles, rows r and r + 2 share an instruction; the dense operand is the halo rows (a, a + 2) read by the two
 // lane halves (the lane's 16 pixels of ITS row: four transposing reads).  18 instead of 36 matrix instructions per tile, the same products (zeros are
 // skipped), 48 instead of 36 fragment reads.  A dout that breaks the structure would be multiplied WRONGLY: the entry point is a separate one.
-template <bool FAST, bool GROUPED, int GEO, bool SPARSE = false>
+template <bool FAST, bool GROUPED, int GEO, int SPARSE = 0>   // SPARSE: 0 dense, 1 dout as the 2:4-sparse operand, 2 the same operand from the POOLED gradient + routing record
 __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int per_slice, const char* __restrict__ zero, char* lds, const int ks,
                                                const int cot, const int cit) {
   static_assert(GEO == 0 || FAST, "the edge geometries use the descriptor DMA path");
@@ -100,7 +100,11 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   constexpr int B_BYTES = GEO == 1 ? 8192 : GEO == 2 ? 32768 : 16384;                   // 108 px x B_PIX, padded to whole 8-block rounds
   constexpr int STAGE = A_BYTES + B_BYTES;
   constexpr int NS = WIDE ? 3 : ::NS_REG;                     // ring depth
-  constexpr int NA = A_BYTES / 1024 / 8, NBK = B_BYTES / 1024 / 8, NDMA = NA + NBK;  // DMA instructions per wave and tile: 2 + 2 / 4 + 1 / 1 + 4
+  constexpr bool POOLED = SPARSE == 2;
+  static_assert(!POOLED || (FAST && GEO == 0), "the pooled operand is built for the regular slabs of the descriptor DMA path");
+  // DMA instructions per wave and tile: 2 + 2 / 4 + 1 / 1 + 4; POOLED: ONE for the sparse operand's sources (waves 0-3: the pooled gradient's 4 KB,
+  // wave 4: 512 bytes of routing codes, waves 5-7: an all-out-of-range instruction that only keeps the counted waits uniform) + 2
+  constexpr int NA = POOLED ? 1 : A_BYTES / 1024 / 8, NBK = B_BYTES / 1024 / 8, NDMA = NA + NBK;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -224,6 +228,28 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   }
   const unsigned b_pxb = 2u * (unsigned)bs;
   const long long b_img = (long long)p.H * p.W * b_pxb;
+  // POOLED: this lane's piece of the tile's 2 x 8 pooled pixels.  Waves 0-3: piece P = 64 wave + lane = pooled pixel P / 16 (row P / 128, column (P / 16) % 8),
+  // 16-byte channel piece P % 16 in physical quarter (P % 16) / 4 carrying logical quarter ^ (pixel & 3) - the dense layout's swizzle, [pixel][256 B] at the
+  // stage's origin; wave 4, lanes 0-31: routing codes of pooled pixel lane / 2, octets 8 (lane % 2) .. + 7 of this co tile, [pixel][32 B] at + 4096
+  const int Hp = p.H >> 1, Wp = p.W >> 1;
+  [[maybe_unused]] unsigned pa_voff = SENT;
+  [[maybe_unused]] const long long g_img = (long long)Hp * Wp * p.pool_s * 2, r_img = (long long)Hp * Wp * (p.dc >> 3) * 2;
+  if constexpr (POOLED) {
+    if (wave < 4) {
+      const int P = 64 * wave + lane, pp = P >> 4, c16 = P & 15;
+      const int ch = cot * DMA_CO_T + (((c16 >> 2) ^ (pp & 3)) * 32) + (c16 & 3) * 8;
+      if (ch < p.dc) pa_voff = (unsigned)((((pp >> 3) * Wp + (pp & 7)) * p.pool_s + ch) * 2);
+    } else if (wave == 4 && lane < 32) {
+      const int pp = lane >> 1, oct = cot * (DMA_CO_T / 8) + (lane & 1) * 8;
+      if (oct * 8 < p.dc) pa_voff = (unsigned)((((pp >> 3) * Wp + (pp & 7)) * (p.dc >> 3) + oct) * 2);
+    }
+  }
+  auto pooled_image = [&](int n) {   // the pooling's outer permutation of the image index
+    if (p.pool_L == 0) return n;
+    const int b = n % p.pool_B, t = (n / p.pool_B) % p.pool_T, l = n / (p.pool_B * p.pool_T);
+    return (t * p.pool_L + l) * p.pool_B + b;
+  };
+  [[maybe_unused]] int nx_ng = POOLED ? pooled_image(nx_n) : 0;
   auto issue_fast = [&]() {
     const bool live = nx_i < my_tiles;
     const int n = nx_n, px0 = (nx_ty * TR) * p.W + nx_tx * TW;
@@ -233,6 +259,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     const __amdgpu_buffer_rsrc_t rsa = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.dout + n * a_img), 0, __builtin_amdgcn_readfirstlane((int)a_img), 0x00020000);
     const unsigned soa = (unsigned)px0 * (unsigned)a_pxb;
     const int rows_left = p.H - nx_ty * TR, cols_left = p.W - nx_tx * TW;
+    if constexpr (POOLED) {
+      const unsigned pix0 = (unsigned)((nx_ty * (TR / 2)) * Wp + nx_tx * (TW / 2));
+      const __amdgpu_buffer_rsrc_t rsg = wave < 4
+          ? __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.pool_g + nx_ng * g_img), 0, __builtin_amdgcn_readfirstlane((int)g_img), 0x00020000)
+          : __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.pool_route + n * r_img), 0, __builtin_amdgcn_readfirstlane((int)r_img), 0x00020000);
+      bufdma16(live ? pa_voff : SENT, rsg, pix0 * (unsigned)(wave < 4 ? p.pool_s * 2 : (p.dc >> 3) * 2), stage + wave * 1024);
+    } else
 #pragma unroll
     for (int u = 0; u < NA; ++u) {
       const int a = wave + 8 * u, row_a = (PPB * a) >> 4, x_a = (PPB * a) & 15;
@@ -257,7 +290,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
 #endif
     ++nx_i;
     nx_stage = nx_stage + 1 == NS ? 0 : nx_stage + 1;
-    if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; } }
+    if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; if constexpr (POOLED) nx_ng = pooled_image(nx_n); } }
   };
   auto issue = [&]() {
     if constexpr (FAST) issue_fast(); else issue_slow();
@@ -461,6 +494,41 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     sp.i13 = (int)(nb[1] | (nb[3] << 8));
     sp.bias = bs_;
   };
+  // POOLED: the same two operands from the pooled gradient and the routing codes.  A lane (channel i of its fragment, half h) needs the tile's pooled
+  // pixels 4h .. 4h + 3 of both pooled rows: one transposing read each (4 values = 4 windows of the lane's channel) and the 8 windows' code words (the
+  // lane's octet; lanes of an octet read the same address).  Window (pr, pc) with code 2 dy + dx puts g at dense pixel (2 pr + dy, 2 pc + dx): it is the
+  // (possibly zero) survivor of pixel PAIR pc in dense row 2 pr + dy - so slot s of K block h (dense row dy) / block 2 + h (dense row 2 + dy) holds
+  // dy == code.dy ? g : 0, and the pair's position bit is dx for both dense rows: rows (0, 2) and (1, 3) share ONE index word.
+  const unsigned ap_base = lds0 + (4 * khalf + m) * 256 + ((wq ^ m) * 64) + cbyte;                       // + pooled row * 2048
+  const unsigned cp_base = lds0 + 4096 + (4 * khalf) * 32 + (4 * wq + ((lane & 31) >> 3)) * 2;           // + (pooled row * 8 + s) * 32
+  const unsigned csh = 2u * (lane & 7);
+  auto load_pooled = [&](unsigned so, SpA& sp) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
+    const unsigned ag = (ap_base + so) & 0x3ffffu, ac = (cp_base + so) & 0x3ffffu;
+    const u32x2 g0 = __builtin_bit_cast(u32x2, tr_read(ag)), g1 = __builtin_bit_cast(u32x2, tr_read(ag + 2048));
+    unsigned code[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) code[s] = ((unsigned)*(lds_u16)(uintptr_t)(ac + ((s >> 2) * 8 + (s & 3)) * 32) >> csh) & 3u;
+    const unsigned gd[4] = {g0[0], g0[1], g1[0], g1[1]};   // slots (0, 1), (2, 3) of pooled row 0, (4, 5), (6, 7) of pooled row 1
+    unsigned v02[4], v13[4], idx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned ce = code[2 * q], co = code[2 * q + 1];
+      const unsigned keep1 = ((ce & 2u) ? 0x0000ffffu : 0u) | ((co & 2u) ? 0xffff0000u : 0u);   // halves whose window routed to its LOWER row (dy = 1)
+      v13[q] = gd[q] & keep1;
+      v02[q] = gd[q] & ~keep1;
+      idx |= ((ce & 1u) | ((2u + (co & 1u)) << 2)) << (4 * q);
+    }
+    sp.a02 = __builtin_bit_cast(bf16x8, u32x4{v02[0], v02[1], v02[2], v02[3]});
+    sp.a13 = __builtin_bit_cast(bf16x8, u32x4{v13[0], v13[1], v13[2], v13[3]});
+    sp.i02 = sp.i13 = (int)idx;
+    float bs_ = 0.f;
+    if (want_bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bs_ += __builtin_bit_cast(float, gd[q] << 16) + __builtin_bit_cast(float, gd[q] & 0xffff0000u);
+    }
+    sp.bias = bs_;
+  };
 #ifdef SF_EXP_WG_NOSB   // experiment: leave the interleaving of fragment reads, compression and matrix instructions to the compiler
 #define SF_SPARSE_SB
 #else
@@ -483,13 +551,14 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     if (!stage_late) issue();
     // the next tile's dout rows are requested NOW (its stage is visible behind the barrier) and compressed under the six instructions of step 2
     unsigned nA, nBS[3];
+    const unsigned nso = (unsigned)(rd_stage * STAGE);
     stage_addr_s(nA, nBS);
-    bf16x8 rows[TR];
-    load_a(nA, rows);
+    [[maybe_unused]] bf16x8 rows[TR];
+    if constexpr (!POOLED) load_a(nA, rows);
     SF_SPARSE_SB;
     smf(cur.a02, cur.i02, 2, sq0);
     smf(cur.a13, cur.i13, 1, sq0);
-    compress_rows(rows, nxt);
+    if constexpr (POOLED) load_pooled(nso, nxt); else compress_rows(rows, nxt);
     SF_SPARSE_SB;
     load_b16(nBS, 0, sq0);
     if (stage_late) issue();
@@ -539,10 +608,14 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   if constexpr (SPARSE) {
     {
       unsigned sA;
+      const unsigned so0 = (unsigned)(rd_stage * STAGE);
       stage_addr_s(sA, aBS);
-      bf16x8 rows0[TR];
-      load_a(sA, rows0);
-      compress_rows(rows0, spa);
+      if constexpr (POOLED) load_pooled(so0, spa);
+      else {
+        bf16x8 rows0[TR];
+        load_a(sA, rows0);
+        compress_rows(rows0, spa);
+      }
       load_b16(aBS, 0, sq0);
     }
     for (int i = 0; i < my_tiles; i += 2) {
@@ -564,7 +637,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
 // slab per PAIR of co tiles of the last ci tile; edge_mode 2: one GEO-2 slab per PAIR of ci tiles of the last co tile, a leftover ci tile stays
 // regular).  The slabs of one K slice are consecutive on one XCD (blocks are dealt round-robin to the 8 XCDs), so a slice's tiles are shared
 // through that XCD's L2 (pure speed choice).
-template <bool FAST, bool GROUPED = false, bool SPARSE = false>
+template <bool FAST, bool GROUPED = false, int SPARSE = 0>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
                                                                      const int xcd_groups, const int cot_n, const int cit_n, const int edge_mode) {
   __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
@@ -671,7 +744,14 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
   if (p.sparse24 && (!fast || pl.edge_mode != 0 || (p.W & 1))) { sf_set_error("wgrad_bf16_dma: the 2:4-sparse path takes regular slabs of a single-source launch with an even image width"); return 1; }
   if (pl.tpg > 0) {
     if (!fast) { sf_set_error("wgrad_bf16_dma: grouped slices need a single input source"); return 1; }
-    if (p.sparse24) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
+    if (p.sparse24 == 2) {
+      if (!p.pool_g || !p.pool_route || (p.H % TR) || (p.W % TW) || (p.dc % 8) || (p.pool_s % 8) || (p.pool_L > 0 && (p.pool_T <= 0 || p.pool_B <= 0 || p.N != p.pool_L * p.pool_T * p.pool_B)) ||
+          (long long)(p.H / 2) * (p.W / 2) * p.pool_s * 2 >= (1ll << 31)) {
+        sf_set_error("wgrad_bf16_dma: the pooled sparse operand needs the pooled gradient + routing record, whole 4 x 16 tiles and a permutation that covers n");
+        return 1;
+      }
+      hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true, 2>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
+    } else if (p.sparse24) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true, 1>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
     else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
   } else if (p.sparse24) { sf_set_error("wgrad_bf16_dma: the 2:4-sparse path is built for the grouped (folded BatchNorm) launches"); return 1; }
   else if (fast) hipLaunchKernelGGL(wgrad_bf16_dma_kernel<true>, grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);

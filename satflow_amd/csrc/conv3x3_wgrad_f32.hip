@@ -436,7 +436,8 @@ size_t sf_conv3x3_bwd_weight_folded_workspace_bytes(int32_t Np, int32_t Kp, int3
 static int bwd_weight_folded_impl(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
                                   int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
                                   int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
-                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream, int sparse24);
+                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream, int sparse24, sfTensor pooled = sfTensor{},
+                                  const void* route = nullptr, int32_t perm_l = 0, int32_t perm_t = 0);
 
 int sf_conv3x3_bwd_weight_folded(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
                                  int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
@@ -456,17 +457,21 @@ int32_t sf_conv3x3_bwd_weight_folded_sparse24_supported(int32_t Np, int32_t Kp, 
 int sf_conv3x3_bwd_weight_folded_sparse24(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
                                           int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
                                           int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
+                                          sfTensor pooled_dout, const void* route, int32_t perm_l, int32_t perm_t,
                                           void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
   SF_REQUIRE(sf_conv3x3_bwd_weight_folded_sparse24_supported(dout.c, src.c, n, h, w, groups),
              "sf_conv3x3_bwd_weight_folded_sparse24: shape not taken by the 2:4-sparse path (ask sf_conv3x3_bwd_weight_folded_sparse24_supported)");
+  static const bool no_pooled = getenv("SF_NO_WGRAD_POOLED") != nullptr;   // A/B switch: build the sparse operand from dout even when the pooled form is given
+  const bool pooled = pooled_dout.ptr && !no_pooled && h % 4 == 0 && w % 16 == 0 && dout.c % 128 == 0;
   return bwd_weight_folded_impl(src, dout, n, h, w, nmap, kmap, O, I, scale, shift, groups, dw, db, accumulate, weight, mean, rstd, bn_sums, workspace,
-                                workspace_bytes, dtype, stream, 1);
+                                workspace_bytes, dtype, stream, pooled ? 2 : 1, pooled_dout, route, perm_l, perm_t);
 }
 
 static int bwd_weight_folded_impl(sfTensor src, sfTensor dout, int32_t n, int32_t h, int32_t w, const int32_t* nmap, const int32_t* kmap,
                                   int32_t O, int32_t I, const float* scale, const float* shift, int32_t groups, float* dw, float* db,
                                   int32_t accumulate, const float* weight, const float* mean, const float* rstd, double* bn_sums,
-                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream, int sparse24) {
+                                  void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream, int sparse24, sfTensor pooled,
+                                  const void* route, int32_t perm_l, int32_t perm_t) {
   SF_REQUIRE(dtype == SF_BF16 && src.ptr && dout.ptr && src.dtype == SF_BF16 && dout.dtype == SF_BF16,
              "sf_conv3x3_bwd_weight_folded: bf16-stored tensors and the SF_BF16 kernels only");
   SF_REQUIRE(groups >= 1 && n % groups == 0 && h >= 2 && w >= 2, "bwd_weight_folded: n=%d must split into %d groups of whole images, h, w >= 2", n, groups);
@@ -486,6 +491,14 @@ static int bwd_weight_folded_impl(sfTensor src, sfTensor dout, int32_t n, int32_
   p.dout = (const float*)dout.ptr; p.dc = dout.c; p.ds = dout.stride;
   p.N = n; p.H = h; p.W = w;
   p.sparse24 = sparse24;
+  if (sparse24 == 2) {
+    SF_REQUIRE(pooled.ptr && route && pooled.dtype == SF_BF16 && pooled.c == dout.c && pooled.idiv <= 1 && pooled.imod <= 0,
+               "bwd_weight_folded_sparse24: the pooled gradient must be a bf16 tensor of dout's lanes, with the routing record");
+    SF_REQUIRE((perm_l == 0 && perm_t == 0) || (perm_l > 0 && perm_t > 0 && n % (perm_l * perm_t) == 0),
+               "bwd_weight_folded_sparse24: n=%d not divisible by the pooling's permutation %d x %d", n, perm_l, perm_t);
+    p.pool_g = pooled.ptr; p.pool_s = pooled.stride; p.pool_route = (const unsigned short*)route;
+    p.pool_L = perm_l; p.pool_T = perm_t; p.pool_B = perm_l > 0 ? n / (perm_l * perm_t) : 0;
+  }
   if (int rc = sf_launch_wgrad_bf16_dma(p, pl, (float*)workspace, st)) return rc;
   float* bpart = (float*)workspace + fl.bpart_off;
   float* V = (float*)workspace + fl.v_off;

@@ -200,7 +200,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const TI* __restrict__
 template <typename TI, typename TO, bool DROP>  // TI: input and its gradient, TO: pooled output's gradient
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__ in, int is, const TO* __restrict__ dout, int dos,
                                                           long long N, int H, int W, int C, TI* __restrict__ din, int dis,
-                                                          const OuterPerm pm, const sfDrop dr, long long npt, const unsigned short* __restrict__ route) {
+                                                          const OuterPerm pm, const sfDrop dr, long long npt, const unsigned short* __restrict__ route,
+                                                          TO* __restrict__ gmask) {
   const int Ho = H / 2, Wo = W / 2, q = C / 8;
   const long long total = N * Ho * Wo * q;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
@@ -222,6 +223,8 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
       const unsigned long long pixq = (unsigned long long)((yo * Wo + xo) * (C / 4) + c / 4), imgq = (unsigned long long)Ho * Wo * (C / 4);
       g = g * drop_scales8(dr, (unsigned long long)no * imgq + pixq, (unsigned long long)(no % npt) * imgq + pixq);
     }
+    // the masked pooled gradient itself (stored like dout): what the 2:4-sparse weight gradient builds its operand from instead of reading din
+    if (gmask) stv8(gmask + ((no * Ho + yo) * Wo + xo) * dos + c, g);
     f32x8_t g0, g1, g2, g3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -466,7 +469,7 @@ int sf_metnet_preprocess_bwd(sfTensor dout, int32_t B, int32_t T, int32_t C, int
 }
 
 static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t,
-                          const sfDrop* drop, int64_t period, hipStream_t st, void* route = nullptr) {
+                          const sfDrop* drop, int64_t period, hipStream_t st, void* route = nullptr, void* gmask = nullptr) {
   sfTensor& out = dout_or_out;
   if (bwd && route && !in.ptr) { in = din; in.ptr = din.ptr; }  // routing recorded: the input tensor is only described (never read)
   SF_REQUIRE(!route || ((uintptr_t)route & 1) == 0, "maxpool2: route must be 2-byte aligned");
@@ -493,7 +496,8 @@ static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n
 #define SF_MP(TI_, TO_, DROP_)                                                                                                                   \
   do {                                                                                                                                            \
     if (bwd) hipLaunchKernelGGL((maxpool_bwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (const TO_*)out.ptr,   \
-                                out.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm, dr, npt, (const unsigned short*)route); \
+                                out.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm, dr, npt, (const unsigned short*)route,   \
+                                (TO_*)gmask);                                                                                                    \
     else hipLaunchKernelGGL((maxpool_fwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (long long)n, h, w, in.c,   \
                             (TO_*)out.ptr, out.stride, pm, dr, npt, (unsigned short*)route);                                                     \
   } while (0)
@@ -554,14 +558,15 @@ int sf_maxpool2_route_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor
 }
 
 int sf_maxpool2_route_bwd(const void* route, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din, int32_t perm_l, int32_t perm_t, float p1,
-                          float p2, int64_t period, uint64_t seed1, uint64_t seed2, int32_t dtype, sfStream stream) {
+                          float p2, int64_t period, uint64_t seed1, uint64_t seed2, void* masked_dout, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_maxpool2_route_bwd: dtype %d not built", dtype);
   SF_REQUIRE(route != nullptr && din.ptr != nullptr, "sf_maxpool2_route_bwd: route / din must not be null");
+  SF_REQUIRE(!masked_dout || ((uintptr_t)masked_dout & 15) == 0, "sf_maxpool2_route_bwd: masked_dout must be 16-byte aligned");
   sfTensor none{};
-  if (p1 == 0.f && p2 == 0.f) return maxpool_launch(true, none, dout, n, h, w, din, perm_l, perm_t, nullptr, 0, (hipStream_t)stream, (void*)route);
+  if (p1 == 0.f && p2 == 0.f) return maxpool_launch(true, none, dout, n, h, w, din, perm_l, perm_t, nullptr, 0, (hipStream_t)stream, (void*)route, masked_dout);
   if (int rc = check_drop(p1, p2)) return rc;
   const sfDrop d = sf_make_drop(p1, p2, seed1, seed2);
-  return maxpool_launch(true, none, dout, n, h, w, din, perm_l, perm_t, &d, period, (hipStream_t)stream, (void*)route);
+  return maxpool_launch(true, none, dout, n, h, w, din, perm_l, perm_t, &d, period, (hipStream_t)stream, (void*)route, masked_dout);
 }
 
 static int bn_reduce_launch(int mode, sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups, const float* mean,

@@ -24,7 +24,11 @@ struct WgradParams {
   // all-bf16 kernel (regular slabs): dout holds AT MOST ONE non-zero per aligned horizontal pixel pair and channel - the gradient behind a 2x2 / stride-2
   // max-pooling - so any four consecutive pixels of a row hold at most two: the 2:4 structured-sparse MFMA (v_smfmac_f32_32x32x32_bf16) takes dout as its
   // sparse operand, half the matrix instructions for the same products (sf_conv3x3_bwd_weight_folded_sparse24)
+  // 2: the POOLED form of the same launch - the sparse operand is built from the pooled gradient g [n'][H/2][W/2][pool_s] (bf16; image n' = the pooling's
+  // outer permutation of n: (l T + t) B + b -> (t L + l) B + b, pool_L == 0: identity) and the pooling's routing record [n][H/2][W/2][dc/8] (2 bits per
+  // channel: 2 dy + dx of the window element that took the maximum) instead of from dout, which this kernel then does not read: 4.5 KB per K tile, not 16
   int sparse24;
+  const void* pool_g; const unsigned short* pool_route; int pool_s, pool_L, pool_T, pool_B;
 };
 
 

@@ -633,9 +633,16 @@ class _BNConvFn(torch.autograd.Function):
             gy = gy.contiguous()
             if gy.dtype != torch.bfloat16:
                 gy = gy.to(torch.bfloat16)
-            gy = K.maxpool2_route_bwd(route, gy, (x.shape[0], x.shape[1], x.shape[2], eng.coutp), torch.bfloat16, ctx.pool[0], ctx.pool[1])
+            # (without dropout in the routing kernel the weight gradient can build its sparse operand from the pooled gradient + codes themselves)
+            # (... after the dropout masks, which the routing kernel applies on the way: it leaves the masked pooled gradient behind as well)
+            dropped = ctx.pool[1] is not None and (ctx.pool[1][0] > 0 or ctx.pool[1][1] > 0)
+            use_pooled = K.conv3x3_bwd_weight_pooled_supported(eng.coutp, x.shape[-1], x.shape[0], x.shape[1], x.shape[2], ctx.groups)
+            masked = torch.empty_like(gy) if dropped and use_pooled else None
+            pooled = (masked if masked is not None else gy, route, ctx.pool[0]) if use_pooled else None
+            gy = K.maxpool2_route_bwd(route, gy, (x.shape[0], x.shape[1], x.shape[2], eng.coutp), torch.bfloat16, ctx.pool[0], ctx.pool[1], masked)
         else:
             x, gamma, stats, weight = ctx.saved_tensors
+            pooled = None
         n, H, W, C = x.shape
         groups = ctx.groups
         gy = gy.contiguous()
@@ -663,7 +670,7 @@ class _BNConvFn(torch.autograd.Function):
             # gradient convolution applies dx = A dn + B x + K in its epilogue.
             w4 = weight.reshape(weight.shape[0], weight.shape[1], 3, 3)
             K.conv3x3_bwd_weight_folded(T(x), T(gy), n, H, W, eng.wgrad_map, stats[2], stats[3], dw4, db, bn=(w4, stats[0], stats[1], sums),
-                                        pooled_gradient=ctx.pool is not None)   # (gy then comes out of maxpool2_route_bwd just above)
+                                        pooled_gradient=ctx.pool is not None, pooled=pooled)   # (gy then comes out of maxpool2_route_bwd just above)
             check(lib().sf_batchnorm_train_bwd_coef(sums.data_ptr(), (n * H * W) // groups, groups, C, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
                                                     stats[1].data_ptr(), coef.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr(), SF_F32, stream_ptr()),
                   "sf_batchnorm_train_bwd_coef")

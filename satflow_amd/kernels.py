@@ -279,17 +279,31 @@ def conv3x3_fold_supported(n: int, h: int, w: int, gm: GemmMap, groups: int, sta
     return h >= 2 and w >= 2 and n % groups == 0 and (h > 16 or stats or gm.nf < 4 or n < 512) and table_lds <= 64 * 1024
 
 
+def conv3x3_bwd_weight_pooled_supported(np_: int, kp: int, n: int, h: int, w: int, groups: int) -> bool:
+    """Will ``conv3x3_bwd_weight_folded(..., pooled=)`` build its sparse operand from the pooled gradient (whole 4 x 16 tiles, 128-channel tiles)?"""
+    return (not os.environ.get("SF_NO_WGRAD_POOLED") and h % 4 == 0 and w % 16 == 0 and np_ % 128 == 0
+            and bool(lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(np_, kp, n, h, w, groups)))
+
+
 def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: int, gm: GemmMap, scale: Tensor, shift: Tensor,
                               dw: Tensor, db: Optional[Tensor], bn: Optional[Tuple[Tensor, Tensor, Tensor, Tensor]] = None,
-                              pooled_gradient: bool = False) -> None:
+                              pooled_gradient: bool = False, pooled: Optional[Tuple[Tensor, Tensor, Optional[Tuple[int, int]]]] = None) -> None:
     """sf_conv3x3_bwd_weight_folded: dW/db of a convolution behind a folded BatchNorm, from the un-normalised input.
     ``bn = (weight OIHW, mean, rstd, sums[groups,2,C] float64)``: also fills ``sums`` with the BatchNorm backward's two reductions.
     ``pooled_gradient``: ``dout`` is the output of ``maxpool2_route_bwd`` (one non-zero per 2x2 window and channel): where the shape allows, dout is the
-    sparse operand of the 2:4 structured-sparse matrix instruction (sf_conv3x3_bwd_weight_folded_sparse24; SF_NO_WGRAD_SPARSE=1: A/B switch)."""
+    sparse operand of the 2:4 structured-sparse matrix instruction (sf_conv3x3_bwd_weight_folded_sparse24; SF_NO_WGRAD_SPARSE=1: A/B switch).
+    ``pooled = (pooled gradient, routing record, (perm_l, perm_t) or None)``: the inputs of that ``maxpool2_route_bwd`` call - the kernel then builds the
+    sparse operand from them instead of reading ``dout`` (SF_NO_WGRAD_POOLED=1: A/B switch)."""
     dev = dw.device
     fn, fname = lib().sf_conv3x3_bwd_weight_folded, "sf_conv3x3_bwd_weight_folded"
+    extra: tuple = ()
     if pooled_gradient and lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(dout.c, src.c, n, h, w, scale.shape[0]):
         fn, fname = lib().sf_conv3x3_bwd_weight_folded_sparse24, "sf_conv3x3_bwd_weight_folded_sparse24"
+        if pooled is not None and pooled[0].dtype == torch.bfloat16 and pooled[0].is_contiguous() and pooled[1].is_contiguous():
+            pl, pt = pooled[2] or (0, 0)
+            extra = (T(pooled[0]), pooled[1].data_ptr(), pl, pt)
+        else:
+            extra = (NULL, None, 0, 0)
     nmap, kmap = gm.tables(dev)
     groups = scale.shape[0]
     nbytes = lib().sf_conv3x3_bwd_weight_folded_workspace_bytes(dout.c, src.c, n, h, w, groups)
@@ -302,7 +316,7 @@ def conv3x3_bwd_weight_folded(src: sfTensor, dout: sfTensor, n: int, h: int, w: 
     check(fn(src, dout, n, h, w, nmap.data_ptr(), kmap.data_ptr(), dw.shape[0], dw.shape[1], scale.data_ptr(),
              shift.data_ptr(), groups, dw.data_ptr(), db.data_ptr() if db is not None else None, 0,
              wgt.data_ptr() if bn is not None else None, mean.data_ptr() if bn is not None else None,
-             rstd.data_ptr() if bn is not None else None, sums.data_ptr() if bn is not None else None,
+             rstd.data_ptr() if bn is not None else None, sums.data_ptr() if bn is not None else None, *extra,
              ws.data_ptr(), nbytes, _hip.SF_BF16, stream_ptr()), fname)
 
 
@@ -389,12 +403,15 @@ def maxpool2_route_fwd(x: Tensor, perm: Optional[Tuple[int, int]] = None, out_dt
     return y, route
 
 
-def maxpool2_route_bwd(route: Tensor, gy: Tensor, shape, dtype, perm: Optional[Tuple[int, int]] = None, drop=None) -> Tensor:
+def maxpool2_route_bwd(route: Tensor, gy: Tensor, shape, dtype, perm: Optional[Tuple[int, int]] = None, drop=None, masked: Optional[Tensor] = None) -> Tensor:
+    """``masked``: a tensor like ``gy`` that receives the pooled gradient after the dropout masks (the operand source of the pooled sparse weight gradient)."""
     n, h, w, c = shape
     gx = torch.empty(shape, dtype=dtype, device=gy.device)
     pl, pt = perm or (0, 0)
     d = drop if drop is not None else (0.0, 0.0, 0, 0, 0)
-    check(lib().sf_maxpool2_route_bwd(route.data_ptr(), T(gy), n, h, w, T(gx), pl, pt, *d, SF_F32, stream_ptr()), "sf_maxpool2_route_bwd")
+    assert masked is None or (masked.shape == gy.shape and masked.dtype == gy.dtype and masked.is_contiguous() and gy.is_contiguous())
+    check(lib().sf_maxpool2_route_bwd(route.data_ptr(), T(gy), n, h, w, T(gx), pl, pt, *d, masked.data_ptr() if masked is not None else None, SF_F32,
+                                      stream_ptr()), "sf_maxpool2_route_bwd")
     return gx
 
 

@@ -82,7 +82,7 @@ int main(void) {
   REFUSED(sf_maxpool2_dropout_bwd(a16, a16, 1, 8, 8, a16, 0, 0, 0.1f, 0.1f, 100, 1, 2, SF_F32, st)); /* period not whole images */
   REFUSED(sf_maxpool2_route_fwd(a16, 1, 8, 8, a16, 0, 0, 0.f, 0.f, 0, 0, 0, 0, SF_F32, st));         /* no routing buffer */
   REFUSED(sf_maxpool2_route_fwd(a16, 1, 8, 8, a16, 0, 0, 0.f, 0.f, 0, 0, 0, (char*)ok + 1, SF_F32, st)); /* misaligned routing buffer */
-  REFUSED(sf_maxpool2_route_bwd(ok, a16, 1, 8, 8, N0, 0, 0, 0.f, 0.f, 0, 0, 0, SF_F32, st));         /* no din */
+  REFUSED(sf_maxpool2_route_bwd(ok, a16, 1, 8, 8, N0, 0, 0, 0.f, 0.f, 0, 0, 0, 0, SF_F32, st));         /* no din */
   REFUSED(sf_batchnorm_train_fwd(odd, 64, 1, 12, ok, ok, 1e-5f, 0.1f, 0, 0, ok, ok, ok, ok, ok, odd, SF_F32, st));
   REFUSED(sf_batchnorm_train_fwd_stats(a16, 64, 1, 16, ok, ok, 1e-5f, 0.1f, 0, 0, ok, ok, ok, ok, ok, 0, 4, 32, a16, SF_F32, st)); /* null stats */
   REFUSED(sf_batchnorm_eval_fwd(a16, 64, 32, ok, ok, 1e-5f, ok, ok, ok, ok, a16, SF_F32, st));       /* creal > lanes */
@@ -134,9 +134,9 @@ int main(void) {
   REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 16, SF_BF16, st));      /* workspace too small */
   REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, ok, ok, ok, ok, 1 << 30, SF_BF16, st)); /* bn_sums without the weights */
   REFUSED(sf_conv3x3_bwd_weight_folded(b16, b16, 3, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* ragged groups */
-  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
-  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* 16 lanes: no 128 x 64 slabs */
-  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(b16, b16, 2, 7, 7, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* odd maps: no 2x2 windows */
+  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, N0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
+  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(b16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, N0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* 16 lanes: no 128 x 64 slabs */
+  REFUSED(sf_conv3x3_bwd_weight_folded_sparse24(b16, b16, 2, 7, 7, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, N0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* odd maps: no 2x2 windows */
   REFUSED(sf_conv3x3_bwd_data_bn(b16, 2, 8, 8, ok, 32, 1, a16, ok, 2, b16, SF_BF16, st));               /* fp32-stored x */
   REFUSED(sf_conv3x3_bwd_data_bn(b16, 3, 8, 8, ok, 32, 1, b16, ok, 2, b16, SF_BF16, st));               /* ragged groups */
   REFUSED(sf_conv3x3_bwd_data_bn(b16, 2, 8, 8, ok, 32, 1, b16, mis, 2, b16, SF_BF16, st));              /* misaligned coefficients */

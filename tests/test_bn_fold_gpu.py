@@ -317,7 +317,8 @@ def test_leadtime_pool_statistics_fall_back_beyond_the_register_budget(device):
     assert st is None and torch.equal(out, F.leadtime_pool(base, w1, 4, 13))
 
 
-@pytest.mark.parametrize("n,cin,cout,H,W,groups,drop", [(48, 256, 256, 32, 32, 12, 0.2), (24, 128, 256, 32, 32, 4, 0.0), (12, 64, 128, 16, 48, 3, 0.5), (16, 128, 256, 64, 64, 2, 0.0)])
+@pytest.mark.parametrize("n,cin,cout,H,W,groups,drop", [(48, 256, 256, 32, 32, 12, 0.2), (24, 128, 256, 32, 32, 4, 0.0), (12, 64, 128, 16, 48, 3, 0.5), (16, 128, 256, 64, 64, 2, 0.0),
+                                                         (12, 64, 128, 18, 48, 3, 0.0)])
 def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(device, n, cin, cout, H, W, groups, drop):
     """Round 5: sf_conv3x3_bwd_weight_folded_sparse24 - dout = the gradient behind a 2x2 max-pooling (one non-zero per window and channel, fewer after the
     dropout) as the SPARSE operand of v_smfmac_f32_32x32x32_bf16 (two dout rows per instruction, compressed in registers).  Same products as the dense
@@ -358,6 +359,34 @@ def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(d
         assert torch.isfinite(dw1).all() and torch.isfinite(db1).all() and torch.isfinite(s1).all()
         assert rel_l2(dw1, dw0) < 5e-6 and rel_l2(db1, db0) < 1e-6, (rel_l2(dw1, dw0), rel_l2(db1, db0))
         assert float((s1 - s0).norm() / s0.norm()) < 5e-6
+        # the POOLED form: the sparse operand built from the pooled gradient + the routing record (what sf_maxpool2_route_bwd was given) instead of from
+        # dout - with and without the pooling's outer image permutation, and with the dropout masks applied by the routing kernel (its masked side output)
+        if K.conv3x3_bwd_weight_pooled_supported(eng.coutp, cpad(cin), n, H, W, groups):
+            for perm, dropout in ((None, None), ((groups, 2), None) if n % (2 * groups) == 0 else (None, None), (None, (0.3, 0.25, gp[: n // groups].numel(), 77, 99))):
+                masked = torch.full_like(gp, float("nan")) if dropout is not None else None
+                if perm is not None:   # the pooled tensor lives in the pooling's OUTPUT image order
+                    L, Tt = perm
+                    B = n // (L * Tt)
+                    gp_in = gp.view(L, Tt, B, *gp.shape[1:]).transpose(0, 1).reshape(gp.shape).contiguous()
+                else:
+                    gp_in = gp
+                dout_p = K.maxpool2_route_bwd(route, gp_in, tuple(y.shape), torch.bfloat16, perm, dropout, masked)
+                if dropout is None:
+                    assert torch.equal(dout_p, dout)
+                else:
+                    assert torch.isfinite(masked.float()).all() and int((masked == 0).sum()) > masked.numel() // 4
+                ref_w, ref_b = torch.full_like(w, float("nan")), torch.full((cout,), float("nan"), device=device)
+                ref_s = torch.full((groups, 2, cpad(cin)), float("nan"), dtype=torch.float64, device=device)
+                K.conv3x3_bwd_weight_folded(T(x), T(dout_p), n, H, W, gm, scale, shift, ref_w, ref_b, bn=(w, mean, rstd, ref_s), pooled_gradient=True)
+                dw2, db2 = torch.full_like(w, float("nan")), torch.full((cout,), float("nan"), device=device)
+                s2 = torch.full((groups, 2, cpad(cin)), float("nan"), dtype=torch.float64, device=device)
+                K.conv3x3_bwd_weight_folded(T(x), T(dout_p), n, H, W, gm, scale, shift, dw2, db2, bn=(w, mean, rstd, s2), pooled_gradient=True,
+                                            pooled=(masked if masked is not None else gp_in, route, perm))
+                torch.cuda.synchronize()
+                assert torch.isfinite(dw2).all() and torch.isfinite(db2).all() and torch.isfinite(s2).all(), (perm, dropout)
+                # the same non-zero products (an empty pixel pair carries another position code: its zero enters the instruction's adder elsewhere)
+                assert rel_l2(dw2, ref_w) < 1e-6 and float((s2 - ref_s).norm() / ref_s.norm()) < 1e-6, (perm, dropout, rel_l2(dw2, ref_w))
+                assert rel_l2(db2, ref_b) < 1e-6, (perm, dropout, rel_l2(db2, ref_b))
         # float64: dW = sum_g scale_g (.) dWraw_g + shift_g (x) V_g  ==  the weight gradient of conv(scale_g * x + shift_g) for the group's images
         xd = x[..., :cin].double().cpu().permute(0, 3, 1, 2)
         per = n // groups

@@ -19,10 +19,11 @@ dout = K.maxpool2_route_bwd(route, g, tuple(y.shape), torch.bfloat16, None, None
 scale = 0.5 + torch.rand(G, cpad(cin), device=dev); shift = torch.randn(G, cpad(cin), device=dev)
 w = torch.randn(cout, cin, 3, 3, device=dev) * 0.03
 mean, rstd = torch.randn(G, cpad(cin), device=dev), 0.5 + torch.rand(G, cpad(cin), device=dev)
-def run(sparse):
+def run(sparse, pooled=None):
     dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
     sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
-    f = lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=sparse)
+    f = lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=sparse,
+                                            pooled=pooled)
     for _ in range(3): f()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,6 +31,7 @@ def run(sparse):
     for _ in range(10): f()
     e1.record(); torch.cuda.synchronize()
     return dw, db, sums, e0.elapsed_time(e1) / 10
-d0 = run(False); d1 = run(True)
+d0 = run(False); d1 = run(True); d2 = run(True, (g, route, None))
 rel = lambda a, b: float((a.double() - b.double()).norm() / b.double().norm())
 print(f"dense {d0[3]:.3f} ms   sparse {d1[3]:.3f} ms   dW rel {rel(d1[0], d0[0]):.2e}  db rel {rel(d1[1], d0[1]):.2e}  bn sums rel {rel(d1[2], d0[2]):.2e}")
+print(f"pooled operand {d2[3]:.3f} ms   dW == sparse-from-dout: {torch.equal(d2[0], d1[0])} (rel {rel(d2[0], d1[0]):.2e})  db rel {rel(d2[1], d1[1]):.2e}  bn sums equal {torch.equal(d2[2], d1[2])}")
