@@ -345,7 +345,7 @@ class MetNetWorkload:
             mean, rstd = torch.randn(G, cpad(cin), device=dev), 0.5 + torch.rand(G, cpad(cin), device=dev)
             sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
             sparse = cin == 256 and bool(lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(eng.coutp, cpad(cin), n, H, W, G))
-            row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true, false>", (1 if sparse else 2) if cin == 256 else 1, cin, cout,
+            row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true, 0>", (1 if sparse else 2) if cin == 256 else 1, cin, cout,
                 lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums)),
                 ("weight gradient of conv3 (grouped slabs + BatchNorm-backward sums)" if sparse else "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)")
                 if cin == 256 else "weight gradient of conv2", out_lanes=0, shape=(1 if cin == 256 else 0, 2, "write_bytes" if sparse else "launches"))
@@ -354,13 +354,16 @@ class MetNetWorkload:
                 # of v_smfmac_f32_32x32x32_bf16.  The row keeps the dense flop count (what the launch replaces): frac is "dense-equivalent" of the 2.5 PF peak.
                 yp = torch.randn(n, H, W, eng.coutp, device=dev).to(bf)
                 pooled_, route_ = K.maxpool2_route_fwd(yp, None, bf, None)
-                dsp = K.maxpool2_route_bwd(route_, torch.randn_like(pooled_), tuple(yp.shape), bf, None, None)
-                del yp, pooled_, route_
-                row(f"wgrad_bf16_dma_kernel<FAST, GROUPED, SPARSE> {cin}->{cout}: dout behind the max-pooling as the 2:4 structured-sparse MFMA operand (+ folded-BatchNorm helpers)",
-                    "wgrad_bf16_dma_kernel<true, true, true>", 1, cin, cout,
-                    lambda: K.conv3x3_bwd_weight_folded(T(x), T(dsp), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=True),
+                gp_ = torch.randn_like(pooled_)
+                dsp = K.maxpool2_route_bwd(route_, gp_, tuple(yp.shape), bf, None, None)
+                pooled_form = K.conv3x3_bwd_weight_pooled_supported(eng.coutp, cpad(cin), n, H, W, G)
+                row(f"wgrad_bf16_dma_kernel<FAST, GROUPED, SPARSE {2 if pooled_form else 1}> {cin}->{cout}: the gradient behind the max-pooling as the 2:4 structured-sparse MFMA "
+                    f"operand{', built from the pooled gradient + routing codes' if pooled_form else ''} (+ folded-BatchNorm helpers)",
+                    f"wgrad_bf16_dma_kernel<true, true, {2 if pooled_form else 1}>", 1, cin, cout,
+                    lambda: K.conv3x3_bwd_weight_folded(T(x), T(dsp), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=True,
+                                                        pooled=(gp_, route_, None) if pooled_form else None),
                     "weight gradient of conv4 (dense-equivalent flops: half the matrix instructions)", out_lanes=0)
-                del dsp
+                del dsp, yp, pooled_, route_, gp_
             del x, y, dout, dx, st
         rows.sort(key=lambda r: -r["ms_per_step"])
         return {"rows": rows, "traffic_source": pmc_note,

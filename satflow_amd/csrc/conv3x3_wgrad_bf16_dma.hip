@@ -540,12 +540,20 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     SF_SPARSE_SB;
     smf(cur.a02, cur.i02, 0, sq0);
     SF_SPARSE_SB;
+#ifdef SF_EXP_WG_SHIFT   // experiment: rows (a, a + 2) from rows (a - 2, a) in registers + a half-wave read
+    shift_b16(aBS, 2, sq0);
+#else
     load_b16(aBS, 2, sq0);
+#endif
     SF_SPARSE_SB;
     smf(cur.a02, cur.i02, 1, sq1);
     smf(cur.a13, cur.i13, 0, sq1);
     SF_SPARSE_SB;
+#ifdef SF_EXP_WG_SHIFT
+    shift_b16(aBS, 3, sq1);
+#else
     load_b16(aBS, 3, sq1);
+#endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 3)) : "memory");
     __builtin_amdgcn_s_barrier();
     if (!stage_late) issue();
