@@ -325,14 +325,16 @@ def test_cloudgan_step_hipgraph_replay_equals_eager(device):
         b.model.load_state_dict(copy.deepcopy(a.model.state_dict()))
         for oa, ob in ((a.opt_g, b.opt_g), (a.opt_d, b.opt_d)):
             ob.load_state_dict(copy.deepcopy(oa.state_dict()))
-        la, lb = a.step(), b._eager_step()
-        torch.cuda.synchronize()
-        assert_close(la, lb, "loss of the replayed step")
+        # THREE steps each: a captured scratch reset that only works on a graph's first launch (hipMemsetAsync nodes, round 5) shows from the second on
+        for k in range(3):
+            la, lb = a.step(), b._eager_step()
+            torch.cuda.synchronize()
+            assert_close(la, lb, f"loss of replayed step {k}", rtol=2e-3 if k else 1e-4, atol=1e-4 if k else 1e-5)
         sa, sb = a.model.state_dict(), b.model.state_dict()
         n = 0
         for k, v in sa.items():
             if v.dtype.is_floating_point:
-                assert_close(v.float(), sb[k].float(), f"{k} after a replayed step vs after the eager step")
+                assert_close(v.float(), sb[k].float(), f"{k} after three replayed steps vs after three eager steps", rtol=2e-2, atol=2e-4)
                 n += 1
         assert n > 20
     finally:
