@@ -300,6 +300,9 @@ class MetNetWorkload:
                          "algorithmic_flops": fl, "achieved_tflops": fl / t / 1e12, "frac": fl / t / 1e12 / PEAK_BF16_TFLOPS,
                          "algorithmic_bytes": alg, "traffic": traffic(pmc_sub, *shape)})
 
+        # conv4's weight gradient runs on its own instantiation when the 2:4-sparse path takes it: the dense name then runs ONCE at each of its two shapes per
+        # step, and the PMC record's shape classes are told apart by their write bytes (160 -> 256 has fewer partial slabs) instead of by launch count
+        sparse4 = bool(lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(cpad(256), cpad(256), n, H, W, G))
         for cin, cout, fwd_stats, fwd_plain, dgrad_name in ((256, 256, 1, 1, "conv3x3_bf16_persist4_kernel<2"), (160, 256, 1, 0, "conv3x3_bf16_kernel<8, 5, 0, false, true, true")):
             eng = ConvEngine([cin], cout)
             gm = eng.fwd_map
@@ -344,11 +347,11 @@ class MetNetWorkload:
             dw, db = torch.empty_like(w), torch.empty(cout, device=dev)
             mean, rstd = torch.randn(G, cpad(cin), device=dev), 0.5 + torch.rand(G, cpad(cin), device=dev)
             sums = torch.empty(G, 2, cpad(cin), dtype=torch.float64, device=dev)
-            sparse = cin == 256 and bool(lib().sf_conv3x3_bwd_weight_folded_sparse24_supported(eng.coutp, cpad(cin), n, H, W, G))
+            sparse = cin == 256 and sparse4
             row(f"wgrad_bf16_dma_kernel<FAST, GROUPED> {cin}->{cout} (+ folded-BatchNorm helpers)", "wgrad_bf16_dma_kernel<true, true, 0>", (1 if sparse else 2) if cin == 256 else 1, cin, cout,
                 lambda: K.conv3x3_bwd_weight_folded(T(x), T(dout), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums)),
                 ("weight gradient of conv3 (grouped slabs + BatchNorm-backward sums)" if sparse else "weight gradients of conv3 / conv4 (grouped slabs + BatchNorm-backward sums)")
-                if cin == 256 else "weight gradient of conv2", out_lanes=0, shape=(1 if cin == 256 else 0, 2, "write_bytes" if sparse else "launches"))
+                if cin == 256 else "weight gradient of conv2", out_lanes=0, shape=(1 if cin == 256 else 0, 2, "write_bytes" if sparse4 else "launches"))
             if sparse:
                 # conv4's weight gradient: its dout comes out of the 2x2 max-pooling's backward - one non-zero per window and channel - and is the SPARSE operand
                 # of v_smfmac_f32_32x32x32_bf16.  The row keeps the dense flop count (what the launch replaces): frac is "dense-equivalent" of the 2.5 PF peak.
