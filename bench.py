@@ -376,25 +376,28 @@ class MetNetWorkload:
                         "algorithmic_bytes of the input-gradient rows = dout + x (BatchNorm-backward epilogue) read + dx written"}
 
     def roofline(self):
-        """The kernel with the largest share of the step: the grouped weight gradient of the folded 256 -> 256 convolutions
-        (wgrad_bf16_dma_kernel<FAST, GROUPED>, 2 launches per step + 1 at 160 -> 256), timed live; the other four big kernels are in
-        extra.kernels.  Modes without the bf16-stored encoder report the forward convolution as before."""
+        """The kernel with the largest share of the step, timed live: the first row of the kernel table (rounds 3-4: the grouped weight
+        gradient of the folded 256 -> 256 convolutions; round 5: their input gradient + BatchNorm backward); the other rows are in extra.kernels.  Modes without the bf16-stored encoder report the forward convolution as before."""
         import satflow_amd
         mode = satflow_amd.compute_dtype_name()
         if mode == "bf16a":
             tab = self.kernel_table()
             self._kernel_table = tab
-            r = next(x for x in tab["rows"] if x["kernel"].startswith("wgrad_bf16_dma_kernel<FAST, GROUPED> 256->256"))
+            # the row with the largest share of the step (rows are sorted by launches x duration): since round 5 - conv4's weight gradient left the dense
+            # weight-gradient family for the 2:4-sparse instruction - the input gradient + BatchNorm backward of conv3 / conv4 on the one-wave-per-SIMD kernel
+            r = tab["rows"][0]
             tr = r["traffic"]
+            share = r["ms_per_step"] / max(self.last_ms_per_step, 1e-9) if getattr(self, "last_ms_per_step", None) else None
             return {"bound": "mfma", "achieved": r["achieved_tflops"], "peak": PEAK_BF16_TFLOPS, "unit": "TFLOP/s", "frac": r["frac"],
                     "traffic": tr["bytes"] if tr else None, "traffic_source": tab["traffic_source"],
-                    "kernel": "wgrad_bf16_dma_kernel<FAST=true, GROUPED=true> (sf_conv3x3_bwd_weight_folded, 256->256 ch, 32x32, 2304 images, 12 BatchNorm groups): "
-                              "the largest kernel of the step by time (3 launches, ~23 %)",
+                    "kernel": f"{r['kernel']} [{r['replaces']}; 256 channels, 32x32, 2304 images, 12 BatchNorm groups]: the largest kernel of the step by time "
+                              f"({r['launches_per_step']} launches = {r['ms_per_step']:.2f} ms" + (f", {100 * share:.0f} % of the step)" if share else ")"),
                     "launch_us": r["launch_us"], "algorithmic_flops": r["algorithmic_flops"], "algorithmic_bytes": r["algorithmic_bytes"],
                     "hbm_gbps_algorithmic": r["algorithmic_bytes"] / (r["launch_us"] * 1e-6) / 1e9,
                     "hbm_frac_algorithmic": r["algorithmic_bytes"] / (r["launch_us"] * 1e-6) / 1e9 / PEAK_HBM_GBPS,
-                    "note": "bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16), bf16 activations and gradients in HBM, NHWC tiles by LDS-DMA, transposing "
-                            "ds_read_b64_tr_b16 fragment reads; launch_us includes the helper kernels of the call (~0.15 ms: the kernel alone is faster by that much)"}
+                    "note": "bf16 operands / fp32 accumulate (v_mfma_f32_32x32x16_bf16; the sparse row: v_smfmac_f32_32x32x32_bf16), bf16 activations and gradients in HBM, "
+                            "tiles by LDS-DMA, transposing ds_read_b64_tr_b16 fragment reads; the weight-gradient rows' launch_us includes the helper kernels of the call "
+                            "(~0.15 ms).  All eight rows: extra.kernels"}
         return self._roofline_forward_conv()
 
     def _roofline_forward_conv(self):
@@ -1150,6 +1153,7 @@ def main(argv=None):
             out["config"]["parity"] = ("ConvLSTM, CloudGAN and ST-LSTM paths pinned to reference-generated goldens; MetNet arithmetic checked against "
                                    "oracle/metnet.py, which is UNPINNED (upstream metnet / axial_attention packages absent); observed errors of this "
                                    f"mode at this size: profiles/{PROFILE_ROUND}_parity_observed.jsonl")
+        wl.last_ms_per_step = out["ms_per_step"]
         out["roofline"] = wl.roofline()
     if world > 1 or rank == 0:
         comm = comm_report(wl, world, dev)  # collective: every rank takes part
