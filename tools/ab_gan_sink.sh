@@ -1,3 +1,5 @@
+#!/bin/bash
+# A/B of the gradient sink on the CloudGAN line (the one step that is half host-bound: fewer launches count there), alternating on one box.
 cd $GRAFT_REPO_ROOT
 for rep in 1 2; do
 for cfg in "SF_NO_GRAD_SINK=1" ""; do
