@@ -555,7 +555,9 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
     load_b16(aBS, 3, sq1);
 #endif
     asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 3)) : "memory");
+#ifndef SF_EXP_WG_NOBAR   // timing experiment (results WRONG): what does the per-tile rendezvous cost?
     __builtin_amdgcn_s_barrier();
+#endif
     if (!stage_late) issue();
     // the next tile's dout rows are requested NOW (its stage is visible behind the barrier) and compressed under the six instructions of step 2
     unsigned nA, nBS[3];
