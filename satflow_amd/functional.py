@@ -47,12 +47,17 @@ class GradSink:
         import weakref
 
         self.table[(param.data_ptr(), param.numel())] = (grad_view, id(owner), weakref.ref(owner), param.untyped_storage().data_ptr())
-        self.taken.setdefault(id(owner), set())
+        if id(owner) not in self.taken:
+            self.taken[id(owner)] = set()
+            weakref.finalize(owner, self._drop_owner, id(owner))   # (the table holds views of the owner's gradient buffer: let go of them with the owner)
+
+    def _drop_owner(self, oid: int) -> None:
+        self.table = {k: v for k, v in self.table.items() if v[1] != oid}
+        self.taken.pop(oid, None)
+        self.closed.discard(oid)
 
     def unregister(self, owner) -> None:
-        self.table = {k: v for k, v in self.table.items() if v[1] != id(owner)}
-        self.taken.pop(id(owner), None)
-        self.closed.discard(id(owner))
+        self._drop_owner(id(owner))
 
     def reopen(self, owner) -> None:
         """``zero_grad()`` of ``owner``: its buffer is zero again."""
