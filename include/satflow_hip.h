@@ -175,7 +175,9 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
  *        output is stored as bf16 in "bf16a" mode, as a 16-bit autocast leaves it; summed in fp32)
  *   dc_next (nullable) gradient flowing into c'; gates = saved i,f,o,g; c_prev nullable (zeros)
  *   -> dz [.., 4*hidp] gradient wrt the pre-activation conv output, dc_prev (nullable out).
- *   gates and dz share one storage type (SF_F32 or SF_BF16; dz may overwrite gates in place). */
+ *   gates and dz share one storage type (SF_F32 or SF_BF16; dz may overwrite gates in place).
+ *   c_new (ABI 7: nullable): the step's new cell state; NULL = taken again as f * c_prev + i * g from the saved gates (one read of the state
+ *   sequence less; with bf16-stored gates it then carries their rounding like the rest of this pass). */
 int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor dc_next,
                                sfTensor gates, sfTensor c_prev, sfTensor c_new, int64_t pixels,
                                int32_t hidp, sfTensor dz, sfTensor dc_prev, int32_t dtype,

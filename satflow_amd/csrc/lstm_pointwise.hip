@@ -38,9 +38,16 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
     if (p.dh2) dh += ldh(p.dh2, p.s_dh2, p.bf_dh2);
     const TG* g = reinterpret_cast<const TG*>(p.gates) + pix * p.s_g + c;
     const f32x4 gi = ldv4(g), gf = ldv4(g + p.hidp), go = ldv4(g + 2 * p.hidp), gg = ldv4(g + 3 * p.hidp);
-    const f32x4 cn = ld4(p.c_new + pix * p.s_cn + c);
     f32x4 cp = {0.f, 0.f, 0.f, 0.f};
     if (p.c_prev) cp = ld4(p.c_prev + pix * p.s_cp + c);
+    // c' = f c + i g: read back, or (c_new NULL) taken again from the saved gates - with bf16-stored gates one more value of the step that carries their
+    // rounding (2^-9 relative, like every other use of the gates here) for 4 of the pass's 36 bytes per element
+    f32x4 cn;
+    if (p.c_new) cn = ld4(p.c_new + pix * p.s_cn + c);
+    else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) cn[j] = gf[j] * cp[j] + gi[j] * gg[j];
+    }
     f32x4 dc = {0.f, 0.f, 0.f, 0.f};
     if (p.dc_next) dc = ld4(p.dc_next + pix * p.s_dcn + c);
     f32x4 zi, zf, zo, zg, dcp;
@@ -76,7 +83,7 @@ extern "C" int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor d
                                           sfTensor dc_prev, int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_convlstm_cell_bwd_gates: dtype %d not built", dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && hidp > 0, "bwd_gates: hidp=%d", hidp);
-  SF_REQUIRE(dh0.ptr && gates.ptr && c_new.ptr && dz.ptr, "bwd_gates: dh0, gates, c_new, dz must be non-null");
+  SF_REQUIRE(dh0.ptr && gates.ptr && dz.ptr, "bwd_gates: dh0, gates, dz must be non-null");
   SF_REQUIRE(aligned4g0(dh0) && aligned4g0(dh1) && aligned4g0(dh2) && aligned4(dc_next) && aligned4g(gates) && aligned4(c_prev) &&
                  aligned4(c_new) && aligned4g(dz) && aligned4(dc_prev) && gates.dtype == dz.dtype,
              "bwd_gates: tensors must be 16-byte aligned with stride %% 4 == 0, fp32 (gates / dz: fp32 or bf16, both alike; dh sources: fp32 or bf16 each)");

@@ -13,6 +13,7 @@ this single-step surface.
 """
 from __future__ import annotations
 
+import os
 from typing import List, Optional, Sequence, Tuple
 
 import torch
@@ -70,7 +71,10 @@ class CellEngine:
     def bwd_gates(self, dh: Sequence[sfTensor], dc_next: Optional[Tensor], gates: Tensor, c_prev: Optional[Tensor],
                   c_new: Tensor, dz: Tensor, dc_prev: Optional[Tensor]) -> None:
         pixels = gates.numel() // gates.shape[-1]
-        K.convlstm_cell_bwd_gates(dh, T(dc_next, self.hidp), T(gates), T(c_prev, self.hidp), T(c_new), pixels, self.hidp,
+        # bf16-stored gates ("bf16a"): c' is taken again from them instead of read back - 4 of the 36 bytes per element of this HBM-bound pass
+        # (SF_LSTM_READ_C=1: A/B switch); with fp32-stored gates the state is read (bit-exact backward of the parity mode)
+        recompute = gates.dtype == torch.bfloat16 and not os.environ.get("SF_LSTM_READ_C")
+        K.convlstm_cell_bwd_gates(dh, T(dc_next, self.hidp), T(gates), T(c_prev, self.hidp), NULL if recompute else T(c_new), pixels, self.hidp,
                                   T(dz), T(dc_prev, self.hidp))
 
     def bwd_data(self, dz: Tensor, n: int, h: int, w: int, need_dx: bool, dcat: Tensor) -> None:
