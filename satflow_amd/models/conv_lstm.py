@@ -135,14 +135,18 @@ class _StackFn(torch.autograd.Function):
         x, Hs, Cs, Gs = saved[0], saved[1:5], saved[5:9], saved[9:13]
         hidp = e1.hidp
         dev = x.device
-        g_out = g_out.contiguous().float().view(T_out, B, H, W, hidp)  # gradients of the states are fp32 throughout
+        # the head's gradient: summed in fp32 by the gate kernel whatever its storage (bf16 when the head convolution's input - the bf16-stored
+        # states - is: no fp32 copy of it is made)
+        g_out = g_out.contiguous()
+        if g_out.dtype not in (torch.float32, torch.bfloat16) or os.environ.get("SF_LSTM_GOUT_F32"):   # (A/B switch: the fp32 copy)
+            g_out = g_out.float()
+        g_out = g_out.view(T_out, B, H, W, hidp)
         xs = x.view(T_in, B, H, W, x.shape[-1])
         need_dx = [ctx.need_dx, True, True, True]
         # per cell: [dx (if needed) ; dh_prev] scratch of the input-gradient conv, and the dc carry
         widths = [(eng.cinp if nd else 0) + hidp for eng, nd in zip(engines, need_dx)]
         # [dx ; dh] of the input-gradient convolutions: bf16 in "bf16a" mode (what a 16-bit autocast leaves between a convolution's backward and
         # the gate arithmetic; summed in fp32 by the gate backward) - half the stores of those launches, a tenth of the gate backward's bytes
-        import os
         dcat_dt = torch.float32 if os.environ.get("SF_LSTM_DCAT_F32") else gate_storage_dtype()   # (A/B switch)
         dcat = [torch.empty(B, H, W, wd, dtype=dcat_dt, device=dev) for wd in widths]
         dc = [torch.empty(B, H, W, hidp, dtype=torch.float32, device=dev) for _ in range(4)]
