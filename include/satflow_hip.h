@@ -525,6 +525,9 @@ int sf_conv2d_bwd_weight(sfTensor x, sfTensor dy, int32_t n, int32_t h, int32_t 
 /* y = x > 0 ? x : slope*x over n contiguous floats; sign_ref (nullable) supplies the sign instead of x: the backward pass is
  * sf_leaky_relu(dy, y_forward, ...) (slope > 0 preserves signs). */
 int sf_leaky_relu(const float* x, const float* sign_ref, int64_t n, float slope, float* y, sfStream stream);
+/* (ABI 7) dx = dy * y * (1 - y) over n contiguous floats (dx == dy allowed): backward of the sigmoid the head convolutions apply in their epilogue
+ * (satflow/models/conv_lstm.py:200-203 `torch.nn.Sigmoid()(self.decoder_CNN(...))`), in torch's evaluation order. */
+int sf_sigmoid_bwd(const float* dy, const float* y, int64_t n, float* dx, sfStream stream);
 
 /* nn.L1Loss (mean) and nn.BCEWithLogitsLoss against a constant label (GANLoss "vanilla", discriminators.py:70-136) over the first c
  * lanes of `rows` NHWC rows split into `groups` equal contiguous groups (timesteps): out[0] = mean over everything, out[1+g] =

@@ -129,6 +129,7 @@ PROTOTYPES = {
     "sf_conv2d_bwd_weight_workspace_bytes": (_sz, [_i32, _i32, _i32, _i32, _i32, _i32, _i32]),
     "sf_conv2d_bwd_weight": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _vp, _vp, _i32, _vp, _sz, _i32, _vp]),
     "sf_leaky_relu": (C.c_int, [_vp, _vp, _i64, C.c_float, _vp, _vp]),
+    "sf_sigmoid_bwd": (C.c_int, [_vp, _vp, _i64, _vp, _vp]),
     "sf_l1_loss": (C.c_int, [sfTensor, sfTensor, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_bce_logits_loss": (C.c_int, [sfTensor, C.c_float, C.c_float, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),
     "sf_gan_loss": (C.c_int, [_i32, sfTensor, C.c_float, C.c_float, _i64, _i32, _i32, sfTensor, _vp, _vp, _vp]),

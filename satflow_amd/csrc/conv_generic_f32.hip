@@ -199,6 +199,18 @@ __global__ __launch_bounds__(256) void leaky_kernel(const float* __restrict__ x,
   }
 }
 
+// dx = dy * y * (1 - y): the sigmoid's backward from its OUTPUT (the head convolutions' fused sigmoid epilogue), in the order torch evaluates it
+__global__ __launch_bounds__(256) void sigmoid_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ y, long long n4, float* __restrict__ dx) {
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < n4; idx += (long long)gridDim.x * blockDim.x) {
+#pragma clang fp contract(off)
+    const f32x4 g = reinterpret_cast<const f32x4*>(dy)[idx], v = reinterpret_cast<const f32x4*>(y)[idx];
+    f32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = (g[j] * v[j]) * (1.0f - v[j]);
+    reinterpret_cast<f32x4*>(dx)[idx] = o;
+  }
+}
+
 bool okt(const sfTensor& t) { return t.ptr && t.dtype == SF_F32 && ((uintptr_t)t.ptr & 15) == 0 && t.stride % 8 == 0 && t.c % 8 == 0; }
 
 }  // namespace
@@ -278,6 +290,17 @@ int sf_leaky_relu(const float* x, const float* sign_ref, int64_t n, float slope,
   const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
   hipLaunchKernelGGL(leaky_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, x, sign_ref, n4, slope, y);
   SF_CHECK_LAUNCH("leaky_relu");
+  return 0;
+}
+
+int sf_sigmoid_bwd(const float* dy, const float* y, int64_t n, float* dx, sfStream stream) {
+  SF_REQUIRE(dy && y && dx && n >= 0 && n % 4 == 0 && ((uintptr_t)dy & 15) == 0 && ((uintptr_t)y & 15) == 0 && ((uintptr_t)dx & 15) == 0,
+             "sf_sigmoid_bwd: 16-byte aligned, n %% 4 == 0");
+  if (n == 0) return 0;
+  const long long n4 = n / 4;
+  const int blocks = (int)((n4 + 255) / 256 < 8192 ? (n4 + 255) / 256 : 8192);
+  hipLaunchKernelGGL(sigmoid_bwd_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, dy, y, n4, dx);
+  SF_CHECK_LAUNCH("sigmoid_bwd");
   return 0;
 }
 

@@ -354,7 +354,12 @@ class _ConvFn(torch.autograd.Function):
         H, W = x0.shape[1], x0.shape[2]
         gy = gy.contiguous()
         if ctx.sigmoid:
-            gy = gy * y * (1.0 - y)  # pointwise torch op on the small head tensor only
+            if gy.dtype == torch.float32 and y.dtype == torch.float32 and y.is_contiguous() and gy.numel() % 4 == 0:
+                g2 = torch.empty_like(gy)
+                check(lib().sf_sigmoid_bwd(gy.data_ptr(), y.data_ptr(), gy.numel(), g2.data_ptr(), stream_ptr()), "sf_sigmoid_bwd")
+                gy = g2
+            else:
+                gy = gy * y * (1.0 - y)  # pointwise torch op on the small head tensor only
         if x0.dtype == torch.bfloat16 and gy.dtype != torch.bfloat16:
             # bf16-stored sources take a bf16-stored output gradient (weight-gradient kernel).  Exact: both kernels below
             # round the gradient to bf16 when they build their MFMA operands anyway.

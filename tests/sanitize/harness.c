@@ -128,6 +128,8 @@ int main(void) {
   REFUSED(sf_conv2d_fwd(a16, 1, 8, 8, ok, 0, 16, 16, 4, 4, 2, 1, 1.f, a16, SF_BF16, st));            /* fp32 kernel only */
   REFUSED(sf_conv2d_bwd_data(a16, 1, 8, 8, 0, 16, 16, 4, 4, 2, 1, a16, SF_F32, st));                 /* null weight */
   REFUSED(sf_conv2d_bwd_weight(a16, a16, 1, 8, 8, 16, 16, 4, 4, 2, 1, ok, 0, 0, 0, 0, SF_F32, st));  /* no workspace */
+  REFUSED(sf_sigmoid_bwd(ok, mis, 64, ok, st));       /* misaligned */
+  REFUSED(sf_sigmoid_bwd(ok, ok, 63, ok, st));        /* n % 4 */
   REFUSED(sf_leaky_relu(mis, 0, 64, 0.2f, ok, st));
   REFUSED(sf_leaky_relu(ok, 0, 63, 0.2f, ok, st));
   REFUSED(sf_conv3x3_bwd_weight_folded(a16, b16, 2, 8, 8, ok, ok, 16, 16, ok, ok, 2, ok, 0, 0, 0, 0, 0, 0, ok, 1 << 30, SF_BF16, st)); /* fp32 source */
