@@ -1,6 +1,6 @@
 """Which Python lines launch the small torch kernels (fills, copies, adds, cats) of one training step?
 
-    python tools/trace_glue.py metnet|convlstm|dgmr  [mode]
+    python tools/trace_glue.py metnet|convlstm|cloudgan|dgmr  [mode]
 
 Runs three warm-up steps, profiles ONE step with torch.profiler (with_stack) and prints, per aten op that launched a device kernel, the call count,
 the device time and the innermost frames inside this repository.  The output is the work list for "remove torch glue".
@@ -24,6 +24,8 @@ if name == "metnet":
     wl = bench.MetNetWorkload(dev, 8, 0)
 elif name == "convlstm":
     wl = bench.ConvLSTMWorkload(dev, 8, 0)
+elif name == "cloudgan":
+    wl = bench.CloudGANWorkload(dev, 8, 0)
 else:
     os.environ["SF_NO_GRAPH"] = "1"
     wl = bench.DGMRWorkload(dev, 2, 0)
