@@ -41,20 +41,26 @@ class _SpectralNormFn(torch.autograd.Function):
         ws = _ws(lib().sf_spectral_norm_workspace_floats(height, width), wb.device)
         check(lib().sf_spectral_norm_fwd(wb.data_ptr(), height, width, u.data_ptr(), v.data_ptr(), int(power_iterations), w.data_ptr(), sigma.data_ptr(),
                                          ws.data_ptr(), stream_ptr()), "sf_spectral_norm_fwd")
-        # the vectors this call ended with (a later call advances the module's own copies before the backward pass runs)
-        ctx.save_for_backward(wb, u.detach().clone(), v.detach().clone(), sigma)
+        # the vectors this call ended with (a later call advances the module's own copies before the backward pass runs): both in ONE launch
+        uv = torch.empty(height + width, dtype=torch.float32, device=wb.device)
+        F._copy_blocks([(u.detach().view(1, -1), 0, 0, height, uv, 0, 0, height + width, 1, height),
+                        (v.detach().view(1, -1), 0, 0, width, uv, 0, height, height + width, 1, width)])
+        ctx.save_for_backward(wb, uv, sigma)
+        ctx.w_bar = w_bar   # (identity: where its gradient goes)
         return w
 
     @staticmethod
     def backward(ctx, g: Tensor):
-        wb, u, v, sigma = ctx.saved_tensors
+        wb, uv, sigma = ctx.saved_tensors
         g = g.contiguous()
         height = wb.shape[0]
-        dw = torch.empty_like(wb)
+        u, v = uv[:height], uv[height:]
+        # (the parameter's own gradient slice when an optimizer registered it with functional.GRAD_SINK: no add_ by autograd afterwards)
+        dw, dw_ret = F.grad_out(ctx.w_bar if ctx.w_bar.is_contiguous() else wb)
         ws = _ws(512, wb.device)
         check(lib().sf_spectral_norm_bwd(g.data_ptr(), wb.data_ptr(), u.data_ptr(), v.data_ptr(), sigma.data_ptr(), height, wb.numel() // height, dw.data_ptr(),
                                          ws.data_ptr(), stream_ptr()), "sf_spectral_norm_bwd")
-        return dw, None, None, None
+        return dw_ret, None, None, None
 
 
 def spectral_norm_weight(w_bar: Tensor, u: Tensor, v: Tensor, power_iterations: int = 1) -> Tensor:
@@ -617,11 +623,12 @@ class _DvdGruOutFn(torch.autograd.Function):
     """``(gx_o, gh_o, zr, h) -> h' = h (1 - z) + tanh(gx_o + gh_o) z``."""
 
     @staticmethod
-    def forward(ctx, gx: Tensor, gh: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int):
+    def forward(ctx, gx: Tensor, gh: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None):
         shp, dev = gx.shape[:-1], gx.device
         pixels = gx.numel() // gx.shape[-1]
         cand = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
-        hn = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
+        hn = out if out is not None else torch.empty(*shp, hidp, dtype=torch.float32, device=dev)   # (``out``: a frame's slot of ``sequence_slots``)
+        assert hn.shape == (*shp, hidp) and hn.dtype == torch.float32 and hn.is_contiguous()
         check(lib().sf_dvdgru_out_fwd(T(gx), T(gh) if gh is not None else NULL, T(zr), T(h) if h is not None else NULL, pixels, hidp, T(cand), T(hn), stream_ptr()),
               "sf_dvdgru_out_fwd")
         ctx.hidp, ctx.has, ctx.lanes = hidp, (gh is not None, h is not None), gx.shape[-1]
@@ -640,15 +647,48 @@ class _DvdGruOutFn(torch.autograd.Function):
         dh = torch.empty_like(cand) if has_h else None
         check(lib().sf_dvdgru_out_bwd(T(dhn), T(cand), T(zr), T(h) if has_h else NULL, pixels, hidp, T(da), T(dzr), T(dh) if dh is not None else NULL, stream_ptr()),
               "sf_dvdgru_out_bwd")
-        return da, (da if has_gh else None), dzr, dh, None
+        return da, (da if has_gh else None), dzr, dh, None, None
+
+
+def sequence_slots(frames: int, shape, device):
+    """``(buffer [frames * shape[0], ...], [slot_0, ...])``: one contiguous fp32 buffer for a sequence of per-frame results and a tensor per frame on
+    its slice of the storage (own tensors, not autograd views: a kernel writes each through ``out=``).  ``assemble(buffer, results)`` then IS the
+    concatenation of the per-frame results - the frames were written where ``torch.cat`` would have copied them."""
+    buf = torch.empty(frames * shape[0], *shape[1:], dtype=torch.float32, device=device)
+    per = buf.numel() // max(frames, 1)
+    slots = [torch.empty(0, dtype=torch.float32, device=device).set_(buf.untyped_storage(), buf.storage_offset() + t * per, tuple(shape)) for t in range(frames)]
+    return buf, slots
+
+
+class _AssembleFn(torch.autograd.Function):
+    """``torch.cat(results, 0)`` for results that already sit in consecutive slices of ``holder[0]`` (``sequence_slots``): no copy; backward = the slices."""
+
+    @staticmethod
+    def forward(ctx, holder, *results: Tensor):
+        buf = holder[0]
+        per = buf.numel() // len(results)
+        for t, r in enumerate(results):
+            if r.data_ptr() != buf.data_ptr() + 4 * t * per or r.numel() != per:
+                raise RuntimeError("assemble: result %d is not slot %d of the buffer" % (t, t))
+        ctx.frames = len(results)
+        return buf
+
+    @staticmethod
+    def backward(ctx, g: Tensor):
+        g = g.contiguous()
+        return (None, *g.view(ctx.frames, g.shape[0] // ctx.frames, *g.shape[1:]).unbind(0))
+
+
+def assemble(buf: Tensor, results) -> Tensor:
+    return _AssembleFn.apply((buf,), *results)
 
 
 def dvdgru_gates(gx_zr: Tensor, gh_zr: Optional[Tensor], h: Optional[Tensor], hidp: int) -> Tuple[Tensor, Tensor]:
     return _DvdGruGatesFn.apply(gx_zr.contiguous(), gh_zr.contiguous() if gh_zr is not None else None, h.contiguous() if h is not None else None, hidp)
 
 
-def dvdgru_out(gx_o: Tensor, gh_o: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int) -> Tensor:
-    return _DvdGruOutFn.apply(gx_o.contiguous(), gh_o.contiguous() if gh_o is not None else None, zr, h.contiguous() if h is not None else None, hidp)
+def dvdgru_out(gx_o: Tensor, gh_o: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None) -> Tensor:
+    return _DvdGruOutFn.apply(gx_o.contiguous(), gh_o.contiguous() if gh_o is not None else None, zr, h.contiguous() if h is not None else None, hidp, out)
 
 
 # ----------------------------------------------------------------------------------------------
