@@ -305,9 +305,24 @@ class WeightGradBatch:
         return len(self.xs) == self.uses
 
     def take(self) -> Tuple[Tensor, Tensor]:
-        x, g = torch.cat(self.xs, 0), torch.cat(self.gys, 0)
+        """(inputs, output gradients) of all applications, concatenated along the image axis in ONE order (a weight gradient sums over images: any).  Inputs
+        that lie back to back in one storage - a recurrent layer's states written into ``functional_gan.sequence_slots`` - are read in place: the pairs
+        are ordered by the inputs' addresses and, if those are consecutive, the input is a tensor on that storage span instead of a copy of it."""
+        xs, gys = self.xs, self.gys
         self.xs, self.gys = [], []
-        return x, g
+        order = sorted(range(len(xs)), key=lambda i: xs[i].data_ptr())
+        xs, gys = [xs[i] for i in order], [gys[i] for i in order]
+        esize = xs[0].element_size()
+        consecutive = len(xs) > 1 and all(
+            a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:]
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.data_ptr() + a.numel() * esize == b.data_ptr()
+            for a, b in zip(xs, xs[1:]))
+        if consecutive:
+            x = torch.empty(0, dtype=xs[0].dtype, device=xs[0].device).set_(xs[0].untyped_storage(), xs[0].storage_offset(),
+                                                                             (sum(t.shape[0] for t in xs), *xs[0].shape[1:]))
+        else:
+            x = torch.cat(xs, 0)
+        return x, torch.cat(gys, 0)
 
     def _end_of_backward(self) -> None:
         left, self._armed = len(self.xs), False

@@ -591,11 +591,12 @@ class _DvdGruGatesFn(torch.autograd.Function):
     """``(gx_zr, gh_zr, h) -> (z, rh)``: ``z = sig(.)`` is returned as the first ``hidp`` lanes of ``zr`` (kept whole for the out stage)."""
 
     @staticmethod
-    def forward(ctx, gx: Tensor, gh: Optional[Tensor], h: Optional[Tensor], hidp: int):
+    def forward(ctx, gx: Tensor, gh: Optional[Tensor], h: Optional[Tensor], hidp: int, out_rh: Optional[Tensor] = None):
         shp, dev = gx.shape[:-1], gx.device
         pixels = gx.numel() // gx.shape[-1]
         zr = torch.empty(*shp, 2 * hidp, dtype=torch.float32, device=dev)
-        rh = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
+        rh = out_rh if out_rh is not None else torch.empty(*shp, hidp, dtype=torch.float32, device=dev)   # (a frame's slot: see sequence_slots)
+        assert rh.shape == (*shp, hidp) and rh.dtype == torch.float32 and rh.is_contiguous()
         check(lib().sf_dvdgru_gates_fwd(T(gx), T(gh) if gh is not None else NULL, T(h) if h is not None else NULL, pixels, hidp, T(zr), T(rh), stream_ptr()),
               "sf_dvdgru_gates_fwd")
         ctx.hidp, ctx.has = hidp, (gh is not None, h is not None)
@@ -616,7 +617,7 @@ class _DvdGruGatesFn(torch.autograd.Function):
         dh = torch.empty(*zr.shape[:-1], hidp, dtype=torch.float32, device=zr.device) if has_h else None
         check(lib().sf_dvdgru_gates_bwd(T(dz) if dz is not None else NULL, T(drh) if drh is not None else NULL, T(zr), T(h) if has_h else NULL, pixels, hidp, T(dpre),
                                         T(dh) if dh is not None else NULL, stream_ptr()), "sf_dvdgru_gates_bwd")
-        return dpre, (dpre if has_gh else None), dh, None
+        return dpre, (dpre if has_gh else None), dh, None, None
 
 
 class _DvdGruOutFn(torch.autograd.Function):
@@ -683,8 +684,8 @@ def assemble(buf: Tensor, results) -> Tensor:
     return _AssembleFn.apply((buf,), *results)
 
 
-def dvdgru_gates(gx_zr: Tensor, gh_zr: Optional[Tensor], h: Optional[Tensor], hidp: int) -> Tuple[Tensor, Tensor]:
-    return _DvdGruGatesFn.apply(gx_zr.contiguous(), gh_zr.contiguous() if gh_zr is not None else None, h.contiguous() if h is not None else None, hidp)
+def dvdgru_gates(gx_zr: Tensor, gh_zr: Optional[Tensor], h: Optional[Tensor], hidp: int, out_rh: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
+    return _DvdGruGatesFn.apply(gx_zr.contiguous(), gh_zr.contiguous() if gh_zr is not None else None, h.contiguous() if h is not None else None, hidp, out_rh)
 
 
 def dvdgru_out(gx_o: Tensor, gh_o: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None) -> Tensor:

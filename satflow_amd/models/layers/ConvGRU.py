@@ -120,15 +120,16 @@ class ConvGRUCell(nn.Module):
         return (self._conv("zr_x", x, W["zr_x"], W["b_zr"], s2d=s2d, wt=W.get("zr_x_t")),
                 self._conv("o_x", x, W["o_x"], W["b_o"], s2d=s2d, wt=W.get("o_x_t")))
 
-    def step(self, gx_zr: Tensor, gx_o: Tensor, h: Optional[Tensor], W: dict, out: Optional[Tensor] = None) -> Tensor:
-        """``out``: where the new state is written (a frame's slot of ``functional_gan.sequence_slots``)."""
+    def step(self, gx_zr: Tensor, gx_o: Tensor, h: Optional[Tensor], W: dict, out: Optional[Tensor] = None, out_rh: Optional[Tensor] = None) -> Tensor:
+        """``out`` / ``out_rh``: where the new state / the reset state r * h is written (a frame's slot of ``functional_gan.sequence_slots``: the inputs
+        of the two state convolutions of all frames then lie back to back, and their batched weight gradients read them in place)."""
         s2d = bool(W.get("s2d"))
         hp = 4 * self._hp if s2d else self._hp   # the pointwise stages are layout-blind: [z | r] halves of 4 * hidp lanes each
         if h is None:  # zero state: the h-parts vanish
             zr, _ = FG.dvdgru_gates(gx_zr, None, None, hp)
             return FG.dvdgru_out(gx_o, None, zr, None, hp, out)
         gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"), s2d, W.get("zr_h_t"))
-        zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp)
+        zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp, out_rh)
         gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"), s2d, W.get("o_h_t"))
         return FG.dvdgru_out(gx_o, gh_o, zr, h, hp, out)
 
@@ -196,9 +197,11 @@ class ConvGRU(nn.Module):
             # every frame's state is written straight into its slice of the layer's output sequence (no torch.cat of the frames afterwards)
             slots_ok = not os.environ.get("SF_GRU_CAT")
             if slots_ok:
-                buf, slots = FG.sequence_slots(T_frames, (*o_t[0].shape[:-1], 4 * cell._hp if fold else cell._hp), o_t[0].device)
+                slot_shape = (*o_t[0].shape[:-1], 4 * cell._hp if fold else cell._hp)
+                buf, slots = FG.sequence_slots(T_frames, slot_shape, o_t[0].device)
+                _, rh_slots = FG.sequence_slots(max(T_frames - 1, 1), slot_shape, o_t[0].device)   # frames 1.. have a reset state
             for t in range(T_frames):
-                h = cell.step(zr_t[t], o_t[t], h, W, slots[t] if slots_ok else None)
+                h = cell.step(zr_t[t], o_t[t], h, W, slots[t] if slots_ok else None, rh_slots[t - 1] if slots_ok and t else None)
                 outs.append(h)
             seq, const = (FG.assemble(buf, outs) if slots_ok else torch.cat(outs, 0)), False
         return FG.depth_to_space2(seq) if folded else seq
