@@ -401,12 +401,28 @@ def regroup4x4s2(weight: Tensor, lanes: int) -> Tensor:
     return torch.nn.functional.pad(g.reshape(O, 4 * lanes, 2, 2), (1, 0, 1, 0))
 
 
+def regroup4x4s2_same(weight: Tensor, lanes: int) -> Tensor:
+    """``[O, I, 4, 4]`` (stride 2, padding 1) -> ``[O, 4 * lanes, 3, 3]``: the weight of the 3x3 'SAME' convolution over ``space_to_depth2(x)`` - the
+    UNPADDED input with its 2x2 pixel blocks folded into channels - that equals the strided convolution.  Output row i reads input rows 2i - 1 .. 2i + 2
+    = the second row of block i - 1, both rows of block i, the first row of block i + 1: block tap ty in {0, 1, 2} and row parity dy carry kernel row
+    ``2 ty + dy - 1`` (outside 0..3: zero), the same along the columns; the convolution's own zero padding IS the strided convolution's padding, so the
+    result has exactly the strided convolution's h/2 x w/2 pixels - no padded copy of the input, no crop of the output (round 5; the padded form is
+    ``regroup4x4s2``).  Autograd-tracked torch ops on a parameter-sized tensor."""
+    O, I = weight.shape[0], weight.shape[1]
+    g = torch.nn.functional.pad(weight, (1, 1, 1, 1)).reshape(O, I, 3, 2, 3, 2).permute(0, 3, 5, 1, 2, 4)   # [O, dy, dx, I, ty, tx]
+    if lanes != I:
+        g = torch.nn.functional.pad(g, (0, 0, 0, 0, 0, lanes - I))
+    return g.reshape(O, 4 * lanes, 3, 3)
+
+
 def conv4x4_as_3x3(x: Tensor, weight: Tensor, bias: Optional[Tensor], stride: int, eng: "F.ConvEngine") -> Tensor:
     """``nn.Conv2d(k=4, stride=1|2, padding=1)`` on the 3x3 MFMA kernels.  Stride 2 (even h, w): one 3x3 convolution over the padded input with its
     2x2 pixel blocks folded into channels (``regroup4x4s2``).  Stride 1: the 4x4 kernel is a 5x5 kernel with a zero first row and column, i.e.
     ``conv5x5_as_3x3``; its last output row and column do not exist in the reference's result.  ``eng``: a ConvEngine for ``[4 * x lanes] -> cout``."""
     n, h, w, cp = x.shape
     if stride == 2:
+        if not os.environ.get("SF_CONV4_PADDED"):   # (A/B switch: the padded input + cropped output of rounds 2-4)
+            return F.conv3x3(eng, space_to_depth2(x), regroup4x4s2_same(weight, cp), bias)
         y = F.conv3x3(eng, _PadS2dFn.apply(x.contiguous()), regroup4x4s2(weight, cp), bias)
         return y[:, : h // 2, : w // 2].contiguous()
     assert stride == 1

@@ -311,6 +311,11 @@ def test_conv4x4_weight_embeddings_on_cpu():
     ys = torch.cat([xp[:, dy:dy + 2 * H2:2, dx:dx + 2 * W2:2, :] for dy in (0, 1) for dx in (0, 1)], -1)   # what sf_pad_s2d_fwd writes
     out = TF.conv2d(ys.permute(0, 3, 1, 2), FG.regroup4x4s2(W, cp), b, padding=1)[:, :, : h // 2, : w // 2]
     assert torch.allclose(out, ref, rtol=1e-5, atol=1e-5)
+    # round 5: the unpadded form - space_to_depth2 of the input itself, the 3x3 convolution's own zero padding is the strided convolution's
+    xq = TF.pad(x.permute(0, 2, 3, 1), (0, cp - C))
+    xs = torch.cat([xq[:, dy::2, dx::2, :] for dy in (0, 1) for dx in (0, 1)], -1)                         # what sf_space_to_depth2 writes
+    out2 = TF.conv2d(xs.permute(0, 3, 1, 2), FG.regroup4x4s2_same(W, cp), b, padding=1)
+    assert out2.shape == ref.shape and torch.allclose(out2, ref, rtol=1e-5, atol=1e-5)
     ref1 = TF.conv2d(x, W, b, stride=1, padding=1)
     out1 = TF.conv2d(x, TF.pad(W, (1, 0, 1, 0)), b, padding=2)[:, :, : h - 1, : w - 1]
     assert torch.allclose(out1, ref1, rtol=1e-5, atol=1e-5)
