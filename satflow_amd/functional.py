@@ -322,7 +322,17 @@ class WeightGradBatch:
                                                                              (sum(t.shape[0] for t in xs), *xs[0].shape[1:]))
         else:
             x = torch.cat(xs, 0)
-        return x, torch.cat(gys, 0)
+        gsize = gys[0].element_size()
+        g_consecutive = len(gys) > 1 and all(
+            a.is_contiguous() and b.is_contiguous() and a.dtype == b.dtype and a.shape[1:] == b.shape[1:]
+            and a.untyped_storage().data_ptr() == b.untyped_storage().data_ptr() and a.data_ptr() + a.numel() * gsize == b.data_ptr()
+            for a, b in zip(gys, gys[1:]))
+        if g_consecutive:   # (the frames' gradients written into functional_gan.GradSlots: in place too)
+            g = torch.empty(0, dtype=gys[0].dtype, device=gys[0].device).set_(gys[0].untyped_storage(), gys[0].storage_offset(),
+                                                                              (sum(t.shape[0] for t in gys), *gys[0].shape[1:]))
+        else:
+            g = torch.cat(gys, 0)
+        return x, g
 
     def _end_of_backward(self) -> None:
         left, self._armed = len(self.xs), False

@@ -607,7 +607,7 @@ class _DvdGruGatesFn(torch.autograd.Function):
     """``(gx_zr, gh_zr, h) -> (z, rh)``: ``z = sig(.)`` is returned as the first ``hidp`` lanes of ``zr`` (kept whole for the out stage)."""
 
     @staticmethod
-    def forward(ctx, gx: Tensor, gh: Optional[Tensor], h: Optional[Tensor], hidp: int, out_rh: Optional[Tensor] = None):
+    def forward(ctx, gx: Tensor, gh: Optional[Tensor], h: Optional[Tensor], hidp: int, out_rh: Optional[Tensor] = None, gslot=None):
         shp, dev = gx.shape[:-1], gx.device
         pixels = gx.numel() // gx.shape[-1]
         zr = torch.empty(*shp, 2 * hidp, dtype=torch.float32, device=dev)
@@ -616,6 +616,7 @@ class _DvdGruGatesFn(torch.autograd.Function):
         check(lib().sf_dvdgru_gates_fwd(T(gx), T(gh) if gh is not None else NULL, T(h) if h is not None else NULL, pixels, hidp, T(zr), T(rh), stream_ptr()),
               "sf_dvdgru_gates_fwd")
         ctx.hidp, ctx.has = hidp, (gh is not None, h is not None)
+        ctx.gslot = gslot   # (GradSlots, frame): where this frame's pre-activation gradient is written
         ctx.save_for_backward(zr, h if h is not None else gx.new_empty(0))
         ctx.set_materialize_grads(False)
         return zr, rh
@@ -629,18 +630,19 @@ class _DvdGruGatesFn(torch.autograd.Function):
         pixels = zr.numel() // (2 * hidp)
         dz = dzr.contiguous() if dzr is not None else None   # read through its row stride: no slice copy
         drh = drh.contiguous() if drh is not None else None
-        dpre = torch.empty_like(zr)
+        dpre = ctx.gslot[0].slot(ctx.gslot[1]) if ctx.gslot is not None else torch.empty_like(zr)
+        assert dpre.shape == zr.shape
         dh = torch.empty(*zr.shape[:-1], hidp, dtype=torch.float32, device=zr.device) if has_h else None
         check(lib().sf_dvdgru_gates_bwd(T(dz) if dz is not None else NULL, T(drh) if drh is not None else NULL, T(zr), T(h) if has_h else NULL, pixels, hidp, T(dpre),
                                         T(dh) if dh is not None else NULL, stream_ptr()), "sf_dvdgru_gates_bwd")
-        return dpre, (dpre if has_gh else None), dh, None, None
+        return dpre, (dpre if has_gh else None), dh, None, None, None
 
 
 class _DvdGruOutFn(torch.autograd.Function):
     """``(gx_o, gh_o, zr, h) -> h' = h (1 - z) + tanh(gx_o + gh_o) z``."""
 
     @staticmethod
-    def forward(ctx, gx: Tensor, gh: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None):
+    def forward(ctx, gx: Tensor, gh: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None, gslot=None):
         shp, dev = gx.shape[:-1], gx.device
         pixels = gx.numel() // gx.shape[-1]
         cand = torch.empty(*shp, hidp, dtype=torch.float32, device=dev)
@@ -649,6 +651,7 @@ class _DvdGruOutFn(torch.autograd.Function):
         check(lib().sf_dvdgru_out_fwd(T(gx), T(gh) if gh is not None else NULL, T(zr), T(h) if h is not None else NULL, pixels, hidp, T(cand), T(hn), stream_ptr()),
               "sf_dvdgru_out_fwd")
         ctx.hidp, ctx.has, ctx.lanes = hidp, (gh is not None, h is not None), gx.shape[-1]
+        ctx.gslot = gslot
         ctx.save_for_backward(cand, zr, h if h is not None else gx.new_empty(0))
         return hn
 
@@ -659,12 +662,13 @@ class _DvdGruOutFn(torch.autograd.Function):
         has_gh, has_h = ctx.has
         pixels = cand.numel() // hidp
         dhn = dhn.contiguous()
-        da = torch.empty_like(cand)
+        da = ctx.gslot[0].slot(ctx.gslot[1]) if ctx.gslot is not None else torch.empty_like(cand)
+        assert da.shape == cand.shape
         dzr = torch.empty_like(zr)   # the kernel zeroes the r half: it does not reach h' through this stage
         dh = torch.empty_like(cand) if has_h else None
         check(lib().sf_dvdgru_out_bwd(T(dhn), T(cand), T(zr), T(h) if has_h else NULL, pixels, hidp, T(da), T(dzr), T(dh) if dh is not None else NULL, stream_ptr()),
               "sf_dvdgru_out_bwd")
-        return da, (da if has_gh else None), dzr, dh, None, None
+        return da, (da if has_gh else None), dzr, dh, None, None, None
 
 
 def sequence_slots(frames: int, shape, device):
@@ -700,12 +704,56 @@ def assemble(buf: Tensor, results) -> Tensor:
     return _AssembleFn.apply((buf,), *results)
 
 
-def dvdgru_gates(gx_zr: Tensor, gh_zr: Optional[Tensor], h: Optional[Tensor], hidp: int, out_rh: Optional[Tensor] = None) -> Tuple[Tensor, Tensor]:
-    return _DvdGruGatesFn.apply(gx_zr.contiguous(), gh_zr.contiguous() if gh_zr is not None else None, h.contiguous() if h is not None else None, hidp, out_rh)
+class GradSlots:
+    """The backward-pass counterpart of ``sequence_slots``: ONE gradient buffer for a tensor that the forward pass split into frames, allocated when the
+    first frame's backward asks for its slot.  A frame's backward kernel writes its gradient into ``slot(t)``; ``split_frames``' backward then finds the
+    frames' gradients already in place and returns the buffer (no ``torch.stack``), and a batched weight gradient reads them in place as well."""
+
+    def __init__(self, frames: int, frame_shape, device) -> None:
+        self.frames, self.shape, self.device, self.buf = frames, tuple(frame_shape), device, None
+
+    def slot(self, t: int) -> Tensor:
+        if self.buf is None:
+            self.buf = torch.empty(self.frames * self.shape[0], *self.shape[1:], dtype=torch.float32, device=self.device)
+        per = self.buf.numel() // self.frames
+        return torch.empty(0, dtype=torch.float32, device=self.device).set_(self.buf.untyped_storage(), self.buf.storage_offset() + t * per, self.shape)
 
 
-def dvdgru_out(gx_o: Tensor, gh_o: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None) -> Tensor:
-    return _DvdGruOutFn.apply(gx_o.contiguous(), gh_o.contiguous() if gh_o is not None else None, zr, h.contiguous() if h is not None else None, hidp, out)
+class _SplitFn(torch.autograd.Function):
+    """``x.view(frames, n, ...).unbind(0)`` as tensors of their own on x's storage; backward: the frames' gradients where they lie in the ``GradSlots``
+    buffer (written there by the frames' backward kernels), else their concatenation."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, frames: int, gslots: "GradSlots"):
+        x = x.contiguous()
+        per = x.numel() // frames
+        shape = (x.shape[0] // frames, *x.shape[1:])
+        ctx.gslots, ctx.frames, ctx.shape = gslots, frames, shape
+        return tuple(torch.empty(0, dtype=x.dtype, device=x.device).set_(x.untyped_storage(), x.storage_offset() + t * per, shape) for t in range(frames))
+
+    @staticmethod
+    def backward(ctx, *gs):
+        buf = ctx.gslots.buf
+        per = (buf.numel() // ctx.frames) if buf is not None else 0
+        if buf is not None and all(g is not None and g.is_contiguous() and g.data_ptr() == buf.data_ptr() + 4 * t * per and g.numel() == per
+                                   for t, g in enumerate(gs)):
+            return buf, None, None
+        ref = next(g for g in gs if g is not None)
+        return torch.cat([g if g is not None else torch.zeros(ctx.shape, dtype=ref.dtype, device=ref.device) for g in gs], 0), None, None
+
+
+def split_frames(x: Tensor, frames: int):
+    """``(per-frame tensors of time-major x, GradSlots for their gradients)``."""
+    gs = GradSlots(frames, (x.shape[0] // frames, *x.shape[1:]), x.device)
+    return _SplitFn.apply(x, frames, gs), gs
+
+
+def dvdgru_gates(gx_zr: Tensor, gh_zr: Optional[Tensor], h: Optional[Tensor], hidp: int, out_rh: Optional[Tensor] = None, gslot=None) -> Tuple[Tensor, Tensor]:
+    return _DvdGruGatesFn.apply(gx_zr.contiguous(), gh_zr.contiguous() if gh_zr is not None else None, h.contiguous() if h is not None else None, hidp, out_rh, gslot)
+
+
+def dvdgru_out(gx_o: Tensor, gh_o: Optional[Tensor], zr: Tensor, h: Optional[Tensor], hidp: int, out: Optional[Tensor] = None, gslot=None) -> Tensor:
+    return _DvdGruOutFn.apply(gx_o.contiguous(), gh_o.contiguous() if gh_o is not None else None, zr, h.contiguous() if h is not None else None, hidp, out, gslot)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -120,18 +120,21 @@ class ConvGRUCell(nn.Module):
         return (self._conv("zr_x", x, W["zr_x"], W["b_zr"], s2d=s2d, wt=W.get("zr_x_t")),
                 self._conv("o_x", x, W["o_x"], W["b_o"], s2d=s2d, wt=W.get("o_x_t")))
 
-    def step(self, gx_zr: Tensor, gx_o: Tensor, h: Optional[Tensor], W: dict, out: Optional[Tensor] = None, out_rh: Optional[Tensor] = None) -> Tensor:
+    def step(self, gx_zr: Tensor, gx_o: Tensor, h: Optional[Tensor], W: dict, out: Optional[Tensor] = None, out_rh: Optional[Tensor] = None,
+             gslots=(None, None)) -> Tensor:
         """``out`` / ``out_rh``: where the new state / the reset state r * h is written (a frame's slot of ``functional_gan.sequence_slots``: the inputs
         of the two state convolutions of all frames then lie back to back, and their batched weight gradients read them in place)."""
         s2d = bool(W.get("s2d"))
         hp = 4 * self._hp if s2d else self._hp   # the pointwise stages are layout-blind: [z | r] halves of 4 * hidp lanes each
+        # gslots: where the backward pass writes this frame's two pre-activation gradients (functional_gan.GradSlots: the gradients of the x-parts of all
+        # frames - which are also the output gradients of the state convolutions - then lie back to back)
         if h is None:  # zero state: the h-parts vanish
-            zr, _ = FG.dvdgru_gates(gx_zr, None, None, hp)
-            return FG.dvdgru_out(gx_o, None, zr, None, hp, out)
+            zr, _ = FG.dvdgru_gates(gx_zr, None, None, hp, None, gslots[0])
+            return FG.dvdgru_out(gx_o, None, zr, None, hp, out, gslots[1])
         gh_zr = self._conv("zr_h", h, W["zr_h"], None, W.get("batch_zr_h"), s2d, W.get("zr_h_t"))
-        zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp, out_rh)
+        zr, rh = FG.dvdgru_gates(gx_zr, gh_zr, h, hp, out_rh, gslots[0])
         gh_o = self._conv("o_h", rh, W["o_h"], None, W.get("batch_o_h"), s2d, W.get("o_h_t"))
-        return FG.dvdgru_out(gx_o, gh_o, zr, h, hp, out)
+        return FG.dvdgru_out(gx_o, gh_o, zr, h, hp, out, gslots[1])
 
     def run(self, x: Tensor, h: Optional[Tensor]) -> Tensor:
         W = self.weights(x.shape[-1])
@@ -191,17 +194,23 @@ class ConvGRU(nn.Module):
             gx_zr, gx_o = cell.x_parts(seq, W)
             n = gx_zr.shape[0] if const else gx_zr.shape[0] // T_frames
             # per-frame views through unbind (its backward is ONE stack, not a zero-filled full-size tensor per slice)
-            zr_t = [gx_zr] * T_frames if const else gx_zr.view(T_frames, n, *gx_zr.shape[1:]).unbind(0)
-            o_t = [gx_o] * T_frames if const else gx_o.view(T_frames, n, *gx_o.shape[1:]).unbind(0)
+            slots_ok = not os.environ.get("SF_GRU_CAT")
+            gz = go = None
+            if const:
+                zr_t, o_t = [gx_zr] * T_frames, [gx_o] * T_frames
+            elif slots_ok:   # frames as tensors of their own + one gradient buffer each for the way back (no torch.stack of the frames' gradients)
+                (zr_t, gz), (o_t, go) = FG.split_frames(gx_zr, T_frames), FG.split_frames(gx_o, T_frames)
+            else:
+                zr_t, o_t = gx_zr.view(T_frames, n, *gx_zr.shape[1:]).unbind(0), gx_o.view(T_frames, n, *gx_o.shape[1:]).unbind(0)
             h, outs = None, []
             # every frame's state is written straight into its slice of the layer's output sequence (no torch.cat of the frames afterwards)
-            slots_ok = not os.environ.get("SF_GRU_CAT")
             if slots_ok:
                 slot_shape = (*o_t[0].shape[:-1], 4 * cell._hp if fold else cell._hp)
                 buf, slots = FG.sequence_slots(T_frames, slot_shape, o_t[0].device)
                 _, rh_slots = FG.sequence_slots(max(T_frames - 1, 1), slot_shape, o_t[0].device)   # frames 1.. have a reset state
             for t in range(T_frames):
-                h = cell.step(zr_t[t], o_t[t], h, W, slots[t] if slots_ok else None, rh_slots[t - 1] if slots_ok and t else None)
+                h = cell.step(zr_t[t], o_t[t], h, W, slots[t] if slots_ok else None, rh_slots[t - 1] if slots_ok and t else None,
+                              ((gz, t) if gz is not None else None, (go, t) if go is not None else None))
                 outs.append(h)
             seq, const = (FG.assemble(buf, outs) if slots_ok else torch.cat(outs, 0)), False
         return FG.depth_to_space2(seq) if folded else seq
