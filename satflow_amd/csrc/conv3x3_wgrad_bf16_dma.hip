@@ -37,6 +37,11 @@ constexpr int TR = 4, TW = 16;             // K tile: 4 rows x 16 pixels
 constexpr int HR = TR + 2, HW = TW + 2;    // halo tile 6 x 18
 constexpr int NS_REG = 4;                  // ring depth (tiles) of the regular slab: 3, 4 and 5 measured alike (the DMA's latency is covered)
 constexpr int LDS_BYTES = NS_REG * 32768;  // regular: 4 stages x (16 KiB dout + 16 KiB input); wide: 3 x 40 KiB
+#ifndef SF_EXP_NS_POOLED
+#define SF_EXP_NS_POOLED 6
+#endif
+constexpr int NS_POOLED = SF_EXP_NS_POOLED;               // pooled sparse operand: stages of 8 KiB + 16 KiB
+constexpr int LDS_BYTES_POOLED = NS_POOLED * 24576;
 constexpr int THREADS = 512;
 
 __device__ __forceinline__ bf16x4_t tr_read(unsigned lds_addr) {
@@ -96,10 +101,13 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   constexpr bool WIDE = GEO != 0;
   constexpr int A_PIX = GEO == 1 ? 4 * DMA_CO_T : GEO == 2 ? DMA_CO_T : 2 * DMA_CO_T;   // bytes per dout pixel in a stage (256 / 64 / 128 channels)
   constexpr int B_PIX = GEO == 1 ? DMA_CI_T : GEO == 2 ? 4 * DMA_CI_T : 2 * DMA_CI_T;   // bytes per input pixel (32 / 128 / 64 channels)
-  constexpr int A_BYTES = TR * TW * A_PIX;                                              // 32768 / 8192 / 16384
+  // (SPARSE 2: the pooled gradient's 4 KB + 512 B of codes + the dummy pieces of waves 5-7 in 8 KB)
+  constexpr int A_BYTES = SPARSE == 2 ? 8192 : TR * TW * A_PIX;                         // 32768 / 8192 / 16384
   constexpr int B_BYTES = GEO == 1 ? 8192 : GEO == 2 ? 32768 : 16384;                   // 108 px x B_PIX, padded to whole 8-block rounds
   constexpr int STAGE = A_BYTES + B_BYTES;
-  constexpr int NS = WIDE ? 3 : ::NS_REG;                     // ring depth
+  // ring depth.  SPARSE 2: SIX stages of 24 KB - a tile of the sparse kernel is half the matrix work of a dense one, so the same DMA latency spans twice
+  // as many tiles: with four stages (two tiles in flight behind the rendezvous) the fetch rate was bytes-in-flight / latency, 0.35 ms of the call
+  constexpr int NS = WIDE ? 3 : SPARSE == 2 ? ::NS_POOLED : ::NS_REG;
   constexpr bool POOLED = SPARSE == 2;
   static_assert(!POOLED || (FAST && GEO == 0), "the pooled operand is built for the regular slabs of the descriptor DMA path");
   // DMA instructions per wave and tile: 2 + 2 / 4 + 1 / 1 + 4; POOLED: ONE for the sparse operand's sources (waves 0-3: the pooled gradient's 4 KB,
@@ -650,7 +658,7 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
 template <bool FAST, bool GROUPED = false, int SPARSE = 0>
 __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradParams p, const int per_slice, const char* __restrict__ zero,
                                                                      const int xcd_groups, const int cot_n, const int cit_n, const int edge_mode) {
-  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES];
+  __shared__ __attribute__((aligned(1024))) char lds[SPARSE == 2 ? LDS_BYTES_POOLED : LDS_BYTES];
   const int units = gridDim.y;
   int ks, unit;
   {
