@@ -21,6 +21,8 @@
 // issues exactly 4 DMA instructions per tile and the counted waits stay exact.
 // The bias gradient is summed from the dout fragments (VALU, one wave in eight).  Split-K partial slabs in the shared
 // layout; `wgrad_reduce_kernel` (conv3x3_wgrad_f32.hip) finishes.
+#include <type_traits>
+
 #include "wgrad_common.h"
 
 namespace {
@@ -651,6 +653,281 @@ __device__ __forceinline__ void wgrad_dma_body(const WgradParams& p, const int p
   store_partial(GROUPED ? ks * p.maxseg + seg : ks);
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------------------
+// POOLED sparse operand on 8-ROW K tiles (SPARSE 2 in pairs; round 5).  Timing builds and SQ counters of the kernels above say the whole family is
+// bound by the bytes it pulls through the LDS-DMA path (~4 TB/s whatever the matrix work; profiles/r05_wgrad_sparse_ab.txt), and a 4 x 16 tile
+// fetches a 6 x 18 halo of the input: 1.69x its pixels.  Here a stage holds TWO vertically adjacent tiles - 4 pooled rows of the gradient + codes
+// (9 KB) and a 10 x 18 input halo (22.5 KB; 1.41x) - fetched by 2 + 3 DMA instructions per wave, and the two halves run the SPARSE-2 tile code on
+// their rows of it: 31.5 KB instead of 36 per 128 pixels, one rendezvous per 36 matrix instructions instead of per 18.  Image heights in whole 8-row
+// tiles (the plan counts tiles of 8 rows: Plan::tr); everything else - slab, waves, operand construction, partial slabs - as SPARSE 2.
+// ---------------------------------------------------------------------------------------------------------------------------------------
+constexpr int TR8 = 8, HR8 = TR8 + 2;
+constexpr int P8_A_BYTES = 10240, P8_B_BYTES = 24576, P8_STAGE = P8_A_BYTES + P8_B_BYTES, P8_NS = 4;   // [g 8 KB | codes 1 KB | dump 1 KB][halo 24 KB]
+constexpr int LDS_BYTES_P8 = P8_NS * P8_STAGE;   // 136 KB
+constexpr int LDS_CONST_P8 = THREADS * 32;       // + 16 KB: every lane's eight DMA constants (offsets, class masks) - in registers they pushed the kernel into scratch
+                                                 // INSIDE the tile loop, and a scratch reload is a vector memory operation: it breaks the ring's counted waits
+__device__ __forceinline__ void wgrad_pooled8_body(const WgradParams& p, const int per_slice, char* lds, const int ks, const int cot, const int cit) {
+  constexpr int B_PIX = 2 * DMA_CI_T;
+  constexpr int A_BYTES = P8_A_BYTES, STAGE = P8_STAGE, NS = P8_NS;
+  constexpr int NA = 2, NBK = 3, NDMA = NA + NBK;
+  constexpr unsigned SENT = 0x80000000u;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wq = wave & 3, wc = wave >> 2;
+  const int t_begin = ks * per_slice;
+  const int t_end = t_begin + per_slice < p.ntiles ? t_begin + per_slice : p.ntiles;
+  const int my_tiles = t_end > t_begin ? t_end - t_begin : 0;   // (tiles of 8 rows)
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
+  int nx_i = 0, nx_stage = 0, nx_tx, nx_ty, nx_n;
+  {
+    int t = t_begin < p.ntiles ? t_begin : 0;
+    nx_tx = t % p.tiles_x; t /= p.tiles_x;
+    nx_ty = t % p.tiles_y;
+    nx_n = t / p.tiles_y;
+  }
+  const int Hp = p.H >> 1, Wp = p.W >> 1;
+  const long long g_img = (long long)Hp * Wp * p.pool_s * 2, r_img = (long long)Hp * Wp * (p.dc >> 3) * 2;
+  // pooled gradient: piece P = 64 wave + lane of the tile's 4 x 8 pooled pixels (pixel P / 16: row P / 128, column (P / 16) % 8), [pixel][256 B] at the stage's origin,
+  // the 64-byte channel groups xor-ed with (pixel & 3); routing codes: wave 0, lane = (pooled pixel lane / 2, octets 8 (lane % 2) ..), [pixel][32 B] at + 8192
+  unsigned pa_voff = SENT, pc_voff = SENT;
+  {
+    const int P = 64 * wave + lane, pp = P >> 4, c16 = P & 15;
+    const int ch = cot * DMA_CO_T + (((c16 >> 2) ^ (pp & 3)) * 32) + (c16 & 3) * 8;
+    if (ch < p.dc) pa_voff = (unsigned)((((pp >> 3) * Wp + (pp & 7)) * p.pool_s + ch) * 2);
+    if (wave == 0) {
+      const int pq = lane >> 1, oct = cot * (DMA_CO_T / 8) + (lane & 1) * 8;
+      if (oct * 8 < p.dc) pc_voff = (unsigned)((((pq >> 3) * Wp + (pq & 7)) * (p.dc >> 3) + oct) * 2);
+    }
+  }
+  const unsigned pc_dst = wave == 0 ? 8192u : 9216u;   // (the other waves' all-out-of-range instruction zero-fills a dump block)
+  unsigned fb_off[NBK], fb_mask[NBK];
+  const int bs = p.s0;
+#pragma unroll
+  for (int u = 0; u < NBK; ++u) {
+    const int b = wave + 8 * u;
+    const int hp = 8 * b + (lane >> 3);
+    const int hy = hp / HW, hx = hp % HW;
+    const int cb = lane & 7, pqb = cb >> 2;
+    const int kc = cit * DMA_CI_T + ((pqb ^ ((hx >> 1) & 1)) * 32) + (cb & 3) * 8;
+    const bool chok = hp < HR8 * HW && kc < p.c0;
+    fb_off[u] = (unsigned)(((hy * p.W + hx) * bs + kc) * 2);
+    fb_mask[u] = 0;
+    for (int cls = 0; cls < 16; ++cls) {
+      const int y0 = (cls & 2) ? (p.tiles_y - 1) * TR8 : ((cls & 1) ? 0 : TR8), x0 = (cls & 8) ? (p.tiles_x - 1) * TW : ((cls & 4) ? 0 : TW);
+      const int gy = y0 - 1 + hy, gx = x0 - 1 + hx;
+      if (chok && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) fb_mask[u] |= 1u << cls;
+    }
+  }
+  const unsigned b_pxb = 2u * (unsigned)bs;
+  const long long b_img = (long long)p.H * p.W * b_pxb;
+  {
+    typedef __attribute__((address_space(3))) u32x4* lds_w4;
+    const unsigned ca = lds0 + (unsigned)(LDS_BYTES_P8 + tid * 32);
+    *(lds_w4)(uintptr_t)ca = u32x4{pa_voff, pc_voff, fb_off[0], fb_mask[0]};
+    *(lds_w4)(uintptr_t)(ca + 16) = u32x4{fb_off[1], fb_mask[1], fb_off[2], fb_mask[2]};
+  }
+  auto pooled_image = [&](int n) {
+    if (p.pool_L == 0) return n;
+    const int b = n % p.pool_B, t = (n / p.pool_B) % p.pool_T, l = n / (p.pool_B * p.pool_T);
+    return (t * p.pool_L + l) * p.pool_B + b;
+  };
+  int nx_ng = pooled_image(nx_n);
+  const bool stage_late = wave >= 4;
+  auto issue = [&]() {
+    typedef __attribute__((address_space(3))) const u32x4* lds_c4;   // (an LDS read, ordered by lgkmcnt: never a vector-memory operation)
+    // (the lane id is taken again from the exec-mask count: two VALU operations the compiler can repeat anywhere instead of keeping - or spilling - a register)
+    const unsigned lane_now = __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+    const unsigned ca = lds0 + (unsigned)LDS_BYTES_P8 + ((unsigned)wave * 64u + lane_now) * 32u;
+    const u32x4 c0 = *(lds_c4)(uintptr_t)ca, c1 = *(lds_c4)(uintptr_t)(ca + 16);
+    const unsigned pa_voff = c0[0], pc_voff = c0[1];
+    const unsigned fb_off[NBK] = {c0[2], c1[0], c1[2]}, fb_mask[NBK] = {c0[3], c1[1], c1[3]};
+    const bool live = nx_i < my_tiles;
+    const int n = nx_n, px0 = (nx_ty * TR8) * p.W + nx_tx * TW;
+    const unsigned cls = (nx_ty == 0 ? 1u : 0u) | (nx_ty == p.tiles_y - 1 ? 2u : 0u) | (nx_tx == 0 ? 4u : 0u) | (nx_tx == p.tiles_x - 1 ? 8u : 0u);
+    const unsigned sel = live ? 1u << cls : 0u;
+    const unsigned stage = lds0 + (unsigned)(nx_stage * STAGE);
+    const unsigned pix0 = (unsigned)((nx_ty * (TR8 / 2)) * Wp + nx_tx * (TW / 2));
+    const __amdgpu_buffer_rsrc_t rsg = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.pool_g + nx_ng * g_img), 0, __builtin_amdgcn_readfirstlane((int)g_img), 0x00020000);
+    const __amdgpu_buffer_rsrc_t rsr = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.pool_route + n * r_img), 0, __builtin_amdgcn_readfirstlane((int)r_img), 0x00020000);
+    bufdma16(live ? pa_voff : SENT, rsg, pix0 * (unsigned)(p.pool_s * 2), stage + wave * 1024);
+    bufdma16(live ? pc_voff : SENT, rsr, pix0 * (unsigned)((p.dc >> 3) * 2), stage + pc_dst);
+    const long long lead = (long long)(p.W + 1) * b_pxb;
+    const __amdgpu_buffer_rsrc_t rsb = __builtin_amdgcn_make_buffer_rsrc(uniform_ptr((const char*)p.src0 + n * b_img - lead), 0, __builtin_amdgcn_readfirstlane((int)(b_img + 2 * lead)), 0x00020000);
+    const unsigned sob = (unsigned)px0 * b_pxb;
+#pragma unroll
+    for (int u = 0; u < NBK; ++u) bufdma16((fb_mask[u] & sel) ? fb_off[u] : SENT, rsb, sob, stage + A_BYTES + (wave + 8 * u) * 1024);
+    ++nx_i;
+    nx_stage = nx_stage + 1 == NS ? 0 : nx_stage + 1;
+    if (++nx_tx == p.tiles_x) { nx_tx = 0; if (++nx_ty == p.tiles_y) { nx_ty = 0; ++nx_n; nx_ng = pooled_image(nx_n); } }
+  };
+
+  // ---- per-lane LDS read addresses (half 1 of a stage: + 4096 in the pooled gradient, + 512 in the codes, + 4 halo rows) ----
+  const int m = (lane >> 2) & 3, khalf = lane >> 5;
+  const int cbyte = ((lane >> 4) & 1) * 32 + (lane & 3) * 8;
+  unsigned bs_base[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx)
+    bs_base[kx] = lds0 + A_BYTES + (m + kx) * B_PIX + ((wc ^ (((m + kx) >> 1) & 1)) * 64) + cbyte + khalf * (2 * HW * B_PIX);
+  const unsigned ap_base = lds0 + (4 * khalf + m) * 256 + ((wq ^ m) * 64) + cbyte;
+  const unsigned cp_base = lds0 + 8192 + (4 * khalf) * 32 + (4 * wq + ((lane & 31) >> 3)) * 2;
+  const unsigned csh = 2u * (lane & 7);
+  constexpr unsigned HALF_A = 4096, HALF_C = 512, HALF_B = 4 * HW * B_PIX;
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
+  float bsum = 0.f;
+  const bool want_bias = cit == 0 && wc == 0;
+
+#pragma unroll
+  for (int i = 0; i < NS - 1; ++i) issue();
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 2)) : "memory");
+  __builtin_amdgcn_s_barrier();
+
+  struct SpA { bf16x8 a02, a13; int idx; float bias; };
+  auto load_pooled = [&](unsigned so, unsigned half, SpA& sp) __attribute__((always_inline)) {
+    typedef __attribute__((address_space(3))) const unsigned short* lds_u16;
+    const unsigned ag = (ap_base + so + half * HALF_A) & 0x3ffffu, ac = (cp_base + so + half * HALF_C) & 0x3ffffu;
+    const u32x2 g0 = __builtin_bit_cast(u32x2, tr_read(ag)), g1 = __builtin_bit_cast(u32x2, tr_read(ag + 2048));
+    unsigned code[8];
+#pragma unroll
+    for (int s = 0; s < 8; ++s) code[s] = ((unsigned)*(lds_u16)(uintptr_t)(ac + ((s >> 2) * 8 + (s & 3)) * 32) >> csh) & 3u;
+    const unsigned gd[4] = {g0[0], g0[1], g1[0], g1[1]};
+    unsigned v02[4], v13[4], idx = 0;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      const unsigned ce = code[2 * q], co = code[2 * q + 1];
+      const unsigned keep1 = ((ce & 2u) ? 0x0000ffffu : 0u) | ((co & 2u) ? 0xffff0000u : 0u);
+      v13[q] = gd[q] & keep1;
+      v02[q] = gd[q] & ~keep1;
+      idx |= ((ce & 1u) | ((2u + (co & 1u)) << 2)) << (4 * q);
+    }
+    sp.a02 = __builtin_bit_cast(bf16x8, u32x4{v02[0], v02[1], v02[2], v02[3]});
+    sp.a13 = __builtin_bit_cast(bf16x8, u32x4{v13[0], v13[1], v13[2], v13[3]});
+    sp.idx = (int)idx;
+    float bs_ = 0.f;
+    if (want_bias) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) bs_ += __builtin_bit_cast(float, gd[q] << 16) + __builtin_bit_cast(float, gd[q] & 0xffff0000u);
+    }
+    sp.bias = bs_;
+  };
+  auto load_b16 = [&](const unsigned (&aBS)[3], int a, bf16x16 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) {
+      const unsigned ad = aBS[kx] + a * (HW * B_PIX);
+      const bf16x8 lo = cat8(tr_read(ad), tr_read(ad + 4 * B_PIX)), hi = cat8(tr_read(ad + 8 * B_PIX), tr_read(ad + 12 * B_PIX));
+      b[kx] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 14, 15);
+    }
+  };
+  auto smf = [&](const bf16x8& a, int idx, int ky, const bf16x16 (&b)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) acc[ky * 3 + kx] = __builtin_amdgcn_smfmac_f32_32x32x32_bf16(a, b[kx], acc[ky * 3 + kx], idx, 0, 0);
+  };
+  SpA spa, spb;
+  bf16x16 sq0[3], sq1[3];
+  unsigned aBS[3];      // fragment addresses of the half being multiplied
+  unsigned cur_so = 0;  // its stage
+  int rd_stage = 0;
+  auto half_addr = [&](unsigned so, unsigned half, unsigned (&a)[3]) __attribute__((always_inline)) {
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) a[kx] = (bs_base[kx] + so + half * HALF_B) & 0x3ffffu;
+  };
+  // one half (4 rows) of a stage; HALF 0 hands over to half 1 of the same stage, HALF 1 holds the ring's rendezvous and hands over to the next stage
+  auto half_s = [&](auto HALF, SpA& cur, SpA& nxt) __attribute__((always_inline)) {
+    constexpr int H = decltype(HALF)::value;
+    bsum += cur.bias;
+    load_b16(aBS, 1, sq1);
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a02, cur.idx, 0, sq0);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(aBS, 2, sq0);
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a02, cur.idx, 1, sq1);
+    smf(cur.a13, cur.idx, 0, sq1);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(aBS, 3, sq1);
+    unsigned nso;
+    if constexpr (H == 1) {
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(NDMA * (NS - 3)) : "memory");
+      __builtin_amdgcn_s_barrier();
+      if (!stage_late) issue();
+      rd_stage = rd_stage + 1 == NS ? 0 : rd_stage + 1;
+      nso = (unsigned)(rd_stage * STAGE);
+    } else nso = cur_so;
+    unsigned nBS[3];
+    half_addr(nso, H == 1 ? 0u : 1u, nBS);
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a02, cur.idx, 2, sq0);
+    smf(cur.a13, cur.idx, 1, sq0);
+    load_pooled(nso, H == 1 ? 0u : 1u, nxt);
+    __builtin_amdgcn_sched_barrier(0);
+    load_b16(nBS, 0, sq0);
+    if constexpr (H == 1) { if (stage_late) issue(); }
+    __builtin_amdgcn_sched_barrier(0);
+    smf(cur.a13, cur.idx, 2, sq1);
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int kx = 0; kx < 3; ++kx) aBS[kx] = nBS[kx];
+    cur_so = nso;
+  };
+  const int r = lane & 31, kh = lane >> 5;
+  auto store_partial = [&](int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int tap = 0; tap < 9; ++tap)
+#pragma unroll
+      for (int reg = 0; reg < 16; ++reg) {
+        const int co = cot * DMA_CO_T + 32 * wq + frag_row(reg, kh);
+        const int ci = cit * DMA_CI_T + 32 * wc + r;
+        p.partial[(((size_t)slot * 9 + tap) * p.NpT + co) * p.KpT + ci] = acc[tap][reg];
+      }
+    if (want_bias) {
+      const float tot = bsum + __shfl_xor(bsum, 32);
+      if (kh == 0) p.partial_db[(size_t)slot * p.NpT + cot * DMA_CO_T + 32 * wq + r] = tot;
+    }
+  };
+  int seg = 0, next_flush = p.tpg - t_begin % p.tpg;
+  auto group_boundary = [&](int i) __attribute__((always_inline)) {
+    if (__builtin_expect(i == next_flush, 0)) {
+      store_partial(ks * p.maxseg + seg);
+      ++seg; next_flush += p.tpg;
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] = 0.f;
+      bsum = 0.f;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+  };
+  half_addr(0u, 0u, aBS);
+  load_pooled(0u, 0u, spa);
+  load_b16(aBS, 0, sq0);
+  for (int i = 0; i < my_tiles; ++i) {
+    group_boundary(i);
+    half_s(std::integral_constant<int, 0>{}, spa, spb);
+    half_s(std::integral_constant<int, 1>{}, spb, spa);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  store_partial(ks * p.maxseg + seg);
+}
+
+__global__ __launch_bounds__(THREADS, 2) void wgrad_pooled8_kernel(const WgradParams p, const int per_slice, const int xcd_groups, const int cot_n) {
+  __shared__ __attribute__((aligned(1024))) char lds[LDS_BYTES_P8 + LDS_CONST_P8];
+  const int units = gridDim.y;
+  int ks, unit;
+  {
+    const int id = blockIdx.x + gridDim.x * blockIdx.y;
+    if (xcd_groups) {
+      const int x = id % 8, j = id / 8;
+      ks = (j / units) * 8 + x;
+      unit = j % units;
+    } else { ks = blockIdx.x; unit = blockIdx.y; }
+  }
+  wgrad_pooled8_body(p, per_slice, lds, ks, unit % cot_n, unit / cot_n);
+}
+
 // Workgroup -> (K slice, slab).  Grid = (KS, units); `units` = the regular (co tile, ci tile) slabs followed by the edge slabs (edge_mode 1: one GEO-1
 // slab per PAIR of co tiles of the last ci tile; edge_mode 2: one GEO-2 slab per PAIR of ci tiles of the last co tile, a leftover ci tile stays
 // regular).  The slabs of one K slice are consecutive on one XCD (blocks are dealt round-robin to the 8 XCDs), so a slice's tiles are shared
@@ -688,11 +965,12 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_dma_kernel(const WgradP
 
 }  // namespace
 
-sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups, int single_source) {
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups, int single_source, int tr) {
   using namespace sfwgrad;
   Plan pl;
+  pl.tr = tr == TR8 ? TR8 : TR;   // K-tile height: 4 rows; 8 for the pooled sparse operand on tile pairs (wgrad_pooled8_body)
   pl.tiles_x = (w + TW - 1) / TW;
-  pl.tiles_y = (h + TR - 1) / TR;
+  pl.tiles_y = (h + pl.tr - 1) / pl.tr;
   pl.ntiles = pl.tiles_x * pl.tiles_y * n;
   pl.cot = (Np + DMA_CO_T - 1) / DMA_CO_T;
   pl.cit = (Kp + DMA_CI_T - 1) / DMA_CI_T;
@@ -768,6 +1046,10 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
         sf_set_error("wgrad_bf16_dma: the pooled sparse operand needs the pooled gradient + routing record, whole 4 x 16 tiles and a permutation that covers n");
         return 1;
       }
+      if (pl.tr == TR8) {
+        if (p.H % TR8) { sf_set_error("wgrad_bf16_dma: the 8-row plan needs image heights in whole 8-row tiles"); return 1; }
+        hipLaunchKernelGGL(wgrad_pooled8_kernel, grid, dim3(THREADS), 0, st, p, per_slice, xcd_groups, pl.cot);
+      } else
       hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true, 2>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
     } else if (p.sparse24) hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true, 1>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);
     else hipLaunchKernelGGL((wgrad_bf16_dma_kernel<true, true>), grid, dim3(THREADS), 0, st, p, per_slice, (const char*)workspace, xcd_groups, pl.cot, pl.cit, pl.edge_mode);

@@ -479,7 +479,14 @@ static int bwd_weight_folded_impl(sfTensor src, sfTensor dout, int32_t n, int32_
   SF_REQUIRE(scale && shift && dw, "bwd_weight_folded: null argument");
   SF_REQUIRE(!bn_sums || (weight && mean && rstd && ((uintptr_t)workspace & 7) == 0), "bwd_weight_folded: bn_sums needs weight, mean, rstd (and an 8-byte aligned workspace)");
   const int Np = dout.c, Kp = src.c;
-  const Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1);
+  // the pooled sparse operand takes K tiles of 8 rows (two tiles per DMA stage: wgrad_pooled8_body) when the image height allows and the workspace the
+  // caller sized for the 4-row plan holds that plan's slabs too (SF_WGRAD_TR8=0: A/B switch back to 4-row tiles)
+  static const bool no_tr8 = getenv("SF_WGRAD_TR8") != nullptr && getenv("SF_WGRAD_TR8")[0] == '0';
+  Plan pl = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1);
+  if (sparse24 == 2 && !no_tr8 && h % 8 == 0) {
+    const Plan p8 = sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, groups, 1, 8);
+    if (p8.edge_mode == 0 && fold_layout(p8, Np, n, groups).total_floats * sizeof(float) <= workspace_bytes) pl = p8;
+  }
   const FoldLayout fl = fold_layout(pl, Np, n, groups);
   SF_REQUIRE(workspace && workspace_bytes >= fl.total_floats * sizeof(float), "bwd_weight_folded: workspace too small (%zu < %zu)", workspace_bytes,
              fl.total_floats * sizeof(float));

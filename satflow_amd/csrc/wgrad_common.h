@@ -32,7 +32,7 @@ struct WgradParams {
 };
 
 
-struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; int tpg = 0, maxseg = 1; int wide_pairs = 0, units = 0, edge_mode = 0; };
+struct Plan { int tiles_x, tiles_y, ntiles, KS, cot, cit; size_t ws_floats; int tpg = 0, maxseg = 1; int wide_pairs = 0, units = 0, edge_mode = 0; int tr = 4; };
 
 // kt_h: K-tile height of the kernel variant (4 rows fp32, 8 rows bf16)
 inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
@@ -62,7 +62,7 @@ inline Plan make_plan(int Np, int Kp, int n, int h, int w, int kt_h) {
 // plan fields
 // groups > 0 (folded BatchNorm): n splits into `groups` runs of whole images; a slice stores one partial slab per group it touches
 // single_source: the launch reads ONE input tensor (the folded path always; sf_conv3x3_bwd_weight when src1 is empty): wide slabs allowed
-sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups = 0, int single_source = 0);
+sfwgrad::Plan sf_wgrad_bf16_dma_plan(int Np, int Kp, int n, int h, int w, int groups = 0, int single_source = 0, int tr = 4);
 int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, float* workspace, hipStream_t st);
 // bf16-MFMA variant (conv3x3_wgrad_bf16.hip): fills the same partial slabs
 int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);
