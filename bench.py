@@ -360,9 +360,11 @@ class MetNetWorkload:
                 gp_ = torch.randn_like(pooled_)
                 dsp = K.maxpool2_route_bwd(route_, gp_, tuple(yp.shape), bf, None, None)
                 pooled_form = K.conv3x3_bwd_weight_pooled_supported(eng.coutp, cpad(cin), n, H, W, G)
-                row(f"wgrad_bf16_dma_kernel<FAST, GROUPED, SPARSE {2 if pooled_form else 1}> {cin}->{cout}: the gradient behind the max-pooling as the 2:4 structured-sparse MFMA "
+                tr8 = pooled_form and H % 8 == 0 and os.environ.get("SF_WGRAD_TR8", "1")[:1] != "0"   # (8-row K tiles: its own kernel name)
+                row((f"wgrad_pooled8_kernel {cin}->{cout} (FAST, GROUPED, 8-row K tiles)" if tr8 else f"wgrad_bf16_dma_kernel<FAST, GROUPED, SPARSE {2 if pooled_form else 1}> {cin}->{cout}")
+                    + ": the gradient behind the max-pooling as the 2:4 structured-sparse MFMA "
                     f"operand{', built from the pooled gradient + routing codes' if pooled_form else ''} (+ folded-BatchNorm helpers)",
-                    f"wgrad_bf16_dma_kernel<true, true, {2 if pooled_form else 1}>", 1, cin, cout,
+                    "wgrad_pooled8_kernel" if tr8 else f"wgrad_bf16_dma_kernel<true, true, {2 if pooled_form else 1}>", 1, cin, cout,
                     lambda: K.conv3x3_bwd_weight_folded(T(x), T(dsp), n, H, W, eng.wgrad_map, scale, shift, dw, db, bn=(w, mean, rstd, sums), pooled_gradient=True,
                                                         pooled=(gp_, route_, None) if pooled_form else None),
                     "weight gradient of conv4 (dense-equivalent flops: half the matrix instructions)", out_lanes=0)
