@@ -97,6 +97,10 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
   constexpr int NPIECE = (PIECES + THREADS - 1) / THREADS;
   __shared__ __attribute__((aligned(1024))) char lds[WBUFS * W_B + 2 * IN_B];
   __shared__ __attribute__((aligned(16))) float lds_coef[BNB ? 3 * NB : 4];  // BatchNorm-backward epilogue: (A, B, K) of this N block
+  // NF = 5 (160 accumulators, 256 registers all in use): the per-piece DMA words live in LDS, [piece][thread], and are read back at issue time - an LDS
+  // read waits on lgkmcnt; a register that spills waits on vmcnt(0), i.e. on the DMA pieces just issued (see in_pk below)
+  constexpr bool PK_LDS = NF == 5 && !DUAL;
+  __shared__ unsigned lds_pk[PK_LDS ? 5 * THREADS : 1];
   char* lds_w = lds;
   char* lds_in = lds + WBUFS * W_B;
 
@@ -202,7 +206,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
   // Descriptor = the source image, started one image row + one pixel early so that the halo origin has a non-negative offset.
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)lds;
   __amdgpu_buffer_rsrc_t rs_in0 = __builtin_amdgcn_make_buffer_rsrc(nullptr, 0, 0, 0x00020000), rs_in1 = rs_in0, rs_w = rs_in0;
-  unsigned in_off0[NPIECE], in_off1[NPIECE];
+  // ONE packed word per piece - halo pixel offset iy * W + ix in bits 0..29, the logical 16-byte half in bit 30, all ones = outside the image - from which the
+  // byte offset of either source is two VALU operations at issue time.  (Rounds 1-4 kept a ready offset per SOURCE: ten registers in the NF = 5 kernel, which
+  // spilled exactly those - and a scratch reload between two DMA pieces is a vector-memory operation whose `s_waitcnt vmcnt(0)` waits for the pieces just
+  // issued to LAND: the staging block of every chunk stalled four times for a full memory latency.  Found in round 5 through the same effect in
+  // conv3x3_wgrad_bf16_dma.hip.)
+  unsigned in_pk[NPIECE];
   unsigned so_in0 = 0, so_in1 = 0;
   if constexpr (!DUAL) {
     auto desc = [&](const float* src, int stride, int idiv, int imod, unsigned& so) {
@@ -220,8 +229,8 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       const int gy = y0 + iy - 1, gx = x0 + ix - 1;
       const bool ok = pc < PIECES && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
       const int half = (pc & 1) ^ (iy & 1);  // the DMA writes lane-linearly: physical half pc & 1 fetches the logical half (bank swizzle)
-      in_off0[j] = ok ? (unsigned)(((iy * p.W + ix) * p.s0 + 8 * half) * 2) : DMA_SENT;
-      in_off1[j] = ok ? (unsigned)(((iy * p.W + ix) * p.s1 + 8 * half) * 2) : DMA_SENT;
+      in_pk[j] = ok ? (unsigned)(iy * p.W + ix) | ((unsigned)half << 30) : 0xffffffffu;
+      if constexpr (PK_LDS) { static_assert(!PK_LDS || NPIECE <= 5, "lds_pk holds five pieces per thread"); lds_pk[j * THREADS + tid] = in_pk[j]; }
     }
   }
   // weights: descriptor over this N block's packed image; the chunk and the 1 KiB piece go into the scalar offset
@@ -272,6 +281,17 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
   // piece pc = (pixel, physical half) lands in 16-byte slot pc and fetches the LOGICAL half (physical ^ row parity,
   // the bank swizzle of the register path).  Halo pixels outside the image are never written by the DMA (lanes
   // masked off): their slots are zeroed once per block, below.
+  auto piece_off = [](unsigned pk, int stride) __attribute__((always_inline)) {
+    return pk == 0xffffffffu ? DMA_SENT : (pk & 0x3fffffffu) * (unsigned)(2 * stride) + ((pk >> 30) << 4);
+  };
+  auto piece_word = [&](int j) __attribute__((always_inline)) {
+    if constexpr (PK_LDS) {   // (thread index rebuilt from the wave number and the exec-mask count: nothing to keep in a register, nothing to spill)
+      typedef __attribute__((address_space(3))) const unsigned* lds_u32;
+      const unsigned t = (unsigned)wave * 64u + __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+      const unsigned base = (unsigned)(uintptr_t)(__attribute__((address_space(3))) unsigned*)lds_pk;
+      return *(lds_u32)(uintptr_t)(base + (unsigned)(j * THREADS) * 4u + t * 4u);
+    } else return in_pk[j];
+  };
   auto dma_input = [&](int ci, int buf) {
     if constexpr (!DUAL) {
       const unsigned dst = lds0 + (unsigned)(WBUFS * W_B + buf * IN_B + wave * 1024);
@@ -280,12 +300,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
         const unsigned so = so_in0 + (unsigned)(ci * KC * 2);
 #pragma unroll
         for (int j = 0; j < NPIECE; ++j)
-          if (tid + j * THREADS < PIECES) bufdma16(in_off0[j], rs_in0, so, dst + j * WAVES * 1024);  // lanes past the tile are masked off: a zero-filling lane there would write into the other buffer
+          if (tid + j * THREADS < PIECES) bufdma16(piece_off(piece_word(j), p.s0), rs_in0, so, dst + j * WAVES * 1024);  // lanes past the tile are masked off: a zero-filling lane there would write into the other buffer
       } else {
         const unsigned so = so_in1 + (unsigned)((ci - ch0) * KC * 2);
 #pragma unroll
         for (int j = 0; j < NPIECE; ++j)
-          if (tid + j * THREADS < PIECES) bufdma16(in_off1[j], rs_in1, so, dst + j * WAVES * 1024);
+          if (tid + j * THREADS < PIECES) bufdma16(piece_off(piece_word(j), p.s1), rs_in1, so, dst + j * WAVES * 1024);
       }
       return;
     }
