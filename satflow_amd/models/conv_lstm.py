@@ -50,6 +50,12 @@ def _diagonal_bwd() -> bool:
     return os.environ.get("SF_LSTM_DIAG_BWD", "1") == "1"
 
 
+def _streams_allowed() -> bool:
+    """The two-stream schedules run in eager mode; under hipGraph capture they fall back to the serial order unless SF_LSTM_CAPTURE_STREAMS=1 (experiment:
+    fork / join of the side streams inside the capture)."""
+    return not torch.cuda.is_current_stream_capturing() or bool(os.environ.get("SF_LSTM_CAPTURE_STREAMS"))
+
+
 def _side_stream(dev, which: int = 0) -> "torch.cuda.Stream":
     """Second streams of the stack, per device: 0 = the diagonal partner (encoder 2 forward / encoder 1 backward), 1 = the decoder cells' weight
     gradients (their own queue: on the partner's they would sit in front of encoder 1's first gate kernel)."""
@@ -94,7 +100,7 @@ class _StackFn(torch.autograd.Function):
             eng.step(T(inp), Hs[k][t - 1] if t else None, Cs[k][t - 1] if t else None, B, H, W, Hs[k][t], Cs[k][t],
                      Gs[k][t] if keep else None)
 
-        if _diagonal() and T_in > 1 and not torch.cuda.is_current_stream_capturing():
+        if _diagonal() and T_in > 1 and _streams_allowed():
             # diagonal order (reference conv_lstm.py:176-182: encoder_2 at step t only needs encoder_1 at step t): encoder 2 runs one step
             # behind encoder 1 on a second stream, so two cell launches are in flight and one's epilogue meets the other's K loop
             main, side = torch.cuda.current_stream(dev), _side_stream(dev)
@@ -200,14 +206,14 @@ class _StackFn(torch.autograd.Function):
             back(2, s, last, [dx_of(3)])
         # The decoder cells' dz are complete here.  Round 5 (SF_LSTM_WGRAD_SIDE=0: the A/B switch back): their weight gradients - MFMA-bound - go to a second
         # stream now, next to the encoder's backward unroll whose gate kernels are HBM-bound (complementary resources; measured: +0.5 %).
-        wg_side = (os.environ.get("SF_LSTM_WGRAD_SIDE", "1") == "1" and not torch.cuda.is_current_stream_capturing())
+        wg_side = (os.environ.get("SF_LSTM_WGRAD_SIDE", "1") == "1" and _streams_allowed())
         if wg_side:
             main_s, side_s = torch.cuda.current_stream(dev), _side_stream(dev, 1)
             side_s.wait_stream(main_s)
             with torch.cuda.stream(side_s):
                 wgrad_cell(3)
                 wgrad_cell(2)
-        if _diagonal_bwd() and T_in > 1 and not torch.cuda.is_current_stream_capturing():
+        if _diagonal_bwd() and T_in > 1 and _streams_allowed():
             # Diagonal backwards, in ANTI-PHASE (round 5): encoder 1 at step t only needs encoder 2's input gradient of step t, so it runs on a
             # second stream while encoder 2 goes on to step t-1.  The round-4 form released encoder 1's step as soon as its input existed - and a
             # kernel trace (tools/trace_overlap.sh) showed the two streams in lockstep: gate kernel next to gate kernel (both HBM-bound), input-gradient
