@@ -1077,7 +1077,7 @@ def main(argv=None):
     ap.add_argument("--global-batch", type=int, default=64)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the extra figures (fp32 parity mode, hidden 32, attention) on rank 0")
-    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f16", "f32"],
+    ap.add_argument("--dtype", default=os.environ.get("SF_DTYPE", "bf16a"), choices=["bf16a", "bf16", "f16", "f32", "f32e"],
                     help="arithmetic of the convolution kernels: bf16 operands + fp32 accumulate (default), the same with the MetNet "
                          "encoder's activations also STORED as bf16 (bf16a), fp16 operands + fp32 accumulate (f16: the dgmr workload's "
                          "`precision: 16`, BASELINE configs[4]), or exact fp32 (parity mode)")
@@ -1132,7 +1132,7 @@ def main(argv=None):
                          ("samples/sec + per-step ms, DGMR-style GAN generator+discriminator step 12ch 256x256" if args.workload == "dgmr" else "stub")))),
             "value": samples / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
-            "dtype": {"f32": "f32", "f16": "f16"}.get(args.dtype, "bf16"),
+            "dtype": {"f32": "f32", "f16": "f16", "f32e": "f32 (3 x f16)"}.get(args.dtype, "bf16"),
             "data": "synthetic (seeded uniform/normal tensors of the BASELINE shape, random-init weights)",
             "config": wl.config(world), "final_loss": final_loss,
             # the same K steps between two HIP events on the launch stream (this rank); `ms_per_step` is the wall clock incl. the barriers
@@ -1141,6 +1141,9 @@ def main(argv=None):
         }
         out["config"]["arithmetic"] = {
             "f32": "exact-fp32 MFMA, fp32 storage (the parity mode: rtol 1e-4 / atol 1e-5 against the CPU oracle)",
+            "f32e": "fp32-equivalent convolutions on the fp16 matrix pipe: every fp32 operand split into two fp16 parts as it is staged (22 mantissa bits), three fp16 "
+                    "MFMA products per fp32 product (lo*hi + hi*lo, exact 2^-11 rescale, hi*hi), fp32 accumulate and storage; gradient operands scaled per tensor "
+                    "through sf_amax; meets the fp32 parity gate (rtol 1e-4 / atol 1e-5) - every other kernel exact fp32",
             "bf16": "bf16 MFMA operands, fp32 accumulate, fp32 storage of all activations",
             "f16": "fp16 MFMA operands (v_mfma_f32_32x32x16_f16) for every 3x3 / 3x3x3 / 5x5 convolution (forward, input and weight gradients) and the attention "
                    "products, fp32 accumulate, fp32 storage and parameters: configs/trainer/half.yaml:33 `precision: 16`",

@@ -30,14 +30,24 @@
 extern "C" {
 #endif
 
-/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*; 5: sf_space_to_depth2, sf_regroup5x5_s2d_*, sf_conv5x5_*, sf_linear_fwd with 16-bit operands) */
-#define SF_ABI_VERSION 7
+/* bumped on EVERY signature or workspace-layout change (2: workspace arguments of sf_convgru_seq_*, sticky error word; 3: SF_F16, sf_bmm_f16; 4: sf_flash_attention_*; 5: sf_space_to_depth2, sf_regroup5x5_s2d_*, sf_conv5x5_*, sf_linear_fwd with 16-bit operands; 8: SF_F32E, sfTensor.amax, sf_amax) */
+#define SF_ABI_VERSION 8
 #define SF_CPAD 16 /* channel padding granule of NHWC activations */
 
 typedef void* sfStream; /* hipStream_t */
 
 /* Arithmetic/storage type of a kernel family. */
-enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2 };
+enum { SF_F32 = 0, SF_BF16 = 1, SF_F16 = 2, SF_F32E = 3 };
+/* SF_F32E (ABI 8): fp32-EQUIVALENT products on the fp16 matrix pipe (gfx950 has no TF32; v_mfma_f32_32x32x16_f16 is 16x the exact-fp32 MFMA rate).
+ * Every fp32 operand is split as it is staged, x = hi + 2^-11 lo' with hi = fp16(x), lo' = fp16((x - hi) * 2^11) - 22 mantissa bits - and the K loop runs
+ * three times over the operands: first [hi(x) * lo'(w) + lo'(x) * hi(w)], then the accumulators are scaled by 2^-11 (exact), then hi(x) * hi(w); fp32
+ * accumulation, fp32-stored tensors, fp32 epilogues - the arithmetic behind the fp32 parity gate (rtol 1e-4 / atol 1e-5, BASELINE.json north_star) at
+ * three fp16 products per fp32 product (profiles/r06_f32e_numerics.txt: every reference golden passes the unchanged gates with >= 5x margin; the same
+ * split in bf16 does not).  fp16's range is handled per tensor: forward activations and weights are taken as they are (|x| >= 65520 overflows to inf ->
+ * NaN results, loudly), a GRADIENT operand carries sfTensor.amax and is scaled by the power of two that puts its largest magnitude at 2^14 (undone, exactly,
+ * on the accumulators).  Accepted by sf_conv3x3_pack_weights (the packed image then has 3 * Kp / 16 chunks: sf_conv3x3_packed_elems(Np, 3 * Kp) halves),
+ * sf_conv3x3_fwd (linear / sigmoid), sf_convlstm_cell_fwd, sf_convgru_step_fwd and sf_conv3x3_bwd_weight; every other entry refuses it (the host runs the
+ * exact-fp32 kernels there). */
 /* SF_F16 (round 4): fp16 MFMA operands (v_mfma_f32_32x32x16_f16), fp32 accumulate, fp32-STORED tensors - the `precision: 16` of the reference's
  * configs/trainer/half.yaml:33 (BASELINE configs[4]).  Accepted by sf_conv3x3_pack_weights, sf_conv3x3_fwd (linear / sigmoid epilogue),
  * sf_conv3x3_fwd_splitk(+ _workspace_bytes) and sf_conv3x3_bwd_weight; the attention products have sf_bmm_f16.  Every other entry refuses it. */
@@ -70,7 +80,16 @@ typedef struct {
                      `dgh` of sf_convgru_bwd_gates) and for the ConvLSTM's layer inputs / hidden states
                      (`x`, `h_prev`, `h_out` of sf_convlstm_cell_fwd with the SF_BF16 kernel); everything else
                      requires SF_F32 */
+  const float* amax; /* (ABI 8; SF_F32E kernels only, nullable) device word written by sf_amax: max |element| of this tensor.  A convolution source
+                     (`src0` of sf_conv3x3_fwd: the output gradient of an input-gradient launch) or `dout` of sf_conv3x3_bwd_weight that carries it is
+                     multiplied by 2^(14 - floor(log2 amax)) before it is split into fp16 parts, and the accumulators by the inverse afterwards. */
 } sfTensor;
+
+/* (ABI 8) amax[0] = max |t| over `pixels` pixels x t.c channels of an fp32-stored tensor (0 for an empty one), for sfTensor.amax.  Two launches on the
+ * stream (reset word, reduce with one atomic per workgroup: the maximum is order-independent, so the result is deterministic).  amax_acc (nullable): a
+ * second word that takes the maximum of ITS current value and this tensor's - the running maximum over the per-step gate gradients of a recurrent cell,
+ * whose weight gradient reads all steps in one launch; reset_acc != 0 zeroes it first. */
+int sf_amax(sfTensor t, int64_t pixels, float* amax, float* amax_acc, int32_t reset_acc, sfStream stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Weight repack (derived cache; the saved form stays the reference's OIHW fp32 state_dict).

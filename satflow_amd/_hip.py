@@ -13,15 +13,15 @@ import torch
 
 _LIB_PATH = os.environ.get("SATFLOW_HIP_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libsatflow_hip.so")
 
-SF_F32, SF_BF16, SF_F16 = 0, 1, 2
+SF_F32, SF_BF16, SF_F16, SF_F32E = 0, 1, 2, 3
 SF_EPI_LINEAR, SF_EPI_SIGMOID = 0, 1
 SF_CPAD = 16
-ABI_VERSION = 7  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
+ABI_VERSION = 8  # == SF_ABI_VERSION of include/satflow_hip.h; bumped on every signature / workspace-layout change
 
 
 class sfTensor(C.Structure):
     _fields_ = [("ptr", C.c_void_p), ("c", C.c_int32), ("stride", C.c_int32), ("idiv", C.c_int32), ("imod", C.c_int32),
-                ("dtype", C.c_int32)]
+                ("dtype", C.c_int32), ("amax", C.c_void_p)]
 
 
 class sfBlock(C.Structure):
@@ -34,6 +34,7 @@ _i32, _i64, _vp, _sz = C.c_int32, C.c_int64, C.c_void_p, C.c_size_t
 PROTOTYPES = {
     "sf_abi_version": (C.c_int, []),
     "sf_last_error_string": (C.c_char_p, []),
+    "sf_amax": (C.c_int, [sfTensor, _i64, _vp, _vp, _i32, _vp]),
     "sf_conv3x3_packed_elems": (_sz, [_i32, _i32]),
     "sf_conv3x3_pack_weights": (C.c_int, [_vp, _i32, _i32, _vp, _i32, _vp, _i32, _i32, _i32, _vp, _vp, _vp, _i32, _vp]),
     "sf_conv3x3_fwd": (C.c_int, [sfTensor, sfTensor, _i32, _i32, _i32, _vp, _vp, _i32, _i32, _i32, sfTensor, _i32, _vp]),
@@ -219,7 +220,7 @@ def require_device(t: torch.Tensor, name: str) -> None:
         )
 
 
-NULL = sfTensor(None, 0, 0, 0, 0, 0)
+NULL = sfTensor(None, 0, 0, 0, 0, 0, None)
 
 
 # ----------------------------------------------------------------------------------------------
@@ -276,16 +277,18 @@ def clear_device_errors() -> None:
         ws[0].zero_()
 
 
-def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0, idiv: int = 0, imod: int = 0) -> sfTensor:
+def T(t: Optional[torch.Tensor], c: Optional[int] = None, offset: int = 0, idiv: int = 0, imod: int = 0,
+      amax: Optional[torch.Tensor] = None) -> sfTensor:
     """Describe a channels-last tensor ``[..., C]`` (or a channel slice ``offset:offset+c`` of it).
 
-    ``idiv`` / ``imod``: image-index remap for convolution inputs (see ``sfTensor`` in the header)."""
+    ``idiv`` / ``imod``: image-index remap for convolution inputs (see ``sfTensor`` in the header).
+    ``amax``: the device word ``sf_amax`` wrote for this tensor (a gradient operand of the "f32e" kernels; the caller keeps the word alive)."""
     if t is None:
-        return sfTensor(None, c or 0, 0, 0, 0, 0)
+        return sfTensor(None, c or 0, 0, 0, 0, 0, None)
     assert t.is_contiguous() and t.dtype in (torch.float32, torch.bfloat16), (t.shape, t.dtype, t.is_contiguous())
     stride = t.shape[-1]
     return sfTensor(t.data_ptr() + t.element_size() * offset, stride - offset if c is None else c, stride, idiv, imod,
-                    SF_BF16 if t.dtype == torch.bfloat16 else SF_F32)
+                    SF_BF16 if t.dtype == torch.bfloat16 else SF_F32, amax.data_ptr() if amax is not None else None)
 
 
 # Parameter generation: bumped whenever parameters are rewritten through raw pointers (sf_adam_step),
@@ -311,13 +314,17 @@ def generation():
 # "bf16a" = SF_BF16 kernels AND bf16 storage of the MetNet image encoder's activations and their gradients
 # (what torch.autocast(bfloat16) leaves in memory between the reference's Conv2d layers); everything from the
 # encoder's last pooling on (ConvGRU, attention, head, loss, parameters, optimizer state) stays fp32.
+# "f32e" (round 6) = SF_F32E: fp32-EQUIVALENT convolutions on the fp16 matrix pipe - every fp32 operand split into two fp16 parts while it is staged
+# (22 mantissa bits), three fp16 products per fp32 product, fp32 accumulation and storage; meets the fp32 parity gate (profiles/r06_f32e_numerics.txt)
+# at ~3/16 of the exact-fp32 MFMA cost.  The 3x3 convolutions (forward / input gradient / weight gradient) and the fused recurrent cells take it;
+# every other kernel runs its exact-fp32 form in this mode.
 _COMPUTE = [SF_F32]
 _ENCODER_BF16 = [False]
 
 
 def set_compute_dtype(name: str) -> None:
     _COMPUTE[0] = {"f32": SF_F32, "fp32": SF_F32, "float32": SF_F32, "bf16": SF_BF16, "bfloat16": SF_BF16, "bf16a": SF_BF16,
-                   "f16": SF_F16, "fp16": SF_F16, "float16": SF_F16}[name]
+                   "f16": SF_F16, "fp16": SF_F16, "float16": SF_F16, "f32e": SF_F32E}[name]
     _ENCODER_BF16[0] = name == "bf16a"
 
 
@@ -328,7 +335,13 @@ def compute_dtype() -> int:
 def compute_dtype_name() -> str:
     if _COMPUTE[0] == SF_BF16:
         return "bf16a" if _ENCODER_BF16[0] else "bf16"
-    return "f16" if _COMPUTE[0] == SF_F16 else "f32"
+    return {SF_F16: "f16", SF_F32E: "f32e"}.get(_COMPUTE[0], "f32")
+
+
+def exact_dtype(dt: Optional[int] = None) -> int:
+    """The dtype to hand to an entry point that has no SF_F32E instantiation: its exact-fp32 kernels in "f32e" mode, unchanged otherwise."""
+    dt = _COMPUTE[0] if dt is None else dt
+    return SF_F32 if dt == SF_F32E else dt
 
 
 def gate_storage_dtype():

@@ -22,7 +22,21 @@
 // The 16-bit OPERAND type is a compile-time choice of this translation unit: __bf16 here, _Float16 when the file is included by conv3x3_f16.hip
 // (SF_OPERAND_F16: the `precision: 16` of the reference's configs/trainer/half.yaml:33 - fp16 MFMA operands, fp32 accumulate, fp32 storage).  The f16
 // build renames the three launch entry points (sf_launch_conv_f16 / sf_conv_f16_tiles / sf_pack_weights_f16) and never takes the persistent kernels.
-#ifdef SF_OPERAND_F16
+// SF_SPLIT3 (with SF_OPERAND_F16; conv3x3_f32e.hip): the SF_F32E compute mode - fp32-equivalent products from THREE fp16 products.  The K loop runs over 3 x
+// the chunks: phase A, per real chunk c, the virtual chunks 2c = hi(x) * lo'(w) and 2c + 1 = lo'(x) * hi(w) (lo' = the residual after the fp16 rounding,
+// scaled by 2^11 so that it has the operand's own exponent range); then the accumulators are multiplied by 2^-11 (exact) and phase B adds hi(x) * hi(w).
+// The packed weight image holds the virtual chunks in that order (pack kernel below); a real chunk's fp32 halo tile is loaded once for its two phase-A
+// chunks.  fp32-stored tensors only; the recurrent epilogues are allowed (the fused ConvLSTM cell is the pinned hot path of the parity mode).
+#ifdef SF_SPLIT3
+#ifndef SF_OPERAND_F16
+#error "SF_SPLIT3 is built on the fp16 operand type"
+#endif
+#define SF_OP_T _Float16
+#define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define sf_launch_conv_bf16 sf_launch_conv_f32e
+#define sf_conv_bf16_tiles sf_conv_f32e_tiles
+#define sf_pack_weights_bf16 sf_pack_weights_f32e
+#elif defined(SF_OPERAND_F16)
 #define SF_OP_T _Float16
 #define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define sf_launch_conv_bf16 sf_launch_conv_f16
@@ -39,6 +53,29 @@ using namespace sfconv;
 
 typedef SF_OP_T bf16x8 __attribute__((ext_vector_type(8)));  // eight operands of the translation unit's 16-bit type
 typedef float f32x8 __attribute__((ext_vector_type(8)));
+
+#ifdef SF_SPLIT3
+constexpr float SPLIT_UP = 2048.f, SPLIT_DOWN = 1.f / 2048.f;   // 2^11: the low part's scale
+// part of v (already multiplied by the tensor's power-of-two scale) that a virtual chunk multiplies: hi = fp16(v), or lo' = fp16((v - hi) * 2^11)
+__device__ __forceinline__ bf16x8 split_part(f32x8 v, bool lo) {
+  const bf16x8 hi = __builtin_convertvector(v, bf16x8);
+  if (!lo) return hi;
+  return __builtin_convertvector((v - __builtin_convertvector(hi, f32x8)) * SPLIT_UP, bf16x8);
+}
+// power-of-two scale that puts a tensor's largest magnitude (device word `amax`, sf_amax) at 2^14; 1 without a word or for an all-zero tensor.
+// Returns (scale, 1 / scale) - both exact.
+__device__ __forceinline__ void split_scale(const float* amax, float& s, float& inv) {
+  s = inv = 1.f;
+  if (!amax) return;
+  const unsigned bits = __builtin_bit_cast(unsigned, *amax);
+  const int e = (int)((bits >> 23) & 0xffu) - 127;   // floor(log2 amax) of a normal value
+  if ((bits & 0x7fffffffu) == 0u) return;
+  int k = 14 - e;
+  k = k > 126 ? 126 : (k < -126 ? -126 : k);
+  s = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+}
+#endif
 
 constexpr int HALO_W = TILE_W + 2;  // 18
 constexpr int PIX_B = 32;           // bytes per pixel / per weight row in LDS (16 bf16)
@@ -149,6 +186,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       for (int i = 0; i < 16; ++i) acc[mf][nf][i] = 0.f;
   // Fused LSTM cell: the accumulators START at the gate biases (lane = pixel, register 4g + c of fragment q = channel 8g + 4kh + c of gate q): the
   // loads run under the first chunk's staging and the epilogue begins with the cell-state loads instead of sixteen bias loads.
+#ifdef SF_SPLIT3
+  float sx, sx_inv;                        // the source's power-of-two scale (gradient operands, ConvParams::amax0) and its inverse
+  split_scale(p.amax0, sx, sx_inv);
+  const float acc0_scale = SPLIT_UP * sx;  // accumulators that START at a bias live through the 2^-11 rescale and the final 1 / sx
+#endif
   if constexpr (EPI == EPI_LSTM) {
     static_assert(TR, "the LSTM epilogue is the transposed one");
     if (p.bias) {
@@ -160,7 +202,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 #pragma unroll
           for (int mf = 0; mf < 2; ++mf)
 #pragma unroll
+#ifdef SF_SPLIT3
+            for (int c = 0; c < 4; ++c) acc[mf][nf][4 * g + c] = b[c] * acc0_scale;
+#else
             for (int c = 0; c < 4; ++c) acc[mf][nf][4 * g + c] = b[c];
+#endif
         }
     }
   }
@@ -196,7 +242,15 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
   const int ch0 = p.src0 ? p.c0 / KC : 0;
   const int ch1 = p.src1 ? p.c1 / KC : 0;
   const int c0_chunks = p.c0 / KC;
+#ifdef SF_SPLIT3
+  const int nreal = ch0 + ch1;          // real 16-channel chunks of the sources
+  const int nch = 3 * nreal;            // virtual chunks of the K loop
+  const int wreal = p.chunks_total / 3; // real chunks of the packed image (sources that are absent at t = 0 keep their weight chunks)
+  auto v_real = [&](int cv) { return cv < 2 * nreal ? cv >> 1 : cv - 2 * nreal; };
+  auto v_xlo = [&](int cv) { return cv < 2 * nreal && (cv & 1); };   // the chunk multiplies lo'(x) (with hi(w)); every other chunk hi(x)
+#else
   const int nch = ch0 + ch1;
+#endif
 
   f32x8 inreg[NPIECE];
   int staged_bf = 0;  // storage type of the chunk held in inreg (block-uniform)
@@ -238,11 +292,20 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
   rs_w = __builtin_amdgcn_make_buffer_rsrc((void*)((const char*)p.wp + wgrp + (size_t)nb * p.chunks_total * W_B), 0, p.chunks_total * W_B, 0x00020000);
 
   auto issue_weights = [&](int ci, int buf) {
+#ifdef SF_SPLIT3
+    const int rc = v_real(ci), rchunk = rc < ch0 ? rc : c0_chunks + (rc - ch0);
+    const int chunk = ci < 2 * nreal ? 2 * rchunk + (ci & 1) : 2 * wreal + rchunk;   // packed order: [lo'(w) c, hi(w) c] per real chunk, then hi(w) of all
+#else
     const int chunk = ci < ch0 ? ci : c0_chunks + (ci - ch0);
+#endif
     const unsigned dst = lds0 + buf * W_B;
     for (int i = wave; i < 9 * NF; i += WAVES) bufdma16(lane * 16, rs_w, (unsigned)(chunk * W_B + i * 1024), dst + i * 1024);
   };
   auto load_input = [&](int ci) {  // fp32-stored source: registers now, bf16 conversion + ds_write after the chunk's MFMAs
+#ifdef SF_SPLIT3
+    if (v_xlo(ci)) return;   // the second phase-A chunk of a real chunk: its fp32 values are the ones already in `inreg`
+    ci = v_real(ci);
+#endif
     const float* src; int cbase, stride, idiv, imod;
     if (ci < ch0) { src = p.src0; cbase = ci * KC; stride = p.s0; idiv = p.idiv0; imod = p.imod0; }
     else          { src = p.src1; cbase = (ci - ch0) * KC; stride = p.s1; idiv = p.idiv1; imod = p.imod1; }
@@ -265,7 +328,7 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       inreg[j] = v;
     }
   };
-  auto store_input = [&](int buf) {
+  auto store_input = [&](int buf, bool lo_part = false) {
     if (staged_bf) return;  // bf16-stored sources went straight to LDS (dma_input)
     char* dst = lds_in + buf * IN_B;
 #pragma unroll
@@ -273,7 +336,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       const int pc = tid + j * THREADS;
       const int pix = pc >> 1, half = pc & 1;
       const int iy = pix / HALO_W;
+#ifdef SF_SPLIT3
+      if (pc < PIECES) *reinterpret_cast<bf16x8*>(dst + pix * PIX_B + 16 * (half ^ (iy & 1))) = split_part(inreg[j] * sx, lo_part);
+#else
       if (pc < PIECES) *reinterpret_cast<bf16x8*>(dst + pix * PIX_B + 16 * (half ^ (iy & 1))) = __builtin_convertvector(inreg[j], bf16x8);
+#endif
     }
   };
   // bf16-STORED sources need no conversion: their halo tile goes HBM -> LDS by LDS-DMA like the weights (no staging
@@ -326,9 +393,14 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     }
   };
   auto stage_input = [&](int ci) {  // issue side of the next chunk's input staging
+#ifdef SF_SPLIT3
+    (void)dma_input;
+    load_input(ci);   // fp32-stored sources only (the launcher refuses bf16 storage)
+#else
     staged_bf = ci < ch0 ? p.bf0 : p.bf1;
     if (staged_bf) dma_input(ci, ci & 1);
     else load_input(ci);
+#endif
   };
   if (DUAL && (p.bf0 || p.bf1)) {  // compiler-issued DMA path (lanes masked off): zero the out-of-image halo slots of both buffers once
 #pragma unroll
@@ -363,6 +435,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     // ~7 LDS-DMA pieces, and when both partners do that at the same moment the SIMD's matrix pipe idles.  Out of phase,
     // the partner's MFMAs cover the stall (measured 256->256@32x32: 2.56 -> 2.42 ms; splitting by wave parity instead,
     // which pairs waves of different SIMDs, gains nothing; spreading the pieces over the taps loses the gain).
+#ifdef SF_SPLIT3
+    if (ci == 2 * nreal) {   // phase A -> phase B: the correction terms were accumulated at 2^11 times their value
+#pragma unroll
+      for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+        for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+          for (int i = 0; i < 16; ++i) acc[mf][nf][i] *= SPLIT_DOWN;
+    }
+#endif
     const bool stage_late = WAVES == 8 && wave >= 4;
     auto stage_next = [&]() {
 #ifdef SF_EXP_NOSTAGE   // ablation (tools/ablate_lstm_cell.sh): no staging of the next chunk - MFMAs on whatever the LDS holds
@@ -473,7 +555,11 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
       }
     }
     }
+#ifdef SF_SPLIT3
+    if (ci + 1 < nch) store_input(cur ^ 1, v_xlo(ci + 1));
+#else
     if (ci + 1 < nch) store_input(cur ^ 1);  // other buffer: last read in chunk ci-1, every wave is past this chunk's barrier
+#endif
     if constexpr (WS) {
       if (ci + 1 < nch) {
         __syncthreads();              // every wave has read its last weight fragment of this chunk
@@ -482,6 +568,16 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
     }
   }
 
+#ifdef SF_SPLIT3
+  if (p.amax0) {   // block-uniform: the gradient operand's power-of-two scale leaves the accumulators (exact)
+#pragma unroll
+    for (int mf = 0; mf < 2; ++mf)
+#pragma unroll
+      for (int nf = 0; nf < NF; ++nf)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[mf][nf][i] *= sx_inv;
+  }
+#endif
   // optional per-tile BatchNorm statistics of the stored outputs (linear epilogue): lane sums -> LDS (the operand
   // buffers are free once every wave has left the K loop) -> one [32*NF][2] record per workgroup
   float* lds_stats = nullptr;
@@ -529,8 +625,13 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int I, const int* __restrict__ nmap, int Np,
                                          const int* __restrict__ kmap, int Kp, int NB, int transpose, SF_OP_T* __restrict__ packed,
                                          const float* __restrict__ bias, float* __restrict__ bias_packed, const float* __restrict__ kscale, int groups) {
+#ifdef SF_SPLIT3
+  const int rchunks = Kp / KC, chunks = 3 * rchunks;   // virtual chunks: [lo'(w) c, hi(w) c] per real chunk c, then hi(w) of every chunk
+  const size_t image = (size_t)Np * Kp * 27, total = image * groups;
+#else
   const size_t image = (size_t)Np * Kp * 9, total = image * groups;
   const int chunks = Kp / KC;
+#endif
   for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (size_t)gridDim.x * blockDim.x) {
     // logical element e -> [group][nblk][chunk][tap][row][k16]
     const int grp = (int)(e / image);
@@ -541,13 +642,22 @@ __global__ void pack_weights_bf16_kernel(const float* __restrict__ w, int O, int
     const int chunk = t % chunks;
     const int nblk = t / chunks;
     const int nn = nmap[nblk * NB + row];
+#ifdef SF_SPLIT3
+    const int rchunk = chunk < 2 * rchunks ? chunk >> 1 : chunk - 2 * rchunks;
+    const bool lo_part = chunk < 2 * rchunks && !(chunk & 1);
+    const int kk = kmap[rchunk * KC + k16];
+#else
     const int kk = kmap[chunk * KC + k16];
+#endif
     float v = 0.f;
     if (nn >= 0 && kk >= 0) v = transpose ? w[((size_t)kk * I + nn) * 9 + (8 - tap)] : w[((size_t)nn * I + kk) * 9 + tap];
     if (kscale) v *= kscale[(size_t)grp * Kp + chunk * KC + k16];
     // physical position: the two 8-element halves of a row are swapped on rows with bit 3 set
     const int half = (k16 >> 3) ^ ((row >> 3) & 1);
     const size_t base = e - k16;
+#ifdef SF_SPLIT3
+    if (lo_part) v = (v - (float)(SF_OP_T)v) * SPLIT_UP;
+#endif
     packed[base + half * 8 + (k16 & 7)] = (SF_OP_T)v;
   }
   if (bias_packed && blockIdx.x == 0)
@@ -662,6 +772,11 @@ int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, 
 #ifndef SF_OPERAND_F16
   static const bool no_persist = getenv("SF_NO_PERSIST_CONV") != nullptr;
   if (!no_persist && !p.split_c && sf_conv_bf16_persist_ok(p, epi, nf)) return sf_launch_conv_bf16_persist(p, nf, nblk, st);
+#elif defined(SF_SPLIT3)
+  if (p.bf0 || p.bf1 || p.out_bf || p.gates_bf || p.hout_bf || p.stats || p.bias_tab || p.bnb_coef || p.split_c || p.shift4 || p.chunks_total % 3) {
+    sf_set_error("f32e conv: fp32-stored tensors; no statistics / folded BatchNorm / split-K / shifted views");
+    return 1;
+  }
 #else
   if (p.bf0 || p.bf1 || p.out_bf || p.stats || p.bias_tab || p.bnb_coef || epi == EPI_LSTM || epi == EPI_GRU) {
     sf_set_error("f16 conv: fp32-stored tensors, linear / sigmoid epilogue only");
@@ -680,7 +795,11 @@ int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, 
 
 void sf_pack_weights_bf16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
                           void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale, int groups) {
+#ifdef SF_SPLIT3
+  const size_t total = (size_t)Np * Kp * 27 * groups;
+#else
   const size_t total = (size_t)Np * Kp * 9 * groups;
+#endif
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(pack_weights_bf16_kernel, dim3(blocks), dim3(256), 0, st, w, O, I, nmap, Np, kmap, Kp, NB, transpose,
                      (SF_OP_T*)packed, bias, bias_packed, kscale, groups);

@@ -286,11 +286,12 @@ size_t sf_conv3x3_packed_elems(int32_t Np, int32_t Kp) { return (size_t)Np * Kp 
 int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t* nmap, int32_t Np, const int32_t* kmap,
                             int32_t Kp, int32_t nf, int32_t transpose, void* packed, const float* bias,
                             float* bias_packed, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16, "sf_conv3x3_pack_weights: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16 || dtype == SF_F32E, "sf_conv3x3_pack_weights: dtype %d not built", dtype);
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0, "pack: Np=%d must be a multiple of 32*nf (nf=%d)", Np, nf);
   SF_REQUIRE(Kp % KC == 0, "pack: Kp=%d must be a multiple of %d", Kp, KC);
-  if (dtype == SF_BF16 || dtype == SF_F16) {
-    (dtype == SF_BF16 ? sf_pack_weights_bf16 : sf_pack_weights_f16)(w, O, I, nmap, Np, kmap, Kp, 32 * nf, transpose, packed, bias, bias_packed, (hipStream_t)stream, nullptr, 1);
+  if (dtype == SF_BF16 || dtype == SF_F16 || dtype == SF_F32E) {
+    // (SF_F32E: `packed` holds 3 * Kp / 16 virtual chunks - the fp16 parts [lo'(w), hi(w)] of every real chunk, then hi(w) of all - 27 * Np * Kp halves)
+    (dtype == SF_BF16 ? sf_pack_weights_bf16 : dtype == SF_F16 ? sf_pack_weights_f16 : sf_pack_weights_f32e)(w, O, I, nmap, Np, kmap, Kp, 32 * nf, transpose, packed, bias, bias_packed, (hipStream_t)stream, nullptr, 1);
     SF_CHECK_LAUNCH("pack_weights (16-bit)");
     return 0;
   }
@@ -305,7 +306,7 @@ int sf_conv3x3_pack_weights(const float* w, int32_t O, int32_t I, const int32_t*
 static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w, const void* wpacked,
                             const float* bias_packed, int32_t Np, int32_t nf, int32_t epilogue, sfTensor out, float* stats, int32_t dtype,
                             sfStream stream, int32_t fold_groups = 0) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16, "sf_conv3x3_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16 || dtype == SF_F32E, "sf_conv3x3_fwd: dtype %d not built", dtype);
   if (check_src(src0, "conv3x3 src0") || check_src(src1, "conv3x3 src1")) return 1;
   SF_REQUIRE(nf >= 1 && nf <= 5 && Np % (32 * nf) == 0 && out.c <= Np, "conv3x3: bad Np=%d nf=%d out.c=%d", Np, nf, out.c);
   ConvParams p{};
@@ -318,20 +319,25 @@ static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, 
   const int nblk = Np / (32 * nf);
   p.bf0 = src0.ptr && src0.dtype == SF_BF16; p.bf1 = src1.ptr && src1.dtype == SF_BF16; p.out_bf = out.dtype == SF_BF16;
   SF_REQUIRE(dtype == SF_BF16 || !(p.bf0 || p.bf1 || p.out_bf), "conv3x3: bf16-stored tensors need the SF_BF16 kernel");
-  SF_REQUIRE(dtype != SF_F16 || !fold_groups, "conv3x3: the folded-BatchNorm launches are SF_BF16 only");
+  SF_REQUIRE((dtype != SF_F16 && dtype != SF_F32E) || !fold_groups, "conv3x3: the folded-BatchNorm launches are SF_BF16 only");
   SF_REQUIRE(!stats || (dtype == SF_BF16 && epilogue == SF_EPI_LINEAR), "conv3x3: output statistics need the SF_BF16 kernel with the linear epilogue");
   p.stats = stats; p.stats_np = Np;
   if (fold_groups) {  // bias_packed is the [groups][9][Np] border-class table, wpacked holds one image per group
     p.bias = nullptr; p.bias_tab = bias_packed; p.np = Np;
     p.wgroup = n / fold_groups; p.wgroup_bytes = (long long)Np * (src0.c + src1.c) * 9 * 2;
   }
-  if (dtype == SF_BF16 || dtype == SF_F16) {
+  if (dtype == SF_F32E) {   // three fp16 products per fp32 product: the packed image has three virtual chunks per real one; src0 may carry a gradient's amax word
+    p.chunks_total *= 3;
+    p.amax0 = src0.amax;
+    SF_REQUIRE(!src1.amax, "conv3x3 (SF_F32E): only src0 takes an amax word (the output gradient of an input-gradient launch)");
+  }
+  if (dtype == SF_BF16 || dtype == SF_F16 || dtype == SF_F32E) {
     SF_REQUIRE(epilogue == SF_EPI_LINEAR || epilogue == SF_EPI_SIGMOID, "conv3x3: unknown epilogue %d", epilogue);
     // the SF_BF16 kernel stores 16-byte channel quads (fp32) / octets (bf16) per pixel
     SF_REQUIRE(out.ptr && ((uintptr_t)out.ptr & 15) == 0 && out.stride % (p.out_bf ? 8 : 4) == 0 && out.c % 8 == 0,
                "conv3x3: the SF_BF16 kernel needs a 16-byte aligned output (pointer, stride %d, channels %d)", out.stride, out.c);
     SF_REQUIRE(!bias_packed || ((uintptr_t)bias_packed & 15) == 0, "conv3x3: bias_packed must be 16-byte aligned");
-    return (dtype == SF_BF16 ? sf_launch_conv_bf16 : sf_launch_conv_f16)(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
+    return (dtype == SF_BF16 ? sf_launch_conv_bf16 : dtype == SF_F16 ? sf_launch_conv_f16 : sf_launch_conv_f32e)(p, nf, nblk, epilogue == SF_EPI_LINEAR ? EPI_LINEAR : EPI_SIGMOID, (hipStream_t)stream);
   }
   if (epilogue == SF_EPI_LINEAR) return launch_conv<EPI_LINEAR>(p, nf, nblk, (hipStream_t)stream);
   if (epilogue == SF_EPI_SIGMOID) return launch_conv<EPI_SIGMOID>(p, nf, nblk, (hipStream_t)stream);
@@ -531,12 +537,13 @@ int sf_conv3x3_bwd_data_bn(sfTensor dout, int32_t n, int32_t h, int32_t w, const
 int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n, int32_t h, int32_t w,
                          const void* wpacked, const float* bias_packed, int32_t hidp, sfTensor h_out, sfTensor c_out,
                          sfTensor gates, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F32E, "sf_convlstm_cell_fwd: dtype %d not built", dtype);
   if (check_src(x, "convlstm x") || check_src(h_prev, "convlstm h_prev")) return 1;
   SF_F32_ONLY(c_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(c_out, "sf_convlstm_cell_fwd");
   if (dtype != SF_BF16) {  // bf16-stored x / hidden states: SF_BF16 kernel only
     SF_F32_ONLY(x, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_prev, "sf_convlstm_cell_fwd"); SF_F32_ONLY(h_out, "sf_convlstm_cell_fwd");
   }
+  if (dtype == SF_F32E) SF_F32_ONLY(gates, "sf_convlstm_cell_fwd (SF_F32E)");
   SF_REQUIRE(h_out.dtype == SF_F32 || h_out.dtype == SF_BF16, "sf_convlstm_cell_fwd: h_out storage type %d", h_out.dtype);
   SF_REQUIRE(!gates.ptr || gates.dtype == SF_F32 || gates.dtype == SF_BF16, "sf_convlstm_cell_fwd: gates storage type %d", gates.dtype);
   SF_REQUIRE(hidp % SF_CPAD == 0 && h_prev.c == hidp, "convlstm: hidp=%d h_prev.c=%d", hidp, h_prev.c);
@@ -555,9 +562,10 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
   p.bf0 = x.dtype == SF_BF16; p.bf1 = h_prev.ptr && h_prev.dtype == SF_BF16;
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
-  if (dtype == SF_BF16) {  // pixel-per-lane epilogue: states and gates move as 16-byte quads / octets
+  if (dtype == SF_BF16 || dtype == SF_F32E) {  // pixel-per-lane epilogue: states and gates move as 16-byte quads / octets
     auto quad = [](const sfTensor& t) { return !t.ptr || (((uintptr_t)t.ptr & 15) == 0 && t.stride % (t.dtype == SF_BF16 ? 8 : 4) == 0); };
     SF_REQUIRE(quad(c_prev) && quad(h_out) && quad(c_out) && quad(gates), "sf_convlstm_cell_fwd: states / gates need 16-byte aligned pixels");
+    if (dtype == SF_F32E) { p.chunks_total *= 3; return sf_launch_conv_f32e(p, 4, nblk, EPI_LSTM, (hipStream_t)stream); }
     return sf_launch_conv_bf16(p, 4, nblk, EPI_LSTM, (hipStream_t)stream);
   }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
@@ -569,7 +577,7 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
 int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int32_t w, const void* wpacked,
                         const float* bias_packed, int32_t hidp, sfTensor h_out, sfTensor gates, int32_t dtype,
                         sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16, "sf_convgru_step_fwd: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F32E, "sf_convgru_step_fwd: dtype %d not built", dtype);
   if (check_src(h_prev, "convgru h_prev")) return 1;
   SF_F32_ONLY(gx, "sf_convgru_step_fwd"); SF_F32_ONLY(h_prev, "sf_convgru_step_fwd"); SF_F32_ONLY(h_out, "sf_convgru_step_fwd");
   SF_REQUIRE(!gates.ptr || gates.dtype == SF_F32 || (gates.dtype == SF_BF16 && dtype == SF_BF16), "sf_convgru_step_fwd: gates storage type %d", gates.dtype);
@@ -587,6 +595,7 @@ int sf_convgru_step_fwd(sfTensor gx, sfTensor h_prev, int32_t n, int32_t h, int3
   p.hidp = hidp;
   const int nblk = (hidp + 31) / 32;
   if (dtype == SF_BF16) return sf_launch_conv_bf16(p, 3, nblk, EPI_GRU, (hipStream_t)stream);
+  if (dtype == SF_F32E) { p.chunks_total *= 3; return sf_launch_conv_f32e(p, 3, nblk, EPI_GRU, (hipStream_t)stream); }
   dim3 grid(p.tiles_x * p.tiles_y * p.N, nblk), block(256);
   hipLaunchKernelGGL((conv3x3_f32_kernel<3, EPI_GRU>), grid, block, 0, (hipStream_t)stream, p);
   SF_CHECK_LAUNCH("convgru_step_fwd");

@@ -31,7 +31,18 @@ namespace {
 using namespace sfwgrad;
 
 // operand type of the translation unit: __bf16, or _Float16 when included by conv3x3_wgrad_f16.hip (SF_OPERAND_F16; fp32-stored tensors only)
-#ifdef SF_OPERAND_F16
+// SF_SPLIT3 (conv3x3_wgrad_f32e.hip; SF_F32E compute mode): fp32-equivalent products from three fp16 products.  Every K tile (pixel tile) is staged
+// THREE times as virtual tiles - phase A: (hi(dout), lo'(in)) and (lo'(dout), hi(in)) of each real tile (loaded once, converted twice), the compute waves
+// then scale their accumulators by 2^-11, phase B: (hi(dout), hi(in)); lo' = fp16((v - hi) * 2^11).  dout is a gradient: it is multiplied by the power of
+// two that puts WgradParams::amax_dout at 2^14 before the split, the accumulators by the inverse before they are stored.  fp32-stored tensors only.
+#ifdef SF_SPLIT3
+#ifndef SF_OPERAND_F16
+#error "SF_SPLIT3 is built on the fp16 operand type"
+#endif
+#define SF_OP_T _Float16
+#define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
+#define sf_launch_wgrad_bf16 sf_launch_wgrad_f32e
+#elif defined(SF_OPERAND_F16)
 #define SF_OP_T _Float16
 #define SF_MFMA_32X32X16(a, b, c) __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c, 0, 0, 0)
 #define sf_launch_wgrad_bf16 sf_launch_wgrad_f16
@@ -62,6 +73,26 @@ __device__ __forceinline__ bf16x8 pack8(float a0, float a1, float a2, float a3, 
   return __builtin_convertvector(v, bf16x8);
 }
 __device__ __forceinline__ float F(unsigned bits) { return __builtin_bit_cast(float, bits); }
+#ifdef SF_SPLIT3
+constexpr float SPLIT_UP = 2048.f, SPLIT_DOWN = 1.f / 2048.f;
+// the fp16 part of v * scale a virtual tile multiplies: hi = fp16(v s), or lo' = fp16((v s - hi) * 2^11)
+__device__ __forceinline__ float part_f(float v, float scale, bool lo) {
+  v *= scale;
+  const float hi = (float)(SF_OP_T)v;
+  return lo ? (v - hi) * SPLIT_UP : v;
+}
+__device__ __forceinline__ void split_scale(const float* amax, float& s, float& inv) {   // as in conv3x3_bf16.hip
+  s = inv = 1.f;
+  if (!amax) return;
+  const unsigned bits = __builtin_bit_cast(unsigned, *amax);
+  const int e = (int)((bits >> 23) & 0xffu) - 127;
+  if ((bits & 0x7fffffffu) == 0u) return;
+  int k = 14 - e;
+  k = k > 126 ? 126 : (k < -126 ? -126 : k);
+  s = __builtin_bit_cast(float, (unsigned)(127 + k) << 23);
+  inv = __builtin_bit_cast(float, (unsigned)(127 - k) << 23);
+}
+#endif
 __device__ __forceinline__ unsigned bf16_bits(float x) {  // the 16 bits of x in the translation unit's operand type
   SF_OP_T b = (SF_OP_T)x;
   return (unsigned)__builtin_bit_cast(unsigned short, b);
@@ -102,7 +133,15 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       cot = combo % gridDim.y; cit = combo / gridDim.y;
     } else { ks = blockIdx.x; cot = blockIdx.y; cit = blockIdx.z; }
   }
+#ifdef SF_SPLIT3
+  const int real_tiles = ks < p.ntiles ? (p.ntiles - ks + p.KS - 1) / p.KS : 0;
+  const int my_tiles = 3 * real_tiles;   // virtual tiles: 2 t, 2 t + 1 = phase A of real tile t; 2 real_tiles + t = phase B
+  float sa, sa_inv;                      // dout's power-of-two scale
+  split_scale(p.amax_dout, sa, sa_inv);
+  auto v_real = [&](int i) { return i < 2 * real_tiles ? i >> 1 : i - 2 * real_tiles; };
+#else
   const int my_tiles = ks < p.ntiles ? (p.ntiles - ks + p.KS - 1) / p.KS : 0;
+#endif
 
   if (wave >= 4) {
     // =========================== loader waves ===========================
@@ -169,6 +208,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       return __builtin_amdgcn_make_buffer_rsrc((void*)(src ? base : nullptr), 0, src ? (int)((unsigned)(p.H * p.W + lead) * px) : 0, 0x00020000);
     };
     auto load_tile = [&](int i, Stage& s) {
+#ifdef SF_SPLIT3
+      if (i < 2 * real_tiles && (i & 1)) return;   // second phase-A tile of a real tile: the registers already hold it
+      i = v_real(i);
+#endif
       int t = ks + i * p.KS;
       const int tx = t % p.tiles_x; t /= p.tiles_x;
       const int ty = t % p.tiles_y;
@@ -217,6 +260,10 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       }
     };
     auto store_tile = [&](int i, Stage& s) {
+#ifdef SF_SPLIT3
+      const bool phase_b = i >= 2 * real_tiles;
+      const bool a_lo = !phase_b && (i & 1), b_lo = !phase_b && !(i & 1);   // (hi(dout), lo'(in)), (lo'(dout), hi(in)), then (hi, hi)
+#endif
       char* la = lds + (i & 1) * BUF;
       char* lb = la + A_BYTES;
       char* lh = lb + B_BYTES;
@@ -245,6 +292,17 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
           const int rest = (lt + u * LOADERS) / 32, half = rest & 1, row = rest >> 1;
           char* dst = la + a_cq * A_S + (row * 2 + half) * 64;
           const VA (&va)[8] = s.va[u];
+#ifdef SF_SPLIT3
+          if (cit == 0 && phase_b) {  // the bias gradient (fp32 sum of the unrounded values) once per real tile
+#pragma unroll
+            for (int j = 0; j < 8; ++j) bsum += __builtin_bit_cast(f32x4, va[j]);
+          }
+#pragma unroll
+          for (int c = 0; c < 4; ++c)
+            *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
+                pack8(part_f(F(va[0][c]), sa, a_lo), part_f(F(va[1][c]), sa, a_lo), part_f(F(va[2][c]), sa, a_lo), part_f(F(va[3][c]), sa, a_lo),
+                      part_f(F(va[4][c]), sa, a_lo), part_f(F(va[5][c]), sa, a_lo), part_f(F(va[6][c]), sa, a_lo), part_f(F(va[7][c]), sa, a_lo));
+#else
           if (cit == 0) {  // block-uniform: only the first ci tile's blocks report the bias gradient
 #pragma unroll
             for (int j = 0; j < 8; ++j) bsum += __builtin_bit_cast(f32x4, va[j]);
@@ -253,6 +311,7 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
           for (int c = 0; c < 4; ++c)
             *reinterpret_cast<bf16x8*>(dst + quad_slot(a_cq, c)) =
                 pack8(F(va[0][c]), F(va[1][c]), F(va[2][c]), F(va[3][c]), F(va[4][c]), F(va[5][c]), F(va[6][c]), F(va[7][c]));
+#endif
         }
       }
       if (b_item) {
@@ -272,9 +331,16 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
                                                                         pair_bf(vb[5], vb[6], c), pair_bf(vb[7], vb[8], c)};
             hp[bhalf] = bhalf ? chan_bits(vb[9], c) : chan_bits(vb[0], c) << 16;
           } else {
+#ifdef SF_SPLIT3
+            *reinterpret_cast<bf16x8*>(dst + quad_slot(b_cq, c)) =
+                pack8(part_f(F(vb[1][c]), 1.f, b_lo), part_f(F(vb[2][c]), 1.f, b_lo), part_f(F(vb[3][c]), 1.f, b_lo), part_f(F(vb[4][c]), 1.f, b_lo),
+                      part_f(F(vb[5][c]), 1.f, b_lo), part_f(F(vb[6][c]), 1.f, b_lo), part_f(F(vb[7][c]), 1.f, b_lo), part_f(F(vb[8][c]), 1.f, b_lo));
+            hp[bhalf] = bhalf ? bf16_bits(part_f(F(vb[9][c]), 1.f, b_lo)) : bf16_bits(part_f(F(vb[0][c]), 1.f, b_lo)) << 16;
+#else
             *reinterpret_cast<bf16x8*>(dst + quad_slot(b_cq, c)) =
                 pack8(F(vb[1][c]), F(vb[2][c]), F(vb[3][c]), F(vb[4][c]), F(vb[5][c]), F(vb[6][c]), F(vb[7][c]), F(vb[8][c]));
             hp[bhalf] = bhalf ? bf16_bits(F(vb[9][c])) : bf16_bits(F(vb[0][c])) << 16;
+#endif
           }
         }
       }
@@ -339,6 +405,14 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
     const bool dead_ky0 = (view_c >> 1) != 0, dead_kx0 = (view_c & 1) != 0;
     __syncthreads();  // tile 0 staged
     for (int i = 0; i < my_tiles; ++i) {
+#ifdef SF_SPLIT3
+      if (i == 2 * real_tiles) {   // phase A -> phase B: the correction terms were accumulated at 2^11 times their value
+#pragma unroll
+        for (int t = 0; t < 9; ++t)
+#pragma unroll
+          for (int k = 0; k < 16; ++k) acc[t][k] *= SPLIT_DOWN;
+      }
+#endif
       const char* la = lds + (i & 1) * BUF;
       const char* lb = la + A_BYTES;
       // Halo-row major: input row hrow is read and shifted ONCE and feeds the taps ky = 0..2 of the output rows
@@ -385,6 +459,14 @@ __global__ __launch_bounds__(THREADS, 2) void wgrad_bf16_kernel(const WgradParam
       }
       __syncthreads();
     }
+#ifdef SF_SPLIT3
+    if (p.amax_dout) {
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int k = 0; k < 16; ++k) acc[t][k] *= sa_inv;
+    }
+#endif
     // partial[ks][tap][co][ci]
 #pragma unroll
     for (int tap = 0; tap < 9; ++tap)
@@ -422,6 +504,9 @@ int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl,
     const long long smax = p.ds > p.s0 ? (p.ds > p.s1 ? p.ds : p.s1) : (p.s0 > p.s1 ? p.s0 : p.s1);
     if (px * smax * esz >= (1ll << 31)) { sf_set_error("wgrad_bf16: one image of a tensor must be smaller than 2 GiB"); return 1; }
   }
+#ifdef SF_SPLIT3
+  if (p.bf || p.bf_dout || p.shift4) { sf_set_error("wgrad_f32e: fp32-stored tensors, no shifted views"); return 1; }
+#endif
   const int xcd_groups = (pl.KS % 8 == 0) ? 1 : 0;
   const bool mixed = p.src0 && p.src1 && p.c1 > 0 && p.c0 % CI_T != 0;  // some block's 32 input channels straddle the two sources
   const dim3 grid(pl.KS, pl.cot, pl.cit), block(THREADS);

@@ -553,7 +553,7 @@ size_t sf_conv3x3_bwd_weight_workspace_bytes(int32_t Np, int32_t Kp, int32_t n, 
 int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n, int32_t h, int32_t w,
                           const int32_t* nmap, const int32_t* kmap, int32_t O, int32_t I, float* dw, float* db,
                           int32_t accumulate, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream) {
-  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16, "sf_conv3x3_bwd_weight: dtype %d not built", dtype);
+  SF_REQUIRE(dtype == SF_F32 || dtype == SF_BF16 || dtype == SF_F16 || dtype == SF_F32E, "sf_conv3x3_bwd_weight: dtype %d not built", dtype);
   SF_REQUIRE(src0.c % SF_CPAD == 0 && src1.c % SF_CPAD == 0 && dout.c % 4 == 0, "bwd_weight: channel padding");
   SF_REQUIRE(src0.ptr || src0.c == 0, "bwd_weight: src0 null");
   SF_REQUIRE(src1.ptr || src1.c == 0, "bwd_weight: src1 null with c=%d (pass c=0)", src1.c);
@@ -562,7 +562,7 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
                         (src0.ptr || src1.ptr);
   // 1: one input tensor; 2: two, the first a whole number of 64-channel tiles wide (every tile of the K space has one source)
   const int one_src = (src0.ptr && src0.c > 0) != (src1.ptr && src1.c > 0) ? 1 : (src0.c % DMA_CI_T == 0 ? 2 : 0);
-  const Plan pl = all_bf16 ? sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, one_src) : make_plan(Np, Kp, n, h, w, (dtype == SF_BF16 || dtype == SF_F16) ? 8 : KT_H);
+  const Plan pl = all_bf16 ? sf_wgrad_bf16_dma_plan(Np, Kp, n, h, w, 0, one_src) : make_plan(Np, Kp, n, h, w, (dtype == SF_BF16 || dtype == SF_F16 || dtype == SF_F32E) ? 8 : KT_H);
   SF_REQUIRE(workspace && workspace_bytes >= pl.ws_floats * sizeof(float), "bwd_weight: workspace too small (%zu < %zu)",
              workspace_bytes, pl.ws_floats * sizeof(float));
   WgradParams p{};
@@ -589,6 +589,9 @@ int sf_conv3x3_bwd_weight(sfTensor src0, sfTensor src1, sfTensor dout, int32_t n
     if (int rc = sf_launch_wgrad_bf16(p, pl, (hipStream_t)stream)) return rc;
   } else if (dtype == SF_F16) {
     if (int rc = sf_launch_wgrad_f16(p, pl, (hipStream_t)stream)) return rc;
+  } else if (dtype == SF_F32E) {   // three fp16 products per fp32 product; dout (a gradient) scaled through its amax word, if it carries one
+    p.amax_dout = dout.amax;
+    if (int rc = sf_launch_wgrad_f32e(p, pl, (hipStream_t)stream)) return rc;
   } else {
     hipLaunchKernelGGL(wgrad_f32_kernel, dim3(pl.KS, pl.cot, pl.cit), dim3(256), 0, (hipStream_t)stream, p);
     SF_CHECK_LAUNCH("wgrad_f32");

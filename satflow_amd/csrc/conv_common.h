@@ -58,6 +58,10 @@ struct ConvParams {
   // routing record (one 16-bit word per pooled pixel and channel octet of the out_c channels, 2 bits per channel: first maximum in row-major order)
   void* pool_out; int pool_s, pool_L, pool_T, pool_B;
   unsigned short* pool_route;
+  // SF_F32E kernels (conv3x3_f32e.hip): device word with max |src0| (sfTensor::amax, sf_amax) of a GRADIENT source - the kernel scales the source by the
+  // power of two that puts that magnitude at 2^14 before it splits it into fp16 parts, and the accumulators by the inverse behind the K loop; null = as is.
+  // chunks_total counts the packed image's VIRTUAL chunks there (3 per real 16-channel chunk).
+  const float* amax0;
 };
 
 // border class of an output pixel (needs H, W >= 2); pixels outside the image (ragged tiles) get some valid class
@@ -497,6 +501,11 @@ int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, 
 int sf_launch_conv_f16(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
 void sf_pack_weights_f16(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
                          void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale = nullptr, int groups = 1);
+// the same kernels as the SF_F32E compute mode (conv3x3_f32e.hip): three fp16 products per fp32 product, fp32-stored tensors, every epilogue; the packed
+// image has 3 * Kp / 16 chunks (27 * Np * Kp halves)
+int sf_launch_conv_f32e(const sfconv::ConvParams& p, int nf, int nblk, int epi, hipStream_t st);
+void sf_pack_weights_f32e(const float* w, int O, int I, const int* nmap, int Np, const int* kmap, int Kp, int NB, int transpose,
+                          void* packed, const float* bias, float* bias_packed, hipStream_t st, const float* kscale = nullptr, int groups = 1);
 // persistent variant for the large single-source bf16-stored launches (conv3x3_bf16_persist.hip); bit-identical results
 bool sf_conv_bf16_persist_ok(const sfconv::ConvParams& p, int epi, int nf);
 int sf_launch_conv_bf16_persist(const sfconv::ConvParams& p, int nf, int nblk, hipStream_t st);

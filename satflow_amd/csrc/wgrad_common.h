@@ -29,6 +29,9 @@ struct WgradParams {
   // channel: 2 dy + dx of the window element that took the maximum) instead of from dout, which this kernel then does not read: 4.5 KB per K tile, not 16
   int sparse24;
   const void* pool_g; const unsigned short* pool_route; int pool_s, pool_L, pool_T, pool_B;
+  // SF_F32E kernel (conv3x3_wgrad_f32e.hip): device word with max |dout| (sfTensor::amax) - dout is scaled by the power of two that puts it at 2^14 before
+  // the fp16 split, the accumulators by the inverse; null = as is
+  const float* amax_dout;
 };
 
 
@@ -67,3 +70,4 @@ int sf_launch_wgrad_bf16_dma(sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, f
 // bf16-MFMA variant (conv3x3_wgrad_bf16.hip): fills the same partial slabs
 int sf_launch_wgrad_bf16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);
 int sf_launch_wgrad_f16(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);  // fp16 operands (conv3x3_wgrad_f16.hip), fp32-stored tensors
+int sf_launch_wgrad_f32e(const sfwgrad::WgradParams& p, const sfwgrad::Plan& pl, hipStream_t st);  // SF_F32E: three fp16 products per fp32 product (conv3x3_wgrad_f32e.hip)

@@ -393,12 +393,13 @@ class _ConvFn(torch.autograd.Function):
         if (need[0] and remap0 != (0, 0)) or (need[1] and remap1 != (0, 0)):
             raise RuntimeError("gradient wrt a broadcast (image-remapped) convolution source is not implemented")
         d0 = d1 = None
+        gyT = K.grad_operand(gy)   # ("f32e": with the gradient's amax word - one pass here serves the input AND the weight gradient)
         if any(need):
             needk = need if has_x1 else need[:1]
             gm = eng.bwd_map(tuple(needk))
             lanes = sum(cpad(c) for c, nd in zip(eng.cins, needk) if nd)
             dcat = torch.empty(n, H, W, lanes, dtype=x0.dtype, device=gy.device)  # a gradient is stored like its tensor
-            K.conv3x3(T(gy), NULL, n, H, W, eng.packed(weight, ctx.bias, "bwd", tuple(needk))[0], None, gm, T(dcat))
+            K.conv3x3(gyT, NULL, n, H, W, eng.packed(weight, ctx.bias, "bwd", tuple(needk))[0], None, gm, T(dcat))
             if need[0] and need[1]:
                 c0p = cpad(eng.cins[0])
                 d0, d1 = dcat[..., :c0p].contiguous(), dcat[..., c0p:].contiguous()
@@ -413,11 +414,12 @@ class _ConvFn(torch.autograd.Function):
                 return None, d0, d1, None, None, None, None, None, None, None, None, None   # a later application's backward completes the set
             x0, gy = ctx.wbatch.take()
             n = x0.shape[0]
+            gyT = K.grad_operand(gy)
         dw4, dw_ret = grad_out(weight, (weight.shape[0], weight.shape[1], 3, 3))
         db, db_ret = grad_out(ctx.bias) if has_bias else (None, None)
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
-        K.conv3x3_bwd_weight(s0, s1, T(gy), n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
+        K.conv3x3_bwd_weight(s0, s1, gyT, n, H, W, eng.wgrad_map, dw4, db, accumulate=False)
         return None, d0, d1, dw_ret, db_ret, None, None, None, None, None, None, None
 
 
@@ -988,17 +990,20 @@ class _ConvGRUSeqFn(torch.autograd.Function):
                 raise RuntimeError("unexpected number of gradient sources")
             K.convgru_bwd_gates(src, gates[t], hs[t - 1] if t else None, hidp, dgx[t], dgh[t], direct if t else None)
             if t:
-                K.conv3x3(T(dgh[t]), NULL, n, H, W, pk["h_bwd"], None, eng.h_bwd, T(carry))
+                K.conv3x3(K.grad_operand(dgh[t]), NULL, n, H, W, pk["h_bwd"], None, eng.h_bwd, T(carry))
                 have_carry = True
         dx = None
         if ctx.needs_input_grad[1]:
             dx = torch.empty_like(x)  # stored like x (fp32: the encoder's last pooling returns fp32)
-            K.conv3x3(T(dgx.view(N, H, W, 3 * hidp)), NULL, N, H, W, pk["x_bwd"], None, eng.x_bwd, T(dx))
+            dgxT = K.grad_operand(dgx.view(N, H, W, 3 * hidp))
+            K.conv3x3(dgxT, NULL, N, H, W, pk["x_bwd"], None, eng.x_bwd, T(dx))
+        else:
+            dgxT = K.grad_operand(dgx.view(N, H, W, 3 * hidp))
         dWx, dbx = torch.empty_like(Wx), torch.empty(Wx.shape[0], dtype=torch.float32, device=dev)
-        K.conv3x3_bwd_weight(T(x), NULL, T(dgx.view(N, H, W, 3 * hidp)), N, H, W, eng.x_wgrad, dWx, dbx, False)
+        K.conv3x3_bwd_weight(T(x), NULL, dgxT, N, H, W, eng.x_wgrad, dWx, dbx, False)
         dWh, dbh = torch.empty_like(Wh), torch.empty(Wh.shape[0], dtype=torch.float32, device=dev)
         if Tn > 1:
-            K.conv3x3_bwd_weight(T(hs[: Tn - 1]), NULL, T(dgh[1:]), (Tn - 1) * n, H, W, eng.h_wgrad, dWh, dbh, False)
+            K.conv3x3_bwd_weight(T(hs[: Tn - 1]), NULL, K.grad_operand(dgh[1:]), (Tn - 1) * n, H, W, eng.h_wgrad, dWh, dbh, False)
             # bias of the h-part also acts at t = 0 (zero state, bias only): add that step's column sums (tiny torch op)
             dbh = (dbh + dgh[0].float().sum(dim=(0, 1, 2))[K_bias_index(eng, dev)]) * K_bias_mask(eng, dev)
         else:

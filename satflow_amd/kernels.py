@@ -135,7 +135,9 @@ def pack_weights(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, transpose:
     assert w.shape[2:] == (3, 3), "only 3x3 kernels are on the path"
     nmap, kmap = gm.tables(w.device)
     dt = _hip.compute_dtype()
-    packed = torch.empty(gm.Np * gm.Kp * 9, dtype={_hip.SF_BF16: torch.bfloat16, _hip.SF_F16: torch.float16}.get(dt, torch.float32), device=w.device)
+    # ("f32e": three virtual K chunks per real one - the fp16 parts [lo'(w), hi(w)] of every chunk, then hi(w) of all)
+    packed = torch.empty(gm.Np * gm.Kp * (27 if dt == _hip.SF_F32E else 9),
+                         dtype={_hip.SF_BF16: torch.bfloat16, _hip.SF_F16: torch.float16, _hip.SF_F32E: torch.float16}.get(dt, torch.float32), device=w.device)
     bp = torch.empty(gm.Np, dtype=torch.float32, device=w.device) if (bias is not None and not transpose) else None
     check(
         lib().sf_conv3x3_pack_weights(
@@ -146,6 +148,30 @@ def pack_weights(weight: Tensor, bias: Optional[Tensor], gm: GemmMap, transpose:
         "sf_conv3x3_pack_weights",
     )
     return packed, bp
+
+
+def grad_operand(t: Tensor, acc: Optional[Tensor] = None, reset_acc: bool = False, **kw) -> sfTensor:
+    """``T(t)`` for a GRADIENT tensor that is about to be an MFMA operand (the source of an input-gradient convolution, ``dout`` of a weight gradient).
+    In "f32e" mode the descriptor carries the tensor's ``sf_amax`` word (one HBM pass here), through which the kernels scale it into fp16's range; every
+    other mode: plain ``T(t)``.  ``acc``: a second word that accumulates the maximum over several calls (a recurrent cell's per-step gate gradients, for
+    the one weight-gradient launch over all steps: ``grad_operand_with(t, acc)``)."""
+    if _hip.compute_dtype() != _hip.SF_F32E or t.dtype != torch.float32:
+        return T(t, **kw)
+    word = torch.empty(1, dtype=torch.float32, device=t.device)
+    d = T(t, **kw)
+    check(lib().sf_amax(d, t.numel() // t.shape[-1], word.data_ptr(), acc.data_ptr() if acc is not None else None, int(reset_acc), stream_ptr()), "sf_amax")
+    d.amax = word.data_ptr()
+    d._keep = word   # the word lives as long as the descriptor (stream-ordered reuse by the caching allocator is safe: same stream)
+    return d
+
+
+def grad_operand_with(t: Tensor, word: Optional[Tensor], **kw) -> sfTensor:
+    """``T(t)`` carrying an amax word that was accumulated earlier (``grad_operand(..., acc=word)``); plain ``T(t)`` without a word."""
+    d = T(t, **kw)
+    if word is not None and _hip.compute_dtype() == _hip.SF_F32E:
+        d.amax = word.data_ptr()
+        d._keep = word
+    return d
 
 
 def conv3x3(src0: sfTensor, src1: sfTensor, n: int, h: int, w: int, packed: Tensor, bias_packed: Optional[Tensor],
@@ -432,7 +458,7 @@ def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int, low
     rows = x.numel() // x.shape[-1]
     assert W.shape[1] == x.shape[-1] and W.is_contiguous()
     y = torch.empty(*x.shape[:-1], out_lanes, dtype=torch.float32, device=x.device)
-    dt = _hip.compute_dtype() if lowp and not os.environ.get("SF_LINEAR_F32") else SF_F32   # (SF_LINEAR_F32=1: A/B switch)
+    dt = _hip.exact_dtype() if lowp and not os.environ.get("SF_LINEAR_F32") else SF_F32   # (SF_LINEAR_F32=1: A/B switch; "f32e": exact fp32)
     check(lib().sf_linear_fwd(T(x), rows, W.data_ptr(), W.shape[0], bias.data_ptr() if bias is not None else None, T(y), dt,
                               stream_ptr()), "sf_linear_fwd")
     return y

@@ -193,9 +193,10 @@ class _StackFn(torch.autograd.Function):
                 first_in, rest_in = Hs[1][T_in - 1], Hs[3][: T_out - 1]
             else:
                 first_in, rest_in = Hs[2][0], Hs[2][1:]
-            eng.bwd_weight(T(first_in), T(zeros), T(Gs[k][0]), B, H, W, dw, db, False)
+            # (K.grad_operand: in "f32e" mode the gate gradients carry their amax word - one extra pass over dz per launch)
+            eng.bwd_weight(T(first_in), T(zeros), K.grad_operand(Gs[k][0]), B, H, W, dw, db, False)
             if steps > 1:
-                eng.bwd_weight(T(rest_in), T(Hs[k][: steps - 1]), T(Gs[k][1:]), (steps - 1) * B, H, W, dw, db, True)
+                eng.bwd_weight(T(rest_in), T(Hs[k][: steps - 1]), K.grad_operand(Gs[k][1:]), (steps - 1) * B, H, W, dw, db, True)
             cell_grads[k] = (dw_ret, db_ret)
             done[k] = True
 

@@ -77,10 +77,12 @@ class CellEngine:
         K.convlstm_cell_bwd_gates(dh, T(dc_next, self.hidp), T(gates), T(c_prev, self.hidp), NULL if recompute else T(c_new), pixels, self.hidp,
                                   T(dz), T(dc_prev, self.hidp))
 
-    def bwd_data(self, dz: Tensor, n: int, h: int, w: int, need_dx: bool, dcat: Tensor) -> None:
-        """dcat[.., (cinp if need_dx) + hidp] = conv(dz, W^T flipped)."""
+    def bwd_data(self, dz: Tensor, n: int, h: int, w: int, need_dx: bool, dcat: Tensor, amax_acc: Optional[Tensor] = None,
+                 reset_acc: bool = False) -> None:
+        """dcat[.., (cinp if need_dx) + hidp] = conv(dz, W^T flipped).  ``amax_acc`` ("f32e" mode): a device word that collects the maximum of |dz| over
+        the steps of a sequence, for the one weight-gradient launch over all of them (``K.grad_operand``)."""
         gm = self.bwd_maps[need_dx]
-        K.conv3x3(T(dz), NULL, n, h, w, self.packed_bwd(need_dx), None, gm, T(dcat))
+        K.conv3x3(K.grad_operand(dz, amax_acc, reset_acc), NULL, n, h, w, self.packed_bwd(need_dx), None, gm, T(dcat))
 
     def bwd_weight(self, x: sfTensor, h_prev: sfTensor, dz: sfTensor, n: int, h: int, w: int, dw: Tensor, db: Optional[Tensor],
                    accumulate: bool) -> None:
@@ -130,7 +132,7 @@ class _CellStepFn(torch.autograd.Function):
         db = torch.empty_like(eng.conv.bias) if eng.conv.bias is not None else None
         # zero state == zero contribution to dW's h-columns; feed an explicit zero tensor for the K lanes
         hsrc = T(h) if has_h else T(torch.zeros(n, H, W, eng.hidp, dtype=torch.float32, device=x.device))
-        eng.bwd_weight(T(x), hsrc, T(dz), n, H, W, dw, db, accumulate=False)
+        eng.bwd_weight(T(x), hsrc, K.grad_operand(dz), n, H, W, dw, db, accumulate=False)
         return None, dx, dh, dc_prev, dw, db
 
 

@@ -17,6 +17,36 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a HIP device (MI355X); run with -m gpu on the GPU box")
 
 
+# Tests that hold the fp32 parity gate (rtol 1e-4 / atol 1e-5) and run convolutions: each runs twice, in "f32" (exact-fp32 MFMA) and in "f32e"
+# (fp32-equivalent products from three fp16 products, satflow_amd/_hip.py) - UNCHANGED bodies and tolerances.
+FP32_GATED = {
+    "test_convlstm_gpu.py": ("test_conv3x3_vs_oracle", "test_cell_golden", "test_model_golden", "test_model_vs_oracle_no_grad"),
+    "test_metnet_gpu.py": ("test_convgru_sequence", "test_metnet_train_step_vs_oracle", "test_metnet_eval_and_reference_shape_pin"),
+    "test_litmetnet_gpu.py": ("test_training_step_dict_batch", "test_validation_step_eval_mode", "test_metnet_input_gradient"),
+    "test_fullsize_gpu.py": ("test_convlstm_cfg2_forward_fullsize", "test_metnet_cfg3_forward_fullsize", "test_conv_linearity_and_adjoint_fullbatch"),
+    "test_baseline_size_gpu.py": ("test_cfg2_convlstm_train_step_fullsize_f32", "test_cfg3_metnet_train_step_fullsize_f32",
+                                  "test_cfg3_metnet_train_step_fullsize_f32_with_dropout", "test_config0_convgru_two_layers"),
+    "test_cloudgan_gpu.py": ("test_patch_discriminator_golden", "test_cloudgan_training_steps_golden", "test_discriminator_variants_match_reference"),
+    "test_stlstm_gpu.py": ("test_stlstm_cell_matches_reference_golden_fp32",),
+}
+
+
+def pytest_generate_tests(metafunc):
+    names = FP32_GATED.get(os.path.basename(str(metafunc.module.__file__)), ())
+    if metafunc.function.__name__ in names:
+        metafunc.fixturenames.append("fp32_mode")
+        metafunc.parametrize("fp32_mode", ["f32", "f32e"], indirect=True)
+
+
+@pytest.fixture
+def fp32_mode(request):
+    import satflow_amd
+
+    satflow_amd.set_compute_dtype(request.param)
+    yield request.param
+    satflow_amd.set_compute_dtype("f32")
+
+
 @pytest.fixture(scope="session")
 def device():
     import torch

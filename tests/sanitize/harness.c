@@ -39,6 +39,13 @@ int main(void) {
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, 9, a16, SF_F32, st));                       /* unknown epilogue */
   REFUSED(sf_conv3x3_fwd(a16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, 5, st));                /* unknown dtype */
   REFUSED(sf_conv3x3_fwd(b16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F16, st));           /* bf16 storage with the fp16 kernels */
+  REFUSED(sf_conv3x3_fwd(b16, N0, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F32E, st));          /* bf16 storage with the split-fp16 (fp32-equivalent) kernels */
+  { sfTensor am = a16; am.amax = (const float*)ok;
+    REFUSED(sf_conv3x3_fwd(a16, am, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F32E, st)); }      /* an amax word on src1 */
+  REFUSED(sf_amax(a16, 64, 0, 0, 0, st));                                                            /* no destination word */
+  REFUSED(sf_amax(a16, 64, ok, mem + 2, 0, st));                                                     /* misaligned accumulator word */
+  REFUSED(sf_amax(b16, 64, ok, 0, 0, st));                                                           /* bf16 storage */
+  REFUSED(sf_amax(m16, 64, ok, 0, 0, st));                                                           /* misaligned tensor */
   REFUSED(sf_conv3x3_fwd_stats(a16, N0, 1, 8, 8, ok, 0, 32, 1, a16, ok, SF_F32, st));                /* stats need the bf16 kernels */
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 4, a16, ok, 1 << 20, SF_F32, st));         /* split-K: SF_BF16 kernels only */
   REFUSED(sf_conv3x3_fwd_splitk(a16, 1, 8, 8, ok, 0, 128, 2, a16, ok, 1 << 20, SF_BF16, st));        /* split-K: nf = 4 only */

@@ -110,9 +110,9 @@ def test_tensor_descriptor_matches_header():
     hdr = open(os.path.join(ROOT, "include", "satflow_hip.h")).read()
     body = re.search(r"typedef struct \{(.*?)\} sfTensor;", hdr, re.S).group(1)
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
-    fields = re.findall(r"(?:void\*|int32_t)\s+(\w+);", body)
+    fields = re.findall(r"(?:const float\*|void\*|int32_t)\s+(\w+);", body)
     assert fields == [f[0] for f in _hip.sfTensor._fields_], (fields, _hip.sfTensor._fields_)
-    assert C.sizeof(_hip.sfTensor) == 32  # 8-byte pointer + 5 x int32, padded to the pointer's alignment
+    assert C.sizeof(_hip.sfTensor) == 40  # 8-byte pointer + 5 x int32 (padded to the pointer's alignment) + the amax pointer (ABI 8)
     a = torch.zeros(2, 3, 32, dtype=torch.float32)
     b = torch.zeros(2, 3, 32, dtype=torch.bfloat16)
     ta, tb = _hip.T(a, c=16, offset=16), _hip.T(b, c=16, offset=16)
