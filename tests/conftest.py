@@ -20,7 +20,7 @@ def pytest_configure(config):
 # Tests that hold the fp32 parity gate (rtol 1e-4 / atol 1e-5) and run convolutions: each runs twice, in "f32" (exact-fp32 MFMA) and in "f32e"
 # (fp32-equivalent products from three fp16 products, satflow_amd/_hip.py) - UNCHANGED bodies and tolerances.
 FP32_GATED = {
-    "test_convlstm_gpu.py": ("test_conv3x3_vs_oracle", "test_cell_golden", "test_model_golden", "test_model_vs_oracle_no_grad"),
+    "test_convlstm_gpu.py": ("test_conv3x3_vs_oracle", "test_cell_golden", "test_model_golden", "test_model_vs_oracle_no_grad", "test_training_trajectory_golden"),
     "test_metnet_gpu.py": ("test_convgru_sequence", "test_metnet_train_step_vs_oracle", "test_metnet_eval_and_reference_shape_pin"),
     "test_litmetnet_gpu.py": ("test_training_step_dict_batch", "test_validation_step_eval_mode", "test_metnet_input_gradient"),
     "test_fullsize_gpu.py": ("test_convlstm_cfg2_forward_fullsize", "test_metnet_cfg3_forward_fullsize", "test_conv_linearity_and_adjoint_fullbatch"),

@@ -158,6 +158,56 @@ def model_cases():
         f.write("\n".join(keys) + "\n")
 
 
+def trajectory_cases():
+    """Five optimisation steps of the reference's own training loop for the pinned path: ``EncoderDecoderConvLSTM.training_step`` +
+    ``configure_optimizers()`` (Adam(lr), ``conv_lstm.py:48-70``) on a seeded batch sequence -> per-step losses and the final ``state_dict``.
+    What a single pinned step cannot show: the optimizer update feeding the next step's packed weights (pack-cache invalidation), Adam's moments."""
+    from satflow.models.conv_lstm import EncoderDecoderConvLSTM
+    from oracle import convlstm as O
+
+    steps = 5
+    specs = [  # name, B, T, C, H, W, hid, out, forecast, heat, lr
+        ("h32_hot", 2, 4, 4, 32, 32, 32, 1, 4, 4.0, 1e-3),
+        ("rect_h16_o12", 1, 3, 5, 24, 40, 16, 12, 2, 5.0, 1e-3),
+    ]
+    for name, B, T, C, H, W, hid, out_ch, fs, heat, lr in specs:
+        g = torch.Generator().manual_seed(7000 + hid + fs)
+        torch.manual_seed(31 + hid)
+        m = EncoderDecoderConvLSTM(hidden_dim=hid, input_channels=C, out_channels=out_ch, forecast_steps=fs, lr=lr)
+        _heat(m.model, heat, g)
+        xs = torch.randn(steps, B, T, C, H, W, generator=g)
+        ys = torch.rand(steps, B, fs, out_ch, H, W, generator=g)
+        rec = dict(x=xs, y=ys, forecast_steps=fs, lr=lr)
+        for k, v in m.model.state_dict().items():
+            rec[f"param.{k}"] = v.clone()
+        # the oracle, driven by the same optimizer class on a copy of the parameters
+        P = {k: v.detach().clone().requires_grad_() for k, v in m.model.state_dict().items()}
+        o_opt = torch.optim.Adam(list(P.values()), lr=lr)
+        opt = m.configure_optimizers()
+        assert isinstance(opt, torch.optim.Adam) and opt.defaults["lr"] == lr
+        losses = []
+        for k in range(steps):
+            loss = m.training_step((xs[k], ys[k]), k)
+            opt.zero_grad()
+            loss.backward()
+            opt.step()
+            losses.append(loss.detach())
+            o_loss, _ = O.training_loss(xs[k], ys[k], fs, P)
+            o_opt.zero_grad()
+            o_loss.backward()
+            o_opt.step()
+            assert torch.allclose(o_loss.detach(), loss.detach(), rtol=1e-5, atol=0), f"oracle trajectory loss mismatch {name} step {k}"
+        rec["losses"] = torch.stack(losses)
+        worst = 0.0
+        for k, v in m.model.state_dict().items():
+            rec[f"final.{k}"] = v.clone()
+            worst = max(worst, float((P[k].detach() - v).abs().max()))
+        assert worst <= 1e-5, f"oracle trajectory parameters drift {worst:.2e} from the reference ({name})"
+        moved = max(float((rec[f'final.{k}'] - rec[f'param.{k}']).abs().max()) for k in m.model.state_dict())
+        np.savez(f"{HERE}/convlstm_traj_{name}.npz", **_np(rec))
+        print(f"trajectory {name}: ok  losses {[round(float(l), 6) for l in losses]}  largest parameter move {moved:.2e}  oracle-vs-reference {worst:.1e}")
+
+
 def layer_cases():
     from satflow.models.layers.ConditionTime import ConditionTime
     from satflow.models.layers.TimeDistributed import TimeDistributed
@@ -593,11 +643,13 @@ def zlib_seed(s):
 if __name__ == "__main__":
     torch.set_num_threads(8)
     _shim_reference()
-    only = sys.argv[1:] or ["cell", "model", "layer", "cloudgan", "stlstm", "dgmr", "attention"]
+    only = sys.argv[1:] or ["cell", "model", "trajectory", "layer", "cloudgan", "stlstm", "dgmr", "attention"]
     if "cell" in only:
         cell_cases()
     if "model" in only:
         model_cases()
+    if "trajectory" in only:
+        trajectory_cases()
     if "layer" in only:
         layer_cases()
     if "cloudgan" in only:

@@ -317,6 +317,13 @@ def test_leadtime_pool_statistics_fall_back_beyond_the_register_budget(device):
     assert st is None and torch.equal(out, F.leadtime_pool(base, w1, 4, 13))
 
 
+def xn64(x, scale, shift, cin, groups):
+    """float64 NCHW of what a convolution behind the folded BatchNorm multiplies: scale_g * x + shift_g per group of images."""
+    xd = x[..., :cin].double().cpu().permute(0, 3, 1, 2)
+    per = x.shape[0] // groups
+    return torch.cat([xd[i * per:(i + 1) * per] * scale[i, :cin].double().cpu().view(1, -1, 1, 1) + shift[i, :cin].double().cpu().view(1, -1, 1, 1) for i in range(groups)])
+
+
 @pytest.mark.parametrize("n,cin,cout,H,W,groups,drop", [(48, 256, 256, 32, 32, 12, 0.2), (24, 128, 256, 32, 32, 4, 0.0), (12, 64, 128, 16, 48, 3, 0.5), (16, 128, 256, 64, 64, 2, 0.0),
                                                          (12, 64, 128, 18, 48, 3, 0.0)])
 def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(device, n, cin, cout, H, W, groups, drop):
@@ -387,6 +394,27 @@ def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(d
                 # the same non-zero products (an empty pixel pair carries another position code: its zero enters the instruction's adder elsewhere)
                 assert rel_l2(dw2, ref_w) < 1e-6 and float((s2 - ref_s).norm() / ref_s.norm()) < 1e-6, (perm, dropout, rel_l2(dw2, ref_w))
                 assert rel_l2(db2, ref_b) < 1e-6, (perm, dropout, rel_l2(db2, ref_b))
+                # ... and the float64 leg of THIS form: the oracle's dout is the (masked) pooled gradient scattered through torch's own
+                # max_pool2d indices of y (first maximum in row-major order, the kernels' rule) - neither the routing record nor sf_maxpool2_route_bwd's
+                # scatter enters it; then conv2d's weight gradient, the bias gradient and the two BatchNorm-backward reductions of exactly those operands
+                assert dropout is None or perm is None
+                g_in = (masked if masked is not None else gp).double().cpu()                     # pooled gradient in the pooling's INPUT image order
+                _, idx = torch.nn.functional.max_pool2d(y.double().cpu().permute(0, 3, 1, 2), 2, return_indices=True)
+                d64 = torch.zeros(n, eng.coutp, H * W, dtype=torch.float64).scatter_(2, idx.flatten(2), g_in.permute(0, 3, 1, 2).flatten(2)).view(n, -1, H, W)
+                xl = xn64(x, scale, shift, cin, groups).requires_grad_()
+                wl = w.double().cpu().requires_grad_()
+                gw2, gx2 = torch.autograd.grad(torch.nn.functional.conv2d(xl, wl, None, padding=1), (wl, xl), d64[:, :cout])
+                e_w, e_b = rel_l2(dw2.cpu().double(), gw2), rel_l2(db2.cpu().double(), d64[:, :cout].sum(dim=(0, 2, 3)))
+                # dn = conv^T(dout, W) enters the BatchNorm (the gradient wrt the NORMALISED input: gx2 / scale); xhat from the given mean / rstd
+                per = n // groups
+                sc = scale[:, :cin].double().cpu().view(groups, 1, cin, 1, 1)
+                dn = gx2.view(groups, per, cin, H, W) / sc
+                xh = (x[..., :cin].double().cpu().permute(0, 3, 1, 2).reshape(groups, per, cin, H, W) - mean[:, :cin].double().cpu().view(groups, 1, cin, 1, 1)) \
+                    * rstd[:, :cin].double().cpu().view(groups, 1, cin, 1, 1)
+                s_ref = torch.stack([dn.sum(dim=(1, 3, 4)), (dn * xh).sum(dim=(1, 3, 4))], 1)
+                e_s = float((s2[..., :cin].cpu() - s_ref).norm() / s_ref.norm())
+                print(f"pooled sparse wgrad vs float64 (perm {perm}, dropout {dropout is not None}): dW {e_w:.2e} db {e_b:.2e} sums {e_s:.2e}")
+                assert e_w < 2e-5 and e_b < 1e-5 and e_s < 5e-5, (perm, dropout, e_w, e_b, e_s)
         # float64: dW = sum_g scale_g (.) dWraw_g + shift_g (x) V_g  ==  the weight gradient of conv(scale_g * x + shift_g) for the group's images
         xd = x[..., :cin].double().cpu().permute(0, 3, 1, 2)
         per = n // groups

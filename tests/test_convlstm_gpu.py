@@ -147,3 +147,39 @@ def test_diagonal_encoder_schedule_is_bit_identical(device, case, monkeypatch):
     assert torch.equal(p0, p1) and torch.equal(dx0, dx1)
     for k in g0:
         assert torch.equal(g0[k], g1[k]), k
+
+
+@pytest.mark.parametrize("optimizer", ["flat_adam", "torch_adam"])
+@pytest.mark.parametrize("case", ["h32_hot", "rect_h16_o12"])
+def test_training_trajectory_golden(device, case, optimizer, fp32_mode):
+    """FIVE optimisation steps against the reference's own loop: ``training_step`` + Adam(lr) of
+    ``EncoderDecoderConvLSTM`` (reference conv_lstm.py:48-70) on the golden's batch sequence, driven (a) by ``FlatAdam`` (``sf_adam_step`` on the
+    flat buffers, the gradient sink, the pack-cache generation bumped by the raw-pointer update) and (b) by ``configure_optimizers()``'s torch
+    Adam (per-tensor version counters).  Per-step losses at rtol 1e-5 x 10 (they depend on the previous updates), the final parameters at the fp32
+    gate and their DISPLACEMENT (final - initial, 5e-3 at most: the part the training produced) to 1e-3 relative L2.  The trajectory is well
+    conditioned: the float64 oracle lands within 2e-6 / 1.4e-5 of the fp32 reference (tests/golden/make_golden.py trajectory)."""
+    from satflow_amd.models import EncoderDecoderConvLSTM
+    from satflow_amd.optim import FlatAdam
+
+    G = _load(f"convlstm_traj_{case}.npz")
+    steps, B, T, C, H, W = G["x"].shape
+    hid = G["param.encoder_1_convlstm.conv.bias"].shape[0] // 4
+    fs, lr = int(G["forecast_steps"]), float(G["lr"])
+    out_ch = G["y"].shape[3]
+    m = EncoderDecoderConvLSTM(hidden_dim=hid, input_channels=C, out_channels=out_ch, forecast_steps=fs, lr=lr).to(device)
+    m.load_state_dict({"model." + k[len("param."):]: v for k, v in G.items() if k.startswith("param.")}, strict=True)
+    opt = FlatAdam(m.parameters(), lr=lr) if optimizer == "flat_adam" else m.configure_optimizers()
+    assert optimizer == "flat_adam" or (type(opt) is torch.optim.Adam and opt.defaults["lr"] == lr)
+    losses = []
+    for k in range(steps):
+        loss = m.training_step((G["x"][k].to(device), G["y"][k].to(device)), k)
+        opt.zero_grad()
+        loss.backward()
+        opt.step()
+        losses.append(loss.detach())
+    assert_close(torch.stack(losses), G["losses"], f"trajectory losses ({optimizer}, {fp32_mode})", rtol=1e-4, atol=1e-7)
+    for k, p in m.model.named_parameters():
+        f, i = G[f"final.{k}"], G[f"param.{k}"]
+        assert_close(p, f, f"final {k}")
+        disp, err = f - i, p.detach().cpu() - f
+        assert float(err.norm()) <= 1e-3 * float(disp.norm()), f"{k}: displacement off by {float(err.norm() / disp.norm()):.2e} (relative L2)"

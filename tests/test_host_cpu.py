@@ -128,7 +128,7 @@ def test_compute_modes():
 
     try:
         for name, (comp, enc) in {"f32": (_hip.SF_F32, torch.float32), "bf16": (_hip.SF_BF16, torch.float32),
-                                  "bf16a": (_hip.SF_BF16, torch.bfloat16)}.items():
+                                  "bf16a": (_hip.SF_BF16, torch.bfloat16), "f32e": (_hip.SF_F32E, torch.float32)}.items():
             satflow_amd.set_compute_dtype(name)
             assert _hip.compute_dtype() == comp and _hip.encoder_storage_dtype() == enc and satflow_amd.compute_dtype_name() == name
         import pytest
@@ -343,7 +343,11 @@ def test_hot_kernels_do_not_spill():
         "conv3x3_bf16_persist4.hip": {},
         "convgru_seq.hip": {"convgru_seq_fwd_kernelILi2ELb1ELb0E": 64},                  # the one-workgroup-per-map fallback (n > CUs / 2)
         "conv3x3_wgrad_bf16.hip": {},
+        "conv3x3_f32e.hip": {"conv3x3_bf16_kernelILi8ELi5E": 40},                        # the same kernels as the SF_F32E mode (three fp16 products per fp32 product)
+        "conv3x3_wgrad_f32e.hip": {},
     }
+
+    isa = {}
 
     def scratch(src):
         with tempfile.TemporaryDirectory() as d:
@@ -352,6 +356,8 @@ def test_hot_kernels_do_not_spill():
                                capture_output=True, text=True)
             assert r.returncode == 0, r.stderr[-2000:]
             txt = open(out).read()
+        if src == "conv3x3_wgrad_bf16_dma.hip":
+            isa["txt"] = txt
         return src, {m.group(1): int(m.group(2)) for m in re.finditer(r"\.amdhsa_kernel (\S+).*?\.amdhsa_private_segment_fixed_size (\d+)", txt, re.S)}
 
     with cf.ThreadPoolExecutor(max_workers=6) as ex:
@@ -364,3 +370,30 @@ def test_hot_kernels_do_not_spill():
             if sc > allowed:
                 bad.append(f"{src}: {name} uses {sc} bytes of scratch per lane (budget {allowed})")
     assert not bad, "\n".join(bad)
+    # PLACEMENT, not only bytes.  The weight-gradient kernels that spill wait for their LDS-DMA pieces BY COUNT; a scratch access
+    # is a vector-memory operation, so one between two matrix instructions of the tile loop puts `s_waitcnt vmcnt(0)` there and drains the ring (DESIGN.md
+    # section 7, round 5).  Checked on the ISA: (a) no basic block that issues a matrix instruction touches scratch, in any of the spilling instantiations;
+    # (b) in the kernel the benchmark runs (wgrad_pooled8_kernel) the WHOLE span from its first to its last matrix instruction - every block of the tile
+    # loop - holds neither a scratch access nor a `vmcnt(0)`.  (The dense kernels' loop blocks do hold one `vmcnt(0)` each: the rendezvous in front of
+    # their `s_barrier`, by design.)
+    mat = re.compile(r"v_s?mfmac?_")
+    checked = 0
+    for m in re.finditer(r"^(_Z\w+):[^\n]*\n(.*?)^\.Lfunc_end\d+:", isa["txt"], re.S | re.M):
+        name, body = m.group(1), m.group(2)
+        if not ("wgrad_pooled8_kernel" in name or "wgrad_bf16_dma_kernelILb1ELb1E" in name):
+            continue
+        checked += 1
+        lines = [ln.strip() for ln in body.splitlines() if ln.strip() and not ln.strip().startswith(";")]
+        block, has_mat, has_scr = "entry", False, False
+        for ln in lines + [".LBBend_0:"]:
+            if re.match(r"\.LBB\w+:", ln):
+                assert not (has_mat and has_scr), f"{name}: basic block {block} issues matrix instructions AND touches scratch"
+                block, has_mat, has_scr = ln, False, False
+            has_mat |= bool(mat.match(ln))
+            has_scr |= ln.startswith("scratch_")
+        if "wgrad_pooled8_kernel" in name:
+            idx = [i for i, ln in enumerate(lines) if mat.match(ln)]
+            span = lines[idx[0]:idx[-1] + 1]
+            offenders = [ln for ln in span if ln.startswith("scratch_") or re.match(r"s_waitcnt.*vmcnt\(0\)", ln)]
+            assert len(idx) >= 18 and not offenders, f"{name}: {offenders[:4]} inside the tile loop"
+    assert checked == 4, checked
