@@ -195,6 +195,8 @@ int sf_convlstm_cell_fwd(sfTensor x, sfTensor h_prev, sfTensor c_prev, int32_t n
  *   dc_next (nullable) gradient flowing into c'; gates = saved i,f,o,g; c_prev nullable (zeros)
  *   -> dz [.., 4*hidp] gradient wrt the pre-activation conv output, dc_prev (nullable out).
  *   gates and dz share one storage type (SF_F32 or SF_BF16; dz may overwrite gates in place).
+ *   dz.amax (ABI 8, nullable; fp32-stored dz): a device word this launch RAISES to max |dz| (atomic maximum on the bit pattern; the caller sets it to 0
+ *   beforehand) - the scale word the SF_F32E input-gradient / weight-gradient kernels want with dz (sfTensor.amax), without sf_amax's extra pass.
  *   c_new (ABI 7: nullable): the step's new cell state; NULL = taken again as f * c_prev + i * g from the saved gates (one read of the state
  *   sequence less; with bf16-stored gates it then carries their rounding like the rest of this pass). */
 int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor dc_next,

@@ -38,10 +38,9 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ t, 
     m = red[0];
 #pragma unroll
     for (int k = 1; k < 4; ++k) m = red[k] > m ? red[k] : m;
-    if (m) {
-      atomicMax(amax, m);
-      if (acc) atomicMax(acc, m);
-    }
+    // (the words only grow: a workgroup whose maximum is already covered skips its atomics)
+    if (m > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, m);
+    if (acc && m > __atomic_load_n(acc, __ATOMIC_RELAXED)) atomicMax(acc, m);
   }
 }
 

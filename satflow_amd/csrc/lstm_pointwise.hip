@@ -1,6 +1,6 @@
 // Pointwise half of the ConvLSTM cell backward: from the incoming dh / dc' and the saved gates
 // to dz (gradient wrt the pre-activation conv output, gate-major [.., 4*hidp]) and dc_prev.
-// HBM-bound streaming kernel: 16-byte accesses, one pass, no atomics.
+// HBM-bound streaming kernel: 16-byte accesses, one pass; no atomics except the optional scale word (dz.amax: at most one atomic maximum per wave).
 // Autograd of satflow/models/layers/ConvLSTM.py:48-55.
 #include "sf_common.h"
 
@@ -16,6 +16,7 @@ struct GateBwdParams {
   void* dz; int s_dz;
   float* dc_prev; int s_dcp;
   long long pixels; int hidp;
+  unsigned* amax;   // (nullable) raised to max |dz| by this launch: the SF_F32E kernels' scale word of dz (sfTensor::amax); reset by the caller
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -25,6 +26,7 @@ template <typename TG>
 __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams p) {
   const int q = p.hidp >> 2;
   const long long total = p.pixels * q;
+  unsigned zmax = 0u;   // largest |dz| this thread wrote (bit pattern: non-negative floats order like unsigned integers)
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long pix = idx / q;
     const int c = (int)(idx - pix * q) * 4;
@@ -62,9 +64,25 @@ __global__ __launch_bounds__(256) void lstm_bwd_gates_kernel(const GateBwdParams
       zg[j] = d_c * gi[j] * (1.f - gg[j] * gg[j]);
       dcp[j] = d_c * gf[j];
     }
+    if (p.amax) {   // kernel-uniform
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float m = fmaxf(fmaxf(fabsf(zi[j]), fabsf(zf[j])), fmaxf(fabsf(zo[j]), fabsf(zg[j])));
+        const unsigned b = __builtin_bit_cast(unsigned, m);
+        zmax = b > zmax ? b : zmax;
+      }
+    }
     TG* z = reinterpret_cast<TG*>(p.dz) + pix * p.s_dz + c;
     stv4(z, zi); stv4(z + p.hidp, zf); stv4(z + 2 * p.hidp, zo); stv4(z + 3 * p.hidp, zg);
     if (p.dc_prev) *reinterpret_cast<f32x4*>(p.dc_prev + pix * p.s_dcp + c) = dcp;
+  }
+  if (p.amax) {   // one atomic per wave at most, and only while the word is still below this wave's maximum (the word only grows)
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)zmax, off);
+      zmax = o > zmax ? o : zmax;
+    }
+    if ((threadIdx.x & 63) == 0 && zmax > __atomic_load_n(p.amax, __ATOMIC_RELAXED)) atomicMax(p.amax, zmax);
   }
 }
 
@@ -98,6 +116,8 @@ extern "C" int sf_convlstm_cell_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor d
   p.dz = dz.ptr; p.s_dz = dz.stride;
   p.dc_prev = (float*)dc_prev.ptr; p.s_dcp = dc_prev.stride;
   p.pixels = pixels; p.hidp = hidp;
+  SF_REQUIRE(!dz.amax || (dz.dtype == SF_F32 && ((uintptr_t)dz.amax & 3) == 0), "bwd_gates: dz.amax goes with an fp32-stored dz (4-byte aligned word)");
+  p.amax = (unsigned*)dz.amax;
   const long long total = pixels * (hidp / 4);
   if (total == 0) return 0;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);

@@ -165,6 +165,14 @@ def grad_operand(t: Tensor, acc: Optional[Tensor] = None, reset_acc: bool = Fals
     return d
 
 
+def scale_words(n: int, device) -> Optional[Tensor]:
+    """``n`` zeroed scale words for kernels that raise them while they write a gradient (``sf_convlstm_cell_bwd_gates`` with ``dz.amax``) - "f32e" mode
+    only, else None.  One fill launch; never a memset node (torch.zeros fills with a kernel)."""
+    if _hip.compute_dtype() != _hip.SF_F32E:
+        return None
+    return torch.zeros(n, dtype=torch.float32, device=device)
+
+
 def grad_operand_with(t: Tensor, word: Optional[Tensor], **kw) -> sfTensor:
     """``T(t)`` carrying an amax word that was accumulated earlier (``grad_operand(..., acc=word)``); plain ``T(t)`` without a word."""
     d = T(t, **kw)
@@ -212,6 +220,7 @@ def convlstm_cell_fwd(x: sfTensor, h_prev: sfTensor, c_prev: sfTensor, n: int, h
 
 def convlstm_cell_bwd_gates(dh: Sequence[sfTensor], dc_next: sfTensor, gates: sfTensor, c_prev: sfTensor, c_new: sfTensor,
                             pixels: int, hidp: int, dz: sfTensor, dc_prev: sfTensor) -> None:
+    """``dz.amax`` set (``T(dz, amax=word)``, word zeroed by the caller): the launch raises the word to max |dz| ("f32e" mode's scale word)."""
     dh = list(dh) + [NULL] * (3 - len(dh))
     check(
         lib().sf_convlstm_cell_bwd_gates(dh[0], dh[1], dh[2], dc_next, gates, c_prev, c_new, pixels, hidp, dz, dc_prev, SF_F32,

@@ -158,6 +158,12 @@ class _StackFn(torch.autograd.Function):
         dc = [torch.empty(B, H, W, hidp, dtype=torch.float32, device=dev) for _ in range(4)]
         dxs = torch.empty(xs.shape, dtype=torch.float32, device=dev) if ctx.need_dx else None
 
+        # "f32e" mode: one scale word per cell and step, raised to max |dz| by the gate kernel that writes dz and read by the input-gradient convolution
+        # (and, as the maximum over a cell's steps, by its weight gradient) - None in every other mode
+        Tmax = max(T_in, T_out)
+        words = K.scale_words(4 * Tmax, dev)
+        word = (lambda k, t: words[k * Tmax + t: k * Tmax + t + 1]) if words is not None else (lambda k, t: None)
+
         def dx_of(k: int) -> sfTensor:  # gradient wrt the cell's layer input, left by its last bwd_data
             return T(dcat[k], engines[k].cinp, 0)
 
@@ -170,9 +176,9 @@ class _StackFn(torch.autograd.Function):
             if not last:
                 sources = sources + [dh_of(k)]
             eng.bwd_gates(sources, None if last else dc[k], Gs[k][t], Cs[k][t - 1] if t else None, Cs[k][t], Gs[k][t],
-                          dc[k] if t else None)
+                          dc[k] if t else None, word(k, t))
             if t or need_dx[k]:
-                eng.bwd_data(Gs[k][t], B, H, W, need_dx[k], dcat[k])
+                eng.bwd_data(Gs[k][t], B, H, W, need_dx[k], dcat[k], word(k, t))
 
         # weight gradients: one split-K GEMM per cell over all of its timesteps (Gs now hold dz)
         zeros = torch.zeros(B, H, W, hidp, dtype=Hs[0].dtype, device=dev)
@@ -193,10 +199,11 @@ class _StackFn(torch.autograd.Function):
                 first_in, rest_in = Hs[1][T_in - 1], Hs[3][: T_out - 1]
             else:
                 first_in, rest_in = Hs[2][0], Hs[2][1:]
-            # (K.grad_operand: in "f32e" mode the gate gradients carry their amax word - one extra pass over dz per launch)
-            eng.bwd_weight(T(first_in), T(zeros), K.grad_operand(Gs[k][0]), B, H, W, dw, db, False)
+            # ("f32e": the gate gradients go in with their scale word - step 0's own, the maximum of the later steps' for the launch over all of them)
+            eng.bwd_weight(T(first_in), T(zeros), K.grad_operand_with(Gs[k][0], word(k, 0)), B, H, W, dw, db, False)
             if steps > 1:
-                eng.bwd_weight(T(rest_in), T(Hs[k][: steps - 1]), K.grad_operand(Gs[k][1:]), (steps - 1) * B, H, W, dw, db, True)
+                rest = words[k * Tmax + 1: k * Tmax + steps].amax().reshape(1) if words is not None else None
+                eng.bwd_weight(T(rest_in), T(Hs[k][: steps - 1]), K.grad_operand_with(Gs[k][1:], rest), (steps - 1) * B, H, W, dw, db, True)
             cell_grads[k] = (dw_ret, db_ret)
             done[k] = True
 
@@ -238,25 +245,25 @@ class _StackFn(torch.autograd.Function):
                     eng = e1
                     lastt = t == T_in - 1
                     src = [T(d1pair[t & 1], e2.cinp, 0)] + ([] if lastt else [dh_of(0)])
-                    eng.bwd_gates(src, None if lastt else dc[0], Gs[0][t], Cs[0][t - 1] if t else None, Cs[0][t], Gs[0][t], dc[0] if t else None)
+                    eng.bwd_gates(src, None if lastt else dc[0], Gs[0][t], Cs[0][t - 1] if t else None, Cs[0][t], Gs[0][t], dc[0] if t else None, word(0, t))
                     read_done[t & 1] = torch.cuda.Event()
                     read_done[t & 1].record(side)
                     if t or need_dx[0]:
-                        eng.bwd_data(Gs[0][t], B, H, W, need_dx[0], dcat[0])
+                        eng.bwd_data(Gs[0][t], B, H, W, need_dx[0], dcat[0], word(0, t))
                     if ctx.need_dx:
                         dxs[t].copy_(dcat[0][..., : e1.cinp])
 
             for t in range(T_in - 1, -1, -1):
                 last = t == T_in - 1
                 src = ([dx_of(2)] if last else []) + ([] if last else [T(d1pair[(t + 1) & 1], hidp, widths[1] - hidp)])
-                e2.bwd_gates(src, None if last else dc[1], Gs[1][t], Cs[1][t - 1] if t else None, Cs[1][t], Gs[1][t], dc[1] if t else None)
+                e2.bwd_gates(src, None if last else dc[1], Gs[1][t], Cs[1][t - 1] if t else None, Cs[1][t], Gs[1][t], dc[1] if t else None, word(1, t))
                 if not last:
                     g_done = torch.cuda.Event()
                     g_done.record(main)
                     enc1(t + 1, g_done)
                 if read_done[t & 1] is not None:
                     main.wait_event(read_done[t & 1])
-                e2.bwd_data(Gs[1][t], B, H, W, True, d1pair[t & 1])
+                e2.bwd_data(Gs[1][t], B, H, W, True, d1pair[t & 1], word(1, t))
                 data_done = torch.cuda.Event()
                 data_done.record(main)
             enc1(0, None)

@@ -69,20 +69,21 @@ class CellEngine:
                             T(h_out), T(c_out), T(gates) if gates is not None else NULL)
 
     def bwd_gates(self, dh: Sequence[sfTensor], dc_next: Optional[Tensor], gates: Tensor, c_prev: Optional[Tensor],
-                  c_new: Tensor, dz: Tensor, dc_prev: Optional[Tensor]) -> None:
+                  c_new: Tensor, dz: Tensor, dc_prev: Optional[Tensor], amax: Optional[Tensor] = None) -> None:
+        """``amax`` ("f32e" mode): a ZEROED device word the kernel raises to max |dz| - handed on to ``bwd_data`` / ``bwd_weight`` with dz."""
         pixels = gates.numel() // gates.shape[-1]
         # bf16-stored gates ("bf16a"): c' is taken again from them instead of read back - 4 of the 36 bytes per element of this HBM-bound pass
         # (SF_LSTM_READ_C=1: A/B switch); with fp32-stored gates the state is read (bit-exact backward of the parity mode)
         recompute = gates.dtype == torch.bfloat16 and not os.environ.get("SF_LSTM_READ_C")
         K.convlstm_cell_bwd_gates(dh, T(dc_next, self.hidp), T(gates), T(c_prev, self.hidp), NULL if recompute else T(c_new), pixels, self.hidp,
-                                  T(dz), T(dc_prev, self.hidp))
+                                  T(dz, amax=amax if dz.dtype == torch.float32 else None), T(dc_prev, self.hidp))
 
-    def bwd_data(self, dz: Tensor, n: int, h: int, w: int, need_dx: bool, dcat: Tensor, amax_acc: Optional[Tensor] = None,
-                 reset_acc: bool = False) -> None:
-        """dcat[.., (cinp if need_dx) + hidp] = conv(dz, W^T flipped).  ``amax_acc`` ("f32e" mode): a device word that collects the maximum of |dz| over
-        the steps of a sequence, for the one weight-gradient launch over all of them (``K.grad_operand``)."""
+    def bwd_data(self, dz: Tensor, n: int, h: int, w: int, need_dx: bool, dcat: Tensor, amax: Optional[Tensor] = None) -> None:
+        """dcat[.., (cinp if need_dx) + hidp] = conv(dz, W^T flipped).  ``amax`` ("f32e" mode): dz's scale word as left by ``bwd_gates``; without
+        it the word is taken here (one more pass over dz, ``K.grad_operand``)."""
         gm = self.bwd_maps[need_dx]
-        K.conv3x3(K.grad_operand(dz, amax_acc, reset_acc), NULL, n, h, w, self.packed_bwd(need_dx), None, gm, T(dcat))
+        src = K.grad_operand_with(dz, amax) if amax is not None else K.grad_operand(dz)
+        K.conv3x3(src, NULL, n, h, w, self.packed_bwd(need_dx), None, gm, T(dcat))
 
     def bwd_weight(self, x: sfTensor, h_prev: sfTensor, dz: sfTensor, n: int, h: int, w: int, dw: Tensor, db: Optional[Tensor],
                    accumulate: bool) -> None:
@@ -117,13 +118,14 @@ class _CellStepFn(torch.autograd.Function):
         dc_out = dc_out.contiguous() if dc_out is not None else None
         dz = torch.empty_like(gates)
         dc_prev = torch.empty_like(c_out) if has_c else None
-        eng.bwd_gates([T(dh_out)], dc_out, gates, c if has_c else None, c_out, dz, dc_prev)
+        word = K.scale_words(1, x.device)   # ("f32e": dz's scale word, raised by the gate kernel; None otherwise)
+        eng.bwd_gates([T(dh_out)], dc_out, gates, c if has_c else None, c_out, dz, dc_prev, word)
         need_dx = ctx.need_dx
         dx = dh = None
         if need_dx or has_h:
             width = (eng.cinp if need_dx else 0) + eng.hidp
             dcat = torch.empty(n, H, W, width, dtype=torch.float32, device=x.device)
-            eng.bwd_data(dz, n, H, W, need_dx, dcat)
+            eng.bwd_data(dz, n, H, W, need_dx, dcat, word)
             if need_dx:
                 dx = dcat[..., : eng.cinp].contiguous()
             if has_h:
@@ -132,7 +134,7 @@ class _CellStepFn(torch.autograd.Function):
         db = torch.empty_like(eng.conv.bias) if eng.conv.bias is not None else None
         # zero state == zero contribution to dW's h-columns; feed an explicit zero tensor for the K lanes
         hsrc = T(h) if has_h else T(torch.zeros(n, H, W, eng.hidp, dtype=torch.float32, device=x.device))
-        eng.bwd_weight(T(x), hsrc, K.grad_operand(dz), n, H, W, dw, db, accumulate=False)
+        eng.bwd_weight(T(x), hsrc, K.grad_operand_with(dz, word) if word is not None else K.grad_operand(dz), n, H, W, dw, db, accumulate=False)
         return None, dx, dh, dc_prev, dw, db
 
 

@@ -405,16 +405,15 @@ def test_weight_gradient_of_a_pooled_gradient_on_the_sparse_matrix_instruction(d
                 wl = w.double().cpu().requires_grad_()
                 gw2, gx2 = torch.autograd.grad(torch.nn.functional.conv2d(xl, wl, None, padding=1), (wl, xl), d64[:, :cout])
                 e_w, e_b = rel_l2(dw2.cpu().double(), gw2), rel_l2(db2.cpu().double(), d64[:, :cout].sum(dim=(0, 2, 3)))
-                # dn = conv^T(dout, W) enters the BatchNorm (the gradient wrt the NORMALISED input: gx2 / scale); xhat from the given mean / rstd
+                # dn = conv^T(dout, W) enters the BatchNorm = the gradient wrt the convolution's (normalised) input; xhat from the given mean / rstd
                 per = n // groups
-                sc = scale[:, :cin].double().cpu().view(groups, 1, cin, 1, 1)
-                dn = gx2.view(groups, per, cin, H, W) / sc
+                dn = gx2.view(groups, per, cin, H, W)
                 xh = (x[..., :cin].double().cpu().permute(0, 3, 1, 2).reshape(groups, per, cin, H, W) - mean[:, :cin].double().cpu().view(groups, 1, cin, 1, 1)) \
                     * rstd[:, :cin].double().cpu().view(groups, 1, cin, 1, 1)
                 s_ref = torch.stack([dn.sum(dim=(1, 3, 4)), (dn * xh).sum(dim=(1, 3, 4))], 1)
                 e_s = float((s2[..., :cin].cpu() - s_ref).norm() / s_ref.norm())
                 print(f"pooled sparse wgrad vs float64 (perm {perm}, dropout {dropout is not None}): dW {e_w:.2e} db {e_b:.2e} sums {e_s:.2e}")
-                assert e_w < 2e-5 and e_b < 1e-5 and e_s < 5e-5, (perm, dropout, e_w, e_b, e_s)
+                assert e_w < 2e-6 and e_b < 2e-6 and e_s < 2e-6, (perm, dropout, e_w, e_b, e_s)   # observed on MI355X: 0.7 .. 1.1e-7 each
         # float64: dW = sum_g scale_g (.) dWraw_g + shift_g (x) V_g  ==  the weight gradient of conv(scale_g * x + shift_g) for the group's images
         xd = x[..., :cin].double().cpu().permute(0, 3, 1, 2)
         per = n // groups
