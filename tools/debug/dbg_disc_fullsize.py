@@ -1,5 +1,5 @@
 """Stage-by-stage comparison of the spatial discriminator at BASELINE configs[4] size (chn 64, 8 frames of 256x256) against oracle/dgmr.py in fp32 mode.
-python tests/debug/dbg_disc_fullsize.py [chn] [size] [frames]"""
+python tools/debug/dbg_disc_fullsize.py [chn] [size] [frames]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
