@@ -70,16 +70,24 @@ def center_crop(x: Tensor, size: int) -> Tensor:
     return x[..., top : top + size, left : left + size]
 
 
-def preprocess(x: Tensor, sat_channels: int, crop_size: int) -> Tensor:
+def preprocess(x: Tensor, sat_channels: int, crop_size: int, order: str = "pixel_unshuffle") -> Tensor:
     """``MetNetPreprocessor(sat_channels, crop_size, use_space2depth=True, split_input=True)``.
 
     ``x[B,T,C,H,W]``.  Satellite channels: PixelUnshuffle(2) (channel order
     ``c*4 + dh*2 + dw``), then [centre crop ; 2x2 mean] on the channel axis;
     remaining channels: 2x2 mean then centre crop.  Output
     ``[B,T,8*sat+(C-sat),crop,crop]``.
+
+    ``order="einops"``: the space-to-depth channel order of the reference's own in-tree ``space_to_depth``
+    (``satflow/models/utils.py:48-60``: ``"b (h dh) (w dw) c -> b h w (dh dw c)"``, channel ``(dh*2 + dw)*C + c``) - what some upstream
+    versions of the preprocessor use; computed here with that very function (``space_to_depth`` above, pinned by ``metnet_layers.npz``).
     """
     B, T, C, H, W = x.shape
-    sat = F.pixel_unshuffle(x[:, :, :sat_channels].reshape(B * T, sat_channels, H, W), 2)
+    if order == "einops":
+        sat = space_to_depth(x[:, :, :sat_channels].reshape(B * T, sat_channels, H, W).permute(0, 2, 3, 1), 2).permute(0, 3, 1, 2)
+    else:
+        assert order == "pixel_unshuffle", order
+        sat = F.pixel_unshuffle(x[:, :, :sat_channels].reshape(B * T, sat_channels, H, W), 2)
     parts = [center_crop(sat, crop_size), F.avg_pool2d(sat, 2)]
     if C > sat_channels:
         other = F.avg_pool2d(x[:, :, sat_channels:].reshape(B * T, C - sat_channels, H, W), 2)
@@ -213,6 +221,7 @@ def metnet_forward(
     bn_stats: Dict[str, Tuple[Tensor, Tensor]] | None = None,
     pool_routing: Dict[Tuple[str, int], Tensor] | None = None,
     feature_scale: Dict[int, Tensor] | None = None,
+    space2depth_order: str = "pixel_unshuffle",
 ) -> Tensor:
     """``MetNet.forward(imgs[B,T,C,H,W]) -> [B, forecast_steps, out, input_size//4, input_size//4]``.
 
@@ -227,7 +236,7 @@ def metnet_forward(
     the masks are then REPLAYED (they come from the kernels' counter-based generator), not drawn.
     """
     outs = []
-    base = preprocess(imgs, sat_channels, input_size)
+    base = preprocess(imgs, sat_channels, input_size, space2depth_order)
     for i in range(forecast_steps):
         t = condition_time(base, i, forecast_steps)
         rt = (None, None) if pool_routing is None else (pool_routing.get(("p1", i)), pool_routing.get(("p2", i)))

@@ -278,11 +278,21 @@ class MetNet(nn.Module):
         num_att_layers: int = 1,
         forecast_steps: int = 48,
         temporal_dropout: float = 0.2,
+        space2depth_order: str = "pixel_unshuffle",
         **kwargs,
     ):
         """Keyword surface of upstream ``metnet.MetNet`` as called from reference ``pl_metnet.py:46-59``
-        (``head=`` and other extras are swallowed by ``**kwargs`` as upstream does)."""
+        (``head=`` and other extras are swallowed by ``**kwargs`` as upstream does).
+
+        ``space2depth_order`` (not an upstream keyword): channel order of the preprocessor's space-to-depth that ``conv1``'s
+        weight columns are laid out for - ``"pixel_unshuffle"`` (``c*4 + dh*2 + dw``, torch's ``PixelUnshuffle``; default) or ``"einops"``
+        (``(dh*2 + dw)*C + c``, the reference's in-tree ``space_to_depth``, ``satflow/models/utils.py:48-60``) - for checkpoints trained with
+        either upstream variant.  The kernels' data layout does not change: the image part of ``conv1.weight`` is read through a column
+        permutation (one small gather per step; its gradient scatters back through it)."""
         super().__init__()
+        if space2depth_order not in ("pixel_unshuffle", "einops"):
+            raise ValueError(f"space2depth_order={space2depth_order!r}: 'pixel_unshuffle' or 'einops'")
+        self.space2depth_order = space2depth_order
         if image_encoder not in ("downsampler", "default"):
             raise NotImplementedError(f"image_encoder={image_encoder!r}: only the DownSampler encoder is on the hot path")
         self.forecast_steps, self.input_channels, self.output_channels = forecast_steps, input_channels, output_channels
@@ -298,6 +308,13 @@ class MetNet(nn.Module):
         self.head = nn.Conv2d(hidden_dim, output_channels, kernel_size=(1, 1))
         # conv1 restricted to the image lanes (the one-hot lead-time lanes are folded into the first pooling)
         self._conv1 = ConvEngine([self.image_channels], 160)
+        # data lane (pixel-unshuffle order: [centre crop | 2x2 mean] x (c*4 + d), then the other channels) -> column of conv1.weight in "einops" order
+        sat, cols = sat_channels, list(range(self.image_channels))
+        for half in range(2):
+            for c in range(sat):
+                for d in range(4):
+                    cols[half * 4 * sat + c * 4 + d] = half * 4 * sat + d * sat + c
+        self.register_buffer("_s2d_cols", torch.tensor(cols, dtype=torch.long), persistent=False)
 
     def forward(self, imgs: Tensor, lead_time: int = 0) -> Tensor:
         """``imgs[B,T,C,4*input_size,4*input_size] -> [B, forecast_steps, output_channels, input_size//4, input_size//4]``."""
@@ -319,7 +336,8 @@ class MetNet(nn.Module):
         # the convolution is handed a fresh slice of c1.weight every call: its packed-weight cache keys on the LIVE parameters
         # (looked up now, not captured at construction - they may have been replaced by load_state_dict(assign=True) / re-assignment)
         self._conv1.key_tensors = (c1.weight, c1.bias)
-        base = F.conv3x3(self._conv1, frames, c1.weight[:, :cimg].contiguous(), c1.bias, out_dtype=st)  # [T*B, S, S, 160]
+        w_img = c1.weight[:, :cimg].contiguous() if self.space2depth_order == "pixel_unshuffle" else c1.weight[:, :cimg].index_select(1, self._s2d_cols)
+        base = F.conv3x3(self._conv1, frames, w_img, c1.bias, out_dtype=st)  # [T*B, S, S, 160]
         if enc.capture is not None:
             enc.capture["base"] = base.detach()
         # [L*T*B, S/2, S/2, 160], image (l*F + f); in training mode with the per-lead-time sums its BatchNorm needs

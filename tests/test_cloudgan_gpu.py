@@ -241,8 +241,9 @@ def test_cloudgan_training_steps_bf16_modes_vs_golden(device, case):
     """The two optimizer steps of the golden run in the benchmarked arithmetic (bf16 MFMA operands everywhere incl. the PatchGAN discriminator's
     4x4 convolutions, `bf16a`): losses and every parameter gradient against the reference's fp32 goldens.  Yardstick = the CPU oracle of the
     same steps under ``torch.autocast(bfloat16)`` (what the reference's `precision: 16` run computes): a parameter's gradient error may be at
-    most 1.5x the yardstick's error for that parameter, or the yardstick's own worst parameter of the step, or 2e-2 (these B = 1 goldens
-    are sensitive: the autocast run itself is 9-22 % off on some biases); the observed figures are published."""
+    most 1.5x the yardstick's error FOR THAT PARAMETER, or 2e-2 (these B = 1 goldens are sensitive: the autocast run itself is 9-22 % off on
+    some biases); the observed figures are published.  Round 6: the former escape hatch (the yardstick's worst parameter of the whole step as a
+    bound for every parameter) is gone; ONE parameter of ONE golden is allow-listed with its measured cause (``ALLOW`` below)."""
     import satflow_amd
     from oracle import cloudgan as OC
     from parity_util import publish
@@ -269,6 +270,13 @@ def test_cloudgan_training_steps_bf16_modes_vs_golden(device, case):
         grads.update({f"disc.{k}": v.grad for k, v in disc.items() if getattr(v, "grad", None) is not None})
         return float(loss), grads
 
+    # gen.decoder_1_convlstm.conv.bias, generator step of the 'small' golden: 18.0 % against a 9.4 % yardstick (1.9x).  tools/probe_cloudgan_bias.py
+    # (profiles/r06_cloudgan_decoder1_bias.txt) ran the step under every storage switch of the stack: fp32-stored [dx ; dh] 17.9 %, fp32 head gradient
+    # 18.0 %, fp32 frames 18.0 %, c' read back 18.3 %, all four 17.6 %, and the "bf16" mode - fp32 storage EVERYWHERE, only the MFMA operands rounded -
+    # 17.2 %; "f32" / "f32e" 0.0000.  So it is the bf16 operand rounding of the products themselves (what any bf16-operand implementation does), drawn
+    # differently from the CPU autocast run's: the same parameter on the 'rect' golden is 5.7 % against a 9.2 % yardstick (0.6x).  The gradient is a sum
+    # over 6 decoder steps x 4096 pixels that cancels to a fraction of a per cent of its l1 mass.
+    ALLOW = {("small", "g", "gen.decoder_1_convlstm.conv.bias"): 0.20}
     satflow_amd.set_compute_dtype("bf16a")
     try:
         m = CloudGAN(forecast_steps=fs, input_channels=C, num_filters=nf, generator_model="convlstm", norm="batch", discriminator_model="basic",
@@ -290,11 +298,10 @@ def test_cloudgan_training_steps_bf16_modes_vs_golden(device, case):
             worst_upd = ("", 0.0, 0.0)   # ... among the parameters THIS step's optimizer updates (the generator step leaves gradients on the discriminator too)
             live = [(net, pre, k, p) for net, pre in ((m.generator, "gen"), (m.discriminator, "disc")) for k, p in net.named_parameters()
                     if p.grad is not None and f"{pre}.{k}" in y_grads and float(G[f"{tag}_grad.{pre}.{k}"].float().abs().max()) >= 1e-6]
-            y_worst = max(rel(y_grads[f"{pre}.{k}"], G[f"{tag}_grad.{pre}.{k}"].float()) for _, pre, k, _ in live)   # the autocast run's own worst parameter
             for net, pre, k, p in live:
                     ref = G[f"{tag}_grad.{pre}.{k}"].float()
                     err, yerr = rel(p.grad, ref), rel(y_grads[f"{pre}.{k}"], ref)
-                    assert err <= max(1.5 * yerr, y_worst, 2e-2), (tag, pre, k, err, yerr, y_worst)
+                    assert err <= max(1.5 * yerr, 2e-2, ALLOW.get((case, tag, f"{pre}.{k}"), 0.0)), (tag, pre, k, err, yerr)
                     if err > worst[1]:
                         worst = (f"{pre}.{k}", err, yerr)
                     if pre == ("gen" if tag == "g" else "disc") and err > worst_upd[1]:

@@ -363,3 +363,37 @@ def test_maxpool_fused_dropout(device, storage):
     fused.backward(cot)
     plain.backward(cot)
     assert torch.equal(x1.grad, x2.grad)
+
+
+def test_space_to_depth_channel_order_switch(device):
+    """SURVEY App. A.1 / VERDICT r5 item 9: ``MetNet(space2depth_order="einops")`` reads conv1's weight columns in the channel order of the reference's own
+    in-tree ``space_to_depth`` (``satflow/models/utils.py:48-60``, ``(dh dw c)``; pinned by ``metnet_layers.npz``) instead of ``PixelUnshuffle``'s.  Same
+    parameters, eval mode: output AND the gradient of conv1's weight against the oracle run with that order; the default order is unchanged and differs."""
+    cfg = dict(input_channels=6, sat_channels=5, input_size=8, output_channels=2, hidden_dim=16, forecast_steps=2)
+    net, P = _metnet_pair(device, cfg, seed=9)
+    from satflow_amd.models import MetNet
+
+    alt = MetNet(**cfg, temporal_dropout=0.0, space2depth_order="einops")
+    alt.temporal_enc.rnn.input_p = 0.0
+    alt.load_state_dict(net.state_dict())
+    alt = alt.to(device)
+    with pytest.raises(ValueError):
+        MetNet(**cfg, space2depth_order="nchw")
+    xs = torch.randn(2, 2, 6, 32, 32, generator=_g(31))
+    cot = torch.randn(2, 2, 2, 2, 2, generator=_g(32))
+    stats = {i: (net.state_dict()[f"image_encoder.module.module.{i}.running_mean"].cpu(), net.state_dict()[f"image_encoder.module.module.{i}.running_var"].cpu())
+             for i in ("3", "5", "7")}
+    outs = {}
+    for name, m in (("pixel_unshuffle", net), ("einops", alt)):
+        m.eval()
+        m.zero_grad()
+        got = m(xs.to(device))
+        (got * cot.to(device)).sum().backward()
+        Pn = {k: v.detach().clone().requires_grad_() for k, v in P.items()}
+        ref = M.metnet_forward(xs, Pn, sat_channels=5, input_size=8, forecast_steps=2, bn_stats=stats, space2depth_order=name)
+        (ref * cot).sum().backward()
+        assert_close(got, ref, f"metnet eval, {name} order")
+        k1 = "image_encoder.module.module.0.weight"
+        assert_close(dict(m.named_parameters())[k1].grad, Pn[k1].grad, f"d conv1.weight, {name} order", grad=True)
+        outs[name] = got.detach().cpu()
+    assert (outs["einops"] - outs["pixel_unshuffle"]).abs().max() > 1e-3, "the two channel orders must give different results for the same weights"
