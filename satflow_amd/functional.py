@@ -32,8 +32,14 @@ class GradSink:
       a second backward pass of a gradient-accumulation loop - gets ``None`` and the caller returns its gradient to autograd as before;
     * autograd runs a parameter's AccumulateGrad node after ALL functions that consume the parameter, so an ``add_`` from another
       consumer always lands on top of the written value, never under it;
-    * parameters no optimizer registered (tests on bare modules, frozen networks) are not in the table.
-    ``SF_NO_GRAD_SINK=1``: A/B switch (every gradient goes through autograd)."""
+    * parameters no optimizer registered (tests on bare modules, frozen networks) are not in the table;
+    * ANY backward pass that reaches a registered parameter closes its owner until the next ``zero_grad()`` - also a pass that reaches it only through
+      plain autograd operations (a tensor hook on every registered parameter arms the same end-of-pass callback; advisor r5: without it
+      ``(3 * p).sum().backward()`` followed by a sink-aware backward overwrote the accumulated gradient);
+    * a parameter that was frozen after registration (``requires_grad_(False)``) or whose gradient the Function was not asked for
+      (``needs_input_grad``) gets no destination: nothing is written into the optimizer's buffer for it.
+    ``SF_NO_GRAD_SINK=1`` / ``no_grad_sink()``: every gradient goes through autograd (use around ``torch.autograd.grad`` on registered parameters:
+    that call must not touch ``.grad``, and the engine does not tell a Function which of the two it is running under)."""
 
     def __init__(self) -> None:
         self.table: dict = {}      # (data_ptr, numel) of the parameter -> (gradient view, owner)
@@ -47,6 +53,15 @@ class GradSink:
         import weakref
 
         self.table[(param.data_ptr(), param.numel())] = (grad_view, id(owner), weakref.ref(owner), param.untyped_storage().data_ptr())
+        oid = id(owner)
+
+        def reached(_g, oid=oid):   # autograd produced a gradient for this parameter in the running pass: the owner's buffer is no longer "zero"
+            if oid in self.taken:
+                self._arm(oid)
+            return None
+
+        if param.requires_grad:
+            param.register_hook(reached)
         if id(owner) not in self.taken:
             self.taken[id(owner)] = set()
             weakref.finalize(owner, self._drop_owner, id(owner))   # (the table holds views of the owner's gradient buffer: let go of them with the owner)
@@ -60,16 +75,25 @@ class GradSink:
         self._drop_owner(id(owner))
 
     def reopen(self, owner) -> None:
-        """``zero_grad()`` of ``owner``: its buffer is zero again."""
+        """``zero_grad()`` of ``owner``: its buffer is zero again.  Also drops a pass that never ended (a backward that raised leaves the engine's final
+        callbacks unrun: the armed flag would stay set for the rest of the process)."""
         self.taken[id(owner)] = set()
         self.closed.discard(id(owner))
+        self._pass_owners.discard(id(owner))
+        self._armed = False
+
+    def _arm(self, oid: int) -> None:
+        self._pass_owners.add(oid)
+        if not self._armed:
+            self._armed = True
+            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
 
     def _end_of_backward(self) -> None:
         self.closed |= self._pass_owners
         self._pass_owners, self._armed = set(), False
 
     def dest(self, param: Optional[Tensor]) -> Optional[Tensor]:
-        if param is None or self.off or not self.table or not param.is_contiguous():
+        if param is None or self.off or not self.table or not param.is_contiguous() or not param.requires_grad:
             return None
         key = (param.data_ptr(), param.numel())
         e = self.table.get(key)
@@ -82,23 +106,32 @@ class GradSink:
         if e[1] in self.closed or key in self.taken[e[1]]:
             return None
         self.taken[e[1]].add(key)
-        self._pass_owners.add(e[1])
-        if not self._armed:
-            self._armed = True
-            torch.autograd.Variable._execution_engine.queue_callback(self._end_of_backward)
+        self._arm(e[1])
         return e[0]
 
 
 GRAD_SINK = GradSink()
 
 
-def grad_out(param: Optional[Tensor], shape=None, zero: bool = False) -> Tuple[Tensor, Optional[Tensor]]:
+@contextlib.contextmanager
+def no_grad_sink():
+    """Every gradient through autograd inside the block (``torch.autograd.grad`` on parameters an optimizer registered: see ``GradSink``)."""
+    prev, GRAD_SINK.off = GRAD_SINK.off, True
+    try:
+        yield
+    finally:
+        GRAD_SINK.off = prev
+
+
+def grad_out(param: Optional[Tensor], shape=None, zero: bool = False, needed: bool = True) -> Tuple[Tensor, Optional[Tensor]]:
     """``(tensor the gradient kernel writes, value the Function returns for that input)`` for parameter ``param`` (fp32; ``shape``: the
-    kernel's view of it, e.g. OIHW with the taps split).  Call only from inside ``backward``."""
-    dst = GRAD_SINK.dest(param)
+    kernel's view of it, e.g. OIHW with the taps split).  Call only from inside ``backward``.  ``needed`` = ``ctx.needs_input_grad`` of that
+    input: when autograd did not ask for the gradient the kernel writes into scratch and the Function returns ``None`` (never the optimizer's
+    buffer: a parameter frozen after the optimizer registered it must stay untouched)."""
+    dst = GRAD_SINK.dest(param) if needed else None
     if dst is None:
         t = (torch.zeros if zero else torch.empty)(tuple(shape) if shape is not None else param.shape, dtype=torch.float32, device=param.device)
-        return t, (t.reshape(param.shape) if shape is not None else t)
+        return t, ((t.reshape(param.shape) if shape is not None else t) if needed else None)
     return (dst.view(tuple(shape)) if shape is not None else dst), None
 
 
@@ -415,8 +448,8 @@ class _ConvFn(torch.autograd.Function):
             x0, gy = ctx.wbatch.take()
             n = x0.shape[0]
             gyT = K.grad_operand(gy)
-        dw4, dw_ret = grad_out(weight, (weight.shape[0], weight.shape[1], 3, 3))
-        db, db_ret = grad_out(ctx.bias) if has_bias else (None, None)
+        dw4, dw_ret = grad_out(weight, (weight.shape[0], weight.shape[1], 3, 3), needed=ctx.needs_input_grad[3])
+        db, db_ret = grad_out(ctx.bias, needed=ctx.needs_input_grad[4]) if has_bias else (None, None)
         s0 = T(x0, idiv=remap0[0], imod=remap0[1])
         s1 = T(x1, idiv=remap1[0], imod=remap1[1]) if has_x1 else NULL
         K.conv3x3_bwd_weight(s0, s1, gyT, n, H, W, eng.wgrad_map, dw4, db, accumulate=False)

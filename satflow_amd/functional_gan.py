@@ -617,6 +617,8 @@ class _DvdGruGatesFn(torch.autograd.Function):
               "sf_dvdgru_gates_fwd")
         ctx.hidp, ctx.has = hidp, (gh is not None, h is not None)
         ctx.gslot = gslot   # (GradSlots, frame): where this frame's pre-activation gradient is written
+        if out_rh is not None:
+            ctx.mark_dirty(out_rh)   # written in place and returned (advisor r5)
         ctx.save_for_backward(zr, h if h is not None else gx.new_empty(0))
         ctx.set_materialize_grads(False)
         return zr, rh
@@ -652,6 +654,8 @@ class _DvdGruOutFn(torch.autograd.Function):
               "sf_dvdgru_out_fwd")
         ctx.hidp, ctx.has, ctx.lanes = hidp, (gh is not None, h is not None), gx.shape[-1]
         ctx.gslot = gslot
+        if out is not None:
+            ctx.mark_dirty(out)   # written in place and returned: the Function contract (version bump, in-place checks) - advisor r5
         ctx.save_for_backward(cand, zr, h if h is not None else gx.new_empty(0))
         return hn
 

@@ -214,3 +214,63 @@ def test_param_blocks_equal_cat_of_slices(device, sink):
         assert a.shape == b.shape and torch.equal(a, b)
     for a, b, (name, _) in zip(g_new, g_ref, cell.named_parameters()):
         assert torch.equal(a, b), name
+
+
+def test_a_plain_autograd_pass_closes_the_owner_too(monkeypatch):
+    """Advisor r5 (medium): a backward pass that reaches a registered parameter ONLY through plain autograd operations used to leave its owner open, and the
+    next pass's sink-aware Function then OVERWROTE the accumulated gradient (2 instead of 5).  The tensor hook the sink puts on every registered parameter
+    closes the owner at the end of any pass that produced a gradient for it."""
+    sink, owner, flat_g, (p, q) = _fresh()
+    monkeypatch.setattr(F, "GRAD_SINK", sink)
+    (3.0 * p).sum().backward()
+    assert torch.equal(flat_g[:4], torch.tensor([3.0] * 4))
+    log = []
+    _Double.apply(p, log).sum().backward()
+    assert log == [False], "the second pass must go through autograd (accumulate), not overwrite"
+    assert torch.equal(flat_g[:4], torch.tensor([5.0] * 4))
+    # q was never reached by the first pass - but the owner (one optimizer, one zero_grad) is closed as a whole
+    _Double.apply(q, log).sum().backward()
+    assert log == [False, False] and torch.equal(flat_g[4:], torch.tensor([2.0] * 4))
+
+
+def test_frozen_and_unrequested_parameters_get_no_destination(monkeypatch):
+    """Advisor r5 (medium): a parameter frozen after the optimizer registered it must not receive a gradient in the flat buffer (the optimizer updates the
+    whole buffer); neither must an input whose gradient autograd did not ask for (``needs_input_grad``)."""
+    sink, owner, flat_g, (p, q) = _fresh()
+    monkeypatch.setattr(F, "GRAD_SINK", sink)
+    q.requires_grad_(False)
+    assert sink.dest(q) is None
+    out, ret = F.grad_out(q)
+    assert ret is not None and out.data_ptr() != flat_g[4:].data_ptr()
+    out, ret = F.grad_out(p, needed=False)
+    assert ret is None and out.data_ptr() != flat_g.data_ptr() and torch.equal(flat_g, torch.zeros(8))
+    with F.no_grad_sink():   # every gradient through autograd inside the block (for torch.autograd.grad on registered parameters)
+        assert sink.off and sink.dest(p) is None
+    assert not sink.off
+
+
+def test_a_failed_backward_does_not_leave_the_sink_armed(monkeypatch):
+    """Advisor r5 (low): the engine runs no final callbacks when a backward pass raises; ``reopen()`` (zero_grad) drops the stale pass."""
+    sink, owner, flat_g, (p, q) = _fresh()
+    monkeypatch.setattr(F, "GRAD_SINK", sink)
+
+    class _Boom(torch.autograd.Function):
+        @staticmethod
+        def forward(ctx, x):
+            return x * 1.0
+
+        @staticmethod
+        def backward(ctx, g):
+            raise RuntimeError("boom")
+
+    log = []
+    with pytest.raises(RuntimeError, match="boom"):
+        (_Boom.apply(_Double.apply(p, log)).sum() + _Double.apply(q, log).sum()).backward()
+    flat_g.zero_()
+    sink.reopen(owner)
+    assert not sink._armed and not sink._pass_owners
+    log.clear()
+    _Double.apply(p, log).sum().backward()
+    assert log == [True]
+    _Double.apply(p, log).sum().backward()   # ... and that pass's end closed the owner again
+    assert log == [True, False] and torch.equal(flat_g[:4], torch.tensor([4.0] * 4))
