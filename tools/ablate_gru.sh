@@ -18,8 +18,10 @@ if [ "$1" = build ]; then
 else
   for v in $VARIANTS; do
     echo "== $v"
-    SATFLOW_HIP_LIB=$PWD/tools/ablate/libsatflow_gru_$v.so python tools/probe_gru_seq.py 2>/dev/null | tail -1 | python -c "
+    for n in ${MAPS:-96}; do
+    SATFLOW_HIP_LIB=$PWD/tools/ablate/libsatflow_gru_$v.so python tools/probe_gru_seq.py $n 2>/dev/null | tail -1 | python -c "
 import sys,ast
-d=ast.literal_eval(sys.stdin.read()); print('fwd %.1f us  bwd %.1f us' % (d['fwd_us'], d['bwd_us']))"
+d=ast.literal_eval(sys.stdin.read()); print('$n maps: fwd %.1f us (%.2f us/step)  bwd %.1f us (%.2f us/step)' % (d['fwd_us'], d['fwd_us'] / 24, d['bwd_us'], d['bwd_us'] / 24))"
+    done
   done
 fi
