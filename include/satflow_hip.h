@@ -519,6 +519,8 @@ typedef struct sfBlock {
   const float* src;
   float* dst;
   int64_t rows, cols, src_stride, dst_stride;
+  int64_t transpose; /* (ABI 8) != 0: the block lands TRANSPOSED, dst[c * dst_stride + r] = src[r * src_stride + c] (dst_stride >= rows) - the W^T operand
+                        of an input-gradient GEMM built in the launch that builds W */
 } sfBlock;
 int sf_copy_blocks(const sfBlock* blocks, int32_t n, sfStream stream);
 

@@ -15,7 +15,9 @@ __global__ __launch_bounds__(256) void copy_blocks_kernel(const BlockTable t) {
   const long long stride = (long long)gridDim.x * blockDim.x;
   for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += stride) {
     const long long r = i / b.cols, c = i - r * b.cols;
-    b.dst[r * b.dst_stride + c] = b.src ? b.src[r * b.src_stride + c] : 0.0f;
+    const float v = b.src ? b.src[r * b.src_stride + c] : 0.0f;
+    if (b.transpose) b.dst[c * b.dst_stride + r] = v;   // (block-uniform; reads stay coalesced, the strided writes are a few KB of weights)
+    else b.dst[r * b.dst_stride + c] = v;
   }
 }
 
@@ -29,7 +31,7 @@ extern "C" int sf_copy_blocks(const sfBlock* blocks, int32_t n, sfStream stream)
     long long biggest = 0;
     for (int i = 0; i < m; ++i) {
       const sfBlock& b = blocks[i0 + i];
-      SF_REQUIRE(b.dst && b.rows >= 0 && b.cols >= 0 && b.dst_stride >= b.cols && (!b.src || b.src_stride >= b.cols),
+      SF_REQUIRE(b.dst && b.rows >= 0 && b.cols >= 0 && b.dst_stride >= (b.transpose ? b.rows : b.cols) && (!b.src || b.src_stride >= b.cols),
                  "sf_copy_blocks: block %d: rows %lld, cols %lld, strides %lld / %lld", i0 + i, (long long)b.rows, (long long)b.cols,
                  (long long)b.src_stride, (long long)b.dst_stride);
       t.b[i] = b;

@@ -146,10 +146,11 @@ def _copy_blocks(blocks) -> None:
     if not blocks:
         return
     arr = (sfBlock * len(blocks))()
-    for k, (src, sr, sc, sw, dst, dr, dc, dw, rows, cols) in enumerate(blocks):
+    for k, (src, sr, sc, sw, dst, dr, dc, dw, rows, cols, *tr) in enumerate(blocks):   # (an 11th entry True: the block lands transposed at (dr, dc))
         arr[k].src = (src.data_ptr() + 4 * (sr * sw + sc)) if src is not None else None
         arr[k].dst = dst.data_ptr() + 4 * (dr * dw + dc)
         arr[k].rows, arr[k].cols, arr[k].src_stride, arr[k].dst_stride = rows, cols, sw, dw
+        arr[k].transpose = 1 if tr and tr[0] else 0
     check(lib().sf_copy_blocks(arr, len(blocks), stream_ptr()), "sf_copy_blocks")
 
 
@@ -909,6 +910,75 @@ class _AttnCoreFn(torch.autograd.Function):
 
 def attention_core(qkv: Tensor, hid: int, heads: int) -> Tensor:
     return _AttnCoreFn.apply(qkv, hid, heads)
+
+
+class _AxialLayerFn(torch.autograd.Function):
+    """One axial-attention layer (lucidrains ``AxialAttention(dim, heads, num_dimensions=2, sum_axial_out=True)`` as MetNet uses it) as ONE
+    autograd node: q | k | v projections of both axes in one GEMM, the attention core, the two output projections in one GEMM, summed.
+
+    Round 6: the same launches were five nested ``Function``s (parameter blocks, linear, core, linear + a torch add); at 96 maps of
+    16 x 16 the layer's forward + backward is ~230 us of device time, and the host needed 460 us to enqueue it (tools/probe_axial_host.py:
+    autograd-node and Python overhead per launch, not the kernels).  Here the host makes the library calls back to back; results are those of
+    the nested form bit for bit (``tests/test_metnet_gpu.py::test_axial_layer_single_node_equals_nested``).  Lanes must be unpadded (hid % 16 == 0)."""
+
+    @staticmethod
+    def forward(ctx, x: Tensor, q0: Tensor, kv0: Tensor, q1: Tensor, kv1: Tensor, o0: Tensor, b0: Tensor, o1: Tensor, b1: Tensor, hid: int, heads: int):
+        dev = x.device
+        # one buffer: w_in [6h, h] rows [q0 ; k0 | v0 ; q1 ; k1 | v1], w_out [h, 2h] columns [o0 | o1] and - for the backward pass's input-gradient GEMMs -
+        # their transposes w_in_t [h, 6h], w_out_t [2h, h], all written by ONE sf_copy_blocks launch
+        keep = any(ctx.needs_input_grad)
+        wbuf = torch.empty((16 if keep else 8) * hid * hid, dtype=torch.float32, device=dev)
+        w_in, w_out = wbuf[: 6 * hid * hid].view(6 * hid, hid), wbuf[6 * hid * hid: 8 * hid * hid].view(hid, 2 * hid)
+        blocks = [(q0, 0, 0, hid, w_in, 0, 0, hid, hid, hid), (kv0, 0, 0, hid, w_in, hid, 0, hid, 2 * hid, hid),
+                  (q1, 0, 0, hid, w_in, 3 * hid, 0, hid, hid, hid), (kv1, 0, 0, hid, w_in, 4 * hid, 0, hid, 2 * hid, hid),
+                  (o0, 0, 0, hid, w_out, 0, 0, 2 * hid, hid, hid), (o1, 0, 0, hid, w_out, 0, hid, 2 * hid, hid, hid)]
+        if keep:
+            w_in_t, w_out_t = wbuf[8 * hid * hid: 14 * hid * hid].view(hid, 6 * hid), wbuf[14 * hid * hid:].view(2 * hid, hid)
+            blocks += [(q0, 0, 0, hid, w_in_t, 0, 0, 6 * hid, hid, hid, True), (kv0, 0, 0, hid, w_in_t, 0, hid, 6 * hid, 2 * hid, hid, True),
+                       (q1, 0, 0, hid, w_in_t, 0, 3 * hid, 6 * hid, hid, hid, True), (kv1, 0, 0, hid, w_in_t, 0, 4 * hid, 6 * hid, 2 * hid, hid, True),
+                       (o0, 0, 0, hid, w_out_t, 0, 0, hid, hid, hid, True), (o1, 0, 0, hid, w_out_t, hid, 0, hid, hid, hid, True)]
+        _copy_blocks(blocks)
+        bsum = b0 + b1
+        qkv = K.linear_fwd(x, w_in, None, 6 * hid)
+        att = K.attention_core_fwd(qkv, hid, heads)   # [n, h, w, 2 * hid] = [axis 0 | axis 1]
+        y = K.linear_fwd(att, w_out, bsum, hid)
+        ctx.meta = (hid, heads)
+        ctx.params = (q0, kv0, q1, kv1, o0, b0, o1, b1)   # (for the gradient sink: identity of the parameters)
+        if keep:
+            ctx.save_for_backward(x, qkv, att, w_in_t, w_out_t)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy: Tensor):
+        x, qkv, att, w_in_t, w_out_t = ctx.saved_tensors
+        hid, heads = ctx.meta
+        q0, kv0, q1, kv1, o0, b0, o1, b1 = ctx.params
+        gy = gy.contiguous()
+        dev = gy.device
+        need = ctx.needs_input_grad
+        # output projections: d att = gy @ w_out, d w_out = gy^T att, d bias = column sums of gy (both axes' biases receive it)
+        datt = K.linear_fwd(gy, w_out_t, None, 2 * hid)
+        dw_out = torch.empty(hid, 2 * hid, dtype=torch.float32, device=dev)
+        (db0, db0_ret), (db1, db1_ret) = grad_out(b0, needed=need[6]), grad_out(b1, needed=need[8])
+        K.linear_bwd_weight(gy, att, hid, True, out=(dw_out, db0))
+        dqkv = K.attention_core_bwd(qkv, datt, hid, heads)
+        dx = K.linear_fwd(dqkv, w_in_t, None, hid) if need[0] else None
+        dw_in = torch.empty(6 * hid, hid, dtype=torch.float32, device=dev)
+        K.linear_bwd_weight(dqkv, x, 6 * hid, False, out=(dw_in, None))
+        outs = [grad_out(p, needed=need[i]) for p, i in ((q0, 1), (kv0, 2), (q1, 3), (kv1, 4), (o0, 5), (o1, 7))]
+        (dq0, _), (dkv0, _), (dq1, _), (dkv1, _), (do0, _), (do1, _) = outs
+        _copy_blocks([(dw_in, 0, 0, hid, dq0, 0, 0, hid, hid, hid), (dw_in, hid, 0, hid, dkv0, 0, 0, hid, 2 * hid, hid),
+                      (dw_in, 3 * hid, 0, hid, dq1, 0, 0, hid, hid, hid), (dw_in, 4 * hid, 0, hid, dkv1, 0, 0, hid, 2 * hid, hid),
+                      (dw_out, 0, 0, 2 * hid, do0, 0, 0, hid, hid, hid), (dw_out, 0, hid, 2 * hid, do1, 0, 0, hid, hid, hid),
+                      (db0, 0, 0, hid, db1, 0, 0, hid, 1, hid)])   # (the second bias gradient = the first)
+        r = [o[1] for o in outs]
+        return dx, r[0], r[1], r[2], r[3], r[4], db0_ret, r[5], db1_ret, None, None
+
+
+def axial_layer(x: Tensor, a0, a1, hid: int, heads: int) -> Tensor:
+    """``a0`` / ``a1``: the two axes' ``SelfAttention`` parameter containers (``to_q``, ``to_kv``, ``to_out``)."""
+    return _AxialLayerFn.apply(x, a0.to_q.weight, a0.to_kv.weight, a1.to_q.weight, a1.to_kv.weight, a0.to_out.weight, a0.to_out.bias,
+                               a1.to_out.weight, a1.to_out.bias, hid, heads)
 
 
 # ----------------------------------------------------------------------------------------------

@@ -244,6 +244,8 @@ class AxialAttention(nn.Module):
             w = w.view(parts, hid, w.shape[1])
             return torch.nn.functional.pad(w, (0, 0, 0, hidp - hid)).reshape(parts * hidp, -1)
 
+        if hid == hidp and x.is_cuda and x.dtype == torch.float32 and not os.environ.get("SF_AXIAL_NESTED") and not os.environ.get("SF_NO_PARAM_BLOCKS"):
+            return F.axial_layer(x.contiguous(), a0, a1, hid, self.heads)   # one autograd node (round 6; SF_AXIAL_NESTED=1: the nested form below)
         if hid == hidp and x.is_cuda and not os.environ.get("SF_NO_PARAM_BLOCKS"):
             # both projection matrices (and all six weight gradients) in one sf_copy_blocks launch each way
             params = (a0.to_q.weight, a0.to_kv.weight, a1.to_q.weight, a1.to_kv.weight, a0.to_out.weight, a1.to_out.weight)

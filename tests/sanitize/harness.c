@@ -125,6 +125,8 @@ int main(void) {
   { sfBlock bad = {ok, ok, 4, 8, 4, 8};   /* source rows narrower than the block */
     REFUSED(sf_copy_blocks(&bad, 1, st));
     REFUSED(sf_copy_blocks(0, 1, st));     /* no table */
+    sfBlock trbad = {ok, ok, 8, 4, 4, 4, 1};   /* transposed landing: the destination rows (stride 4) are narrower than the block's 8 rows */
+    REFUSED(sf_copy_blocks(&trbad, 1, st));
     sfBlock nodst = {ok, 0, 4, 8, 8, 8};
     REFUSED(sf_copy_blocks(&nodst, 1, st)); }
   REFUSED(sf_dropout2_bf16(ok, 60, 0.1f, 0.1f, 64, 1, 2, ok, st));                                   /* n not a multiple of 8 */

@@ -397,3 +397,45 @@ def test_space_to_depth_channel_order_switch(device):
         assert_close(dict(m.named_parameters())[k1].grad, Pn[k1].grad, f"d conv1.weight, {name} order", grad=True)
         outs[name] = got.detach().cpu()
     assert (outs["einops"] - outs["pixel_unshuffle"]).abs().max() > 1e-3, "the two channel orders must give different results for the same weights"
+
+
+@pytest.mark.parametrize("n,hid,h,w", [(96, 64, 16, 16), (3, 32, 4, 6), (1, 16, 2, 2)])
+def test_axial_layer_single_node_equals_nested(device, n, hid, h, w, monkeypatch):
+    """Round 6: the axial-attention layer as ONE autograd node (``functional._AxialLayerFn``) issues the launches of the nested form (parameter blocks ->
+    linear -> attention core -> linear + bias sum) on the same operands: output, input gradient and all eight parameter gradients bit for bit, with and
+    without an optimizer's gradient sink behind the parameters, and with a frozen parameter left untouched."""
+    from satflow_amd.models.metnet import AxialAttention
+    from satflow_amd.optim import FlatAdam
+
+    torch.manual_seed(hid + n)
+    x = torch.randn(n, h, w, hid, generator=_g(41))
+    cot = torch.randn(n, h, w, hid, generator=_g(42))
+
+    def run(nested, sink, freeze=None):
+        monkeypatch.setenv("SF_AXIAL_NESTED", "1") if nested else monkeypatch.delenv("SF_AXIAL_NESTED", raising=False)
+        torch.manual_seed(5)
+        layer = AxialAttention(hid).to(device)
+        if freeze:
+            dict(layer.named_parameters())[freeze].requires_grad_(False)
+        opt = FlatAdam([p for p in layer.parameters()], lr=1e-3) if sink else None
+        if opt is not None:
+            opt.zero_grad()
+        xd = x.to(device).requires_grad_()
+        y = layer.run(xd)
+        (y * cot.to(device)).sum().backward()
+        grads = {k: (p.grad.detach().clone() if p.grad is not None else None) for k, p in layer.named_parameters()}
+        return y.detach(), xd.grad.detach(), grads, opt
+
+    y0, dx0, g0, _ = run(True, False)
+    for sink in (False, True):
+        y1, dx1, g1, opt = run(False, sink)
+        assert torch.equal(y1, y0) and torch.equal(dx1, dx0)
+        for k in g0:
+            assert torch.equal(g1[k], g0[k]), (k, sink)
+    # a frozen parameter: no gradient, and with the sink its slice of the optimizer's buffer stays zero
+    k_frozen = "axial_attentions.1.fn.to_kv.weight"
+    y2, dx2, g2, opt = run(False, True, freeze=k_frozen)
+    assert torch.equal(y2, y0) and torch.equal(dx2, dx0) and g2[k_frozen] is None
+    for k in g0:
+        if k != k_frozen:
+            assert torch.equal(g2[k], g0[k]), k
