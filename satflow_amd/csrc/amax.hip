@@ -19,12 +19,14 @@ __global__ __launch_bounds__(256) void amax_kernel(const float* __restrict__ t, 
   for (long long e = (long long)blockIdx.x * blockDim.x + threadIdx.x; e < total; e += (long long)gridDim.x * blockDim.x) {
     const long long px = e / quads;
     const int q = (int)(e - px * quads);
-    const f32x4 v = *reinterpret_cast<const f32x4*>(t + px * stride + 4 * q);
-#pragma unroll
-    for (int k = 0; k < 4; ++k) {
-      const unsigned b = __builtin_bit_cast(unsigned, v[k]) & 0x7fffffffu;
-      m = b > m ? b : m;
-    }
+    // (explicit components of an integer vector: with `__builtin_bit_cast(unsigned, v[k])` on a float vector in an unrolled loop hipcc 7.2 kept
+    // component 0 only - found by tests/test_f32e_gpu.py::test_amax_word)
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    const u32x4 v = *reinterpret_cast<const u32x4*>(t + px * stride + 4 * q);
+    const unsigned a0 = v.x & 0x7fffffffu, a1 = v.y & 0x7fffffffu, a2 = v.z & 0x7fffffffu, a3 = v.w & 0x7fffffffu;
+    const unsigned m01 = a0 > a1 ? a0 : a1, m23 = a2 > a3 ? a2 : a3;
+    const unsigned mq = m01 > m23 ? m01 : m23;
+    m = mq > m ? mq : m;
   }
 #pragma unroll
   for (int off = 32; off >= 1; off >>= 1) {

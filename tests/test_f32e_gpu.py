@@ -1,0 +1,133 @@
+"""GPU: the "f32e" compute mode on its own (round 6) - fp32-equivalent 3x3 convolutions from three fp16 MFMA products (include/satflow_hip.h SF_F32E,
+conv3x3_f32e.hip / conv3x3_wgrad_f32e.hip).  The fp32-gated tests of the other modules all run in this mode too (conftest.FP32_GATED); here: the kernels
+against float64 of the UNROUNDED operands across operand magnitudes (what the split + the per-tensor gradient scale are for), the scale word itself, and
+the loud failure past fp16's range."""
+import pytest
+import torch
+import torch.nn.functional as TF
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _f32e():
+    import satflow_amd
+
+    satflow_amd.set_compute_dtype("f32e")
+    yield
+    satflow_amd.set_compute_dtype("f32")
+
+
+def _conv_case(device, cin, cout, n, h, w, xs=1.0, ws=1.0, gs=1.0, seed=0):
+    """conv3x3 forward + backward through the product path; float64 reference of the unrounded fp32 operands.  Returns relative L2 errors."""
+    from satflow_amd.functional import ConvEngine, conv3x3, nchw_to_nhwc, nhwc_to_nchw
+
+    g = torch.Generator().manual_seed(seed + cin * 131 + cout)
+    x = torch.randn(n, cin, h, w, generator=g) * xs
+    wt = torch.randn(cout, cin, 3, 3, generator=g) * (ws / (3 * cin ** 0.5))
+    b = torch.randn(cout, generator=g) * xs * ws
+    cot = torch.randn(n, cout, h, w, generator=g) * gs
+    xr, wr, br = (t.double().requires_grad_() for t in (x, wt, b))
+    ref = TF.conv2d(xr, wr, br, padding=1)
+    (ref * cot.double()).sum().backward()
+    xd, wd, bd = (t.to(device).requires_grad_() for t in (x, wt, b))
+    y = nhwc_to_nchw(conv3x3(ConvEngine([cin], cout), nchw_to_nhwc(xd), wd, bd), cout)
+    (y * cot.to(device)).sum().backward()
+    return {"y": rel_l2(y.double().cpu(), ref), "dx": rel_l2(xd.grad.double().cpu(), xr.grad), "dW": rel_l2(wd.grad.double().cpu(), wr.grad),
+            "db": rel_l2(bd.grad.double().cpu(), br.grad)}, y
+
+
+@pytest.mark.parametrize("cin,cout,n,h,w", [(16, 32, 2, 16, 16), (12, 5, 1, 7, 9), (64, 160, 2, 20, 33), (256, 256, 4, 32, 32), (128, 96, 3, 16, 16)])
+def test_conv_against_float64(device, cin, cout, n, h, w):
+    """Forward, input gradient, weight gradient, bias gradient at O(1) operands: every one within 2e-6 relative L2 of float64 (the exact-fp32 kernels
+    are at 1e-7 .. 5e-7 here; three fp16 products leave ~2^-22 per product)."""
+    err, _ = _conv_case(device, cin, cout, n, h, w)
+    assert max(err.values()) < 2e-6, err
+
+
+@pytest.mark.parametrize("gs", [1e-12, 1e-7, 1e-3, 1.0, 1e4, 1e9])
+def test_gradient_operands_are_scaled_into_range(device, gs):
+    """The output gradient of a real training step is ~1e-7 (an MSE mean over 10^7 elements) - below fp16's normal range - and a random cotangent of a test
+    is O(1) or larger.  The kernels scale a gradient operand by the power of two that puts its amax word (sf_amax / sfTensor.amax) at 2^14 and undo it
+    on the accumulators: the relative error of dx and dW does not depend on the gradient's magnitude over 21 orders of magnitude."""
+    err, _ = _conv_case(device, 64, 96, 2, 24, 24, gs=gs, seed=3)
+    assert err["dx"] < 2e-6 and err["dW"] < 2e-6 and err["db"] < 2e-6, (gs, err)
+
+
+@pytest.mark.parametrize("xs,ws", [(1e-3, 1.0), (1.0, 1e-2), (30.0, 4.0), (1e3, 1.0)])
+def test_forward_operand_magnitudes(device, xs, ws):
+    """Forward activations and weights go in unscaled (hi = fp16(x) is normal for |x| in 6e-5 .. 65504, the scaled low part recovers 11 more bits below that
+    gracefully): O(1e-3) .. O(1e3) activations, saturating-gate-sized weights."""
+    err, _ = _conv_case(device, 48, 64, 2, 16, 16, xs=xs, ws=ws, seed=5)
+    assert err["y"] < 2e-6 and err["dx"] < 2e-6 and err["dW"] < 2e-6, (xs, ws, err)
+
+
+def test_out_of_range_activation_is_loud(device):
+    """|x| >= 65520 overflows fp16: the mode does not clamp silently - the affected outputs are non-finite (NaN / inf), which the training loops' loss
+    checks and `check_device_errors` users see; the exact-fp32 mode is the tool for such data."""
+    from satflow_amd.functional import ConvEngine, conv3x3
+
+    x = torch.randn(1, 8, 8, 16, device=device)
+    x[0, 3, 4, 2] = 1.0e5
+    w = torch.randn(16, 16, 3, 3, device=device) * 0.1
+    y = conv3x3(ConvEngine([16], 16), x, w, None)
+    assert not torch.isfinite(y[0, 2:5, 3:6]).all() and torch.isfinite(y[0, 6:, :]).all()
+
+
+@pytest.mark.parametrize("shape,stride", [((3, 5, 7, 16), 16), ((2, 9, 4, 32), 48), ((1, 1, 1, 4), 4)])
+def test_amax_word(device, shape, stride):
+    """sf_amax: max |t| of an NHWC channel slice (stride > channels: the lanes beyond are not read), the accumulating second word, zero for zeros."""
+    from satflow_amd._hip import T, check, lib, stream_ptr
+
+    torch.manual_seed(shape[-1] + stride)
+    full = torch.randn(*shape[:-1], stride, device=device) * 7.0
+    full[..., shape[-1]:] = 1e6   # outside the slice
+    t = T(full, c=shape[-1])
+    word, acc = torch.full((1,), -1.0, device=device), torch.full((1,), 123.0, device=device)
+    check(lib().sf_amax(t, full.numel() // stride, word.data_ptr(), acc.data_ptr(), 1, stream_ptr()), "sf_amax")
+    want = float(full[..., : shape[-1]].abs().max())
+    assert float(word) == want and float(acc) == want
+    check(lib().sf_amax(T(torch.zeros_like(full), c=shape[-1]), full.numel() // stride, word.data_ptr(), acc.data_ptr(), 0, stream_ptr()), "sf_amax")
+    assert float(word) == 0.0 and float(acc) == want   # the accumulator keeps the larger value when it is not reset
+
+
+def test_lstm_gate_backward_raises_the_scale_word(device):
+    """sf_convlstm_cell_bwd_gates with dz.amax: the word (zeroed by the caller) ends at max |dz| - what sf_amax would have computed in a second pass."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import NULL, T
+
+    n, hid = 2 * 12 * 12, 32
+    g = torch.Generator().manual_seed(11)
+    mk = lambda c: torch.randn(n, c, generator=g).to(device)
+    dh, dc, gates, cp, cn = mk(hid), mk(hid), torch.sigmoid(mk(4 * hid)), mk(hid), mk(hid)
+    dz, dcp = torch.empty(n, 4 * hid, device=device), torch.empty(n, hid, device=device)
+    word = torch.zeros(1, device=device)
+    K.convlstm_cell_bwd_gates([T(dh)], T(dc), T(gates), T(cp), T(cn), n, hid, T(dz, amax=word), T(dcp))
+    assert float(word) == float(dz.abs().max()) > 0
+
+
+def test_f32e_tracks_f32_on_a_recurrent_stack(device):
+    """Twelve recurrent steps (errors compound through the gates): predictions and every parameter gradient of the ConvLSTM encoder-decoder in "f32e" within
+    1e-5 relative L2 of the exact-fp32 mode on the same weights (hot weights: saturating gates)."""
+    import satflow_amd
+    from satflow_amd.models import EncoderDecoderConvLSTM
+
+    torch.manual_seed(3)
+    m = EncoderDecoderConvLSTM(hidden_dim=32, input_channels=6, out_channels=3, forecast_steps=4).to(device)
+    with torch.no_grad():
+        for k, p in m.named_parameters():
+            p.mul_(4.0) if p.dim() > 1 else p.uniform_(-1, 1)
+    x = torch.randn(2, 8, 6, 32, 32, device=device)
+    cot = torch.randn(2, 3, 4, 32, 32, device=device)
+    res = {}
+    for mode in ("f32", "f32e"):
+        satflow_amd.set_compute_dtype(mode)
+        m.zero_grad()
+        y = m(x, 4)
+        (y * cot).sum().backward()
+        res[mode] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in m.named_parameters()})
+    assert rel_l2(res["f32e"][0], res["f32"][0]) < 1e-5
+    for k, gref in res["f32"][1].items():
+        assert rel_l2(res["f32e"][1][k], gref) < 1e-5, k
