@@ -33,7 +33,7 @@ if ROOT not in sys.path:
 PEAK_F32_TFLOPS = 157.3   # MI355X fp32 matrix/vector peak (MI355X_MICROARCH.md)
 PEAK_BF16_TFLOPS = 2500.0  # dense bf16 MFMA peak (MI355X_MICROARCH.md; the 5 PF headline includes 2:1 sparsity)
 PEAK_HBM_GBPS = 8000.0
-PROFILE_ROUND = "r05"        # prefix of the sha-stamped PMC / parity records under profiles/ this file reads
+PROFILE_ROUND = "r06"        # prefix of the sha-stamped PMC / parity records under profiles/ this file reads
 
 
 def event_time(fn, iters: int, warm: int = 3) -> float:

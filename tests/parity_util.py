@@ -8,7 +8,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def publish(record: dict, name: str = "r05_parity_observed.jsonl") -> None:
+def publish(record: dict, name: str = "r06_parity_observed.jsonl") -> None:
     """Append one observed-error record ("publish the observed figure") under gpurun_out/ and print it."""
     os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
     with open(os.path.join(ROOT, "gpurun_out", name), "a") as f:

@@ -84,7 +84,7 @@ def test_cfg2_convlstm_train_step_fullsize_f32(device):
         assert_close(g, R["grads"][k], f"cfg2 d{k}", grad=True, force_rel=True)
     assert_close(loss, R["loss"], "cfg2 train/loss", rtol=1e-5, atol=1e-7)
     assert_close(frames, R["frames"], "cfg2 frame losses", rtol=1e-5, atol=1e-7)
-    publish({"config": "configs[1] ConvLSTM 12ch 128x128 T=12->6 hid 64, B=2, train step", "mode": "f32",
+    publish({"config": "configs[1] ConvLSTM 12ch 128x128 T=12->6 hid 64, B=2, train step", "mode": satflow_amd.compute_dtype_name(),
              "pred_max_abs": float((pred - R["pred"]).abs().max()), "pred_rel_l2": rel_l2(pred, R["pred"]),
              "worst_grad_rel_l2": max(rel_l2(g, R["grads"][k]) for k, g in grads.items()), "dx_rel_l2": rel_l2(dx, R["dx"])})
 
@@ -175,7 +175,7 @@ def test_cfg3_metnet_train_step_fullsize_f32(device):
         assert_close(p.grad, G[k], f"cfg3 d{k}", grad=True)
         r = rel_l2(p.grad, G[k])
         worst = max(worst, (k, r), key=lambda t: t[1])
-    publish({"config": "configs[2] MetNet 12ch 256x256 T=24->12 hid 64, B=2, train step (BN train mode, dropout off)", "mode": "f32",
+    publish({"config": "configs[2] MetNet 12ch 256x256 T=24->12 hid 64, B=2, train step (BN train mode, dropout off)", "mode": satflow_amd.compute_dtype_name(),
              "out_max_abs": float((out.detach().cpu() - ref).abs().max()), "out_rel_l2": rel_l2(out, ref), "worst_grad": worst[0],
              "worst_grad_rel_l2": worst[1]})
 
@@ -232,7 +232,7 @@ def test_cfg3_metnet_train_step_fullsize_f32_with_dropout(device):
         assert_close(p.grad, gk, f"cfg3+dropout d{k}", grad=True)
         worst = max(worst, (k, rel_l2(p.grad, gk)), key=lambda t: t[1])
     publish({"config": "configs[2] MetNet 12ch 256x256 T=24->12 hid 64, B=2, train step, temporal_dropout 0.2 + ConvGRU input dropout (masks replayed)",
-             "mode": "f32", "out_rel_l2": rel_l2(out, ref.detach()), "worst_grad": worst[0], "worst_grad_rel_l2": worst[1], "keep_fraction": keep})
+             "mode": satflow_amd.compute_dtype_name(), "out_rel_l2": rel_l2(out, ref.detach()), "worst_grad": worst[0], "worst_grad_rel_l2": worst[1], "keep_fraction": keep})
 
 
 def test_cfg3_metnet_train_step_fullsize_bf16a(device):

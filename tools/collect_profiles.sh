@@ -2,8 +2,8 @@
 # After tools/refresh_profiles.sh (gpurun): copy the judged summaries from gpurun_out/ into profiles/ (tracked).
 set -u
 cd "$(dirname "$0")/.."
-R=${ROUND:-r05}
-for m in bf16a bf16 f32; do for w in metnet convlstm; do
+R=${ROUND:-r06}
+for m in bf16a bf16 f32 f32e; do for w in metnet convlstm; do
   d=gpurun_out/${R}_${w}_$m
   [ -f $d/prof_kernel_stats.csv ] && cp $d/prof_kernel_stats.csv profiles/${R}_${w}_${m}_kernel_stats.csv
   [ -s $d/bench.json ] && cp $d/bench.json profiles/${R}_${w}_${m}_bench.json

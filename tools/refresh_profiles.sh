@@ -3,8 +3,8 @@
 # Results under gpurun_out/${ROUND}_*; tools/collect_profiles.sh copies the summaries into profiles/.
 set -u
 cd $GRAFT_REPO_ROOT
-R=${ROUND:-r05}
-for m in bf16a bf16 f32; do
+R=${ROUND:-r06}
+for m in bf16a bf16 f32 f32e; do
   bash tools/prof_stats.sh ${R}_metnet_$m --dtype $m --no-cpu-baseline --no-extra > /dev/null 2>&1
   bash tools/prof_stats.sh ${R}_convlstm_$m --workload convlstm --dtype $m --no-cpu-baseline > /dev/null 2>&1
 done
@@ -26,5 +26,5 @@ python bench.py --workload stlstm --dtype f32 --steps 10 --warmup 3 --no-extra -
 SF_NO_GRAPH=1 bash tools/prof_stats.sh ${R}_dgmr_bf16 --workload dgmr --dtype bf16 --steps 3 --warmup 1 --no-cpu-baseline > /dev/null 2>&1
 timeout 900 python bench.py --workload dgmr --dtype bf16 --steps 5 --warmup 2 > gpurun_out/${R}_dgmr_bench_full.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
 timeout 900 python bench.py --workload dgmr --dtype f16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${R}_dgmr_f16_bench.json 2>> gpurun_out/${R}_metnet_bf16a_bench_full.err
-for m in bf16a bf16 f32; do for w in metnet convlstm; do cut -c1-200 gpurun_out/${R}_${w}_$m/bench.json; done; done
+for m in bf16a bf16 f32 f32e; do for w in metnet convlstm; do cut -c1-200 gpurun_out/${R}_${w}_$m/bench.json; done; done
 cut -c1-300 gpurun_out/${R}_metnet_bf16a_bench_full.json
