@@ -1060,7 +1060,10 @@ def timed_steps(wl, steps: int, warmup: int, world: int, dev, sync, pause_gc: bo
         t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    return elapsed, float(loss.item())
+    lv = float(loss.item())
+    if lv != lv or lv in (float("inf"), float("-inf")):   # (every timed figure of this file: a step on NaN operands is not the workload, see main())
+        raise RuntimeError(f"bench.py: non-finite loss ({lv}) after the timed steps - measurement invalid")
+    return elapsed, lv
 
 
 def _free_port() -> int:
@@ -1215,6 +1218,8 @@ def main(argv=None):
             wl.graphed, wl.graph_note = False, f"eager (capture failed: {type(e).__name__}: {str(e)[:200]})"
     elapsed, final_loss = timed_steps(wl, args.steps, args.warmup, world, dev, sync)
     event_ms = getattr(timed_steps, "last_event_ms", None)
+    # (timed_steps raises on a non-finite loss: a step on NaN / inf operands is NOT the workload - and runs faster, the matrix pipes draw less power
+    # on such data: round 6 measured a NaN MetNet step 17 % "faster" than the real one before this check existed.  No line, non-zero exit.)
 
     out = None
     if rank == 0:

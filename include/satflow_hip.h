@@ -469,7 +469,9 @@ size_t sf_convgru_seq_bwd_workspace_bytes(int32_t n, int32_t h, int32_t hidp);
  * convgru_seq.hip a second time with -DSF_TEST_HOOKS for the failure-path test.) */
 /* Pointwise backward of the step: dh = dh0+dh1+dh2 -> dgx = [da_z|da_r|da_n], dgh = [da_z|da_r|dh2],
  * dh_direct = dh*z (nullable).  gates, and dgx / dgh (alike), may each be SF_BF16-stored: the two gradients are only ever
- * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight. */
+ * read as bf16 MFMA operands by sf_conv3x3_fwd / sf_conv3x3_bwd_weight.
+ * (ABI 8) dgx.amax / dgh.amax (nullable, fp32-stored gradients): device words this launch RAISES to max |dgx| / max |dgh| (atomic maximum; the caller zeroes
+ * them - one word may serve all steps of a sequence) - the SF_F32E kernels' scale words (sfTensor.amax) without sf_amax's extra pass. */
 int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sfTensor gates, sfTensor h_prev,
                          int64_t pixels, int32_t hidp, sfTensor dgx, sfTensor dgh,
                          sfTensor dh_direct, int32_t dtype, sfStream stream);

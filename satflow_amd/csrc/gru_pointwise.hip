@@ -17,6 +17,7 @@ struct GruBwdParams {
   void* dgh; int s_dgh;
   float* dh_direct; int s_dd;
   long long pixels; int hidp;
+  unsigned* amax_gx; unsigned* amax_gh;   // (nullable; SF_F32E: dgx.amax / dgh.amax) raised to max |dgx| / max |dgh| of this launch; reset by the caller
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -28,6 +29,7 @@ template <typename TG, typename TD>
 __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p) {
   const int q = p.hidp >> 2;
   const long long total = p.pixels * q;
+  float mx = 0.f, mh = 0.f;   // largest |dgx| / |dgh| element this thread wrote
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long pix = idx / q;
     const int c = (int)(idx - pix * q) * 4;
@@ -44,11 +46,31 @@ __global__ __launch_bounds__(256) void gru_bwd_gates_kernel(const GruBwdParams p
       const sfGruBwd o = sf_gru_bwd(dh[j], z[j], r[j], n[j], h2[j], hp[j]);
       az[j] = o.az; ar[j] = o.ar; an[j] = o.an; d2[j] = o.d2; dd[j] = o.dd;
     }
+    if (p.amax_gx || p.amax_gh) {   // kernel-uniform
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float zr = fmaxf(fabsf(az[j]), fabsf(ar[j]));
+        mx = fmaxf(mx, fmaxf(zr, fabsf(an[j])));
+        mh = fmaxf(mh, fmaxf(zr, fabsf(d2[j])));
+      }
+    }
     TD* a = reinterpret_cast<TD*>(p.dgx) + pix * p.s_dgx + c;
     stv4(a, az); stv4(a + p.hidp, ar); stv4(a + 2 * p.hidp, an);
     TD* b = reinterpret_cast<TD*>(p.dgh) + pix * p.s_dgh + c;
     stv4(b, az); stv4(b + p.hidp, ar); stv4(b + 2 * p.hidp, d2);
     if (p.dh_direct) st4(p.dh_direct + pix * p.s_dd + c, dd);
+  }
+  if (p.amax_gx || p.amax_gh) {   // at most one atomic maximum per wave and word, skipped once the word covers it (lstm_pointwise.hip)
+    unsigned bx = __builtin_bit_cast(unsigned, mx), bh = __builtin_bit_cast(unsigned, mh);
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned ox = (unsigned)__shfl_xor((int)bx, off), oh = (unsigned)__shfl_xor((int)bh, off);
+      bx = ox > bx ? ox : bx; bh = oh > bh ? oh : bh;
+    }
+    if ((threadIdx.x & 63) == 0) {
+      if (p.amax_gx && bx > __atomic_load_n(p.amax_gx, __ATOMIC_RELAXED)) atomicMax(p.amax_gx, bx);
+      if (p.amax_gh && bh > __atomic_load_n(p.amax_gh, __ATOMIC_RELAXED)) atomicMax(p.amax_gh, bh);
+    }
   }
 }
 
@@ -76,6 +98,9 @@ extern "C" int sf_convgru_bwd_gates(sfTensor dh0, sfTensor dh1, sfTensor dh2, sf
   p.dgh = dgh.ptr; p.s_dgh = dgh.stride;
   p.dh_direct = (float*)dh_direct.ptr; p.s_dd = dh_direct.stride;
   p.pixels = pixels; p.hidp = hidp;
+  SF_REQUIRE((!dgx.amax && !dgh.amax) || (dgx.dtype == SF_F32 && (((uintptr_t)dgx.amax | (uintptr_t)dgh.amax) & 3) == 0),
+             "gru bwd_gates: dgx.amax / dgh.amax go with fp32-stored gradients (4-byte aligned words)");
+  p.amax_gx = (unsigned*)dgx.amax; p.amax_gh = (unsigned*)dgh.amax;
   const long long total = pixels * (hidp / 4);
   if (total == 0) return 0;
   const int blocks = (int)((total + 255) / 256 < 8192 ? (total + 255) / 256 : 8192);

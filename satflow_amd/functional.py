@@ -1078,6 +1078,8 @@ class _ConvGRUSeqFn(torch.autograd.Function):
             carry = torch.empty(n, H, W, hidp, dtype=torch.float32, device=dev)   # conv^T(dgh) of the step above
         zeros = None
         have_carry = False
+        # "f32e" mode, per-step route: scale words raised by the gate kernel - [0] max |dgx| over the whole sequence, [1 + t] max |dgh[t]|
+        words = K.scale_words(1 + Tn, dev) if steps and dgx.dtype == torch.float32 else None
         for t in steps:
             src: List[sfTensor] = []
             if g_seq is not None:
@@ -1091,22 +1093,27 @@ class _ConvGRUSeqFn(torch.autograd.Function):
                 src = [T(zeros)]
             if len(src) > 3:  # g_seq + direct + carry (+ g_last only at the last step where there is no carry) <= 3
                 raise RuntimeError("unexpected number of gradient sources")
-            K.convgru_bwd_gates(src, gates[t], hs[t - 1] if t else None, hidp, dgx[t], dgh[t], direct if t else None)
+            K.convgru_bwd_gates(src, gates[t], hs[t - 1] if t else None, hidp, dgx[t], dgh[t], direct if t else None,
+                                words[0:1] if words is not None else None, words[1 + t: 2 + t] if words is not None else None)
             if t:
-                K.conv3x3(K.grad_operand(dgh[t]), NULL, n, H, W, pk["h_bwd"], None, eng.h_bwd, T(carry))
+                src_h = K.grad_operand_with(dgh[t], words[1 + t: 2 + t]) if words is not None else K.grad_operand(dgh[t])
+                K.conv3x3(src_h, NULL, n, H, W, pk["h_bwd"], None, eng.h_bwd, T(carry))
                 have_carry = True
         dx = None
         if ctx.needs_input_grad[1]:
             dx = torch.empty_like(x)  # stored like x (fp32: the encoder's last pooling returns fp32)
-            dgxT = K.grad_operand(dgx.view(N, H, W, 3 * hidp))
+        gx_word = (lambda t_: K.grad_operand_with(t_, words[0:1])) if words is not None else K.grad_operand
+        if ctx.needs_input_grad[1]:
+            dgxT = gx_word(dgx.view(N, H, W, 3 * hidp))
             K.conv3x3(dgxT, NULL, N, H, W, pk["x_bwd"], None, eng.x_bwd, T(dx))
         else:
-            dgxT = K.grad_operand(dgx.view(N, H, W, 3 * hidp))
+            dgxT = gx_word(dgx.view(N, H, W, 3 * hidp))
         dWx, dbx = torch.empty_like(Wx), torch.empty(Wx.shape[0], dtype=torch.float32, device=dev)
         K.conv3x3_bwd_weight(T(x), NULL, dgxT, N, H, W, eng.x_wgrad, dWx, dbx, False)
         dWh, dbh = torch.empty_like(Wh), torch.empty(Wh.shape[0], dtype=torch.float32, device=dev)
         if Tn > 1:
-            K.conv3x3_bwd_weight(T(hs[: Tn - 1]), NULL, K.grad_operand(dgh[1:]), (Tn - 1) * n, H, W, eng.h_wgrad, dWh, dbh, False)
+            gh_all = K.grad_operand_with(dgh[1:], words[2:].amax().reshape(1)) if words is not None and Tn > 1 else K.grad_operand(dgh[1:])
+            K.conv3x3_bwd_weight(T(hs[: Tn - 1]), NULL, gh_all, (Tn - 1) * n, H, W, eng.h_wgrad, dWh, dbh, False)
             # bias of the h-part also acts at t = 0 (zero state, bias only): add that step's column sums (tiny torch op)
             dbh = (dbh + dgh[0].float().sum(dim=(0, 1, 2))[K_bias_index(eng, dev)]) * K_bias_mask(eng, dev)
         else:

@@ -625,8 +625,11 @@ def convgru_seq_bwd(g_seq: Optional[Tensor], g_last: Optional[Tensor], gates: Te
 
 
 def convgru_bwd_gates(dh: Sequence[sfTensor], gates: Tensor, h_prev: Optional[Tensor], hidp: int, dgx: Tensor, dgh: Tensor,
-                      dh_direct: Optional[Tensor]) -> None:
+                      dh_direct: Optional[Tensor], amax_gx: Optional[Tensor] = None, amax_gh: Optional[Tensor] = None) -> None:
+    """``amax_gx`` / ``amax_gh`` ("f32e" mode): device words the launch raises to max |dgx| / max |dgh| (the caller zeroes them; a word may be shared by
+    the launches of a sequence: it then ends at the sequence's maximum)."""
     dh = list(dh) + [NULL] * (3 - len(dh))
     pixels = gates.numel() // gates.shape[-1]
-    check(lib().sf_convgru_bwd_gates(dh[0], dh[1], dh[2], T(gates), T(h_prev, hidp), pixels, hidp, T(dgx), T(dgh), T(dh_direct, hidp),
-                                     SF_F32, stream_ptr()), "sf_convgru_bwd_gates")
+    f32 = dgx.dtype == torch.float32
+    check(lib().sf_convgru_bwd_gates(dh[0], dh[1], dh[2], T(gates), T(h_prev, hidp), pixels, hidp, T(dgx, amax=amax_gx if f32 else None),
+                                     T(dgh, amax=amax_gh if f32 else None), T(dh_direct, hidp), SF_F32, stream_ptr()), "sf_convgru_bwd_gates")

@@ -131,3 +131,37 @@ def test_f32e_tracks_f32_on_a_recurrent_stack(device):
     assert rel_l2(res["f32e"][0], res["f32"][0]) < 1e-5
     for k, gref in res["f32"][1].items():
         assert rel_l2(res["f32e"][1][k], gref) < 1e-5, k
+
+
+def test_gru_gate_backward_raises_both_scale_words(device):
+    """sf_convgru_bwd_gates with dgx.amax / dgh.amax: the words end at max |dgx| / max |dgh|; a word shared by two launches keeps the larger value."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import T
+
+    n, hid = 3 * 8 * 8, 16
+    g = torch.Generator().manual_seed(17)
+    mk = lambda c: torch.randn(n, c, generator=g).to(device)
+    gates, hp = torch.sigmoid(mk(4 * hid)), mk(hid)
+    words = torch.zeros(2, device=device)
+    seen = 0.0
+    for scale in (1.0, 0.01):
+        dh = mk(hid) * scale
+        dgx, dgh = torch.empty(n, 3 * hid, device=device), torch.empty(n, 3 * hid, device=device)
+        words[1].zero_()
+        K.convgru_bwd_gates([T(dh)], gates, hp, hid, dgx, dgh, None, words[0:1], words[1:2])
+        seen = max(seen, float(dgx.abs().max()))
+        assert float(words[1]) == float(dgh.abs().max()) and float(words[0]) == seen
+
+
+@pytest.mark.parametrize("workload", ["metnet", "convlstm"])
+def test_bench_workload_steps_stay_finite(device, workload):
+    """The benchmark's own training steps in "f32e" (MSE-mean loss: output gradients ~1e-7, dropout, Adam): three steps, finite loss, finite parameters.
+    Round 6's first sf_amax read one channel in four; the tests' O(1) cotangents never noticed, the benchmark's MetNet step went NaN - and ran 17 % faster
+    on NaN operands, which is how it was found."""
+    import bench
+
+    wl = bench.MetNetWorkload(device, 2, 0) if workload == "metnet" else bench.ConvLSTMWorkload(device, 2, 0)
+    for _ in range(3):
+        loss = wl.step()
+    assert torch.isfinite(loss).all(), float(loss)
+    assert all(torch.isfinite(p).all() for p in wl.model.parameters())
