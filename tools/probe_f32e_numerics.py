@@ -1,4 +1,5 @@
-"""Split-bf16 "f32e" convolutions - the NUMERICS half of the go / no-go, on the CPU, zero GPU minutes.
+"""Split-operand "f32e" convolutions - the NUMERICS half of the go / no-go, on the CPU, zero GPU minutes.  Outcome: bf16 x 3 / x 4 NO-GO, fp16 x 3 with a
+scaled low part GO (profiles/r06_f32e_numerics.txt) - which is what SF_F32E implements.
 
 gfx950 has no TF32; its bf16 MFMA pipe is 16x the exact-fp32 MFMA pipe.  Writing every fp32 operand as a sum of bf16 parts
 (x = hi + lo [+ lo2], hi = bf16(x), lo = bf16(x - hi), lo2 = bf16(x - hi - lo)) and multiplying the parts on the bf16 pipe with fp32
