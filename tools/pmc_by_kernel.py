@@ -22,7 +22,7 @@ for c, scale, col in (("FETCH_SIZE", 2.0, 1), ("WRITE_SIZE", 1.0, 2)):   # FETCH
 
 def shape_classes(reads, writes):
     """A kernel NAME that runs at several shapes in a step (256->256 and 160->256 launches of the same instantiation) reports a mix when averaged by name.
-    The i-th launch of a name is the same launch in both passes; launches are grouped by their bytes: writes within 3 % (deterministic per shape) AND
+    The i-th launch of a name is the same launch in both passes; launches are grouped by their bytes: writes within 6 % (nearly deterministic per shape: the statistics launches of one shape were seen 3.4 % apart) AND
     reads within 12 % (cache effects move them run to run; the shapes of one name differ by >= 25 %).  Classes are returned sorted by total bytes."""
     if len(reads) != len(writes) or not writes:
         return None
@@ -30,7 +30,7 @@ def shape_classes(reads, writes):
     for rd, wr in zip(reads, writes):
         for c in cls:
             mw, mr = c["write_bytes"] / c["launches"], c["read_bytes"] / c["launches"]
-            if abs(wr - mw) <= 0.03 * max(wr, mw, 1.0) and abs(rd - mr) <= 0.12 * max(rd, mr, 1.0):
+            if abs(wr - mw) <= 0.06 * max(wr, mw, 1.0) and abs(rd - mr) <= 0.12 * max(rd, mr, 1.0):
                 c["launches"] += 1; c["read_bytes"] += rd; c["write_bytes"] += wr
                 break
         else:
