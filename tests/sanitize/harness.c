@@ -43,7 +43,7 @@ int main(void) {
   { sfTensor am = a16; am.amax = (const float*)ok;
     REFUSED(sf_conv3x3_fwd(a16, am, 1, 8, 8, ok, 0, 32, 1, SF_EPI_LINEAR, a16, SF_F32E, st)); }      /* an amax word on src1 */
   REFUSED(sf_amax(a16, 64, 0, 0, 0, st));                                                            /* no destination word */
-  REFUSED(sf_amax(a16, 64, ok, mem + 2, 0, st));                                                     /* misaligned accumulator word */
+  REFUSED(sf_amax(a16, 64, ok, (float*)(void*)(mem + 2), 0, st));                                                     /* misaligned accumulator word */
   REFUSED(sf_amax(b16, 64, ok, 0, 0, st));                                                           /* bf16 storage */
   REFUSED(sf_amax(m16, 64, ok, 0, 0, st));                                                           /* misaligned tensor */
   REFUSED(sf_conv3x3_fwd_stats(a16, N0, 1, 8, 8, ok, 0, 32, 1, a16, ok, SF_F32, st));                /* stats need the bf16 kernels */
