@@ -40,10 +40,25 @@ def pytest_generate_tests(metafunc):
 
 @pytest.fixture
 def fp32_mode(request):
+    """The mode of this parametrisation (set by ``_apply_fp32_mode``); a test may take it as an argument to name the mode in its messages."""
+    return request.param
+
+
+@pytest.fixture(autouse=True)
+def _apply_fp32_mode(request):
+    """Sets the compute mode of an FP32_GATED parametrisation for the duration of the test.  AUTOUSE, reading the parameter from the call spec: a
+    fixture that ``pytest_generate_tests`` merely appends to ``metafunc.fixturenames`` is parametrised (the ids show ``[f32e]``) but never set up unless the
+    test function also takes it as an argument - the first version of this file ran every "f32e" case in "f32" (round 6; found because the published
+    parity records of the two modes were identical to the last digit).  ``test_the_f32e_cases_really_run_in_f32e`` guards it."""
+    cs = getattr(request.node, "callspec", None)
+    mode = cs.params.get("fp32_mode") if cs is not None else None
+    if mode is None:
+        yield
+        return
     import satflow_amd
 
-    satflow_amd.set_compute_dtype(request.param)
-    yield request.param
+    satflow_amd.set_compute_dtype(mode)
+    yield
     satflow_amd.set_compute_dtype("f32")
 
 

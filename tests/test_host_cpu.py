@@ -397,3 +397,28 @@ def test_hot_kernels_do_not_spill():
             offenders = [ln for ln in span if ln.startswith("scratch_") or re.match(r"s_waitcnt.*vmcnt\(0\)", ln)]
             assert len(idx) >= 18 and not offenders, f"{name}: {offenders[:4]} inside the tile loop"
     assert checked == 4, checked
+
+
+def test_the_f32e_cases_really_run_in_f32e():
+    """conftest.FP32_GATED runs every fp32-gated GPU test in "f32" and "f32e".  The mode must actually be SET for test functions that do not take the
+    fixture as an argument (round 6: it was not, for a while): a throw-away test module collected with this conftest reports the mode it ran in."""
+    import subprocess
+    import sys
+    import tempfile
+    import textwrap
+
+    with tempfile.TemporaryDirectory() as d:
+        open(os.path.join(d, "conftest.py"), "w").write(open(os.path.join(ROOT, "tests", "conftest.py")).read().replace(
+            '"test_stlstm_gpu.py": (', '"test_probe_modes.py": ("test_reports_mode",), "test_stlstm_gpu.py": ('))
+        open(os.path.join(d, "test_probe_modes.py"), "w").write(textwrap.dedent("""
+            import satflow_amd
+            def test_reports_mode():
+                print("RAN_IN", satflow_amd.compute_dtype_name())
+            def test_ungated():
+                print("UNGATED_IN", satflow_amd.compute_dtype_name())
+        """))
+        r = subprocess.run([sys.executable, "-m", "pytest", "-q", "-s", "-p", "no:cacheprovider", d], capture_output=True, text=True, cwd=d,
+                           env=dict(os.environ, PYTHONPATH=ROOT))
+        assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+        assert sorted(re.findall(r"RAN_IN (\w+)", r.stdout)) == ["f32", "f32e"], r.stdout[-1500:]
+        assert re.findall(r"UNGATED_IN (\w+)", r.stdout) == ["f32"]
