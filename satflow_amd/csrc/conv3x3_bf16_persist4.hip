@@ -50,6 +50,13 @@ typedef float f32x2_t __attribute__((ext_vector_type(2)));
 constexpr int HALO_W = TILE_W + 2;  // 18
 constexpr int PIX_B = 32;
 constexpr unsigned DMA_SENT = 0x80000000u;  // >= any descriptor's num_records
+// Cache policy of the epilogue's streams (the stored result, MODE 2's read of x): nobody reads them again inside the launch, while every 128-byte line of the
+// INPUT is needed by four consecutive chunks, by the tile's other N block and by the neighbouring waves' halos - `nt` (aux bit 1) keeps the streams from
+// pushing those lines out of the XCD's 4 MiB L2.  -DSF_W4_NT=0: the A/B build.
+#ifndef SF_W4_NT
+#define SF_W4_NT 1
+#endif
+constexpr int ST_AUX = SF_W4_NT >= 2 ? 2 : 0;   // (1: the read of x only)
 
 // LDS-DMA hidden from hipcc (conv3x3_bf16.hip explains why).  M0 is declared clobbered instead of being saved and restored around every
 // piece: this kernel issues ~15 pieces per 144 MFMAs from the only wave of its SIMD, every scalar instruction next to them counts.
@@ -91,12 +98,16 @@ __device__ __forceinline__ unsigned shift_in(unsigned w, unsigned long long mask
 // tools/ubench/vmcnt_order.hip).  The wait is counted by hand and TIED to the loaded registers, so no use can move above it.
 __device__ __forceinline__ u32x4_t bufload16(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
   u32x4_t v;
+#if SF_W4_NT
+  asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen nt" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+#else
   asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=&v"(v) : "v"(voff), "s"(rs), "s"(soff) : "memory");
+#endif
   return v;
 }
 template <int N>
-__device__ __forceinline__ void wait_loaded(u32x4_t& a, u32x4_t& b) {
-  asm volatile("s_waitcnt vmcnt(%2)" : "+v"(a), "+v"(b) : "i"(N) : "memory");
+__device__ __forceinline__ void wait_loaded4(u32x4_t& a, u32x4_t& b, u32x4_t& c, u32x4_t& d) {
+  asm volatile("s_waitcnt vmcnt(%4)" : "+v"(a), "+v"(b), "+v"(c), "+v"(d) : "i"(N) : "memory");
 }
 // One level of a reduce-scatter over the 32 lanes of a half-wave: 2 * M values per lane in, M out - the lane keeps the half its bit M selects and adds
 // the partner's (lane ^ M) copy of that half.  After the levels 16, 8, 4, 2, 1 lane r holds entry r of the 32, summed over the 32 lanes.
@@ -123,7 +134,7 @@ constexpr int IN0 = WST * W_B, TAB0 = IN0 + 4 * 2 * PIN_B;
 // WIN: window-major lane <-> pixel map of the pixel fragments (always with MODE 3; for MODE 1 a launch-time choice, SF_CONV_W4_WIN): 16 instead of
 // 27 pixel-fragment reads per chunk, same products in the same order, the same 64-byte store runs (a store register then covers two window rows).
 template <int MODE, bool WIN = (MODE == 3)>
-__global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const ConvParams p, const int items, const int nblk) {
+__global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const ConvParams p, const int items, const int nblk, const int pair_order) {
   __shared__ __attribute__((aligned(1024))) char lds[TAB0 + TAB_B];  // 110592 + 46080 + 5120 = 161792 of 163840
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -134,7 +145,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   const int tiles_total = items / nblk;
   const bool xcd_order = tiles_total % 8 == 0 && nblk > 1;  // the N blocks of a tile on ONE XCD (conv3x3_bf16.hip)
   const int grid = gridDim.x;
-  const int K = (items - (int)blockIdx.x + grid - 1) / grid;  // items of this workgroup (the launcher keeps grid <= items)
+  // items of this workgroup (the launcher keeps grid <= items).  pair_order (SF_CONV_W4_PAIR=1, an A/B switch): a workgroup takes ALL N blocks of a
+  // tile back to back (the second pass over the tile's input comes out of the L2 it has just been through) instead of one N block of it
+  const int K = pair_order ? nblk * ((tiles_total - (int)blockIdx.x + grid - 1) / grid) : (items - (int)blockIdx.x + grid - 1) / grid;
 
   // ---- work items: a handful of scalars (everything else is derived where it is used) + the per-lane input offsets ----
   struct Item {
@@ -158,7 +171,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     it.valid = k < K;
     const int w = it.valid ? (int)blockIdx.x + k * grid : (int)blockIdx.x;  // past the end: some valid item (its descriptors get 0 records)
     int tile;
-    if (xcd_order) { const int xcd = w & 7, j = w >> 3; tile = (j / nblk) * 8 + xcd; it.nb = j % nblk; }
+    if (pair_order) { const int kk = it.valid ? k : 0; tile = (int)blockIdx.x + (kk / nblk) * grid; it.nb = kk % nblk; }
+    else if (xcd_order) { const int xcd = w & 7, j = w >> 3; tile = (j / nblk) * 8 + xcd; it.nb = j % nblk; }
     else { tile = w % tiles_total; it.nb = w / tiles_total; }
     const int tx = tile % p.tiles_x; tile /= p.tiles_x;
     const int ty = tile % p.tiles_y;
@@ -328,8 +342,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     }
     // the fragment's position goes into the SCALAR offset (an out-of-range one past out_c - a multiple of 32 here: voff + soff never wraps back)
     const unsigned soff = cb < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
-    __builtin_amdgcn_raw_buffer_store_b128(r0, rs_out, voff0, soff, 0);
-    __builtin_amdgcn_raw_buffer_store_b128(r1, rs_out, voff1, soff, 0);
+    __builtin_amdgcn_raw_buffer_store_b128(r0, rs_out, voff0, soff, ST_AUX);
+    __builtin_amdgcn_raw_buffer_store_b128(r1, rs_out, voff1, soff, ST_AUX);
   };
   // byte offset of this lane's piece of pixel (row j of fragment mf, lane & 15) inside the item's output image (+ this N block's first channel), or the sentinel
   auto out_voff = [&](const Item& it, int mf, int j) __attribute__((always_inline)) -> unsigned {
@@ -453,54 +467,76 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       unsigned vo0[MFR], vo1[MFR];
 #pragma unroll
       for (int mf = 0; mf < MFR; ++mf) { vo0[mf] = out_voff(it, mf, 0); vo1[mf] = out_voff(it, mf, 1); }
-      // The LOADS address x with ADJACENT lanes on one 64-byte run - lane L = (pixel L / 4, 16-byte piece L % 4): in the store's lane order (a
-      // quarter-wave = one piece of 16 different pixels) a load instruction is four passes that each touch 16 lines, and the four requests for a line
-      // are not merged on their way to memory: 2.93 GB fetched per launch for this 1.21 GB tensor (PMC, against a build without the read:
-      // -DSF_EXP_W4_NOX).  One ds_bpermute per dword then hands every lane the piece the store order gives it (source lane 4 * pixel + piece; no LDS
-      // memory involved): 2.53 GB and 1 % faster.  Still 2.1x: the two 64-byte halves of a 128-byte line belong to neighbouring channel fragments and are
-      // requested back to back by two instructions - both miss.  (Whole lines per request would need a lane-dependent choice between two loaded
-      // registers in front of every ds_bpermute: twice the exchanges; not built.)
+      // The LOADS address x in WHOLE 128-byte lines: a load instruction covers 8 pixels x one line = the 64-byte quarters of TWO neighbouring channel
+      // fragments (lane L = pixel L / 8 [+ 8 for the second instruction of the row], 16-byte piece L % 8 of the line), four instructions per pair of
+      // fragments - as many as before.  History of this read (PMC, against a build without it, -DSF_EXP_W4_NOX): in the store's lane order (a
+      // quarter-wave = one piece of 16 different pixels) 2.93 GB fetched per launch for this 1.21 GB tensor - four passes per instruction that each
+      // touch 16 lines, not merged on their way to memory; adjacent lanes on one 64-byte run: 2.53 GB - the two halves of a line belong to neighbouring
+      // fragments and were requested back to back by two instructions, both missed; whole lines (round 6): see profiles/r06_w4_bnb_lines.txt.
+      // From line order to the store order: one DPP move per dword gathers a FRAGMENT's 64 pieces from the two instructions of a row (lanes with
+      // L % 8 >= 4 take the other instruction's lane L - 4 for the even fragment, lanes with L % 8 < 4 its lane L + 4 for the odd one: row_shr:4 /
+      // row_shl:4 under a bank mask), then the ds_bpermute per dword as before (source lane 8 (pixel % 8) + 4 (pixel / 8 [even] or 1 - pixel / 8 [odd])
+      // + piece; no LDS memory involved).
       unsigned lo0[MFR], lo1[MFR];
 #pragma unroll
       for (int mf = 0; mf < MFR; ++mf)
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
-          const int py = it.y0 + 8 * wave + 2 * mf + j, px = it.x0 + (lane >> 2);
-          (j ? lo1[mf] : lo0[mf]) = (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * (lane & 3)) * 2) : DMA_SENT;
+          const int py = it.y0 + 8 * wave + 2 * mf + j, px = it.x0 + (lane >> 3);
+          (j ? lo1[mf] : lo0[mf]) = (py < p.H && px < p.W) ? (unsigned)(((py * p.W + px) * p.out_s + it.nb * NB + 8 * (lane & 7)) * 2) : DMA_SENT;
         }
-      const int bp_idx = (4 * (lane & 15) + piece) * 4;
-      u32x4_t xq[3][2];
-      auto request = [&](int f) __attribute__((always_inline)) {
-        const int mf = f / NF, nf = f % NF;
-        const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
+      // the second instruction of a row: 8 pixels to the right (a sentinel stays one: DMA_SENT + the step is still past every descriptor's range)
+      const bool right_ok = it.x0 + 8 + (lane >> 3) < p.W;
+      const unsigned right_step = (unsigned)(8 * p.out_s * 2);
+      auto right = [&](unsigned o) __attribute__((always_inline)) { return right_ok ? o + right_step : DMA_SENT; };
+      const int px16 = lane & 15;
+      const int bp_even = (8 * (px16 & 7) + 4 * (px16 >> 3) + piece) * 4, bp_odd = (8 * (px16 & 7) + 4 * (1 - (px16 >> 3)) + piece) * 4;
+      constexpr int NPAIR = MFR * NF / 2;
+      u32x4_t xq[2][2][2];   // [pair & 1][row j][left / right instruction]
+      auto request = [&](int q) __attribute__((always_inline)) {
+        const int mf = q / (NF / 2), nfp = q % (NF / 2);
+        const unsigned soff = it.nb * NB + nfp * 64 < p.out_c ? (unsigned)(nfp * 64 * 2) : 0x40000000u;
 #ifdef SF_EXP_W4_NOX   // ablation build (tools/ablate_w4.sh): no read of x - what the input tiles alone cost in this mode
-        xq[f % 3][0] = u32x4_t{soff, 0u, 0u, 0u}; xq[f % 3][1] = u32x4_t{soff, 0u, 0u, 0u};
+        for (int j = 0; j < 2; ++j) for (int h = 0; h < 2; ++h) xq[q & 1][j][h] = u32x4_t{soff, 0u, 0u, 0u};
         return;
 #endif
-        xq[f % 3][0] = bufload16(lo0[mf], rs_x, soff);
-        xq[f % 3][1] = bufload16(lo1[mf], rs_x, soff);
+        xq[q & 1][0][0] = bufload16(lo0[mf], rs_x, soff);
+        xq[q & 1][0][1] = bufload16(right(lo0[mf]), rs_x, soff);
+        xq[q & 1][1][0] = bufload16(lo1[mf], rs_x, soff);
+        xq[q & 1][1][1] = bufload16(right(lo1[mf]), rs_x, soff);
       };
-      request(0); request(1);
+      request(0);
 #pragma unroll
       for (int mf = 0; mf < MFR; ++mf) {
 #pragma unroll
         for (int nf = 0; nf < NF; ++nf) {
-          const int f = mf * NF + nf;
+          const int f = mf * NF + nf, q = f >> 1;
           f32x4 cA[4], cB[4], cK[4];
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const char* lc = lds + TAB0 + (nf * 32 + 8 * g + 4 * kh) * 4;
             cA[g] = *reinterpret_cast<const f32x4*>(lc); cB[g] = *reinterpret_cast<const f32x4*>(lc + NB * 4); cK[g] = *reinterpret_cast<const f32x4*>(lc + 2 * NB * 4);
           }
-          if (f + 2 < MFR * NF) request(f + 2);
-          // younger than this fragment's two loads: the loads of the next two fragments and the stores of the previous two
-          u32x4_t& x0 = xq[f % 3][0]; u32x4_t& x1 = xq[f % 3][1];
-          if (f == 0 || f == MFR * NF - 1) wait_loaded<4>(x0, x1); else if (f == 1 || f == MFR * NF - 2) wait_loaded<6>(x0, x1); else wait_loaded<8>(x0, x1);
-          // load order -> store order (ds_bpermute) -> accumulator layout: rows back (v_permlane16_swap), then quads back (v_permlane32_swap)
+          u32x4_t (&xp)[2][2] = xq[q & 1];
+          if ((f & 1) == 0) {
+            if (q + 1 < NPAIR) request(q + 1);
+            // younger than this pair's four loads: the four loads of the next pair and the four stores of the previous one
+            if (q == 0 || q == NPAIR - 1) wait_loaded4<4>(xp[0][0], xp[0][1], xp[1][0], xp[1][1]); else wait_loaded4<8>(xp[0][0], xp[0][1], xp[1][0], xp[1][1]);
+          }
+          // line order -> fragment (DPP) -> store order (ds_bpermute) -> accumulator layout: rows back (v_permlane16_swap), then quads back (v_permlane32_swap)
           u32x4_t oc[2];
 #pragma unroll
           for (int d = 0; d < 4; ++d) {
-            const unsigned s0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp_idx, (int)x0[d]), s1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp_idx, (int)x1[d]);
+            int g0, g1;
+            if ((f & 1) == 0) {
+              g0 = __builtin_amdgcn_update_dpp((int)xp[0][0][d], (int)xp[0][1][d], 0x114, 0xF, 0xA, false);   // row_shr:4 into lanes 4-7, 12-15 of every row
+              g1 = __builtin_amdgcn_update_dpp((int)xp[1][0][d], (int)xp[1][1][d], 0x114, 0xF, 0xA, false);
+            } else {
+              g0 = __builtin_amdgcn_update_dpp((int)xp[0][0][d], (int)xp[0][1][d], 0x104, 0xF, 0x5, false);   // row_shl:4 into lanes 0-3, 8-11
+              g1 = __builtin_amdgcn_update_dpp((int)xp[1][0][d], (int)xp[1][1][d], 0x104, 0xF, 0x5, false);
+            }
+            const int bp = (f & 1) ? bp_odd : bp_even;
+            const unsigned s0 = (unsigned)__builtin_amdgcn_ds_bpermute(bp, g0), s1 = (unsigned)__builtin_amdgcn_ds_bpermute(bp, g1);
             const auto sw = __builtin_amdgcn_permlane16_swap(s0, s1, false, false);
             oc[0][d] = sw[0]; oc[1][d] = sw[1];
           }
@@ -533,8 +569,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
             r0[d] = sw[0]; r1[d] = sw[1];
           }
           const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
-          __builtin_amdgcn_raw_buffer_store_b128(r0, rs_out, vo0[mf], soff, 0);
-          __builtin_amdgcn_raw_buffer_store_b128(r1, rs_out, vo1[mf], soff, 0);
+          __builtin_amdgcn_raw_buffer_store_b128(r0, rs_out, vo0[mf], soff, ST_AUX);
+          __builtin_amdgcn_raw_buffer_store_b128(r1, rs_out, vo1[mf], soff, ST_AUX);
           __builtin_amdgcn_sched_barrier(0);
         }
       }
@@ -604,8 +640,8 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           r0[d] = sw16[0]; r1[d] = sw16[1];
         }
         const unsigned soff = it.nb * NB + nf * 32 < p.out_c ? (unsigned)(nf * 32 * 2) : 0x40000000u;
-        __builtin_amdgcn_raw_buffer_store_b128(r0, rs_pool, pv[0], soff, 0);
-        __builtin_amdgcn_raw_buffer_store_b128(r1, rs_pool, pv[1], soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b128(r0, rs_pool, pv[0], soff, ST_AUX);
+        __builtin_amdgcn_raw_buffer_store_b128(r1, rs_pool, pv[1], soff, ST_AUX);
         // routing words of this block's four octets: word g = byte g of the kh = 0 lane | byte g of the kh = 1 lane << 8
         const auto wsw = __builtin_amdgcn_permlane32_swap(Wc, Wc, false, false);   // [0]: the kh = 0 lane's word, [1]: the kh = 1 lane's (in both lanes)
         rd[nf][0] = __builtin_amdgcn_perm(wsw[1], wsw[0], 0x05010400u);
@@ -618,7 +654,7 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
         typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
         const u32x2_t v = kh ? u32x2_t{rd[2 * q + 1][0], rd[2 * q + 1][1]} : u32x2_t{rd[2 * q][0], rd[2 * q][1]};
         const unsigned soff = it.nb * NB + q * 64 < p.out_c ? (unsigned)(q * 16) : 0x40000000u;
-        __builtin_amdgcn_raw_buffer_store_b64(v, rs_route, rv_off, soff, 0);
+        __builtin_amdgcn_raw_buffer_store_b64(v, rs_route, rv_off, soff, ST_AUX);
       }
       return;
     }
@@ -792,19 +828,22 @@ int sf_launch_conv_bf16_persist4(const sfconv::ConvParams& p0, int nblk, hipStre
     if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: device query failed"); return 2; }
     cus = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  const int grid = items < cus ? items : cus;
+  static const bool pair_env = getenv("SF_CONV_W4_PAIR") != nullptr;
+  const int pair = pair_env && nblk > 1 ? 1 : 0;
+  const int tiles = items / nblk;
+  const int grid = pair ? (tiles < cus ? tiles : cus) : (items < cus ? items : cus);
   // window-major pixel fragments outside the pooled mode (round 5; bit-identical results): the statistics launches take them by default (-0.8 .. -1.0 %:
   // 2.255 -> 2.236 ms at 256 -> 256, 1.536 -> 1.520 at 160 -> 256, two A/B pairs on one box; SF_CONV_W4_WIN=0: the A/B switch back).  The plain
   // launches do not: that instantiation spilled 68 bytes per lane (the fragment set next to the pixel-fragment-outermost epilogue) and ran 2.25 -> 2.49 ms;
   // the MetNet step has no plain launch of this kernel since conv4 took the pooled mode, so it is not instantiated.
   static const char* win_env = getenv("SF_CONV_W4_WIN");
   static const bool win_stats = !win_env || win_env[0] != '0';
-  if (p.pool_out) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<3>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-  else if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+  if (p.pool_out) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<3>), dim3(grid), dim3(256), 0, st, p, items, nblk, pair);
+  else if (p.bnb_coef) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<2>), dim3(grid), dim3(256), 0, st, p, items, nblk, pair);
   else if (p.stats) {
-    if (win_stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1, true>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-    else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk);
-  } else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk);
+    if (win_stats) hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1, true>), dim3(grid), dim3(256), 0, st, p, items, nblk, pair);
+    else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<1>), dim3(grid), dim3(256), 0, st, p, items, nblk, pair);
+  } else hipLaunchKernelGGL((conv3x3_bf16_persist4_kernel<0>), dim3(grid), dim3(256), 0, st, p, items, nblk, pair);
   hipError_t e = hipGetLastError();
   if (e != hipSuccess) { sf_set_error("conv3x3_bf16_persist4: launch failed: %s", hipGetErrorString(e)); return 2; }
   return 0;
