@@ -28,6 +28,9 @@ FP32_GATED = {
                                   "test_cfg3_metnet_train_step_fullsize_f32_with_dropout", "test_config0_convgru_two_layers"),
     "test_cloudgan_gpu.py": ("test_patch_discriminator_golden", "test_cloudgan_training_steps_golden", "test_discriminator_variants_match_reference"),
     "test_stlstm_gpu.py": ("test_stlstm_cell_matches_reference_golden_fp32",),
+    "test_dgmr_gpu.py": ("test_gresblock_matches_reference", "test_discriminator_matches_reference", "test_generator_matches_oracle",
+                         "test_convgru_stack_matches_oracle", "test_conv5x5_on_the_3x3_kernels", "test_dgmr_gan_step_matches_oracle", "test_dgmr_configs4_size"),
+    "test_attention_gpu.py": ("test_attention_layer_matches_reference",),
 }
 
 

@@ -1,7 +1,7 @@
 cd /tmp && export TMPDIR=/tmp
 OUT=$GRAFT_REPO_ROOT/gpurun_out/trace1
 mkdir -p $OUT
-rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --no-cpu-baseline > $OUT/log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $OUT -o tr -- python3 $GRAFT_REPO_ROOT/bench.py --steps 4 --warmup 2 --no-cpu-baseline --no-extra --no-exchange-probe > $OUT/log 2>&1
 python3 $GRAFT_REPO_ROOT/tools/step_gaps.py $OUT/tr_kernel_trace.csv; python3 - <<'PY'
 import csv,os
 f=os.environ["GRAFT_REPO_ROOT"]+"/gpurun_out/trace1/tr_kernel_trace.csv"
