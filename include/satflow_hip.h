@@ -303,7 +303,9 @@ int sf_metnet_preprocess_bwd(sfTensor dout, int32_t B, int32_t T, int32_t C, int
 
 /* nn.MaxPool2d(2, stride 2) of the DownSampler, forward / backward (argmax recomputed from `in`).
  * perm_l > 0: images are reordered on the pooled side, input image (l*perm_t + t)*B + b <->
- * pooled image (t*perm_l + l)*B + b (lead-time-major encoder order -> time-major ConvGRU order). */
+ * pooled image (t*perm_l + l)*B + b (lead-time-major encoder order -> time-major ConvGRU order). 
+ * din.amax (the three backward entries: _bwd, _dropout_bwd, _route_bwd; nullable, fp32-stored din only): a word the CALLER has zeroed, raised to max |din| - the SF_F32E convolutions' scale
+ * word of din (sfTensor::amax) without a separate sf_amax pass. */
 int sf_maxpool2_fwd(sfTensor in, int64_t n, int32_t h, int32_t w, sfTensor out, int32_t perm_l,
                     int32_t perm_t, int32_t dtype, sfStream stream);
 int sf_maxpool2_bwd(sfTensor in, sfTensor dout, int64_t n, int32_t h, int32_t w, sfTensor din,
@@ -356,6 +358,8 @@ int sf_batchnorm_eval_fwd(sfTensor x, int64_t pixels, int32_t creal, const float
 int sf_batchnorm_eval_bwd(sfTensor x, sfTensor dy, int64_t pixels, int32_t creal, const float* gamma, float eps,
                           const float* running_mean, const float* running_var, double* sums, float* scratch,
                           sfTensor dx, float* dgamma, float* dbeta, int32_t dtype, sfStream stream);
+/* dx.amax (both backward entries; nullable, fp32-stored dx only): a word the CALLER has zeroed, raised to max |dx| by the apply pass - the SF_F32E
+ * convolutions' scale word of dx (sfTensor::amax) without a separate sf_amax pass over it. */
 int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32_t groups,
                            int32_t creal, const float* gamma, const float* mean, const float* rstd,
                            double* sums, float* coef /* scratch [groups][3][C] */, sfTensor dx,

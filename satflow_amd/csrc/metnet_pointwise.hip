@@ -201,9 +201,12 @@ template <typename TI, typename TO, bool DROP>  // TI: input and its gradient, T
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__ in, int is, const TO* __restrict__ dout, int dos,
                                                           long long N, int H, int W, int C, TI* __restrict__ din, int dis,
                                                           const OuterPerm pm, const sfDrop dr, long long npt, const unsigned short* __restrict__ route,
-                                                          TO* __restrict__ gmask) {
+                                                          TO* __restrict__ gmask, unsigned* __restrict__ amax) {
+  // amax (nullable): raised to max |din| = the largest masked pooled gradient (every din value is one of them or zero): the SF_F32E kernels' scale word
+  // of din (sfTensor::amax), zeroed by the caller; one atomic per wave at most
   const int Ho = H / 2, Wo = W / 2, q = C / 8;
   const long long total = N * Ho * Wo * q;
+  unsigned vmax = 0u;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const int c = (idx % q) * 8;
     const long long op = idx / q;
@@ -225,6 +228,13 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
     }
     // the masked pooled gradient itself (stored like dout): what the 2:4-sparse weight gradient builds its operand from instead of reading din
     if (gmask) stv8(gmask + ((no * Ho + yo) * Wo + xo) * dos + c, g);
+    if (amax) {   // kernel-uniform
+      float m = fabsf(g[0]);
+#pragma unroll
+      for (int j = 1; j < 8; ++j) m = fmaxf(m, fabsf(g[j]));
+      const unsigned bits = __float_as_uint(m);
+      vmax = bits > vmax ? bits : vmax;
+    }
     f32x8_t g0, g1, g2, g3;
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
@@ -238,6 +248,14 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const TI* __restrict__
     }
     TI* d = din + base * dis + c;
     stv8(d, g0); stv8(d + dis, g1); stv8(d + (long long)W * dis, g2); stv8(d + (long long)W * dis + dis, g3);
+  }
+  if (amax) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)vmax, off);
+      vmax = o > vmax ? o : vmax;
+    }
+    if ((threadIdx.x & 63) == 0 && vmax > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, vmax);
   }
 }
 
@@ -406,14 +424,33 @@ __global__ void bn_bwd_coef_kernel(const double* __restrict__ sums, int G, int C
 template <typename TA>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const TA* __restrict__ x, int xs, const TA* __restrict__ dy, int dys,
                                                            long long pixels, long long pix_per_group, int C, const float* __restrict__ coef,
-                                                           TA* __restrict__ dx, int dxs) {
+                                                           TA* __restrict__ dx, int dxs, unsigned* __restrict__ amax) {
+  // amax (nullable; fp32 storage): raised to max |dx| by this launch - the SF_F32E kernels' scale word of dx (sfTensor::amax), zeroed by the caller;
+  // non-negative floats order like unsigned integers, one atomic per wave at most and only while the word is below the wave's maximum
   const int q = C / 8;
   const long long total = pixels * q;
+  unsigned vmax = 0u;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long long)gridDim.x * blockDim.x) {
     const long long p = idx / q;
     const int c = (idx % q) * 8;
     const float* k = coef + (p / pix_per_group) * 3 * C + c;
-    stv8(dx + p * dxs + c, ldv8(k) * ldv8(dy + p * dys + c) + ldv8(k + C) * ldv8(x + p * xs + c) + ldv8(k + 2 * C));
+    const auto v = ldv8(k) * ldv8(dy + p * dys + c) + ldv8(k + C) * ldv8(x + p * xs + c) + ldv8(k + 2 * C);
+    stv8(dx + p * dxs + c, v);
+    if (amax) {   // kernel-uniform
+      float m = fabsf(v[0]);
+#pragma unroll
+      for (int j = 1; j < 8; ++j) m = fmaxf(m, fabsf(v[j]));
+      const unsigned bits = __float_as_uint(m);
+      vmax = bits > vmax ? bits : vmax;
+    }
+  }
+  if (amax) {
+#pragma unroll
+    for (int off = 32; off >= 1; off >>= 1) {
+      const unsigned o = (unsigned)__shfl_xor((int)vmax, off);
+      vmax = o > vmax ? o : vmax;
+    }
+    if ((threadIdx.x & 63) == 0 && vmax > __atomic_load_n(amax, __ATOMIC_RELAXED)) atomicMax(amax, vmax);
   }
 }
 
@@ -477,6 +514,7 @@ static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n
              "maxpool2: needs even H,W and matching channels (multiple of 8, 16-byte aligned pixels)");
   SF_REQUIRE(in.dtype == out.dtype || (in.dtype == SF_BF16 && out.dtype == SF_F32), "maxpool2: unsupported storage pair %d -> %d", in.dtype, out.dtype);
   SF_REQUIRE(!bwd || in.dtype == din.dtype, "maxpool2 bwd: din must be stored like the input");
+  SF_REQUIRE(!bwd || !din.amax || (din.dtype == SF_F32 && ((uintptr_t)din.amax & 3) == 0), "maxpool2 bwd: din.amax goes with an fp32-stored din (4-byte aligned word)");
   OuterPerm pm{0, 0, 0};
   if (perm_l > 0) {
     SF_REQUIRE(perm_t > 0 && n % ((long long)perm_l * perm_t) == 0, "maxpool2: n=%lld not divisible by perm dims %d x %d", (long long)n, perm_l, perm_t);
@@ -497,7 +535,7 @@ static int maxpool_launch(bool bwd, sfTensor in, sfTensor dout_or_out, int64_t n
   do {                                                                                                                                            \
     if (bwd) hipLaunchKernelGGL((maxpool_bwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (const TO_*)out.ptr,   \
                                 out.stride, (long long)n, h, w, in.c, (TI_*)din.ptr, din.stride, pm, dr, npt, (const unsigned short*)route,   \
-                                (TO_*)gmask);                                                                                                    \
+                                (TO_*)gmask, (unsigned*)din.amax);                                                                               \
     else hipLaunchKernelGGL((maxpool_fwd_kernel<TI_, TO_, DROP_>), grid, block, 0, st, (const TI_*)in.ptr, in.stride, (long long)n, h, w, in.c,   \
                             (TO_*)out.ptr, out.stride, pm, dr, npt, (unsigned short*)route);                                                     \
   } while (0)
@@ -656,6 +694,7 @@ int sf_batchnorm_eval_bwd(sfTensor x, sfTensor dy, int64_t pixels, int32_t creal
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_eval_bwd: dtype %d not built", dtype);
   SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok8(x) && ok8(dy) && ok8(dx) && x.dtype == dx.dtype && creal <= x.c,
              "batchnorm eval bwd: channels (multiple of 8, 16-byte aligned) / storage type");
+  SF_REQUIRE(!dx.amax || (dx.dtype == SF_F32 && ((uintptr_t)dx.amax & 3) == 0), "batchnorm eval bwd: dx.amax goes with an fp32-stored dx (4-byte aligned word)");
   hipStream_t st = (hipStream_t)stream;
   const int C = x.c;
   hipLaunchKernelGGL(bn_eval_bwd_prep_kernel, dim3((C + 127) / 128), dim3(128), 0, st, C, creal, eps, gamma, running_mean, running_var, scratch);
@@ -663,7 +702,7 @@ int sf_batchnorm_eval_bwd(sfTensor x, sfTensor dy, int64_t pixels, int32_t creal
   if (int rc = bn_reduce_launch(1, x, dy, pixels, 1, scratch, scratch + C, sums, st)) return rc;
   SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<TA>), dim3(grid_for(pixels * (C / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               (const TA*)dy.ptr, dy.stride, (long long)pixels, (long long)pixels, C, (const float*)(scratch + 2 * C),
-                                              (TA*)dx.ptr, dx.stride));
+                                              (TA*)dx.ptr, dx.stride, (unsigned*)dx.amax));
   SF_CHECK_LAUNCH("bn_bwd_apply");
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, 1, C, creal, dgamma, dbeta);
   SF_CHECK_LAUNCH("bn_param_grad");
@@ -675,6 +714,7 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
                            int32_t dtype, sfStream stream) {
   SF_REQUIRE(dtype == SF_F32, "sf_batchnorm_train_bwd: dtype %d not built", dtype);
   SF_REQUIRE(x.c == dy.c && x.c == dx.c && ok8(x) && ok8(dy) && ok8(dx) && x.dtype == dx.dtype, "batchnorm bwd: channels (multiple of 8, 16-byte aligned) / storage type");
+  SF_REQUIRE(!dx.amax || (dx.dtype == SF_F32 && ((uintptr_t)dx.amax & 3) == 0), "batchnorm bwd: dx.amax goes with an fp32-stored dx (4-byte aligned word)");
   hipStream_t st = (hipStream_t)stream;
   if (int rc = bn_reduce_launch(1, x, dy, pix_per_group, groups, mean, rstd, sums, st)) return rc;
   const long long pixels = pix_per_group * groups;
@@ -683,7 +723,7 @@ int sf_batchnorm_train_bwd(sfTensor x, sfTensor dy, int64_t pix_per_group, int32
   SF_CHECK_LAUNCH("bn_bwd_coef");
   SF_DISPATCH_ACT(x.dtype, hipLaunchKernelGGL((bn_bwd_apply_kernel<TA>), dim3(grid_for(pixels * (x.c / 8))), dim3(256), 0, st, (const TA*)x.ptr, x.stride,
                                               (const TA*)dy.ptr, dy.stride, pixels, (long long)pix_per_group, x.c, (const float*)coef, (TA*)dx.ptr,
-                                              dx.stride));
+                                              dx.stride, (unsigned*)dx.amax));
   SF_CHECK_LAUNCH("bn_bwd_apply");
   hipLaunchKernelGGL(bn_param_grad_kernel, dim3((creal + 127) / 128), dim3(128), 0, st, sums, groups, x.c, creal, dgamma, dbeta);
   SF_CHECK_LAUNCH("bn_param_grad");

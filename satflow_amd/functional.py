@@ -643,10 +643,12 @@ class _BatchNormTrainFn(torch.autograd.Function):
         sums = torch.empty(ctx.groups, 2, C, dtype=torch.float64, device=x.device)
         (dgamma, dgamma_ret), (dbeta, dbeta_ret) = grad_out(gamma), grad_out(ctx.beta)
         coef = torch.empty(ctx.groups, 3, C, dtype=torch.float32, device=x.device)
+        # "f32e": dx is the gradient operand of the convolution in front of this BatchNorm - its scale word is raised by the apply pass itself
+        word = K.scale_words(1, x.device) if dx.dtype == torch.float32 else None
         check(lib().sf_batchnorm_train_bwd(T(x), T(gy), pixels // ctx.groups, ctx.groups, ctx.creal, gamma.data_ptr(), stats[0].data_ptr(),
-                                           stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx), dgamma.data_ptr(), dbeta.data_ptr(),
+                                           stats[1].data_ptr(), sums.data_ptr(), coef.data_ptr(), T(dx, amax=word), dgamma.data_ptr(), dbeta.data_ptr(),
                                            SF_F32, stream_ptr()), "sf_batchnorm_train_bwd")
-        return dx, dgamma_ret, dbeta_ret, None, None, None, None, None, None
+        return K.tag_amax(dx, word), dgamma_ret, dbeta_ret, None, None, None, None, None, None
 
 
 class _BNConvFn(torch.autograd.Function):

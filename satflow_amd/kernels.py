@@ -157,6 +157,9 @@ def grad_operand(t: Tensor, acc: Optional[Tensor] = None, reset_acc: bool = Fals
     the one weight-gradient launch over all steps: ``grad_operand_with(t, acc)``)."""
     if _hip.compute_dtype() != _hip.SF_F32E or t.dtype != torch.float32:
         return T(t, **kw)
+    tag = getattr(t, "_sf_amax", None)   # left by the kernel that WROTE t (``tag_amax``): no pass over it here
+    if tag is not None and acc is None and tag[1] == t._version and tag[2] == t.data_ptr():
+        return grad_operand_with(t, tag[0], **kw)
     word = torch.empty(1, dtype=torch.float32, device=t.device)
     d = T(t, **kw)
     check(lib().sf_amax(d, t.numel() // t.shape[-1], word.data_ptr(), acc.data_ptr() if acc is not None else None, int(reset_acc), stream_ptr()), "sf_amax")
@@ -171,6 +174,16 @@ def scale_words(n: int, device) -> Optional[Tensor]:
     if _hip.compute_dtype() != _hip.SF_F32E:
         return None
     return torch.zeros(n, dtype=torch.float32, device=device)
+
+
+def tag_amax(t: Tensor, word: Optional[Tensor]) -> Tensor:
+    """Attach the scale word a kernel raised WHILE IT WROTE ``t`` (``sf_batchnorm_train_bwd`` with ``dx.amax``) to the tensor object; ``grad_operand`` of the
+    consumer then skips its ``sf_amax`` pass.  The tag travels with the Python object through the autograd engine (torch keeps a tensor's Python object, with
+    its attributes, alive with the tensor) and is void once the tensor has been written in place (version counter) or is another tensor (a view, a sum of
+    gradients: those have no tag).  ``word`` None (not "f32e"): nothing."""
+    if word is not None:
+        t._sf_amax = (word, t._version, t.data_ptr())
+    return t
 
 
 def grad_operand_with(t: Tensor, word: Optional[Tensor], **kw) -> sfTensor:
@@ -445,20 +458,22 @@ def maxpool2_route_bwd(route: Tensor, gy: Tensor, shape, dtype, perm: Optional[T
     pl, pt = perm or (0, 0)
     d = drop if drop is not None else (0.0, 0.0, 0, 0, 0)
     assert masked is None or (masked.shape == gy.shape and masked.dtype == gy.dtype and masked.is_contiguous() and gy.is_contiguous())
-    check(lib().sf_maxpool2_route_bwd(route.data_ptr(), T(gy), n, h, w, T(gx), pl, pt, *d, masked.data_ptr() if masked is not None else None, SF_F32,
+    word = scale_words(1, gy.device) if dtype == torch.float32 else None   # "f32e": gx is a convolution's gradient operand - its scale word comes with it
+    check(lib().sf_maxpool2_route_bwd(route.data_ptr(), T(gy), n, h, w, T(gx, amax=word), pl, pt, *d, masked.data_ptr() if masked is not None else None, SF_F32,
                                       stream_ptr()), "sf_maxpool2_route_bwd")
-    return gx
+    return tag_amax(gx, word)
 
 
 def maxpool2_bwd(x: Tensor, gy: Tensor, perm: Optional[Tuple[int, int]] = None, drop=None) -> Tensor:
     n, h, w, c = x.shape
     gx = torch.empty_like(x)
     pl, pt = perm or (0, 0)
+    word = scale_words(1, gy.device) if gx.dtype == torch.float32 else None
     if drop is None:
-        check(lib().sf_maxpool2_bwd(T(x), T(gy), n, h, w, T(gx), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_bwd")
+        check(lib().sf_maxpool2_bwd(T(x), T(gy), n, h, w, T(gx, amax=word), pl, pt, SF_F32, stream_ptr()), "sf_maxpool2_bwd")
     else:
-        check(lib().sf_maxpool2_dropout_bwd(T(x), T(gy), n, h, w, T(gx), pl, pt, *drop, SF_F32, stream_ptr()), "sf_maxpool2_dropout_bwd")
-    return gx
+        check(lib().sf_maxpool2_dropout_bwd(T(x), T(gy), n, h, w, T(gx, amax=word), pl, pt, *drop, SF_F32, stream_ptr()), "sf_maxpool2_dropout_bwd")
+    return tag_amax(gx, word)
 
 
 def linear_fwd(x: Tensor, W: Tensor, bias: Optional[Tensor], out_lanes: int, lowp: bool = False) -> Tensor:

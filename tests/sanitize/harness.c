@@ -85,6 +85,8 @@ int main(void) {
   REFUSED(sf_maxpool2_fwd(a16, 1, 7, 8, a16, 0, 0, SF_F32, st));                                     /* odd height */
   REFUSED(sf_maxpool2_fwd(a16, 5, 8, 8, a16, 2, 3, SF_F32, st));                                     /* n not divisible by the permutation */
   REFUSED(sf_maxpool2_bwd(a16, a16, 1, 8, 8, a64, 0, 0, SF_F32, st));                                /* channel mismatch */
+  { sfTensor bm = b16; bm.amax = (const float*)ok;
+    REFUSED(sf_maxpool2_bwd(b16, b16, 1, 8, 8, bm, 0, 0, SF_F32, st)); }                                /* a scale word on a bf16-stored din */
   REFUSED(sf_maxpool2_dropout_fwd(a16, 1, 8, 8, a16, 0, 0, 1.5f, 0.f, 256, 1, 2, SF_F32, st));       /* p >= 1 */
   REFUSED(sf_maxpool2_dropout_bwd(a16, a16, 1, 8, 8, a16, 0, 0, 0.1f, 0.1f, 100, 1, 2, SF_F32, st)); /* period not whole images */
   REFUSED(sf_maxpool2_route_fwd(a16, 1, 8, 8, a16, 0, 0, 0.f, 0.f, 0, 0, 0, 0, SF_F32, st));         /* no routing buffer */
@@ -95,6 +97,8 @@ int main(void) {
   REFUSED(sf_batchnorm_eval_fwd(a16, 64, 32, ok, ok, 1e-5f, ok, ok, ok, ok, a16, SF_F32, st));       /* creal > lanes */
   REFUSED(sf_batchnorm_eval_bwd(a16, a64, 64, 16, ok, 1e-5f, ok, ok, ok, ok, a16, ok, ok, SF_F32, st));
   REFUSED(sf_batchnorm_train_bwd(a16, a64, 64, 1, 16, ok, ok, ok, ok, ok, a16, ok, ok, SF_F32, st));
+  { sfTensor bm = b16; bm.amax = (const float*)ok;
+    REFUSED(sf_batchnorm_train_bwd(b16, b16, 64, 1, 16, ok, ok, ok, ok, ok, bm, ok, ok, SF_F32, st)); }   /* a scale word on a bf16-stored dx */
   REFUSED(sf_batchnorm_train_bwd_coef(0, 64, 1, 16, 16, ok, ok, ok, ok, ok, ok, SF_F32, st));           /* no sums */
   REFUSED(sf_batchnorm_train_bwd_coef(ok, 64, 1, 16, 24, ok, ok, ok, ok, ok, ok, SF_F32, st));          /* more real channels than lanes */
   REFUSED(sf_leadtime_pool_fwd(a16, 1, 7, 8, ok, 16, 20, 8, 12, ok, a16, SF_F32, st));               /* odd height */

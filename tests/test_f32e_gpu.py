@@ -190,3 +190,74 @@ def test_tiny_forward_operands_degrade_gracefully(device, xs, bound):
     K.conv3x3(K.grad_operand(x), NULL, 1, 16, 16, packed, None, eng.fwd_map, T(y))
     ref = TF.conv2d(x.double().cpu().permute(0, 3, 1, 2), w.double().cpu(), padding=1).permute(0, 2, 3, 1)
     assert rel_l2(y.double().cpu(), ref) < 2e-6
+
+
+def test_batchnorm_backward_raises_the_scale_word_and_the_convolution_takes_it(device, monkeypatch):
+    """conv3x3 -> BatchNorm (training) in "f32e": the BatchNorm backward's apply pass raises the scale word of the gradient it writes (``dx.amax``) and tags the
+    tensor; the convolution's backward takes the tag instead of running ``sf_amax`` over the tensor again.  Checked: (a) the word equals max |dx| of the
+    gradient that reached the convolution, (b) NO sf_amax launch for it, (c) gradients bit-identical to the run with the tag removed (same word either way)."""
+    from satflow_amd import kernels as K
+    from satflow_amd._hip import lib
+    from satflow_amd.functional import ConvEngine, batchnorm, conv3x3
+
+    g = torch.Generator().manual_seed(5)
+    n, h, w, cin, cout = 4, 16, 16, 32, 64
+    x0 = torch.randn(n, h, w, cin, generator=g).to(device)
+    wt0 = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(device)
+    cot = (torch.randn(n, h, w, cout, generator=g) * 1e-6).to(device)   # a training step's gradient magnitude: unscaled it is below fp16's range
+    eng = ConvEngine([cin], cout)
+
+    def run(tagged: bool):
+        bn = torch.nn.BatchNorm2d(cout).to(device)
+        x, wt = x0.clone().requires_grad_(), wt0.clone().requires_grad_()
+        seen, calls = [], []
+        real_tag, real_amax = K.tag_amax, lib().sf_amax
+        monkeypatch.setattr(K, "tag_amax", lambda t, word: (seen.append((t, word)), real_tag(t, word) if tagged else t)[1])
+
+        class Lib:   # counts sf_amax launches, everything else passes through
+            def __getattr__(self, name):
+                f = getattr(lib(), name)
+                if name != "sf_amax":
+                    return f
+                return lambda *a: (calls.append(1), f(*a))[1]
+        monkeypatch.setattr(K, "lib", lambda: Lib())
+        y = batchnorm(conv3x3(eng, x, wt, None), bn, 2, True)
+        (y[..., :cout] * cot).sum().backward()
+        torch.cuda.synchronize()
+        monkeypatch.setattr(K, "lib", lib)
+        monkeypatch.setattr(K, "tag_amax", real_tag)
+        assert real_amax is lib().sf_amax
+        return x.grad, wt.grad, seen, len(calls)
+
+    gx1, gw1, seen, calls1 = run(True)
+    assert len(seen) == 1 and seen[0][1] is not None
+    dx, word = seen[0]
+    assert float(word) == float(dx.abs().max()) > 0
+    assert calls1 == 0, calls1
+    gx0, gw0, _, calls0 = run(False)
+    assert calls0 == 1, calls0
+    assert torch.equal(gx1, gx0) and torch.equal(gw1, gw0)
+    assert torch.isfinite(gx1).all() and float(gw1.abs().max()) > 0
+
+
+@pytest.mark.parametrize("drop", [None, (0.2, 0.1)])
+def test_maxpool_backward_raises_the_scale_word(device, drop):
+    """The three max-pool backward entries with ``din.amax``: the word ends at max |din| (= the largest masked pooled gradient) and the tensor carries the tag
+    ``grad_operand`` takes instead of an ``sf_amax`` pass - with and without the dropout masks, routed and recomputed forms."""
+    from satflow_amd import kernels as K
+
+    g = torch.Generator().manual_seed(23)
+    n, h, w, c = 6, 8, 12, 32
+    x = torch.randn(n, h, w, c, generator=g).to(device)
+    gy = (torch.randn(n, h // 2, w // 2, c, generator=g) * 3e-7).to(device)
+    d = None if drop is None else (drop[0], drop[1], (h // 2) * (w // 2) * c * 2, 1234, 5678)
+    y, route = K.maxpool2_route_fwd(x, None, None, d)
+    for gx in (K.maxpool2_route_bwd(route, gy, tuple(x.shape), torch.float32, None, d), K.maxpool2_bwd(x, gy, None, d)):
+        tag = getattr(gx, "_sf_amax", None)
+        assert tag is not None and tag[1] == gx._version and tag[2] == gx.data_ptr()
+        assert float(tag[0]) == float(gx.abs().max()) > 0
+        op = K.grad_operand(gx)
+        assert op.amax == tag[0].data_ptr()
+        gx.mul_(2.0)   # written in place: the tag is void, grad_operand measures again
+        op2 = K.grad_operand(gx)
+        assert op2.amax != tag[0].data_ptr() and float(op2._keep) == float(gx.abs().max())
