@@ -1219,11 +1219,12 @@ __global__ __launch_bounds__(512) void leadbias_pool_bwd2_kernel(const TA* __res
 // positions on the image border share one class, the two inner ones are class 4, so two register sums per lead time
 // suffice and the loop is atomics-free like the main kernel's) and the last LEADBIAS_CORNER_BLOCKS blocks for the corner
 // windows (4 classes; LDS atomics) - or for every border window when the image is too small to have plain edges.
+constexpr int LEADBIAS_BORDER_THREADS = 512;  // two waves per SIMD (227 VGPRs): twice the windows in flight per CU of a kernel that is a chain of dependent loads (round 6: 256 -> 512)
 constexpr int LEADBIAS_CORNER_BLOCKS = 32;  // (8 were the tail of the kernel: 290 us of per-window serial loads)
 // dbase (nullable, round 4): also write the input gradient of the windows visited here - the main kernel then covers the interior windows only
 // (leadbias_pool_bwd2_kernel).
 template <typename TA, bool PLDS>
-__global__ __launch_bounds__(256) void leadbias_border_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
+__global__ __launch_bounds__(LEADBIAS_BORDER_THREADS) void leadbias_border_kernel(const TA* __restrict__ base, int bs, const TA* __restrict__ dout, int dos,
                                                              long long F, int H, int W, int C, int L, const float* __restrict__ ptab_g,
                                                              float* __restrict__ border_part, TA* __restrict__ dbase, int dbs) {
   extern __shared__ float S[];  // [L][9][C] (+ table copy)
@@ -1531,10 +1532,10 @@ int sf_leadtime_pool_bwd(sfTensor base, sfTensor dout, int64_t frames, int32_t h
                                                    SF_LB_ARGS, (TA*)dbase.ptr, dbase.stride, main_part));
   SF_CHECK_LAUNCH("leadbias_pool_bwd");
   if (lds_border + lds_tab <= 160 * 1024)
-    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, true>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(256), lds_border + lds_tab, st,
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, true>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(LEADBIAS_BORDER_THREADS), lds_border + lds_tab, st,
                                                    SF_LB_ARGS, border_part, border_dbase ? (TA*)dbase.ptr : (TA*)nullptr, dbase.stride));
   else
-    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, false>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(256), lds_border, st,
+    SF_DISPATCH_ACT(base.dtype, hipLaunchKernelGGL((leadbias_border_kernel<TA, false>), dim3(LEADBIAS_BORDER_BLOCKS), dim3(LEADBIAS_BORDER_THREADS), lds_border, st,
                                                    SF_LB_ARGS, border_part, border_dbase ? (TA*)dbase.ptr : (TA*)nullptr, dbase.stride));
 #undef SF_LB_ARGS
   SF_CHECK_LAUNCH("leadbias_border");
