@@ -130,7 +130,7 @@ int sf_conv3x3_fwd(sfTensor src0, sfTensor src1, int32_t n, int32_t h, int32_t w
 size_t sf_conv3x3_fwd_splitk_workspace_bytes(int32_t n, int32_t h, int32_t w, int32_t Np, int32_t nf, int32_t Kp, int32_t dtype);
 int sf_conv3x3_fwd_splitk(sfTensor src, int32_t n, int32_t h, int32_t w, const void* wpacked, const float* bias_packed, int32_t Np, int32_t nf,
                           sfTensor out, void* workspace, size_t workspace_bytes, int32_t dtype, sfStream stream);
-/* The same convolution (SF_BF16 kernels, linear epilogue) that also emits what the BatchNorm2d behind it in the DownSampler
+/* The same convolution (SF_BF16 or SF_F32E kernels, linear epilogue) that also emits what the BatchNorm2d behind it in the DownSampler
  * needs: per pixel tile, the sum and the sum of squares of every output channel's STORED values,
  * stats[(image * sf_conv3x3_stats_tiles(h, w) + tile)][Np][2] fp32 - consumed by sf_batchnorm_train_fwd_stats, which then
  * does not have to read the activation a first time. */

@@ -773,8 +773,8 @@ int sf_launch_conv_bf16(const sfconv::ConvParams& p, int nf, int nblk, int epi, 
   static const bool no_persist = getenv("SF_NO_PERSIST_CONV") != nullptr;
   if (!no_persist && !p.split_c && sf_conv_bf16_persist_ok(p, epi, nf)) return sf_launch_conv_bf16_persist(p, nf, nblk, st);
 #elif defined(SF_SPLIT3)
-  if (p.bf0 || p.bf1 || p.out_bf || p.gates_bf || p.hout_bf || p.stats || p.bias_tab || p.bnb_coef || p.split_c || p.shift4 || p.chunks_total % 3) {
-    sf_set_error("f32e conv: fp32-stored tensors; no statistics / folded BatchNorm / split-K / shifted views");
+  if (p.bf0 || p.bf1 || p.out_bf || p.gates_bf || p.hout_bf || p.bias_tab || p.bnb_coef || p.split_c || p.shift4 || p.chunks_total % 3) {
+    sf_set_error("f32e conv: fp32-stored tensors; no folded BatchNorm / split-K / shifted views");
     return 1;
   }
 #else

@@ -320,7 +320,7 @@ static int conv3x3_fwd_impl(sfTensor src0, sfTensor src1, int32_t n, int32_t h, 
   p.bf0 = src0.ptr && src0.dtype == SF_BF16; p.bf1 = src1.ptr && src1.dtype == SF_BF16; p.out_bf = out.dtype == SF_BF16;
   SF_REQUIRE(dtype == SF_BF16 || !(p.bf0 || p.bf1 || p.out_bf), "conv3x3: bf16-stored tensors need the SF_BF16 kernel");
   SF_REQUIRE((dtype != SF_F16 && dtype != SF_F32E) || !fold_groups, "conv3x3: the folded-BatchNorm launches are SF_BF16 only");
-  SF_REQUIRE(!stats || (dtype == SF_BF16 && epilogue == SF_EPI_LINEAR), "conv3x3: output statistics need the SF_BF16 kernel with the linear epilogue");
+  SF_REQUIRE(!stats || ((dtype == SF_BF16 || dtype == SF_F32E) && epilogue == SF_EPI_LINEAR), "conv3x3: output statistics need the SF_BF16 / SF_F32E kernels with the linear epilogue");
   p.stats = stats; p.stats_np = Np;
   if (fold_groups) {  // bias_packed is the [groups][9][Np] border-class table, wpacked holds one image per group
     p.bias = nullptr; p.bias_tab = bias_packed; p.np = Np;

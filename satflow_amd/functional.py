@@ -487,16 +487,16 @@ def conv3x3(eng: ConvEngine, x: Tensor, weight: Tensor, bias: Optional[Tensor], 
             want_stats: Optional[bool] = None, wbatch: Optional[WeightGradBatch] = None):
     """``out_dtype=torch.bfloat16`` stores the result as bf16 (SF_BF16 kernels only; "bf16a" encoder mode).
     ``want_stats`` not None: returns ``(y, stats)`` with ``stats`` a ``ConvStats`` for ``batchnorm(..., stats=)`` when it is
-    true and the bf16 kernels run, else None."""
+    true and the bf16 or f32e kernels run, else None."""
     if want_stats is None:
         scope = _WBATCH_SCOPE[0]
         if wbatch is None and scope is not None and not sigmoid and torch.is_grad_enabled() and weight.requires_grad:
             wbatch = scope.setdefault(id(eng), WeightGradBatch())
         return _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype, None, wbatch)
-    from ._hip import SF_BF16, compute_dtype
+    from ._hip import SF_BF16, SF_F32E, compute_dtype
 
     st = None
-    if want_stats and compute_dtype() == SF_BF16 and not sigmoid:
+    if want_stats and not sigmoid and (compute_dtype() == SF_BF16 or (compute_dtype() == SF_F32E and not os.environ.get("SF_F32E_NO_STATS"))):
         st = ConvStats(x.shape[0], x.shape[1], x.shape[2], eng.fwd_map.Np, x.device)
     y = _ConvFn.apply(eng, x, None, weight, bias, x.shape[0], (0, 0), (0, 0), sigmoid, out_dtype, st.data if st is not None else None)
     return y, st
