@@ -261,3 +261,33 @@ def test_maxpool_backward_raises_the_scale_word(device, drop):
         gx.mul_(2.0)   # written in place: the tag is void, grad_operand measures again
         op2 = K.grad_operand(gx)
         assert op2.amax != tag[0].data_ptr() and float(op2._keep) == float(gx.abs().max())
+
+
+@pytest.mark.parametrize("n,cin,cout,h,w", [(3, 32, 64, 32, 32), (2, 160, 256, 40, 24), (2, 48, 96, 33, 17)])
+def test_convolution_statistics_epilogue(device, n, cin, cout, h, w):
+    """sf_conv3x3_fwd_stats in "f32e" (what saves the BatchNorm behind conv2 / conv3 its statistics pass): the output is the plain launch's bit for bit, the
+    per-tile sums and sums of squares are those of the stored fp32 values (float64 reference over 32 x 16 tiles, ragged tiles included)."""
+    from satflow_amd.functional import ConvEngine, conv3x3
+
+    g = torch.Generator().manual_seed(n * 7 + cin)
+    x = torch.randn(n, h, w, cin, generator=g).to(device)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).to(device)
+    b = torch.randn(cout, generator=g).to(device)
+    eng = ConvEngine([cin], cout)
+    with torch.no_grad():
+        y0 = conv3x3(eng, x, wt, b)
+        y1, st = conv3x3(eng, x, wt, b, want_stats=True)
+    assert st is not None and torch.equal(y0[..., :cout], y1[..., :cout])
+    tx, ty = (w + 15) // 16, (h + 31) // 32
+    assert st.tiles == tx * ty
+    yd = y1[..., :cout].double()
+    ref = torch.zeros(n, ty, tx, cout, 2, dtype=torch.float64, device=device)
+    for j in range(ty):
+        for i in range(tx):
+            blk = yd[:, 32 * j:32 * j + 32, 16 * i:16 * i + 16]
+            ref[:, j, i, :, 0] = blk.sum((1, 2))
+            ref[:, j, i, :, 1] = (blk * blk).sum((1, 2))
+    got = st.data.view(n, ty, tx, st.np, 2)[..., :cout, :].double()
+    assert torch.isfinite(got).all()
+    err = (got - ref).abs().max() / ref[..., 1].abs().max().clamp_min(1.0)
+    assert float(err) < 1e-5, float(err)
