@@ -1153,6 +1153,19 @@ def comm_report(wl, world: int, dev, name: str = "", batch: int = 0, probe: bool
 
 
 
+# The process's ORIGINAL stdout, claimed by the script entry below: the JSON line is the only thing written to it.  fd 1 itself is pointed at stderr for the
+# life of the process, because libraries write banners there through C stdio (RCCL prints "RCCL version : ..." on communicator creation, buffered until exit:
+# it lands BEHIND the line) - a caller that reads "the one line on stdout" must find exactly that.  None when main() is called in-process (tests).
+_JSON_FD = None
+
+
+def _emit(line: str) -> None:
+    if _JSON_FD is None:
+        print(line, flush=True)
+    else:
+        os.write(_JSON_FD, (line + "\n").encode())
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1179,7 +1192,7 @@ def main(argv=None):
         env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"))
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
                "--master-port", str(_free_port()), os.path.abspath(__file__), *(sys.argv[1:] if argv is None else argv)]
-        raise SystemExit(subprocess.run(cmd, env=env).returncode)
+        raise SystemExit(subprocess.run(cmd, env=env, stdout=_JSON_FD).returncode)   # (the ranks write to the ORIGINAL stdout; None: inherit)
     if args.dtype == "f16" and args.workload != "dgmr":
         raise SystemExit("--dtype f16 is built for the DGMR-style layers (--workload dgmr): the recurrent cells and the folded BatchNorm have no fp16 instantiation")
 
@@ -1284,7 +1297,7 @@ def main(argv=None):
                     out["extra"][f"batch{b}_samples_per_s"], out["extra"][f"batch{b}_ms_per_step"] = 20 * b / el, el / 20 * 1e3
                     del wb
             out["extra"].update(parity_mode_figures(lambda: ConvLSTMWorkload(dev, batch, 0), batch, dev, args.dtype))
-        print(json.dumps(out), flush=True)
+        _emit(json.dumps(out))
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
@@ -1334,4 +1347,7 @@ def parity_mode_figures(make, batch: int, dev, current: str) -> dict:
 
 
 if __name__ == "__main__":
+    sys.stdout.flush()
+    _JSON_FD = os.dup(1)
+    os.dup2(2, 1)
     main()

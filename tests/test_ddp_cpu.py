@@ -261,11 +261,30 @@ def test_bench_launches_itself_when_no_launcher_did():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--steps", "3", "--warmup", "1"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert r.returncode == 0, r.stderr[-2000:]
-    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, r.stdout[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1 and lines[0].startswith("{"), r.stdout[-2000:]   # the JSON line and NOTHING else on stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["comm"]["nranks"] == 2 and out["config"]["parallelism"] == "dp2"
     # a failing rank's exit code comes back through the launcher
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--workload", "stub", "--scaling", "strong", "--global-batch", "63"],
                        capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
     assert r.returncode != 0
+
+
+def test_bench_stdout_is_the_json_line_only():
+    """`python bench.py` owns the process's stdout for the ONE JSON line: whatever else writes to fd 1 - Python prints, C stdio of a library (RCCL's version
+    banner, flushed at exit and therefore BEHIND the line) - lands on stderr.  Checked with a child that writes to fd 1 both ways around a stub run."""
+    import json
+    import subprocess
+    import sys
+
+    code = ("import os, sys, runpy; sys.argv = ['bench.py', '--workload', 'stub', '--steps', '2', '--warmup', '1']; "
+            "import atexit; atexit.register(lambda: os.write(1, b'banner at exit\\n')); "
+            "runpy.run_path(os.path.join(%r, 'bench.py'), run_name='__main__')" % ROOT)
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, timeout=300, cwd=ROOT)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = r.stdout.splitlines()
+    assert len(lines) == 1, r.stdout[-2000:]
+    assert json.loads(lines[0])["n_gpus"] == 1
+    assert "banner at exit" in r.stderr
