@@ -674,6 +674,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   // rotation is the same in every chunk and the next chunk's first tap lands in set 0; only two sets are live at any time
   load_tap(0, 0, 0);
 
+#ifdef SF_EXP_W4_SPVALU
+  unsigned spd[4] = {(unsigned)lane, (unsigned)tid, 0x07060302u, 0x05040100u};
+#endif
   int sw = 0;    // weight ring stage of the current chunk
   int gpar = 0;  // parity of the chunk counter: the private input stage
   // K >= 1 items of nch >= 3 chunks (the launcher's contract; do-while loops: no empty-loop join points for the 256 accumulators)
@@ -734,6 +737,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
         }
         // MFMAs 0 .. 7 with one fragment read behind each | DMA piece | MFMAs 8 .. 11 | DMA piece | MFMAs 12 .. 15
         auto mfmas = [&](int lo, int hi) __attribute__((always_inline)) {
+#ifdef SF_EXP_W4_SPVALU   // estimate build (below): the vector-ALU work of building 2:4-compressed operands, ~384 instructions per chunk and wave
+          asm volatile("v_perm_b32 %0, %0, %1, %2\n\tv_and_b32 %1, %1, %3\n\tv_perm_b32 %2, %2, %3, %0\n\tv_or_b32 %3, %3, %1\n\t"
+                       "v_perm_b32 %0, %0, %1, %2\n\tv_and_b32 %1, %1, %3\n\tv_perm_b32 %2, %2, %3, %0\n\tv_or_b32 %3, %3, %1\n\t"
+                       "v_perm_b32 %0, %0, %1, %2\n\tv_and_b32 %1, %1, %3\n\tv_perm_b32 %2, %2, %3, %0\n\tv_or_b32 %3, %3, %1\n\t"
+                       "v_add_u32 %0, %0, %2\n\tv_add_u32 %1, %1, %3" : "+v"(spd[0]), "+v"(spd[1]), "+v"(spd[2]), "+v"(spd[3]));
+#endif
+#ifdef SF_EXP_W4_SPEST    // estimate build (tools/ablate_w4.sh, timing only, results wrong): 6 instead of 9 matrix instructions per (pixel, channel) fragment pair and
+          if (tap % 3 == 2) return;   // chunk - what the 2:4-sparse instruction would issue for a gradient behind a 2x2 max-pool
+#endif
 #pragma unroll
           for (int f = lo; f < hi; ++f) {
             const int mf = f / NF, nf = f % NF;
@@ -790,6 +802,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     cur = nxt;
 #endif
   } while (++k < K);
+#ifdef SF_EXP_W4_SPVALU
+  if ((spd[0] ^ spd[1] ^ spd[2] ^ spd[3]) == 0x12345u && p.N < 0) reinterpret_cast<unsigned*>(p.out)[0] = spd[0];   // (never true: keeps the dummy chain alive)
+#endif
 #ifdef SF_EXP_W4_CLK
   if (tid == 0 && (blockIdx.x == 0 || blockIdx.x == 100)) {
     const unsigned long long c = __builtin_readcyclecounter() - clk0, w = wall_clock64() - wall0;

@@ -19,6 +19,6 @@ if [ "$1" = build ]; then
 else
   for v in $VARIANTS; do
     echo "== $v"
-    SATFLOW_HIP_LIB=$PWD/tools/ablate/libsatflow_w4_$v.so python tools/probe_conv_w4.py 2>&1 | grep 'folded\|shader' | sort | uniq -c | sort -rn | head -8
+    SATFLOW_HIP_LIB=$PWD/tools/ablate/libsatflow_w4_$v.so python tools/probe_conv_w4.py 2>&1 | grep 'folded\|shader\|input gradient' | sort | uniq -c | sort -rn | head -8
   done
 fi
