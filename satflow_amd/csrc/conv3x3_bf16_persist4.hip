@@ -783,6 +783,14 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
           if (first) { if constexpr (MODE == 1) SF_VMCNT(39); else if constexpr (MODE == 2) SF_VMCNT(63); else if constexpr (MODE == 3) SF_VMCNT(16); else SF_VMCNT(38); } else SF_VMCNT(6);   // (MODE 3: 8 + 2 stores + 6 pieces)
           __builtin_amdgcn_s_barrier();
 #endif
+#ifdef SF_EXP_W4_STAGN   // experiment (tools/ablate_w4.sh): behind the chunk's rendezvous wave w idles w x STAGN x 16 cycles, so that the four waves - which run
+          // the same code at the same matrix-instruction pace from here to the next rendezvous - reach the CU's one address unit with their LDS-DMA pieces
+          // one after the other instead of together
+#define SF_W4_NOPS(n) for (int q_ = 0; q_ < (n); ++q_) asm volatile("s_nop 15")
+          if (wave >= 1) { _Pragma("unroll") SF_W4_NOPS(SF_EXP_W4_STAGN); }
+          if (wave >= 2) { _Pragma("unroll") SF_W4_NOPS(SF_EXP_W4_STAGN); }
+          if (wave >= 3) { _Pragma("unroll") SF_W4_NOPS(SF_EXP_W4_STAGN); }
+#endif
           __builtin_amdgcn_sched_barrier(0);
         }
         if (tap == 4 && first) {  // the item after this one (needed from the top of the second-to-last chunk on: nch >= 3)
