@@ -65,6 +65,22 @@ __device__ __forceinline__ void bufdma16(unsigned voff, __amdgpu_buffer_rsrc_t r
   asm volatile("s_mov_b32 m0, %2\n\ts_nop 0\n\tbuffer_load_dwordx4 %0, %1, %3 offen lds"
                : : "v"(voff), "s"(rs), "s"(lds_dst), "s"(soff) : "memory");  // (M0 is not declared: hipcc treats it as reserved and never keeps a value in it across statements here)
 }
+// The K loop's pieces: M0 is written ONCE per group of up to four pieces whose LDS destinations are 1 KiB apart, the piece inside the group is the
+// instruction's immediate offset (added to the LDS address AND to the memory address: the caller's offsets are built for that).  5 instead of 15 M0 writes +
+// wait states per chunk: 6440 -> 6390 shader cycles per chunk, bit-identical results (round 6, profiles/r06_w4_m0.txt - which also records the trap on the way: a
+// timing build with NO M0 writes ran 11 % faster, but because every piece then lands on one LDS address and the matrix operands never change: less power,
+// more clock).  M0 is not written by anything else between the pieces of a group (checked on the ISA).
+__device__ __forceinline__ void dma_group(unsigned lds_dst) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0" : : "s"(__builtin_amdgcn_readfirstlane(lds_dst)) : "memory");
+}
+template <int IMM>
+__device__ __forceinline__ void bufdma16_imm(unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {
+  asm volatile("buffer_load_dwordx4 %0, %1, %2 offen offset:%3 lds" : : "v"(voff), "s"(rs), "s"(soff), "i"(IMM) : "memory");
+}
+__device__ __forceinline__ void bufdma16_q(int q, unsigned voff, __amdgpu_buffer_rsrc_t rs, unsigned soff) {  // q: compile-time after unrolling
+  if (q == 0) bufdma16_imm<0>(voff, rs, soff); else if (q == 1) bufdma16_imm<1024>(voff, rs, soff);
+  else if (q == 2) bufdma16_imm<2048>(voff, rs, soff); else bufdma16_imm<3072>(voff, rs, soff);
+}
 __device__ __forceinline__ void* uniform_ptr(const void* q) {  // inline asm "s" operands are not legalised
   const uintptr_t v = (uintptr_t)q;
   const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
@@ -165,7 +181,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
     const int pc = lane + j * 64, pix = pc >> 1;
     const int iy = pix / HALO_W, ix = slot_col(pix - iy * HALO_W);
     const int half = (pc & 1) ^ half_flip(iy);  // the DMA writes lane-linearly: physical half pc & 1 holds the logical half (bank swizzle)
-    in_base_off[j] = (unsigned)(((iy * p.W + ix) * p.s0 + 8 * half) * 2);
+    // (minus the piece's immediate offset inside its M0 group, see dma_group: a piece j >= 1 starts in halo row >= j, i.e. at least j rows of W * s0 * 2 >= 1024
+    // bytes in - the launcher's contract)
+    in_base_off[j] = (unsigned)(((iy * p.W + ix) * p.s0 + 8 * half) * 2) - (unsigned)((j & 3) * 1024);
   }
   auto setup = [&](int k, Item& it) __attribute__((always_inline)) {
     it.valid = k < K;
@@ -226,9 +244,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
   auto dma_in = [&](const Item& it, __amdgpu_buffer_rsrc_t rs, int ci, int stage, int j) __attribute__((always_inline)) {
     const unsigned dst = lds0 + (unsigned)(IN0 + (wave * 2 + stage) * PIN_B + j * 1024);
     const unsigned so = __builtin_amdgcn_readfirstlane((unsigned)(((it.y0 + 8 * wave) * p.W + it.x0) * pxb + ci * KC * 2));
-    if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16((it.in_mask >> j) & 1u ? in_base_off[j] : DMA_SENT, rs, so, dst);  // the last instruction: 40 lanes (the rest is masked off)
+    if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16((it.in_mask >> j) & 1u ? in_base_off[j] + (unsigned)((j & 3) * 1024) : DMA_SENT, rs, so, dst);  // the last instruction: 40 lanes (the rest is masked off)
   };
-  // one weight piece (i: 0..8 -> 1 KiB piece wave + 4 i) of chunk ci
+  // one weight piece (i: 0..8 -> 1 KiB piece wave + 4 i) of chunk ci (the prologue's assignment; the K loop gives a wave nine CONSECUTIVE pieces)
   auto dma_w = [&](__amdgpu_buffer_rsrc_t rs, int ci, int stage, int i) __attribute__((always_inline)) {
     const int pc = wave + 4 * i;
     bufdma16(lane * 16, rs, __builtin_amdgcn_readfirstlane((unsigned)(ci * W_B + pc * 1024)), lds0 + (unsigned)(stage * W_B + pc * 1024));
@@ -695,9 +713,9 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
       const __amdgpu_buffer_rsrc_t ri = rs_input(it1);
       const __amdgpu_buffer_rsrc_t rw = rs_weights(it2);
       const unsigned so_in = __builtin_amdgcn_readfirstlane((unsigned)(((it1.y0 + 8 * wave) * p.W + it1.x0) * pxb + (last ? 0 : ci + 1) * KC * 2));
-      const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((last2 ? ci + 2 - nch : ci + 2) * W_B + wave * 1024));
+      const unsigned so_w = __builtin_amdgcn_readfirstlane((unsigned)((last2 ? ci + 2 - nch : ci + 2) * W_B + wave * 9 * 1024));   // this wave's nine consecutive pieces
       const unsigned dst_in = lds0 + (unsigned)(IN0 + (wave * 2 + si1) * PIN_B);
-      const unsigned dst_w = lds0 + (unsigned)(sw2 * W_B + wave * 1024);
+      const unsigned dst_w = lds0 + (unsigned)(sw2 * W_B + wave * 9 * 1024);
       const unsigned m1 = it1.in_mask;
       // (-DSF_EXP_W4_*: ablation builds of tools/ablate_w4.sh, never part of the shipped library)
       auto piece_in = [&](int j) __attribute__((always_inline)) {
@@ -705,13 +723,15 @@ __global__ __launch_bounds__(256, 1) void conv3x3_bf16_persist4_kernel(const Con
         return;
 #endif
         const unsigned voff = (m1 >> j) & 1u ? in_base_off[j] : DMA_SENT;
-        if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16(voff, ri, so_in, dst_in + j * 1024);  // the last instruction: 40 lanes
+        if ((j & 3) == 0) dma_group(dst_in + j * 1024);   // pieces 0 .. 3 | 4, 5
+        if (j + 1 < NPJ || lane < PPIECES - (NPJ - 1) * 64) bufdma16_q(j & 3, voff, ri, so_in);  // the last instruction: 40 lanes
       };
       auto piece_w = [&](int i) __attribute__((always_inline)) {
 #ifdef SF_EXP_W4_NODMA
         return;
 #endif
-        bufdma16(lane * 16, rw, so_w + i * 4096, dst_w + i * 4096);
+        if ((i & 3) == 0) dma_group(dst_w + i * 1024);    // pieces 0 .. 3 | 4 .. 7 | 8
+        bufdma16_q(i & 3, lane * 16, rw, so_w + (i & ~3) * 1024);
       };
 
 #pragma unroll
@@ -830,6 +850,7 @@ bool sf_conv_bf16_persist4_ok(const sfconv::ConvParams& p, int nf) {
   static const bool no_stats = getenv("SF_NO_CONV_W4_STATS") != nullptr;  // A/B switch: statistics on the 8-wave persistent kernel
   static const bool no_bnb = getenv("SF_NO_CONV_W4_BNB") != nullptr;      // A/B switch: the BatchNorm-backward epilogue on the 8-wave one-item kernel
   if (off || nf != 4 || (p.stats && no_stats) || p.bias || p.c0 / sfconv::KC < 3 || p.src1 || p.out_c % 32) return false;
+  if ((long long)p.W * p.s0 * 2 < 1024) return false;   // an image row of the input is at least 1 KiB: the input pieces' immediate offsets (dma_group) never exceed a lane's own offset
   // pooled epilogue: whole windows per tile (even H, W), no statistics / BatchNorm backward, routing words of whole 64-channel pairs
   if (p.pool_out && (p.stats || p.bnb_coef || (p.H & 1) || (p.W & 1) || p.out_c % 64 || !p.pool_route || p.pool_s % 8 ||
                      (long long)(p.H / 2) * (p.W / 2) * p.pool_s * 2 >= 0x7fffffffll)) return false;
