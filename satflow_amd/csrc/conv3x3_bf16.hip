@@ -428,7 +428,12 @@ __global__ __launch_bounds__(WAVES * 64, (WAVES == 8 || WS) ? 2 : 1) void conv3x
 
   for (int ci = 0; ci < nch; ++ci) {
     const int cur = ci & 1;
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weight DMA has landed (LDS-DMA is not covered by the barrier)
+    // this chunk's weight DMA has landed (LDS-DMA is not covered by the barrier) AND this wave's ds_write of the staged input has left the LDS queue.
+    // The second half is not a formality: hipcc 7.2 drops the LDS wait of __syncthreads()'s release fence when it can (it assumes the LDS serves all
+    // waves in one order), and in the SF_SPLIT3 build it did so on the path loop tail -> this barrier.  A wave of another SIMD then read a 16-byte piece
+    // of the staged tile before the write arrived: one stale piece in ~1000 launches of the f32e ConvGRU step, found as a once-in-25-runs parity failure
+    // (round 6; tools/scan_barrier_waits.py + tests/test_host_cpu.py check the ISA of every kernel for the pattern).
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
     __syncthreads();
     // Staging of the NEXT chunk (weight DMA + input DMA / loads) is issued at a different tap by the two waves that
     // share a SIMD (wave w and w + 4 of an 8-wave workgroup): a wave stalls for a few hundred cycles while it issues its

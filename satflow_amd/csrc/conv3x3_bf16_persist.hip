@@ -166,7 +166,7 @@ __global__ __launch_bounds__(512, 2) void conv3x3_bf16_persist_kernel(const Conv
 
     for (int ci = 0; ci < nch; ++ci, ++g) {
       const int cbuf = g & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's DMA has landed (and, at ci = 0, the previous item's stores have left)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this chunk's DMA has landed (and, at ci = 0, the previous item's stores have left)
       __syncthreads();
       const bool stage_late = wave >= 4;  // the two waves of a SIMD stage at different taps (conv3x3_bf16.hip)
       auto stage_next = [&]() __attribute__((always_inline)) {

@@ -388,7 +388,7 @@ __global__ __launch_bounds__(256 * NBLK, NBLK) void convgru_seq_fwd_kernel(const
     auto chunk = [&](int ci, auto last_tag) {
       constexpr bool LAST = decltype(last_tag)::value;
       const int it = t * chunks + ci, cur = it & 1;
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this chunk's weights have landed (and everything older)
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");  // this chunk's weights have landed (and everything older)
       __syncthreads();                                   // ... everybody's; the previous step's state tile writes are visible
       if (ci == 0) SF_GRU_STAMP(1)                       // wait + barrier of the first chunk
       else if (LAST) SF_GRU_STAMP(2)                     // chunks 0 .. n-2 and the last chunk's wait
@@ -1085,7 +1085,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
           else if (extra == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2 + 1) : "memory");
           else if (extra == 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2 + 24) : "memory");
           else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PW + S2 + 25) : "memory");
-        } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
         __syncthreads();
         if (CI == 0) SF_GRUB_STAMP(2)
         const bool more = it + 2 < total_chunks;
@@ -1126,7 +1126,7 @@ __global__ __launch_bounds__(512 / MFW, 2 / MFW) void convgru_seq_bwd_kernel(con
       if (it + 1 < total_chunks) {
         if (many) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / WAVES + 1) : "memory");
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES / WAVES) : "memory");
-      } else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      } else asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
       __syncthreads();  // ... everybody's; the tile writes of this step are visible; stage (it + 2) % RING (chunk it - 1) is free
       if (ci == 0) SF_GRUB_STAMP(2)  // first chunk's wait + barrier
       const bool more = it + 2 < total_chunks;

@@ -291,3 +291,31 @@ def test_convolution_statistics_epilogue(device, n, cin, cout, h, w):
     assert torch.isfinite(got).all()
     err = (got - ref).abs().max() / ref[..., 1].abs().max().clamp_min(1.0)
     assert float(err) < 1e-5, float(err)
+
+
+def test_convgru_steps_repeat_bit_for_bit_after_idle_gaps(device):
+    """The per-step ConvGRU forward (24 steps over 24 maps of 16 x 16, hidden 64: MetNet's recurrent part in the fp32 modes) gives the SAME bits every time it
+    is run, also when the GPU idled in between.  Round 6: in "f32e" it did not - the chunk loop's barrier was reached with the wave's last ds_write of the
+    staged input still in the LDS queue (hipcc had dropped that wait from __syncthreads() in the SF_SPLIT3 build), and after an idle gap a wave of another SIMD
+    read one 16-byte piece early in every third repetition: errors of 1e-6 here, 1e-3 on MetNet's final state, a parity failure once in ~25 runs.  The kernels
+    wait for their LDS writes explicitly now (conv3x3_bf16.hip); tests/test_host_cpu.py checks the ISA for the pattern."""
+    import time
+
+    from satflow_amd.models import MetNet
+
+    torch.manual_seed(1234)
+    net = MetNet(input_channels=12, sat_channels=12, input_size=64, output_channels=12, hidden_dim=64, forecast_steps=12).to(device).train()
+    rnn = net.temporal_enc.rnn
+    feat = torch.randn(24 * 24, 16, 16, 256, generator=torch.Generator().manual_seed(7)).to(device)
+    ref = None
+    for it in range(30):
+        torch.cuda.synchronize()
+        time.sleep(0.25)
+        with torch.no_grad():
+            _, last = rnn.run(feat, 24, 24, input_dropout_done=True)
+        torch.cuda.synchronize()
+        cur = last[-1].clone()
+        if ref is None:
+            ref = cur
+        else:
+            assert torch.equal(cur, ref), f"repetition {it}: max |difference| {float((cur - ref).abs().max()):.3e}"

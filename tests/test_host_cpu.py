@@ -422,3 +422,27 @@ def test_the_f32e_cases_really_run_in_f32e():
         assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
         assert sorted(re.findall(r"RAN_IN (\w+)", r.stdout)) == ["f32", "f32e"], r.stdout[-1500:]
         assert re.findall(r"UNGATED_IN (\w+)", r.stdout) == ["f32"]
+
+
+def test_no_barrier_is_reached_from_an_lds_write_without_a_wait():
+    """ISA of every kernel (hipcc -S for gfx950, tools/scan_barrier_waits.py): walking backwards from each s_barrier through straight-line code there is an
+    `s_waitcnt lgkmcnt(0)` before any ds_write.  hipcc drops the LDS wait of __syncthreads()'s release fence when it believes it can; where it did (the
+    SF_SPLIT3 build of the convolution, round 6) a wave of another SIMD read a staged piece before the write had landed - once in ~1000 launches.  The kernels
+    now wait explicitly in front of those barriers; this test keeps it that way for code the compiler touches later."""
+    import concurrent.futures as cf
+    import glob
+    import importlib.util
+
+    spec = importlib.util.spec_from_file_location("scan_barrier_waits", os.path.join(ROOT, "tools", "scan_barrier_waits.py"))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    files = sorted(glob.glob(os.path.join(ROOT, "satflow_amd", "csrc", "*.hip")))
+    with cf.ThreadPoolExecutor(max_workers=7) as ex:
+        results = dict(zip(files, ex.map(mod.scan, files)))
+    bad = []
+    for f, r in results.items():
+        assert r is not None, f"{f} did not compile"
+        total, hits = r
+        for k, v in hits.items():
+            bad.append(f"{os.path.basename(f)}: {k[:100]}: {v} barrier(s) behind an un-waited LDS write")
+    assert not bad, "\n".join(bad[:20])
