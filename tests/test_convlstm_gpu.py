@@ -183,3 +183,37 @@ def test_training_trajectory_golden(device, case, optimizer, fp32_mode):
         assert_close(p, f, f"final {k}")
         disp, err = f - i, p.detach().cpu() - f
         assert float(err.norm()) <= 1e-3 * float(disp.norm()), f"{k}: displacement off by {float(err.norm() / disp.norm()):.2e} (relative L2)"
+
+
+@pytest.mark.parametrize("mode", ["f32", "f32e", "bf16", "bf16a"])
+def test_training_step_gradients_repeat_bit_for_bit(device, mode):
+    """The pinned path's training step is bit-reproducible: no atomics decide a value, so forward, loss and every gradient of EncoderDecoderConvLSTM repeat exactly
+    (also after the GPU idled in between - what exposed the one race this property caught, in the f32e ConvGRU step: tests/test_f32e_gpu.py).  Full-size repetition
+    over all four modes: tools/debug/stress_convlstm_bwd_det.py (0 of 11 differing)."""
+    import time
+
+    import satflow_amd
+    from satflow_amd.models import EncoderDecoderConvLSTM
+
+    satflow_amd.set_compute_dtype(mode)
+    try:
+        torch.manual_seed(5)
+        net = EncoderDecoderConvLSTM(hidden_dim=32, input_channels=12, out_channels=12, forecast_steps=4).to(device).train()
+        g = torch.Generator().manual_seed(1)
+        x, cot = torch.randn(2, 6, 12, 64, 64, generator=g).to(device), torch.randn(2, 12, 4, 64, 64, generator=g).to(device)
+        ref = None
+        for it in range(5):
+            for p in net.parameters():
+                p.grad = None
+            torch.cuda.synchronize()
+            time.sleep(0.2)
+            y = net(x, future_seq=4)
+            (y * cot).sum().backward()
+            torch.cuda.synchronize()
+            cur = [y.detach().clone()] + [p.grad.detach().clone() for p in net.parameters()]
+            if ref is None:
+                ref = cur
+            else:
+                assert all(torch.equal(a, b) for a, b in zip(cur, ref)), f"{mode}: repetition {it} differs"
+    finally:
+        satflow_amd.set_compute_dtype("f32")
